@@ -1,0 +1,276 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY (imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by pyscf_amd/).
+
+numpy restatement of the reference's density-fitting algorithm on top of the C integral
+oracle (oracle/cint_oracle.c):
+
+* ``cholesky_eri``  <- pyscf/df/incore.py:129-220  (j2c Cholesky + trsm, eig fallback :263-270)
+* ``get_jk``        <- pyscf/df/df_jk.py:280-413   (J via packed-tril two-pass product, K via
+                       per-row unpack + symm half transform + X^T X; general-DM branch :382-408)
+* ``pack_tril`` / ``unpack_tril`` <- pyscf/lib/numpy_helper.py:328-466
+* ``fp``            <- pyscf/lib/misc.py:1359-1363
+* ``rhf_kernel``    <- pyscf/scf/hf.py:49-241 (+ CDIIS pyscf/scf/diis.py:40-96,
+                       pyscf/lib/diis.py:225-290)
+
+Parity status: pinned against the reference's golden vectors G1-G7 in
+tests/test_oracle_golden.py.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import scipy.linalg
+
+_here = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', _here])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(_here, 'liboracle.so')
+        if not os.path.exists(so):
+            build()
+        _lib = ctypes.CDLL(so)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def fp(a):
+    """lib.fp fingerprint: sum(cos(arange(n)) * a.ravel())  (pyscf/lib/misc.py:1359-1363)."""
+    a = np.asarray(a)
+    return np.dot(np.cos(np.arange(a.size)), a.ravel())
+
+
+def pack_tril(mat):
+    mat = np.asarray(mat)
+    n = mat.shape[-1]
+    idx = np.tril_indices(n)
+    return mat[..., idx[0], idx[1]]
+
+
+def unpack_tril(tril, filltriu=1):
+    tril = np.asarray(tril)
+    npair = tril.shape[-1]
+    n = int((np.sqrt(8 * npair + 1) - 1) / 2)
+    idx = np.tril_indices(n)
+    out = np.zeros(tril.shape[:-1] + (n, n))
+    out[..., idx[0], idx[1]] = tril
+    if filltriu:
+        out[..., idx[1], idx[0]] = tril
+    return out
+
+
+# ----------------------------------------------------------------------------- integrals
+def _tables(mol):
+    return (np.ascontiguousarray(mol._atm, np.int32), np.ascontiguousarray(mol._bas, np.int32),
+            np.ascontiguousarray(mol._env, np.float64))
+
+
+def int1e(mol, kind):
+    """kind: 'ovlp' | 'kin' | 'nuc'  (int1e_ovlp_sph / int1e_kin_sph / int1e_nuc_sph)."""
+    atm, bas, env = _tables(mol)
+    n = mol.nao_nr()
+    out = np.zeros((n, n))
+    lib().oracle_int1e(ctypes.c_int({'ovlp': 0, 'kin': 1, 'nuc': 2}[kind]), _p(out), _p(atm),
+                       ctypes.c_int(len(atm)), _p(bas), ctypes.c_int(len(bas)), _p(env))
+    return out
+
+
+def int2c2e(auxmol):
+    atm, bas, env = _tables(auxmol)
+    n = auxmol.nao_nr()
+    out = np.zeros((n, n))
+    lib().oracle_int2c2e(_p(out), _p(atm), ctypes.c_int(len(atm)), _p(bas), ctypes.c_int(0),
+                         ctypes.c_int(len(bas)), _p(env))
+    return out
+
+
+def int3c2e(mol, auxmol):
+    """(naux, nao, nao) s1 tensor == reference's int3c2e_sph viewed as [k][i][j]."""
+    from pyscf_amd.gto import conc_env
+    atm, bas, env = conc_env(mol._atm, mol._bas, mol._env, auxmol._atm, auxmol._bas, auxmol._env)
+    atm = np.ascontiguousarray(atm, np.int32)
+    bas = np.ascontiguousarray(bas, np.int32)
+    env = np.ascontiguousarray(env)
+    nao, naux = mol.nao_nr(), auxmol.nao_nr()
+    out = np.zeros((naux, nao, nao))
+    lib().oracle_int3c2e(_p(out), _p(atm), ctypes.c_int(len(atm)), _p(bas),
+                         ctypes.c_int(mol.nbas), ctypes.c_int(auxmol.nbas), _p(env))
+    return out
+
+
+def int2e(mol):
+    atm, bas, env = _tables(mol)
+    n = mol.nao_nr()
+    out = np.zeros((n, n, n, n))
+    lib().oracle_int2e(_p(out), _p(atm), ctypes.c_int(len(atm)), _p(bas),
+                       ctypes.c_int(len(bas)), _p(env))
+    return out
+
+
+# ----------------------------------------------------------------------------- DF tensor
+LINEAR_DEP_THR = 1e-7  # pyscf/df/incore.py:33
+
+
+def cholesky_eri(mol, auxmol, lindep=LINEAR_DEP_THR):
+    """cderi (naux, nao_pair), B = L^-1 (Q|pq)   (pyscf/df/incore.py:129-220)."""
+    j2c = int2c2e(auxmol)
+    j3c = pack_tril(int3c2e(mol, auxmol))         # (naux, nao_pair), s2ij
+    try:
+        low = scipy.linalg.cholesky(j2c, lower=True)
+        return scipy.linalg.solve_triangular(low, j3c, lower=True, check_finite=False)
+    except scipy.linalg.LinAlgError:
+        w, v = scipy.linalg.eigh(j2c)
+        mask = w > lindep
+        v = v[:, mask] / np.sqrt(w[mask])
+        return v.T.dot(j3c)
+
+
+# ----------------------------------------------------------------------------- J/K
+def get_jk(cderi, dm, hermi=1, with_j=True, with_k=True, mo_coeff=None, mo_occ=None,
+           blockdim=240):
+    """Restatement of pyscf/df/df_jk.py:329-411 in numpy."""
+    dms = np.asarray(dm)
+    shape = dms.shape
+    nao = shape[-1]
+    dms = dms.reshape(-1, nao, nao)
+    nset = len(dms)
+    naux = cderi.shape[0]
+    vj = 0
+    vk = np.zeros_like(dms)
+    if with_j:
+        idx = np.arange(nao)
+        dmtril = pack_tril(dms + dms.transpose(0, 2, 1))
+        dmtril[:, idx * (idx + 1) // 2 + idx] *= .5
+    orbo = None
+    if with_k and mo_coeff is not None:
+        mo_coeff = np.asarray(mo_coeff).reshape(-1, nao, np.asarray(mo_occ).shape[-1])
+        mo_occ = np.asarray(mo_occ).reshape(-1, mo_coeff.shape[-1])
+        orbo = [mo_coeff[k][:, mo_occ[k] > 0] * np.sqrt(mo_occ[k][mo_occ[k] > 0])
+                for k in range(nset)]
+    for b0 in range(0, naux, blockdim):
+        eri1 = cderi[b0:b0 + blockdim]
+        if with_j:
+            vj = vj + dmtril.dot(eri1.T).dot(eri1)
+        if with_k:
+            full = unpack_tril(eri1)                      # (blk, nao, nao)
+            for k in range(nset):
+                if orbo is not None:
+                    buf1 = np.einsum('Lpq,qi->Lip', full, orbo[k], optimize=True)
+                    buf1 = buf1.reshape(-1, nao)
+                    vk[k] += buf1.T.dot(buf1)
+                else:
+                    buf1 = np.einsum('pij,jk->pki', full, dms[k], optimize=True)
+                    vk[k] += np.einsum('pki,pkj->ij', buf1, full, optimize=True)
+    if with_j:
+        vj = unpack_tril(vj, 1).reshape(shape)
+    else:
+        vj = None
+    vk = vk.reshape(shape) if with_k else None
+    return vj, vk
+
+
+def get_jk_exact(eri, dm):
+    """4-centre J/K from the full ERI tensor (config-1 plumbing reference)."""
+    dm = np.asarray(dm)
+    vj = np.einsum('ijkl,...lk->...ij', eri, dm)
+    vk = np.einsum('ikjl,...kl->...ij', eri, dm)   # K_ij = (ik|jl) D_kl
+    return vj, vk
+
+
+# ----------------------------------------------------------------------------- SCF driver
+class CDIIS:
+    """Commutator DIIS (pyscf/scf/diis.py:40-96; pyscf/lib/diis.py:225-290), space 8."""
+
+    def __init__(self, space=8):
+        self.space = space
+        self.fs, self.es = [], []
+
+    def update(self, s, d, f, x_orth):
+        sdf = s.dot(d).dot(f)
+        err = x_orth.T.dot(sdf.T - sdf).dot(x_orth)      # C^T (FDS - SDF) C
+        self.fs.append(f.copy())
+        self.es.append(err.ravel())
+        if len(self.fs) > self.space:
+            self.fs.pop(0)
+            self.es.pop(0)
+        n = len(self.fs)
+        h = np.zeros((n + 1, n + 1))
+        h[0, 1:] = h[1:, 0] = 1
+        for i in range(n):
+            for j in range(n):
+                h[i + 1, j + 1] = np.dot(self.es[i], self.es[j])
+        g = np.zeros(n + 1)
+        g[0] = 1
+        w, v = scipy.linalg.eigh(h)
+        if np.any(abs(w) < 1e-14):
+            idx = abs(w) > 1e-14
+            c = np.dot(v[:, idx] * (1. / w[idx]), np.dot(v[:, idx].T, g))
+        else:
+            c = np.linalg.solve(h, g)
+        return sum(ci * fi for ci, fi in zip(c[1:], self.fs))
+
+
+def rhf_kernel(mol, get_veff, conv_tol=1e-10, max_cycle=60, dm0=None, h1e=None, s1e=None,
+               verbose=False):
+    """Minimal RHF loop with the reference's semantics (hf.py:49-241): core-Hamiltonian
+    ('1e') initial guess unless dm0 is given, CDIIS from cycle 1, canonical
+    orthogonalisation x_orth with threshold 1e-6 (hf.py:1363-1379), E = Tr(hD)+1/2 Tr(VD)+E_nuc.
+    ``get_veff(dm, mo_coeff, mo_occ) -> vhf``."""
+    if h1e is None:
+        h1e = int1e(mol, 'kin') + int1e(mol, 'nuc')
+    if s1e is None:
+        s1e = int1e(mol, 'ovlp')
+    enuc = mol.energy_nuc()
+    nocc = mol.nelectron // 2
+    w, v = scipy.linalg.eigh(s1e)
+    keep = w > 1e-6
+    x_orth = v[:, keep] / np.sqrt(w[keep])
+
+    def eig(f):
+        e, c = scipy.linalg.eigh(x_orth.T.dot(f).dot(x_orth))
+        return e, x_orth.dot(c)
+
+    def make_rdm1(c, occ):
+        co = c[:, occ > 0]
+        return (co * occ[occ > 0]).dot(co.T)
+
+    mo_occ = np.zeros(x_orth.shape[1])
+    mo_occ[:nocc] = 2
+    if dm0 is None:
+        e, c = eig(h1e)
+        dm = make_rdm1(c, mo_occ)
+    else:
+        dm = dm0
+        c = None
+    vhf = get_veff(dm, c, mo_occ if c is not None else None)
+    e_tot = np.einsum('ij,ji', h1e, dm) + .5 * np.einsum('ij,ji', vhf, dm) + enuc
+    diis = CDIIS()
+    conv = False
+    for cycle in range(max_cycle):
+        f = h1e + vhf
+        if cycle >= 1:
+            f = diis.update(s1e, dm, f, x_orth)
+        e, c = eig(f)
+        dm = make_rdm1(c, mo_occ)
+        vhf = get_veff(dm, c, mo_occ)
+        e_last = e_tot
+        e_tot = np.einsum('ij,ji', h1e, dm) + .5 * np.einsum('ij,ji', vhf, dm) + enuc
+        f = h1e + vhf
+        g = c[:, mo_occ == 0].T.dot(f).dot(c[:, mo_occ > 0]) * 2
+        ng = np.linalg.norm(g)
+        if verbose:
+            print('cycle %d E=%.12f dE=%.3g |g|=%.3g' % (cycle + 1, e_tot, e_tot - e_last, ng))
+        if abs(e_tot - e_last) < conv_tol and ng < np.sqrt(conv_tol):
+            conv = True
+            break
+    return conv, e_tot, e, c, mo_occ, dm

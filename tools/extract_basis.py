@@ -1,0 +1,37 @@
+"""Build pyscf_amd/gto/basis/data.json from the NWChem-format basis tables that
+ship with the reference (pyscf/gto/basis/*.dat, public Basis-Set-Exchange data).
+
+Run in the authoring container only (needs /root/reference):
+    python tools/extract_basis.py
+Only numeric exponent/coefficient tables of H-Ne for the basis sets the hot path's
+configurations need are kept (sto-3g, 6-31g, cc-pvdz, cc-pvtz, def2-svp, def2-tzvp and
+their J/JK fitting sets).
+"""
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+from pyscf_amd.gto.basis import parse_nwchem
+
+REF = '/root/reference/pyscf/gto/basis'
+FILES = {
+    'sto3g': 'sto-3g.dat', '631g': 'pople-basis/6-31G.dat',
+    'ccpvdz': 'cc-pvdz.dat', 'ccpvtz': 'cc-pvtz.dat',
+    'def2svp': 'def2-svp.dat', 'def2tzvp': 'def2-tzvp.dat',
+    'ccpvdzjkfit': 'cc-pvdz-jkfit.dat', 'ccpvtzjkfit': 'cc-pvtz-jkfit.dat',
+    'def2universaljkfit': 'def2-universal-jkfit.dat',
+    'def2universaljfit': 'def2-universal-jfit.dat',
+    'ccpvdzri': 'cc-pvdz-ri.dat',
+}
+ELEMENTS = ['H', 'He', 'Li', 'Be', 'B', 'C', 'N', 'O', 'F', 'Ne']
+
+out = {}
+for name, fn in FILES.items():
+    text = open(os.path.join(REF, fn)).read()
+    out[name] = {}
+    for el in ELEMENTS:
+        try:
+            out[name][el] = parse_nwchem.parse(text, el)
+        except KeyError:
+            pass
+dst = os.path.join(os.path.dirname(__file__), '..', 'pyscf_amd', 'gto', 'basis', 'data.json')
+json.dump(out, open(dst, 'w'), separators=(',', ':'))
+print({k: sorted(v) for k, v in out.items()})
