@@ -1,0 +1,154 @@
+// C ABI of the on-device integral generation and of the cderi = L^-1 (Q|pq) solve.
+//   PAMD_int3c2e_class   <- GTOnr3c_drv / GTOnr3c_fill_s2ij + libcint int3c2e_sph
+//                           (pyscf/lib/gto/fill_nr_3c.c:127-225), also used for GTOint2c
+//                           (pyscf/lib/gto/fill_int2c.c) through a unit "dummy" j shell
+//   PAMD_cderi_solve     <- scipy trsm at pyscf/df/incore.py:204-213 (and lib.dot at :216
+//                           for the eigen-decomposition fallback)
+#include "common.h"
+#define RYS_QUAL static
+#define RYS_WANT_TABLE
+#include "rys_tables.inc"
+#undef RYS_QUAL
+#include "int3c2e_args.h"
+
+namespace pamd {
+int launch_int3c2e_lk0(int, int, const Int3c2eArgs &, hipStream_t);
+int launch_int3c2e_lk1(int, int, const Int3c2eArgs &, hipStream_t);
+int launch_int3c2e_lk2(int, int, const Int3c2eArgs &, hipStream_t);
+int launch_int3c2e_lk3(int, int, const Int3c2eArgs &, hipStream_t);
+int launch_int3c2e_lk4(int, int, const Int3c2eArgs &, hipStream_t);
+}
+
+using namespace pamd;
+
+namespace {
+
+constexpr int KB = 16, NT = 128, LDN = NT + 16, LDT = KB + 1;
+
+// C[m][n] = sum_{k < klimit(m tile)} At[k][m] * Bt[n][k]
+//   At: [kdim][lda]  (= Linv^T, k = aux function Q, m = local aux row L)
+//   Bt: [n][ldb]     (= T, n = pq of the slab, k contiguous)
+//   C : cderi + column offset, ldc = nao_pair
+// triangular: rows m (global index m_off + m) only need k <= m_off + m.
+__global__ __launch_bounds__(256, 2) void cderi_solve_kernel(
+    const double *__restrict__ At, int lda, const double *__restrict__ Bt, long ldb,
+    double *__restrict__ C, long ldc, int m, long n, int kdim, int m_off, int triangular)
+{
+    __shared__ double sA[KB * LDN];
+    __shared__ double sB[NT * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * NT;
+    const long n0 = (long)blockIdx.x * NT;
+    int kend = kdim;
+    if (triangular) {
+        int lim = m_off + m0 + NT;
+        if (lim < kend) kend = lim;
+    }
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+    double pa[8], pb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int e = tid + j * 256;
+            int k = e >> 7, c = e & 127;                  // A: row k, col c
+            pa[j] = (k0 + k < kend && m0 + c < m) ? At[(long)(k0 + k) * lda + m0 + c] : 0.0;
+            int nn = e >> 4, kq = e & 15;                 // B: row nn (pq), 16 consecutive k
+            pb[j] = (k0 + kq < kend && n0 + nn < n) ? Bt[(n0 + nn) * ldb + k0 + kq] : 0.0;
+        }
+    };
+    if (kend > 0) fetch(0);
+    for (int k0 = 0; k0 < kend; k0 += KB) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int e = tid + j * 256;
+            sA[(e >> 7) * LDN + (e & 127)] = pa[j];
+            sB[(e >> 4) * LDT + (e & 15)] = pb[j];
+        }
+        __syncthreads();
+        if (k0 + KB < kend) fetch(k0 + KB);
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = sA[(kk + fk) * LDN + wr * 64 + a * 16 + fn];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = sB[(wc * 64 + b * 16 + fn) * LDT + kk + fk];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            long col = n0 + wc * 64 + b * 16 + fn;
+            if (col >= n) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int row = m0 + wr * 64 + a * 16 + fk + 4 * r;
+                if (row < m) C[(long)row * ldc + col] = acc[a][b][r];
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+long PAMD_rys_table_len(void) { return RYS_TABLE_LEN; }
+
+// Host copy of the table and its layout (for the CPU-side accuracy test of the tables).
+int PAMD_rys_table_host(double *h_dst, int *offsets /*[RYS_NMAX+1]*/, int *nint /*[RYS_NMAX+1]*/,
+                        double *herm_u /*[(NMAX+1)*NMAX]*/, double *herm_w)
+{
+    memcpy(h_dst, RYS_TABLE, sizeof(double) * RYS_TABLE_LEN);
+    for (int i = 0; i <= RYS_NMAX; i++) { offsets[i] = RYS_OFFSET[i]; nint[i] = RYS_NINT[i]; }
+    memcpy(herm_u, RYS_HERM_U, sizeof(RYS_HERM_U));
+    memcpy(herm_w, RYS_HERM_W, sizeof(RYS_HERM_W));
+    return RYS_NMAX;
+}
+
+int PAMD_rys_table_upload(double *d_dst, void *stream)
+{
+    PAMD_CHECK_HIP(hipMemcpyAsync(d_dst, RYS_TABLE, sizeof(double) * RYS_TABLE_LEN, hipMemcpyHostToDevice,
+                                  (hipStream_t)stream));
+    PAMD_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int PAMD_int3c2e_class(int li, int lj, int lk, const PAMD_int3c2e_args *args, void *stream)
+{
+    PAMD_REQUIRE(li >= lj, "int3c2e class needs l_i >= l_j");
+    const Int3c2eArgs &a = *reinterpret_cast<const Int3c2eArgs *>(args);
+    hipStream_t st = (hipStream_t)stream;
+    switch (lk) {
+    case 0: return launch_int3c2e_lk0(li, lj, a, st);
+    case 1: return launch_int3c2e_lk1(li, lj, a, st);
+    case 2: return launch_int3c2e_lk2(li, lj, a, st);
+    case 3: return launch_int3c2e_lk3(li, lj, a, st);
+    case 4: return launch_int3c2e_lk4(li, lj, a, st);
+    default: return set_error(-2, "int3c2e: aux angular momentum > 4 unsupported", __FILE__, __LINE__);
+    }
+}
+
+int PAMD_cderi_solve(const double *d_linvT, int lda, const double *d_T, long ldT, double *d_cderi,
+                     long ldc, int nL, long npq, int naux, int l_off, int triangular, void *stream)
+{
+    if (nL == 0 || npq == 0) return 0;
+    dim3 grid(ceil_div(npq, NT), ceil_div(nL, NT));
+    cderi_solve_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_linvT, lda, d_T, ldT, d_cderi, ldc, nL, npq,
+                                                               naux, l_off, triangular);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,33 @@
+// Argument block of one int3c2e class launch (plain C layout, mirrored by
+// PAMD_int3c2e_args in include/pyscf_amd.h and by ctypes in pyscf_amd/gto/moleintor.py).
+#pragma once
+extern "C" {
+typedef struct PAMD_int3c2e_args {
+    // shell pairs of this class
+    const int *pair_ish;        // [npairs] shell a (l = LI)
+    const int *pair_jsh;        // [npairs] shell b (l = LJ)
+    const int *pair_pp0;        // [npairs] first primitive-pair record
+    const int *pair_npp;        // [npairs] number of primitive-pair records
+    const double *pp;           // [npp_total][8]: zeta, Px,Py,Pz, cc, PAx,PAy,PAz
+    const double *shell_xyz;    // [nshell_ao][3]
+    const int *shell_ao0;       // [nshell_ao] first AO function of the shell
+    // aux shells of class LK (sorted list)
+    const int *aux_f0;          // [naux_cls] first aux function index (column of T)
+    const double *aux_xyz;      // [naux_cls][3]
+    const double *aux_exp;      // [naux_cls][npk]
+    const double *aux_coef;     // [naux_cls][npk]  (zero padded)
+    int naux_cls;
+    int npk;                    // primitives per aux shell (padded, uniform over the class)
+    const double *rys_table;    // Chebyshev table (device copy of RYS_TABLE)
+    // cart->sph matrices: c2s[l] = [(2l+1)][ncart(l)] at c2s + c2s_off[l]
+    const double *c2s;
+    const int *c2s_off;
+    // output
+    double *T;
+    long ldT;
+    long row_offset;            // subtracted from the packed-tril row index
+    int tril;                   // 1: rows are packed-tril AO pairs; 0: row = ao0_i + fi (2-centre)
+    int npairs;
+} PAMD_int3c2e_args;
+}
+namespace pamd { typedef PAMD_int3c2e_args Int3c2eArgs; }

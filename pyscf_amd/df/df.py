@@ -1,0 +1,131 @@
+"""``DF`` object: owner of the Cholesky-decomposed 3-centre tensor on the GPU.
+
+Duck-types ``pyscf.df.df.DF`` (pyscf/df/df.py:40-337): ``build`` (:147-199), ``reset``
+(:204-212), ``loop`` (:214-242), ``get_naoaux`` (:248-257), ``get_jk`` (:259-267), so that
+``mf.with_df = pyscf_amd.df.DF(mol, auxbasis)`` (or ``mf.density_fit(with_df=...)``,
+pyscf/df/df_jk.py:31,77-105) routes ``_DFHF.get_jk`` (df_jk.py:150-179) onto the MI355X path.
+
+The tensor lives in HBM as the row shard ``cderi[l0:l1, :nao_pair]`` of this rank
+(aux-index sharding); with one process it is the whole ``_cderi``.
+"""
+import numpy as np
+
+from . import addons, df_jk
+
+
+class DF:
+    blockdim = 240     # pyscf/df/df.py:95
+
+    def __init__(self, mol, auxbasis=None, device=None, group=None):
+        self.mol = mol
+        self.stdout = getattr(mol, 'stdout', None)
+        self.verbose = getattr(mol, 'verbose', 0)
+        self.max_memory = getattr(mol, 'max_memory', 4000)
+        self._auxbasis = auxbasis
+        self.auxmol = None
+        self._cderi = None          # optional host ndarray (naux, nao_pair) to upload
+        self._cderi_dev = None      # torch CUDA tensor: rows [l0, l1)
+        self._cderi_to_save = None
+        self._naux = None
+        self.device = device
+        self.group = group
+        # HBM budget for the half-transformed block X (MI355X: 288 GB per GPU)
+        self.k_block_bytes = 8 << 30
+        self.k_nsplit = 4
+        self.lindep = 1e-7         # pyscf/df/incore.py:33
+
+    # -- distributed geometry ----------------------------------------------------------
+    @property
+    def world_size(self):
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_world_size(self.group)
+        except ImportError:
+            pass
+        return 1
+
+    @property
+    def rank(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            return dist.get_rank(self.group)
+        return 0
+
+    @staticmethod
+    def shard_range(naux, rank, world):
+        """Contiguous, row-count-balanced aux range of `rank`."""
+        base, rem = divmod(naux, world)
+        l0 = rank * base + min(rank, rem)
+        return l0, l0 + base + (1 if rank < rem else 0)
+
+    # -- reference attributes -------------------------------------------------------------
+    @property
+    def auxbasis(self):
+        return self._auxbasis
+
+    @auxbasis.setter
+    def auxbasis(self, x):
+        if self._auxbasis != x:
+            self.reset()
+            self._auxbasis = x
+
+    def reset(self, mol=None):
+        if mol is not None:
+            self.mol = mol
+        self.auxmol = None
+        self._cderi = None
+        self._cderi_dev = None
+        self._naux = None
+        return self
+
+    def _device(self):
+        import torch
+        if self.device is not None:
+            return torch.device(self.device)
+        if not torch.cuda.is_available():
+            raise RuntimeError('pyscf_amd.df.DF needs a HIP device (MI355X); none is visible '
+                               'and there is no CPU fallback for the DF J/K path')
+        return torch.device('cuda', torch.cuda.current_device())
+
+    def build(self):
+        import torch
+        dev = self._device()
+        if self._cderi is not None and isinstance(self._cderi, np.ndarray):
+            # pre-computed tensor handed over by the caller (pyscf/df/df.py:153-155)
+            naux = self._cderi.shape[0]
+            l0, l1 = self.shard_range(naux, self.rank, self.world_size)
+            self._cderi_dev = torch.from_numpy(np.ascontiguousarray(self._cderi[l0:l1])).to(dev)
+            self._naux = naux
+            return self
+        if self.auxmol is None:
+            self.auxmol = addons.make_auxmol(self.mol, self.auxbasis)
+        from . import incore
+        self._naux = self.auxmol.nao_nr()
+        l0, l1 = self.shard_range(self._naux, self.rank, self.world_size)
+        self._cderi_dev = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1,
+                                                  lindep=self.lindep)
+        return self
+
+    def get_naoaux(self):
+        if self._naux is None:
+            self.build()
+        return self._naux
+
+    def loop(self, blksize=None):
+        """Yield host row blocks of the rank-local shard (pyscf/df/df.py:214-242)."""
+        if self._cderi_dev is None:
+            self.build()
+        if blksize is None:
+            blksize = self.blockdim
+        n = self._cderi_dev.shape[0]
+        for b0 in range(0, n, blksize):
+            yield self._cderi_dev[b0:b0 + blksize].cpu().numpy()
+
+    def get_jk(self, dm, hermi=1, with_j=True, with_k=True, direct_scf_tol=1e-13, omega=None):
+        if omega is not None:
+            raise NotImplementedError('range-separated Coulomb (omega) - SURVEY.md §8f row 3')
+        return df_jk.get_jk(self, dm, hermi, with_j, with_k, direct_scf_tol)
+
+
+GDF = DF

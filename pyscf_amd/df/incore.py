@@ -1,0 +1,94 @@
+"""Cholesky-decomposed 3-centre tensor built on the GPU.
+
+Mirror of ``pyscf/df/incore.py:129-220`` (``cholesky_eri``): j2c = (P|Q) -> Cholesky
+(``scipy.linalg.cholesky`` on the host exactly as the reference does at :154, eigen-
+decomposition fallback with ``lindep`` :153-158,:263-270) -> per AO-row slab
+``cderi[:, slab] = L^-1 (Q|pq)`` (:189-217).  Integrals and the triangular solve run on the
+device: ``PAMD_int3c2e_class`` (Rys kernels) and ``PAMD_cderi_solve`` (FP64 MFMA GEMM with the
+host-inverted Cholesky factor; rows of this rank's aux shard only).
+"""
+import ctypes
+
+import numpy as np
+import scipy.linalg
+
+from .. import lib as _lib_mod
+from ..gto.moleintor import IntEngine
+
+LINEAR_DEP_THR = 1e-7   # pyscf/df/incore.py:33
+
+
+def _decompose_j2c(j2c, lindep):
+    """-> (M^T with cderi = M (Q|pq), triangular flag).  M = L^-1 or the eig fallback."""
+    try:
+        low = scipy.linalg.cholesky(j2c, lower=True)
+        linv = scipy.linalg.solve_triangular(low, np.eye(len(low)), lower=True, check_finite=False)
+        return linv, True
+    except scipy.linalg.LinAlgError:
+        w, v = scipy.linalg.eigh(j2c)
+        mask = w > lindep
+        v = v[:, mask] / np.sqrt(w[mask])
+        return v.T, False
+
+
+def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_THR,
+                     slab_bytes=24 << 30, engine=None, return_engine=False):
+    """Rows [l0, l1) of cderi (naux, nao_pair) as a torch CUDA tensor."""
+    import torch
+    lib = _lib_mod.load_library()
+    eng = engine or IntEngine(mol, auxmol, device)
+    naux = eng.aux.nao
+    nao = eng.ao.nao
+    npair = nao * (nao + 1) // 2
+    j2c = eng.int2c2e().cpu().numpy()
+    j2c = (j2c + j2c.T) * .5
+    M, tri = _decompose_j2c(j2c, lindep)
+    nrow_total = M.shape[0]
+    if l0 is None:
+        l0, l1 = 0, nrow_total
+    l1 = min(l1, nrow_total)
+    nL = max(l1 - l0, 0)
+    # M^T columns of this shard: [naux][nL]
+    lda = max((nL + 15) // 16 * 16, 16)
+    mt = np.zeros((naux, lda))
+    mt[:, :nL] = M[l0:l1].T
+    mt_dev = torch.from_numpy(mt).to(device)
+    cderi = torch.empty((nL, npair), dtype=torch.float64, device=device)
+    # AO row-shell slabs bounded by slab_bytes of T = [rows][naux]
+    nsh = eng.ao.n
+    max_rows = max(int(slab_bytes // (naux * 8)), 1)
+    slabs = []
+    sh0 = 0
+    while sh0 < nsh:
+        sh1 = sh0 + 1
+        while sh1 < nsh:
+            r0, r1 = eng.slab_rows(sh0, sh1 + 1)
+            if r1 - r0 > max_rows:
+                break
+            sh1 += 1
+        slabs.append((sh0, sh1))
+        sh0 = sh1
+    bufrows = max(eng.slab_rows(a, b)[1] - eng.slab_rows(a, b)[0] for a, b in slabs)
+    T = torch.empty((bufrows, naux), dtype=torch.float64, device=device)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for sh0, sh1 in slabs:
+        r0, r1 = eng.slab_rows(sh0, sh1)
+        Tv = eng.int3c2e_slab(sh0, sh1, out=T)
+        _lib_mod.check(lib.PAMD_cderi_solve(
+            ctypes.c_void_p(mt_dev.data_ptr()), ctypes.c_int(lda),
+            ctypes.c_void_p(Tv.data_ptr()), ctypes.c_long(naux),
+            ctypes.c_void_p(cderi.data_ptr() + 8 * r0), ctypes.c_long(npair),
+            ctypes.c_int(nL), ctypes.c_long(r1 - r0), ctypes.c_int(naux), ctypes.c_int(l0),
+            ctypes.c_int(1 if tri else 0), st))
+    torch.cuda.synchronize()
+    if return_engine:
+        return cderi, eng
+    return cderi
+
+
+def aux_e2_gpu(mol, auxmol, device):
+    """(naux, nao_pair) s2ij tensor of raw 3-centre integrals (df.incore.aux_e2 analogue,
+    pyscf/df/incore.py:40-70), transposed to the cderi layout; for tests."""
+    eng = IntEngine(mol, auxmol, device)
+    T = eng.int3c2e_slab(0, eng.ao.n)
+    return T.T.contiguous()

@@ -1,0 +1,81 @@
+"""Host-side helpers that mirror the parts of ``pyscf.lib`` the DF path uses.
+
+* ``load_library``  <- pyscf/lib/misc.py:123-157 (ctypes loader; ours fails loudly when the HIP
+  library is missing - there is no CPU fallback for the hot path)
+* ``pack_tril`` / ``unpack_tril`` <- pyscf/lib/numpy_helper.py:328-466
+* ``tag_array``     <- pyscf/lib/numpy_helper.py:1487
+* ``fp``            <- pyscf/lib/misc.py:1359-1363
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_LIBDIR = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+class LibraryNotBuiltError(ImportError):
+    pass
+
+
+def load_library(name='libpyscf_amd'):
+    """Load the gfx950 shared library built by ``python __graft_entry__.py`` (in-tree)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = os.path.join(_LIBDIR, name + '.so')
+    if not os.path.exists(so):
+        raise LibraryNotBuiltError(
+            '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950). The DF J/K path has no CPU fallback.' % so)
+    lib = ctypes.CDLL(so)
+    lib.PAMD_last_error.restype = ctypes.c_char_p
+    lib.PAMD_df_vj_pass1_worksize.restype = ctypes.c_long
+    _lib = lib
+    return lib
+
+
+class HIPError(RuntimeError):
+    pass
+
+
+def check(code):
+    if code != 0:
+        raise HIPError('libpyscf_amd call failed (%d): %s'
+                       % (code, load_library().PAMD_last_error().decode()))
+
+
+def fp(a):
+    a = np.asarray(a)
+    return np.dot(np.cos(np.arange(a.size)), a.ravel())
+
+
+def pack_tril(mat):
+    mat = np.asarray(mat)
+    idx = np.tril_indices(mat.shape[-1])
+    return np.ascontiguousarray(mat[..., idx[0], idx[1]])
+
+
+def unpack_tril(tril, filltriu=1):
+    tril = np.asarray(tril)
+    npair = tril.shape[-1]
+    n = int((np.sqrt(8 * npair + 1) - 1) / 2)
+    idx = np.tril_indices(n)
+    out = np.zeros(tril.shape[:-1] + (n, n), dtype=tril.dtype)
+    out[..., idx[0], idx[1]] = tril
+    if filltriu == 1:
+        out[..., idx[1], idx[0]] = tril
+    return out
+
+
+class NPArrayWithTag(np.ndarray):
+    pass
+
+
+def tag_array(a, **kwargs):
+    t = np.asarray(a).view(NPArrayWithTag)
+    if isinstance(a, NPArrayWithTag):
+        t.__dict__.update(a.__dict__)
+    t.__dict__.update(kwargs)
+    return t

@@ -1,0 +1,323 @@
+"""SCF driver: the caller side of the DF J/K hot path.
+
+Host-side mirror of ``pyscf/scf/hf.py`` restricted to what the density-fitted path needs:
+``kernel`` (:49-241), ``energy_elec``/``energy_tot`` (:244-319), ``get_hcore`` (:322-345),
+``init_guess_by_1e`` (:491-498), ``make_rdm1`` (:855-868, DM tagged with mo_coeff/mo_occ),
+``get_fock`` (:1098-1146), ``get_occ`` (:1148-1190), ``get_grad`` (:1193-1210), ``eig`` /
+``_eigh`` with canonical orthogonalisation (:1363-1403,:1873-1882), ``get_veff`` (:2172-2201),
+``density_fit`` (:2252-2259 -> pyscf/df/df_jk.py:31-105) and CDIIS
+(pyscf/scf/diis.py:40-96, pyscf/lib/diis.py:225-290).
+
+All O(nao^3) linear algebra here is plain numpy/scipy on the host (as in the reference); the
+J/K build - the hot path - runs on the MI355X through ``mf.with_df.get_jk``.  One-electron
+integrals come from the device integral engine (no libcint).
+"""
+import ctypes
+import sys
+import time
+
+import numpy as np
+import scipy.linalg
+
+from .. import lib as _lib_mod
+from ..lib import tag_array
+
+TIGHT_GRAD_CONV_TOL = True     # hf.py:43
+OVERLAP_ZERO_EIGENVALUE_THRESHOLD = 1e-6   # hf.py:46-47
+
+
+def energy_elec(mf, dm=None, h1e=None, vhf=None):
+    if dm is None: dm = mf.make_rdm1()
+    if h1e is None: h1e = mf.get_hcore()
+    if vhf is None: vhf = mf.get_veff(mf.mol, dm)
+    e1 = np.einsum('ij,ji->', h1e, dm).real
+    e_coul = np.einsum('ij,ji->', vhf, dm).real * .5
+    mf.scf_summary['e1'] = e1
+    mf.scf_summary['e2'] = e_coul
+    return e1 + e_coul, e_coul
+
+
+class CDIIS:
+    """pyscf/scf/diis.py:40-96 + pyscf/lib/diis.py:225-290 (space 8, min_space 1)."""
+
+    def __init__(self, space=8):
+        self.space = space
+        self.Corth = None
+        self._f, self._e = [], []
+
+    def update(self, s, d, f):
+        sdf = s.dot(d).dot(f)
+        err = sdf.conj().T - sdf
+        if self.Corth is not None:
+            err = self.Corth.conj().T.dot(err).dot(self.Corth)
+        self._f.append(f.copy())
+        self._e.append(err.ravel())
+        if len(self._f) > self.space:
+            self._f.pop(0)
+            self._e.pop(0)
+        n = len(self._f)
+        h = np.zeros((n + 1, n + 1))
+        h[0, 1:] = h[1:, 0] = 1
+        for i in range(n):
+            for j in range(i + 1):
+                h[i + 1, j + 1] = h[j + 1, i + 1] = np.dot(self._e[i].conj(), self._e[j]).real
+        g = np.zeros(n + 1)
+        g[0] = 1
+        w, v = scipy.linalg.eigh(h)
+        if np.any(abs(w) < 1e-14):
+            idx = abs(w) > 1e-14
+            c = np.dot(v[:, idx] * (1. / w[idx]), np.dot(v[:, idx].T.conj(), g))
+        else:
+            try:
+                c = np.linalg.solve(h, g)
+            except np.linalg.LinAlgError:
+                idx = abs(w) > 1e-14
+                c = np.dot(v[:, idx] * (1. / w[idx]), np.dot(v[:, idx].T.conj(), g))
+        out = np.zeros_like(f)
+        for ci, fi in zip(c[1:], self._f):
+            out += ci * fi
+        return out
+
+
+def kernel(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, callback=None, conv_check=True):
+    """pyscf/scf/hf.py:49-241."""
+    if conv_tol_grad is None:
+        conv_tol_grad = np.sqrt(conv_tol)
+    mol = mf.mol
+    s1e = mf.get_ovlp(mol)
+    dm = mf.get_init_guess(mol, mf.init_guess, s1e=s1e) if dm0 is None else dm0
+    h1e = mf.get_hcore(mol)
+    vhf = mf.get_veff(mol, dm)
+    e_tot = mf.energy_tot(dm, h1e, vhf)
+    mf._log('init E= %.15g', e_tot)
+    x_orth = mf.check_linear_dependency(s1e)
+    scf_conv = False
+    mo_energy = mo_coeff = mo_occ = None
+    mf_diis = None
+    if mf.diis:
+        mf_diis = CDIIS(mf.diis_space)
+        mf_diis.Corth = x_orth
+    mf.cycles = 0
+    fock = None
+    for cycle in range(mf.max_cycle):
+        t0 = time.perf_counter()
+        dm_last = dm
+        last_hf_e = e_tot
+        fock = mf.get_fock(h1e, s1e, vhf, dm, cycle, mf_diis)
+        mo_energy, mo_coeff = mf.eig(fock, s1e, x=x_orth)
+        mo_occ = mf.get_occ(mo_energy, mo_coeff)
+        dm = mf.make_rdm1(mo_coeff, mo_occ)
+        vhf = mf.get_veff(mol, dm, dm_last, vhf)
+        e_tot = mf.energy_tot(dm, h1e, vhf)
+        fock = mf.get_fock(h1e, s1e, vhf, dm)
+        norm_gorb = np.linalg.norm(mf.get_grad(mo_coeff, mo_occ, fock))
+        norm_ddm = np.linalg.norm(dm - dm_last)
+        mf._log('cycle= %d E= %.15g  delta_E= %4.3g  |g|= %4.3g  |ddm|= %4.3g  (%.3f s)',
+                cycle + 1, e_tot, e_tot - last_hf_e, norm_gorb, norm_ddm, time.perf_counter() - t0)
+        if abs(e_tot - last_hf_e) < conv_tol and norm_gorb < conv_tol_grad:
+            scf_conv = True
+        if callable(callback):
+            callback(locals())
+        if scf_conv:
+            break
+    mf.cycles = cycle + 1
+    if scf_conv and conv_check:
+        mo_energy, mo_coeff = mf.eig(fock, s1e, x=x_orth)
+        mo_occ = mf.get_occ(mo_energy, mo_coeff)
+        dm, dm_last = mf.make_rdm1(mo_coeff, mo_occ), dm
+        vhf = mf.get_veff(mol, dm, dm_last, vhf)
+        e_tot, last_hf_e = mf.energy_tot(dm, h1e, vhf), e_tot
+        fock = mf.get_fock(h1e, s1e, vhf, dm)
+        norm_gorb = np.linalg.norm(mf.get_grad(mo_coeff, mo_occ, fock))
+        if abs(e_tot - last_hf_e) < conv_tol * 10 or norm_gorb < conv_tol_grad * 3:
+            scf_conv = True
+        else:
+            scf_conv = False
+        mf._log('Extra cycle  E= %.15g  delta_E= %4.3g  |g|= %4.3g', e_tot, e_tot - last_hf_e, norm_gorb)
+    return scf_conv, e_tot, mo_energy, mo_coeff, mo_occ
+
+
+class SCF:
+    """Attributes and defaults as pyscf/scf/hf.py:1737-1760."""
+    conv_tol = 1e-9
+    conv_tol_grad = None
+    max_cycle = 50
+    init_guess = '1e'          # the reference's default 'minao' needs the ANO tables (out of scope)
+    diis = True
+    diis_space = 8
+    direct_scf = True
+    direct_scf_tol = 1e-13
+    conv_check = True
+
+    def __init__(self, mol):
+        self.mol = mol
+        self.verbose = getattr(mol, 'verbose', 0)
+        self.stdout = getattr(mol, 'stdout', None) or sys.stdout
+        self.max_memory = getattr(mol, 'max_memory', 4000)
+        self.mo_energy = self.mo_coeff = self.mo_occ = None
+        self.e_tot = 0
+        self.converged = False
+        self.scf_summary = {}
+        self.with_df = None
+        self._int1e = None
+
+    def _log(self, fmt, *args):
+        if self.verbose >= 4:
+            print(fmt % args, file=self.stdout)
+
+    # -- one-electron part (device integral engine) ----------------------------------------
+    def _get_int1e(self):
+        if self._int1e is None:
+            self._int1e = int1e_gpu(self.mol)
+        return self._int1e
+
+    def get_ovlp(self, mol=None):
+        return self._get_int1e()[0]
+
+    def get_hcore(self, mol=None):
+        s, t, v = self._get_int1e()
+        return t + v
+
+    def get_init_guess(self, mol=None, key='1e', s1e=None):
+        if key.lower() not in ('1e', 'hcore'):
+            raise NotImplementedError("init_guess %s (only '1e' is restated; hf.py:491-498)" % key)
+        h1e = self.get_hcore()
+        if s1e is None:
+            s1e = self.get_ovlp()
+        mo_energy, mo_coeff = self.eig(h1e, s1e)
+        mo_occ = self.get_occ(mo_energy, mo_coeff)
+        return self.make_rdm1(mo_coeff, mo_occ)
+
+    def check_linear_dependency(self, s1e):
+        """hf.py:1363-1379: x = v[:, e > 1e-6] / sqrt(e) (always returned)."""
+        e, v = scipy.linalg.eigh(s1e)
+        mask = e > OVERLAP_ZERO_EIGENVALUE_THRESHOLD
+        return v[:, mask] / np.sqrt(e[mask])
+
+    def eig(self, h, s, x=None):
+        if x is None:
+            e, c = scipy.linalg.eigh(h, s)
+        else:
+            e, c = scipy.linalg.eigh(x.conj().T.dot(h).dot(x))
+            c = x.dot(c)
+        idx = np.argmax(abs(c.real), axis=0)          # _adjust_phase_ hf.py:1393-1403
+        c[:, c[idx, np.arange(len(e))].real < 0] *= -1
+        return e, c
+
+    def get_occ(self, mo_energy, mo_coeff=None):
+        e_idx = np.argsort(mo_energy.round(9), kind='stable')
+        nocc = self.mol.nelectron // 2
+        mo_occ = np.zeros_like(mo_energy)
+        mo_occ[e_idx[:nocc]] = 2
+        return mo_occ
+
+    def make_rdm1(self, mo_coeff=None, mo_occ=None):
+        if mo_coeff is None: mo_coeff = self.mo_coeff
+        if mo_occ is None: mo_occ = self.mo_occ
+        mocc = mo_coeff[:, mo_occ > 0]
+        dm = (mocc * mo_occ[mo_occ > 0]).dot(mocc.conj().T)
+        return tag_array(dm, mo_coeff=mo_coeff, mo_occ=mo_occ)
+
+    def get_fock(self, h1e, s1e, vhf, dm, cycle=-1, diis=None):
+        f = h1e + vhf
+        if cycle < 0 or diis is None:
+            return f
+        if cycle >= 1:                                   # diis_start_cycle = 1
+            f = diis.update(s1e, dm, f)
+        return f
+
+    def get_grad(self, mo_coeff, mo_occ, fock):
+        occidx, viridx = mo_occ > 0, mo_occ == 0
+        g = mo_coeff[:, viridx].conj().T.dot(fock.dot(mo_coeff[:, occidx])) * 2
+        return g.ravel()
+
+    # -- two-electron part -------------------------------------------------------------------
+    def get_jk(self, mol=None, dm=None, hermi=1, with_j=True, with_k=True, omega=None):
+        if self.with_df is None:
+            raise NotImplementedError('4-centre J/K is out of scope (SURVEY.md §8 A20): call '
+                                      '.density_fit() first')
+        return self.with_df.get_jk(dm, hermi, with_j, with_k, self.direct_scf_tol, omega)
+
+    def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
+        """hf.py:2172-2201 - _DFHF sets direct_scf falsy (df_jk.py:138): full build each cycle."""
+        if dm is None: dm = self.make_rdm1()
+        t0 = time.perf_counter()
+        vj, vk = self.get_jk(mol, dm, hermi)
+        self._log('df vj and vk: %.4f s', time.perf_counter() - t0)
+        return vj - vk * .5
+
+    def energy_elec(self, dm=None, h1e=None, vhf=None):
+        return energy_elec(self, dm, h1e, vhf)
+
+    def energy_nuc(self):
+        return self.mol.energy_nuc()
+
+    def energy_tot(self, dm=None, h1e=None, vhf=None):
+        nuc = self.energy_nuc()
+        self.scf_summary['nuc'] = nuc
+        return self.energy_elec(dm, h1e, vhf)[0] + nuc
+
+    def density_fit(self, auxbasis=None, with_df=None, only_dfj=False):
+        """pyscf/df/df_jk.py:31-105: attach a DF object; J/K are then routed to it."""
+        from .. import df
+        if with_df is None:
+            with_df = df.DF(self.mol, auxbasis)
+        self.with_df = with_df
+        return self
+
+    def kernel(self, dm0=None):
+        self.converged, self.e_tot, self.mo_energy, self.mo_coeff, self.mo_occ = kernel(
+            self, self.conv_tol, self.conv_tol_grad, dm0=dm0, conv_check=self.conv_check)
+        return self.e_tot
+
+    scf = kernel
+
+
+class RHF(SCF):
+    pass
+
+
+def int1e_gpu(mol, device=None):
+    """(S, T, V) in the real-spherical AO basis from the device integral engine."""
+    import torch
+    from ..gto.moleintor import IntEngine, _AuxClass, _Shells, _dev, c2s_matrix
+    lib = _lib_mod.load_library()
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError('int1e_gpu needs a HIP device')
+        device = torch.device('cuda', torch.cuda.current_device())
+    eng = IntEngine(mol, None, device)
+    sh = eng.ao
+    nao = sh.nao
+    prim0 = np.cumsum([0] + [len(e) for e in sh.exps])[:-1].astype(np.int32)
+    nprim = np.array([len(e) for e in sh.exps], np.int32)
+    d_l, d_ao0 = _dev(sh.l, device), _dev(sh.ao0, device)
+    d_p0, d_np = _dev(prim0, device), _dev(nprim, device)
+    d_ex, d_co = _dev(np.concatenate(sh.exps), device), _dev(np.concatenate(sh.coefs), device)
+    S = torch.zeros((nao, nao), dtype=torch.float64, device=device)
+    T = torch.zeros((nao, nao), dtype=torch.float64, device=device)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib_mod.check(lib.PAMD_int1e_ovlp_kin(p(d_l), p(d_ao0), p(d_p0), p(d_np), p(eng.ao_xyz), p(d_ex), p(d_co),
+                                           ctypes.c_int(sh.n), ctypes.c_int(nao), p(eng.c2s), p(eng.c2s_off),
+                                           p(S), p(T), st))
+    # nuclear attraction: (ij| point charge) = limit of a normalised s Gaussian, eta -> infinity
+    natm = len(mol._atm)
+    nuc = _Shells.__new__(_Shells)
+    eta = 1e30
+    nuc.l = np.zeros(natm, np.int32)
+    nuc.xyz = mol.atom_coords()
+    nuc.exps = [np.array([eta])] * natm
+    z = mol.atom_charges().astype(float)
+    nuc.coefs = [np.array([-zi * (eta / np.pi) ** 1.5 / c2s_matrix(0)[0, 0]]) for zi in z]
+    nuc.ao0 = np.arange(natm, dtype=np.int32)
+    nuc.n = natm
+    nuc.nao = natm
+    ac = _AuxClass(nuc, 0, device)
+    npair = nao * (nao + 1) // 2
+    V3 = torch.zeros((npair, natm), dtype=torch.float64, device=device)
+    for pc in eng.pair_classes():
+        eng._launch(pc, 0, pc.n, ac, V3, natm, 0, 1, eng.ao_xyz, eng.ao_ao0)
+    vtril = V3.sum(dim=1).cpu().numpy()
+    V = _lib_mod.unpack_tril(vtril, 1)
+    return S.cpu().numpy(), T.cpu().numpy(), V
