@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark: ms per SCF iteration of the density-fitted J/K build.
+
+Workload (BASELINE.json metric): (H2O)_32 cc-pVTZ, aux cc-pvtz-jkfit (nao 1856, naux 4448,
+nocc 160; B = 61.3 GB FP64 resident in HBM), one `with_df.get_jk(dm, hermi=1)` (J and K, MO
+branch) per step with the DM / orbitals already resident on the device.  With N GPUs the aux
+index is sharded over the ranks and the partial J/K are all-reduced (RCCL): strong scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nwater 32] [--basis cc-pvtz]
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (HIP events on the launch
+stream); `cpu_baseline` times the oracle's numpy restatement of the reference algorithm
+(pyscf/df/df_jk.py:329-381) on a bounded sample of aux rows of the same tensor.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix peak (vendor spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--nwater', type=int, default=32)
+    ap.add_argument('--basis', default='cc-pvtz')
+    ap.add_argument('--cpu-sample-rows', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from pyscf_amd import gto, df, lib
+    from pyscf_amd.data import clusters
+    from pyscf_amd.df import df_jk
+    from pyscf_amd.scf import hf
+
+    mol = gto.M(atom=clusters.water_cluster(args.nwater), basis=args.basis)
+    nao, nocc = mol.nao, mol.nelectron // 2
+    dfobj = df.DF(mol)                      # aux basis by the reference's rule (cc-pvtz -> cc-pvtz-jkfit)
+    t0 = time.perf_counter()
+    dfobj.build()
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    naux = dfobj.get_naoaux()
+    npair = nao * (nao + 1) // 2
+    naux_local = dfobj._cderi_dev.shape[0]
+
+    # converged-like idempotent DM: Loewdin-orthogonalised random orbitals, seed 1
+    s1e = hf.int1e_gpu(mol, dev)[0]
+    rng = np.random.RandomState(1)
+    x = rng.random_sample((nao, nao))
+    w, v = np.linalg.eigh(x.T.dot(s1e).dot(x))
+    c = x.dot(v / np.sqrt(w)).dot(v.T)
+    mo_occ = np.zeros(nao)
+    mo_occ[:nocc] = 2
+    orbo = c[:, :nocc] * np.sqrt(2.0)
+    dm = orbo.dot(orbo.T)
+    dms_dev = torch.from_numpy(dm[None]).to(dev)
+    orb_list = [df_jk.pad_orbitals(orbo, dev)]
+
+    def step():
+        return df_jk.get_jk_device(dfobj, dms_dev, orb_list, True, True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vjtril, vk = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # per-kernel durations (one extra, untimed step with HIP events around every launch)
+    dfobj.kernel_timer = df_jk.KernelTimer()
+    step()
+    ksum = dfobj.kernel_timer.summary()
+    dfobj.kernel_timer = None
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    nocc_pad = orb_list[0][1]
+    # algorithmic work of this rank's shard
+    flops_e2 = 2.0 * naux_local * nao * nao * nocc          # X_L = B_L C
+    flops_syrk = 2.0 * naux_local * nao * nao * nocc        # K += X^T X (full-square figure)
+    bytes_j = 8.0 * naux_local * npair
+    kern = {}
+    for name, (tot, cnt) in ksum.items():
+        kern[name] = {'ms_total': round(tot, 4), 'launches': cnt, 'ms_avg': round(tot / cnt, 4)}
+    dom = max(ksum, key=lambda k: ksum[k][0])
+    dtot, dcnt = ksum[dom]
+    if dom in ('e2_symm', 'dgemm_tn'):
+        fl = flops_e2 if dom == 'e2_symm' else flops_syrk
+        ach = fl / (dtot * 1e-3) / 1e12
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(ach / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                    'avg_launch_ms': round(dtot / dcnt, 4), 'launches': dcnt,
+                    'flops_per_step': fl}
+    else:
+        ach = bytes_j / (dtot * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'avg_launch_ms': round(dtot / dcnt, 4), 'launches': dcnt}
+    # HBM GB/s of the J kernels (the metric's second figure): one algorithmic read of B per pass
+    j_gbs = {}
+    for name in ('vj_pass1', 'vj_pass2'):
+        if name in ksum:
+            j_gbs[name] = round(bytes_j / (ksum[name][0] * 1e-3) / 1e9, 1)
+    k_tflops = {}
+    if 'e2_symm' in ksum:
+        k_tflops['e2_symm'] = round(flops_e2 / (ksum['e2_symm'][0] * 1e-3) / 1e12, 2)
+    if 'dgemm_tn' in ksum:
+        k_tflops['dgemm_tn'] = round(flops_syrk / (ksum['dgemm_tn'][0] * 1e-3) / 1e12, 2)
+
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline:
+        from oracle import ref
+        nrow = min(args.cpu_sample_rows, naux_local)
+        sample = dfobj._cderi_dev[:nrow].cpu().numpy()
+        t0 = time.perf_counter()
+        vj0, vk0 = ref.get_jk(sample, dm, 1, mo_coeff=c, mo_occ=mo_occ)
+        cpu_s = time.perf_counter() - t0
+        cpu = {'value': round(cpu_s / nrow * naux * 1e3, 1), 'unit': 'ms/iter (extrapolated to all %d aux rows)' % naux,
+               'cores': os.cpu_count(), 'kind': 'port',
+               'sample': 'oracle/ref.get_jk (numpy/OpenBLAS restatement of df_jk.py:329-381) on %d of %d aux rows '
+                         'of the GPU-built tensor: %.2f s' % (nrow, naux, cpu_s)}
+        # parity at full size: the same rows through the HIP path
+        sub = df.DF(mol)
+        sub._cderi_dev = dfobj._cderi_dev[:nrow]
+        vjt, vkd = df_jk.get_jk_device(_Single(sub), dms_dev, orb_list, True, True)
+        vj1 = lib.unpack_tril(vjt.cpu().numpy(), 1)[0]
+        vk1 = vkd.cpu().numpy()[0]
+        parity = {'rows': nrow, 'max_abs_err_vj': float(np.abs(vj1 - vj0).max()),
+                  'max_abs_err_vk': float(np.abs(vk1 - vk0).max())}
+
+    out = {
+        'metric': 'ms per SCF iter (DF J/K build)', 'value': round(ms_per_step, 3), 'unit': 'ms',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+        'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': '(H2O)_%d %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM'
+                               % (args.nwater, args.basis, 'cc-pvtz-jkfit' if 'tz' in args.basis else 'auto',
+                                  nao, naux, nocc, 8e-9 * naux * npair),
+                   'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
+                   'naux_local': naux_local},
+        'roofline': roofline,
+        'cpu_baseline': cpu,
+        'kernels': kern, 'j_hbm_GBs': j_gbs, 'k_mfma_TFLOPs': k_tflops,
+        'build_s': round(build_s, 2), 'parity_sample': parity,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+class _Single:
+    """View of a DF object that never all-reduces (used for the single-rank parity sample)."""
+
+    def __init__(self, obj):
+        self.__dict__['_o'] = obj
+
+    def __getattr__(self, k):
+        if k == 'world_size':
+            return 1
+        return getattr(self.__dict__['_o'], k)
+
+
+if __name__ == '__main__':
+    main()

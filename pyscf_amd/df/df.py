@@ -33,6 +33,8 @@ class DF:
         self.k_block_bytes = 8 << 30
         self.k_nsplit = 4
         self.lindep = 1e-7         # pyscf/df/incore.py:33
+        self.kernel_timer = None   # df_jk.KernelTimer() to collect per-kernel HIP-event timings
+        self._ws = {}
 
     # -- distributed geometry ----------------------------------------------------------
     @property
@@ -59,6 +61,16 @@ class DF:
         l0 = rank * base + min(rank, rem)
         return l0, l0 + base + (1 if rank < rem else 0)
 
+    def _workspace(self, name, shape):
+        """Persistent HBM scratch (no per-iteration hipMalloc): returns a view of `shape`."""
+        import torch
+        n = int(np.prod(shape))
+        buf = self._ws.get(name)
+        if buf is None or buf.numel() < n or buf.device != self._cderi_dev.device:
+            buf = torch.empty(n, dtype=torch.float64, device=self._cderi_dev.device)
+            self._ws[name] = buf
+        return buf[:n].view(*shape)
+
     # -- reference attributes -------------------------------------------------------------
     @property
     def auxbasis(self):
@@ -77,6 +89,7 @@ class DF:
         self._cderi = None
         self._cderi_dev = None
         self._naux = None
+        self._ws = {}
         return self
 
     def _device(self):

@@ -37,6 +37,42 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class KernelTimer:
+    """Optional per-kernel timing with HIP events recorded on the launch stream (torch's current
+    stream is the stream every PAMD_* launch uses).  bench.py reads `.summary()`."""
+
+    def __init__(self):
+        self.records = []
+
+    def call(self, name, fn, *args):
+        torch = _torch()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        self.records.append((name, e0, e1))
+        return rc
+
+    def summary(self):
+        _torch().cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            tot, cnt = out.get(name, (0.0, 0))
+            out[name] = (tot + ms, cnt + 1)
+        return out
+
+    def reset(self):
+        self.records = []
+
+
+def _call(dfobj, name, fn, *args):
+    timer = getattr(dfobj, 'kernel_timer', None)
+    rc = timer.call(name, fn, *args) if timer is not None else fn(*args)
+    _lib_mod.check(rc)
+
+
 def _allreduce(dfobj, tensors):
     """Sum the rank-partial results over the aux-index shards (RCCL over xGMI)."""
     if dfobj.world_size > 1:
@@ -55,15 +91,15 @@ def _vj(dfobj, lib, dms_dev, nset, nao):
     for s0 in range(0, nset, 4):
         ns = min(4, nset - s0)
         dmtril = torch.empty((ns, npair), dtype=torch.float64, device=dev)
-        _lib_mod.check(lib.PAMD_pack_dm_tril(_ptr(dms_dev[s0:s0 + ns]), _c.c_int(ns), _c.c_int(nao),
-                                             _ptr(dmtril), st))
+        _call(dfobj, 'pack_dm_tril', lib.PAMD_pack_dm_tril, _ptr(dms_dev[s0:s0 + ns]), _c.c_int(ns), _c.c_int(nao),
+                                             _ptr(dmtril), st)
         rho = torch.empty((ns, naux), dtype=torch.float64, device=dev)
         wlen = lib.PAMD_df_vj_pass1_worksize(_c.c_long(npair), _c.c_int(naux), _c.c_int(ns))
         work = torch.empty((max(wlen, 1),), dtype=torch.float64, device=dev)
-        _lib_mod.check(lib.PAMD_df_vj_pass1(_ptr(cderi), _c.c_long(npair), _c.c_int(naux),
-                                            _ptr(dmtril), _c.c_int(ns), _ptr(rho), _ptr(work), st))
-        _lib_mod.check(lib.PAMD_df_vj_pass2(_ptr(cderi), _c.c_long(npair), _c.c_int(naux),
-                                            _ptr(rho), _c.c_int(ns), _ptr(vjtril[s0:s0 + ns]), st))
+        _call(dfobj, 'vj_pass1', lib.PAMD_df_vj_pass1, _ptr(cderi), _c.c_long(npair), _c.c_int(naux),
+                                            _ptr(dmtril), _c.c_int(ns), _ptr(rho), _ptr(work), st)
+        _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(cderi), _c.c_long(npair), _c.c_int(naux),
+                                            _ptr(rho), _c.c_int(ns), _ptr(vjtril[s0:s0 + ns]), st)
     return vjtril
 
 
@@ -75,9 +111,21 @@ def _k_blocksize(dfobj, naux, rows, ldx):
     return min(blk, max(naux, 1))
 
 
-def _vk_mo(dfobj, lib, orbo_list, nao):
+def pad_orbitals(orbo, device):
+    """Host (nao, nocc) occupied-orbital block C_occ*sqrt(occ) -> zero-padded device operand
+    (orb[nao][ldo], nocc_pad) in the layout PAMD_nr_e2_symm expects."""
+    torch = _torch()
+    nao, nocc = orbo.shape
+    nocc_pad = _round_up(max(nocc, 1), 16)
+    ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
+    orb_h = np.zeros((nao, ldo))
+    orb_h[:, :nocc] = orbo
+    return torch.from_numpy(orb_h).to(device), (nocc_pad if nocc else 0), ldo
+
+
+def _vk_mo(dfobj, lib, orb_list, nao):
     """K_pq = sum_{L,i} X[L,i,p] X[L,i,q],  X[L,i,p] = sum_q B_L[p,q] orbo[q,i]
-    (df_jk.py:353-380; nr_ao2mo.c:399-419,1240-1266)."""
+    (df_jk.py:353-380; nr_ao2mo.c:399-419,1240-1266).  orb_list: [(orb_dev, nocc_pad, ldo)]."""
     torch = _torch()
     cderi = dfobj._cderi_dev
     naux, npair = cderi.shape
@@ -86,30 +134,24 @@ def _vk_mo(dfobj, lib, orbo_list, nao):
     ldx = _round_up(nao, 16)
     nsplit = dfobj.k_nsplit
     vks = []
-    for orbo in orbo_list:
-        nocc = orbo.shape[1]
+    for orb, nocc_pad, ldo in orb_list:
         vk = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
-        if nocc == 0 or naux == 0:
+        if nocc_pad == 0 or naux == 0:
             vks.append(vk)
             continue
-        nocc_pad = _round_up(nocc, 16)
-        ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
-        orb_h = np.zeros((nao, ldo))
-        orb_h[:, :nocc] = orbo
-        orb = torch.from_numpy(orb_h).to(dev)
         blk = _k_blocksize(dfobj, naux, nocc_pad, ldx)
-        X = torch.empty((blk, nocc_pad, ldx), dtype=torch.float64, device=dev)
-        part = torch.zeros((nsplit, nao, nao), dtype=torch.float64, device=dev)
+        X = dfobj._workspace('X', (blk, nocc_pad, ldx))
+        part = dfobj._workspace('kpart', (nsplit, nao, nao))
+        part.zero_()
         for b0 in range(0, naux, blk):
             nb = min(blk, naux - b0)
-            _lib_mod.check(lib.PAMD_nr_e2_symm(_ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
-                                               _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
-                                               _c.c_int(nocc_pad), _ptr(X), _c.c_int(ldx), st))
-            _lib_mod.check(lib.PAMD_dgemm_tn(_ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
-                                             _c.c_int(nao), _c.c_int(nao), _c.c_int(nao),
-                                             _c.c_long(nb * nocc_pad), _c.c_int(1), _c.c_int(nsplit), st))
-        _lib_mod.check(lib.PAMD_reduce_splits(_ptr(part), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
-                                              _ptr(vk), _c.c_int(nao), _c.c_int(1), st))
+            _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
+                  _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(nocc_pad), _ptr(X), _c.c_int(ldx), st)
+            _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
+                  _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(1),
+                  _c.c_int(nsplit), st)
+        _call(dfobj, 'reduce_splits', lib.PAMD_reduce_splits, _ptr(part), _c.c_int(nsplit), _c.c_int(nao),
+              _c.c_int(nao), _ptr(vk), _c.c_int(nao), _c.c_int(1), st)
         vks.append(vk)
     return torch.stack(vks)
 
@@ -129,8 +171,9 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
     vk = torch.zeros((nset, nao, nao), dtype=torch.float64, device=dev)
     if naux == 0:
         return vk
-    X = torch.empty((blk, rows, ldx), dtype=torch.float64, device=dev)
-    full = torch.zeros((blk, rows, ldx), dtype=torch.float64, device=dev)
+    X = dfobj._workspace('X', (blk, rows, ldx))
+    full = dfobj._workspace('full', (blk, rows, ldx))
+    full.zero_()
     for k in range(nset):
         orb = torch.zeros((nao, ldo), dtype=torch.float64, device=dev)
         orb[:, :nao] = dms_dev[k]
@@ -138,24 +181,46 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
         for b0 in range(0, naux, blk):
             nb = min(blk, naux - b0)
             sub = cderi[b0:b0 + nb]
-            _lib_mod.check(lib.PAMD_nr_e2_symm(_ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
+            _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
                                                _ptr(orb), _c.c_int(ldo), _c.c_int(rows), _ptr(X),
-                                               _c.c_int(ldx), st))
-            _lib_mod.check(lib.PAMD_unpack_tril(_ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
-                                                _ptr(full), _c.c_int(ldx), _c.c_int(rows), st))
-            _lib_mod.check(lib.PAMD_dgemm_tn(_ptr(X), _c.c_int(ldx), _ptr(full), _c.c_int(ldx), _ptr(part),
+                                               _c.c_int(ldx), st)
+            _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
+                                                _ptr(full), _c.c_int(ldx), _c.c_int(rows), st)
+            _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(full), _c.c_int(ldx), _ptr(part),
                                              _c.c_int(nao), _c.c_int(nao), _c.c_int(nao),
-                                             _c.c_long(nb * rows), _c.c_int(0), _c.c_int(nsplit), st))
-        _lib_mod.check(lib.PAMD_reduce_splits(_ptr(part), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
-                                              _ptr(vk[k]), _c.c_int(nao), _c.c_int(0), st))
+                                             _c.c_long(nb * rows), _c.c_int(0), _c.c_int(nsplit), st)
+        _call(dfobj, 'reduce_splits', lib.PAMD_reduce_splits, _ptr(part), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
+                                              _ptr(vk[k]), _c.c_int(nao), _c.c_int(0), st)
     return vk
+
+
+def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
+    """Device-resident J/K build: inputs and outputs stay in HBM.
+      dms_dev   (nset, nao, nao) f64 CUDA tensor
+      orb_list  None (general-DM branch) or [(orb_dev, nocc_pad, ldo)] from `pad_orbitals`
+    Returns (vjtril_dev (nset, nao_pair) | None, vk_dev (nset, nao, nao) | None), already summed
+    over the aux-index shards of all ranks."""
+    lib = _lib_mod.load_library()
+    nset, nao = dms_dev.shape[0], dms_dev.shape[-1]
+    vjtril = vk_dev = None
+    outs = []
+    if with_j:
+        vjtril = _vj(dfobj, lib, dms_dev, nset, nao)
+        outs.append(vjtril)
+    if with_k:
+        if orb_list is not None:
+            vk_dev = _vk_mo(dfobj, lib, orb_list, nao)
+        else:
+            vk_dev = _vk_general(dfobj, lib, dms_dev, nset, nao)
+        outs.append(vk_dev)
+    _allreduce(dfobj, outs)
+    return vjtril, vk_dev
 
 
 def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
     """Same contract as ``pyscf.df.df_jk.get_jk`` (df_jk.py:280): returns (vj, vk) shaped like dm."""
     assert with_j or with_k
     torch = _torch()
-    lib = _lib_mod.load_library()
     if dfobj._cderi_dev is None:
         dfobj.build()
     dms = np.asarray(dm)
@@ -170,31 +235,23 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
     nset = dms.shape[0]
     dev = dfobj._cderi_dev.device
     dms_dev = torch.from_numpy(dms).to(dev)
-    vj = vk = None
-    outs = []
-    if with_j:
-        vjtril = _vj(dfobj, lib, dms_dev, nset, nao)
-        outs.append(vjtril)
-    if with_k:
-        mo_coeff = getattr(dm, 'mo_coeff', None)
-        if mo_coeff is not None:
-            mo_coeff = np.asarray(mo_coeff)
-            mo_occ = np.asarray(dm.mo_occ)
-            nmo = mo_occ.shape[-1]
-            mo_coeff = mo_coeff.reshape(-1, nao, nmo)
-            mo_occ = mo_occ.reshape(-1, nmo)
-            if mo_occ.shape[0] * 2 == nset:      # ROHF-style DM (df_jk.py:346-351)
-                mo_coeff = np.vstack((mo_coeff, mo_coeff))
-                mo_occa = np.array(mo_occ > 0, dtype=np.double)
-                mo_occb = np.array(mo_occ == 2, dtype=np.double)
-                mo_occ = np.vstack((mo_occa, mo_occb))
-            orbo = [mo_coeff[k][:, mo_occ[k] > 0] * np.sqrt(mo_occ[k][mo_occ[k] > 0])
+    orb_list = None
+    mo_coeff = getattr(dm, 'mo_coeff', None)
+    if with_k and mo_coeff is not None:
+        mo_coeff = np.asarray(mo_coeff)
+        mo_occ = np.asarray(dm.mo_occ)
+        nmo = mo_occ.shape[-1]
+        mo_coeff = mo_coeff.reshape(-1, nao, nmo)
+        mo_occ = mo_occ.reshape(-1, nmo)
+        if mo_occ.shape[0] * 2 == nset:      # ROHF-style DM (df_jk.py:346-351)
+            mo_coeff = np.vstack((mo_coeff, mo_coeff))
+            mo_occa = np.array(mo_occ > 0, dtype=np.double)
+            mo_occb = np.array(mo_occ == 2, dtype=np.double)
+            mo_occ = np.vstack((mo_occa, mo_occb))
+        orb_list = [pad_orbitals(mo_coeff[k][:, mo_occ[k] > 0] * np.sqrt(mo_occ[k][mo_occ[k] > 0]), dev)
                     for k in range(nset)]
-            vk_dev = _vk_mo(dfobj, lib, orbo, nao)
-        else:
-            vk_dev = _vk_general(dfobj, lib, dms_dev, nset, nao)
-        outs.append(vk_dev)
-    _allreduce(dfobj, outs)
+    vjtril, vk_dev = get_jk_device(dfobj, dms_dev, orb_list, with_j, with_k)
+    vj = vk = None
     if with_j:
         vj = _lib_mod.unpack_tril(vjtril.cpu().numpy(), 1).reshape(dm_shape)
     if with_k:

@@ -213,8 +213,9 @@ class IntEngine:
             raise NotImplementedError('aux angular momentum > %d' % LMAX_AUX)
         n = self.lib.PAMD_rys_table_len()
         self.rys = torch.empty(n, dtype=torch.float64, device=device)
-        self._stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib_mod.check(self.lib.PAMD_rys_table_upload(ctypes.c_void_p(self.rys.data_ptr()), self._stream))
+        if torch.device(device).type == 'cuda':
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib_mod.check(self.lib.PAMD_rys_table_upload(ctypes.c_void_p(self.rys.data_ptr()), st))
         mats = [c2s_matrix(l) for l in range(max(LMAX_AO, LMAX_AUX) + 1)]
         off = np.cumsum([0] + [m.size for m in mats])[:-1].astype(np.int32)
         self.c2s = _dev(np.concatenate([m.ravel() for m in mats]), device)

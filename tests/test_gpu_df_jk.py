@@ -72,15 +72,17 @@ def test_random_tensor_ragged_sizes(nao, naux, nocc):
     full = ref.unpack_tril(cderi)
     rho = np.einsum('Lpq,pq->L', full, dm)
     vj0 = np.einsum('L,Lpq->pq', rho, full)
-    tmp = np.einsum('Lpq,qr->Lpr', full, dm)
-    vk0 = np.einsum('Lpr,Lqr->pq', tmp, full)
+    tmp = full.dot(dm)                                     # [L][p][r]
+    vk0 = np.einsum('Lpr,Lqr->pq', tmp, full, optimize=True)
     scale = max(1.0, np.abs(vk0).max())
     assert np.abs(vj - vj0).max() < 1e-10 * max(1.0, np.abs(vj0).max())
     assert np.abs(vk - vk0).max() < 1e-10 * scale
     dms = rng.standard_normal((3, nao, nao))
     vj, vk = obj.get_jk(dms, hermi=0)
-    vj0 = np.einsum('Lpq,sqp,Lrt->srt', full, dms, full, optimize=True)
-    vk0 = np.einsum('Lij,sjk,Lkl->sil', full, dms, full, optimize=True)
+    rho = np.einsum('Lpq,sqp->sL', full, dms)
+    vj0 = np.einsum('sL,Lrt->srt', rho, full)
+    f2 = full.reshape(-1, nao)
+    vk0 = np.stack([(full.dot(d).transpose(0, 2, 1).reshape(-1, nao)).T.dot(f2) for d in dms])
     assert np.abs(vj - vj0).max() < 1e-10 * max(1.0, np.abs(vj0).max())
     assert np.abs(vk - vk0).max() < 1e-10 * max(1.0, np.abs(vk0).max())
 
