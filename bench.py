@@ -34,7 +34,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--nwater', type=int, default=32)
     ap.add_argument('--basis', default='cc-pvtz')
-    ap.add_argument('--cpu-sample-rows', type=int, default=8)
+    ap.add_argument('--cpu-sample-rows', type=int, default=240)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

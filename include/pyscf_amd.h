@@ -1,0 +1,99 @@
+/*
+ * pyscf_amd.h - C ABI of libpyscf_amd.so (MI355X / gfx950 density-fitted Fock-build engine).
+ *
+ * Drop-in boundary: these are the entry points a PySCF maintainer would bind with ctypes in
+ * place of the reference's CPU entry points on the DF J/K hot path.  Every function
+ *   - is extern "C", takes plain pointers and sizes (no torch / C++ types),
+ *   - takes DEVICE pointers (d_ prefix) owned by the caller, plus the HIP stream to launch on
+ *     (hipStream_t passed as void*; NULL = default stream); launches are asynchronous,
+ *   - returns 0 on success or a negative error code (never exits); PAMD_last_error() gives the
+ *     message of the last failure in the calling thread.
+ *
+ * Reference interfaces replaced (paths relative to the reference tree pyscf/):
+ *   PAMD_int3c2e_class   lib/gto/fill_nr_3c.c:196-225 GTOnr3c_drv + :127-185 GTOnr3c_fill_s2ij
+ *                        (+ libcint int3c2e_sph), and lib/gto/fill_int2c.c GTOint2c (int2c2e_sph)
+ *   PAMD_int1e_ovlp_kin  lib/gto/fill_int2c.c GTOint2c with int1e_ovlp_sph / int1e_kin_sph
+ *   PAMD_cderi_solve     df/incore.py:204-213 (BLAS trsm), :216 (lib.dot, eig fallback)
+ *   PAMD_pack_dm_tril    df/df_jk.py:329-332 (lib.pack_tril + halved diagonal; lib/np_helper/pack_tril.c:59-112)
+ *   PAMD_df_vj_pass1/2   df/df_jk.py:367 `vj += dmtril.dot(eri1.T).dot(eri1)`
+ *   PAMD_nr_e2_symm      lib/ao2mo/nr_ao2mo.c:1240-1266 AO2MOnr_e2_drv with
+ *                        ftrans = AO2MOtranse2_nr_s2 (:1026-1031), fmmm = AO2MOmmm_bra_nr_s2 (:399-419)
+ *   PAMD_dgemm_tn        lib/np_helper/npdot.c:32 NPdgemm as used by lib.dot(buf1.T, buf1), df/df_jk.py:380,407
+ *   PAMD_unpack_tril     lib/np_helper/pack_tril.c:150-273 NPdunpack_tril_2d
+ *
+ * Array conventions (identical to the reference): cderi is (naux, nao_pair) row-major f64 with
+ * pq = p(p+1)/2+q, p >= q (df/df.py:59-72); density matrices are (nset, nao, nao) row-major f64.
+ */
+#ifndef PYSCF_AMD_H
+#define PYSCF_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char *PAMD_last_error(void);
+int PAMD_version(void);
+int PAMD_device_count(void);                 /* 0 when no HIP device / driver is present */
+int PAMD_set_device(int dev);
+int PAMD_stream_synchronize(void *stream);
+
+/* ---- integral generation -------------------------------------------------------------------- */
+/* Argument block of one (l_i >= l_j | l_k) class launch.  All pointers are device pointers. */
+typedef struct PAMD_int3c2e_args {
+    const int *pair_ish;        /* [npairs] shell a (l = l_i) of each shell pair                */
+    const int *pair_jsh;        /* [npairs] shell b (l = l_j)                                   */
+    const int *pair_pp0;        /* [npairs] first primitive-pair record                         */
+    const int *pair_npp;        /* [npairs] number of primitive-pair records                    */
+    const double *pp;           /* [][8]: zeta, Px,Py,Pz, K_ab c_a c_b, (P-A)x,(P-A)y,(P-A)z     */
+    const double *shell_xyz;    /* [nshell][3] centres of the segmented AO shells (Bohr)        */
+    const int *shell_ao0;       /* [nshell] first AO function of each shell                     */
+    const int *aux_f0;          /* [naux_cls] first aux function of each aux shell of class l_k */
+    const double *aux_xyz;      /* [naux_cls][3]                                                */
+    const double *aux_exp;      /* [naux_cls][npk]                                              */
+    const double *aux_coef;     /* [naux_cls][npk] (zero padded)                                */
+    int naux_cls;
+    int npk;
+    const double *rys_table;    /* device copy of the Rys Chebyshev table (PAMD_rys_table_upload) */
+    const double *c2s;          /* cart->sph matrices, c2s + c2s_off[l] = [(2l+1)][ncart(l)]     */
+    const int *c2s_off;
+    double *T;                  /* output T[row][aux function], leading dimension ldT            */
+    long ldT;
+    long row_offset;            /* subtracted from the packed-tril row index                     */
+    int tril;                   /* 1: rows = packed-tril AO pairs; 0: row = AO index (2-centre)  */
+    int npairs;
+} PAMD_int3c2e_args;
+
+long PAMD_rys_table_len(void);
+int PAMD_rys_table_upload(double *d_dst, void *stream);
+int PAMD_rys_table_host(double *h_dst, int *offsets, int *nint, double *herm_u, double *herm_w);
+int PAMD_int3c2e_class(int li, int lj, int lk, const PAMD_int3c2e_args *args, void *stream);
+int PAMD_int1e_ovlp_kin(const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,
+                        const double *d_xyz, const double *d_exps, const double *d_coefs, int nsh,
+                        int nao, const double *d_c2s, const int *d_c2s_off, double *d_S, double *d_K,
+                        void *stream);
+
+/* cderi[l_off + m][pq] = sum_Q linvT[Q][m] * T[pq][Q]   (m < nL; Q <= l_off + m when triangular) */
+int PAMD_cderi_solve(const double *d_linvT, int lda, const double *d_T, long ldT, double *d_cderi,
+                     long ldc, int nL, long npq, int naux, int l_off, int triangular, void *stream);
+
+/* ---- J/K contraction ------------------------------------------------------------------------ */
+int PAMD_pack_dm_tril(const double *d_dm, int nset, int nao, double *d_tril, void *stream);
+long PAMD_df_vj_pass1_worksize(long npair, int naux, int nset);           /* doubles of d_work */
+int PAMD_df_vj_pass1(const double *d_cderi, long npair, int naux, const double *d_dmtril, int nset,
+                     double *d_rho, double *d_work, void *stream);        /* rho[s][L] = B_L . dmtril_s */
+int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *d_rho, int nset,
+                     double *d_vjtril, void *stream);                     /* vjtril[s] += rho_s^T B  */
+int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
+                    int nocc_pad, double *d_out, int ldx, void *stream);  /* out[L][i][p]            */
+int PAMD_dgemm_tn(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc, int m,
+                  int n, long k, int lower_only, int nsplit, void *stream); /* C[s] += A^T B (k split s) */
+int PAMD_reduce_splits(const double *d_part, int nsplit, int m, int ldc, double *d_out, int ldo,
+                       int symmetrize, void *stream);
+int PAMD_unpack_tril(const double *d_tril, long npair, int count, int nao, double *d_full, int ld,
+                     int rows, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSCF_AMD_H */

@@ -573,3 +573,22 @@ void oracle_int1e(int type, double *out, const int *atm, int natm, const int *ba
     }
     free(loc);
 }
+
+/* NPdunpack_tril analogue (pyscf/lib/np_helper/pack_tril.c:150-273), hermitian fill, OpenMP
+ * over the leading index; used by the CPU-baseline leg so that the timed port does its unpack
+ * in C like the reference does (AO2MOtranse2_nr_s2, nr_ao2mo.c:1016-1031). */
+void oracle_unpack_tril(const double *tril, double *full, int count, int n)
+{
+    size_t npair = (size_t)n * (n + 1) / 2;
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < count; c++) {
+        const double *t = tril + c * npair;
+        double *f = full + (size_t)c * n * n;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j <= i; j++) {
+                double v = t[(size_t)i * (i + 1) / 2 + j];
+                f[(size_t)i * n + j] = v;
+                f[(size_t)j * n + i] = v;
+            }
+    }
+}

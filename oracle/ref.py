@@ -61,6 +61,11 @@ def unpack_tril(tril, filltriu=1):
     tril = np.asarray(tril)
     npair = tril.shape[-1]
     n = int((np.sqrt(8 * npair + 1) - 1) / 2)
+    if filltriu and tril.ndim == 2 and tril.dtype == np.float64 and tril.shape[0] * n * n > 1 << 22:
+        t = np.ascontiguousarray(tril)
+        out = np.empty((t.shape[0], n, n))
+        lib().oracle_unpack_tril(_p(t), _p(out), ctypes.c_int(t.shape[0]), ctypes.c_int(n))
+        return out
     idx = np.tril_indices(n)
     out = np.zeros(tril.shape[:-1] + (n, n))
     out[..., idx[0], idx[1]] = tril
@@ -165,12 +170,12 @@ def get_jk(cderi, dm, hermi=1, with_j=True, with_k=True, mo_coeff=None, mo_occ=N
             full = unpack_tril(eri1)                      # (blk, nao, nao)
             for k in range(nset):
                 if orbo is not None:
-                    buf1 = np.einsum('Lpq,qi->Lip', full, orbo[k], optimize=True)
-                    buf1 = buf1.reshape(-1, nao)
-                    vk[k] += buf1.T.dot(buf1)
+                    # dsymm per aux row (nr_ao2mo.c:399-419): buf1[L,i,p] = sum_q B_L[p,q] orbo[q,i]
+                    buf1 = np.matmul(np.ascontiguousarray(orbo[k].T)[None], full).reshape(-1, nao)
+                    vk[k] += buf1.T.dot(buf1)       # lib.dot / NPdgemm (df_jk.py:380)
                 else:
-                    buf1 = np.einsum('pij,jk->pki', full, dms[k], optimize=True)
-                    vk[k] += np.einsum('pki,pkj->ij', buf1, full, optimize=True)
+                    buf1 = np.matmul(np.ascontiguousarray(dms[k].T)[None], full)   # [p][k][i]
+                    vk[k] += buf1.reshape(-1, nao).T.dot(full.reshape(-1, nao))
     if with_j:
         vj = unpack_tril(vj, 1).reshape(shape)
     else:

@@ -113,6 +113,9 @@ constexpr int LDT = KB + 1;     // transposed tile [n][k], odd stride -> conflic
 // X[L][i][p] = sum_q Bsym_L[q][p] * orb[q][i]
 //   grid: x = p tile (128 cols), y = L, z = chunk of MT*16 orbitals
 //   MFMA roles: m = orbital i (A operand from orb), n = AO index p (B operand from cderi row)
+//   The packed row is read directly: tiles below the diagonal (q >= p) are row-contiguous,
+//   tiles above it are read through the transposed element row[p(p+1)/2+q] (q-contiguous) and
+//   kept transposed in LDS.  Next tile is prefetched into registers during the MFMA phase.
 template <int MT>
 __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
     const double *__restrict__ cderi, long npair, int nao, const double *__restrict__ orb, int ldo,
@@ -136,35 +139,50 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
         for (int b = 0; b < 2; b++) acc[a][b] = double4_t{0, 0, 0, 0};
 
     const int fk = lane >> 4, fn = lane & 15;
-    for (int q0 = 0; q0 < nao; q0 += KB) {
-        // ---- stage orbital tile: sA[k][i] = orb[q0+k][m0+i]
-        for (int e = tid; e < KB * MW; e += 256) {
-            int k = e / MW, i = e - k * MW;
-            int q = q0 + k;
-            sA[k * LDA + i] = (q < nao) ? orb[(long)q * ldo + m0 + i] : 0.0;
-        }
-        // ---- stage the symmetric cderi tile (rows q0..q0+KB-1, cols p0..p0+NT-1)
-        const bool below = (q0 >= p0 + NT - 1);        // every q >= every p : row-major reads
-        const bool above = (q0 + KB - 1 <= p0);        // every q <= every p : transposed reads
-        if (above) {
-            // element (q,p) = row[p(p+1)/2 + q]; contiguous in q.  LDS image sB[n][k]
-            for (int e = tid; e < NT * KB; e += 256) {
-                int n = e / KB, k = e - n * KB;
-                long p = p0 + n;
-                int q = q0 + k;
-                sB[n * LDT + k] = (p < nao && q < nao) ? row[p * (p + 1) / 2 + q] : 0.0;
-            }
+    const int sk = tid >> 4, sc = tid & 15;             // staging coordinates (row-major tiles)
+    const int tn = tid >> 1, tk = (tid & 1) * 8;        // staging coordinates (transposed tiles)
+    double ra[MT], rb[8];
+
+    auto tile_above = [&](int q0) { return q0 + KB - 1 <= p0; };
+    auto fetch = [&](int q0) {
+        const int q = q0 + sk;
+        const double *orow = orb + (long)q * ldo + m0 + sc;
+#pragma unroll
+        for (int j = 0; j < MT; j++) ra[j] = (q < nao) ? orow[16 * j] : 0.0;
+        if (tile_above(q0)) {
+            const long p = p0 + tn;
+            const double *src = row + p * (p + 1) / 2 + q0 + tk;
+#pragma unroll
+            for (int j = 0; j < 8; j++) rb[j] = (p < nao && q0 + tk + j < nao) ? src[j] : 0.0;
+        } else if (q0 >= p0 + NT - 1) {
+            const double *src = row + (long)q * (q + 1) / 2 + p0 + sc;
+#pragma unroll
+            for (int j = 0; j < 8; j++) rb[j] = (q < nao && p0 + sc + 16 * j < nao) ? src[16 * j] : 0.0;
         } else {
-            for (int e = tid; e < KB * NT; e += 256) {
-                int k = e / NT, n = e - k * NT;
-                long p = p0 + n, q = q0 + k;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const long p = p0 + sc + 16 * j, qq = q;
                 double v = 0.0;
-                if (p < nao && q < nao) v = (q >= p) ? row[q * (q + 1) / 2 + p] : row[p * (p + 1) / 2 + q];
-                sB[k * LDN + n] = v;
+                if (p < nao && qq < nao) v = (qq >= p) ? row[qq * (qq + 1) / 2 + p] : row[p * (p + 1) / 2 + qq];
+                rb[j] = v;
             }
         }
-        (void)below;
+    };
+
+    fetch(0);
+    for (int q0 = 0; q0 < nao; q0 += KB) {
+        const bool above = tile_above(q0);
+#pragma unroll
+        for (int j = 0; j < MT; j++) sA[sk * LDA + sc + 16 * j] = ra[j];
+        if (above) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) sB[tn * LDT + tk + j] = rb[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) sB[sk * LDN + sc + 16 * j] = rb[j];
+        }
         __syncthreads();
+        if (q0 + KB < nao) fetch(q0 + KB);
 #pragma unroll
         for (int kk = 0; kk < KB; kk += 4) {
             double bf[2];

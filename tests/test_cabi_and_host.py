@@ -1,0 +1,112 @@
+"""CPU-only: the C-ABI library loads and exports every symbol declared in include/pyscf_amd.h;
+host-side logic (Mole tables, aux selection, shard ranges, pair tables, c2s matrices)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.conftest import H2O, ROOT
+
+
+def test_header_symbols_exported():
+    from pyscf_amd import lib
+    so = lib.load_library()
+    hdr = open(os.path.join(ROOT, 'include', 'pyscf_amd.h')).read()
+    names = sorted(set(re.findall(r'\b(PAMD_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(so, n), 'missing symbol %s' % n
+    assert so.PAMD_version() >= 100
+    assert so.PAMD_device_count() >= 0            # no compute call without a GPU
+    assert so.PAMD_rys_table_len() == 28224
+
+
+def test_args_struct_matches_header():
+    from pyscf_amd.gto import moleintor
+    hdr = open(os.path.join(ROOT, 'include', 'pyscf_amd.h')).read()
+    body = hdr[hdr.index('typedef struct PAMD_int3c2e_args {'):hdr.index('} PAMD_int3c2e_args;')]
+    fields = re.findall(r'\b(\w+);', re.sub(r'/\*.*?\*/', '', body, flags=re.S))
+    assert fields == [f[0] for f in moleintor._Args._fields_]
+
+
+def test_no_cpu_fallback_without_device():
+    """The product path must fail loudly when no HIP device is present."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from pyscf_amd import gto, df
+    mol = gto.M(atom=H2O, basis='sto-3g')
+    with pytest.raises(RuntimeError):
+        df.DF(mol, 'weigend').build()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'pyscf_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(d, f)).read()
+                assert 'oracle' not in src.replace('test oracle', ''), os.path.join(d, f)
+
+
+def test_mole_tables_and_aux_selection():
+    from pyscf_amd import gto, df
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    assert (mol.nao, mol.nbas, mol.nelectron) == (24, 11, 10)
+    assert abs(mol.energy_nuc() - 9.188258417746113) < 1e-12
+    assert abs(gto.gto_norm(0, 1.0) - 2.5264751109842591) < 1e-14        # mole.py:127-157 docstring
+    # general contraction row kept as one bas row with nctr=2 (mole.py:986-1018)
+    assert tuple(mol._bas[0][[1, 2, 3]]) == (0, 8, 2)
+    assert df.make_auxmol(mol).nao == 116                                 # df/test/test_df.py:53
+    assert df.make_auxmol(mol, 'weigend').nao == 71
+    tz = gto.M(atom=H2O, basis='cc-pvtz')
+    assert tz.nao == 58 and df.make_auxmol(tz).nao == 139
+
+
+def test_shard_ranges_cover_and_balance():
+    from pyscf_amd.df import DF
+    for naux, world in [(4448, 8), (14848, 8), (71, 2), (5, 8), (4448, 1)]:
+        r = [DF.shard_range(naux, k, world) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == naux
+        assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+        sizes = [b - a for a, b in r]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_c2s_matrices_match_oracle_and_are_orthonormal():
+    from oracle import ref
+    from pyscf_amd.gto.moleintor import c2s_matrix
+    for l in range(5):
+        m = c2s_matrix(l)
+        nc = (l + 1) * (l + 2) // 2
+        o = np.zeros((2 * l + 1, nc))
+        ref.lib().oracle_c2s_matrix(ctypes.c_int(l), o.ctypes.data_as(ctypes.c_void_p))
+        assert np.abs(m - o).max() < 1e-14
+    d = c2s_matrix(2)           # d_xy = sqrt(15/4pi) xy, p order x,y,z
+    assert abs(d[0, 1] - 1.092548430592079070) < 1e-15
+    assert np.allclose(c2s_matrix(1), np.eye(3) * 0.488602511902919921)
+
+
+def test_pair_tables_host_side():
+    """Pair classes partition all significant shell pairs; row-shell slabs are contiguous."""
+    from pyscf_amd import gto, df
+    from pyscf_amd.gto.moleintor import IntEngine
+    mol = gto.M(atom=H2O, basis='cc-pvtz')
+    aux = df.make_auxmol(mol)
+    eng = IntEngine(mol, aux, 'cpu')
+    nsh = eng.ao.n
+    assert eng.ao.nao == 58 and nsh == 22         # O: 2 contracted s split -> segmented shells
+    tot = sum(pc.n for pc in eng.pair_classes())
+    assert tot == nsh * (nsh + 1) // 2            # nothing screened in one water molecule
+    for pc in eng.pair_classes():
+        assert np.all(np.diff(pc.rowshell) >= 0)
+        i0, i1 = pc.subrange(0, nsh)
+        assert (i0, i1) == (0, pc.n)
+        mid = nsh // 2
+        a0, a1 = pc.subrange(0, mid)
+        b0, b1 = pc.subrange(mid, nsh)
+        assert a0 == 0 and a1 == b0 and b1 == pc.n
+    r0, r1 = eng.slab_rows(0, nsh)
+    assert (r0, r1) == (0, 58 * 59 // 2)
