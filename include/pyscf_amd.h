@@ -20,6 +20,12 @@
  *                        ftrans = AO2MOtranse2_nr_s2 (:1026-1031), fmmm = AO2MOmmm_bra_nr_s2 (:399-419)
  *   PAMD_dgemm_tn        lib/np_helper/npdot.c:32 NPdgemm as used by lib.dot(buf1.T, buf1), df/df_jk.py:380,407
  *   PAMD_unpack_tril     lib/np_helper/pack_tril.c:150-273 NPdunpack_tril_2d
+ *   PAMD_becke_partition lib/dft/grid_basis.c:32-101 VXCgen_grid
+ *   PAMD_eval_ao         gto/eval_gto.py:31-144 -> lib/gto/grid_ao_drv.c:222-284,415-459 (GTOval_sph_deriv0/1)
+ *   PAMD_rho_from_mo/_dm dft/numint.py:116-469 eval_rho / eval_rho2 (VXCdot_ao_dm, VXCdcontract_rho)
+ *   PAMD_eval_xc         lib/dft/libxc_itrf.c:968-1024 LIBXC_eval_xc (+ libxc 7.1.2) and dft/xc_deriv.py:32-85
+ *   PAMD_scale_ao        dft/numint.py:803-834 (VXCdscale_ao_sparse, lib/dft/nr_numint_sparse.c:1103)
+ *   PAMD_dgemm_nt        dft/numint.py:836-874 (VXCdot_ao_ao_sparse, lib/dft/nr_numint_sparse.c:890-973)
  *
  * Array conventions (identical to the reference): cderi is (naux, nao_pair) row-major f64 with
  * pq = p(p+1)/2+q, p >= q (df/df.py:59-72); density matrices are (nset, nao, nao) row-major f64.
@@ -92,6 +98,32 @@ int PAMD_reduce_splits(const double *d_part, int nsplit, int m, int ldc, double 
                        int symmetrize, void *stream);
 int PAMD_unpack_tril(const double *d_tril, long npair, int count, int nao, double *d_full, int ld,
                      int rows, void *stream);
+
+int PAMD_set_tuning(const char *key, int value);      /* benchmarking switches, e.g. "glds" 0/1 */
+
+/* ---- DFT grid path -------------------------------------------------------------------------- */
+/* pbecke[natm][ngrids]: unnormalised Becke cell functions; radii table a[i][j] nullable */
+int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
+                         const double *d_radii_table, int natm, long ngrids, void *stream);
+/* ao[comp][nao][ldg] (grid index fastest), comp = 1 (deriv 0) or 4 (deriv 1), points [g0, g0+ng) */
+int PAMD_eval_ao(int deriv, const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,
+                 const double *d_xyz, const double *d_exps, const double *d_coefs, int nsh, int nao,
+                 const double *d_coords, long g0, long ng, const double *d_c2s, const int *d_c2s_off,
+                 double *d_ao, long ldg, void *stream);
+/* rho[4][ldg] (rho, grad) from c[comp][g][ldc] = ao_comp . C_occ, or from ao and c0 = D . ao0 */
+int PAMD_rho_from_mo(const double *d_c, long comp_stride, int ldc, int nocc, int ncomp, long ng,
+                     double *d_rho, long ldg, void *stream);
+int PAMD_rho_from_dm(const double *d_ao, const double *d_c0, int nao, long ldg, int ncomp, long ng,
+                     double *d_rho, void *stream);
+/* fac7: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C}.  wv[4][ldg] = w (vrho/2, 2 vsigma grad rho);
+ * d_acc[0] += sum w rho, d_acc[1] += sum w e_xc; d_exc nullable */
+int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double *d_weights, long ng,
+                 long ldg, double *d_wv, double *d_exc, double *d_acc, void *stream);
+int PAMD_scale_ao(const double *d_ao, const double *d_wv, int nao, long ldg, int ncomp, long ng,
+                  double *d_aow, void *stream);
+int PAMD_dgemm_nt(const double *d_A, long lda, const double *d_B, long ldb, double *d_C, int ldc, int m,
+                  int n, long k, int nsplit, void *stream);                /* C[s] += A B^T (k split s) */
+int PAMD_reduce_sym(const double *d_part, int nsplit, int m, int ldc, double *d_out, void *stream);
 
 #ifdef __cplusplus
 }

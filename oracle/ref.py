@@ -226,7 +226,7 @@ class CDIIS:
 
 
 def rhf_kernel(mol, get_veff, conv_tol=1e-10, max_cycle=60, dm0=None, h1e=None, s1e=None,
-               verbose=False):
+               verbose=False, e2_fn=None):
     """Minimal RHF loop with the reference's semantics (hf.py:49-241): core-Hamiltonian
     ('1e') initial guess unless dm0 is given, CDIIS from cycle 1, canonical
     orthogonalisation x_orth with threshold 1e-6 (hf.py:1363-1379), E = Tr(hD)+1/2 Tr(VD)+E_nuc.
@@ -257,8 +257,13 @@ def rhf_kernel(mol, get_veff, conv_tol=1e-10, max_cycle=60, dm0=None, h1e=None, 
     else:
         dm = dm0
         c = None
+    def etot(dm, vhf):
+        # HF: E = Tr(hD) + 1/2 Tr(VD) + Enuc;  KS: the caller supplies the two-electron energy
+        e2 = .5 * np.einsum('ij,ji', vhf, dm) if e2_fn is None else e2_fn()
+        return np.einsum('ij,ji', h1e, dm) + e2 + enuc
+
     vhf = get_veff(dm, c, mo_occ if c is not None else None)
-    e_tot = np.einsum('ij,ji', h1e, dm) + .5 * np.einsum('ij,ji', vhf, dm) + enuc
+    e_tot = etot(dm, vhf)
     diis = CDIIS()
     conv = False
     for cycle in range(max_cycle):
@@ -269,7 +274,7 @@ def rhf_kernel(mol, get_veff, conv_tol=1e-10, max_cycle=60, dm0=None, h1e=None, 
         dm = make_rdm1(c, mo_occ)
         vhf = get_veff(dm, c, mo_occ)
         e_last = e_tot
-        e_tot = np.einsum('ij,ji', h1e, dm) + .5 * np.einsum('ij,ji', vhf, dm) + enuc
+        e_tot = etot(dm, vhf)
         f = h1e + vhf
         g = c[:, mo_occ == 0].T.dot(f).dot(c[:, mo_occ > 0]) * 2
         ng = np.linalg.norm(g)

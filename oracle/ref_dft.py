@@ -1,0 +1,263 @@
+"""ORACLE (DFT part) - TEST INFRASTRUCTURE ONLY.
+
+CPU restatement of the XC grid path:
+* Becke partition            <- pyscf/lib/dft/grid_basis.c:32-101 (VXCgen_grid) in numpy
+* AO values on a grid        <- pyscf/lib/gto/grid_ao_drv.c:222-284, deriv1.c (GTOval_sph_deriv0/1) in numpy
+* nr_rks                     <- pyscf/dft/numint.py:1074-1190 (dense path)
+* XC functionals: the reference calls libxc 7.1.2 (not in tree, pyscf/lib/CMakeLists.txt:229-250).
+  Here the published energy expressions (Slater; VWN5 / VWN-RPA; B88; LYP) are written in sympy and
+  differentiated SYMBOLICALLY - independent of the forward-mode AD used by the HIP kernel.
+* RKS energy                 <- pyscf/dft/rks.py:37-142,228-258
+
+Parity status: PINNED through the reference's SCF energies (tests/test_oracle_dft_golden.py):
+LDA,VWN_RPA -76.01330948329084; B88,VWN -76.690247578608236; B3LYPG -76.384928891413438
+(pyscf/dft/test/test_h2o.py:95-115), DF B88,VWN -76.690346887915879 (:236-240), grid norms
+(pyscf/dft/test/test_grids.py:54-65).  Pointwise libxc values themselves are not available here.
+PBE is restated but has no golden in the reference tests: "parity unpinned" for PBE.
+"""
+import ctypes
+
+import numpy as np
+
+from . import ref
+
+# ----------------------------------------------------------------------------- grids
+
+
+def becke_partition(coords, atm_coords, radii_table):
+    """pbecke[natm][ngrids], original Becke cell functions (grid_basis.c:32-101)."""
+    natm = len(atm_coords)
+    d = np.linalg.norm(coords[None, :, :] - atm_coords[:, None, :], axis=2)   # [natm][ng]
+    pb = np.ones((natm, len(coords)))
+    for i in range(natm):
+        for j in range(i):
+            g = (d[i] - d[j]) / np.linalg.norm(atm_coords[i] - atm_coords[j])
+            if radii_table is not None:
+                g = g + radii_table[i, j] * (1 - g * g)
+            s = g
+            s = (3 - s * s) * s * .5
+            s = (3 - s * s) * s * .5
+            s = ((3 - s * s) * s * .5) * .5
+            pb[i] *= .5 - s
+            pb[j] *= .5 + s
+    return pb
+
+
+def build_grids(mol, atom_grid=None, radi_method=None, prune='nwchem', radii_adjust='treutler', level=3,
+                sort_grids=True, alignment=8):
+    """coords, weights (host).  Atomic (radial x Lebedev) tables come from the host-side generator
+    (pure numpy restatement of gen_grid.gen_atomic_grids, pinned by the grid-norm goldens); the
+    partition is done here in numpy."""
+    from pyscf_amd.dft import gen_grid, radi
+    prune_fn = {'nwchem': gen_grid.nwchem_prune, 'treutler': gen_grid.treutler_prune, None: None}[prune]
+    tab = gen_grid.gen_atomic_grids(mol, atom_grid or {}, radi_method or radi.treutler, level, prune_fn)
+    table = None
+    if radii_adjust == 'treutler':
+        table = radi.treutler_atomic_radii_adjust(mol, radi.BRAGG_RADII)
+    elif radii_adjust == 'becke':
+        table = radi.becke_atomic_radii_adjust(mol, radi.BRAGG_RADII)
+    atm = mol.atom_coords()
+    cs, ws = [], []
+    for ia in range(mol.natm):
+        c, vol = tab[mol.atom_symbol(ia)]
+        c = c + atm[ia]
+        pb = becke_partition(c, atm, table)
+        cs.append(c)
+        ws.append(vol * pb[ia] / pb.sum(axis=0))
+    coords, weights = np.vstack(cs), np.hstack(ws)
+    if sort_grids:
+        idx = gen_grid.arg_group_grids(mol, coords)
+        coords, weights = coords[idx], weights[idx]
+    if alignment > 1:
+        pad = (-len(weights)) % alignment
+        if pad:
+            coords = np.vstack([coords, np.repeat([[1e-4] * 3], pad, axis=0)])
+            weights = np.hstack([weights, np.zeros(pad)])
+    return coords, weights
+
+
+# ----------------------------------------------------------------------------- AO values
+def _cart_list(l):
+    return [(x, y, l - x - y) for x in range(l, -1, -1) for y in range(l - x, -1, -1)]
+
+
+def _c2s(l):
+    nc = (l + 1) * (l + 2) // 2
+    m = np.zeros((2 * l + 1, nc))
+    ref.lib().oracle_c2s_matrix(ctypes.c_int(l), m.ctypes.data_as(ctypes.c_void_p))
+    return m
+
+
+def eval_ao(mol, coords, deriv=0):
+    """(ngrids, nao) or (4, ngrids, nao) like numint.eval_ao (numint.py:51-114)."""
+    ng = len(coords)
+    nao = mol.nao_nr()
+    out = np.zeros((4 if deriv else 1, ng, nao))
+    loc = mol.ao_loc_nr()
+    for ib in range(mol.nbas):
+        l = mol.bas_angular(ib)
+        r = coords - mol.atom_coords()[mol.bas_atom(ib)]
+        r2 = np.einsum('ij,ij->i', r, r)
+        es = mol.bas_exp(ib)
+        cs = mol.bas_ctr_coeff_raw(ib)          # (nprim, nctr), normalised
+        ex = np.exp(-np.outer(r2, es))          # (ng, nprim)
+        rad = ex.dot(cs)                        # (ng, nctr)
+        rad1 = (ex * (-2 * es)).dot(cs)
+        carts = _cart_list(l)
+        x, y, z = r[:, 0], r[:, 1], r[:, 2]
+        poly = np.array([x ** a * y ** b * z ** c for a, b, c in carts])          # (nc, ng)
+        c2s = _c2s(l)
+        nctr = cs.shape[1]
+        for k in range(nctr):
+            p0 = loc[ib] + k * (2 * l + 1)
+            out[0, :, p0:p0 + 2 * l + 1] = (c2s.dot(poly) * rad[:, k]).T
+            if deriv:
+                for d in range(3):
+                    dp = []
+                    for (a, b, c) in carts:
+                        e = [a, b, c]
+                        t = np.array([x, y, z][d]) * (x ** a * y ** b * z ** c) * rad1[:, k]
+                        if e[d] > 0:
+                            e2 = list(e)
+                            e2[d] -= 1
+                            t = t + e[d] * (x ** e2[0] * y ** e2[1] * z ** e2[2]) * rad[:, k]
+                        dp.append(t)
+                    out[1 + d, :, p0:p0 + 2 * l + 1] = c2s.dot(np.array(dp)).T
+    return out[0] if deriv == 0 else out
+
+
+# ----------------------------------------------------------------------------- functionals (sympy)
+_FUNCS = None
+
+
+def _build_functionals():
+    import sympy as sp
+    rho, sigma = sp.symbols('rho sigma', positive=True)
+    pi = sp.pi
+    out = {}
+    out['slater'] = -sp.Rational(3, 4) * (3 / pi) ** sp.Rational(1, 3) * rho ** sp.Rational(4, 3)
+
+    def vwn(A, x0, b, c):
+        rs = (3 / (4 * pi * rho)) ** sp.Rational(1, 3)
+        x = sp.sqrt(rs)
+        Q = sp.sqrt(4 * c - b * b)
+        X = x * x + b * x + c
+        X0 = x0 * x0 + b * x0 + c
+        at = sp.atan(Q / (2 * x + b))
+        eps = A * (sp.log(x * x / X) + 2 * b / Q * at -
+                   b * x0 / X0 * (sp.log((x - x0) ** 2 / X) + 2 * (b + 2 * x0) / Q * at))
+        return rho * eps
+    out['vwn5'] = vwn(sp.Float('0.0310907', 20), sp.Float('-0.10498', 20), sp.Float('3.72744', 20),
+                      sp.Float('12.9352', 20))
+    out['vwnrpa'] = vwn(sp.Float('0.0310907', 20), sp.Float('-0.409286', 20), sp.Float('13.0720', 20),
+                        sp.Float('42.7198', 20))
+    # B88, closed shell
+    beta = sp.Float('0.0042', 20)
+    cx = sp.Rational(3, 2) * (3 / (4 * pi)) ** sp.Rational(1, 3)
+    rs_ = rho / 2
+    x = sp.sqrt(sigma / 4) / rs_ ** sp.Rational(4, 3)
+    out['b88'] = 2 * (-cx * rs_ ** sp.Rational(4, 3) -
+                      beta * rs_ ** sp.Rational(4, 3) * x * x / (1 + 6 * beta * x * sp.asinh(x)))
+    # LYP, closed shell (Miehlich, Savin, Stoll, Preuss, CPL 157, 200 (1989) eq. 2)
+    a, b, c, d = [sp.Float(v, 20) for v in ('0.04918', '0.132', '0.2533', '0.349')]
+    CF = sp.Rational(3, 10) * (3 * pi ** 2) ** sp.Rational(2, 3)
+    ra = rho / 2
+    gaa = sigma / 4
+    rm13 = rho ** sp.Rational(-1, 3)
+    den = 1 + d * rm13
+    omega = sp.exp(-c * rm13) / den * rho ** sp.Rational(-11, 3)
+    delta = c * rm13 + d * rm13 / den
+    t1 = -a * 4 / den * ra * ra / rho
+    br = (ra * ra * (2 ** sp.Rational(11, 3) * CF * 2 * ra ** sp.Rational(8, 3)
+                     + (sp.Rational(47, 18) - sp.Rational(7, 18) * delta) * sigma
+                     - (sp.Rational(5, 2) - delta / 18) * 2 * gaa
+                     - (delta - 11) / 9 * gaa)
+          - sp.Rational(2, 3) * rho ** 2 * sigma + 2 * (sp.Rational(2, 3) * rho ** 2 - ra ** 2) * gaa)
+    out['lyp'] = t1 - a * b * omega * br
+    # PBE (unpinned)
+    kappa, mu = sp.Float('0.804', 20), sp.Float('0.2195149727645171', 20)
+    kf = (3 * pi ** 2 * rho) ** sp.Rational(1, 3)
+    s2 = sigma / (4 * kf ** 2 * rho ** 2)
+    out['pbex'] = out['slater'] * (1 + kappa - kappa / (1 + mu / kappa * s2))
+    A, a1, b1, b2, b3, b4 = [sp.Float(v, 20) for v in ('0.0310907', '0.21370', '7.5957', '3.5876', '1.6382', '0.49294')]
+    rs = (3 / (4 * pi * rho)) ** sp.Rational(1, 3)
+    ec = -2 * A * (1 + a1 * rs) * sp.log(1 + 1 / (2 * A * (b1 * sp.sqrt(rs) + b2 * rs + b3 * rs ** sp.Rational(3, 2) + b4 * rs ** 2)))
+    betap, gamma = sp.Float('0.06672455060314922', 20), (1 - sp.log(2)) / pi ** 2
+    ks = sp.sqrt(4 * kf / pi)
+    t2 = sigma / (4 * ks ** 2 * rho ** 2)
+    Aa = betap / gamma / (sp.exp(-ec / gamma) - 1)
+    H = gamma * sp.log(1 + betap / gamma * t2 * (1 + Aa * t2) / (1 + Aa * t2 + Aa ** 2 * t2 ** 2))
+    out['pbec'] = rho * (ec + H)
+    fns = {}
+    for k, e in out.items():
+        fns[k] = (sp.lambdify((rho, sigma), e, 'numpy'), sp.lambdify((rho, sigma), sp.diff(e, rho), 'numpy'),
+                  sp.lambdify((rho, sigma), sp.diff(e, sigma), 'numpy'))
+    return fns
+
+
+_ORDER = ['slater', 'vwn5', 'vwnrpa', 'b88', 'lyp', 'pbex', 'pbec']
+
+
+def eval_xc(fac, rho, sigma):
+    """-> e (per volume), vrho, vsigma for component weights fac[7] (same order as the device)."""
+    global _FUNCS
+    if _FUNCS is None:
+        _FUNCS = _build_functionals()
+    e = np.zeros_like(rho)
+    vr = np.zeros_like(rho)
+    vs = np.zeros_like(rho)
+    ok = rho > 1e-14
+    r = rho[ok]
+    s = np.maximum(sigma[ok], 1e-300)
+    for w, name in zip(fac, _ORDER):
+        if w == 0:
+            continue
+        f, fr, fs = _FUNCS[name]
+        e[ok] += w * f(r, s)
+        vr[ok] += w * fr(r, s)
+        vs[ok] += w * fs(r, s) * np.ones_like(r)
+    return e, vr, vs
+
+
+def nr_rks(mol, coords, weights, fac, gga, dm):
+    """(nelec, excsum, vmat) - dense restatement of numint.nr_rks (numint.py:1116-1157)."""
+    dm = (dm + dm.T) * .5
+    if gga:
+        ao = eval_ao(mol, coords, 1)
+        c0 = ao[0].dot(dm)
+        rho = np.einsum('gi,gi->g', ao[0], c0)
+        grad = 2 * np.einsum('xgi,gi->xg', ao[1:], c0)
+        sigma = np.einsum('xg,xg->g', grad, grad)
+    else:
+        ao0 = eval_ao(mol, coords, 0)
+        ao = ao0[None]
+        rho = np.einsum('gi,ij,gj->g', ao0, dm, ao0)
+        sigma = np.zeros_like(rho)
+    e, vr, vs = eval_xc(fac, rho, sigma)
+    nelec = np.dot(weights, rho)
+    exc = np.dot(weights, e)
+    wv0 = .5 * weights * vr
+    aow = ao[0] * wv0[:, None]
+    if gga:
+        for d in range(3):
+            aow += ao[1 + d] * (2 * weights * vs * grad[d])[:, None]
+    m = ao[0].T.dot(aow)
+    return nelec, exc, m + m.T
+
+
+def rks_energy(mol, xc_fac, hyb, gga, coords, weights, get_jk, conv_tol=1e-10, verbose=False):
+    """RKS SCF with the oracle pieces.  get_jk(dm, c, occ, with_k) -> (vj, vk|None)."""
+    state = {}
+
+    def veff(dm, c, occ):
+        n, exc, vxc = nr_rks(mol, coords, weights, xc_fac, gga, dm)
+        vj, vk = get_jk(dm, c, occ, hyb != 0)
+        v = vxc + vj
+        e2 = .5 * np.einsum('ij,ji', dm, vj) + exc
+        if hyb != 0:
+            v = v - .5 * hyb * vk
+            e2 -= .25 * hyb * np.einsum('ij,ji', dm, vk)
+        state['e2'] = e2
+        state['nelec'] = n
+        return v
+    return ref.rhf_kernel(mol, veff, conv_tol=conv_tol, verbose=verbose, e2_fn=lambda: state['e2'])

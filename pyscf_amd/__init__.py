@@ -5,7 +5,7 @@ from . import lib, gto    # noqa: F401
 
 
 def __getattr__(name):
-    if name in ('df', 'scf'):
+    if name in ('df', 'scf', 'dft'):
         import importlib
         return importlib.import_module('.' + name, __name__)
     raise AttributeError(name)

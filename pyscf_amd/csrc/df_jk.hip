@@ -22,54 +22,69 @@ namespace {
 
 // ------------------------------------------------------------------------------------ J
 constexpr int J1_THREADS = 256;
-constexpr int J1_CHUNK = 8192;     // pq elements per workgroup (2 x 16B loads/thread x 8 iters)
 constexpr int MAX_NSET = 4;
 
+// v2: R aux rows per workgroup share one register copy of the dmtril chunk, so the L2 traffic
+// for dmtril drops R-fold and the kernel streams cderi at the HBM rate.
+constexpr int J1R = 16;            // aux rows per workgroup
+constexpr int J1E = 8;             // elements per thread per row
+constexpr int J1_CHUNK2 = J1_THREADS * J1E;
+
 template <int NSET>
-__global__ __launch_bounds__(J1_THREADS) void vj_pass1_kernel(
-    const double *__restrict__ cderi, long npair, const double *__restrict__ dmtril,
+__global__ __launch_bounds__(J1_THREADS) void vj_pass1_rows_kernel(
+    const double *__restrict__ cderi, long npair, int naux, const double *__restrict__ dmtril,
     double *__restrict__ partial, int nchunk)
 {
-    const int L = blockIdx.y;
     const int chunk = blockIdx.x;
-    const double *row = cderi + (long)L * npair;
-    long base = (long)chunk * J1_CHUNK;
-    double acc[NSET];
+    const int L0 = blockIdx.y * J1R;
+    const long base = (long)chunk * J1_CHUNK2 + threadIdx.x;
+    double d[NSET][J1E];
 #pragma unroll
-    for (int s = 0; s < NSET; s++) acc[s] = 0;
-    // npair may be odd: rows are only 8-byte aligned, use scalar 8-byte loads, 4 in flight
-#pragma unroll 4
-    for (int it = 0; it < J1_CHUNK / J1_THREADS; it++) {
-        long i = base + it * J1_THREADS + threadIdx.x;
-        if (i < npair) {
-            double b = __builtin_nontemporal_load(row + i);
+    for (int s = 0; s < NSET; s++)
 #pragma unroll
-            for (int s = 0; s < NSET; s++) acc[s] += b * dmtril[(long)s * npair + i];
+        for (int e = 0; e < J1E; e++) {
+            long i = base + e * J1_THREADS;
+            d[s][e] = (i < npair) ? dmtril[(long)s * npair + i] : 0.0;
+        }
+    __shared__ double red[J1R][NSET][J1_THREADS / 64];
+    const int nrow = (naux - L0 < J1R) ? naux - L0 : J1R;
+    for (int r = 0; r < nrow; r++) {
+        const double *row = cderi + (long)(L0 + r) * npair;
+        double b[J1E];
+#pragma unroll
+        for (int e = 0; e < J1E; e++) {
+            long i = base + e * J1_THREADS;
+            b[e] = (i < npair) ? __builtin_nontemporal_load(row + i) : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < NSET; s++) {
+            double v = 0;
+#pragma unroll
+            for (int e = 0; e < J1E; e++) v += b[e] * d[s][e];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) red[r][s][threadIdx.x >> 6] = v;
         }
     }
-    __shared__ double red[NSET][J1_THREADS / 64];
-#pragma unroll
-    for (int s = 0; s < NSET; s++) {
-        double v = acc[s];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0) red[s][threadIdx.x >> 6] = v;
-    }
     __syncthreads();
-    if (threadIdx.x < NSET) {
+    if (threadIdx.x < nrow * NSET) {
+        const int r = threadIdx.x / NSET, s = threadIdx.x - r * NSET;
         double v = 0;
-        for (int w = 0; w < J1_THREADS / 64; w++) v += red[threadIdx.x][w];
-        partial[((long)threadIdx.x * gridDim.y + L) * nchunk + chunk] = v;
+        for (int w = 0; w < J1_THREADS / 64; w++) v += red[r][s][w];
+        partial[((long)s * naux + L0 + r) * nchunk + chunk] = v;
     }
 }
 
 __global__ void vj_pass1_reduce_kernel(const double *__restrict__ partial, double *__restrict__ rho,
                                        int n, int nchunk)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;   // over nset*naux
+    // one wave per output element (fixed summation order -> deterministic)
+    int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // over nset*naux
     if (i >= n) return;
+    const int lane = threadIdx.x & 63;
     double v = 0;
-    for (int c = 0; c < nchunk; c++) v += partial[(long)i * nchunk + c];
-    rho[i] = v;
+    for (int c = lane; c < nchunk; c += 64) v += partial[(long)i * nchunk + c];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) rho[i] = v;
 }
 
 template <int NSET>
@@ -304,6 +319,91 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
         }
 }
 
+// LDS-DMA variant of gemm_tn: both panels are streamed HBM/L2 -> LDS with global_load_lds_dwordx4
+// (one 1 KiB wave-instruction = one 128-double panel row), double-buffered, one barrier per
+// k-tile, no staging VGPRs.  Requirements (checked by the launcher): lda, ldb even, 16-byte
+// aligned bases, every k range a multiple of KB, and 128 readable doubles from any row start
+// (edge tiles read past m/n inside the allocation; those columns are never stored).
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
+    const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
+    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n)
+{
+    __shared__ double sbuf[2][2][KB * LDN];     // [buffer][panel][k][col]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tm, tn;
+    if (lower_only) {
+        int t = blockIdx.x;
+        tm = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
+        while (tm * (tm + 1) / 2 > t) tm--;
+        tn = t - tm * (tm + 1) / 2;
+    } else {
+        tm = blockIdx.x / ntile_n;
+        tn = blockIdx.x - tm * ntile_n;
+    }
+    const int p0 = tm * NT, q0 = tn * NT;
+    const int nsplit = gridDim.y;
+    const long kchunk = ((kdim + nsplit - 1) / nsplit + KB - 1) / KB * KB;
+    const long kbeg = (long)blockIdx.y * kchunk;
+    const long kend = (kbeg + kchunk < kdim) ? kbeg + kchunk : kdim;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+
+    // wave w stages rows 4w..4w+3 of each panel: lane -> 2 doubles (16 B) of the row
+    auto stage = [&](long k0, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = wave * 4 + j;
+            const double *ga = A + (k0 + k) * lda + p0 + lane * 2;
+            const double *gb = B + (k0 + k) * ldb + q0 + lane * 2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ga,
+                                             (__attribute__((address_space(3))) void *)(&sbuf[buf][0][k * LDN]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gb,
+                                             (__attribute__((address_space(3))) void *)(&sbuf[buf][1][k * LDN]), 16, 0, 0);
+        }
+    };
+    int buf = 0;
+    if (kbeg < kend) stage(kbeg, 0);
+    for (long k0 = kbeg; k0 < kend; k0 += KB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k0 + KB < kend) stage(k0 + KB, buf ^ 1);
+        const double *sP = sbuf[buf][0], *sQ = sbuf[buf][1];
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = sP[(kk + fk) * LDN + wr * 64 + a * 16 + fn];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = sQ[(kk + fk) * LDN + wc * 64 + b * 16 + fn];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+        buf ^= 1;
+    }
+    double *out = C + (long)blockIdx.y * m * ldc;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int col = q0 + wc * 64 + b * 16 + fn;
+            if (col >= n) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int rowi = p0 + wr * 64 + a * 16 + fk + 4 * r;
+                if (rowi < m) out[(long)rowi * ldc + col] += acc[a][b][r];
+            }
+        }
+}
+
 // out[i][j] = sum_s part[s][i][j]  (i>=j when lower), mirrored to the upper triangle when sym
 __global__ void reduce_splits_kernel(const double *__restrict__ part, int nsplit, int m, int ldc,
                                      double *__restrict__ out, int ldo, int sym)
@@ -351,11 +451,20 @@ __global__ void pack_dm_kernel(const double *__restrict__ dm, int nao, double *_
 // ======================================================================================
 // C ABI
 // ======================================================================================
+static int g_use_glds = 1;
+
 extern "C" {
+
+// Runtime tuning switches (benchmarking aid): key "glds" = 0/1.
+int PAMD_set_tuning(const char *key, int value)
+{
+    if (strcmp(key, "glds") == 0) { g_use_glds = value; return 0; }
+    return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
+}
 
 long PAMD_df_vj_pass1_worksize(long npair, int naux, int nset)
 {
-    return (long)nset * naux * ceil_div(npair, J1_CHUNK);
+    return (long)nset * naux * ceil_div(npair, J1_CHUNK2);
 }
 
 int PAMD_df_vj_pass1(const double *d_cderi, long npair, int naux, const double *d_dmtril, int nset,
@@ -364,17 +473,17 @@ int PAMD_df_vj_pass1(const double *d_cderi, long npair, int naux, const double *
     PAMD_REQUIRE(nset >= 1 && nset <= MAX_NSET, "nset must be 1..4 per call");
     if (naux == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    int nchunk = ceil_div(npair, J1_CHUNK);
-    dim3 grid(nchunk, naux);
+    int nchunk = ceil_div(npair, J1_CHUNK2);
+    dim3 grid(nchunk, ceil_div(naux, J1R));
     switch (nset) {
-    case 1: vj_pass1_kernel<1><<<grid, J1_THREADS, 0, st>>>(d_cderi, npair, d_dmtril, d_work, nchunk); break;
-    case 2: vj_pass1_kernel<2><<<grid, J1_THREADS, 0, st>>>(d_cderi, npair, d_dmtril, d_work, nchunk); break;
-    case 3: vj_pass1_kernel<3><<<grid, J1_THREADS, 0, st>>>(d_cderi, npair, d_dmtril, d_work, nchunk); break;
-    default: vj_pass1_kernel<4><<<grid, J1_THREADS, 0, st>>>(d_cderi, npair, d_dmtril, d_work, nchunk); break;
+    case 1: vj_pass1_rows_kernel<1><<<grid, J1_THREADS, 0, st>>>(d_cderi, npair, naux, d_dmtril, d_work, nchunk); break;
+    case 2: vj_pass1_rows_kernel<2><<<grid, J1_THREADS, 0, st>>>(d_cderi, npair, naux, d_dmtril, d_work, nchunk); break;
+    case 3: vj_pass1_rows_kernel<3><<<grid, J1_THREADS, 0, st>>>(d_cderi, npair, naux, d_dmtril, d_work, nchunk); break;
+    default: vj_pass1_rows_kernel<4><<<grid, J1_THREADS, 0, st>>>(d_cderi, npair, naux, d_dmtril, d_work, nchunk); break;
     }
     PAMD_CHECK_LAUNCH();
     int n = nset * naux;
-    vj_pass1_reduce_kernel<<<ceil_div(n, 256), 256, 0, st>>>(d_work, d_rho, n, nchunk);
+    vj_pass1_reduce_kernel<<<ceil_div(n, 4), 256, 0, st>>>(d_work, d_rho, n, nchunk);
     PAMD_CHECK_LAUNCH();
     return 0;
 }
@@ -439,13 +548,21 @@ int PAMD_dgemm_tn(const double *d_A, int lda, const double *d_B, int ldb, double
                   int m, int n, long k, int lower_only, int nsplit, void *stream)
 {
     PAMD_REQUIRE(nsplit >= 1, "nsplit >= 1");
-    PAMD_REQUIRE(!lower_only || m == n, "lower_only needs a square result");
+    PAMD_REQUIRE(!(lower_only & 1) || m == n, "lower_only needs a square result");
     if (m == 0 || n == 0 || k == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int tm = ceil_div(m, NT), tn = ceil_div(n, NT);
-    int ntiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    int ntiles = (lower_only & 1) ? tm * (tm + 1) / 2 : tm * tn;
     dim3 grid(ntiles, nsplit);
-    gemm_tn_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only, tn);
+    // flags bit 1 (value 2): caller guarantees 128 readable doubles from every row start and
+    // k ranges that are multiples of 16 -> LDS-DMA kernel
+    const long kchunk = ((k + nsplit - 1) / nsplit + KB - 1) / KB * KB;
+    const bool aligned = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)d_A | (uintptr_t)d_B) % 16 == 0) &&
+                         (k % KB == 0) && (kchunk % KB == 0);
+    if ((lower_only & 2) && aligned && g_use_glds)
+        gemm_tn_glds_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn);
+    else
+        gemm_tn_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

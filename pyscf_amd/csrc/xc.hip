@@ -1,0 +1,419 @@
+// Exchange-correlation grid kernels (closed shell, LDA / GGA).
+//   PAMD_rho_from_mo      <- numint.eval_rho2 (pyscf/dft/numint.py:328-469): rho, grad rho from c = ao . C_occ
+//   PAMD_rho_from_dm      <- numint.eval_rho  (:116-225): rho, grad rho from ao and ao . D
+//   PAMD_eval_xc          <- LIBXC_eval_xc (pyscf/lib/dft/libxc_itrf.c:968-1024; libxc 7.1.2 is not in the
+//                            reference tree) + xc_deriv.transform_vxc (pyscf/dft/xc_deriv.py:32-85) + the
+//                            weighting of numint.nr_rks (:1132-1153).  Functionals are restated from
+//                            the literature and differentiated by forward-mode automatic differentiation
+//                            (dual numbers), not by hand:
+//                              Slater exchange; VWN5 and VWN-RPA correlation (Vosko, Wilk, Nusair 1980);
+//                              B88 exchange (Becke 1988); LYP correlation (Lee, Yang, Parr 1988 in the
+//                              Miehlich-Savin-Stoll-Preuss 1989 form); PBE exchange and correlation.
+//   PAMD_scale_ao         <- numint._scale_ao (:803-834 / VXCdscale_ao_sparse)
+//   PAMD_dgemm_nt         <- numint._dot_ao_ao (:836-874 / VXCdot_ao_ao_sparse): vmat = ao0 . aow^T
+#include "common.h"
+
+using namespace pamd;
+
+namespace {
+
+// ---------------------------------------------------------------------------- dual numbers
+struct Dual {            // value, d/d rho, d/d sigma
+    double v, r, s;
+};
+__device__ inline Dual mk(double v, double r = 0, double s = 0) { return Dual{v, r, s}; }
+__device__ inline Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.r + b.r, a.s + b.s}; }
+__device__ inline Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.r - b.r, a.s - b.s}; }
+__device__ inline Dual operator-(Dual a) { return {-a.v, -a.r, -a.s}; }
+__device__ inline Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.r * b.v + a.v * b.r, a.s * b.v + a.v * b.s}; }
+__device__ inline Dual operator/(Dual a, Dual b)
+{
+    double iv = 1.0 / b.v, q = a.v * iv;
+    return {q, (a.r - q * b.r) * iv, (a.s - q * b.s) * iv};
+}
+__device__ inline Dual operator+(Dual a, double b) { return {a.v + b, a.r, a.s}; }
+__device__ inline Dual operator+(double a, Dual b) { return {a + b.v, b.r, b.s}; }
+__device__ inline Dual operator-(Dual a, double b) { return {a.v - b, a.r, a.s}; }
+__device__ inline Dual operator-(double a, Dual b) { return {a - b.v, -b.r, -b.s}; }
+__device__ inline Dual operator*(Dual a, double b) { return {a.v * b, a.r * b, a.s * b}; }
+__device__ inline Dual operator*(double a, Dual b) { return b * a; }
+__device__ inline Dual operator/(Dual a, double b) { return a * (1.0 / b); }
+__device__ inline Dual operator/(double a, Dual b) { return mk(a) / b; }
+__device__ inline Dual chain(Dual a, double f, double df) { return {f, df * a.r, df * a.s}; }
+__device__ inline Dual dpow(Dual a, double p) { double f = pow(a.v, p); return chain(a, f, p * f / a.v); }
+__device__ inline Dual dsqrt(Dual a) { double f = sqrt(a.v); return chain(a, f, 0.5 / f); }
+__device__ inline Dual dlog(Dual a) { return chain(a, log(a.v), 1.0 / a.v); }
+__device__ inline Dual dexp(Dual a) { double f = exp(a.v); return chain(a, f, f); }
+__device__ inline Dual datan(Dual a) { return chain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+__device__ inline Dual dasinh(Dual a) { return chain(a, asinh(a.v), 1.0 / sqrt(1.0 + a.v * a.v)); }
+
+// ---------------------------------------------------------------------------- functionals
+// All return the energy density per unit volume e(rho, sigma) for a closed-shell density.
+constexpr double PI = 3.14159265358979323846;
+
+__device__ inline Dual slater_x(Dual rho)
+{
+    const double cx = 0.75 * 0.98474502184269654;     // (3/4)(3/pi)^(1/3)
+    return -cx * dpow(rho, 4.0 / 3.0);
+}
+
+// VWN paramagnetic correlation energy per particle; params (A, x0, b, c)
+__device__ inline Dual vwn_eps(Dual rho, double A, double x0, double b, double c)
+{
+    Dual rs = dpow(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
+    Dual x = dsqrt(rs);
+    const double Q = sqrt(4 * c - b * b);
+    Dual X = x * x + b * x + c;
+    const double X0 = x0 * x0 + b * x0 + c;
+    Dual at = datan(Q / (2.0 * x + b));
+    Dual t1 = dlog(x * x / X) + (2 * b / Q) * at;
+    Dual t2 = dlog((x - x0) * (x - x0) / X) + (2 * (b + 2 * x0) / Q) * at;
+    return A * (t1 - (b * x0 / X0) * t2);
+}
+__device__ inline Dual vwn5_c(Dual rho) { return rho * vwn_eps(rho, 0.0310907, -0.10498, 3.72744, 12.9352); }
+__device__ inline Dual vwnrpa_c(Dual rho) { return rho * vwn_eps(rho, 0.0310907, -0.409286, 13.0720, 42.7198); }
+
+// B88 exchange, spin-scaled to the closed-shell case (rho_s = rho/2, sigma_ss = sigma/4)
+__device__ inline Dual b88_x(Dual rho, Dual sigma)
+{
+    const double beta = 0.0042;
+    const double cx = 1.5 * 0.62035049089940001;      // (3/2)(3/(4 pi))^(1/3)
+    Dual rs = 0.5 * rho;
+    Dual r43 = dpow(rs, 4.0 / 3.0);
+    Dual g = dsqrt(0.25 * sigma + 1e-300);
+    Dual x = g / r43;
+    Dual e = -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * dasinh(x));
+    return 2.0 * e;
+}
+
+// LYP correlation, closed shell (Miehlich et al. form)
+__device__ inline Dual lyp_c(Dual rho, Dual sigma)
+{
+    const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349;
+    const double CF = 0.3 * 9.5707800006273392;       // (3/10)(3 pi^2)^(2/3)
+    Dual rm13 = dpow(rho, -1.0 / 3.0);
+    Dual den = 1.0 + d * rm13;
+    Dual omega = dexp(-c * rm13) / den * dpow(rho, -11.0 / 3.0);
+    Dual delta = c * rm13 + d * rm13 / den;
+    Dual ra = 0.5 * rho;                               // = rb
+    Dual saa = 0.25 * sigma;                           // |grad rho_a|^2 = |grad rho_b|^2, total sigma
+    Dual rab = ra * ra;
+    Dual t1 = -a * 4.0 / den * rab / rho;
+    Dual br = rab * (pow(2.0, 11.0 / 3.0) * CF * 2.0 * dpow(ra, 8.0 / 3.0)
+                     + (47.0 / 18.0 - 7.0 / 18.0 * delta) * sigma
+                     - (2.5 - delta / 18.0) * (2.0 * saa)
+                     - (delta - 11.0) / 9.0 * (saa))       // (ra/rho + rb/rho) saa = saa
+              - (2.0 / 3.0) * rho * rho * sigma
+              + 2.0 * ((2.0 / 3.0) * rho * rho - ra * ra) * saa;
+    return t1 - a * b * omega * br;
+}
+
+// PBE exchange (closed shell) and correlation (zeta = 0)
+__device__ inline Dual pbe_x(Dual rho, Dual sigma)
+{
+    const double kappa = 0.804, mu = 0.2195149727645171;
+    Dual ex_lda = slater_x(rho);
+    Dual kf = dpow(3.0 * PI * PI * rho, 1.0 / 3.0);
+    Dual s2 = sigma / (4.0 * kf * kf * rho * rho);
+    Dual fx = 1.0 + kappa - kappa / (1.0 + mu / kappa * s2);
+    return ex_lda * fx;
+}
+__device__ inline Dual pw92_eps(Dual rs)
+{   // PW92 paramagnetic, libxc "pw_mod" parameters
+    const double A = 0.0310907, a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
+    Dual srs = dsqrt(rs);
+    Dual q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
+    return -2.0 * A * (1.0 + a1 * rs) * dlog(1.0 + 1.0 / q);
+}
+__device__ inline Dual pbe_c(Dual rho, Dual sigma)
+{
+    const double beta = 0.06672455060314922, gamma = 0.031090690869654895;   // (1 - ln 2)/pi^2
+    Dual rs = dpow(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
+    Dual ec = pw92_eps(rs);
+    Dual kf = dpow(3.0 * PI * PI * rho, 1.0 / 3.0);
+    Dual ks = dsqrt(4.0 * kf / PI);
+    Dual t2 = sigma / (4.0 * ks * ks * rho * rho);
+    Dual Aa = beta / gamma / (dexp(-ec / gamma) - 1.0);
+    Dual num = 1.0 + Aa * t2;
+    Dual H = gamma * dlog(1.0 + beta / gamma * t2 * num / (1.0 + Aa * t2 + Aa * Aa * t2 * t2));
+    return rho * (ec + H);
+}
+
+enum { F_SLATER = 0, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC, F_NUM };
+
+struct XCSpec {
+    double fac[F_NUM];
+};
+
+// rho[4][ldg] (rho, dx, dy, dz; only row 0 used for LDA), weights[ng]
+// wv[4][ldg]: wv0 = 0.5 w vrho, wv1..3 = w 2 vsigma grad rho     (numint.py:1139-1153, xc_deriv.py:81-84)
+// acc[0] += sum w rho, acc[1] += sum w e
+__global__ __launch_bounds__(256) void eval_xc_kernel(XCSpec spec, int gga, const double *__restrict__ rho,
+                                                      const double *__restrict__ weights, long ng, long ldg,
+                                                      double *__restrict__ wv, double *__restrict__ exc_out,
+                                                      double *__restrict__ acc)
+{
+    long g = (long)blockIdx.x * 256 + threadIdx.x;
+    double nel = 0, exc = 0;
+    if (g < ng) {
+        const double r = rho[g];
+        const double w = weights[g];
+        double gxv = 0, gyv = 0, gzv = 0, sig = 0;
+        if (gga) {
+            gxv = rho[ldg + g]; gyv = rho[2 * ldg + g]; gzv = rho[3 * ldg + g];
+            sig = gxv * gxv + gyv * gyv + gzv * gzv;
+        }
+        double e = 0, vr = 0, vs = 0;
+        if (r > 1e-14) {
+            Dual dr = mk(r, 1, 0), ds = mk(sig, 0, 1);
+            Dual tot = mk(0);
+            if (spec.fac[F_SLATER] != 0) tot = tot + spec.fac[F_SLATER] * slater_x(dr);
+            if (spec.fac[F_VWN5] != 0) tot = tot + spec.fac[F_VWN5] * vwn5_c(dr);
+            if (spec.fac[F_VWNRPA] != 0) tot = tot + spec.fac[F_VWNRPA] * vwnrpa_c(dr);
+            if (spec.fac[F_B88] != 0) tot = tot + spec.fac[F_B88] * b88_x(dr, ds);
+            if (spec.fac[F_LYP] != 0) tot = tot + spec.fac[F_LYP] * lyp_c(dr, ds);
+            if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * pbe_x(dr, ds);
+            if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c(dr, ds);
+            e = tot.v; vr = tot.r; vs = tot.s;
+        }
+        nel = w * r;
+        exc = w * e;
+        wv[g] = 0.5 * w * vr;
+        if (gga) {
+            const double f = 2.0 * w * vs;
+            wv[ldg + g] = f * gxv; wv[2 * ldg + g] = f * gyv; wv[3 * ldg + g] = f * gzv;
+        }
+        if (exc_out) exc_out[g] = (r > 1e-14) ? e / r : 0.0;
+    }
+    for (int off = 32; off > 0; off >>= 1) { nel += __shfl_down(nel, off, 64); exc += __shfl_down(exc, off, 64); }
+    __shared__ double red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nel; red[1][threadIdx.x >> 6] = exc; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(acc + threadIdx.x, v);
+    }
+}
+
+// rho[c][g] from c[comp][g][ldc] = ao_comp . C_occ (rows g, nocc_pad columns; padded columns are zero)
+__global__ __launch_bounds__(256) void rho_from_mo_kernel(const double *__restrict__ c, long comp_stride, int ldc,
+                                                          int nocc, int ncomp, long ng, double *__restrict__ rho,
+                                                          long ldg)
+{
+    // one wave per grid point
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= ng) return;
+    const int lane = threadIdx.x & 63;
+    double s0 = 0, sx = 0, sy = 0, sz = 0;
+    for (int i = lane; i < nocc; i += 64) {
+        const double c0 = c[g * ldc + i];
+        s0 += c0 * c0;
+        if (ncomp == 4) {
+            sx += c0 * c[comp_stride + g * ldc + i];
+            sy += c0 * c[2 * comp_stride + g * ldc + i];
+            sz += c0 * c[3 * comp_stride + g * ldc + i];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64); sx += __shfl_down(sx, off, 64);
+        sy += __shfl_down(sy, off, 64); sz += __shfl_down(sz, off, 64);
+    }
+    if (lane == 0) {
+        rho[g] = s0;
+        if (ncomp == 4) { rho[ldg + g] = 2 * sx; rho[2 * ldg + g] = 2 * sy; rho[3 * ldg + g] = 2 * sz; }
+    }
+}
+
+// rho[g] = sum_mu ao0[mu][g] c0[mu][g];  grad = 2 sum_mu ao_x[mu][g] c0[mu][g]  (hermitian D; c0 = D ao0)
+__global__ __launch_bounds__(256) void rho_from_dm_kernel(const double *__restrict__ ao, const double *__restrict__ c0,
+                                                          int nao, long ldg, int ncomp, long ng,
+                                                          double *__restrict__ rho)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ng) return;
+    const long cs = (long)nao * ldg;
+    double s0 = 0, sx = 0, sy = 0, sz = 0;
+    for (int m = 0; m < nao; m++) {
+        const double c = c0[(long)m * ldg + g];
+        s0 += ao[(long)m * ldg + g] * c;
+        if (ncomp == 4) {
+            sx += ao[cs + (long)m * ldg + g] * c;
+            sy += ao[2 * cs + (long)m * ldg + g] * c;
+            sz += ao[3 * cs + (long)m * ldg + g] * c;
+        }
+    }
+    rho[g] = s0;
+    if (ncomp == 4) { rho[ldg + g] = 2 * sx; rho[2 * ldg + g] = 2 * sy; rho[3 * ldg + g] = 2 * sz; }
+}
+
+// aow[mu][g] = sum_c wv[c][g] ao[c][mu][g]
+__global__ __launch_bounds__(256) void scale_ao_kernel(const double *__restrict__ ao, const double *__restrict__ wv,
+                                                       int nao, long ldg, int ncomp, long ng, double *__restrict__ aow)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (g >= ldg) return;
+    double v = 0;
+    if (g < ng) {
+        const long cs = (long)nao * ldg;
+        v = wv[g] * ao[(long)m * ldg + g];
+        if (ncomp == 4)
+            v += wv[ldg + g] * ao[cs + (long)m * ldg + g] + wv[2 * ldg + g] * ao[2 * cs + (long)m * ldg + g] +
+                 wv[3 * ldg + g] * ao[3 * cs + (long)m * ldg + g];
+    }
+    aow[(long)m * ldg + g] = v;
+}
+
+// C[m][n] += sum_k A[m][k] B[n][k]   (both operands k-contiguous), split-K over gridDim.y
+constexpr int KB = 16, NT = 128, LDT = KB + 1;
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const double *__restrict__ A, long lda,
+                                                         const double *__restrict__ B, long ldb,
+                                                         double *__restrict__ C, int ldc, int m, int n, long kdim,
+                                                         int ntile_n)
+{
+    __shared__ double sA[NT * LDT];
+    __shared__ double sB[NT * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tm = blockIdx.x / ntile_n, tn = blockIdx.x - tm * ntile_n;
+    const int p0 = tm * NT, q0 = tn * NT;
+    const int nsplit = gridDim.y;
+    const long kchunk = ((kdim + nsplit - 1) / nsplit + KB - 1) / KB * KB;
+    const long kbeg = (long)blockIdx.y * kchunk;
+    const long kend = (kbeg + kchunk < kdim) ? kbeg + kchunk : kdim;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+    const int row = tid >> 1, kq = (tid & 1) * 8;       // each thread stages 8 consecutive k of one row
+    double pa[8], pb[8];
+    auto fetch = [&](long k0) {
+        const double *ga = A + (long)(p0 + row) * lda + k0 + kq;
+        const double *gb = B + (long)(q0 + row) * ldb + k0 + kq;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            pa[j] = (p0 + row < m && k0 + kq + j < kend) ? ga[j] : 0.0;
+            pb[j] = (q0 + row < n && k0 + kq + j < kend) ? gb[j] : 0.0;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (long k0 = kbeg; k0 < kend; k0 += KB) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            sA[row * LDT + kq + j] = pa[j];
+            sB[row * LDT + kq + j] = pb[j];
+        }
+        __syncthreads();
+        if (k0 + KB < kend) fetch(k0 + KB);
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = sA[(wr * 64 + a * 16 + fn) * LDT + kk + fk];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = sB[(wc * 64 + b * 16 + fn) * LDT + kk + fk];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+    double *out = C + (long)blockIdx.y * m * ldc;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int col = q0 + wc * 64 + b * 16 + fn;
+            if (col >= n) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int rowi = p0 + wr * 64 + a * 16 + fk + 4 * r;
+                if (rowi < m) out[(long)rowi * ldc + col] += acc[a][b][r];
+            }
+        }
+}
+
+// out[i][j] = sum_s (part[s][i][j] + part[s][j][i])     (vmat = M + M^T, numint.py:1157)
+__global__ void reduce_sym_kernel(const double *__restrict__ part, int nsplit, int m, int ldc,
+                                  double *__restrict__ out)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (j >= m) return;
+    double v = 0;
+    for (int s = 0; s < nsplit; s++)
+        v += part[((long)s * m + i) * ldc + j] + part[((long)s * m + j) * ldc + i];
+    out[(long)i * m + j] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+// spec: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C}; gga = 1 if any GGA term.
+// d_acc[0] += sum w rho (nelec), d_acc[1] += sum w e_xc.  d_exc (nullable): e_xc per particle.
+int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double *d_weights, long ng, long ldg,
+                 double *d_wv, double *d_exc, double *d_acc, void *stream)
+{
+    if (ng == 0) return 0;
+    XCSpec spec;
+    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
+    eval_xc_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho, d_weights, ng, ldg, d_wv,
+                                                                       d_exc, d_acc);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int PAMD_rho_from_mo(const double *d_c, long comp_stride, int ldc, int nocc, int ncomp, long ng, double *d_rho,
+                     long ldg, void *stream)
+{
+    if (ng == 0) return 0;
+    rho_from_mo_kernel<<<ceil_div(ng, 4), 256, 0, (hipStream_t)stream>>>(d_c, comp_stride, ldc, nocc, ncomp, ng,
+                                                                         d_rho, ldg);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int PAMD_rho_from_dm(const double *d_ao, const double *d_c0, int nao, long ldg, int ncomp, long ng, double *d_rho,
+                     void *stream)
+{
+    if (ng == 0) return 0;
+    rho_from_dm_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(d_ao, d_c0, nao, ldg, ncomp, ng, d_rho);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int PAMD_scale_ao(const double *d_ao, const double *d_wv, int nao, long ldg, int ncomp, long ng, double *d_aow,
+                  void *stream)
+{
+    if (ldg == 0) return 0;
+    dim3 grid(ceil_div(ldg, 256), nao);
+    scale_ao_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_ao, d_wv, nao, ldg, ncomp, ng, d_aow);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// C[s][m][ldc] += A[m][k] B[n][k]^T over the s-th k range
+int PAMD_dgemm_nt(const double *d_A, long lda, const double *d_B, long ldb, double *d_C, int ldc, int m, int n,
+                  long k, int nsplit, void *stream)
+{
+    if (m == 0 || n == 0 || k == 0) return 0;
+    int tm = ceil_div(m, NT), tn = ceil_div(n, NT);
+    dim3 grid(tm * tn, nsplit);
+    gemm_nt_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, tn);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int PAMD_reduce_sym(const double *d_part, int nsplit, int m, int ldc, double *d_out, void *stream)
+{
+    dim3 grid(ceil_div(m, 256), m);
+    reduce_sym_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_part, nsplit, m, ldc, d_out);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -67,7 +67,8 @@ class DF:
         n = int(np.prod(shape))
         buf = self._ws.get(name)
         if buf is None or buf.numel() < n or buf.device != self._cderi_dev.device:
-            buf = torch.empty(n, dtype=torch.float64, device=self._cderi_dev.device)
+            # +256 doubles of slack: the LDS-DMA GEMM reads whole 128-column panel rows
+            buf = torch.zeros(n + 256, dtype=torch.float64, device=self._cderi_dev.device)
             self._ws[name] = buf
         return buf[:n].view(*shape)
 

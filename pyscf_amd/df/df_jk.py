@@ -148,7 +148,7 @@ def _vk_mo(dfobj, lib, orb_list, nao):
             _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
                   _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(nocc_pad), _ptr(X), _c.c_int(ldx), st)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
-                  _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(1),
+                  _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(1 | 2),
                   _c.c_int(nsplit), st)
         _call(dfobj, 'reduce_splits', lib.PAMD_reduce_splits, _ptr(part), _c.c_int(nsplit), _c.c_int(nao),
               _c.c_int(nao), _ptr(vk), _c.c_int(nao), _c.c_int(1), st)
@@ -188,7 +188,7 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
                                                 _ptr(full), _c.c_int(ldx), _c.c_int(rows), st)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(full), _c.c_int(ldx), _ptr(part),
                                              _c.c_int(nao), _c.c_int(nao), _c.c_int(nao),
-                                             _c.c_long(nb * rows), _c.c_int(0), _c.c_int(nsplit), st)
+                                             _c.c_long(nb * rows), _c.c_int(0 | 2), _c.c_int(nsplit), st)
         _call(dfobj, 'reduce_splits', lib.PAMD_reduce_splits, _ptr(part), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
                                               _ptr(vk[k]), _c.c_int(nao), _c.c_int(0), st)
     return vk

@@ -1,0 +1,233 @@
+"""Numerical integration of the XC potential on the MI355X.
+
+Mirror of ``pyscf/dft/numint.py``: ``NumInt.nr_rks`` (:1074-1190), ``block_loop`` (:2887-2928),
+``eval_ao`` (:51-114), ``eval_rho``/``eval_rho2`` (:116-469), ``_scale_ao`` / ``_dot_ao_ao``
+(:803-874), ``rsh_and_hybrid_coeff`` (:2805-2828).  Per grid block, on the device:
+
+    ao   = PAMD_eval_ao              (comp, nao, ldg)          GTOval_sph_deriv0/1
+    c    = ao_comp^T-free GEMM       c[comp][g][i] = sum_mu ao[comp][mu][g] C_occ[mu][i]   (MO branch)
+    rho  = PAMD_rho_from_mo / _dm    rho, grad rho
+    wv   = PAMD_eval_xc              w * (vrho/2, 2 vsigma grad rho); nelec, exc accumulated
+    aow  = PAMD_scale_ao             sum_c wv_c ao_c
+    vmat+= PAMD_dgemm_nt             ao0 . aow^T ;  finally vmat = M + M^T
+
+AO values are recomputed per SCF iteration block by block (exp-bound, cheap next to the two
+GEMMs) instead of being stored; with several ranks the grid blocks are dealt round-robin and
+vmat / nelec / exc are all-reduced.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import lib as _lib_mod
+from . import libxc as _xc
+
+_c = ctypes
+
+
+def _ptr(t):
+    return _c.c_void_p(t.data_ptr())
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class NumInt:
+    """Duck-types the attributes RKS.get_veff uses (pyscf/dft/rks.py:76-131,384-404)."""
+    libxc = _xc
+    cutoff = 1e-13
+
+    def __init__(self, device=None, block_bytes=6 << 30, group=None):
+        self.device = device
+        self.block_bytes = block_bytes
+        self.group = group
+        self._cache = {}
+        self.kernel_timer = None
+
+    # -- functional properties --------------------------------------------------------------
+    def _xc_type(self, xc_code):
+        return _xc.xc_type(xc_code)
+
+    def hybrid_coeff(self, xc_code, spin=0):
+        return _xc.hybrid_coeff(xc_code)
+
+    def nlc_coeff(self, xc_code):
+        return ()
+
+    def rsh_coeff(self, xc_code):
+        return _xc.rsh_coeff(xc_code)
+
+    def rsh_and_hybrid_coeff(self, xc_code, spin=0):
+        omega, alpha, beta = self.rsh_coeff(xc_code)
+        return omega, alpha, self.hybrid_coeff(xc_code, spin)
+
+    # -- device plumbing ----------------------------------------------------------------------
+    def _dev(self):
+        import torch
+        if self.device is not None:
+            return torch.device(self.device)
+        if not torch.cuda.is_available():
+            raise RuntimeError('NumInt needs a HIP device (MI355X); there is no CPU fallback')
+        return torch.device('cuda', torch.cuda.current_device())
+
+    def _world(self):
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_rank(self.group), dist.get_world_size(self.group)
+        except ImportError:
+            pass
+        return 0, 1
+
+    def _shell_tables(self, mol, dev):
+        key = ('shells', id(mol))
+        if key not in self._cache:
+            from ..gto.moleintor import IntEngine, _dev
+            eng = IntEngine(mol, None, dev)
+            sh = eng.ao
+            prim0 = np.cumsum([0] + [len(e) for e in sh.exps])[:-1].astype(np.int32)
+            nprim = np.array([len(e) for e in sh.exps], np.int32)
+            self._cache[key] = dict(
+                eng=eng, nsh=sh.n, nao=sh.nao, l=_dev(sh.l, dev), ao0=_dev(sh.ao0, dev), prim0=_dev(prim0, dev),
+                nprim=_dev(nprim, dev), exps=_dev(np.concatenate(sh.exps), dev),
+                coefs=_dev(np.concatenate(sh.coefs), dev))
+        return self._cache[key]
+
+    def _grid_tables(self, grids, dev):
+        import torch
+        key = ('grids', id(grids), grids.size)
+        if key not in self._cache:
+            self._cache[key] = (torch.from_numpy(np.ascontiguousarray(grids.coords)).to(dev),
+                                torch.from_numpy(np.ascontiguousarray(grids.weights)).to(dev))
+        return self._cache[key]
+
+    def _call(self, name, fn, *args):
+        if self.kernel_timer is not None:
+            _lib_mod.check(self.kernel_timer.call(name, fn, *args))
+        else:
+            _lib_mod.check(fn(*args))
+
+    def eval_ao_block(self, mol, coords_dev, g0, ng, deriv, out, ldg):
+        """out[comp][nao][ldg] <- AO values (deriv=0: comp=1; deriv=1: comp=4) for grid points [g0,g0+ng)."""
+        import torch
+        lib = _lib_mod.load_library()
+        dev = coords_dev.device
+        t = self._shell_tables(mol, dev)
+        eng = t['eng']
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._call('eval_ao', lib.PAMD_eval_ao, _c.c_int(deriv), _ptr(t['l']), _ptr(t['ao0']), _ptr(t['prim0']),
+                   _ptr(t['nprim']), _ptr(eng.ao_xyz), _ptr(t['exps']), _ptr(t['coefs']), _c.c_int(t['nsh']),
+                   _c.c_int(t['nao']), _ptr(coords_dev), _c.c_long(g0), _c.c_long(ng), _ptr(eng.c2s),
+                   _ptr(eng.c2s_off), _ptr(out), _c.c_long(ldg), st)
+
+    def eval_ao(self, mol, coords, deriv=0):
+        """Host convenience (tests): returns (nao, ngrids) or (4, nao, ngrids) like the reference's
+        C-order buffer of GTOval_sph_deriv0/1 (eval_gto.py:123-127; transposed w.r.t. numint.eval_ao)."""
+        import torch
+        dev = self._dev()
+        c = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.float64)).to(dev)
+        ng = len(coords)
+        nao = self._shell_tables(mol, dev)['nao']
+        ncomp = 4 if deriv else 1
+        out = torch.zeros((ncomp, nao, ng), dtype=torch.float64, device=dev)
+        self.eval_ao_block(mol, c, 0, ng, deriv, out, ng)
+        out = out.cpu().numpy()
+        return out[0] if deriv == 0 else out
+
+    # -- the hot entry point ----------------------------------------------------------------------
+    def nr_rks(self, mol, grids, xc_code, dms, relativity=0, hermi=1, max_memory=2000, verbose=None):
+        """-> (nelec, excsum, vmat) with the contract of numint.nr_rks (numint.py:1074-1190)."""
+        import torch
+        lib = _lib_mod.load_library()
+        dev = self._dev()
+        if grids.coords is None:
+            grids.build()
+        hyb, fac = _xc.parse_xc(xc_code)
+        xctype = _xc.xc_type(xc_code)
+        dms_arr = np.asarray(dms)
+        nao = dms_arr.shape[-1]
+        shape = dms_arr.shape
+        dms2 = dms_arr.reshape(-1, nao, nao)
+        nset = len(dms2)
+        mo_coeff = getattr(dms, 'mo_coeff', None)
+        mo_occ = getattr(dms, 'mo_occ', None)
+        nelec = np.zeros(nset)
+        excsum = np.zeros(nset)
+        vmat = np.zeros((nset, nao, nao))
+        if xctype == 'HF':
+            return (nelec[0], excsum[0], vmat[0]) if dms_arr.ndim == 2 else (nelec, excsum, vmat)
+        gga = 1 if xctype == 'GGA' else 0
+        ncomp = 4 if gga else 1
+        coords_dev, weights_dev = self._grid_tables(grids, dev)
+        ngrids = grids.size
+        blk = int(self.block_bytes // (ncomp * nao * 8))
+        blk = max(256, min(_round_up(ngrids, 256), blk // 256 * 256))
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        f64 = torch.float64
+        ao = torch.empty((ncomp, nao, blk), dtype=f64, device=dev)
+        aow = torch.empty((nao, blk), dtype=f64, device=dev)
+        rho = torch.empty((4, blk), dtype=f64, device=dev)
+        wv = torch.empty((4, blk), dtype=f64, device=dev)
+        nsplit = 4
+        rank, world = self._world()
+        fac_c = (ctypes.c_double * 7)(*fac)
+        for iset in range(nset):
+            use_mo = mo_coeff is not None and np.ndim(mo_occ) == 1 and nset == 1
+            if use_mo:
+                occ = np.asarray(mo_occ)
+                orbo = np.asarray(mo_coeff)[:, occ > 0] * np.sqrt(occ[occ > 0])
+                nocc = orbo.shape[1]
+                nocc_pad = _round_up(max(nocc, 1), 16)
+                orb_h = np.zeros((nao, nocc_pad))
+                orb_h[:, :nocc] = orbo
+                orb = torch.from_numpy(orb_h).to(dev)
+                cmo = torch.empty((ncomp, blk, nocc_pad), dtype=f64, device=dev)
+            else:
+                d = dms2[iset]
+                dsym = torch.from_numpy(np.ascontiguousarray((d + d.T) * .5)).to(dev)
+                c0 = torch.empty((nao, blk), dtype=f64, device=dev)
+            part = torch.zeros((nsplit, nao, nao), dtype=f64, device=dev)
+            acc = torch.zeros(2, dtype=f64, device=dev)
+            for ib, g0 in enumerate(range(0, ngrids, blk)):
+                if ib % world != rank:
+                    continue
+                ng = min(blk, ngrids - g0)
+                self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk)
+                if use_mo:
+                    cmo.zero_()
+                    for c in range(ncomp):
+                        self._call('ao_dot_mo', lib.PAMD_dgemm_tn, _ptr(ao[c]), _c.c_int(blk), _ptr(orb),
+                                   _c.c_int(nocc_pad), _ptr(cmo[c]), _c.c_int(nocc_pad), _c.c_int(ng),
+                                   _c.c_int(nocc_pad), _c.c_long(nao), _c.c_int(0), _c.c_int(1), st)
+                    self._call('rho', lib.PAMD_rho_from_mo, _ptr(cmo), _c.c_long(blk * nocc_pad), _c.c_int(nocc_pad),
+                               _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho), _c.c_long(blk), st)
+                else:
+                    c0.zero_()
+                    self._call('dm_dot_ao', lib.PAMD_dgemm_tn, _ptr(dsym), _c.c_int(nao), _ptr(ao[0]), _c.c_int(blk),
+                               _ptr(c0), _c.c_int(blk), _c.c_int(nao), _c.c_int(ng), _c.c_long(nao), _c.c_int(0),
+                               _c.c_int(1), st)
+                    self._call('rho', lib.PAMD_rho_from_dm, _ptr(ao), _ptr(c0), _c.c_int(nao), _c.c_long(blk),
+                               _c.c_int(ncomp), _c.c_long(ng), _ptr(rho), st)
+                self._call('eval_xc', lib.PAMD_eval_xc, fac_c, _c.c_int(gga), _ptr(rho), _ptr(weights_dev[g0:g0 + ng]),
+                           _c.c_long(ng), _c.c_long(blk), _ptr(wv), _c.c_void_p(0), _ptr(acc), st)
+                self._call('scale_ao', lib.PAMD_scale_ao, _ptr(ao), _ptr(wv), _c.c_int(nao), _c.c_long(blk),
+                           _c.c_int(ncomp), _c.c_long(ng), _ptr(aow), st)
+                self._call('ao_dot_aow', lib.PAMD_dgemm_nt, _ptr(ao[0]), _c.c_long(blk), _ptr(aow), _c.c_long(blk),
+                           _ptr(part), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(ng), _c.c_int(nsplit), st)
+            v = torch.empty((nao, nao), dtype=f64, device=dev)
+            self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(part), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
+                       _ptr(v), st)
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(v, group=self.group)
+                dist.all_reduce(acc, group=self.group)
+            a = acc.cpu().numpy()
+            nelec[iset], excsum[iset] = a[0], a[1]
+            vmat[iset] = v.cpu().numpy()
+        if dms_arr.ndim == 2:
+            return nelec[0], excsum[0], vmat[0]
+        return nelec, excsum, vmat.reshape(shape)
+
+    def nr_uks(self, *args, **kwargs):
+        raise NotImplementedError('nr_uks: SURVEY.md §8f row 4')

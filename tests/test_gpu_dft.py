@@ -1,0 +1,116 @@
+"""GPU parity of the XC grid path (grids, AO values, nr_rks, DF-RKS energies) vs the CPU oracle
+and the reference's golden values."""
+import numpy as np
+import pytest
+
+from oracle import ref, ref_dft
+from tests.conftest import H2O
+
+pytestmark = pytest.mark.gpu
+
+LOWSYM = 'O 0.1 -0.2 0.05; C 0.25 0.4 1.15; H 0.95 -0.3 -0.35'
+ATOM_GRID = {'H': (50, 194), 'O': (50, 194)}
+
+
+def test_golden_grid_norms_and_becke_vs_oracle():
+    """pyscf/dft/test/test_grids.py:54-65."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import radi
+    mol = gto.M(atom=H2O, basis='6-31g')
+    g = dft.Grids(mol)
+    g.prune = None
+    g.radi_method = radi.gauss_chebyshev
+    g.radii_adjust = radi.becke_atomic_radii_adjust
+    g.alignment = 0
+    g.atom_grid = {'H': (10, 50), 'O': (10, 50)}
+    g.build()
+    assert abs(np.linalg.norm(g.coords) - 185.91245945279027) < 1e-9
+    assert abs(np.linalg.norm(g.weights) - 1720.1317185648893) < 1e-8
+    # default scheme (Treutler radial + adjust, NWChem pruning, level 3) vs the numpy partition
+    g2 = dft.Grids(mol).build()
+    c, w = ref_dft.build_grids(mol)
+    assert g2.size == len(w) and g2.size % 8 == 0
+    assert np.abs(g2.coords - c).max() < 1e-12
+    assert np.abs(g2.weights - w).max() < 1e-11 * np.abs(w).max()
+
+
+@pytest.mark.parametrize('basis', ['cc-pvtz', '6-31g'])
+def test_eval_ao_vs_oracle(basis):
+    from pyscf_amd import gto, dft
+    mol = gto.M(atom=LOWSYM, basis=basis, spin=1)
+    rng = np.random.default_rng(5)
+    coords = rng.uniform(-4, 5, (333, 3))
+    coords[0] = mol.atom_coords()[0]                  # a point on a nucleus
+    ni = dft.NumInt()
+    ao = ni.eval_ao(mol, coords, deriv=1)             # (4, nao, ng)
+    want = ref_dft.eval_ao(mol, coords, deriv=1)      # (4, ng, nao)
+    assert np.abs(ao.transpose(0, 2, 1) - want).max() < 1e-12 * max(1, np.abs(want).max())
+    ao0 = ni.eval_ao(mol, coords, deriv=0)
+    assert np.abs(ao0.T - want[0]).max() < 1e-12 * max(1, np.abs(want).max())
+
+
+@pytest.mark.parametrize('xc', ['lda,vwn', 'lda,vwn_rpa', 'b88,vwn', 'b88,lyp', 'b3lyp', 'pbe,pbe'])
+def test_nr_rks_vs_oracle(xc):
+    from pyscf_amd import gto, dft, lib
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    grids = dft.Grids(mol)
+    grids.atom_grid = (30, 110)
+    grids.build()
+    hyb, fac = libxc.parse_xc(xc)
+    gga = libxc.xc_type(xc) == 'GGA'
+    rng = np.random.default_rng(11)
+    c = np.linalg.qr(rng.standard_normal((mol.nao, mol.nao)))[0] * 0.7
+    occ = np.zeros(mol.nao)
+    occ[:5] = 2
+    dm = (c * occ).dot(c.T)
+    n0, e0, v0 = ref_dft.nr_rks(mol, grids.coords, grids.weights, fac, gga, dm)
+    ni = dft.NumInt()
+    n1, e1, v1 = ni.nr_rks(mol, grids, xc, dm)                                   # general-DM branch
+    n2, e2, v2 = ni.nr_rks(mol, grids, xc, lib.tag_array(dm, mo_coeff=c, mo_occ=occ))   # MO branch
+    for n, e, v in ((n1, e1, v1), (n2, e2, v2)):
+        assert abs(n - n0) < 1e-10 * abs(n0)
+        assert abs(e - e0) < 1e-10 * abs(e0)
+        assert np.abs(v - v0).max() < 1e-9 * max(1.0, np.abs(v0).max())
+    # several small blocks must give the same result as one block
+    ni2 = dft.NumInt(block_bytes=4 * mol.nao * 8 * 1024)
+    n3, e3, v3 = ni2.nr_rks(mol, grids, xc, dm)
+    assert abs(e3 - e0) < 1e-10 * abs(e0) and np.abs(v3 - v0).max() < 1e-9 * max(1.0, np.abs(v0).max())
+
+
+def test_golden_df_rks_energy():
+    """DF-RKS B88,VWN / 6-31G / 'weigend': -76.690346887915879 (pyscf/dft/test/test_h2o.py:236-240)."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import radi, gen_grid
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False            # test_h2o.py:86-89
+    try:
+        mol = gto.M(atom=H2O, basis='6-31g')
+        mf = dft.RKS(mol).density_fit(auxbasis='weigend')
+        mf.grids.prune = gen_grid.treutler_prune
+        mf.grids.atom_grid = ATOM_GRID
+        mf.xc = 'b88, vwn'
+        mf.conv_tol = 1e-10
+        e = mf.kernel()
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    assert mf.converged and abs(e - -76.690346887915879) < 1e-8, e
+
+
+def test_df_rks_b3lyp_vs_oracle():
+    """Config-3 functional on a small case: DF-RKS B3LYP cc-pVDZ / cc-pvdz-jkfit, level-3 grid."""
+    from pyscf_amd import gto, dft, df
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    mf = dft.RKS(mol, xc='b3lyp').density_fit()
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    assert mf.converged
+    cderi = ref.cholesky_eri(mol, df.make_auxmol(mol, 'cc-pvdz-jkfit'))
+    coords, weights = ref_dft.build_grids(mol)
+    hyb, fac = libxc.parse_xc('b3lyp')
+
+    def get_jk(dm, c, occ, with_k):
+        return ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
+    conv, e0 = ref_dft.rks_energy(mol, fac, hyb, True, coords, weights, get_jk)[:2]
+    assert conv and abs(e - e0) < 1e-8, (e, e0)

@@ -1,0 +1,66 @@
+"""Pins the DFT part of the CPU oracle (oracle/ref_dft.py) to the reference's known-answer tests
+(pyscf/dft/test/test_h2o.py:86-115,236-240 - note ATOM_SPECIFIC_TREUTLER_GRIDS=False there)."""
+import numpy as np
+import pytest
+
+from oracle import ref, ref_dft
+from tests.conftest import H2O
+
+ATOM_GRID = {'H': (50, 194), 'O': (50, 194)}
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from pyscf_amd import gto
+    from pyscf_amd.dft import radi
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
+    mol = gto.M(atom=H2O, basis='6-31g')
+    coords, weights = ref_dft.build_grids(mol, ATOM_GRID, prune='treutler')
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    eri = ref.int2e(mol)
+    return mol, coords, weights, eri
+
+
+def _exact_jk(eri):
+    def get_jk(dm, c, occ, with_k):
+        vj, vk = ref.get_jk_exact(eri, dm)
+        return vj, (vk if with_k else None)
+    return get_jk
+
+
+@pytest.mark.parametrize('xc,e_ref', [('lda,vwn_rpa', -76.01330948329084), ('b88,vwn', -76.690247578608236),
+                                      ('b3lypg', -76.384928891413438)])
+def test_rks_energies_exact_jk(setup, xc, e_ref):
+    from pyscf_amd.dft import libxc
+    mol, coords, weights, eri = setup
+    hyb, fac = libxc.parse_xc(xc)
+    gga = libxc.xc_type(xc) == 'GGA'
+    conv, e = ref_dft.rks_energy(mol, fac, hyb, gga, coords, weights, _exact_jk(eri))[:2]
+    assert conv and abs(e - e_ref) < 2e-8, (xc, e, e_ref)
+
+
+def test_df_rks_b88vwn(setup):
+    """DF-RKS B88,VWN with the 'weigend' fitting basis: -76.690346887915879 (test_h2o.py:236-240)."""
+    from pyscf_amd import df
+    from pyscf_amd.dft import libxc
+    mol, coords, weights, _ = setup
+    cderi = ref.cholesky_eri(mol, df.make_auxmol(mol, 'weigend'))
+
+    def get_jk(dm, c, occ, with_k):
+        return ref.get_jk(cderi, dm, 1, with_k=False)
+    hyb, fac = libxc.parse_xc('b88,vwn')
+    conv, e = ref_dft.rks_energy(mol, fac, hyb, True, coords, weights, get_jk)[:2]
+    assert conv and abs(e - -76.690346887915879) < 2e-8, e
+
+
+def test_grid_norms():
+    """pyscf/dft/test/test_grids.py:54-65: gauss_chebyshev radial, no pruning, Becke radii adjust,
+    (10, 50) grids, alignment 0: |coords| = 185.91245945279027, |weights| = 1720.1317185648893."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import radi
+    mol = gto.M(atom=H2O, basis='6-31g')
+    c, w = ref_dft.build_grids(mol, {'H': (10, 50), 'O': (10, 50)}, radi_method=radi.gauss_chebyshev, prune=None,
+                               radii_adjust='becke', alignment=0)
+    assert abs(np.linalg.norm(c) - 185.91245945279027) < 1e-9
+    assert abs(np.linalg.norm(w) - 1720.1317185648893) < 1e-8

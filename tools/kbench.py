@@ -1,0 +1,65 @@
+"""Kernel micro-benchmark on a synthetic (random) cderi of a given size - no integral build.
+    python tools/kbench.py [--nao 1856 --naux 4448 --nocc 160 --steps 3]
+Prints per-kernel ms and rates (HIP events on the launch stream)."""
+import argparse, os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from pyscf_amd import df
+from pyscf_amd.df import df_jk
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--nao', type=int, default=1856)
+ap.add_argument('--naux', type=int, default=4448)
+ap.add_argument('--nocc', type=int, default=160)
+ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--tag', default='')
+a = ap.parse_args()
+dev = torch.device('cuda', 0)
+npair = a.nao * (a.nao + 1) // 2
+obj = df.DF(None)
+g = torch.Generator(device=dev); g.manual_seed(1)
+obj._cderi_dev = torch.empty((a.naux, npair), dtype=torch.float64, device=dev)
+for b0 in range(0, a.naux, 256):
+    obj._cderi_dev[b0:b0 + 256].normal_(generator=g)
+obj._cderi_dev.mul_(1.0 / np.sqrt(a.nao))
+obj._naux = a.naux
+rng = np.random.default_rng(1)
+c = np.linalg.qr(rng.standard_normal((a.nao, a.nocc)))[0] * np.sqrt(2.0)
+dm = c.dot(c.T)
+dms = torch.from_numpy(dm[None]).to(dev)
+orb = [df_jk.pad_orbitals(c, dev)]
+df_jk.get_jk_device(obj, dms, orb)
+torch.cuda.synchronize()
+obj.kernel_timer = df_jk.KernelTimer()
+for _ in range(a.steps):
+    vj, vk = df_jk.get_jk_device(obj, dms, orb)
+s = obj.kernel_timer.summary()
+fl = 2.0 * a.naux * a.nao * a.nao * a.nocc
+by = 8.0 * a.naux * npair
+out = {'tag': a.tag, 'total_ms': round(sum(t for t, _ in s.values()) / a.steps, 2)}
+for k, (t, n) in s.items():
+    ms = t / a.steps
+    out[k] = round(ms, 3)
+    if k in ('e2_symm', 'dgemm_tn'):
+        out[k + '_TF'] = round(fl / ms / 1e9, 1)
+    if k.startswith('vj_pass'):
+        out[k + '_GBs'] = round(by / ms / 1e6, 0)
+# cheap correctness probe on a few entries (fp64 reference on device for 32 aux rows)
+sub = obj._cderi_dev[:32]
+idx = torch.tril_indices(a.nao, a.nao, device=dev)
+full = torch.zeros((32, a.nao, a.nao), dtype=torch.float64, device=dev)
+full[:, idx[0], idx[1]] = sub
+full = full + full.transpose(1, 2) - torch.diag_embed(torch.diagonal(full, dim1=1, dim2=2))
+o2 = df.DF(None); o2._cderi_dev = sub
+vj2, vk2 = df_jk.get_jk_device(o2, dms, orb)
+cd = torch.from_numpy(c).to(dev)
+xx = torch.matmul(full, cd)                         # [L][p][i]
+vk_ref = torch.einsum('Lpi,Lqi->pq', xx, xx)
+rho = torch.einsum('Lpq,pq->L', full, dms[0])
+vj_ref = torch.einsum('L,Lpq->pq', rho, full)
+vj_full = torch.zeros((a.nao, a.nao), dtype=torch.float64, device=dev)
+vj_full[idx[0], idx[1]] = vj2[0]
+out['err_vk'] = float((vk2[0] - vk_ref).abs().max() / vk_ref.abs().max())
+out['err_vj'] = float((vj_full.tril() - vj_ref.tril()).abs().max() / vj_ref.abs().max())
+print(json.dumps(out))
