@@ -92,6 +92,9 @@ int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *
                      double *d_vjtril, void *stream);                     /* vjtril[s] += rho_s^T B  */
 int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
                     int nocc_pad, double *d_out, int ldx, void *stream);  /* out[L][i][p]            */
+/* out[y][i][n] = sum_k src_y[n][k] orb[k][i] (plain-operand mode of the e2_symm MFMA kernel) */
+int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, long nrows, int kdim,
+                      const double *d_orb, int ldo, int nocc_pad, double *d_out, long ldout, void *stream);
 int PAMD_dgemm_tn(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc, int m,
                   int n, long k, int lower_only, int nsplit, void *stream); /* C[s] += A^T B (k split s) */
 int PAMD_reduce_splits(const double *d_part, int nsplit, int m, int ldc, double *d_out, int ldo,
@@ -105,22 +108,24 @@ int PAMD_set_tuning(const char *key, int value);      /* benchmarking switches, 
 /* pbecke[natm][ngrids]: unnormalised Becke cell functions; radii table a[i][j] nullable */
 int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
                          const double *d_radii_table, int natm, long ngrids, void *stream);
-/* ao[comp][nao][ldg] (grid index fastest), comp = 1 (deriv 0) or 4 (deriv 1), points [g0, g0+ng) */
+/* ao[comp][ldg_rows][ldao] (AO index fastest, columns nao..ldao-1 zero), comp = 1 (deriv 0) or 4 (deriv 1),
+ * grid points [g0, g0+ng) of d_coords; d_fn2sh[mu] = segmented shell of AO mu */
 int PAMD_eval_ao(int deriv, const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,
-                 const double *d_xyz, const double *d_exps, const double *d_coefs, int nsh, int nao,
-                 const double *d_coords, long g0, long ng, const double *d_c2s, const int *d_c2s_off,
-                 double *d_ao, long ldg, void *stream);
-/* rho[4][ldg] (rho, grad) from c[comp][g][ldc] = ao_comp . C_occ, or from ao and c0 = D . ao0 */
-int PAMD_rho_from_mo(const double *d_c, long comp_stride, int ldc, int nocc, int ncomp, long ng,
+                 const double *d_xyz, const double *d_exps, const double *d_coefs, int nsh, const int *d_fn2sh,
+                 int nao, const double *d_coords, long g0, long ng, const double *d_c2s, const int *d_c2s_off,
+                 double *d_ao, long ldg_rows, int ldao, void *stream);
+/* rho[4][ldg] (rho, grad rho) from c[comp][i][ldc] = C_occ^T ao_comp^T (orbital rows), or from ao and
+ * c0t[mu][ldc] = (D ao0^T) */
+int PAMD_rho_from_mo(const double *d_c, long comp_stride, long ldc, int nocc, int ncomp, long ng,
                      double *d_rho, long ldg, void *stream);
-int PAMD_rho_from_dm(const double *d_ao, const double *d_c0, int nao, long ldg, int ncomp, long ng,
-                     double *d_rho, void *stream);
+int PAMD_rho_from_dm(const double *d_ao, const double *d_c0t, int nao, int ldao, long ldg_rows, long ldc,
+                     int ncomp, long ng, double *d_rho, long ldg, void *stream);
 /* fac7: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C}.  wv[4][ldg] = w (vrho/2, 2 vsigma grad rho);
  * d_acc[0] += sum w rho, d_acc[1] += sum w e_xc; d_exc nullable */
 int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double *d_weights, long ng,
                  long ldg, double *d_wv, double *d_exc, double *d_acc, void *stream);
-int PAMD_scale_ao(const double *d_ao, const double *d_wv, int nao, long ldg, int ncomp, long ng,
-                  double *d_aow, void *stream);
+int PAMD_scale_ao(const double *d_ao, const double *d_wv, int ldao, long ldg_rows, long ldg, int ncomp,
+                  long ng, long nrows, double *d_aow, void *stream);     /* aow[g][ldao], rows ng..nrows-1 zero */
 int PAMD_dgemm_nt(const double *d_A, long lda, const double *d_B, long ldb, double *d_C, int ldc, int m,
                   int n, long k, int nsplit, void *stream);                /* C[s] += A B^T (k split s) */
 int PAMD_reduce_sym(const double *d_part, int nsplit, int m, int ldc, double *d_out, void *stream);

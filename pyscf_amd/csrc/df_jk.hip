@@ -131,10 +131,13 @@ constexpr int LDT = KB + 1;     // transposed tile [n][k], odd stride -> conflic
 //   The packed row is read directly: tiles below the diagonal (q >= p) are row-contiguous,
 //   tiles above it are read through the transposed element row[p(p+1)/2+q] (q-contiguous) and
 //   kept transposed in LDS.  Next tile is prefetched into registers during the MFMA phase.
-template <int MT>
+//   PLAIN = true: the same MFMA structure for a plain operand src[n][k] (k contiguous, leading
+//   dimension npair): out[y][i][n] = sum_k src_y[n][k] orb[k][i]  (used for c = C_occ^T ao^T in nr_rks);
+//   then `nao` is the k extent, `ncols` the n extent and `npair` doubles as the row stride of src.
+template <int MT, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
     const double *__restrict__ cderi, long npair, int nao, const double *__restrict__ orb, int ldo,
-    double *__restrict__ X, int nocc_pad, int ldx)
+    double *__restrict__ X, int nocc_pad, long ldx, long src_stride, long ncols)
 {
     constexpr int MW = MT * 16;                         // orbitals per workgroup
     constexpr int LDA = MW + ((MW % 32 == 16) ? 0 : 16);  // == 16 mod 32
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
     const int p0 = blockIdx.x * NT;
     const int L = blockIdx.y;
     const int m0 = blockIdx.z * MW;
-    const double *row = cderi + (long)L * npair;
+    const double *row = PLAIN ? cderi + (long)L * src_stride : cderi + (long)L * npair;
 
     double4_t acc[MT][2];
 #pragma unroll
@@ -158,13 +161,18 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
     const int tn = tid >> 1, tk = (tid & 1) * 8;        // staging coordinates (transposed tiles)
     double ra[MT], rb[8];
 
-    auto tile_above = [&](int q0) { return q0 + KB - 1 <= p0; };
+    auto tile_above = [&](int q0) { return PLAIN || q0 + KB - 1 <= p0; };
     auto fetch = [&](int q0) {
         const int q = q0 + sk;
         const double *orow = orb + (long)q * ldo + m0 + sc;
 #pragma unroll
         for (int j = 0; j < MT; j++) ra[j] = (q < nao) ? orow[16 * j] : 0.0;
-        if (tile_above(q0)) {
+        if (PLAIN) {
+            const long p = p0 + tn;
+            const double *src = row + p * npair + q0 + tk;
+#pragma unroll
+            for (int j = 0; j < 8; j++) rb[j] = (p < ncols && q0 + tk + j < nao) ? src[j] : 0.0;
+        } else if (tile_above(q0)) {
             const long p = p0 + tn;
             const double *src = row + p * (p + 1) / 2 + q0 + tk;
 #pragma unroll
@@ -221,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
     for (int a = 0; a < MT; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) {
-            int p = p0 + wave * 32 + b * 16 + fn;
-            if (p >= ldx) continue;
+            long p = p0 + wave * 32 + b * 16 + fn;
+            if (p >= (PLAIN ? ncols : ldx)) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 int i = m0 + a * 16 + fk + 4 * r;
@@ -522,7 +530,7 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     // the kernel writes rows i < nocc_pad only; chunks are mt*16 wide
     dim3 grid(ceil_div(ldx, NT), nL, nchunk);
 #define LAUNCH_E2(MT)                                                                         \
-    e2_symm_kernel<MT><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx)
+    e2_symm_kernel<MT, false><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx, 0, 0)
     // orbital tile reads m0+i < ldo must stay in bounds: require ldo >= nchunk*mt*16
     PAMD_REQUIRE(ldo >= nchunk * mt * 16, "orbital leading dimension too small for tile padding");
     switch (mt) {
@@ -538,6 +546,39 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     default: LAUNCH_E2(10); break;
     }
 #undef LAUNCH_E2
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[y][i][n] = sum_k src_y[n][k] * orb[k][i]   (y < ny; src_y = d_src + y*src_stride, rows n of
+// leading dimension lds, k contiguous).  Same MFMA kernel as PAMD_nr_e2_symm with a plain operand;
+// numint's c = ao . C_occ (pyscf/dft/numint.py:328-469, VXCdot_ao_dm) in the [orbital][grid] layout.
+int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, long nrows, int kdim,
+                      const double *d_orb, int ldo, int nocc_pad, double *d_out, long ldout, void *stream)
+{
+    PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
+    if (ny == 0 || nrows == 0 || nocc_pad == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int mt_total = nocc_pad / 16;
+    int nchunk = ceil_div(mt_total, 10);
+    int mt = ceil_div(mt_total, nchunk);
+    PAMD_REQUIRE(ldo >= nchunk * mt * 16, "orbital leading dimension too small for tile padding");
+    dim3 grid(ceil_div(nrows, NT), ny, nchunk);
+#define LAUNCH_P(MT)                                                                          \
+    e2_symm_kernel<MT, true><<<grid, 256, 0, st>>>(d_src, lds, kdim, d_orb, ldo, d_out, nocc_pad, ldout, src_stride, nrows)
+    switch (mt) {
+    case 1: LAUNCH_P(1); break;
+    case 2: LAUNCH_P(2); break;
+    case 3: LAUNCH_P(3); break;
+    case 4: LAUNCH_P(4); break;
+    case 5: LAUNCH_P(5); break;
+    case 6: LAUNCH_P(6); break;
+    case 7: LAUNCH_P(7); break;
+    case 8: LAUNCH_P(8); break;
+    case 9: LAUNCH_P(9); break;
+    default: LAUNCH_P(10); break;
+    }
+#undef LAUNCH_P
     PAMD_CHECK_LAUNCH();
     return 0;
 }

@@ -3,8 +3,8 @@
 //   PAMD_eval_ao         <- GTOval_sph_deriv0 / GTOval_sph_deriv1 (pyscf/gto/eval_gto.py:31-144;
 //                           pyscf/lib/gto/grid_ao_drv.c:222-284 GTOeval_sph_iter, :125-141 GTOnabla1,
 //                           pyscf/lib/gto/deriv1.c:129-520)
-// Output layout of PAMD_eval_ao is the reference's: ao[comp][nao][ldg] (grid index fastest,
-// eval_gto.py:123-127), comp = 1 (value) or 4 (value, d/dx, d/dy, d/dz).
+// Output layout of PAMD_eval_ao: ao[comp][grid][ldao] (AO index fastest = numint.eval_ao's
+// (comp, ngrids, nao) view, numint.py:51-114), comp = 1 (value) or 4 (value, d/dx, d/dy, d/dz).
 #include "common.h"
 
 using namespace pamd;
@@ -48,63 +48,90 @@ struct AOShells {
     const double *xyz, *exps, *coefs;
 };
 
-__device__ inline void cart_exps(int l, int c, int &lx, int &ly, int &lz)
+// value and gradient of  R(r) * sum_c m[c] x^lx y^ly z^lz  with compile-time L (all monomial
+// indices become register indices after unrolling)
+template <int L, int DERIV>
+__device__ __forceinline__ void ao_angular(double x, double y, double z, double rad, double rad1,
+                                           const double *__restrict__ m, double &v, double &vx, double &vy, double &vz)
 {
-    int x = l, rem = c;
-    while (rem > l - x) { rem -= (l - x + 1); x--; }
-    lx = x; ly = (l - x) - rem; lz = rem;
+    double px[L + 2], py[L + 2], pz[L + 2];
+    px[0] = py[0] = pz[0] = 1;
+#pragma unroll
+    for (int i = 1; i <= L + 1; i++) { px[i] = px[i - 1] * x; py[i] = py[i - 1] * y; pz[i] = pz[i - 1] * z; }
+    int c = 0;
+#pragma unroll
+    for (int lx = L; lx >= 0; lx--)
+#pragma unroll
+        for (int ly = L - lx; ly >= 0; ly--, c++) {
+            const int lz = L - lx - ly;
+            const double f = m[c];
+            v += f * px[lx] * py[ly] * pz[lz] * rad;
+            if (DERIV) {
+                vx += f * (rad1 * px[lx + 1] * py[ly] * pz[lz] + (lx ? lx * px[lx ? lx - 1 : 0] * py[ly] * pz[lz] * rad : 0.0));
+                vy += f * (rad1 * px[lx] * py[ly + 1] * pz[lz] + (ly ? ly * px[lx] * py[ly ? ly - 1 : 0] * pz[lz] * rad : 0.0));
+                vz += f * (rad1 * px[lx] * py[ly] * pz[lz + 1] + (lz ? lz * px[lx] * py[ly] * pz[lz ? lz - 1 : 0] * rad : 0.0));
+            }
+        }
 }
 
-// one thread per grid point, blockIdx.y strides over shells
+// Grid-major output ao[comp][g][ldao] (AO index fastest): one wave per grid point.  Phase 1: lanes
+// over shells evaluate the contracted radial sums (one exp per primitive, not per function) into
+// LDS; phase 2: lanes over AO functions combine them with the angular polynomials, so stores are
+// fully coalesced and the (ngrids x nao) blocks feed the FP64 MFMA GEMMs as [k = grid][m = AO] panels.
+constexpr int AO_SC = 256;            // shells per chunk (LDS: 4 waves x 256 x 2 doubles = 16 KB)
+
 template <int DERIV>
-__global__ __launch_bounds__(256) void eval_ao_kernel(AOShells sh, int nsh, const double *__restrict__ coords,
-                                                      long g0, long ng, const double *__restrict__ c2s,
-                                                      const int *__restrict__ c2s_off, double *__restrict__ ao,
-                                                      long ldg, int nao)
+__global__ __launch_bounds__(256) void eval_ao_kernel(AOShells sh, int nsh, const int *__restrict__ fn2sh,
+                                                      const double *__restrict__ coords, long g0, long ng,
+                                                      const double *__restrict__ c2s, const int *__restrict__ c2s_off,
+                                                      double *__restrict__ ao, long ldg_rows, int ldao, int nao)
 {
-    const long gl = (long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ double s_rad[4][AO_SC][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gl = (long)blockIdx.x * 4 + wave;
     const bool valid = gl < ng;
     const long g = g0 + (valid ? gl : 0);
     const double gx = coords[g * 3 + 0], gy = coords[g * 3 + 1], gz = coords[g * 3 + 2];
-    const long comp_stride = (long)nao * ldg;
-    for (int s = blockIdx.y; s < nsh; s += gridDim.y) {
-        const int l = sh.l[s];
-        const double x = gx - sh.xyz[s * 3], y = gy - sh.xyz[s * 3 + 1], z = gz - sh.xyz[s * 3 + 2];
-        const double r2 = x * x + y * y + z * z;
-        double rad = 0, rad1 = 0;                        // sum c e^{-a r2},  sum -2 a c e^{-a r2}
-        for (int p = 0; p < sh.nprim[s]; p++) {
-            const double a = sh.exps[sh.prim0[s] + p];
-            const double e = sh.coefs[sh.prim0[s] + p] * exp(-a * r2);
-            rad += e;
-            rad1 += -2 * a * e;
-        }
-        // monomial powers
-        double px[AO_LMAX + 2], py[AO_LMAX + 2], pz[AO_LMAX + 2];
-        px[0] = py[0] = pz[0] = 1;
-        for (int i = 1; i <= l + 1; i++) { px[i] = px[i - 1] * x; py[i] = py[i - 1] * y; pz[i] = pz[i - 1] * z; }
-        const int nc = (l + 1) * (l + 2) / 2;
-        double cv[AO_NC], cdx[AO_NC], cdy[AO_NC], cdz[AO_NC];
-        for (int c = 0; c < nc; c++) {
-            int lx, ly, lz;
-            cart_exps(l, c, lx, ly, lz);
-            const double poly = px[lx] * py[ly] * pz[lz];
-            cv[c] = poly * rad;
-            if (DERIV) {
-                cdx[c] = rad1 * px[lx + 1] * py[ly] * pz[lz] + (lx ? lx * px[lx - 1] * py[ly] * pz[lz] * rad : 0.0);
-                cdy[c] = rad1 * px[lx] * py[ly + 1] * pz[lz] + (ly ? ly * px[lx] * py[ly - 1] * pz[lz] * rad : 0.0);
-                cdz[c] = rad1 * px[lx] * py[ly] * pz[lz + 1] + (lz ? lz * px[lx] * py[ly] * pz[lz - 1] * rad : 0.0);
+    const long comp_stride = ldg_rows * ldao;
+    for (int s0 = 0; s0 < nsh; s0 += AO_SC) {
+        const int s1 = (s0 + AO_SC < nsh) ? s0 + AO_SC : nsh;
+        __syncthreads();
+        for (int s = s0 + lane; s < s1; s += 64) {
+            const double x = gx - sh.xyz[s * 3], y = gy - sh.xyz[s * 3 + 1], z = gz - sh.xyz[s * 3 + 2];
+            const double r2 = x * x + y * y + z * z;
+            double rad = 0, rad1 = 0;
+            for (int p = 0; p < sh.nprim[s]; p++) {
+                const double a = sh.exps[sh.prim0[s] + p];
+                const double e = sh.coefs[sh.prim0[s] + p] * exp(-a * r2);
+                rad += e;
+                rad1 += -2 * a * e;
             }
+            s_rad[wave][s - s0][0] = rad;
+            s_rad[wave][s - s0][1] = rad1;
         }
-        const double *m = c2s + c2s_off[l];
-        for (int k = 0; k < 2 * l + 1; k++) {
+        __syncthreads();
+        const int mu0 = sh.ao0[s0];
+        const int mu1 = (s1 < nsh) ? sh.ao0[s1] : ldao;     // last chunk also zero-fills the padding
+        for (int mu = mu0 + lane; mu < mu1; mu += 64) {
             double v = 0, vx = 0, vy = 0, vz = 0;
-            for (int c = 0; c < nc; c++) {
-                const double f = m[k * nc + c];
-                v += f * cv[c];
-                if (DERIV) { vx += f * cdx[c]; vy += f * cdy[c]; vz += f * cdz[c]; }
+            if (mu < nao) {
+                const int s = fn2sh[mu];
+                const int l = sh.l[s];
+                const int k = mu - sh.ao0[s];
+                const double x = gx - sh.xyz[s * 3], y = gy - sh.xyz[s * 3 + 1], z = gz - sh.xyz[s * 3 + 2];
+                const double rad = s_rad[wave][s - s0][0], rad1 = s_rad[wave][s - s0][1];
+                const int nc = (l + 1) * (l + 2) / 2;
+                const double *m = c2s + c2s_off[l] + k * nc;
+                switch (l) {
+                case 0: ao_angular<0, DERIV>(x, y, z, rad, rad1, m, v, vx, vy, vz); break;
+                case 1: ao_angular<1, DERIV>(x, y, z, rad, rad1, m, v, vx, vy, vz); break;
+                case 2: ao_angular<2, DERIV>(x, y, z, rad, rad1, m, v, vx, vy, vz); break;
+                case 3: ao_angular<3, DERIV>(x, y, z, rad, rad1, m, v, vx, vy, vz); break;
+                default: ao_angular<4, DERIV>(x, y, z, rad, rad1, m, v, vx, vy, vz); break;
+                }
             }
             if (valid) {
-                double *o = ao + (long)(sh.ao0[s] + k) * ldg + gl;
+                double *o = ao + gl * ldao + mu;
                 o[0] = v;
                 if (DERIV) { o[comp_stride] = vx; o[2 * comp_stride] = vy; o[3 * comp_stride] = vz; }
             }
@@ -126,21 +153,22 @@ int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_
     return 0;
 }
 
-// ao[comp][nao][ldg], grid points [g0, g0+ng) of d_coords[][3]; deriv = 0 or 1
+// ao[comp][ldg_rows][ldao] (AO index fastest; columns nao..ldao-1 zero), grid points
+// [g0, g0+ng) of d_coords[][3]; deriv = 0 (comp 1) or 1 (comp 4); d_fn2sh[mu] = shell of AO mu
 int PAMD_eval_ao(int deriv, const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,
-                 const double *d_xyz, const double *d_exps, const double *d_coefs, int nsh, int nao,
-                 const double *d_coords, long g0, long ng, const double *d_c2s, const int *d_c2s_off,
-                 double *d_ao, long ldg, void *stream)
+                 const double *d_xyz, const double *d_exps, const double *d_coefs, int nsh, const int *d_fn2sh,
+                 int nao, const double *d_coords, long g0, long ng, const double *d_c2s, const int *d_c2s_off,
+                 double *d_ao, long ldg_rows, int ldao, void *stream)
 {
     PAMD_REQUIRE(deriv == 0 || deriv == 1, "eval_ao: deriv must be 0 or 1");
-    if (ng == 0 || nsh == 0) return 0;
+    PAMD_REQUIRE(ldao >= nao, "eval_ao: ldao < nao");
+    if (ng == 0 || nao == 0) return 0;
     AOShells sh{d_l, d_ao0, d_prim0, d_nprim, d_xyz, d_exps, d_coefs};
-    int ny = nsh < 64 ? nsh : 64;
-    dim3 grid(ceil_div(ng, 256), ny);
+    dim3 grid(ceil_div(ng, 4));
     if (deriv)
-        eval_ao_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg, nao);
+        eval_ao_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_fn2sh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg_rows, ldao, nao);
     else
-        eval_ao_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg, nao);
+        eval_ao_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_fn2sh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg_rows, ldao, nao);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

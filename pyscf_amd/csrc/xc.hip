@@ -195,23 +195,45 @@ __global__ __launch_bounds__(256) void eval_xc_kernel(XCSpec spec, int gga, cons
     }
 }
 
-// rho[c][g] from c[comp][g][ldc] = ao_comp . C_occ (rows g, nocc_pad columns; padded columns are zero)
-__global__ __launch_bounds__(256) void rho_from_mo_kernel(const double *__restrict__ c, long comp_stride, int ldc,
+// rho from c[comp][i][ldc] = sum_mu C_occ[mu][i] ao_comp[g][mu]   (orbital rows, grid index fastest)
+__global__ __launch_bounds__(256) void rho_from_mo_kernel(const double *__restrict__ c, long comp_stride, long ldc,
                                                           int nocc, int ncomp, long ng, double *__restrict__ rho,
                                                           long ldg)
 {
-    // one wave per grid point
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ng) return;
+    double s0 = 0, sx = 0, sy = 0, sz = 0;
+    for (int i = 0; i < nocc; i++) {
+        const double c0 = c[(long)i * ldc + g];
+        s0 += c0 * c0;
+        if (ncomp == 4) {
+            sx += c0 * c[comp_stride + (long)i * ldc + g];
+            sy += c0 * c[2 * comp_stride + (long)i * ldc + g];
+            sz += c0 * c[3 * comp_stride + (long)i * ldc + g];
+        }
+    }
+    rho[g] = s0;
+    if (ncomp == 4) { rho[ldg + g] = 2 * sx; rho[2 * ldg + g] = 2 * sy; rho[3 * ldg + g] = 2 * sz; }
+}
+
+// rho[g] = sum_mu ao0[g][mu] c0t[mu][g], grad = 2 sum_mu ao_x[g][mu] c0t[mu][g]   (c0t = (D ao0^T), [mu][ldc])
+// one wave per grid point (general-DM branch; not a hot path)
+__global__ __launch_bounds__(256) void rho_from_dm_kernel(const double *__restrict__ ao, const double *__restrict__ c0t,
+                                                          int nao, int ldao, long ldg_rows, long ldc, int ncomp,
+                                                          long ng, double *__restrict__ rho, long ldg)
+{
     const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= ng) return;
     const int lane = threadIdx.x & 63;
+    const long cs = ldg_rows * ldao;
     double s0 = 0, sx = 0, sy = 0, sz = 0;
-    for (int i = lane; i < nocc; i += 64) {
-        const double c0 = c[g * ldc + i];
-        s0 += c0 * c0;
+    for (int m = lane; m < nao; m += 64) {
+        const double c = c0t[(long)m * ldc + g];
+        s0 += ao[g * ldao + m] * c;
         if (ncomp == 4) {
-            sx += c0 * c[comp_stride + g * ldc + i];
-            sy += c0 * c[2 * comp_stride + g * ldc + i];
-            sz += c0 * c[3 * comp_stride + g * ldc + i];
+            sx += ao[cs + g * ldao + m] * c;
+            sy += ao[2 * cs + g * ldao + m] * c;
+            sz += ao[3 * cs + g * ldao + m] * c;
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -224,44 +246,23 @@ __global__ __launch_bounds__(256) void rho_from_mo_kernel(const double *__restri
     }
 }
 
-// rho[g] = sum_mu ao0[mu][g] c0[mu][g];  grad = 2 sum_mu ao_x[mu][g] c0[mu][g]  (hermitian D; c0 = D ao0)
-__global__ __launch_bounds__(256) void rho_from_dm_kernel(const double *__restrict__ ao, const double *__restrict__ c0,
-                                                          int nao, long ldg, int ncomp, long ng,
-                                                          double *__restrict__ rho)
-{
-    const long g = (long)blockIdx.x * 256 + threadIdx.x;
-    if (g >= ng) return;
-    const long cs = (long)nao * ldg;
-    double s0 = 0, sx = 0, sy = 0, sz = 0;
-    for (int m = 0; m < nao; m++) {
-        const double c = c0[(long)m * ldg + g];
-        s0 += ao[(long)m * ldg + g] * c;
-        if (ncomp == 4) {
-            sx += ao[cs + (long)m * ldg + g] * c;
-            sy += ao[2 * cs + (long)m * ldg + g] * c;
-            sz += ao[3 * cs + (long)m * ldg + g] * c;
-        }
-    }
-    rho[g] = s0;
-    if (ncomp == 4) { rho[ldg + g] = 2 * sx; rho[2 * ldg + g] = 2 * sy; rho[3 * ldg + g] = 2 * sz; }
-}
-
-// aow[mu][g] = sum_c wv[c][g] ao[c][mu][g]
+// aow[g][mu] = sum_c wv[c][g] ao[c][g][mu]   (rows g >= ng are zeroed)
 __global__ __launch_bounds__(256) void scale_ao_kernel(const double *__restrict__ ao, const double *__restrict__ wv,
-                                                       int nao, long ldg, int ncomp, long ng, double *__restrict__ aow)
+                                                       int ldao, long ldg_rows, long ldg, int ncomp, long ng,
+                                                       double *__restrict__ aow)
 {
-    const long g = (long)blockIdx.x * 256 + threadIdx.x;
-    const int m = blockIdx.y;
-    if (g >= ldg) return;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const long g = blockIdx.y;
+    if (m >= ldao) return;
     double v = 0;
     if (g < ng) {
-        const long cs = (long)nao * ldg;
-        v = wv[g] * ao[(long)m * ldg + g];
+        const long cs = ldg_rows * ldao;
+        v = wv[g] * ao[g * ldao + m];
         if (ncomp == 4)
-            v += wv[ldg + g] * ao[cs + (long)m * ldg + g] + wv[2 * ldg + g] * ao[2 * cs + (long)m * ldg + g] +
-                 wv[3 * ldg + g] * ao[3 * cs + (long)m * ldg + g];
+            v += wv[ldg + g] * ao[cs + g * ldao + m] + wv[2 * ldg + g] * ao[2 * cs + g * ldao + m] +
+                 wv[3 * ldg + g] * ao[3 * cs + g * ldao + m];
     }
-    aow[(long)m * ldg + g] = v;
+    aow[g * ldao + m] = v;
 }
 
 // C[m][n] += sum_k A[m][k] B[n][k]   (both operands k-contiguous), split-K over gridDim.y
@@ -367,31 +368,33 @@ int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double 
     return 0;
 }
 
-int PAMD_rho_from_mo(const double *d_c, long comp_stride, int ldc, int nocc, int ncomp, long ng, double *d_rho,
+int PAMD_rho_from_mo(const double *d_c, long comp_stride, long ldc, int nocc, int ncomp, long ng, double *d_rho,
                      long ldg, void *stream)
 {
     if (ng == 0) return 0;
-    rho_from_mo_kernel<<<ceil_div(ng, 4), 256, 0, (hipStream_t)stream>>>(d_c, comp_stride, ldc, nocc, ncomp, ng,
-                                                                         d_rho, ldg);
+    rho_from_mo_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(d_c, comp_stride, ldc, nocc, ncomp, ng,
+                                                                           d_rho, ldg);
     PAMD_CHECK_LAUNCH();
     return 0;
 }
 
-int PAMD_rho_from_dm(const double *d_ao, const double *d_c0, int nao, long ldg, int ncomp, long ng, double *d_rho,
-                     void *stream)
+int PAMD_rho_from_dm(const double *d_ao, const double *d_c0t, int nao, int ldao, long ldg_rows, long ldc, int ncomp,
+                     long ng, double *d_rho, long ldg, void *stream)
 {
     if (ng == 0) return 0;
-    rho_from_dm_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(d_ao, d_c0, nao, ldg, ncomp, ng, d_rho);
+    rho_from_dm_kernel<<<ceil_div(ng, 4), 256, 0, (hipStream_t)stream>>>(d_ao, d_c0t, nao, ldao, ldg_rows, ldc, ncomp,
+                                                                         ng, d_rho, ldg);
     PAMD_CHECK_LAUNCH();
     return 0;
 }
 
-int PAMD_scale_ao(const double *d_ao, const double *d_wv, int nao, long ldg, int ncomp, long ng, double *d_aow,
-                  void *stream)
+// aow[g][ldao] for g < nrows (rows ng..nrows-1 zeroed so that padded k ranges contribute nothing)
+int PAMD_scale_ao(const double *d_ao, const double *d_wv, int ldao, long ldg_rows, long ldg, int ncomp, long ng,
+                  long nrows, double *d_aow, void *stream)
 {
-    if (ldg == 0) return 0;
-    dim3 grid(ceil_div(ldg, 256), nao);
-    scale_ao_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_ao, d_wv, nao, ldg, ncomp, ng, d_aow);
+    if (nrows == 0) return 0;
+    dim3 grid(ceil_div(ldao, 256), nrows);
+    scale_ao_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_ao, d_wv, ldao, ldg_rows, ldg, ncomp, ng, d_aow);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

@@ -4,12 +4,12 @@ Mirror of ``pyscf/dft/numint.py``: ``NumInt.nr_rks`` (:1074-1190), ``block_loop`
 ``eval_ao`` (:51-114), ``eval_rho``/``eval_rho2`` (:116-469), ``_scale_ao`` / ``_dot_ao_ao``
 (:803-874), ``rsh_and_hybrid_coeff`` (:2805-2828).  Per grid block, on the device:
 
-    ao   = PAMD_eval_ao              (comp, nao, ldg)          GTOval_sph_deriv0/1
-    c    = ao_comp^T-free GEMM       c[comp][g][i] = sum_mu ao[comp][mu][g] C_occ[mu][i]   (MO branch)
+    ao   = PAMD_eval_ao              (comp, grid, ldao), AO index fastest     GTOval_sph_deriv0/1
+    c    = PAMD_cderi_solve (GEMM)   c[comp][i][g] = sum_mu C_occ[mu][i] ao[comp][g][mu]   (MO branch)
     rho  = PAMD_rho_from_mo / _dm    rho, grad rho
     wv   = PAMD_eval_xc              w * (vrho/2, 2 vsigma grad rho); nelec, exc accumulated
     aow  = PAMD_scale_ao             sum_c wv_c ao_c
-    vmat+= PAMD_dgemm_nt             ao0 . aow^T ;  finally vmat = M + M^T
+    vmat+= PAMD_dgemm_tn (LDS-DMA)   ao0^T . aow ;  finally vmat = M + M^T
 
 AO values are recomputed per SCF iteration block by block (exp-bound, cheap next to the two
 GEMMs) instead of being stored; with several ranks the grid blocks are dealt round-robin and
@@ -88,7 +88,8 @@ class NumInt:
             sh = eng.ao
             prim0 = np.cumsum([0] + [len(e) for e in sh.exps])[:-1].astype(np.int32)
             nprim = np.array([len(e) for e in sh.exps], np.int32)
-            self._cache[key] = dict(
+            fn2sh = np.repeat(np.arange(sh.n, dtype=np.int32), 2 * sh.l + 1)
+            self._cache[key] = dict(fn2sh=_dev(fn2sh, dev),
                 eng=eng, nsh=sh.n, nao=sh.nao, l=_dev(sh.l, dev), ao0=_dev(sh.ao0, dev), prim0=_dev(prim0, dev),
                 nprim=_dev(nprim, dev), exps=_dev(np.concatenate(sh.exps), dev),
                 coefs=_dev(np.concatenate(sh.coefs), dev))
@@ -108,8 +109,8 @@ class NumInt:
         else:
             _lib_mod.check(fn(*args))
 
-    def eval_ao_block(self, mol, coords_dev, g0, ng, deriv, out, ldg):
-        """out[comp][nao][ldg] <- AO values (deriv=0: comp=1; deriv=1: comp=4) for grid points [g0,g0+ng)."""
+    def eval_ao_block(self, mol, coords_dev, g0, ng, deriv, out, rows, ldao):
+        """out[comp][rows][ldao] <- AO values (deriv=0: comp=1; deriv=1: comp=4) for grid points [g0,g0+ng)."""
         import torch
         lib = _lib_mod.load_library()
         dev = coords_dev.device
@@ -118,21 +119,22 @@ class NumInt:
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
         self._call('eval_ao', lib.PAMD_eval_ao, _c.c_int(deriv), _ptr(t['l']), _ptr(t['ao0']), _ptr(t['prim0']),
                    _ptr(t['nprim']), _ptr(eng.ao_xyz), _ptr(t['exps']), _ptr(t['coefs']), _c.c_int(t['nsh']),
-                   _c.c_int(t['nao']), _ptr(coords_dev), _c.c_long(g0), _c.c_long(ng), _ptr(eng.c2s),
-                   _ptr(eng.c2s_off), _ptr(out), _c.c_long(ldg), st)
+                   _ptr(t['fn2sh']), _c.c_int(t['nao']), _ptr(coords_dev), _c.c_long(g0), _c.c_long(ng), _ptr(eng.c2s),
+                   _ptr(eng.c2s_off), _ptr(out), _c.c_long(rows), _c.c_int(ldao), st)
 
     def eval_ao(self, mol, coords, deriv=0):
-        """Host convenience (tests): returns (nao, ngrids) or (4, nao, ngrids) like the reference's
-        C-order buffer of GTOval_sph_deriv0/1 (eval_gto.py:123-127; transposed w.r.t. numint.eval_ao)."""
+        """Host convenience (tests): (ngrids, nao) or (4, ngrids, nao) like numint.eval_ao
+        (pyscf/dft/numint.py:51-114)."""
         import torch
         dev = self._dev()
         c = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.float64)).to(dev)
         ng = len(coords)
         nao = self._shell_tables(mol, dev)['nao']
+        ldao = _round_up(nao, 16)
         ncomp = 4 if deriv else 1
-        out = torch.zeros((ncomp, nao, ng), dtype=torch.float64, device=dev)
-        self.eval_ao_block(mol, c, 0, ng, deriv, out, ng)
-        out = out.cpu().numpy()
+        out = torch.zeros((ncomp, ng, ldao), dtype=torch.float64, device=dev)
+        self.eval_ao_block(mol, c, 0, ng, deriv, out, ng, ldao)
+        out = out[:, :, :nao].cpu().numpy()
         return out[0] if deriv == 0 else out
 
     # -- the hot entry point ----------------------------------------------------------------------
@@ -161,12 +163,14 @@ class NumInt:
         ncomp = 4 if gga else 1
         coords_dev, weights_dev = self._grid_tables(grids, dev)
         ngrids = grids.size
-        blk = int(self.block_bytes // (ncomp * nao * 8))
+        ldao = _round_up(nao, 16)
+        blk = int(self.block_bytes // (ncomp * ldao * 8))
         blk = max(256, min(_round_up(ngrids, 256), blk // 256 * 256))
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
         f64 = torch.float64
-        ao = torch.empty((ncomp, nao, blk), dtype=f64, device=dev)
-        aow = torch.empty((nao, blk), dtype=f64, device=dev)
+        # +256 doubles of slack: the LDS-DMA GEMM reads whole 128-column panel rows
+        ao = torch.zeros(ncomp * blk * ldao + 256, dtype=f64, device=dev)[:ncomp * blk * ldao].view(ncomp, blk, ldao)
+        aow = torch.zeros(blk * ldao + 256, dtype=f64, device=dev)[:blk * ldao].view(blk, ldao)
         rho = torch.empty((4, blk), dtype=f64, device=dev)
         wv = torch.empty((4, blk), dtype=f64, device=dev)
         nsplit = 4
@@ -179,42 +183,49 @@ class NumInt:
                 orbo = np.asarray(mo_coeff)[:, occ > 0] * np.sqrt(occ[occ > 0])
                 nocc = orbo.shape[1]
                 nocc_pad = _round_up(max(nocc, 1), 16)
-                orb_h = np.zeros((nao, nocc_pad))
+                ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
+                orb_h = np.zeros((nao, ldo))
                 orb_h[:, :nocc] = orbo
                 orb = torch.from_numpy(orb_h).to(dev)
-                cmo = torch.empty((ncomp, blk, nocc_pad), dtype=f64, device=dev)
+                cmo = torch.empty((ncomp, nocc_pad, blk), dtype=f64, device=dev)
             else:
                 d = dms2[iset]
-                dsym = torch.from_numpy(np.ascontiguousarray((d + d.T) * .5)).to(dev)
-                c0 = torch.empty((nao, blk), dtype=f64, device=dev)
+                ldd = _round_up(nao, 128)
+                d_h = np.zeros((nao, ldd))
+                d_h[:, :nao] = (d + d.T) * .5
+                dsym = torch.from_numpy(d_h).to(dev)
+                c0t = torch.empty((nao, blk), dtype=f64, device=dev)
             part = torch.zeros((nsplit, nao, nao), dtype=f64, device=dev)
             acc = torch.zeros(2, dtype=f64, device=dev)
             for ib, g0 in enumerate(range(0, ngrids, blk)):
                 if ib % world != rank:
                     continue
                 ng = min(blk, ngrids - g0)
-                self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk)
+                ng16 = _round_up(ng, 16)
+                self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk, ldao)
                 if use_mo:
-                    cmo.zero_()
-                    for c in range(ncomp):
-                        self._call('ao_dot_mo', lib.PAMD_dgemm_tn, _ptr(ao[c]), _c.c_int(blk), _ptr(orb),
-                                   _c.c_int(nocc_pad), _ptr(cmo[c]), _c.c_int(nocc_pad), _c.c_int(ng),
-                                   _c.c_int(nocc_pad), _c.c_long(nao), _c.c_int(0), _c.c_int(1), st)
-                    self._call('rho', lib.PAMD_rho_from_mo, _ptr(cmo), _c.c_long(blk * nocc_pad), _c.c_int(nocc_pad),
+                    # c[comp][i][g] = sum_mu orb[mu][i] ao[comp][g][mu]   (GEMM shape of PAMD_cderi_solve)
+                    self._call('ao_dot_mo', lib.PAMD_orb_dot_rows, _ptr(ao), _c.c_long(ldao), _c.c_long(blk * ldao),
+                               _c.c_int(ncomp), _c.c_long(ng), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
+                               _c.c_int(nocc_pad), _ptr(cmo), _c.c_long(blk), st)
+                    self._call('rho', lib.PAMD_rho_from_mo, _ptr(cmo), _c.c_long(nocc_pad * blk), _c.c_long(blk),
                                _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho), _c.c_long(blk), st)
                 else:
-                    c0.zero_()
-                    self._call('dm_dot_ao', lib.PAMD_dgemm_tn, _ptr(dsym), _c.c_int(nao), _ptr(ao[0]), _c.c_int(blk),
-                               _ptr(c0), _c.c_int(blk), _c.c_int(nao), _c.c_int(ng), _c.c_long(nao), _c.c_int(0),
-                               _c.c_int(1), st)
-                    self._call('rho', lib.PAMD_rho_from_dm, _ptr(ao), _ptr(c0), _c.c_int(nao), _c.c_long(blk),
-                               _c.c_int(ncomp), _c.c_long(ng), _ptr(rho), st)
+                    # c0t[mu][g] = sum_nu D[nu][mu] ao0[g][nu]
+                    self._call('dm_dot_ao', lib.PAMD_cderi_solve, _ptr(dsym), _c.c_int(ldd), _ptr(ao[0]),
+                               _c.c_long(ldao), _ptr(c0t), _c.c_long(blk), _c.c_int(nao), _c.c_long(ng),
+                               _c.c_int(nao), _c.c_int(0), _c.c_int(0), st)
+                    self._call('rho', lib.PAMD_rho_from_dm, _ptr(ao), _ptr(c0t), _c.c_int(nao), _c.c_int(ldao),
+                               _c.c_long(blk), _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho),
+                               _c.c_long(blk), st)
                 self._call('eval_xc', lib.PAMD_eval_xc, fac_c, _c.c_int(gga), _ptr(rho), _ptr(weights_dev[g0:g0 + ng]),
                            _c.c_long(ng), _c.c_long(blk), _ptr(wv), _c.c_void_p(0), _ptr(acc), st)
-                self._call('scale_ao', lib.PAMD_scale_ao, _ptr(ao), _ptr(wv), _c.c_int(nao), _c.c_long(blk),
-                           _c.c_int(ncomp), _c.c_long(ng), _ptr(aow), st)
-                self._call('ao_dot_aow', lib.PAMD_dgemm_nt, _ptr(ao[0]), _c.c_long(blk), _ptr(aow), _c.c_long(blk),
-                           _ptr(part), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(ng), _c.c_int(nsplit), st)
+                self._call('scale_ao', lib.PAMD_scale_ao, _ptr(ao), _ptr(wv), _c.c_int(ldao), _c.c_long(blk),
+                           _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _c.c_long(ng16), _ptr(aow), st)
+                # vmat partial: M += ao0^T aow over the (16-padded, zero-weighted) grid rows of this block
+                self._call('ao_dot_aow', lib.PAMD_dgemm_tn, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow), _c.c_int(ldao),
+                           _ptr(part), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(ng16), _c.c_int(2),
+                           _c.c_int(nsplit), st)
             v = torch.empty((nao, nao), dtype=f64, device=dev)
             self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(part), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
                        _ptr(v), st)

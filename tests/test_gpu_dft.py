@@ -42,11 +42,11 @@ def test_eval_ao_vs_oracle(basis):
     coords = rng.uniform(-4, 5, (333, 3))
     coords[0] = mol.atom_coords()[0]                  # a point on a nucleus
     ni = dft.NumInt()
-    ao = ni.eval_ao(mol, coords, deriv=1)             # (4, nao, ng)
+    ao = ni.eval_ao(mol, coords, deriv=1)             # (4, ng, nao)
     want = ref_dft.eval_ao(mol, coords, deriv=1)      # (4, ng, nao)
-    assert np.abs(ao.transpose(0, 2, 1) - want).max() < 1e-12 * max(1, np.abs(want).max())
+    assert np.abs(ao - want).max() < 1e-12 * max(1, np.abs(want).max())
     ao0 = ni.eval_ao(mol, coords, deriv=0)
-    assert np.abs(ao0.T - want[0]).max() < 1e-12 * max(1, np.abs(want).max())
+    assert np.abs(ao0 - want[0]).max() < 1e-12 * max(1, np.abs(want).max())
 
 
 @pytest.mark.parametrize('xc', ['lda,vwn', 'lda,vwn_rpa', 'b88,vwn', 'b88,lyp', 'b3lyp', 'pbe,pbe'])

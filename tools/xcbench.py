@@ -1,0 +1,47 @@
+"""nr_rks micro-benchmark: (H2O)_n cc-pVTZ, level-3 grid, B3LYP, per-kernel HIP-event timings.
+    python tools/xcbench.py [--nwater 32 --xc b3lyp --steps 2]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from pyscf_amd import gto, dft, lib
+from pyscf_amd.data import clusters
+from pyscf_amd.df import df_jk
+from pyscf_amd.scf import hf
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--nwater', type=int, default=32)
+ap.add_argument('--basis', default='cc-pvtz')
+ap.add_argument('--xc', default='b3lyp')
+ap.add_argument('--steps', type=int, default=2)
+a = ap.parse_args()
+dev = torch.device('cuda', 0)
+mol = gto.M(atom=clusters.water_cluster(a.nwater), basis=a.basis)
+nao, nocc = mol.nao, mol.nelectron // 2
+t0 = time.perf_counter()
+grids = dft.Grids(mol).build()
+t_grid = time.perf_counter() - t0
+s1e = hf.int1e_gpu(mol, dev)[0]
+rng = np.random.RandomState(1)
+x = rng.random_sample((nao, nao))
+w, v = np.linalg.eigh(x.T.dot(s1e).dot(x))
+c = x.dot(v / np.sqrt(w)).dot(v.T)
+occ = np.zeros(nao); occ[:nocc] = 2
+dm = lib.tag_array((c[:, :nocc] * 2).dot(c[:, :nocc].T), mo_coeff=c, mo_occ=occ)
+ni = dft.NumInt()
+n, e, vm = ni.nr_rks(mol, grids, a.xc, dm)
+torch.cuda.synchronize()
+ni.kernel_timer = df_jk.KernelTimer()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    n, e, vm = ni.nr_rks(mol, grids, a.xc, dm)
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / a.steps
+s = ni.kernel_timer.summary()
+out = {'nao': nao, 'nocc': nocc, 'ngrids': int(grids.size), 'grid_build_s': round(t_grid, 2), 'nelec': float(n),
+       'nelec_exact': mol.nelectron, 'exc': float(e), 'wall_ms_per_call': round(wall * 1e3, 1),
+       'kernel_ms': {k: round(t / a.steps, 2) for k, (t, c_) in s.items()}}
+ng = grids.size
+out['TF'] = {'ao_dot_mo': round(4 * 2.0 * ng * nao * ((nocc + 15) // 16 * 16) / (s['ao_dot_mo'][0] / a.steps) / 1e9, 1),
+             'ao_dot_aow': round(2.0 * ng * nao * nao / (s['ao_dot_aow'][0] / a.steps) / 1e9, 1)}
+print(json.dumps(out))
