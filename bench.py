@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--basis', default='cc-pvtz')
     ap.add_argument('--cpu-sample-rows', type=int, default=240)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--xc', default='b3lyp', help="XC functional of the secondary nr_rks timing ('' to skip)")
     args = ap.parse_args()
 
     import torch
@@ -102,10 +103,37 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     # per-kernel durations (one extra, untimed step with HIP events around every launch)
+    # (J and K are issued back-to-back on one stream for this pass so that each kernel is timed alone;
+    # the timed steps above overlap the HBM-bound J kernels with the MFMA-bound SYRK on a second stream)
     dfobj.kernel_timer = df_jk.KernelTimer()
+    dfobj.overlap_jk = False
     step()
     ksum = dfobj.kernel_timer.summary()
     dfobj.kernel_timer = None
+    dfobj.overlap_jk = True
+
+    # secondary figure (config 3 is DF-RKS B3LYP): one numint.nr_rks call per SCF iteration, grid blocks
+    # dealt round-robin over the ranks; not part of `value`
+    xc_info = None
+    if args.xc:
+        from pyscf_amd import dft
+        t0 = time.perf_counter()
+        grids = dft.Grids(mol).build()
+        grid_s = time.perf_counter() - t0
+        ni = dft.NumInt()
+        dm_tag = lib.tag_array(dm, mo_coeff=c, mo_occ=mo_occ)
+        ni.nr_rks(mol, grids, args.xc, dm_tag)
+        fence()
+        t0 = time.perf_counter()
+        nel, exc, _ = ni.nr_rks(mol, grids, args.xc, dm_tag)
+        fence()
+        xc_ms = (time.perf_counter() - t0) * 1e3
+        ni.kernel_timer = df_jk.KernelTimer()
+        ni.nr_rks(mol, grids, args.xc, dm_tag)
+        xs = ni.kernel_timer.summary()
+        xc_info = {'xc': args.xc, 'nr_rks_ms_per_call': round(xc_ms, 1), 'ngrids': int(grids.size),
+                   'grid_build_s': round(grid_s, 2), 'nelec': float(nel),
+                   'kernels_ms': {k: round(t, 2) for k, (t, n_) in xs.items()}}
 
     if rank != 0:
         if world > 1:
@@ -179,7 +207,7 @@ def main():
         'roofline': roofline,
         'cpu_baseline': cpu,
         'kernels': kern, 'j_hbm_GBs': j_gbs, 'k_mfma_TFLOPs': k_tflops,
-        'build_s': round(build_s, 2), 'parity_sample': parity,
+        'build_s': round(build_s, 2), 'parity_sample': parity, 'xc_path': xc_info,
     }
     print(json.dumps(out))
     if world > 1:

@@ -91,7 +91,7 @@ int PAMD_df_vj_pass1(const double *d_cderi, long npair, int naux, const double *
 int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *d_rho, int nset,
                      double *d_vjtril, void *stream);                     /* vjtril[s] += rho_s^T B  */
 int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
-                    int nocc_pad, double *d_out, int ldx, void *stream);  /* out[L][i][p]            */
+                    int orb_rows, int nocc_pad, double *d_out, int ldx, void *stream);  /* out[L][i][p] */
 /* out[y][i][n] = sum_k src_y[n][k] orb[k][i] (plain-operand mode of the e2_symm MFMA kernel) */
 int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, long nrows, int kdim,
                       const double *d_orb, int ldo, int nocc_pad, double *d_out, long ldout, void *stream);

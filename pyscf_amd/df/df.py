@@ -33,6 +33,7 @@ class DF:
         self.k_block_bytes = 8 << 30
         self.k_nsplit = 4
         self.lindep = 1e-7         # pyscf/df/incore.py:33
+        self.overlap_jk = True     # run J (HBM-bound) on a second stream beside K (MFMA-bound)
         self.kernel_timer = None   # df_jk.KernelTimer() to collect per-kernel HIP-event timings
         self._ws = {}
 
@@ -60,6 +61,12 @@ class DF:
         base, rem = divmod(naux, world)
         l0 = rank * base + min(rank, rem)
         return l0, l0 + base + (1 if rank < rem else 0)
+
+    def _side_stream(self):
+        import torch
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self._cderi_dev.device)
+        return self._side
 
     def _workspace(self, name, shape):
         """Persistent HBM scratch (no per-iteration hipMalloc): returns a view of `shape`."""

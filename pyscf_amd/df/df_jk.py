@@ -118,12 +118,12 @@ def pad_orbitals(orbo, device):
     nao, nocc = orbo.shape
     nocc_pad = _round_up(max(nocc, 1), 16)
     ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
-    orb_h = np.zeros((nao, ldo))
-    orb_h[:, :nocc] = orbo
+    orb_h = np.zeros((_round_up(nao, 16), ldo))          # zero rows up to a multiple of the k-tile
+    orb_h[:nao, :nocc] = orbo
     return torch.from_numpy(orb_h).to(device), (nocc_pad if nocc else 0), ldo
 
 
-def _vk_mo(dfobj, lib, orb_list, nao):
+def _vk_mo(dfobj, lib, orb_list, nao, after_first_e2=None):
     """K_pq = sum_{L,i} X[L,i,p] X[L,i,q],  X[L,i,p] = sum_q B_L[p,q] orbo[q,i]
     (df_jk.py:353-380; nr_ao2mo.c:399-419,1240-1266).  orb_list: [(orb_dev, nocc_pad, ldo)]."""
     torch = _torch()
@@ -146,7 +146,11 @@ def _vk_mo(dfobj, lib, orb_list, nao):
         for b0 in range(0, naux, blk):
             nb = min(blk, naux - b0)
             _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
-                  _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(nocc_pad), _ptr(X), _c.c_int(ldx), st)
+                  _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
+                  _c.c_int(ldx), st)
+            if after_first_e2 is not None:
+                after_first_e2()
+                after_first_e2 = None
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
                   _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(1 | 2),
                   _c.c_int(nsplit), st)
@@ -175,15 +179,14 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
     full = dfobj._workspace('full', (blk, rows, ldx))
     full.zero_()
     for k in range(nset):
-        orb = torch.zeros((nao, ldo), dtype=torch.float64, device=dev)
-        orb[:, :nao] = dms_dev[k]
+        orb = torch.zeros((rows, ldo), dtype=torch.float64, device=dev)
+        orb[:nao, :nao] = dms_dev[k]
         part = torch.zeros((nsplit, nao, nao), dtype=torch.float64, device=dev)
         for b0 in range(0, naux, blk):
             nb = min(blk, naux - b0)
             sub = cderi[b0:b0 + nb]
             _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
-                                               _ptr(orb), _c.c_int(ldo), _c.c_int(rows), _ptr(X),
-                                               _c.c_int(ldx), st)
+                  _ptr(orb), _c.c_int(ldo), _c.c_int(rows), _c.c_int(rows), _ptr(X), _c.c_int(ldx), st)
             _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
                                                 _ptr(full), _c.c_int(ldx), _c.c_int(rows), st)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(full), _c.c_int(ldx), _ptr(part),
@@ -204,12 +207,32 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
     nset, nao = dms_dev.shape[0], dms_dev.shape[-1]
     vjtril = vk_dev = None
     outs = []
-    if with_j:
+    torch = _torch()
+    overlap = with_j and with_k and orb_list is not None and getattr(dfobj, 'overlap_jk', False)
+    if with_j and not overlap:
         vjtril = _vj(dfobj, lib, dms_dev, nset, nao)
         outs.append(vjtril)
     if with_k:
         if orb_list is not None:
-            vk_dev = _vk_mo(dfobj, lib, orb_list, nao)
+            if overlap:
+                # J is HBM-bound, the K SYRK is FP64-MFMA-bound and leaves register-file room: run J
+                # on a second HIP stream, released once the first half transform has been queued
+                side = dfobj._side_stream()
+                holder = {}
+
+                def launch_j():
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        holder['vj'] = _vj(dfobj, lib, dms_dev, nset, nao)
+                vk_dev = _vk_mo(dfobj, lib, orb_list, nao, after_first_e2=launch_j)
+                vjtril = holder['vj']
+                torch.cuda.current_stream().wait_stream(side)
+                vjtril.record_stream(torch.cuda.current_stream())
+                outs.append(vjtril)
+            else:
+                vk_dev = _vk_mo(dfobj, lib, orb_list, nao)
         else:
             vk_dev = _vk_general(dfobj, lib, dms_dev, nset, nao)
         outs.append(vk_dev)

@@ -14,6 +14,8 @@ ap.add_argument('--naux', type=int, default=4448)
 ap.add_argument('--nocc', type=int, default=160)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--tag', default='')
+ap.add_argument('--tune', default='', help='comma list key=value for PAMD_set_tuning')
+ap.add_argument('--no-overlap', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 npair = a.nao * (a.nao + 1) // 2
@@ -24,6 +26,12 @@ for b0 in range(0, a.naux, 256):
     obj._cderi_dev[b0:b0 + 256].normal_(generator=g)
 obj._cderi_dev.mul_(1.0 / np.sqrt(a.nao))
 obj._naux = a.naux
+obj.overlap_jk = not a.no_overlap
+import ctypes
+from pyscf_amd import lib as _L
+for kv in filter(None, a.tune.split(',')):
+    k, v = kv.split('=')
+    _L.check(_L.load_library().PAMD_set_tuning(k.encode(), int(v)))
 rng = np.random.default_rng(1)
 c = np.linalg.qr(rng.standard_normal((a.nao, a.nocc)))[0] * np.sqrt(2.0)
 dm = c.dot(c.T)
@@ -31,13 +39,18 @@ dms = torch.from_numpy(dm[None]).to(dev)
 orb = [df_jk.pad_orbitals(c, dev)]
 df_jk.get_jk_device(obj, dms, orb)
 torch.cuda.synchronize()
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(a.steps):
+    vj, vk = df_jk.get_jk_device(obj, dms, orb)
+torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / a.steps * 1e3
 obj.kernel_timer = df_jk.KernelTimer()
 for _ in range(a.steps):
     vj, vk = df_jk.get_jk_device(obj, dms, orb)
 s = obj.kernel_timer.summary()
 fl = 2.0 * a.naux * a.nao * a.nao * a.nocc
 by = 8.0 * a.naux * npair
-out = {'tag': a.tag, 'total_ms': round(sum(t for t, _ in s.values()) / a.steps, 2)}
+out = {'tag': a.tag, 'wall_ms': round(wall, 2), 'sum_kernel_ms': round(sum(t for t, _ in s.values()) / a.steps, 2)}
 for k, (t, n) in s.items():
     ms = t / a.steps
     out[k] = round(ms, 3)
