@@ -48,7 +48,7 @@ _CHARGE = {s.upper(): z for z, s in enumerate(ELEMENTS)}
 _BASIS_DATA = None
 # alias -> key in data.json (pyscf/gto/basis/__init__.py:49-208)
 _ALIAS = {
-    'sto3g': 'sto3g', '631g': '631g', 'ccpvdz': 'ccpvdz', 'ccpvtz': 'ccpvtz',
+    'ano': 'ano', 'sto3g': 'sto3g', '631g': '631g', 'ccpvdz': 'ccpvdz', 'ccpvtz': 'ccpvtz',
     'def2svp': 'def2svp', 'def2tzvp': 'def2tzvp',
     'ccpvdzjkfit': 'ccpvdzjkfit', 'ccpvtzjkfit': 'ccpvtzjkfit', 'ccpvdzri': 'ccpvdzri',
     'def2universaljkfit': 'def2universaljkfit', 'def2universaljfit': 'def2universaljfit',

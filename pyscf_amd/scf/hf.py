@@ -142,7 +142,7 @@ class SCF:
     conv_tol = 1e-9
     conv_tol_grad = None
     max_cycle = 50
-    init_guess = '1e'          # the reference's default 'minao' needs the ANO tables (out of scope)
+    init_guess = 'minao'       # hf.py:1737-1760
     diis = True
     diis_space = 8
     direct_scf = True
@@ -179,8 +179,10 @@ class SCF:
         return t + v
 
     def get_init_guess(self, mol=None, key='1e', s1e=None):
+        if key.lower() == 'minao':
+            return init_guess_by_minao(mol or self.mol, s1e)
         if key.lower() not in ('1e', 'hcore'):
-            raise NotImplementedError("init_guess %s (only '1e' is restated; hf.py:491-498)" % key)
+            raise NotImplementedError("init_guess %s ('minao' and '1e' are restated; hf.py:354-498)" % key)
         h1e = self.get_hcore()
         if s1e is None:
             s1e = self.get_ovlp()
@@ -277,15 +279,22 @@ class RHF(SCF):
     pass
 
 
-def int1e_gpu(mol, device=None):
-    """(S, T, V) in the real-spherical AO basis from the device integral engine."""
+# pyscf/data/elements.py:582-596 (electrons per l of the spherically averaged ROHF atom)
+NRSRHF_CONFIGURATION = [[0, 0, 0, 0], [1, 0, 0, 0], [2, 0, 0, 0], [3, 0, 0, 0], [4, 0, 0, 0], [4, 1, 0, 0],
+                        [4, 2, 0, 0], [4, 3, 0, 0], [4, 4, 0, 0], [4, 5, 0, 0], [4, 6, 0, 0]]
+
+
+class _FakeMol:
+    """(atm, bas, env) holder accepted by the integral engine."""
+
+    def __init__(self, atm, bas, env):
+        self._atm, self._bas, self._env = atm, bas, env
+
+
+def _ovlp_kin_gpu(mol, device):
     import torch
-    from ..gto.moleintor import IntEngine, _AuxClass, _Shells, _dev, c2s_matrix
+    from ..gto.moleintor import IntEngine, _dev
     lib = _lib_mod.load_library()
-    if device is None:
-        if not torch.cuda.is_available():
-            raise RuntimeError('int1e_gpu needs a HIP device')
-        device = torch.device('cuda', torch.cuda.current_device())
     eng = IntEngine(mol, None, device)
     sh = eng.ao
     nao = sh.nao
@@ -301,6 +310,69 @@ def int1e_gpu(mol, device=None):
     _lib_mod.check(lib.PAMD_int1e_ovlp_kin(p(d_l), p(d_ao0), p(d_p0), p(d_np), p(eng.ao_xyz), p(d_ex), p(d_co),
                                            ctypes.c_int(sh.n), ctypes.c_int(nao), p(eng.c2s), p(eng.c2s_off),
                                            p(S), p(T), st))
+    return eng, S, T
+
+
+def _default_device(device=None):
+    import torch
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError('the integral engine needs a HIP device')
+        device = torch.device('cuda', torch.cuda.current_device())
+    return device
+
+
+def init_guess_by_minao(mol, s1e=None, device=None):
+    """Superposition of ANO minimal-basis atomic densities projected onto the AO basis
+    (pyscf/scf/hf.py:354-488 without the ECP branch; occupations from atom_hf.frac_occ :196-205;
+    projection C2 = S22^-1 <AO2|AO1> of scf/addons.py:359-394)."""
+    from ..gto import mole as _mole
+    device = _default_device(device)
+    basis, occdic = {}, {}
+    for ia in range(mol.natm):
+        symb = mol.atom_symbol(ia)
+        if symb in basis:
+            continue
+        nuc = _mole.charge(symb)
+        if nuc >= len(NRSRHF_CONFIGURATION):
+            raise NotImplementedError('minao guess: element table covers H-Ne')
+        ano = _mole.load_basis('ano', symb)
+        by_l = {}
+        for b in ano:
+            by_l.setdefault(b[0], b)
+        occ, bas = [], []
+        for l in range(4):
+            ne = NRSRHF_CONFIGURATION[nuc][l]
+            nd = (2 * l + 1) * 2
+            ndocc, frac = (ne // nd, (float(ne) / nd - ne // nd) * 2) if ne > 0 else (0, 0)
+            if l not in by_l:
+                continue
+            occ.append(np.repeat([2.] * ndocc + [frac], 2 * l + 1))
+            bas.append([l] + [row[:1] + row[1:ndocc + 2] for row in by_l[l][1:]])
+        basis[symb] = bas
+        occdic[symb] = np.hstack(occ)
+    occ = np.hstack([occdic[mol.atom_symbol(ia)] for ia in range(mol.natm)])
+    patm, pbas, penv = _mole.make_env(mol._atom, basis, np.zeros(_mole.PTR_ENV_START))
+    atm, bas, env = _mole.conc_env(mol._atm, mol._bas, mol._env, patm, pbas, penv)
+    _, S, _ = _ovlp_kin_gpu(_FakeMol(atm, bas, env), device)
+    S = S.cpu().numpy()
+    nao = mol.nao_nr()
+    s22, s21 = S[:nao, :nao], S[:nao, nao:]
+    e, v = scipy.linalg.eigh(s22)
+    mask = e > OVERLAP_ZERO_EIGENVALUE_THRESHOLD
+    x = v[:, mask] / np.sqrt(e[mask])
+    mo = x.dot(x.T.dot(s21))
+    dm = (mo * occ).dot(mo.T)
+    return tag_array(dm, mo_coeff=mo, mo_occ=occ)
+
+
+def int1e_gpu(mol, device=None):
+    """(S, T, V) in the real-spherical AO basis from the device integral engine."""
+    import torch
+    from ..gto.moleintor import _AuxClass, _Shells, c2s_matrix
+    device = _default_device(device)
+    eng, S, T = _ovlp_kin_gpu(mol, device)
+    nao = eng.ao.nao
     # nuclear attraction: (ij| point charge) = limit of a normalised s Gaussian, eta -> infinity
     natm = len(mol._atm)
     nuc = _Shells.__new__(_Shells)

@@ -50,3 +50,18 @@ def test_df_rhf_tz_vs_oracle():
         return vj - .5 * vk
     conv, e0 = ref.rhf_kernel(mol, veff, conv_tol=1e-10)[:2]
     assert conv and abs(e - e0) < 1e-8, (e, e0)
+
+
+def test_golden_minao_guess():
+    """Docstring example of init_guess_by_minao (pyscf/scf/hf.py:363-368): H2 / sto-3g."""
+    from pyscf_amd import gto
+    from pyscf_amd.scf import hf
+    mol = gto.M(atom='H 0 0 0; H 0 0 1.1', basis='sto-3g')
+    dm = hf.init_guess_by_minao(mol)
+    want = np.array([[0.94758917, 0.09227308], [0.09227308, 0.94758917]])
+    assert np.abs(dm - want).max() < 1e-8
+    # water: the guess carries (about) the right number of electrons
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    dm = hf.init_guess_by_minao(mol)
+    s = hf.int1e_gpu(mol)[0]
+    assert abs(np.einsum('ij,ji', dm, s) - 10) < 0.05

@@ -20,6 +20,7 @@ FILES = {
     'def2universaljkfit': 'def2-universal-jkfit.dat',
     'def2universaljfit': 'def2-universal-jfit.dat',
     'ccpvdzri': 'cc-pvdz-ri.dat',
+    'ano': 'ano.dat',      # ANO-RCC tables: source of the MINAO initial guess (scf/hf.py:354-488)
 }
 ELEMENTS = ['H', 'He', 'Li', 'Be', 'B', 'C', 'N', 'O', 'F', 'Ne']
 
