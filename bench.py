@@ -149,18 +149,29 @@ def main():
     for name, (tot, cnt) in ksum.items():
         kern[name] = {'ms_total': round(tot, 4), 'launches': cnt, 'ms_avg': round(tot / cnt, 4)}
     dom = max(ksum, key=lambda k: ksum[k][0])
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # profiles/r01/pmc_summary.json; KiB per launch as reported, no half-count correction applied because
+    # the 8-byte-per-lane streaming pattern calibrates to 1.00x on vj_pass1)
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))['kernels']
+        pk = {'e2_symm': 'e2_symm', 'dgemm_tn': 'gemm_tn_glds_kernel', 'vj_pass1': 'vj_pass1_rows_kernel',
+              'vj_pass2': 'vj_pass2_kernel'}[dom]
+        traffic = (pm[pk]['FETCH_SIZE_KiB_per_launch_mean'] + pm[pk]['WRITE_SIZE_KiB_per_launch_mean']) * 1024.0
+    except Exception:
+        pass
     dtot, dcnt = ksum[dom]
     if dom in ('e2_symm', 'dgemm_tn'):
         fl = flops_e2 if dom == 'e2_symm' else flops_syrk
         ach = fl / (dtot * 1e-3) / 1e12
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(ach / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                    'unit': 'TFLOP/s', 'frac': round(ach / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                     'avg_launch_ms': round(dtot / dcnt, 4), 'launches': dcnt,
                     'flops_per_step': fl}
     else:
         ach = bytes_j / (dtot * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
                     'avg_launch_ms': round(dtot / dcnt, 4), 'launches': dcnt}
     # HBM GB/s of the J kernels (the metric's second figure): one algorithmic read of B per pass
     j_gbs = {}
