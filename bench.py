@@ -186,7 +186,7 @@ def main():
 
     cpu = None
     parity = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
         from oracle import ref
         nrow = min(args.cpu_sample_rows, naux_local)
         sample = dfobj._cderi_dev[:nrow].cpu().numpy()

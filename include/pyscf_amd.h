@@ -83,6 +83,14 @@ int PAMD_int1e_ovlp_kin(const int *d_l, const int *d_ao0, const int *d_prim0, co
 int PAMD_cderi_solve(const double *d_linvT, int lda, const double *d_T, long ldT, double *d_cderi,
                      long ldc, int nL, long npq, int naux, int l_off, int triangular, void *stream);
 
+/* integral-direct J (df/df_jk.py:415-506 get_j; screens of lib/vhf/optimizer.c:305-349 replaced by the
+ * primitive-pair screening of the pair tables): contract a generated slab T[row][Q] in place */
+long PAMD_vj_direct_pass1_worksize(long nrows, int naux);
+int PAMD_vj_direct_pass1(const double *d_T, long ldT, long nrows, int naux, const double *d_dmtril_rows,
+                         double *d_part, void *stream);                 /* part[chunk][Q] = sum_r T[r][Q] d[r] */
+int PAMD_vj_direct_pass2(const double *d_T, long ldT, long nrows, int naux, const double *d_rho,
+                         double *d_vj_rows, void *stream);              /* vj[r] = sum_Q T[r][Q] rho[Q]        */
+
 /* ---- J/K contraction ------------------------------------------------------------------------ */
 int PAMD_pack_dm_tril(const double *d_dm, int nset, int nao, double *d_tril, void *stream);
 long PAMD_df_vj_pass1_worksize(long npair, int naux, int nset);           /* doubles of d_work */

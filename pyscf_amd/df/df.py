@@ -33,6 +33,8 @@ class DF:
         self.k_block_bytes = 8 << 30
         self.k_nsplit = 4
         self.lindep = 1e-7         # pyscf/df/incore.py:33
+        self.incore_anyway = False  # mol.incore_anyway analogue (df_jk.py:282): force the tensor path
+        self._eng = None
         self.overlap_jk = True     # run J (HBM-bound) on a second stream beside K (MFMA-bound)
         self.kernel_timer = None   # df_jk.KernelTimer() to collect per-kernel HIP-event timings
         self._ws = {}
@@ -68,6 +70,40 @@ class DF:
             self._side = torch.cuda.Stream(device=self._cderi_dev.device)
         return self._side
 
+    # -- integral-direct J support (no tensor) ---------------------------------------------------
+    def _direct_engine(self):
+        """(IntEngine, lower Cholesky factor of j2c) cached for df_jk.get_j."""
+        if getattr(self, '_eng', None) is None:
+            import scipy.linalg
+            from ..gto.moleintor import IntEngine
+            if self.auxmol is None:
+                self.auxmol = addons.make_auxmol(self.mol, self.auxbasis)
+            self._eng = IntEngine(self.mol, self.auxmol, self._device())
+            j2c = self._eng.int2c2e().cpu().numpy()
+            self._j2c_low = scipy.linalg.cholesky((j2c + j2c.T) * .5, lower=True)
+            self._naux = self._eng.aux.nao
+        return self._eng, self._j2c_low
+
+    def _direct_slabs(self, eng, slab_bytes=8 << 30):
+        naux = eng.aux.nao
+        max_rows = max(int(slab_bytes // (naux * 8)), 1)
+        slabs, sh0, nsh = [], 0, eng.ao.n
+        while sh0 < nsh:
+            sh1 = sh0 + 1
+            while sh1 < nsh and eng.slab_rows(sh0, sh1 + 1)[1] - eng.slab_rows(sh0, sh1 + 1)[0] <= max_rows:
+                sh1 += 1
+            slabs.append((sh0, sh1))
+            sh0 = sh1
+        return slabs
+
+    def _direct_buffer(self, rows, naux, dev):
+        import torch
+        buf = self._ws.get('T')
+        if buf is None or buf.numel() < rows * naux or buf.device != dev:
+            buf = torch.empty(rows * naux, dtype=torch.float64, device=dev)
+            self._ws['T'] = buf
+        return buf[:rows * naux].view(rows, naux)
+
     def _workspace(self, name, shape):
         """Persistent HBM scratch (no per-iteration hipMalloc): returns a view of `shape`."""
         import torch
@@ -98,6 +134,7 @@ class DF:
         self._cderi_dev = None
         self._naux = None
         self._ws = {}
+        self._eng = None
         return self
 
     def _device(self):

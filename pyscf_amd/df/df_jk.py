@@ -197,6 +197,62 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
     return vk
 
 
+def get_j(dfobj, dm, hermi=0, direct_scf_tol=1e-13):
+    """Integral-direct J without the 3-index tensor (pyscf/df/df_jk.py:415-506): pass 1
+    gamma_Q = sum_pq (pq|Q) D_pq over freshly generated AO-row slabs (:473-478), rho = j2c^-1 gamma by
+    cho_solve on the host (:481-484), pass 2 J_pq = sum_Q (pq|Q) rho_Q (:493-502).  With several ranks the
+    slabs are dealt round-robin and gamma / J are all-reduced."""
+    import scipy.linalg
+    torch = _torch()
+    lib = _lib_mod.load_library()
+    dms = np.asarray(dm)
+    shape = dms.shape
+    nao = shape[-1]
+    dms = np.ascontiguousarray(dms.reshape(-1, nao, nao), dtype=np.float64)
+    nset = len(dms)
+    eng, low = dfobj._direct_engine()
+    dev = eng.device
+    naux = eng.aux.nao
+    npair = nao * (nao + 1) // 2
+    st = _stream()
+    dms_dev = torch.from_numpy(dms).to(dev)
+    dmtril = torch.empty((nset, npair), dtype=torch.float64, device=dev)
+    for s0 in range(0, nset, 4):
+        ns = min(4, nset - s0)
+        _call(dfobj, 'pack_dm_tril', lib.PAMD_pack_dm_tril, _ptr(dms_dev[s0:s0 + ns]), _c.c_int(ns), _c.c_int(nao),
+              _ptr(dmtril[s0:s0 + ns]), st)
+    slabs = dfobj._direct_slabs(eng)
+    rank, world = dfobj.rank, dfobj.world_size
+    bufrows = max(eng.slab_rows(a, b)[1] - eng.slab_rows(a, b)[0] for a, b in slabs)
+    T = dfobj._direct_buffer(bufrows, naux, dev)
+    gamma = torch.zeros((nset, naux), dtype=torch.float64, device=dev)
+    for i, (sh0, sh1) in enumerate(slabs):
+        if i % world != rank:
+            continue
+        r0, r1 = eng.slab_rows(sh0, sh1)
+        Tv = eng.int3c2e_slab(sh0, sh1, out=T)
+        nchunk = lib.PAMD_vj_direct_pass1_worksize(_c.c_long(r1 - r0), _c.c_int(naux)) // naux
+        part = torch.empty((nchunk, naux), dtype=torch.float64, device=dev)
+        for s in range(nset):
+            _call(dfobj, 'vj_direct_pass1', lib.PAMD_vj_direct_pass1, _ptr(Tv), _c.c_long(naux), _c.c_long(r1 - r0),
+                  _c.c_int(naux), _ptr(dmtril[s, r0:r1]), _ptr(part), st)
+            gamma[s] += part.sum(dim=0)
+    _allreduce(dfobj, [gamma])
+    rho_h = scipy.linalg.cho_solve((low, True), gamma.cpu().numpy().T).T
+    rho = torch.from_numpy(np.ascontiguousarray(rho_h)).to(dev)
+    vjtril = torch.zeros((nset, npair), dtype=torch.float64, device=dev)
+    for i, (sh0, sh1) in enumerate(slabs):
+        if i % world != rank:
+            continue
+        r0, r1 = eng.slab_rows(sh0, sh1)
+        Tv = eng.int3c2e_slab(sh0, sh1, out=T)
+        for s in range(nset):
+            _call(dfobj, 'vj_direct_pass2', lib.PAMD_vj_direct_pass2, _ptr(Tv), _c.c_long(naux), _c.c_long(r1 - r0),
+                  _c.c_int(naux), _ptr(rho[s]), _ptr(vjtril[s, r0:r1]), st)
+    _allreduce(dfobj, [vjtril])
+    return _lib_mod.unpack_tril(vjtril.cpu().numpy(), 1).reshape(shape)
+
+
 def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
     """Device-resident J/K build: inputs and outputs stay in HBM.
       dms_dev   (nset, nao, nao) f64 CUDA tensor
@@ -244,6 +300,10 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
     """Same contract as ``pyscf.df.df_jk.get_jk`` (df_jk.py:280): returns (vj, vk) shaped like dm."""
     assert with_j or with_k
     torch = _torch()
+    if (not with_k and dfobj._cderi_dev is None and dfobj._cderi is None and
+            not getattr(dfobj, 'incore_anyway', False)):
+        # 3-index tensor not initialised: integral-direct J (df_jk.py:282-285)
+        return get_j(dfobj, dm, hermi, direct_scf_tol), None
     if dfobj._cderi_dev is None:
         dfobj.build()
     dms = np.asarray(dm)

@@ -33,6 +33,18 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+def grid_block_size(ngrids, max_rows, world=1):
+    """Rows per grid block: a multiple of 256, at most `max_rows`, and such that the number of blocks
+    is a multiple of the number of ranks (blocks are dealt round-robin, block b -> rank b % world)."""
+    max_rows = max(256, max_rows // 256 * 256)
+    nblk = max(1, -(-ngrids // max_rows))
+    if world > 1:
+        nblk = max(nblk, 2 * world)
+        nblk = -(-nblk // world) * world
+    blk = _round_up(-(-ngrids // nblk), 256)
+    return max(256, min(blk, max_rows))
+
+
 class NumInt:
     """Duck-types the attributes RKS.get_veff uses (pyscf/dft/rks.py:76-131,384-404)."""
     libxc = _xc
@@ -164,8 +176,8 @@ class NumInt:
         coords_dev, weights_dev = self._grid_tables(grids, dev)
         ngrids = grids.size
         ldao = _round_up(nao, 16)
-        blk = int(self.block_bytes // (ncomp * ldao * 8))
-        blk = max(256, min(_round_up(ngrids, 256), blk // 256 * 256))
+        rank, world = self._world()
+        blk = grid_block_size(ngrids, int(self.block_bytes // (ncomp * ldao * 8)), world)
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
         f64 = torch.float64
         # +256 doubles of slack: the LDS-DMA GEMM reads whole 128-column panel rows
@@ -174,7 +186,6 @@ class NumInt:
         rho = torch.empty((4, blk), dtype=f64, device=dev)
         wv = torch.empty((4, blk), dtype=f64, device=dev)
         nsplit = 4
-        rank, world = self._world()
         fac_c = (ctypes.c_double * 7)(*fac)
         for iset in range(nset):
             use_mo = mo_coeff is not None and np.ndim(mo_occ) == 1 and nset == 1

@@ -110,3 +110,19 @@ def test_pair_tables_host_side():
         assert a0 == 0 and a1 == b0 and b1 == pc.n
     r0, r1 = eng.slab_rows(0, nsh)
     assert (r0, r1) == (0, 58 * 59 // 2)
+
+
+def test_grid_block_assignment():
+    """nr_rks deals grid blocks round-robin over the ranks: every grid point is covered exactly once and
+    the block count is a multiple of the world size (balanced)."""
+    from pyscf_amd.dft.numint import grid_block_size
+    for ngrids, max_rows, world in [(1078336, 100000, 1), (1078336, 100000, 8), (1078336, 100000, 3),
+                                    (5000, 100000, 4), (300, 1 << 20, 2)]:
+        blk = grid_block_size(ngrids, max_rows, world)
+        assert blk % 256 == 0 and 256 <= blk <= max(256, max_rows // 256 * 256)
+        starts = list(range(0, ngrids, blk))
+        covered = sum(min(blk, ngrids - g0) for g0 in starts)
+        assert covered == ngrids
+        owners = [b % world for b in range(len(starts))]
+        counts = [owners.count(r) for r in range(world)]
+        assert max(counts) - min(counts) <= 1

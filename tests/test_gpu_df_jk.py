@@ -100,3 +100,23 @@ def test_linearity_and_symmetry(h2o):
     assert np.abs(jc - (2 * ja - 3 * jb)).max() < 1e-10
     assert np.abs(kc - (2 * ka - 3 * kb)).max() < 1e-10
     assert np.abs(ja - ja.T).max() < 1e-12 and np.abs(ka - ka.T).max() < 1e-11
+
+
+def test_golden_integral_direct_get_j(h2o):
+    """J-only call before the tensor exists takes the integral-direct path and reproduces the same
+    fingerprint (pyscf/df/test/test_df_jk.py:186-195; df_jk.get_j, df_jk.py:415-506)."""
+    from pyscf_amd import df
+    mol, aux, cderi = h2o
+    obj = df.DF(mol, auxbasis='weigend')
+    np.random.seed(1)
+    dms = np.random.random((2, mol.nao, mol.nao))
+    vj, vk = obj.get_jk(dms, hermi=0, with_k=False)
+    assert vk is None and obj._cderi_dev is None          # no tensor was built
+    assert abs(ref.fp(vj) - -194.15910890730066) < 1e-9
+    vj0, _ = ref.get_jk(cderi, dms, hermi=0, with_k=False)
+    assert np.abs(vj - vj0).max() < 1e-11
+    # several slabs give the same J
+    obj2 = df.DF(mol, auxbasis='weigend')
+    obj2._direct_slabs = lambda eng: [(i, i + 1) for i in range(eng.ao.n)]
+    vj2, _ = obj2.get_jk(dms, hermi=0, with_k=False)
+    assert np.abs(vj2 - vj0).max() < 1e-11
