@@ -75,10 +75,10 @@ class DF:
         """(IntEngine, lower Cholesky factor of j2c) cached for df_jk.get_j."""
         if getattr(self, '_eng', None) is None:
             import scipy.linalg
-            from ..gto.moleintor import IntEngine
+            from ..gto.moleintor import get_engine
             if self.auxmol is None:
                 self.auxmol = addons.make_auxmol(self.mol, self.auxbasis)
-            self._eng = IntEngine(self.mol, self.auxmol, self._device())
+            self._eng = get_engine(self.mol, self.auxmol, self._device())
             j2c = self._eng.int2c2e().cpu().numpy()
             self._j2c_low = scipy.linalg.cholesky((j2c + j2c.T) * .5, lower=True)
             self._naux = self._eng.aux.nao

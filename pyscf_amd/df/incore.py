@@ -13,7 +13,7 @@ import numpy as np
 import scipy.linalg
 
 from .. import lib as _lib_mod
-from ..gto.moleintor import IntEngine
+from ..gto.moleintor import IntEngine, get_engine
 
 LINEAR_DEP_THR = 1e-7   # pyscf/df/incore.py:33
 
@@ -36,7 +36,7 @@ def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_TH
     """Rows [l0, l1) of cderi (naux, nao_pair) as a torch CUDA tensor."""
     import torch
     lib = _lib_mod.load_library()
-    eng = engine or IntEngine(mol, auxmol, device)
+    eng = engine or get_engine(mol, auxmol, device)
     naux = eng.aux.nao
     nao = eng.ao.nao
     npair = nao * (nao + 1) // 2

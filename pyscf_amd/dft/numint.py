@@ -95,8 +95,8 @@ class NumInt:
     def _shell_tables(self, mol, dev):
         key = ('shells', id(mol))
         if key not in self._cache:
-            from ..gto.moleintor import IntEngine, _dev
-            eng = IntEngine(mol, None, dev)
+            from ..gto.moleintor import get_engine, _dev
+            eng = get_engine(mol, None, dev)
             sh = eng.ao
             prim0 = np.cumsum([0] + [len(e) for e in sh.exps])[:-1].astype(np.int32)
             nprim = np.array([len(e) for e in sh.exps], np.int32)

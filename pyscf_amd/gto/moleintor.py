@@ -134,61 +134,63 @@ class _PairClass:
     """All shell pairs (a, b) with l_a = li >= l_b = lj, sorted by the row shell (the one with
     the larger AO offset) so that an AO-row slab is a contiguous sub-range."""
 
-    def __init__(self, sa, li, lj, device, sb=None, same=True):
-        # sa: _Shells of the bra;  sb: optional distinct ket shells (2-centre: the dummy shell)
-        sb_ = sa if sb is None else sb
-        ia = np.nonzero(sa.l == li)[0]
-        ib = np.nonzero(sb_.l == lj)[0]
+    def __init__(self, sa, li, lj, device):
         self.li, self.lj = li, lj
         self.n = 0
-        if len(ia) == 0 or len(ib) == 0:
+        ia_all = np.nonzero(sa.l == li)[0]
+        ib_all = np.nonzero(sa.l == lj)[0]
+        if len(ia_all) == 0 or len(ib_all) == 0:
             return
-        A, B = np.meshgrid(ia, ib, indexing='ij')
-        A, B = A.ravel(), B.ravel()
-        if same and sb is None:
-            keep = (A >= B) if li == lj else np.ones(len(A), bool)
-            A, B = A[keep], B[keep]
-        ish_l, jsh_l, pp0_l, npp_l, recs = [], [], [], [], []
-        rowshell = []
-        nrec = 0
-        rab = sa.xyz[A] - sb_.xyz[B]
-        r2 = np.einsum('ij,ij->i', rab, rab)
-        for n in range(len(A)):
-            a, b = int(A[n]), int(B[n])
-            ea, eb = sa.exps[a][:, None], sb_.exps[b][None, :]
-            ca, cb = sa.coefs[a][:, None], sb_.coefs[b][None, :]
-            zeta = ea + eb
-            mu = ea * eb / zeta
-            arg = mu * r2[n]
-            keep = arg < EXPCUTOFF
-            if not keep.any():
-                continue
-            kab = np.exp(-arg[keep]) * (ca * cb)[keep]
-            z = zeta[keep]
-            wa = (ea / zeta)[keep]
-            wb = (eb / zeta)[keep]
-            P = wa[:, None] * sa.xyz[a] + wb[:, None] * sb_.xyz[b]
-            rec = np.empty((len(z), 8))
-            rec[:, 0] = z
-            rec[:, 1:4] = P
-            rec[:, 4] = kab
-            rec[:, 5:8] = P - sa.xyz[a]
-            recs.append(rec)
-            ish_l.append(a)
-            jsh_l.append(b)
-            pp0_l.append(nrec)
-            npp_l.append(len(z))
-            nrec += len(z)
-            rowshell.append(max(a, b) if sb is None else a)
-        if not ish_l:
+        nprim = np.array([len(e) for e in sa.exps])
+        ish_l, jsh_l, npp_l, recs = [], [], [], []
+        # vectorised over groups of shells with equal primitive counts (rectangular arrays)
+        for na in np.unique(nprim[ia_all]):
+            A = ia_all[nprim[ia_all] == na]
+            EA = np.array([sa.exps[i] for i in A])            # [nA, na]
+            CA = np.array([sa.coefs[i] for i in A])
+            XA = sa.xyz[A]
+            for nb in np.unique(nprim[ib_all]):
+                B = ib_all[nprim[ib_all] == nb]
+                EB = np.array([sa.exps[i] for i in B])
+                CB = np.array([sa.coefs[i] for i in B])
+                XB = sa.xyz[B]
+                pmask = (A[:, None] >= B[None, :]) if li == lj else np.ones((len(A), len(B)), bool)
+                rab = XA[:, None, :] - XB[None, :, :]
+                r2 = np.einsum('abx,abx->ab', rab, rab)
+                zeta = EA[:, None, :, None] + EB[None, :, None, :]                 # [nA, nB, na, nb]
+                arg = EA[:, None, :, None] * EB[None, :, None, :] / zeta * r2[:, :, None, None]
+                keep = (arg < EXPCUTOFF) & pmask[:, :, None, None]
+                cnt = keep.sum(axis=(2, 3))
+                pa, pb = np.nonzero(cnt)
+                if len(pa) == 0:
+                    continue
+                ka, kb, kp, kq = np.nonzero(keep)                                 # grouped by (a, b)
+                z = zeta[ka, kb, kp, kq]
+                wa = EA[ka, kp] / z
+                P = wa[:, None] * XA[ka] + (1 - wa)[:, None] * XB[kb]
+                rec = np.empty((len(z), 8))
+                rec[:, 0] = z
+                rec[:, 1:4] = P
+                rec[:, 4] = np.exp(-arg[ka, kb, kp, kq]) * CA[ka, kp] * CB[kb, kq]
+                rec[:, 5:8] = P - XA[ka]
+                recs.append(rec)
+                ish_l.append(A[pa])
+                jsh_l.append(B[pb])
+                npp_l.append(cnt[pa, pb])
+        if not recs:
             return
-        order = np.argsort(np.array(rowshell), kind='stable')
+        ish = np.concatenate(ish_l).astype(np.int32)
+        jsh = np.concatenate(jsh_l).astype(np.int32)
+        npp = np.concatenate(npp_l).astype(np.int32)
+        pp0 = (np.cumsum(npp) - npp).astype(np.int32)
+        rowshell = np.maximum(ish, jsh)
+        order = np.argsort(rowshell, kind='stable')
         self.n = len(order)
-        self.rowshell = np.array(rowshell)[order]
-        self.ish = _dev(np.array(ish_l, np.int32)[order], device)
-        self.jsh = _dev(np.array(jsh_l, np.int32)[order], device)
-        self.pp0 = _dev(np.array(pp0_l, np.int32)[order], device)
-        self.npp = _dev(np.array(npp_l, np.int32)[order], device)
+        self.rowshell = rowshell[order]
+        self.ish = _dev(ish[order], device)
+        self.jsh = _dev(jsh[order], device)
+        self.pp0 = _dev(pp0[order], device)
+        self.npp = _dev(npp[order], device)
         self.pp = _dev(np.vstack(recs), device)
 
     def subrange(self, sh0, sh1):
@@ -343,6 +345,28 @@ class _PairClass2c(_PairClass):
         self.pp0 = _dev(np.array(pp0, np.int32), device)
         self.npp = _dev(np.array(npp, np.int32), device)
         self.pp = _dev(np.vstack(recs), device)
+
+
+_ENGINE_CACHE = {}
+
+
+def get_engine(mol, auxmol, device):
+    """IntEngine cached per (mol, auxmol, device): the shell-pair tables are the expensive host part."""
+    import torch
+    key = (id(mol), id(auxmol) if auxmol is not None else None, str(torch.device(device)))
+    ent = _ENGINE_CACHE.get(key)
+    if ent is not None and ent[0] is mol and ent[1] is auxmol:
+        return ent[2]
+    # an engine built for the same mol with another aux basis can lend its AO pair tables
+    eng = IntEngine(mol, auxmol, device)
+    for (k0, k1, k2), (m, a, e) in list(_ENGINE_CACHE.items()):
+        if m is mol and k2 == key[2] and e._pair_classes is not None:
+            eng._pair_classes = e._pair_classes
+            break
+    if len(_ENGINE_CACHE) > 8:
+        _ENGINE_CACHE.clear()
+    _ENGINE_CACHE[key] = (mol, auxmol, eng)
+    return eng
 
 
 def getints(name, atm, bas, env, shls_slice=None, hermi=0, aosym='s1'):

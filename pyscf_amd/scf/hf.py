@@ -148,6 +148,7 @@ class SCF:
     direct_scf = True
     direct_scf_tol = 1e-13
     conv_check = True
+    device_linalg = True
 
     def __init__(self, mol):
         self.mol = mol
@@ -199,6 +200,14 @@ class SCF:
     def eig(self, h, s, x=None):
         if x is None:
             e, c = scipy.linalg.eigh(h, s)
+        elif self.device_linalg and h.shape[0] >= 512 and _has_device():
+            # O(nao^3) dense algebra of the driver on the GPU (hipSOLVER through torch): not part of the
+            # hot path, but once J/K takes 0.14 s the host eigh (0.5 s at nao = 1856) would dominate
+            import torch
+            xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+            hd = torch.from_numpy(np.ascontiguousarray(h)).cuda()
+            ed, cd = torch.linalg.eigh(xd.T @ hd @ xd)
+            e, c = ed.cpu().numpy(), (xd @ cd).cpu().numpy()
         else:
             e, c = scipy.linalg.eigh(x.conj().T.dot(h).dot(x))
             c = x.dot(c)
@@ -284,6 +293,14 @@ NRSRHF_CONFIGURATION = [[0, 0, 0, 0], [1, 0, 0, 0], [2, 0, 0, 0], [3, 0, 0, 0], 
                         [4, 2, 0, 0], [4, 3, 0, 0], [4, 4, 0, 0], [4, 5, 0, 0], [4, 6, 0, 0]]
 
 
+def _has_device():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except ImportError:
+        return False
+
+
 class _FakeMol:
     """(atm, bas, env) holder accepted by the integral engine."""
 
@@ -293,9 +310,9 @@ class _FakeMol:
 
 def _ovlp_kin_gpu(mol, device):
     import torch
-    from ..gto.moleintor import IntEngine, _dev
+    from ..gto.moleintor import IntEngine, get_engine, _dev
     lib = _lib_mod.load_library()
-    eng = IntEngine(mol, None, device)
+    eng = get_engine(mol, None, device) if hasattr(mol, 'nao_nr') else IntEngine(mol, None, device)
     sh = eng.ao
     nao = sh.nao
     prim0 = np.cumsum([0] + [len(e) for e in sh.exps])[:-1].astype(np.int32)
