@@ -283,6 +283,8 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
                     with torch.cuda.stream(side):
                         holder['vj'] = _vj(dfobj, lib, dms_dev, nset, nao)
                 vk_dev = _vk_mo(dfobj, lib, orb_list, nao, after_first_e2=launch_j)
+                if 'vj' not in holder:          # nothing was queued for K (empty shard / no occupied orbitals)
+                    launch_j()
                 vjtril = holder['vj']
                 torch.cuda.current_stream().wait_stream(side)
                 vjtril.record_stream(torch.cuda.current_stream())

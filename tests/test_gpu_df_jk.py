@@ -120,3 +120,40 @@ def test_golden_integral_direct_get_j(h2o):
     obj2._direct_slabs = lambda eng: [(i, i + 1) for i in range(eng.ao.n)]
     vj2, _ = obj2.get_jk(dms, hermi=0, with_k=False)
     assert np.abs(vj2 - vj0).max() < 1e-11
+
+
+def test_edge_cases_empty_shard_zero_occ_and_eig_fallback(h2o):
+    """Empty aux shard (more ranks than aux rows), a DM with no occupied orbitals, a single aux row, and
+    the eigen-decomposition fallback for a linearly dependent fitting basis (df/incore.py:153-158,263-270)."""
+    import torch
+    from pyscf_amd import df, gto, lib
+    from pyscf_amd.df import df_jk, incore
+    mol, aux, cderi = h2o
+    nao = mol.nao
+    dev = torch.device('cuda', 0)
+    # empty shard: contributes exact zeros
+    obj = df.DF(mol)
+    obj._cderi_dev = torch.zeros((0, cderi.shape[1]), dtype=torch.float64, device=dev)
+    dm = np.eye(nao)
+    vj, vk = obj.get_jk(dm, hermi=1)
+    assert np.all(vj == 0) and np.all(vk == 0)
+    # one aux row
+    obj1 = df.DF(mol)
+    obj1._cderi = cderi[:1]
+    obj1.build()
+    vj1, vk1 = obj1.get_jk(dm, hermi=1)
+    vj0, vk0 = ref.get_jk(cderi[:1], dm, 1)
+    assert np.abs(vj1 - vj0).max() < 1e-12 and np.abs(vk1 - vk0).max() < 1e-12
+    # no occupied orbitals in the tagged DM -> K = 0, J from the (zero) DM = 0
+    full = df.DF(mol)
+    full._cderi = cderi
+    full.build()
+    z = lib.tag_array(np.zeros((nao, nao)), mo_coeff=np.eye(nao), mo_occ=np.zeros(nao))
+    vjz, vkz = full.get_jk(z, hermi=1)
+    assert np.all(vjz == 0) and np.all(vkz == 0)
+    # linearly dependent aux basis (the same shells twice) -> Cholesky fails -> eig fallback, naux rows drop
+    basis2 = {'O': gto.load_basis('weigend', 'O') * 2, 'H': gto.load_basis('weigend', 'H') * 2}
+    aux2 = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis=basis2)
+    cd2 = incore.cholesky_eri_gpu(mol, aux2, dev).cpu().numpy()
+    assert cd2.shape[0] < aux2.nao                       # dependent functions were projected out
+    assert np.abs(cd2.T.dot(cd2) - cderi.T.dot(cderi)).max() < 1e-6
