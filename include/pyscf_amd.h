@@ -68,6 +68,7 @@ typedef struct PAMD_int3c2e_args {
     long row_offset;            /* subtracted from the packed-tril row index                     */
     int tril;                   /* 1: rows = packed-tril AO pairs; 0: row = AO index (2-centre)  */
     int npairs;
+    double omega;               /* > 0: erf(omega r12)/r12 (range-separated LR, gto/mole.py:76-84 PTR_RANGE_OMEGA); 0: 1/r12 */
 } PAMD_int3c2e_args;
 
 long PAMD_rys_table_len(void);

@@ -183,6 +183,12 @@ static void hermite_E(int la, int lb, double a, double b, double Ax, double Bx, 
 #define NR (4 * LMAX + 1)
 typedef struct { double v[NR][NR][NR]; } Rarr;
 
+/* long-range attenuation erf(omega r12)/r12 (env[PTR_RANGE_OMEGA], pyscf/gto/mole.py:76-84): the Boys
+ * moments become theta^(n+1/2) F_n(theta x) with theta = omega^2/(omega^2 + alpha).  Set only around
+ * the 2e integral calls by oracle/ref.py (never for the nuclear attraction). */
+static double g_omega = 0.0;
+void oracle_set_omega(double omega) { g_omega = omega; }
+
 static void hermite_R(int N, double alpha, const double *PQ, Rarr *R)
 {
     int n1 = N + 1;
@@ -190,7 +196,14 @@ static void hermite_R(int N, double alpha, const double *PQ, Rarr *R)
 #define TMP(n, t, u, v) tmp[((((size_t)(n)) * n1 + (t)) * n1 + (u)) * n1 + (v)]
     double f[NR + 2];
     double x = alpha * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
-    boys(N, x, f);
+    if (g_omega > 0) {
+        double theta = g_omega * g_omega / (g_omega * g_omega + alpha);
+        boys(N, x * theta, f);
+        double th = sqrt(theta);
+        for (int n = 0; n <= N; n++) { f[n] *= th; th *= theta; }
+    } else {
+        boys(N, x, f);
+    }
     double m2a = 1;
     for (int n = 0; n <= N; n++) { TMP(n, 0, 0, 0) = m2a * f[n]; m2a *= -2 * alpha; }
     /* increasing total order L = t+u+v:  R^n_{t+1,u,v} = t R^{n+1}_{t-1,u,v} + X R^{n+1}_{t,u,v} */

@@ -90,16 +90,18 @@ def int1e(mol, kind):
     return out
 
 
-def int2c2e(auxmol):
+def int2c2e(auxmol, omega=0.0):
     atm, bas, env = _tables(auxmol)
     n = auxmol.nao_nr()
     out = np.zeros((n, n))
+    lib().oracle_set_omega(ctypes.c_double(omega))
     lib().oracle_int2c2e(_p(out), _p(atm), ctypes.c_int(len(atm)), _p(bas), ctypes.c_int(0),
                          ctypes.c_int(len(bas)), _p(env))
+    lib().oracle_set_omega(ctypes.c_double(0.0))
     return out
 
 
-def int3c2e(mol, auxmol):
+def int3c2e(mol, auxmol, omega=0.0):
     """(naux, nao, nao) s1 tensor == reference's int3c2e_sph viewed as [k][i][j]."""
     from pyscf_amd.gto import conc_env
     atm, bas, env = conc_env(mol._atm, mol._bas, mol._env, auxmol._atm, auxmol._bas, auxmol._env)
@@ -108,17 +110,21 @@ def int3c2e(mol, auxmol):
     env = np.ascontiguousarray(env)
     nao, naux = mol.nao_nr(), auxmol.nao_nr()
     out = np.zeros((naux, nao, nao))
+    lib().oracle_set_omega(ctypes.c_double(omega))
     lib().oracle_int3c2e(_p(out), _p(atm), ctypes.c_int(len(atm)), _p(bas),
                          ctypes.c_int(mol.nbas), ctypes.c_int(auxmol.nbas), _p(env))
+    lib().oracle_set_omega(ctypes.c_double(0.0))
     return out
 
 
-def int2e(mol):
+def int2e(mol, omega=0.0):
     atm, bas, env = _tables(mol)
     n = mol.nao_nr()
     out = np.zeros((n, n, n, n))
+    lib().oracle_set_omega(ctypes.c_double(omega))
     lib().oracle_int2e(_p(out), _p(atm), ctypes.c_int(len(atm)), _p(bas),
                        ctypes.c_int(len(bas)), _p(env))
+    lib().oracle_set_omega(ctypes.c_double(0.0))
     return out
 
 
@@ -126,10 +132,10 @@ def int2e(mol):
 LINEAR_DEP_THR = 1e-7  # pyscf/df/incore.py:33
 
 
-def cholesky_eri(mol, auxmol, lindep=LINEAR_DEP_THR):
+def cholesky_eri(mol, auxmol, lindep=LINEAR_DEP_THR, omega=0.0):
     """cderi (naux, nao_pair), B = L^-1 (Q|pq)   (pyscf/df/incore.py:129-220)."""
-    j2c = int2c2e(auxmol)
-    j3c = pack_tril(int3c2e(mol, auxmol))         # (naux, nao_pair), s2ij
+    j2c = int2c2e(auxmol, omega)
+    j3c = pack_tril(int3c2e(mol, auxmol, omega))         # (naux, nao_pair), s2ij
     try:
         low = scipy.linalg.cholesky(j2c, lower=True)
         return scipy.linalg.solve_triangular(low, j3c, lower=True, check_finite=False)

@@ -28,6 +28,7 @@ typedef struct PAMD_int3c2e_args {
     long row_offset;            // subtracted from the packed-tril row index
     int tril;                   // 1: rows are packed-tril AO pairs; 0: row = ao0_i + fi (2-centre)
     int npairs;
+    double omega;               // > 0: long-range operator erf(omega r12)/r12 (env[PTR_RANGE_OMEGA]); 0: Coulomb
 } PAMD_int3c2e_args;
 }
 namespace pamd { typedef PAMD_int3c2e_args Int3c2eArgs; }

@@ -172,9 +172,15 @@ __global__ __launch_bounds__(NTHREADS) void int3c2e_kernel(Int3c2eArgs a)
                 const double ck = a.aux_coef[kk * a.npk + kp];
                 const double ze = zeta + eta;
                 const double rho = zeta * eta / ze;
-                const double x = rho * r2;
+                // long-range attenuation erf(omega r)/r: the t-integral stops at t^2 = theta = omega^2/(omega^2+rho),
+                // i.e. x -> theta x, roots -> theta u, weights -> sqrt(theta) w
+                const double theta = (a.omega > 0) ? a.omega * a.omega / (a.omega * a.omega + rho) : 1.0;
+                const double x = rho * r2 * theta;
                 // ---- phase 1: roots and weights, dealt over the S lanes
-                for (int q = s; q < 2 * NR; q += S) rw[q] = rys_root_or_weight<NR>(a.rys_table, x, q);
+                for (int q = s; q < 2 * NR; q += S) {
+                    const double v = rys_root_or_weight<NR>(a.rys_table, x, q);
+                    rw[q] = (q < NR) ? v * theta : v * sqrt(theta);
+                }
                 __syncthreads();
                 // ---- phase 2: 2-D integrals, unit = (root r, direction d)
                 const double fac = 2.0 * 17.493418327624862846 /* pi^2.5 */ / (zeta * eta * sqrt(ze)) * cc * ck;

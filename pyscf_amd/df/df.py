@@ -33,6 +33,8 @@ class DF:
         self.k_block_bytes = 8 << 30
         self.k_nsplit = 4
         self.lindep = 1e-7         # pyscf/df/incore.py:33
+        self.omega = 0.0           # > 0: long-range tensor (set by range_coulomb)
+        self._rsh_df = {}
         self.incore_anyway = False  # mol.incore_anyway analogue (df_jk.py:282): force the tensor path
         self._eng = None
         self.overlap_jk = True     # run J (HBM-bound) on a second stream beside K (MFMA-bound)
@@ -78,7 +80,7 @@ class DF:
             from ..gto.moleintor import get_engine
             if self.auxmol is None:
                 self.auxmol = addons.make_auxmol(self.mol, self.auxbasis)
-            self._eng = get_engine(self.mol, self.auxmol, self._device())
+            self._eng = get_engine(self.mol, self.auxmol, self._device(), self.omega)
             j2c = self._eng.int2c2e().cpu().numpy()
             self._j2c_low = scipy.linalg.cholesky((j2c + j2c.T) * .5, lower=True)
             self._naux = self._eng.aux.nao
@@ -162,7 +164,7 @@ class DF:
         self._naux = self.auxmol.nao_nr()
         l0, l1 = self.shard_range(self._naux, self.rank, self.world_size)
         self._cderi_dev = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1,
-                                                  lindep=self.lindep)
+                                                  lindep=self.lindep, omega=self.omega)
         return self
 
     def get_naoaux(self):
@@ -180,9 +182,25 @@ class DF:
         for b0 in range(0, n, blksize):
             yield self._cderi_dev[b0:b0 + blksize].cpu().numpy()
 
+    def range_coulomb(self, omega):
+        """DF object holding the long-range (erf(omega r12)/r12) tensor, cached per omega
+        (pyscf/df/df.py:298-333)."""
+        if omega is None or omega == 0:
+            return self
+        if omega < 0:
+            raise NotImplementedError('short-range (omega < 0) density fitting')
+        key = '%.6f' % omega
+        if key not in self._rsh_df:
+            obj = DF(self.mol, self.auxbasis, self.device, self.group)
+            obj.omega = float(omega)
+            obj.auxmol = self.auxmol
+            obj.k_block_bytes, obj.k_nsplit, obj.lindep = self.k_block_bytes, self.k_nsplit, self.lindep
+            self._rsh_df[key] = obj
+        return self._rsh_df[key]
+
     def get_jk(self, dm, hermi=1, with_j=True, with_k=True, direct_scf_tol=1e-13, omega=None):
-        if omega is not None:
-            raise NotImplementedError('range-separated Coulomb (omega) - SURVEY.md §8f row 3')
+        if omega is not None and omega != 0:
+            return df_jk.get_jk(self.range_coulomb(omega), dm, hermi, with_j, with_k, direct_scf_tol)
         return df_jk.get_jk(self, dm, hermi, with_j, with_k, direct_scf_tol)
 
 

@@ -32,11 +32,11 @@ def _decompose_j2c(j2c, lindep):
 
 
 def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_THR,
-                     slab_bytes=24 << 30, engine=None, return_engine=False):
+                     slab_bytes=24 << 30, engine=None, return_engine=False, omega=0.0):
     """Rows [l0, l1) of cderi (naux, nao_pair) as a torch CUDA tensor."""
     import torch
     lib = _lib_mod.load_library()
-    eng = engine or get_engine(mol, auxmol, device)
+    eng = engine or get_engine(mol, auxmol, device, omega)
     naux = eng.aux.nao
     nao = eng.ao.nao
     npair = nao * (nao + 1) // 2
@@ -86,9 +86,9 @@ def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_TH
     return cderi
 
 
-def aux_e2_gpu(mol, auxmol, device):
+def aux_e2_gpu(mol, auxmol, device, omega=0.0):
     """(naux, nao_pair) s2ij tensor of raw 3-centre integrals (df.incore.aux_e2 analogue,
     pyscf/df/incore.py:40-70), transposed to the cderi layout; for tests."""
-    eng = IntEngine(mol, auxmol, device)
+    eng = IntEngine(mol, auxmol, device, omega)
     T = eng.int3c2e_slab(0, eng.ao.n)
     return T.T.contiguous()

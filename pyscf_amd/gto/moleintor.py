@@ -106,7 +106,7 @@ class _Args(ctypes.Structure):
                 ('rys_table', ctypes.c_void_p),
                 ('c2s', ctypes.c_void_p), ('c2s_off', ctypes.c_void_p),
                 ('T', ctypes.c_void_p), ('ldT', ctypes.c_long), ('row_offset', ctypes.c_long),
-                ('tril', ctypes.c_int), ('npairs', ctypes.c_int)]
+                ('tril', ctypes.c_int), ('npairs', ctypes.c_int), ('omega', ctypes.c_double)]
 
 
 class _AuxClass:
@@ -202,10 +202,13 @@ class _PairClass:
 class IntEngine:
     """Device-resident tables for (ij|k), (P|Q) over mol / auxmol."""
 
-    def __init__(self, mol, auxmol, device):
+    def __init__(self, mol, auxmol, device, omega=0.0):
         import torch
         self.torch = torch
         self.device = device
+        if omega < 0:
+            raise NotImplementedError('short-range (omega < 0) integrals')
+        self.omega = float(omega)
         self.lib = _lib_mod.load_library()
         self.ao = _Shells(mol._atm, mol._bas, mol._env)
         self.aux = _Shells(auxmol._atm, auxmol._bas, auxmol._env) if auxmol is not None else None
@@ -269,6 +272,7 @@ class IntEngine:
         a.row_offset = row_offset
         a.tril = tril
         a.npairs = i1 - i0
+        a.omega = getattr(self, '_omega_override', self.omega)
         st = ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
         _lib_mod.check(self.lib.PAMD_int3c2e_class(ctypes.c_int(pc.li), ctypes.c_int(pc.lj),
                                                    ctypes.c_int(ac.l), ctypes.byref(a), st))
@@ -350,17 +354,17 @@ class _PairClass2c(_PairClass):
 _ENGINE_CACHE = {}
 
 
-def get_engine(mol, auxmol, device):
-    """IntEngine cached per (mol, auxmol, device): the shell-pair tables are the expensive host part."""
+def get_engine(mol, auxmol, device, omega=0.0):
+    """IntEngine cached per (mol, auxmol, device, omega): the shell-pair tables are the expensive host part."""
     import torch
-    key = (id(mol), id(auxmol) if auxmol is not None else None, str(torch.device(device)))
+    key = (id(mol), id(auxmol) if auxmol is not None else None, str(torch.device(device)) + '|%.6f' % omega)
     ent = _ENGINE_CACHE.get(key)
     if ent is not None and ent[0] is mol and ent[1] is auxmol:
         return ent[2]
     # an engine built for the same mol with another aux basis can lend its AO pair tables
-    eng = IntEngine(mol, auxmol, device)
+    eng = IntEngine(mol, auxmol, device, omega)
     for (k0, k1, k2), (m, a, e) in list(_ENGINE_CACHE.items()):
-        if m is mol and k2 == key[2] and e._pair_classes is not None:
+        if m is mol and k2.split('|')[0] == key[2].split('|')[0] and e._pair_classes is not None:
             eng._pair_classes = e._pair_classes
             break
     if len(_ENGINE_CACHE) > 8:

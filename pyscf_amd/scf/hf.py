@@ -405,8 +405,10 @@ def int1e_gpu(mol, device=None):
     ac = _AuxClass(nuc, 0, device)
     npair = nao * (nao + 1) // 2
     V3 = torch.zeros((npair, natm), dtype=torch.float64, device=device)
+    eng._omega_override = 0.0            # nuclear attraction is always the bare Coulomb operator
     for pc in eng.pair_classes():
         eng._launch(pc, 0, pc.n, ac, V3, natm, 0, 1, eng.ao_xyz, eng.ao_ao0)
+    del eng._omega_override
     vtril = V3.sum(dim=1).cpu().numpy()
     V = _lib_mod.unpack_tril(vtril, 1)
     return S.cpu().numpy(), T.cpu().numpy(), V

@@ -57,3 +57,32 @@ def test_all_classes_low_symmetry(basis, auxbasis):
     want = ref.pack_tril(ref.int3c2e(mol, aux))
     err = np.abs(got - want).max()
     assert err < 1e-11 * max(1.0, np.abs(want).max()), err
+
+
+def test_long_range_integrals_and_rsh_get_jk(h2o_dz):
+    """omega > 0: erf(omega r12)/r12 integrals vs the oracle (tight), and DF.get_jk(dm, omega=1.1) vs the
+    reference fingerprints (3 places, pyscf/df/test/test_df.py:101-117)."""
+    from pyscf_amd import gto, df
+    from pyscf_amd.df import incore
+    from pyscf_amd.gto.moleintor import IntEngine
+    from tests.conftest import H2O
+    mol = gto.M(atom=LOWSYM, basis='cc-pvtz', spin=1)
+    aux = gto.M(atom=LOWSYM, basis='cc-pvtz-jkfit', spin=1)
+    for omega in (0.3, 1.1):
+        got = incore.aux_e2_gpu(mol, aux, _dev(), omega=omega).cpu().numpy()
+        want = ref.pack_tril(ref.int3c2e(mol, aux, omega))
+        assert np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max())
+        j2c = IntEngine(mol, aux, _dev(), omega).int2c2e().cpu().numpy()
+        w2 = ref.int2c2e(aux, omega)
+        assert np.abs(j2c - w2).max() < 1e-11 * np.abs(w2).max()
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    obj = df.DF(mol)
+    np.random.seed(1)
+    dm = np.random.random((2, mol.nao, mol.nao))
+    vj, vk = obj.get_jk(dm, hermi=0, omega=1.1)
+    assert abs(ref.fp(vj) - -181.5033531437091) < 5e-4
+    assert abs(ref.fp(vk) - -37.78854217974532) < 5e-4
+    vj0, vk0 = obj.get_jk(dm, hermi=0)                       # the Coulomb tensor is a separate object
+    assert abs(ref.fp(vj0) - ref.fp(vj)) > 1.0
+    with pytest.raises(NotImplementedError):
+        obj.get_jk(dm, hermi=0, omega=-0.5)

@@ -76,3 +76,20 @@ def test_exact_rhf_energy(data):
         return vj - .5 * vk
     conv, e = ref.rhf_kernel(mol, veff)[:2]
     assert conv and abs(e - -76.026765673119627) < 1e-8
+
+
+def test_long_range_df_jk_golden():
+    """Range-separated (omega = 1.1) DF J/K: lib.fp(vj) = -181.5033531437091, lib.fp(vk) = -37.78854217974532
+    to 3 places (the reference itself quotes 1e-4 reproducibility: the LR metric is linearly dependent and
+    goes through the eig fallback), and DF vs exact LR J/K within 1e-2 (pyscf/df/test/test_df.py:101-117)."""
+    from pyscf_amd import gto, df
+    from tests.conftest import H2O
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    cd = ref.cholesky_eri(mol, df.make_auxmol(mol), omega=1.1)
+    np.random.seed(1)
+    dm = np.random.random((2, mol.nao, mol.nao))
+    vj, vk = ref.get_jk(cd, dm, hermi=0)
+    assert abs(ref.fp(vj) - -181.5033531437091) < 5e-4
+    assert abs(ref.fp(vk) - -37.78854217974532) < 5e-4
+    vj1, vk1 = ref.get_jk_exact(ref.int2e(mol, omega=1.1), dm)
+    assert np.abs(vj - vj1).max() < 1e-2 and np.abs(vk - vk1).max() < 1e-2
