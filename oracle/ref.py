@@ -290,3 +290,44 @@ def rhf_kernel(mol, get_veff, conv_tol=1e-10, max_cycle=60, dm0=None, h1e=None, 
             conv = True
             break
     return conv, e_tot, e, c, mo_occ, dm
+
+
+def uhf_kernel(mol, cderi, nelec, conv_tol=1e-10, max_cycle=80):
+    """Minimal DF-UHF loop with the oracle pieces (pyscf/scf/uhf.py semantics: V_s = J[Da+Db] - K[Ds])."""
+    h1e = int1e(mol, 'kin') + int1e(mol, 'nuc')
+    s1e = int1e(mol, 'ovlp')
+    enuc = mol.energy_nuc()
+    w, v = scipy.linalg.eigh(s1e)
+    x = v[:, w > 1e-6] / np.sqrt(w[w > 1e-6])
+
+    def eig(f):
+        e, c = scipy.linalg.eigh(x.T.dot(f).dot(x))
+        return e, x.dot(c)
+    e0, c0 = eig(h1e)
+    cs = [c0, c0]
+    diis_f, diis_e = [], []
+    e_tot = 0
+    for cycle in range(max_cycle):
+        dms = np.array([cs[s][:, :nelec[s]].dot(cs[s][:, :nelec[s]].T) for s in range(2)])
+        vj, vk = get_jk(cderi, dms, 1)
+        vhf = vj[0] + vj[1] - vk
+        e_last = e_tot
+        e_tot = np.einsum('ij,ji', h1e, dms[0] + dms[1]) + .5 * sum(np.einsum('ij,ji', vhf[s], dms[s]) for s in range(2)) + enuc
+        f = h1e + vhf
+        err = np.hstack([x.T.dot(f[s].dot(dms[s]).dot(s1e) - s1e.dot(dms[s]).dot(f[s])).dot(x).ravel() for s in range(2)])
+        if abs(e_tot - e_last) < conv_tol and np.linalg.norm(err) < 1e-5:
+            return True, e_tot
+        diis_f.append(f); diis_e.append(err)
+        diis_f, diis_e = diis_f[-8:], diis_e[-8:]
+        n = len(diis_f)
+        h = np.zeros((n + 1, n + 1)); h[0, 1:] = h[1:, 0] = 1
+        for i in range(n):
+            for j in range(n):
+                h[i + 1, j + 1] = diis_e[i].dot(diis_e[j])
+        g = np.zeros(n + 1); g[0] = 1
+        ww, vv = scipy.linalg.eigh(h)
+        idx = abs(ww) > 1e-14
+        c = np.dot(vv[:, idx] * (1. / ww[idx]), vv[:, idx].T.dot(g))
+        f = sum(ci * fi for ci, fi in zip(c[1:], diis_f))
+        cs = [eig(f[s])[1] for s in range(2)]
+    return False, e_tot

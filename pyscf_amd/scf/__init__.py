@@ -1,5 +1,6 @@
 from . import hf
 from .hf import RHF, SCF
+from .uhf import UHF
 
 
 def density_fit(mf, auxbasis=None, with_df=None):

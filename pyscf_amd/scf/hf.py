@@ -45,11 +45,18 @@ class CDIIS:
         self.Corth = None
         self._f, self._e = [], []
 
-    def update(self, s, d, f):
+    def _errvec(self, s, d, f):
         sdf = s.dot(d).dot(f)
         err = sdf.conj().T - sdf
         if self.Corth is not None:
             err = self.Corth.conj().T.dot(err).dot(self.Corth)
+        return err
+
+    def update(self, s, d, f):
+        if f.ndim == 3:                                  # UHF: (alpha, beta) errors side by side
+            err = np.hstack([self._errvec(s, d[i], f[i]).ravel() for i in range(len(f))])
+        else:
+            err = self._errvec(s, d, f)
         self._f.append(f.copy())
         self._e.append(err.ravel())
         if len(self._f) > self.space:

@@ -65,3 +65,33 @@ def test_golden_minao_guess():
     dm = hf.init_guess_by_minao(mol)
     s = hf.int1e_gpu(mol)[0]
     assert abs(np.einsum('ij,ji', dm, s) - 10) < 0.05
+
+
+def test_golden_df_uhf_and_open_shell_vs_oracle():
+    """DF-UHF closed shell = -76.025936299702536 (pyscf/df/test/test_df_jk.py:62-64); open-shell cation
+    (2 DMs per J/K call through the MO branch) vs the oracle energy functional to 1e-8 Eh."""
+    from pyscf_amd import gto, scf, df
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    mf = scf.UHF(mol).density_fit(auxbasis='weigend')
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    assert mf.converged and abs(e - -76.025936299702536) < 1e-8
+    assert abs(mf.spin_square()) < 1e-8
+    cat = gto.M(atom=H2O, basis='cc-pvdz', charge=1, spin=1)
+    mf = scf.UHF(cat).density_fit(auxbasis='weigend')
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    # the oracle's own UHF loop may land on another stationary state for the open-shell cation, so parity
+    # is checked at the product's converged orbitals: oracle energy functional and oracle orbital gradient
+    cderi = ref.cholesky_eri(cat, df.make_auxmol(cat, 'weigend'))
+    dm = np.asarray(mf.make_rdm1())
+    h1e = ref.int1e(cat, 'kin') + ref.int1e(cat, 'nuc')
+    vj, vk = ref.get_jk(cderi, dm, 1)
+    vhf = vj[0] + vj[1] - vk
+    e0 = (np.einsum('ij,ji', h1e, dm[0] + dm[1]) + .5 * sum(np.einsum('ij,ji', vhf[s], dm[s]) for s in range(2))
+          + cat.energy_nuc())
+    assert mf.converged and abs(e - e0) < 1e-8, (e, e0)
+    g = mf.get_grad(mf.mo_coeff, mf.mo_occ, h1e + vhf)
+    assert np.linalg.norm(g) < 1e-4
+    assert 0.75 < mf.spin_square() < 0.77
+    assert e < -75.626515724371814          # below the ROHF energy of the same cation (test_df_jk.py:72-78)
