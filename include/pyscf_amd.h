@@ -133,6 +133,10 @@ int PAMD_rho_from_dm(const double *d_ao, const double *d_c0t, int nao, int ldao,
  * d_acc[0] += sum w rho, d_acc[1] += sum w e_xc; d_exc nullable */
 int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double *d_weights, long ng,
                  long ldg, double *d_wv, double *d_exc, double *d_acc, void *stream);
+/* spin-polarised variant for nr_uks (dft/numint.py:1192-1324): d_acc3 = {nelec_a, nelec_b, exc} */
+int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
+                     const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,
+                     void *stream);
 int PAMD_scale_ao(const double *d_ao, const double *d_wv, int ldao, long ldg_rows, long ldg, int ncomp,
                   long ng, long nrows, double *d_aow, void *stream);     /* aow[g][ldao], rows ng..nrows-1 zero */
 int PAMD_dgemm_nt(const double *d_A, long lda, const double *d_B, long ldb, double *d_C, int ldc, int m,

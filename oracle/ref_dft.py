@@ -261,3 +261,164 @@ def rks_energy(mol, xc_fac, hyb, gga, coords, weights, get_jk, conv_tol=1e-10, v
         state['nelec'] = n
         return v
     return ref.rhf_kernel(mol, veff, conv_tol=conv_tol, verbose=verbose, e2_fn=lambda: state['e2'])
+
+
+# ============================================================================ spin-polarised (UKS)
+_FUNCS_POL = None
+
+
+def _build_functionals_pol():
+    """e(rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb) per unit volume and its 5 first derivatives."""
+    import sympy as sp
+    ra, rb, saa, sab, sbb = sp.symbols('ra rb saa sab sbb', positive=True)
+    pi = sp.pi
+    rho = ra + rb
+    sig = saa + 2 * sab + sbb
+    zeta = (ra - rb) / rho
+    out = {}
+    cx = sp.Rational(3, 2) * (3 / (4 * pi)) ** sp.Rational(1, 3)
+    out['slater'] = -cx * (ra ** sp.Rational(4, 3) + rb ** sp.Rational(4, 3))
+
+    def vwn_eps(A, x0, b, c):
+        rs = (3 / (4 * pi * rho)) ** sp.Rational(1, 3)
+        x = sp.sqrt(rs)
+        Q = sp.sqrt(4 * c - b * b)
+        X = x * x + b * x + c
+        X0 = x0 * x0 + b * x0 + c
+        at = sp.atan(Q / (2 * x + b))
+        return A * (sp.log(x * x / X) + 2 * b / Q * at -
+                    b * x0 / X0 * (sp.log((x - x0) ** 2 / X) + 2 * (b + 2 * x0) / Q * at))
+    F = lambda v: sp.Float(v, 20)
+    fz = ((1 + zeta) ** sp.Rational(4, 3) + (1 - zeta) ** sp.Rational(4, 3) - 2) / (2 ** sp.Rational(4, 3) - 2)
+    fpp = sp.Rational(4, 9) / (2 ** sp.Rational(1, 3) - 1)
+    A_alpha = -1 / (6 * pi ** 2)
+
+    def vwn(para, ferro, alpha):
+        eP, eF, eA = vwn_eps(*para), vwn_eps(*ferro), vwn_eps(*alpha)
+        return rho * (eP + eA * fz / fpp * (1 - zeta ** 4) + (eF - eP) * fz * zeta ** 4)
+    out['vwn5'] = vwn((F('0.0310907'), F('-0.10498'), F('3.72744'), F('12.9352')),
+                      (F('0.01554535'), F('-0.32500'), F('7.06042'), F('18.0578')),
+                      (A_alpha, F('-0.0047584'), F('1.13107'), F('13.0045')))
+    # libxc LDA_C_VWN_RPA interpolates para / ferro linearly in f(zeta) (no spin-stiffness term); established
+    # against the reference's UKS B3LYPG golden (tests/test_oracle_dft_golden.py)
+    out['vwnrpa'] = rho * (vwn_eps(F('0.0310907'), F('-0.409286'), F('13.0720'), F('42.7198')) * (1 - fz) +
+                           vwn_eps(F('0.01554535'), F('-0.743294'), F('20.1231'), F('101.578')) * fz)
+    beta = F('0.0042')
+
+    def b88s(r, s):
+        x = sp.sqrt(s) / r ** sp.Rational(4, 3)
+        return -cx * r ** sp.Rational(4, 3) - beta * r ** sp.Rational(4, 3) * x * x / (1 + 6 * beta * x * sp.asinh(x))
+    out['b88'] = b88s(ra, saa) + b88s(rb, sbb)
+    a, b, c, d = [F(v) for v in ('0.04918', '0.132', '0.2533', '0.349')]
+    CF = sp.Rational(3, 10) * (3 * pi ** 2) ** sp.Rational(2, 3)
+    rm13 = rho ** sp.Rational(-1, 3)
+    den = 1 + d * rm13
+    omega = sp.exp(-c * rm13) / den * rho ** sp.Rational(-11, 3)
+    delta = c * rm13 + d * rm13 / den
+    br = (ra * rb * (2 ** sp.Rational(11, 3) * CF * (ra ** sp.Rational(8, 3) + rb ** sp.Rational(8, 3))
+                     + (sp.Rational(47, 18) - sp.Rational(7, 18) * delta) * sig
+                     - (sp.Rational(5, 2) - delta / 18) * (saa + sbb)
+                     - (delta - 11) / 9 * (ra / rho * saa + rb / rho * sbb))
+          - sp.Rational(2, 3) * rho ** 2 * sig + (sp.Rational(2, 3) * rho ** 2 - ra ** 2) * sbb
+          + (sp.Rational(2, 3) * rho ** 2 - rb ** 2) * saa)
+    out['lyp'] = -a * 4 / den * ra * rb / rho - a * b * omega * br
+    fns = {}
+    v = (ra, rb, saa, sab, sbb)
+    for k, e in out.items():
+        fns[k] = [sp.lambdify(v, e, 'numpy')] + [sp.lambdify(v, sp.diff(e, x), 'numpy') for x in v]
+    return fns
+
+
+def eval_xc_pol(fac, ra, rb, saa, sab, sbb):
+    """-> e, (vra, vrb, vsaa, vsab, vsbb).  Components: slater, vwn5, vwnrpa, b88, lyp (PBE not restated
+    spin-polarised)."""
+    global _FUNCS_POL
+    if _FUNCS_POL is None:
+        _FUNCS_POL = _build_functionals_pol()
+    if fac[5] != 0 or fac[6] != 0:
+        raise NotImplementedError('spin-polarised PBE')
+    n = len(ra)
+    e = np.zeros(n)
+    dv = [np.zeros(n) for _ in range(5)]
+    ok = (ra + rb) > 1e-14
+    args = [np.maximum(ra[ok], 1e-30), np.maximum(rb[ok], 1e-30), np.maximum(saa[ok], 1e-300), sab[ok],
+            np.maximum(sbb[ok], 1e-300)]
+    # sympy symbols are declared positive; sab may be negative: shift-free evaluation is fine numerically
+    for w, name in zip(fac[:5], _ORDER[:5]):
+        if w == 0:
+            continue
+        f = _FUNCS_POL[name]
+        e[ok] += w * f[0](*args)
+        for k in range(5):
+            dv[k][ok] += w * f[1 + k](*args) * np.ones(ok.sum())
+    return e, dv
+
+
+def nr_uks(mol, coords, weights, fac, gga, dma, dmb):
+    """(nelec[2], excsum, vmat[2]) - dense restatement of numint.nr_uks (pyscf/dft/numint.py:1192-1324)."""
+    ao = eval_ao(mol, coords, 1) if gga else eval_ao(mol, coords, 0)[None]
+    rho, grad = [], []
+    for dm in (dma, dmb):
+        dm = (dm + dm.T) * .5
+        c0 = ao[0].dot(dm)
+        rho.append(np.einsum('gi,gi->g', ao[0], c0))
+        grad.append(2 * np.einsum('xgi,gi->xg', ao[1:], c0) if gga else np.zeros((3, len(coords))))
+    saa = np.einsum('xg,xg->g', grad[0], grad[0])
+    sab = np.einsum('xg,xg->g', grad[0], grad[1])
+    sbb = np.einsum('xg,xg->g', grad[1], grad[1])
+    e, (vra, vrb, vsaa, vsab, vsbb) = eval_xc_pol(fac, rho[0], rho[1], saa, sab, sbb)
+    nelec = (np.dot(weights, rho[0]), np.dot(weights, rho[1]))
+    exc = np.dot(weights, e)
+    vmat = []
+    for s, (vr, vss, g_same, g_other) in enumerate(((vra, vsaa, grad[0], grad[1]), (vrb, vsbb, grad[1], grad[0]))):
+        aow = ao[0] * (.5 * weights * vr)[:, None]
+        if gga:
+            for d in range(3):
+                aow += ao[1 + d] * (weights * (2 * vss * g_same[d] + vsab * g_other[d]))[:, None]
+        m = ao[0].T.dot(aow)
+        vmat.append(m + m.T)
+    return nelec, exc, np.array(vmat)
+
+
+def uks_energy(mol, xc_fac, hyb, gga, coords, weights, eri, nelec, conv_tol=1e-10, max_cycle=100):
+    """UKS SCF with exact 4-centre J/K (for the reference's non-DF goldens)."""
+    import scipy.linalg
+    h1e = ref.int1e(mol, 'kin') + ref.int1e(mol, 'nuc')
+    s1e = ref.int1e(mol, 'ovlp')
+    enuc = mol.energy_nuc()
+    w, v = scipy.linalg.eigh(s1e)
+    x = v[:, w > 1e-6] / np.sqrt(w[w > 1e-6])
+
+    def eig(f):
+        e, c = scipy.linalg.eigh(x.T.dot(f).dot(x))
+        return x.dot(c)
+    c0 = eig(h1e)
+    cs = [c0, c0]
+    fs, es = [], []
+    e_tot = 0
+    for cycle in range(max_cycle):
+        dms = np.array([cs[s][:, :nelec[s]].dot(cs[s][:, :nelec[s]].T) for s in range(2)])
+        n, exc, vxc = nr_uks(mol, coords, weights, xc_fac, gga, dms[0], dms[1])
+        vj, vk = ref.get_jk_exact(eri, dms)
+        vjt = vj[0] + vj[1]
+        f = h1e + vxc + vjt - hyb * vk
+        e_last = e_tot
+        e_tot = (np.einsum('ij,ji', h1e, dms[0] + dms[1]) + .5 * np.einsum('ij,ji', vjt, dms[0] + dms[1]) + exc
+                 - .5 * hyb * sum(np.einsum('ij,ji', vk[s], dms[s]) for s in range(2)) + enuc)
+        err = np.hstack([x.T.dot(f[s].dot(dms[s]).dot(s1e) - s1e.dot(dms[s]).dot(f[s])).dot(x).ravel() for s in range(2)])
+        if abs(e_tot - e_last) < conv_tol and np.linalg.norm(err) < 1e-5:
+            return True, e_tot
+        fs.append(f); es.append(err)
+        fs, es = fs[-8:], es[-8:]
+        m = len(fs)
+        h = np.zeros((m + 1, m + 1)); h[0, 1:] = h[1:, 0] = 1
+        for i in range(m):
+            for j in range(m):
+                h[i + 1, j + 1] = es[i].dot(es[j])
+        g = np.zeros(m + 1); g[0] = 1
+        ww, vv = scipy.linalg.eigh(h)
+        idx = abs(ww) > 1e-14
+        c = np.dot(vv[:, idx] * (1. / ww[idx]), vv[:, idx].T.dot(g))
+        f = sum(ci * fi for ci, fi in zip(c[1:], fs))
+        cs = [eig(f[s]) for s in range(2)]
+    return False, e_tot

@@ -195,6 +195,167 @@ __global__ __launch_bounds__(256) void eval_xc_kernel(XCSpec spec, int gga, cons
     }
 }
 
+// ============================================================================ spin-polarised (UKS)
+// forward-mode AD with 5 directions: d/d(rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb)
+struct D5 {
+    double v, d[5];
+};
+__device__ inline D5 c5(double v) { D5 r; r.v = v; for (int i = 0; i < 5; i++) r.d[i] = 0; return r; }
+__device__ inline D5 var5(double v, int k) { D5 r = c5(v); r.d[k] = 1; return r; }
+__device__ inline D5 operator+(D5 a, D5 b) { D5 r; r.v = a.v + b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ inline D5 operator-(D5 a, D5 b) { D5 r; r.v = a.v - b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ inline D5 operator-(D5 a) { D5 r; r.v = -a.v; for (int i = 0; i < 5; i++) r.d[i] = -a.d[i]; return r; }
+__device__ inline D5 operator*(D5 a, D5 b) { D5 r; r.v = a.v * b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ inline D5 operator/(D5 a, D5 b)
+{
+    D5 r; double iv = 1.0 / b.v; r.v = a.v * iv;
+    for (int i = 0; i < 5; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * iv;
+    return r;
+}
+__device__ inline D5 operator+(D5 a, double b) { a.v += b; return a; }
+__device__ inline D5 operator+(double a, D5 b) { b.v += a; return b; }
+__device__ inline D5 operator-(D5 a, double b) { a.v -= b; return a; }
+__device__ inline D5 operator-(double a, D5 b) { return c5(a) - b; }
+__device__ inline D5 operator*(D5 a, double b) { a.v *= b; for (int i = 0; i < 5; i++) a.d[i] *= b; return a; }
+__device__ inline D5 operator*(double a, D5 b) { return b * a; }
+__device__ inline D5 operator/(D5 a, double b) { return a * (1.0 / b); }
+__device__ inline D5 operator/(double a, D5 b) { return c5(a) / b; }
+__device__ inline D5 chain5(D5 a, double f, double df) { D5 r; r.v = f; for (int i = 0; i < 5; i++) r.d[i] = df * a.d[i]; return r; }
+__device__ inline D5 pow5(D5 a, double p) { double f = pow(a.v, p); return chain5(a, f, p * f / a.v); }
+__device__ inline D5 sqrt5(D5 a) { double f = sqrt(a.v); return chain5(a, f, 0.5 / f); }
+__device__ inline D5 log5(D5 a) { return chain5(a, log(a.v), 1.0 / a.v); }
+__device__ inline D5 exp5(D5 a) { double f = exp(a.v); return chain5(a, f, f); }
+__device__ inline D5 atan5(D5 a) { return chain5(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+__device__ inline D5 asinh5(D5 a) { return chain5(a, asinh(a.v), 1.0 / sqrt(1.0 + a.v * a.v)); }
+
+__device__ inline D5 slater_pol(D5 ra, D5 rb)
+{
+    const double cx = 1.5 * 0.62035049089940001;       // (3/2)(3/(4 pi))^(1/3)
+    return -cx * (pow5(ra, 4.0 / 3.0) + pow5(rb, 4.0 / 3.0));
+}
+__device__ inline D5 vwn_eps5(D5 rho, double A, double x0, double b, double c)
+{
+    D5 rs = pow5(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
+    D5 x = sqrt5(rs);
+    const double Q = sqrt(4 * c - b * b);
+    D5 X = x * x + b * x + c;
+    const double X0 = x0 * x0 + b * x0 + c;
+    D5 at = atan5(Q / (2.0 * x + b));
+    D5 t1 = log5(x * x / X) + (2 * b / Q) * at;
+    D5 t2 = log5((x - x0) * (x - x0) / X) + (2 * (b + 2 * x0) / Q) * at;
+    return A * (t1 - (b * x0 / X0) * t2);
+}
+__device__ inline D5 fzeta5(D5 zeta)
+{
+    // guard the fully polarised limit: (1 -+ zeta)^(4/3) with a tiny floor keeps the derivative finite
+    D5 p = 1.0 + zeta, m = 1.0 - zeta;
+    if (p.v < 1e-14) p.v = 1e-14;
+    if (m.v < 1e-14) m.v = 1e-14;
+    return (pow5(p, 4.0 / 3.0) + pow5(m, 4.0 / 3.0) - 2.0) / (2.5198420997897464 - 2.0);
+}
+// VWN5: para + spin stiffness + ferro (Vosko, Wilk, Nusair 1980, eq. 4.4 interpolation)
+__device__ inline D5 vwn5_pol(D5 rho, D5 zeta)
+{
+    D5 eP = vwn_eps5(rho, 0.0310907, -0.10498, 3.72744, 12.9352);
+    D5 eF = vwn_eps5(rho, 0.01554535, -0.32500, 7.06042, 18.0578);
+    D5 eA = vwn_eps5(rho, -1.0 / (6.0 * PI * PI), -0.0047584, 1.13107, 13.0045);
+    const double fpp = 4.0 / (9.0 * (1.2599210498948732 - 1.0));
+    D5 f = fzeta5(zeta);
+    D5 z4 = zeta * zeta * zeta * zeta;
+    return rho * (eP + eA * f / fpp * (1.0 - z4) + (eF - eP) * f * z4);
+}
+// VWN-RPA (libxc LDA_C_VWN_RPA): linear interpolation in f(zeta) between para and ferro RPA fits
+__device__ inline D5 vwnrpa_pol(D5 rho, D5 zeta)
+{
+    D5 eP = vwn_eps5(rho, 0.0310907, -0.409286, 13.0720, 42.7198);
+    D5 eF = vwn_eps5(rho, 0.01554535, -0.743294, 20.1231, 101.578);
+    D5 f = fzeta5(zeta);
+    return rho * (eP * (1.0 - f) + eF * f);
+}
+__device__ inline D5 b88_spin(D5 r, D5 s)
+{
+    const double beta = 0.0042, cx = 1.5 * 0.62035049089940001;
+    D5 r43 = pow5(r, 4.0 / 3.0);
+    D5 x = sqrt5(s + 1e-300) / r43;
+    return -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * asinh5(x));
+}
+__device__ inline D5 lyp_pol(D5 ra, D5 rb, D5 saa, D5 sab, D5 sbb)
+{
+    const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349;
+    const double CF = 0.3 * 9.5707800006273392;
+    D5 rho = ra + rb;
+    D5 sig = saa + 2.0 * sab + sbb;
+    D5 rm13 = pow5(rho, -1.0 / 3.0);
+    D5 den = 1.0 + d * rm13;
+    D5 omega = exp5(-c * rm13) / den * pow5(rho, -11.0 / 3.0);
+    D5 delta = c * rm13 + d * rm13 / den;
+    D5 rab = ra * rb;
+    D5 br = rab * (pow(2.0, 11.0 / 3.0) * CF * (pow5(ra, 8.0 / 3.0) + pow5(rb, 8.0 / 3.0))
+                   + (47.0 / 18.0 - 7.0 / 18.0 * delta) * sig
+                   - (2.5 - delta / 18.0) * (saa + sbb)
+                   - (delta - 11.0) / 9.0 * (ra / rho * saa + rb / rho * sbb))
+            - (2.0 / 3.0) * rho * rho * sig
+            + ((2.0 / 3.0) * rho * rho - ra * ra) * sbb + ((2.0 / 3.0) * rho * rho - rb * rb) * saa;
+    return -a * 4.0 / den * rab / rho - a * b * omega * br;
+}
+
+// rho_a / rho_b [4][ldg]; wv_a / wv_b [4][ldg]: wv_s0 = 0.5 w vrho_s, wv_s(1..3) = w (2 vsigma_ss grad rho_s +
+// vsigma_ab grad rho_other)  (pyscf/dft/numint.py:1192-1324, xc_deriv.transform_vxc for spin = 1)
+// acc[0] += sum w rho_a, acc[1] += sum w rho_b, acc[2] += sum w e
+__global__ __launch_bounds__(256) void eval_xc_pol_kernel(XCSpec spec, int gga, const double *__restrict__ rho_a,
+                                                          const double *__restrict__ rho_b,
+                                                          const double *__restrict__ weights, long ng, long ldg,
+                                                          double *__restrict__ wv_a, double *__restrict__ wv_b,
+                                                          double *__restrict__ acc)
+{
+    long g = (long)blockIdx.x * 256 + threadIdx.x;
+    double na = 0, nb = 0, exc = 0;
+    if (g < ng) {
+        const double w = weights[g];
+        double ra = rho_a[g], rb = rho_b[g];
+        double ga[3] = {0, 0, 0}, gb[3] = {0, 0, 0};
+        if (gga)
+            for (int x = 0; x < 3; x++) { ga[x] = rho_a[(x + 1) * ldg + g]; gb[x] = rho_b[(x + 1) * ldg + g]; }
+        na = w * ra; nb = w * rb;
+        double dv[5] = {0, 0, 0, 0, 0};
+        if (ra + rb > 1e-14) {
+            if (ra < 1e-30) ra = 1e-30;
+            if (rb < 1e-30) rb = 1e-30;
+            D5 Ra = var5(ra, 0), Rb = var5(rb, 1);
+            D5 Saa = var5(ga[0] * ga[0] + ga[1] * ga[1] + ga[2] * ga[2], 2);
+            D5 Sab = var5(ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2], 3);
+            D5 Sbb = var5(gb[0] * gb[0] + gb[1] * gb[1] + gb[2] * gb[2], 4);
+            D5 rho = Ra + Rb;
+            D5 zeta = (Ra - Rb) / rho;
+            D5 tot = c5(0);
+            if (spec.fac[F_SLATER] != 0) tot = tot + spec.fac[F_SLATER] * slater_pol(Ra, Rb);
+            if (spec.fac[F_VWN5] != 0) tot = tot + spec.fac[F_VWN5] * vwn5_pol(rho, zeta);
+            if (spec.fac[F_VWNRPA] != 0) tot = tot + spec.fac[F_VWNRPA] * vwnrpa_pol(rho, zeta);
+            if (spec.fac[F_B88] != 0) tot = tot + spec.fac[F_B88] * (b88_spin(Ra, Saa) + b88_spin(Rb, Sbb));
+            if (spec.fac[F_LYP] != 0) tot = tot + spec.fac[F_LYP] * lyp_pol(Ra, Rb, Saa, Sab, Sbb);
+            exc = w * tot.v;
+            for (int k = 0; k < 5; k++) dv[k] = tot.d[k];
+        }
+        wv_a[g] = 0.5 * w * dv[0];
+        wv_b[g] = 0.5 * w * dv[1];
+        if (gga)
+            for (int x = 0; x < 3; x++) {
+                wv_a[(x + 1) * ldg + g] = w * (2.0 * dv[2] * ga[x] + dv[3] * gb[x]);
+                wv_b[(x + 1) * ldg + g] = w * (2.0 * dv[4] * gb[x] + dv[3] * ga[x]);
+            }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        na += __shfl_down(na, off, 64); nb += __shfl_down(nb, off, 64); exc += __shfl_down(exc, off, 64);
+    }
+    __shared__ double red[3][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = na; red[1][threadIdx.x >> 6] = nb; red[2][threadIdx.x >> 6] = exc; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(acc + threadIdx.x, v);
+    }
+}
+
 // rho from c[comp][i][ldc] = sum_mu C_occ[mu][i] ao_comp[g][mu]   (orbital rows, grid index fastest)
 __global__ __launch_bounds__(256) void rho_from_mo_kernel(const double *__restrict__ c, long comp_stride, long ldc,
                                                           int nocc, int ncomp, long ng, double *__restrict__ rho,
@@ -364,6 +525,21 @@ int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double 
     for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
     eval_xc_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho, d_weights, ng, ldg, d_wv,
                                                                        d_exc, d_acc);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// spin-polarised variant (numint.nr_uks): fac7 must not contain PBE terms (not restated spin-polarised)
+int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
+                     const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,
+                     void *stream)
+{
+    if (ng == 0) return 0;
+    PAMD_REQUIRE(fac7[F_PBEX] == 0 && fac7[F_PBEC] == 0, "spin-polarised PBE is not implemented");
+    XCSpec spec;
+    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
+    eval_xc_pol_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho_a, d_rho_b, d_weights,
+                                                                           ng, ldg, d_wv_a, d_wv_b, d_acc3);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

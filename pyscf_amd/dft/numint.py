@@ -251,5 +251,100 @@ class NumInt:
             return nelec[0], excsum[0], vmat[0]
         return nelec, excsum, vmat.reshape(shape)
 
-    def nr_uks(self, *args, **kwargs):
-        raise NotImplementedError('nr_uks: SURVEY.md §8f row 4')
+    def nr_uks(self, mol, grids, xc_code, dms, relativity=0, hermi=1, max_memory=2000, verbose=None):
+        """-> (nelec[2], excsum, vmat[2]) with the contract of numint.nr_uks (numint.py:1192-1324);
+        dms = (dm_alpha, dm_beta), optionally tagged with mo_coeff (2, nao, nmo) / mo_occ (2, nmo)."""
+        import torch
+        lib = _lib_mod.load_library()
+        dev = self._dev()
+        if grids.coords is None:
+            grids.build()
+        hyb, fac = _xc.parse_xc(xc_code)
+        xctype = _xc.xc_type(xc_code)
+        dms_arr = np.asarray(dms)
+        assert dms_arr.ndim == 3 and dms_arr.shape[0] == 2, 'nr_uks expects (dm_alpha, dm_beta)'
+        nao = dms_arr.shape[-1]
+        if xctype == 'HF':
+            return np.zeros(2), 0.0, np.zeros((2, nao, nao))
+        gga = 1 if xctype == 'GGA' else 0
+        ncomp = 4 if gga else 1
+        mo_coeff = getattr(dms, 'mo_coeff', None)
+        mo_occ = getattr(dms, 'mo_occ', None)
+        use_mo = mo_coeff is not None and np.ndim(mo_occ) == 2
+        coords_dev, weights_dev = self._grid_tables(grids, dev)
+        ngrids = grids.size
+        ldao = _round_up(nao, 16)
+        rank, world = self._world()
+        blk = grid_block_size(ngrids, int(self.block_bytes // (ncomp * ldao * 8)), world)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        f64 = torch.float64
+        ao = torch.zeros(ncomp * blk * ldao + 256, dtype=f64, device=dev)[:ncomp * blk * ldao].view(ncomp, blk, ldao)
+        aow = torch.zeros(blk * ldao + 256, dtype=f64, device=dev)[:blk * ldao].view(blk, ldao)
+        rho = torch.zeros((2, 4, blk), dtype=f64, device=dev)
+        wv = torch.empty((2, 4, blk), dtype=f64, device=dev)
+        nsplit = 4
+        fac_c = (ctypes.c_double * 7)(*fac)
+        ops = []
+        for s in range(2):
+            if use_mo:
+                occ = np.asarray(mo_occ[s])
+                orbo = np.asarray(mo_coeff[s])[:, occ > 0] * np.sqrt(occ[occ > 0])
+                nocc = orbo.shape[1]
+                nocc_pad = _round_up(max(nocc, 1), 16)
+                ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
+                orb_h = np.zeros((nao, ldo))
+                orb_h[:, :nocc] = orbo
+                ops.append((torch.from_numpy(orb_h).to(dev), nocc, nocc_pad, ldo,
+                            torch.empty((ncomp, nocc_pad, blk), dtype=f64, device=dev)))
+            else:
+                d = dms_arr[s]
+                ldd = _round_up(nao, 128)
+                d_h = np.zeros((nao, ldd))
+                d_h[:, :nao] = (d + d.T) * .5
+                ops.append((torch.from_numpy(d_h).to(dev), ldd, torch.empty((nao, blk), dtype=f64, device=dev)))
+        part = torch.zeros((2, nsplit, nao, nao), dtype=f64, device=dev)
+        acc = torch.zeros(3, dtype=f64, device=dev)
+        for ib, g0 in enumerate(range(0, ngrids, blk)):
+            if ib % world != rank:
+                continue
+            ng = min(blk, ngrids - g0)
+            ng16 = _round_up(ng, 16)
+            self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk, ldao)
+            for s in range(2):
+                if use_mo:
+                    orb, nocc, nocc_pad, ldo, cmo = ops[s]
+                    if nocc == 0:
+                        rho[s].zero_()
+                        continue
+                    self._call('ao_dot_mo', lib.PAMD_orb_dot_rows, _ptr(ao), _c.c_long(ldao), _c.c_long(blk * ldao),
+                               _c.c_int(ncomp), _c.c_long(ng), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
+                               _c.c_int(nocc_pad), _ptr(cmo), _c.c_long(blk), st)
+                    self._call('rho', lib.PAMD_rho_from_mo, _ptr(cmo), _c.c_long(nocc_pad * blk), _c.c_long(blk),
+                               _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho[s]), _c.c_long(blk), st)
+                else:
+                    dsym, ldd, c0t = ops[s]
+                    self._call('dm_dot_ao', lib.PAMD_cderi_solve, _ptr(dsym), _c.c_int(ldd), _ptr(ao[0]),
+                               _c.c_long(ldao), _ptr(c0t), _c.c_long(blk), _c.c_int(nao), _c.c_long(ng),
+                               _c.c_int(nao), _c.c_int(0), _c.c_int(0), st)
+                    self._call('rho', lib.PAMD_rho_from_dm, _ptr(ao), _ptr(c0t), _c.c_int(nao), _c.c_int(ldao),
+                               _c.c_long(blk), _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho[s]),
+                               _c.c_long(blk), st)
+            self._call('eval_xc', lib.PAMD_eval_xc_pol, fac_c, _c.c_int(gga), _ptr(rho[0]), _ptr(rho[1]),
+                       _ptr(weights_dev[g0:g0 + ng]), _c.c_long(ng), _c.c_long(blk), _ptr(wv[0]), _ptr(wv[1]),
+                       _ptr(acc), st)
+            for s in range(2):
+                self._call('scale_ao', lib.PAMD_scale_ao, _ptr(ao), _ptr(wv[s]), _c.c_int(ldao), _c.c_long(blk),
+                           _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _c.c_long(ng16), _ptr(aow), st)
+                self._call('ao_dot_aow', lib.PAMD_dgemm_tn, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow), _c.c_int(ldao),
+                           _ptr(part[s]), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(ng16), _c.c_int(2),
+                           _c.c_int(nsplit), st)
+        v = torch.empty((2, nao, nao), dtype=f64, device=dev)
+        for s in range(2):
+            self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(part[s]), _c.c_int(nsplit), _c.c_int(nao),
+                       _c.c_int(nao), _ptr(v[s]), st)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(v, group=self.group)
+            dist.all_reduce(acc, group=self.group)
+        a = acc.cpu().numpy()
+        return a[:2].copy(), float(a[2]), v.cpu().numpy()

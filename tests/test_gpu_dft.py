@@ -114,3 +114,60 @@ def test_df_rks_b3lyp_vs_oracle():
         return ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
     conv, e0 = ref_dft.rks_energy(mol, fac, hyb, True, coords, weights, get_jk)[:2]
     assert conv and abs(e - e0) < 1e-8, (e, e0)
+
+
+@pytest.mark.parametrize('xc', ['lda,vwn', 'lda,vwn_rpa', 'b88,lyp', 'b3lyp'])
+def test_nr_uks_vs_oracle(xc):
+    """Spin-polarised nr_uks (both branches) vs the oracle whose functionals are pinned by the UKS goldens."""
+    from pyscf_amd import gto, dft, lib
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom=H2O, basis='cc-pvdz', charge=1, spin=1)
+    grids = dft.Grids(mol)
+    grids.atom_grid = (30, 110)
+    grids.build()
+    hyb, fac = libxc.parse_xc(xc)
+    gga = libxc.xc_type(xc) == 'GGA'
+    rng = np.random.default_rng(3)
+    ca = np.linalg.qr(rng.standard_normal((mol.nao, mol.nao)))[0] * 0.7
+    cb = np.linalg.qr(rng.standard_normal((mol.nao, mol.nao)))[0] * 0.7
+    occ = np.zeros((2, mol.nao))
+    occ[0, :5] = 1
+    occ[1, :4] = 1
+    dms = np.array([(ca * occ[0]).dot(ca.T), (cb * occ[1]).dot(cb.T)])
+    n0, e0, v0 = ref_dft.nr_uks(mol, grids.coords, grids.weights, fac, gga, dms[0], dms[1])
+    ni = dft.NumInt()
+    for d in (dms, lib.tag_array(dms, mo_coeff=np.array([ca, cb]), mo_occ=occ)):
+        n1, e1, v1 = ni.nr_uks(mol, grids, xc, d)
+        assert np.abs(n1 - np.array(n0)).max() < 1e-10 * max(n0)
+        assert abs(e1 - e0) < 1e-10 * abs(e0)
+        assert np.abs(v1 - v0).max() < 1e-9 * max(1.0, np.abs(v0).max())
+    # closed-shell consistency: nr_uks(D/2, D/2) reproduces nr_rks(D)
+    d = dms[0] + dms[1]
+    nr, er, vr = ni.nr_rks(mol, grids, xc, d)
+    nu, eu, vu = ni.nr_uks(mol, grids, xc, np.array([d * .5, d * .5]))
+    assert abs(er - eu) < 1e-10 * abs(er) and np.abs(vu[0] - vr).max() < 1e-9 and np.abs(vu[1] - vr).max() < 1e-9
+
+
+def test_df_uks_b3lyp_cation_vs_oracle_functional():
+    """DF-UKS B3LYP for H2O+ : converged energy vs the oracle energy functional at the same orbitals."""
+    from pyscf_amd import gto, dft, df
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom=H2O, basis='cc-pvdz', charge=1, spin=1)
+    mf = dft.UKS(mol, xc='b3lyp').density_fit()
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    assert mf.converged
+    dm = np.asarray(mf.make_rdm1())
+    cderi = ref.cholesky_eri(mol, df.make_auxmol(mol))
+    coords, weights = ref_dft.build_grids(mol)
+    hyb, fac = libxc.parse_xc('b3lyp')
+    n, exc, vxc = ref_dft.nr_uks(mol, coords, weights, fac, True, dm[0], dm[1])
+    vj, vk = ref.get_jk(cderi, dm, 1)
+    h1e = ref.int1e(mol, 'kin') + ref.int1e(mol, 'nuc')
+    vjt = vj[0] + vj[1]
+    e0 = (np.einsum('ij,ji', h1e, dm[0] + dm[1]) + .5 * np.einsum('ij,ji', vjt, dm[0] + dm[1]) + exc
+          - .5 * hyb * sum(np.einsum('ij,ji', vk[s], dm[s]) for s in range(2)) + mol.energy_nuc())
+    assert abs(e - e0) < 1e-8, (e, e0)
+    f = h1e + vxc + vjt - hyb * vk
+    assert np.linalg.norm(mf.get_grad(mf.mo_coeff, mf.mo_occ, f)) < 1e-4
+    assert 0.75 < mf.spin_square() < 0.78

@@ -64,3 +64,22 @@ def test_grid_norms():
                                radii_adjust='becke', alignment=0)
     assert abs(np.linalg.norm(c) - 185.91245945279027) < 1e-9
     assert abs(np.linalg.norm(w) - 1720.1317185648893) < 1e-8
+
+
+@pytest.mark.parametrize('xc,e_ref', [('lda,vwn', -75.350995324984709), ('b3lypg', -75.927304010489976)])
+def test_uks_cation_energies_exact_jk(xc, e_ref):
+    """Spin-polarised functionals of the oracle vs the reference's UKS goldens for H2O+ / 6-31G
+    (pyscf/dft/test/test_h2o.py:131-142): LSDA (Slater + VWN5 with spin stiffness) and B3LYPG
+    (polarised B88, LYP and VWN-RPA)."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import radi, libxc
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
+    try:
+        cat = gto.M(atom=H2O, basis='6-31g', charge=1, spin=1)
+        coords, weights = ref_dft.build_grids(cat, ATOM_GRID, prune='treutler')
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    hyb, fac = libxc.parse_xc(xc)
+    conv, e = ref_dft.uks_energy(cat, fac, hyb, libxc.xc_type(xc) == 'GGA', coords, weights, ref.int2e(cat), cat.nelec)
+    assert conv and abs(e - e_ref) < 2e-8, (e, e_ref)
