@@ -44,6 +44,8 @@ class DF:
     # -- distributed geometry ----------------------------------------------------------
     @property
     def world_size(self):
+        if getattr(self, '_shard_override', None) is not None:     # (rank, world) without a process group:
+            return self._shard_override[1]                         # build / contract one shard only (tools, tests)
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
@@ -54,6 +56,8 @@ class DF:
 
     @property
     def rank(self):
+        if getattr(self, '_shard_override', None) is not None:
+            return self._shard_override[0]
         if self.world_size > 1:
             import torch.distributed as dist
             return dist.get_rank(self.group)

@@ -75,7 +75,7 @@ def _call(dfobj, name, fn, *args):
 
 def _allreduce(dfobj, tensors):
     """Sum the rank-partial results over the aux-index shards (RCCL over xGMI)."""
-    if dfobj.world_size > 1:
+    if dfobj.world_size > 1 and getattr(dfobj, '_shard_override', None) is None:
         import torch.distributed as dist
         for t in tensors:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=dfobj.group)

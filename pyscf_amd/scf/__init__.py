@@ -1,6 +1,7 @@
 from . import hf
 from .hf import RHF, SCF
 from .uhf import UHF
+from .rohf import ROHF
 
 
 def density_fit(mf, auxbasis=None, with_df=None):

@@ -95,3 +95,15 @@ def test_golden_df_uhf_and_open_shell_vs_oracle():
     assert np.linalg.norm(g) < 1e-4
     assert 0.75 < mf.spin_square() < 0.77
     assert e < -75.626515724371814          # below the ROHF energy of the same cation (test_df_jk.py:72-78)
+
+
+def test_golden_df_rohf_cation():
+    """DF-ROHF H2O+ / cc-pVDZ / 'weigend': -75.626515724371814 (pyscf/df/test/test_df_jk.py:72-78); the
+    K build goes through the ROHF-tagged-DM branch (df_jk.py:346-351)."""
+    from pyscf_amd import gto, scf
+    mol = gto.M(atom=H2O, basis='cc-pvdz', charge=1, spin=1)
+    mf = scf.ROHF(mol).density_fit(auxbasis='weigend')
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    assert mf.converged and abs(e - -75.626515724371814) < 1e-8, e
+    assert sorted(set(mf.mo_occ.tolist())) == [0.0, 1.0, 2.0]

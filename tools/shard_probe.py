@@ -1,0 +1,57 @@
+"""Build and contract ONE aux-row shard of a large configuration on a single GPU (emulates rank r of N
+without a process group): checks memory footprint, 64-bit indexing and timings at BASELINE config-5 scale.
+    python tools/shard_probe.py --nwater 128 --basis cc-pvdz --world 8 --rank 3"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from pyscf_amd import gto, df
+from pyscf_amd.data import clusters
+from pyscf_amd.df import df_jk
+ap = argparse.ArgumentParser()
+ap.add_argument('--nwater', type=int, default=128)
+ap.add_argument('--basis', default='cc-pvdz')
+ap.add_argument('--world', type=int, default=8)
+ap.add_argument('--rank', type=int, default=3)
+a = ap.parse_args()
+mol = gto.M(atom=clusters.water_cluster(a.nwater), basis=a.basis)
+nao, nocc = mol.nao, mol.nelectron // 2
+obj = df.DF(mol)
+obj._shard_override = (a.rank, a.world)
+t0 = time.perf_counter()
+obj.build()
+torch.cuda.synchronize()
+tb = time.perf_counter() - t0
+cd = obj._cderi_dev
+naux = obj.get_naoaux()
+rng = np.random.default_rng(1)
+c = np.linalg.qr(rng.standard_normal((nao, nocc)))[0] * np.sqrt(2.0)
+dev = cd.device
+dm = torch.from_numpy(c.dot(c.T)[None]).to(dev)
+orb = [df_jk.pad_orbitals(c, dev)]
+vj, vk = df_jk.get_jk_device(obj, dm, orb)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+vj, vk = df_jk.get_jk_device(obj, dm, orb)
+torch.cuda.synchronize()
+tjk = time.perf_counter() - t0
+# spot check against a dense fp64 reference on 8 rows of the shard
+sub = cd[:8]
+idx = torch.tril_indices(nao, nao, device=dev)
+full = torch.zeros((8, nao, nao), dtype=torch.float64, device=dev)
+full[:, idx[0], idx[1]] = sub
+full = full + full.transpose(1, 2) - torch.diag_embed(torch.diagonal(full, dim1=1, dim2=2))
+o2 = df.DF(mol); o2._cderi_dev = sub
+vj2, vk2 = df_jk.get_jk_device(o2, dm, orb)
+cdv = torch.from_numpy(c).to(dev)
+xx = torch.matmul(full, cdv)
+vk_ref = torch.einsum('Lpi,Lqi->pq', xx, xx)
+rho = torch.einsum('Lpq,pq->L', full, dm[0])
+vj_ref = torch.einsum('L,Lpq->pq', rho, full)
+vjf = torch.zeros((nao, nao), dtype=torch.float64, device=dev); vjf[idx[0], idx[1]] = vj2[0]
+print(json.dumps({'nao': nao, 'naux': naux, 'nocc': nocc, 'shard_rows': int(cd.shape[0]),
+                  'shard_GB': round(cd.numel() * 8e-9, 1), 'build_s': round(tb, 1), 'jk_ms_this_shard': round(tjk * 1e3, 1),
+                  'mem_peak_GB': round(torch.cuda.max_memory_allocated() * 1e-9, 1),
+                  'err_vk': float((vk2[0] - vk_ref).abs().max() / vk_ref.abs().max()),
+                  'err_vj': float((vjf.tril() - vj_ref.tril()).abs().max() / vj_ref.abs().max()),
+                  'finite': bool(torch.isfinite(vk).all() and torch.isfinite(vj).all())}))
