@@ -1,0 +1,99 @@
+"""Direct C-ABI calls (ctypes + device pointers) of the generic entry points, against numpy."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup():
+    import torch
+    from pyscf_amd import lib
+    so = lib.load_library()
+    dev = torch.device('cuda', 0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch, so, dev, st, lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize('m,n,k,lower', [(200, 200, 1024, 1), (130, 77, 333, 0), (128, 128, 16, 0), (300, 300, 4096, 1)])
+@pytest.mark.parametrize('glds', [0, 1])
+def test_dgemm_tn_split_k_and_lds_dma(m, n, k, lower, glds):
+    torch, so, dev, st, lib = _setup()
+    rng = np.random.default_rng(m + n + k)
+    lda, ldb = (m + 15) // 16 * 16, (n + 15) // 16 * 16
+    a = np.zeros((k, lda)); a[:, :m] = rng.standard_normal((k, m))
+    b = np.zeros((k, ldb)); b[:, :n] = rng.standard_normal((k, n))
+    # slack of 256 doubles after the panels (LDS-DMA kernel reads whole 128-column rows)
+    ta = torch.zeros(k * lda + 256, dtype=torch.float64, device=dev); ta[:k * lda] = torch.from_numpy(a.ravel()).to(dev)
+    tb = torch.zeros(k * ldb + 256, dtype=torch.float64, device=dev); tb[:k * ldb] = torch.from_numpy(b.ravel()).to(dev)
+    if lower:
+        tb, ldb, b = ta, lda, a
+    nsplit = 3
+    part = torch.zeros((nsplit, m, n), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_set_tuning(b'glds', glds))
+    flag = lower | 2
+    for _ in range(2):            # accumulates
+        lib.check(so.PAMD_dgemm_tn(_p(ta), lda, _p(tb), ldb, _p(part), n, m, n, C.c_long(k), flag, nsplit, st))
+    lib.check(so.PAMD_set_tuning(b'glds', 1))
+    out = torch.empty((m, n), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_reduce_splits(_p(part), nsplit, m, n, _p(out), n, lower, st)) if m == n else None
+    want = 2 * a[:, :m].T.dot(b[:, :n])
+    if m == n:
+        got = out.cpu().numpy()
+        if lower:
+            assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()      # symmetrised from the lower tiles
+        else:
+            assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
+    else:
+        got = part.sum(0).cpu().numpy()
+        assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
+
+
+def test_dgemm_nt_pack_unpack_reduce_sym():
+    torch, so, dev, st, lib = _setup()
+    rng = np.random.default_rng(9)
+    m, n, k = 150, 90, 700
+    a, b = rng.standard_normal((m, k)), rng.standard_normal((n, k))
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    part = torch.zeros((2, m, n), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_dgemm_nt(_p(ta), C.c_long(k), _p(tb), C.c_long(k), _p(part), n, m, n, C.c_long(k), 2, st))
+    assert np.abs(part.sum(0).cpu().numpy() - a.dot(b.T)).max() < 1e-11 * k
+    # pack_dm_tril / unpack_tril / reduce_sym
+    nao = 37
+    dm = rng.standard_normal((2, nao, nao))
+    tdm = torch.from_numpy(dm).to(dev)
+    npair = nao * (nao + 1) // 2
+    tril = torch.zeros((2, npair), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_pack_dm_tril(_p(tdm), 2, nao, _p(tril), st))
+    idx = np.tril_indices(nao)
+    want = (dm + dm.transpose(0, 2, 1))[:, idx[0], idx[1]]
+    want[:, np.arange(nao) * (np.arange(nao) + 1) // 2 + np.arange(nao)] *= .5
+    assert np.abs(tril.cpu().numpy() - want).max() < 1e-14
+    ld, rows = 48, 40
+    full = torch.zeros((2, rows, ld), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_unpack_tril(_p(tril), C.c_long(npair), 2, nao, _p(full), ld, rows, st))
+    f = full.cpu().numpy()
+    assert np.all(f[:, nao:, :] == 0) and np.all(f[:, :, nao:] == 0)
+    assert np.abs(f[:, :nao, :nao] - lib.unpack_tril(want, 1)).max() < 1e-14
+    p2 = torch.from_numpy(rng.standard_normal((3, nao, nao))).to(dev)
+    out = torch.empty((nao, nao), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_reduce_sym(_p(p2), 3, nao, nao, _p(out), st))
+    s = p2.sum(0).cpu().numpy()
+    assert np.abs(out.cpu().numpy() - (s + s.T)).max() < 1e-13
+
+
+def test_error_codes_not_exit():
+    """Bad arguments come back as negative codes with a message (the reference's C aborts with exit(1))."""
+    torch, so, dev, st, lib = _setup()
+    x = torch.zeros(16, dtype=torch.float64, device=dev)
+    rc = so.PAMD_df_vj_pass1(_p(x), C.c_long(4), 2, _p(x), 9, _p(x), _p(x), st)
+    assert rc < 0 and b'nset' in so.PAMD_last_error()
+    rc = so.PAMD_int3c2e_class(0, 1, 0, None, st)
+    assert rc < 0
+    with pytest.raises(lib.HIPError):
+        lib.check(so.PAMD_set_tuning(b'nope', 1))
