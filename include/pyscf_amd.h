@@ -103,9 +103,16 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
                     int orb_rows, int nocc_pad, double *d_out, int ldx, void *stream);  /* out[L][i][p] */
 /* out[y][i][n] = sum_k src_y[n][k] orb[k][i] (plain-operand mode of the e2_symm MFMA kernel) */
 int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, long nrows, int kdim,
-                      const double *d_orb, int ldo, int nocc_pad, double *d_out, long ldout, void *stream);
+                      const double *d_orb, int ldo, int nocc_pad, double *d_out, long ldout,
+                      const unsigned char *d_kmask, void *stream);   /* kmask nullable: [ny][nrows/128][kdim/16] */
 int PAMD_dgemm_tn(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc, int m,
                   int n, long k, int lower_only, int nsplit, void *stream); /* C[s] += A^T B (k split s) */
+/* screened GEMM (VXCdot_ao_ao_sparse role): maskA[k/16][m/128], maskB[k/16][n/128] bytes, operands as flag 2 */
+int PAMD_dgemm_tn_masked(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc, int m,
+                         int n, long k, int nsplit, const unsigned char *d_maskA, const unsigned char *d_maskB,
+                         void *stream);
+/* flags[nrows/16][ld/16] = any |src| > thr in the 16 x 16 tile (value-based screen index) */
+int PAMD_tile_mask(const double *d_src, long ld, long nrows, double thr, unsigned char *d_flags, void *stream);
 int PAMD_reduce_splits(const double *d_part, int nsplit, int m, int ldc, double *d_out, int ldo,
                        int symmetrize, void *stream);
 int PAMD_unpack_tril(const double *d_tril, long npair, int count, int nao, double *d_full, int ld,
@@ -118,11 +125,13 @@ int PAMD_set_tuning(const char *key, int value);      /* benchmarking switches, 
 int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
                          const double *d_radii_table, int natm, long ngrids, void *stream);
 /* ao[comp][ldg_rows][ldao] (AO index fastest, columns nao..ldao-1 zero), comp = 1 (deriv 0) or 4 (deriv 1),
- * grid points [g0, g0+ng) of d_coords; d_fn2sh[mu] = segmented shell of AO mu */
+ * grid points [g0, g0+ng) of d_coords; d_fn2sh[mu] = segmented shell of AO mu.
+ * d_flags (nullable; caller zeroes it): [ceil(ldg_rows/16)][ldao/16] bytes <- 1 where the 16 x 16 (grid x AO) tile
+ * has a value of any component above thr: the screening table of GTO_screen_index (lib/gto/grid_ao_drv.c:32-123) */
 int PAMD_eval_ao(int deriv, const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,
                  const double *d_xyz, const double *d_exps, const double *d_coefs, int nsh, const int *d_fn2sh,
                  int nao, const double *d_coords, long g0, long ng, const double *d_c2s, const int *d_c2s_off,
-                 double *d_ao, long ldg_rows, int ldao, void *stream);
+                 double *d_ao, long ldg_rows, int ldao, double thr, unsigned char *d_flags, void *stream);
 /* rho[4][ldg] (rho, grad rho) from c[comp][i][ldc] = C_occ^T ao_comp^T (orbital rows), or from ao and
  * c0t[mu][ldc] = (D ao0^T) */
 int PAMD_rho_from_mo(const double *d_c, long comp_stride, long ldc, int nocc, int ncomp, long ng,

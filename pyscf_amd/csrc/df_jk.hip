@@ -137,7 +137,8 @@ constexpr int LDT = KB + 1;     // transposed tile [n][k], odd stride -> conflic
 template <int MT, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
     const double *__restrict__ cderi, long npair, int nao, const double *__restrict__ orb, int ldo,
-    double *__restrict__ X, int nocc_pad, long ldx, long src_stride, long ncols)
+    double *__restrict__ X, int nocc_pad, long ldx, long src_stride, long ncols,
+    const unsigned char *__restrict__ kmask)
 {
     constexpr int MW = MT * 16;                         // orbitals per workgroup
     constexpr int LDA = MW + ((MW % 32 == 16) ? 0 : 16);  // == 16 mod 32
@@ -192,8 +193,16 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
         }
     };
 
-    fetch(0);
-    for (int q0 = 0; q0 < nao; q0 += KB) {
+    // optional screening (PLAIN mode): kmask[(y * ntiles + tile) * nk + k-tile] == 0 -> the 128 x 16 operand
+    // tile is negligible and its k-tile is skipped (numint's non0tab idea, pyscf/gto/eval_gto.py:146+)
+    const unsigned char *km = kmask ? kmask + ((long)L * gridDim.x + blockIdx.x) * ((nao + KB - 1) / KB) : nullptr;
+    auto next_active = [&](int q) {
+        if (km) while (q < nao && !km[q / KB]) q += KB;
+        return q;
+    };
+    int q0 = next_active(0);
+    if (q0 < nao) fetch(q0);
+    while (q0 < nao) {
         const bool above = tile_above(q0);
 #pragma unroll
         for (int j = 0; j < MT; j++) sA[sk * LDA + sc + 16 * j] = ra[j];
@@ -205,7 +214,8 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
             for (int j = 0; j < 8; j++) sB[sk * LDN + sc + 16 * j] = rb[j];
         }
         __syncthreads();
-        if (q0 + KB < nao) fetch(q0 + KB);
+        const int qn = next_active(q0 + KB);
+        if (qn < nao) fetch(qn);
 #pragma unroll
         for (int kk = 0; kk < KB; kk += 4) {
             double bf[2];
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
             }
         }
         __syncthreads();
+        q0 = qn;
     }
     // ---- store: D[m = (lane>>4)+4r][n = lane&15]
     double *out = X + (long)L * nocc_pad * ldx;
@@ -436,9 +447,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
 // k-tile, no staging VGPRs.  Requirements (checked by the launcher): lda, ldb even, 16-byte
 // aligned bases, every k range a multiple of KB, and 128 readable doubles from any row start
 // (edge tiles read past m/n inside the allocation; those columns are never stored).
+constexpr int KLMAX = 2048;             // k-tiles per compaction segment of the screened LDS-DMA GEMM
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
-    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n)
+    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n,
+    const unsigned char *__restrict__ maskA, const unsigned char *__restrict__ maskB, int ntile_m)
 {
     __shared__ double sbuf[2][2][KB * LDN];     // [buffer][panel][k][col]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -480,26 +493,57 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
                                              (__attribute__((address_space(3))) void *)(&sbuf[buf][1][k * LDN]), 16, 0, 0);
         }
     };
-    int buf = 0;
-    if (kbeg < kend) stage(kbeg, 0);
-    for (long k0 = kbeg; k0 < kend; k0 += KB) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (k0 + KB < kend) stage(k0 + KB, buf ^ 1);
-        const double *sP = sbuf[buf][0], *sQ = sbuf[buf][1];
-#pragma unroll
-        for (int kk = 0; kk < KB; kk += 4) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int a = 0; a < 4; a++) af[a] = sP[(kk + fk) * LDN + wr * 64 + a * 16 + fn];
-#pragma unroll
-            for (int b = 0; b < 4; b++) bf[b] = sQ[(kk + fk) * LDN + wc * 64 + b * 16 + fn];
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+    // optional screening: k-tile kt is skipped when either 16 x 128 panel tile is negligible
+    // (maskA[kt][tm], maskB[kt][tn]; VXCdot_ao_ao_sparse's pair_mask idea, nr_numint_sparse.c:890-973).
+    // The surviving k-tiles of a segment are compacted (in order) into an LDS list first so the
+    // pipelined loop never waits on a mask byte.
+    __shared__ unsigned short klist[KLMAX];
+    __shared__ int s_cnt[4];
+    const long seglen = maskA ? (long)KLMAX * KB : (kend > kbeg ? kend - kbeg : 1);
+    for (long seg = kbeg; seg < kend; seg += seglen) {
+        const long segend = (seg + seglen < kend) ? seg + seglen : kend;
+        int nact = (int)((segend - seg) / KB);
+        if (maskA) {
+            const int nt = nact;
+            const long t0g = seg / KB;
+            int total = 0;
+            __syncthreads();
+            for (int t0 = 0; t0 < nt; t0 += 256) {
+                const int t = t0 + tid;
+                const bool act = t < nt && maskA[(t0g + t) * ntile_m + tm] && maskB[(t0g + t) * ntile_n + tn];
+                const unsigned long long b = __ballot(act);
+                if (lane == 0) s_cnt[wave] = __popcll(b);
+                __syncthreads();
+                int off = total;
+                for (int w = 0; w < wave; w++) off += s_cnt[w];
+                if (act) klist[off + __popcll(b & ((1ull << lane) - 1))] = (unsigned short)t;
+                total += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+                __syncthreads();
+            }
+            nact = total;
         }
-        buf ^= 1;
+        auto kof = [&](int i) { return seg + (long)(maskA ? klist[i] : i) * KB; };
+        int buf = 0;
+        if (nact > 0) stage(kof(0), 0);
+        for (int i = 0; i < nact; i++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (i + 1 < nact) stage(kof(i + 1), buf ^ 1);
+            const double *sP = sbuf[buf][0], *sQ = sbuf[buf][1];
+#pragma unroll
+            for (int kk = 0; kk < KB; kk += 4) {
+                double af[4], bf[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) af[a] = sP[(kk + fk) * LDN + wr * 64 + a * 16 + fn];
+#pragma unroll
+                for (int b = 0; b < 4; b++) bf[b] = sQ[(kk + fk) * LDN + wc * 64 + b * 16 + fn];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+            }
+            buf ^= 1;
+        }
     }
     double *out = C + (long)blockIdx.y * m * ldc;
 #pragma unroll
@@ -514,6 +558,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
                 if (rowi < m) out[(long)rowi * ldc + col] += acc[a][b][r];
             }
         }
+}
+
+// flag[rt][ct] = max |src[16 rt .. 16 rt + 15][16 ct .. 16 ct + 15]| > thr   (rows >= nrows count as zero)
+__global__ __launch_bounds__(256) void tile_mask_kernel(const double *__restrict__ src, long ld, long nrows, double thr,
+                                                        unsigned char *__restrict__ out, int nct)
+{
+    const long rt = blockIdx.x;
+    for (int c = threadIdx.x; c < nct * 16; c += 256) {
+        double mx = 0;
+        if (c < ld)
+            for (int r = 0; r < 16; r++) {
+                long row = rt * 16 + r;
+                if (row < nrows) mx = fmax(mx, fabs(src[row * ld + c]));
+            }
+        for (int off = 8; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+        if ((c & 15) == 0) out[rt * nct + (c >> 4)] = mx > thr;
+    }
 }
 
 // out[i][j] = sum_s part[s][i][j]  (i>=j when lower), mirrored to the upper triangle when sym
@@ -637,7 +698,7 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     // the kernel writes rows i < nocc_pad only; chunks are mt*16 wide
     dim3 grid(ceil_div(ldx, NT), nL, nchunk);
 #define LAUNCH_E2(MT)                                                                         \
-    e2_symm_kernel<MT, false><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx, 0, 0)
+    e2_symm_kernel<MT, false><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx, 0, 0, nullptr)
     // orbital tile reads m0+i < ldo must stay in bounds: require ldo >= nchunk*mt*16
     PAMD_REQUIRE(ldo >= nchunk * mt * 16, "orbital leading dimension too small for tile padding");
     // v3 (LDS-DMA + register B fragments) needs orb rows zero-padded to a multiple of KB and
@@ -682,9 +743,11 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
 
 // out[y][i][n] = sum_k src_y[n][k] * orb[k][i]   (y < ny; src_y = d_src + y*src_stride, rows n of
 // leading dimension lds, k contiguous).  Same MFMA kernel as PAMD_nr_e2_symm with a plain operand;
-// numint's c = ao . C_occ (pyscf/dft/numint.py:328-469, VXCdot_ao_dm) in the [orbital][grid] layout.
+// numint's c = ao . C_occ (pyscf/dft/numint.py:328-469, VXCdot_ao_dm_sparse) in the [orbital][grid] layout.
+// d_kmask (nullable): [ny][ceil(nrows/128)][ceil(kdim/16)] bytes, 0 = skip that 128 x 16 tile of src.
 int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, long nrows, int kdim,
-                      const double *d_orb, int ldo, int nocc_pad, double *d_out, long ldout, void *stream)
+                      const double *d_orb, int ldo, int nocc_pad, double *d_out, long ldout,
+                      const unsigned char *d_kmask, void *stream)
 {
     PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
     if (ny == 0 || nrows == 0 || nocc_pad == 0) return 0;
@@ -695,7 +758,7 @@ int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, lo
     PAMD_REQUIRE(ldo >= nchunk * mt * 16, "orbital leading dimension too small for tile padding");
     dim3 grid(ceil_div(nrows, NT), ny, nchunk);
 #define LAUNCH_P(MT)                                                                          \
-    e2_symm_kernel<MT, true><<<grid, 256, 0, st>>>(d_src, lds, kdim, d_orb, ldo, d_out, nocc_pad, ldout, src_stride, nrows)
+    e2_symm_kernel<MT, true><<<grid, 256, 0, st>>>(d_src, lds, kdim, d_orb, ldo, d_out, nocc_pad, ldout, src_stride, nrows, d_kmask)
     switch (mt) {
     case 1: LAUNCH_P(1); break;
     case 2: LAUNCH_P(2); break;
@@ -715,8 +778,9 @@ int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, lo
 
 // C[s][m][ldc] += A[k][m]^T B[k][n] over the s-th k range; s in [0,nsplit).  Device analogue of
 // lib.dot(buf1.T, buf1) (pyscf/df/df_jk.py:380; NPdgemm, pyscf/lib/np_helper/npdot.c:32).
-int PAMD_dgemm_tn(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc,
-                  int m, int n, long k, int lower_only, int nsplit, void *stream)
+static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc,
+                         int m, int n, long k, int lower_only, int nsplit, const unsigned char *d_maskA,
+                         const unsigned char *d_maskB, void *stream)
 {
     PAMD_REQUIRE(nsplit >= 1, "nsplit >= 1");
     PAMD_REQUIRE(!(lower_only & 1) || m == n, "lower_only needs a square result");
@@ -730,10 +794,41 @@ int PAMD_dgemm_tn(const double *d_A, int lda, const double *d_B, int ldb, double
     const long kchunk = ((k + nsplit - 1) / nsplit + KB - 1) / KB * KB;
     const bool aligned = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)d_A | (uintptr_t)d_B) % 16 == 0) &&
                          (k % KB == 0) && (kchunk % KB == 0);
-    if ((lower_only & 2) && aligned && g_use_glds)
-        gemm_tn_glds_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn);
-    else
+    if ((lower_only & 2) && aligned && (g_use_glds || d_maskA))
+        gemm_tn_glds_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn,
+                                                  d_maskA, d_maskB, tm);
+    else {
+        PAMD_REQUIRE(d_maskA == nullptr, "masked dgemm_tn needs the aligned LDS-DMA path (flag 2, 16-byte aligned, k % 16 == 0)");
         gemm_tn_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn);
+    }
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int PAMD_dgemm_tn(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc,
+                  int m, int n, long k, int lower_only, int nsplit, void *stream)
+{
+    return dgemm_tn_impl(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only, nsplit, nullptr, nullptr, stream);
+}
+
+// Screened variant (numint._dot_ao_ao_sparse, pyscf/dft/numint.py:836-874 / VXCdot_ao_ao_sparse):
+// d_maskA[ceil(k/16)][ceil(m/128)], d_maskB[ceil(k/16)][ceil(n/128)] bytes; a k-tile is skipped for an output
+// tile when either panel tile is flagged 0.  Requires the aligned-operand contract of flag 2.
+int PAMD_dgemm_tn_masked(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc,
+                         int m, int n, long k, int nsplit, const unsigned char *d_maskA,
+                         const unsigned char *d_maskB, void *stream)
+{
+    PAMD_REQUIRE(d_maskA && d_maskB, "masks required");
+    return dgemm_tn_impl(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, 2, nsplit, d_maskA, d_maskB, stream);
+}
+
+// d_flags[ceil(nrows/16)][ceil(ld/16)]: 1 where the 16 x 16 tile of src[nrows][ld] has an element above thr
+// (the role of GTO_screen_index / make_mask, pyscf/lib/gto/grid_ao_drv.c:32-123, computed from the values)
+int PAMD_tile_mask(const double *d_src, long ld, long nrows, double thr, unsigned char *d_flags, void *stream)
+{
+    if (nrows == 0) return 0;
+    int nct = ceil_div(ld, 16);
+    tile_mask_kernel<<<ceil_div(nrows, 16), 256, 0, (hipStream_t)stream>>>(d_src, ld, nrows, thr, d_flags, nct);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

@@ -84,7 +84,8 @@ template <int DERIV>
 __global__ __launch_bounds__(256) void eval_ao_kernel(AOShells sh, int nsh, const int *__restrict__ fn2sh,
                                                       const double *__restrict__ coords, long g0, long ng,
                                                       const double *__restrict__ c2s, const int *__restrict__ c2s_off,
-                                                      double *__restrict__ ao, long ldg_rows, int ldao, int nao)
+                                                      double *__restrict__ ao, long ldg_rows, int ldao, int nao,
+                                                      double thr, unsigned char *__restrict__ flags)
 {
     __shared__ double s_rad[4][AO_SC][2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -135,6 +136,19 @@ __global__ __launch_bounds__(256) void eval_ao_kernel(AOShells sh, int nsh, cons
                 o[0] = v;
                 if (DERIV) { o[comp_stride] = vx; o[2 * comp_stride] = vy; o[3 * comp_stride] = vz; }
             }
+            if (flags) {
+                // 16 x 16 (grid x AO) tile flag: some component above thr.  One store per tile and wave:
+                // the lowest flagged lane among the lanes that share this lane's column tile writes it.
+                bool ex = valid && fabs(v) > thr;
+                if (DERIV) ex = ex || (valid && (fabs(vx) > thr || fabs(vy) > thr || fabs(vz) > thr));
+                const unsigned long long b = __ballot(ex);
+                if (ex) {
+                    int start = (mu & ~15) - (mu - lane);
+                    if (start < 0) start = 0;
+                    const unsigned long long earlier = b & ((1ull << lane) - 1) & ~((1ull << start) - 1);
+                    if (!earlier) flags[(gl >> 4) * (ldao >> 4) + (mu >> 4)] = 1;
+                }
+            }
         }
     }
 }
@@ -154,21 +168,25 @@ int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_
 }
 
 // ao[comp][ldg_rows][ldao] (AO index fastest; columns nao..ldao-1 zero), grid points
-// [g0, g0+ng) of d_coords[][3]; deriv = 0 (comp 1) or 1 (comp 4); d_fn2sh[mu] = shell of AO mu
+// [g0, g0+ng) of d_coords[][3]; deriv = 0 (comp 1) or 1 (comp 4); d_fn2sh[mu] = shell of AO mu.
+// d_flags (nullable, zeroed by the caller): [ceil(ldg_rows/16)][ldao/16] bytes, set to 1 where the
+// 16 x 16 (grid x AO) tile holds a value (any component) above thr -- the screening table that
+// GTO_screen_index / make_mask (pyscf/lib/gto/grid_ao_drv.c:32-123) estimate from exponents.
 int PAMD_eval_ao(int deriv, const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,
                  const double *d_xyz, const double *d_exps, const double *d_coefs, int nsh, const int *d_fn2sh,
                  int nao, const double *d_coords, long g0, long ng, const double *d_c2s, const int *d_c2s_off,
-                 double *d_ao, long ldg_rows, int ldao, void *stream)
+                 double *d_ao, long ldg_rows, int ldao, double thr, unsigned char *d_flags, void *stream)
 {
+    PAMD_REQUIRE(d_flags == nullptr || ldao % 16 == 0, "eval_ao: tile flags need ldao % 16 == 0");
     PAMD_REQUIRE(deriv == 0 || deriv == 1, "eval_ao: deriv must be 0 or 1");
     PAMD_REQUIRE(ldao >= nao, "eval_ao: ldao < nao");
     if (ng == 0 || nao == 0) return 0;
     AOShells sh{d_l, d_ao0, d_prim0, d_nprim, d_xyz, d_exps, d_coefs};
     dim3 grid(ceil_div(ng, 4));
     if (deriv)
-        eval_ao_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_fn2sh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg_rows, ldao, nao);
+        eval_ao_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_fn2sh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg_rows, ldao, nao, thr, d_flags);
     else
-        eval_ao_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_fn2sh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg_rows, ldao, nao);
+        eval_ao_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_fn2sh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg_rows, ldao, nao, thr, d_flags);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

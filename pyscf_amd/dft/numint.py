@@ -45,6 +45,18 @@ def grid_block_size(ngrids, max_rows, world=1):
     return max(256, min(blk, max_rows))
 
 
+def pick_nsplit(ntiles, slots=512, lo=2, hi=12):
+    """Split-k factor of the vmat GEMM: fill whole rounds of the chip's workgroup slots
+    (256 CUs x 2 resident 128 x 128 tiles) -- 225 tiles x 9 splits = 2025 of 2048, not 900 of 1024."""
+    best, best_eff = lo, 0.0
+    for ns in range(lo, hi + 1):
+        wg = ntiles * ns
+        eff = wg / (-(-wg // slots) * slots)
+        if eff > best_eff + 1e-9:
+            best, best_eff = ns, eff
+    return best
+
+
 class NumInt:
     """Duck-types the attributes RKS.get_veff uses (pyscf/dft/rks.py:76-131,384-404)."""
     libxc = _xc
@@ -52,6 +64,8 @@ class NumInt:
 
     def __init__(self, device=None, block_bytes=6 << 30, group=None):
         self.device = device
+        self.vmat_nsplit = None         # None: pick_nsplit()
+        self.screen_cutoff = 1e-15      # |value| below which a 16 x 16 AO tile is skipped (None: dense)
         self.block_bytes = block_bytes
         self.group = group
         self._cache = {}
@@ -121,18 +135,58 @@ class NumInt:
         else:
             _lib_mod.check(fn(*args))
 
-    def eval_ao_block(self, mol, coords_dev, g0, ng, deriv, out, rows, ldao):
-        """out[comp][rows][ldao] <- AO values (deriv=0: comp=1; deriv=1: comp=4) for grid points [g0,g0+ng)."""
+    # -- value-based screening (the role of non0tab / pair_mask, numint.py:2845, eval_gto.py:146+) -------
+    def _tile_flags(self, src, ld, total_rows):
+        """uint8 [total_rows/16][ld/16]: 16 x 16 tiles of src[total_rows][ld] holding an element > cutoff
+        (stand-alone pass; the AO flags come fused out of PAMD_eval_ao instead)."""
+        import torch
+        lib = _lib_mod.load_library()
+        flags = torch.empty((total_rows // 16, ld // 16), dtype=torch.uint8, device=src.device)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._call('tile_mask', lib.PAMD_tile_mask, _ptr(src), _c.c_long(ld), _c.c_long(total_rows),
+                   _c.c_double(self.screen_cutoff), _ptr(flags), st)
+        return flags
+
+    def _screen_masks(self, flags, ncomp, blk, ng):
+        """AO tile flags [blk/16][ldao/16] -> (kmask for PAMD_orb_dot_rows, panel mask for PAMD_dgemm_tn_masked).
+        One flag covers all components, so the scaled block aow = sum_c wv_c ao_c shares the panel mask."""
+        nct = flags.shape[1]
+        kmask = self._mask_n128_k16(flags, 1, blk)[:, :(ng + 127) // 128]
+        kmask = kmask.expand(ncomp, kmask.shape[1], nct).contiguous()
+        return kmask, self._mask_k16_n128(flags)
+
+    @staticmethod
+    def _mask_k16_n128(flags):
+        """[rows/16][ld/16] -> [rows/16][ceil(ld/128)]: panel tiles of the grid-contracted GEMM."""
+        import torch
+        nrt, nct = flags.shape
+        pad = (-nct) % 8
+        if pad:
+            flags = torch.nn.functional.pad(flags, (0, pad))
+        return flags.view(nrt, -1, 8).amax(dim=2).contiguous()
+
+    @staticmethod
+    def _mask_n128_k16(flags, ncomp, blk):
+        """[ncomp*blk/16][ld/16] -> [ncomp][blk/128][ld/16]: operand tiles of the AO-contracted GEMM."""
+        nct = flags.shape[1]
+        return flags.view(ncomp, blk // 128, 8, nct).amax(dim=2).contiguous()
+
+    def eval_ao_block(self, mol, coords_dev, g0, ng, deriv, out, rows, ldao, flags=None):
+        """out[comp][rows][ldao] <- AO values (deriv=0: comp=1; deriv=1: comp=4) for grid points [g0,g0+ng).
+        flags (optional uint8 [rows/16][ldao/16], zeroed here): screening tile table filled by the same kernel."""
         import torch
         lib = _lib_mod.load_library()
         dev = coords_dev.device
         t = self._shell_tables(mol, dev)
         eng = t['eng']
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if flags is not None:
+            flags.zero_()
         self._call('eval_ao', lib.PAMD_eval_ao, _c.c_int(deriv), _ptr(t['l']), _ptr(t['ao0']), _ptr(t['prim0']),
                    _ptr(t['nprim']), _ptr(eng.ao_xyz), _ptr(t['exps']), _ptr(t['coefs']), _c.c_int(t['nsh']),
                    _ptr(t['fn2sh']), _c.c_int(t['nao']), _ptr(coords_dev), _c.c_long(g0), _c.c_long(ng), _ptr(eng.c2s),
-                   _ptr(eng.c2s_off), _ptr(out), _c.c_long(rows), _c.c_int(ldao), st)
+                   _ptr(eng.c2s_off), _ptr(out), _c.c_long(rows), _c.c_int(ldao),
+                   _c.c_double(self.screen_cutoff or 0.0), _ptr(flags) if flags is not None else _c.c_void_p(0), st)
 
     def eval_ao(self, mol, coords, deriv=0):
         """Host convenience (tests): (ngrids, nao) or (4, ngrids, nao) like numint.eval_ao
@@ -184,8 +238,10 @@ class NumInt:
         ao = torch.zeros(ncomp * blk * ldao + 256, dtype=f64, device=dev)[:ncomp * blk * ldao].view(ncomp, blk, ldao)
         aow = torch.zeros(blk * ldao + 256, dtype=f64, device=dev)[:blk * ldao].view(blk, ldao)
         rho = torch.empty((4, blk), dtype=f64, device=dev)
+        screen = self.screen_cutoff is not None
+        fl_ao = torch.empty((blk // 16, ldao // 16), dtype=torch.uint8, device=dev) if screen else None
         wv = torch.empty((4, blk), dtype=f64, device=dev)
-        nsplit = 4
+        nsplit = self.vmat_nsplit or pick_nsplit(((nao + 127) // 128) ** 2)
         fac_c = (ctypes.c_double * 7)(*fac)
         for iset in range(nset):
             use_mo = mo_coeff is not None and np.ndim(mo_occ) == 1 and nset == 1
@@ -213,12 +269,15 @@ class NumInt:
                     continue
                 ng = min(blk, ngrids - g0)
                 ng16 = _round_up(ng, 16)
-                self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk, ldao)
+                self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk, ldao, fl_ao)
+                if screen:
+                    kmask, mpanel = self._screen_masks(fl_ao, ncomp, blk, ng)
                 if use_mo:
                     # c[comp][i][g] = sum_mu orb[mu][i] ao[comp][g][mu]   (GEMM shape of PAMD_cderi_solve)
                     self._call('ao_dot_mo', lib.PAMD_orb_dot_rows, _ptr(ao), _c.c_long(ldao), _c.c_long(blk * ldao),
                                _c.c_int(ncomp), _c.c_long(ng), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
-                               _c.c_int(nocc_pad), _ptr(cmo), _c.c_long(blk), st)
+                               _c.c_int(nocc_pad), _ptr(cmo), _c.c_long(blk),
+                               _ptr(kmask) if screen else _c.c_void_p(0), st)
                     self._call('rho', lib.PAMD_rho_from_mo, _ptr(cmo), _c.c_long(nocc_pad * blk), _c.c_long(blk),
                                _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho), _c.c_long(blk), st)
                 else:
@@ -234,9 +293,14 @@ class NumInt:
                 self._call('scale_ao', lib.PAMD_scale_ao, _ptr(ao), _ptr(wv), _c.c_int(ldao), _c.c_long(blk),
                            _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _c.c_long(ng16), _ptr(aow), st)
                 # vmat partial: M += ao0^T aow over the (16-padded, zero-weighted) grid rows of this block
-                self._call('ao_dot_aow', lib.PAMD_dgemm_tn, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow), _c.c_int(ldao),
-                           _ptr(part), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(ng16), _c.c_int(2),
-                           _c.c_int(nsplit), st)
+                if screen:
+                    self._call('ao_dot_aow', lib.PAMD_dgemm_tn_masked, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow),
+                               _c.c_int(ldao), _ptr(part), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao),
+                               _c.c_long(ng16), _c.c_int(nsplit), _ptr(mpanel), _ptr(mpanel), st)
+                else:
+                    self._call('ao_dot_aow', lib.PAMD_dgemm_tn, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow),
+                               _c.c_int(ldao), _ptr(part), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao),
+                               _c.c_long(ng16), _c.c_int(2), _c.c_int(nsplit), st)
             v = torch.empty((nao, nao), dtype=f64, device=dev)
             self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(part), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
                        _ptr(v), st)
@@ -281,8 +345,10 @@ class NumInt:
         ao = torch.zeros(ncomp * blk * ldao + 256, dtype=f64, device=dev)[:ncomp * blk * ldao].view(ncomp, blk, ldao)
         aow = torch.zeros(blk * ldao + 256, dtype=f64, device=dev)[:blk * ldao].view(blk, ldao)
         rho = torch.zeros((2, 4, blk), dtype=f64, device=dev)
+        screen = self.screen_cutoff is not None
+        fl_ao = torch.empty((blk // 16, ldao // 16), dtype=torch.uint8, device=dev) if screen else None
         wv = torch.empty((2, 4, blk), dtype=f64, device=dev)
-        nsplit = 4
+        nsplit = self.vmat_nsplit or pick_nsplit(((nao + 127) // 128) ** 2)
         fac_c = (ctypes.c_double * 7)(*fac)
         ops = []
         for s in range(2):
@@ -309,7 +375,9 @@ class NumInt:
                 continue
             ng = min(blk, ngrids - g0)
             ng16 = _round_up(ng, 16)
-            self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk, ldao)
+            self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk, ldao, fl_ao)
+            if screen:
+                kmask, mpanel = self._screen_masks(fl_ao, ncomp, blk, ng)
             for s in range(2):
                 if use_mo:
                     orb, nocc, nocc_pad, ldo, cmo = ops[s]
@@ -318,7 +386,8 @@ class NumInt:
                         continue
                     self._call('ao_dot_mo', lib.PAMD_orb_dot_rows, _ptr(ao), _c.c_long(ldao), _c.c_long(blk * ldao),
                                _c.c_int(ncomp), _c.c_long(ng), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
-                               _c.c_int(nocc_pad), _ptr(cmo), _c.c_long(blk), st)
+                               _c.c_int(nocc_pad), _ptr(cmo), _c.c_long(blk),
+                               _ptr(kmask) if screen else _c.c_void_p(0), st)
                     self._call('rho', lib.PAMD_rho_from_mo, _ptr(cmo), _c.c_long(nocc_pad * blk), _c.c_long(blk),
                                _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho[s]), _c.c_long(blk), st)
                 else:
@@ -335,9 +404,14 @@ class NumInt:
             for s in range(2):
                 self._call('scale_ao', lib.PAMD_scale_ao, _ptr(ao), _ptr(wv[s]), _c.c_int(ldao), _c.c_long(blk),
                            _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _c.c_long(ng16), _ptr(aow), st)
-                self._call('ao_dot_aow', lib.PAMD_dgemm_tn, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow), _c.c_int(ldao),
-                           _ptr(part[s]), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(ng16), _c.c_int(2),
-                           _c.c_int(nsplit), st)
+                if screen:
+                    self._call('ao_dot_aow', lib.PAMD_dgemm_tn_masked, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow),
+                               _c.c_int(ldao), _ptr(part[s]), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao),
+                               _c.c_long(ng16), _c.c_int(nsplit), _ptr(mpanel), _ptr(mpanel), st)
+                else:
+                    self._call('ao_dot_aow', lib.PAMD_dgemm_tn, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow),
+                               _c.c_int(ldao), _ptr(part[s]), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao),
+                               _c.c_long(ng16), _c.c_int(2), _c.c_int(nsplit), st)
         v = torch.empty((2, nao, nao), dtype=f64, device=dev)
         for s in range(2):
             self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(part[s]), _c.c_int(nsplit), _c.c_int(nao),

@@ -97,3 +97,54 @@ def test_error_codes_not_exit():
     assert rc < 0
     with pytest.raises(lib.HIPError):
         lib.check(so.PAMD_set_tuning(b'nope', 1))
+
+
+@pytest.mark.parametrize('m,n,k,nsplit', [(300, 200, 4096, 3), (128, 128, 16 * 2500 * 2, 1), (257, 257, 1024, 4)])
+def test_dgemm_tn_masked_and_tile_mask(m, n, k, nsplit):
+    """Screened GEMM == dense GEMM with the flagged-off 16 x 128 panel tiles zeroed; the flags come from
+    PAMD_tile_mask (16 x 16 tiles), reduced to panels on the host side of the test."""
+    torch, so, dev, st, lib = _setup()
+    rng = np.random.default_rng(m * 7 + n + k)
+    lda, ldb = (m + 15) // 16 * 16, (n + 15) // 16 * 16
+
+    def blocky(rows, ld, cols):
+        x = np.zeros((rows, ld))
+        x[:, :cols] = rng.standard_normal((rows, cols))
+        kill = rng.random((rows // 16, ld // 16)) < 0.6          # 60 % of the 16 x 16 tiles ~ 1e-20
+        x *= np.where(np.kron(kill, np.ones((16, 16))) > 0, 1e-20, 1.0)
+        return x
+    a, b = blocky(k, lda, m), blocky(k, ldb, n)
+    ta = torch.zeros(k * lda + 256, dtype=torch.float64, device=dev); ta[:k * lda] = torch.from_numpy(a.ravel()).to(dev)
+    tb = torch.zeros(k * ldb + 256, dtype=torch.float64, device=dev); tb[:k * ldb] = torch.from_numpy(b.ravel()).to(dev)
+    thr = 1e-15
+
+    def panel_mask(t, ld):
+        fl = torch.empty((k // 16, ld // 16), dtype=torch.uint8, device=dev)
+        lib.check(so.PAMD_tile_mask(_p(t), C.c_long(ld), C.c_long(k), C.c_double(thr), _p(fl), st))
+        f = fl.cpu().numpy()
+        ref = np.abs(t[:k * ld].cpu().numpy().reshape(k // 16, 16, ld // 16, 16)).max(axis=(1, 3)) > thr
+        assert np.array_equal(f.astype(bool), ref)
+        npan = (ld + 127) // 128
+        pm = np.zeros((k // 16, npan), np.uint8)
+        for j in range(ld // 16):
+            pm[:, j // 8] |= f[:, j]
+        return pm
+    ma, mb = panel_mask(ta, lda), panel_mask(tb, ldb)
+    # the kernel indexes masks with ceil(m/128), ceil(n/128) columns
+    tm, tn = (m + 127) // 128, (n + 127) // 128
+    ma, mb = np.ascontiguousarray(ma[:, :tm]), np.ascontiguousarray(mb[:, :tn])
+    tma, tmb = torch.from_numpy(ma).to(dev), torch.from_numpy(mb).to(dev)
+    part = torch.zeros((nsplit, m, n), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_dgemm_tn_masked(_p(ta), lda, _p(tb), ldb, _p(part), n, m, n, C.c_long(k), nsplit,
+                                      _p(tma), _p(tmb), st))
+    got = part.sum(0).cpu().numpy()
+    # reference: k-tile contributes to output tile (i, j) only when both panel tiles are flagged
+    ref = np.zeros((m, n))
+    for i in range(tm):
+        for j in range(tn):
+            act = (ma[:, i] & mb[:, j]).astype(bool)
+            rows = np.repeat(act, 16)
+            ref[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = \
+                a[rows][:, i * 128:min((i + 1) * 128, m)].T @ b[rows][:, j * 128:min((j + 1) * 128, n)]
+    assert abs(got - ref).max() < 1e-10
+    assert abs(got - a[:, :m].T @ b[:, :n]).max() < 1e-10          # and the skipped work was negligible

@@ -14,6 +14,8 @@ ap.add_argument('--nwater', type=int, default=32)
 ap.add_argument('--basis', default='cc-pvtz')
 ap.add_argument('--xc', default='b3lyp')
 ap.add_argument('--steps', type=int, default=2)
+ap.add_argument('--nsplit', type=int, default=0)
+ap.add_argument('--dense', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 mol = gto.M(atom=clusters.water_cluster(a.nwater), basis=a.basis)
@@ -29,6 +31,8 @@ c = x.dot(v / np.sqrt(w)).dot(v.T)
 occ = np.zeros(nao); occ[:nocc] = 2
 dm = lib.tag_array((c[:, :nocc] * 2).dot(c[:, :nocc].T), mo_coeff=c, mo_occ=occ)
 ni = dft.NumInt()
+if a.nsplit: ni.vmat_nsplit = a.nsplit
+if a.dense: ni.screen_cutoff = None
 n, e, vm = ni.nr_rks(mol, grids, a.xc, dm)
 torch.cuda.synchronize()
 ni.kernel_timer = df_jk.KernelTimer()
@@ -38,7 +42,7 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / a.steps
 s = ni.kernel_timer.summary()
-out = {'nao': nao, 'nocc': nocc, 'ngrids': int(grids.size), 'grid_build_s': round(t_grid, 2), 'nelec': float(n),
+out = {'nsplit': a.nsplit, 'dense': a.dense, 'nao': nao, 'nocc': nocc, 'ngrids': int(grids.size), 'grid_build_s': round(t_grid, 2), 'nelec': float(n),
        'nelec_exact': mol.nelectron, 'exc': float(e), 'wall_ms_per_call': round(wall * 1e3, 1),
        'kernel_ms': {k: round(t / a.steps, 2) for k, (t, c_) in s.items()}}
 ng = grids.size
