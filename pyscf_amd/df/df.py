@@ -155,6 +155,9 @@ class DF:
     def build(self):
         import torch
         dev = self._device()
+        if isinstance(self._cderi, str):
+            with open(self._cderi, 'rb') as f:
+                self._cderi = np.load(f)
         if self._cderi is not None and isinstance(self._cderi, np.ndarray):
             # pre-computed tensor handed over by the caller (pyscf/df/df.py:153-155)
             naux = self._cderi.shape[0]
@@ -169,7 +172,10 @@ class DF:
         l0, l1 = self.shard_range(self._naux, self.rank, self.world_size)
         self._cderi_dev = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1,
                                                   lindep=self.lindep, omega=self.omega)
+        if isinstance(self._cderi_to_save, str):
+            self.save(self._cderi_to_save)
         return self
+    kernel = build
 
     def get_naoaux(self):
         if self._naux is None:
@@ -185,6 +191,91 @@ class DF:
         n = self._cderi_dev.shape[0]
         for b0 in range(0, n, blksize):
             yield self._cderi_dev[b0:b0 + blksize].cpu().numpy()
+
+    # -- downstream consumers of the tensor ----------------------------------
+    def _pair_gram(self, a, b):
+        """sum_L a[L,:]^T b[L,:] over this rank's rows, all-reduced over the aux shards."""
+        import torch
+        import ctypes as _c
+        from .. import lib as _lib
+        so = _lib.load_library()
+        m, n, k = a.shape[1], b.shape[1], a.shape[0]
+        out = torch.zeros((1, m, n), dtype=torch.float64, device=a.device)
+        if k:
+            st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+            df_jk._call(self, 'dgemm_tn', so.PAMD_dgemm_tn, _c.c_void_p(a.data_ptr()), _c.c_int(a.stride(0)),
+                        _c.c_void_p(b.data_ptr()), _c.c_int(b.stride(0)), _c.c_void_p(out.data_ptr()), _c.c_int(n),
+                        _c.c_int(m), _c.c_int(n), _c.c_long(k), _c.c_int(0), _c.c_int(1), st)
+        df_jk._allreduce(self, [out])
+        return out[0]
+
+    def get_eri(self):
+        """8-fold packed (pq|rs) ~ sum_L B[L,pq] B[L,rs] (pyscf/df/df.py:269-276: lib.dot(eri1.T, eri1)
+        then ao2mo.restore(8, ...)): the lower triangle of the (nao_pair, nao_pair) matrix."""
+        from .. import lib as _lib
+        if self._cderi_dev is None:
+            self.build()
+        eri4 = self._pair_gram(self._cderi_dev, self._cderi_dev).cpu().numpy()
+        return _lib.pack_tril(eri4)
+    get_ao_eri = get_eri
+
+    def _half_transform_pairs(self, ci, cj, compact):
+        """Lij[L, ij] = sum_pq ci[p,i] B_L[p,q] cj[q,j] on the device (the role of _ao2mo.nr_e2 with
+        aosym='s2', pyscf/df/df.py:287-293); ij packed i >= j when ci is cj and compact."""
+        import torch
+        import ctypes as _c
+        from .. import lib as _lib
+        so = _lib.load_library()
+        cderi = self._cderi_dev
+        naux, npair = cderi.shape
+        nao = self.mol.nao_nr()
+        dev = cderi.device
+        same = compact and ci.shape == cj.shape and abs(ci - cj).max() < 1e-13      # iden_coeffs, ao2mo/incore.py
+        orb, ni_pad, ldo = df_jk.pad_orbitals(np.asarray(ci, dtype=np.float64), dev)
+        ni, nj = ci.shape[1], cj.shape[1]
+        cj_dev = torch.from_numpy(np.ascontiguousarray(cj, dtype=np.float64)).to(dev)
+        ldx = (nao + 15) // 16 * 16
+        blk = max(1, min(max(naux, 1), int((1 << 30) // (max(ni_pad, 16) * ldx * 8))))
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        out = torch.empty((naux, ni * (ni + 1) // 2 if same else ni * nj), dtype=torch.float64, device=dev)
+        if same:
+            ti, tj = np.tril_indices(ni)
+            sel = torch.from_numpy(ti * nj + tj).to(dev)
+        for b0 in range(0, naux, blk):
+            nb = min(blk, naux - b0)
+            X = torch.zeros((nb, ni_pad, ldx), dtype=torch.float64, device=dev)
+            df_jk._call(self, 'e2_symm', so.PAMD_nr_e2_symm, _c.c_void_p(cderi[b0:b0 + nb].data_ptr()), _c.c_long(npair),
+                        _c.c_int(nb), _c.c_int(nao), _c.c_void_p(orb.data_ptr()), _c.c_int(ldo),
+                        _c.c_int(orb.shape[0]), _c.c_int(ni_pad), _c.c_void_p(X.data_ptr()), _c.c_int(ldx), st)
+            y = torch.matmul(X[:, :ni, :nao], cj_dev).reshape(nb, ni * nj)      # second index: plain library GEMM
+            out[b0:b0 + nb] = y[:, sel] if same else y
+        return out
+
+    def ao2mo(self, mo_coeffs, compact=True):
+        """(ij|kl) in the MO bases mo_coeffs = (Ci, Cj, Ck, Cl) (or one matrix for all four):
+        matrix (nij_pair, nkl_pair), pairs packed when the two coefficient blocks coincide and
+        `compact` (pyscf/df/df.py:278-296)."""
+        if self._cderi_dev is None:
+            self.build()
+        if isinstance(mo_coeffs, np.ndarray) and mo_coeffs.ndim == 2:
+            mo_coeffs = (mo_coeffs,) * 4
+        ci, cj, ck, cl = [np.asarray(c, dtype=np.float64) for c in mo_coeffs]
+        lij = self._half_transform_pairs(ci, cj, compact)
+        sym = ci.shape == ck.shape and cj.shape == cl.shape and abs(ci - ck).max() < 1e-13 and abs(cj - cl).max() < 1e-13
+        lkl = lij if sym else self._half_transform_pairs(ck, cl, compact)
+        return self._pair_gram(lij, lkl).cpu().numpy()
+    get_mo_eri = ao2mo
+
+    def save(self, path=None):
+        """Write the rank-local rows as a .npy file (the reference writes the HDF5 dataset 'j3c',
+        pyscf/df/df.py:97-99,185-199; h5py is not available in this image).  `DF(mol)._cderi = path`
+        loads it back in build()."""
+        path = path or self._cderi_to_save
+        if self._cderi_dev is None:
+            self.build()
+        with open(path, 'wb') as f:
+            np.save(f, self._cderi_dev.cpu().numpy())
+        return path
 
     def range_coulomb(self, omega):
         """DF object holding the long-range (erf(omega r12)/r12) tensor, cached per omega

@@ -157,3 +157,40 @@ def test_edge_cases_empty_shard_zero_occ_and_eig_fallback(h2o):
     cd2 = incore.cholesky_eri_gpu(mol, aux2, dev).cpu().numpy()
     assert cd2.shape[0] < aux2.nao                       # dependent functions were projected out
     assert np.abs(cd2.T.dot(cd2) - cderi.T.dot(cderi)).max() < 1e-6
+
+
+def test_get_eri_ao2mo_and_npy_roundtrip(h2o, tmp_path):
+    """pyscf/df/test/test_df.py:44-70 (test_ao2mo: four different MO blocks, then one square block) and
+    :72-87 (_cderi_to_save / _cderi = file): DF.get_eri, DF.ao2mo and the saved tensor against plain
+    numpy contractions of the oracle tensor."""
+    from pyscf_amd import df, lib
+    mol, aux, cderi = h2o
+    obj = _dfobj(mol, cderi)
+    nao = mol.nao
+    eri4 = cderi.T.dot(cderi)
+    assert np.abs(obj.get_eri() - lib.pack_tril(eri4)).max() < 1e-11
+    b = lib.unpack_tril(cderi)                                   # (naux, nao, nao)
+    np.random.seed(1)
+    mos = np.random.random((nao, nao * 10))
+    mos = (mos[:, :5], mos[:, 5:11], mos[:, 3:9], mos[:, 2:4])
+    lij = np.einsum('pi,Lpq,qj->Lij', mos[0], b, mos[1]).reshape(len(b), -1)
+    lkl = np.einsum('pi,Lpq,qj->Lij', mos[2], b, mos[3]).reshape(len(b), -1)
+    got = obj.ao2mo(mos)
+    assert got.shape == (30, 12) and np.abs(got - lij.T.dot(lkl)).max() < 1e-10
+    mo = np.random.random((nao, nao))
+    l1 = np.einsum('pi,Lpq,qj->Lij', mo, b, mo)
+    ti, tj = np.tril_indices(nao)
+    l1 = l1[:, ti, tj]
+    got = obj.ao2mo(mo)
+    assert got.shape == (nao * (nao + 1) // 2,) * 2 and np.abs(got - l1.T.dot(l1)).max() < 1e-9
+    full = obj.ao2mo(mo, compact=False)
+    assert full.shape == (nao * nao, nao * nao)
+    # save / reload
+    path = str(tmp_path / 'cderi.npy')
+    obj.save(path)
+    obj2 = df.DF(mol)
+    obj2._cderi = path
+    assert obj2.get_naoaux() == cderi.shape[0]
+    assert np.abs(obj2.get_eri() - obj.get_eri()).max() < 1e-12
+    blocks = np.vstack(list(obj2.loop(40)))
+    assert np.abs(blocks - cderi).max() < 1e-14
