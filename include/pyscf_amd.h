@@ -75,6 +75,29 @@ long PAMD_rys_table_len(void);
 int PAMD_rys_table_upload(double *d_dst, void *stream);
 int PAMD_rys_table_host(double *h_dst, int *offsets, int *nint, double *herm_u, double *herm_w);
 int PAMD_int3c2e_class(int li, int lj, int lk, const PAMD_int3c2e_args *args, void *stream);
+
+/* Nuclear-gradient contraction, generate-and-contract in place (no derivative tensor):
+ *   grad[rep][atom][3] += sum_{pq,Q} Z[row(pq)][Q] d(pq|Q)/dR_atom        for one angular class.
+ * Replaces the int3c2e_ip1 / int3c2e_ip2 / int2c2e_ip1 blocks that pyscf/df/grad/rhf.py:117-199 (get_jk) forms with
+ * libcint and contracts on the host; with point-charge aux shells also the int1e_ipnuc / int1e_iprinv terms of
+ * pyscf/grad/rhf.py:91-146.  The third-centre derivative is -(d/dA + d/dB) (translational invariance). */
+typedef struct PAMD_int3c2e_grad_args {
+    PAMD_int3c2e_args base;      /* base.T = Z (read only), addressed exactly like the integral output T        */
+    const double *pp_ab;         /* [npp_total][2] primitive exponents (alpha_i, alpha_j) of each pp record      */
+    const int *shell_atom;       /* [nshell_ao] atom of each AO-side shell                                       */
+    const int *aux_atom;         /* [naux_cls]  atom of each aux shell of the class                              */
+    double *grad;                /* [nrep][natm][3] FP64 atomicAdd accumulators; the caller sums the replicas   */
+    int nrep;
+    int natm;
+    int aux_response;            /* 0: omit the third-centre derivative (auxbasis_response=False, df/grad/rhf.py:133) */
+} PAMD_int3c2e_grad_args;
+int PAMD_int3c2e_grad_class(int li, int lj, int lk, const PAMD_int3c2e_grad_args *args, void *stream);
+/* d_grad[natm][3] += Tr(Dt dT/dR) - Tr(Ws dS/dR): int1e_ipkin / int1e_ipovlp contractions of
+ * pyscf/grad/rhf.py:62-75; Dt, Ws symmetric (nao, nao) */
+int PAMD_int1e_grad(const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,
+                    const double *d_xyz, const double *d_exps, const double *d_coefs, const int *d_sh_atom,
+                    int nsh, int nao, const double *d_c2s, const int *d_c2s_off, const double *d_Dt,
+                    const double *d_Ws, double *d_grad, void *stream);
 int PAMD_int1e_ovlp_kin(const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,
                         const double *d_xyz, const double *d_exps, const double *d_coefs, int nsh,
                         int nao, const double *d_c2s, const int *d_c2s_off, double *d_S, double *d_K,

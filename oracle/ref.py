@@ -292,8 +292,9 @@ def rhf_kernel(mol, get_veff, conv_tol=1e-10, max_cycle=60, dm0=None, h1e=None, 
     return conv, e_tot, e, c, mo_occ, dm
 
 
-def uhf_kernel(mol, cderi, nelec, conv_tol=1e-10, max_cycle=80):
-    """Minimal DF-UHF loop with the oracle pieces (pyscf/scf/uhf.py semantics: V_s = J[Da+Db] - K[Ds])."""
+def uhf_kernel(mol, cderi, nelec, conv_tol=1e-10, max_cycle=80, mo0=None):
+    """Minimal DF-UHF loop with the oracle pieces (pyscf/scf/uhf.py semantics: V_s = J[Da+Db] - K[Ds]).
+    mo0 = (Ca, Cb) optional starting orbitals (to follow a given SCF state); default core-Hamiltonian guess."""
     h1e = int1e(mol, 'kin') + int1e(mol, 'nuc')
     s1e = int1e(mol, 'ovlp')
     enuc = mol.energy_nuc()
@@ -304,7 +305,7 @@ def uhf_kernel(mol, cderi, nelec, conv_tol=1e-10, max_cycle=80):
         e, c = scipy.linalg.eigh(x.T.dot(f).dot(x))
         return e, x.dot(c)
     e0, c0 = eig(h1e)
-    cs = [c0, c0]
+    cs = [c0, c0] if mo0 is None else [np.asarray(mo0[0]), np.asarray(mo0[1])]
     diis_f, diis_e = [], []
     e_tot = 0
     for cycle in range(max_cycle):

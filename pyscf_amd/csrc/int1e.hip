@@ -107,6 +107,106 @@ __global__ void int1e_ovlp_kin_kernel(ShellTab t, int nsh, int nao, const double
         }
 }
 
+
+// grad[atom] += sum_pq ( Dt[p][q] d<p|T|q>/dR_atom - Ws[p][q] d<p|q>/dR_atom ): the int1e_ipkin and
+// int1e_ipovlp contractions of pyscf/grad/rhf.py:62-75 (grad_elec: h1ao . dm0, s1 . dme0), one thread per
+// shell pair i > j on different atoms.  d/dA = -grad_r on function i; (grad i|O|j) = -(i|O|grad j) for
+// these two-centre operators, so one derivative block serves both atoms.
+__global__ void int1e_grad_kernel(ShellTab t, const int *__restrict__ sh_atom, int nsh, int nao,
+                                  const double *__restrict__ c2s, const int *__restrict__ c2s_off,
+                                  const double *__restrict__ Dt, const double *__restrict__ Ws,
+                                  double *__restrict__ grad)
+{
+    long pid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long npairs = (long)nsh * (nsh + 1) / 2;
+    if (pid >= npairs) return;
+    int ish = (int)((sqrt(8.0 * pid + 1.0) - 1.0) * 0.5);
+    while ((long)(ish + 1) * (ish + 2) / 2 <= pid) ish++;
+    while ((long)ish * (ish + 1) / 2 > pid) ish--;
+    int jsh = (int)(pid - (long)ish * (ish + 1) / 2);
+    const int ia = sh_atom[ish], ja = sh_atom[jsh];
+    if (ia == ja) return;
+    const int li = t.l[ish], lj = t.l[jsh];
+    const int nci = (li + 1) * (li + 2) / 2, ncj = (lj + 1) * (lj + 2) / 2;
+    const int nsi = 2 * li + 1, nsj = 2 * lj + 1;
+    // contraction weights of the block in the Cartesian basis: xk for the kinetic, xs for the overlap derivative
+    double xk[NC * NC], xs[NC * NC];
+    const double *ci_m = c2s + c2s_off[li], *cj_m = c2s + c2s_off[lj];
+    for (int ci = 0; ci < nci; ci++)
+        for (int cj = 0; cj < ncj; cj++) {
+            double vk = 0, vs = 0;
+            for (int mi = 0; mi < nsi; mi++) {
+                const double f = ci_m[mi * nci + ci];
+                if (f == 0) continue;
+                for (int mj = 0; mj < nsj; mj++) {
+                    const double g = f * cj_m[mj * ncj + cj];
+                    const long p = t.ao0[ish] + mi, q = t.ao0[jsh] + mj;
+                    vk += g * Dt[p * nao + q];
+                    vs += g * Ws[p * nao + q];
+                }
+            }
+            xk[ci * ncj + cj] = vk;
+            xs[ci * ncj + cj] = vs;
+        }
+    double gr[3] = {0, 0, 0};
+    const double *A = t.xyz + 3 * ish, *B = t.xyz + 3 * jsh;
+    for (int pa = 0; pa < t.nprim[ish]; pa++)
+    for (int pb = 0; pb < t.nprim[jsh]; pb++) {
+        const double a = t.exps[t.prim0[ish] + pa], b = t.exps[t.prim0[jsh] + pb];
+        const double cc = t.coefs[t.prim0[ish] + pa] * t.coefs[t.prim0[jsh] + pb];
+        const double p = a + b, mu = a * b / p, hp = 0.5 / p;
+        double s[3][LMAX + 2][LMAX + 3];
+        for (int d = 0; d < 3; d++) {
+            const double ab = A[d] - B[d];
+            const double P = (a * A[d] + b * B[d]) / p;
+            const double pa_ = P - A[d], pb_ = P - B[d];
+            s[d][0][0] = sqrt(M_PI / p) * exp(-mu * ab * ab);
+            for (int i = 0; i < li + 1; i++)
+                s[d][i + 1][0] = pa_ * s[d][i][0] + (i ? hp * i * s[d][i - 1][0] : 0.0);
+            for (int j = 0; j < lj + 2; j++)
+                for (int i = 0; i <= li + 1; i++) {
+                    double v = pb_ * s[d][i][j];
+                    if (i) v += hp * i * s[d][i - 1][j];
+                    if (j) v += hp * j * s[d][i][j - 1];
+                    s[d][i][j + 1] = v;
+                }
+        }
+        auto kin1 = [&](int d, int i, int j) {           // 1-D kinetic factor T(i,j)
+            double v = -2 * b * (2 * j + 1) * s[d][i][j] + 4 * b * b * s[d][i][j + 2];
+            if (j >= 2) v += j * (j - 1) * s[d][i][j - 2];
+            return -0.5 * v;
+        };
+        for (int ci = 0; ci < nci; ci++) {
+            int ix[3];
+            cart_exps(li, ci, ix[0], ix[1], ix[2]);
+            for (int cj = 0; cj < ncj; cj++) {
+                int jx[3];
+                cart_exps(lj, cj, jx[0], jx[1], jx[2]);
+                double s1[3], t1[3], ds[3], dt[3];
+                for (int d = 0; d < 3; d++) {
+                    const int i = ix[d], j = jx[d];
+                    s1[d] = s[d][i][j];
+                    t1[d] = kin1(d, i, j);
+                    ds[d] = -2 * a * s[d][i + 1][j] + (i ? i * s[d][i - 1][j] : 0.0);
+                    dt[d] = -2 * a * kin1(d, i + 1, j) + (i ? i * kin1(d, i - 1, j) : 0.0);
+                }
+                const double wk = cc * xk[ci * ncj + cj], ws = cc * xs[ci * ncj + cj];
+                for (int d = 0; d < 3; d++) {
+                    const int e = (d + 1) % 3, f = (d + 2) % 3;
+                    const double dS = ds[d] * s1[e] * s1[f];
+                    const double dT = dt[d] * s1[e] * s1[f] + ds[d] * (t1[e] * s1[f] + s1[e] * t1[f]);
+                    gr[d] += wk * dT - ws * dS;
+                }
+            }
+        }
+    }
+    // the block (p in i, q in j) and its transpose: factor 2; nuclear derivative on A = -(grad i|..), on B = +(grad i|..)
+    for (int d = 0; d < 3; d++) {
+        atomicAdd(grad + ia * 3 + d, -2.0 * gr[d]);
+        atomicAdd(grad + ja * 3 + d, 2.0 * gr[d]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -121,6 +221,21 @@ int PAMD_int1e_ovlp_kin(const int *d_l, const int *d_ao0, const int *d_prim0, co
     long npairs = (long)nsh * (nsh + 1) / 2;
     int1e_ovlp_kin_kernel<<<ceil_div(npairs, 64), 64, 0, (hipStream_t)stream>>>(t, nsh, nao, d_c2s, d_c2s_off,
                                                                                d_S, d_K);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// d_grad[natm][3] += Tr(Dt dT/dR) - Tr(Ws dS/dR); Dt, Ws symmetric (nao, nao) device matrices
+int PAMD_int1e_grad(const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,
+                    const double *d_xyz, const double *d_exps, const double *d_coefs, const int *d_sh_atom,
+                    int nsh, int nao, const double *d_c2s, const int *d_c2s_off, const double *d_Dt,
+                    const double *d_Ws, double *d_grad, void *stream)
+{
+    if (nsh == 0) return 0;
+    ShellTab t{d_l, d_ao0, d_prim0, d_nprim, d_xyz, d_exps, d_coefs};
+    long npairs = (long)nsh * (nsh + 1) / 2;
+    int1e_grad_kernel<<<ceil_div(npairs, 64), 64, 0, (hipStream_t)stream>>>(t, d_sh_atom, nsh, nao, d_c2s, d_c2s_off,
+                                                                           d_Dt, d_Ws, d_grad);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

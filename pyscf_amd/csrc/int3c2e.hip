@@ -17,6 +17,11 @@ int launch_int3c2e_lk1(int, int, const Int3c2eArgs &, hipStream_t);
 int launch_int3c2e_lk2(int, int, const Int3c2eArgs &, hipStream_t);
 int launch_int3c2e_lk3(int, int, const Int3c2eArgs &, hipStream_t);
 int launch_int3c2e_lk4(int, int, const Int3c2eArgs &, hipStream_t);
+int launch_int3c2e_grad_lk0(int, int, const Int3c2eGradArgs &, hipStream_t);
+int launch_int3c2e_grad_lk1(int, int, const Int3c2eGradArgs &, hipStream_t);
+int launch_int3c2e_grad_lk2(int, int, const Int3c2eGradArgs &, hipStream_t);
+int launch_int3c2e_grad_lk3(int, int, const Int3c2eGradArgs &, hipStream_t);
+int launch_int3c2e_grad_lk4(int, int, const Int3c2eGradArgs &, hipStream_t);
 }
 
 using namespace pamd;
@@ -191,6 +196,25 @@ int PAMD_int3c2e_class(int li, int lj, int lk, const PAMD_int3c2e_args *args, vo
     case 3: return launch_int3c2e_lk3(li, lj, a, st);
     case 4: return launch_int3c2e_lk4(li, lj, a, st);
     default: return set_error(-2, "int3c2e: aux angular momentum > 4 unsupported", __FILE__, __LINE__);
+    }
+}
+
+// grad[rep][atom][3] += sum_{pq,Q} Z[pq][Q] d(pq|Q)/dR_atom for one angular class: the contraction that
+// pyscf/df/grad/rhf.py:117-199 performs with int3c2e_ip1 / int3c2e_ip2 / int2c2e_ip1 blocks, and (with
+// point-charge aux shells) the int1e_ipnuc / int1e_iprinv part of pyscf/grad/rhf.py:91-146 (hcore_generator).
+int PAMD_int3c2e_grad_class(int li, int lj, int lk, const PAMD_int3c2e_grad_args *args, void *stream)
+{
+    PAMD_REQUIRE(li >= lj, "int3c2e_grad class needs l_i >= l_j");
+    PAMD_REQUIRE(args->nrep >= 1 && args->natm >= 1, "int3c2e_grad: nrep, natm >= 1");
+    const Int3c2eGradArgs &a = *reinterpret_cast<const Int3c2eGradArgs *>(args);
+    hipStream_t st = (hipStream_t)stream;
+    switch (lk) {
+    case 0: return launch_int3c2e_grad_lk0(li, lj, a, st);
+    case 1: return launch_int3c2e_grad_lk1(li, lj, a, st);
+    case 2: return launch_int3c2e_grad_lk2(li, lj, a, st);
+    case 3: return launch_int3c2e_grad_lk3(li, lj, a, st);
+    case 4: return launch_int3c2e_grad_lk4(li, lj, a, st);
+    default: return set_error(-2, "int3c2e_grad: aux angular momentum > 4 unsupported", __FILE__, __LINE__);
     }
 }
 

@@ -31,4 +31,18 @@ typedef struct PAMD_int3c2e_args {
     double omega;               // > 0: long-range operator erf(omega r12)/r12 (env[PTR_RANGE_OMEGA]); 0: Coulomb
 } PAMD_int3c2e_args;
 }
-namespace pamd { typedef PAMD_int3c2e_args Int3c2eArgs; }
+extern "C" {
+// Argument block of one gradient-contraction class launch (int3c2e_grad_kernel.h).
+typedef struct PAMD_int3c2e_grad_args {
+    PAMD_int3c2e_args base;      // base.T = Z (read only): same row/column addressing as the integral kernel
+    const double *pp_ab;         // [npp_total][2]: primitive exponents (alpha_i, alpha_j) of every primitive-pair record
+    const int *shell_atom;       // [nshell_ao]  atom of each AO-side shell
+    const int *aux_atom;         // [naux_cls]   atom of each aux shell of the class
+    double *grad;                // [nrep][natm][3] accumulators (atomicAdd; the caller sums the replicas)
+    int nrep;
+    int natm;
+    int aux_response;            // 0: leave out the derivative of the third centre
+} PAMD_int3c2e_grad_args;
+}
+
+namespace pamd { typedef PAMD_int3c2e_args Int3c2eArgs; typedef PAMD_int3c2e_grad_args Int3c2eGradArgs; }

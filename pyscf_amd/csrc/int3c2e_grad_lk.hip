@@ -1,0 +1,34 @@
+// Instantiates the gradient-contraction kernel family for one aux angular momentum (compile with
+// -DPAMD_LK=<0..4>); see int3c2e_grad_kernel.h.
+#include "int3c2e_grad_kernel.h"
+
+#ifndef PAMD_LK
+#error "compile with -DPAMD_LK=<l_aux>"
+#endif
+
+namespace pamd {
+
+#define PAMD_CAT2(a, b) a##b
+#define PAMD_CAT(a, b) PAMD_CAT2(a, b)
+
+int PAMD_CAT(launch_int3c2e_grad_lk, PAMD_LK)(int li, int lj, const Int3c2eGradArgs &a, hipStream_t st)
+{
+    constexpr int LK = PAMD_LK;
+    switch (li * 8 + lj) {
+    case 0 * 8 + 0: return launch_grad_class<0, 0, LK>(a, st);
+    case 1 * 8 + 0: return launch_grad_class<1, 0, LK>(a, st);
+    case 1 * 8 + 1: return launch_grad_class<1, 1, LK>(a, st);
+    case 2 * 8 + 0: return launch_grad_class<2, 0, LK>(a, st);
+    case 2 * 8 + 1: return launch_grad_class<2, 1, LK>(a, st);
+    case 2 * 8 + 2: return launch_grad_class<2, 2, LK>(a, st);
+    case 3 * 8 + 0: return launch_grad_class<3, 0, LK>(a, st);
+    case 3 * 8 + 1: return launch_grad_class<3, 1, LK>(a, st);
+    case 3 * 8 + 2: return launch_grad_class<3, 2, LK>(a, st);
+    case 3 * 8 + 3: return launch_grad_class<3, 3, LK>(a, st);
+    case 4 * 8 + 0: return launch_grad_class<4, 0, LK>(a, st);   // 2-centre d(P|Q) with l_P = 4
+    default:
+        return set_error(-2, "int3c2e_grad: unsupported (l_i, l_j) class (AO l <= 3 supported)", __FILE__, __LINE__);
+    }
+}
+
+}  // namespace pamd

@@ -1,0 +1,243 @@
+"""Analytic nuclear gradients of density-fitted RHF / UHF on the MI355X path.
+
+Mirror of ``pyscf/grad/rhf.py`` (``grad_elec`` :36-88, ``grad_nuc`` :148-166, ``hcore_generator`` :91-146,
+``make_rdm1e`` :196-205) with the J/K part of ``pyscf/df/grad/rhf.py`` (``get_jk`` :44-260,
+``auxbasis_response``), and ``pyscf/grad/uhf.py`` / ``pyscf/df/grad/uhf.py`` for two spin blocks.
+
+The reference materialises derivative-integral tensors (int3c2e_ip1, int3c2e_ip2, int2c2e_ip1, int1e_ipovlp,
+int1e_ipkin, int1e_ipnuc, int1e_iprinv) and contracts them on the host.  Here the DF energy is differentiated
+as a function of the raw integrals A = (Q|pq) and the metric M = (P|Q),
+
+    E_2e = 1/2 g^T M^-1 g - k/2 sum_s sum_PQ M^-1_PQ Tr[D_s A_P D_s A_Q],     g_Q = sum_pq A_Q,pq D_pq
+    dE   = sum_{Q,pq} Z_Q,pq dA_Q,pq + sum_PQ Y_PQ dM_PQ
+    Z_Q  = sum_L (L^-T)_QL [ rho_L D - k sum_s C_s (C_s^T B_L C_s) C_s^T ]
+    Y    = L^-T [ -1/2 rho rho^T + k/2 sum_s sum_ij y^s_L,ij y^s_L',ij ] L^-1,  y^s_L = C_s^T B_L C_s
+
+(B = cderi, rho = B d, M = L L^T), and one generate-and-contract kernel family (``PAMD_int3c2e_grad_class``)
+dots every shell triple's derivative block with the matching block of Z; the same kernel with the aux shells
+replaced by (P, unit s) pairs gives the metric term and with point charges the nuclear-attraction term.
+The derivative on the third centre comes from translational invariance inside the kernel, so
+``auxbasis_response=False`` (df/grad/rhf.py:133-138) is a kernel flag.
+"""
+import ctypes as _c
+
+import numpy as np
+import scipy.linalg
+
+from .. import lib as _lib_mod
+from ..df import df_jk
+from ..gto.moleintor import _AuxClass, _Shells, _dev, c2s_matrix, get_engine
+
+NREP = 64          # replicated accumulators: spreads the FP64 atomics of the contraction kernel
+
+
+def grad_nuc(mol, atmlst=None):
+    """pyscf/grad/rhf.py:148-166."""
+    z = mol.atom_charges().astype(float)
+    r = mol.atom_coords()
+    natm = len(z)
+    g = np.zeros((natm, 3))
+    for i in range(natm):
+        for j in range(natm):
+            if i != j:
+                d = r[i] - r[j]
+                g[i] -= z[i] * z[j] * d / np.linalg.norm(d) ** 3
+    return g if atmlst is None else g[atmlst]
+
+
+def _dbg(msg):
+    import os
+    if os.environ.get('PAMD_DEBUG_GRAD'):
+        import torch
+        torch.cuda.synchronize()
+        print('[grad]', msg, flush=True)
+
+
+def _ptr(t):
+    return _c.c_void_p(t.data_ptr())
+
+
+def _pack_tril_dev(m):
+    """(..., nao, nao) device -> (..., nao_pair) lower-triangular packed, p(p+1)/2+q."""
+    import torch
+    nao = m.shape[-1]
+    ti, tj = np.tril_indices(nao)
+    idx = torch.from_numpy(ti * nao + tj).to(m.device)
+    return m.reshape(*m.shape[:-2], nao * nao)[..., idx]
+
+
+def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, low):
+    """Z_T[pq][Q] (nao_pair, naux) and Y[P][Q] (naux, naux) of the module docstring, on the device.
+
+    occ_blocks: [(C (nao, nocc) with D_s = C C^T, weight)], e.g. RHF [(C_occ, 2)], UHF [(Ca, 1), (Cb, 1)].
+    low: lower Cholesky factor of the metric (host)."""
+    import torch
+    so = _lib_mod.load_library()
+    cderi = dfobj._cderi_dev
+    naux, npair = cderi.shape
+    dev = cderi.device
+    nao = dm_tot.shape[0]
+    f64 = torch.float64
+    st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d_dev = torch.from_numpy(np.ascontiguousarray(dm_tot)).to(dev)
+    dtril = _pack_tril_dev(d_dev)
+    dsum = dtril * 2
+    diag = torch.from_numpy(np.arange(nao) * (np.arange(nao) + 1) // 2 + np.arange(nao)).to(dev)
+    dsum[diag] *= .5
+    rho = cderi @ dsum                                           # rho_L = sum_pq B_L,pq D_pq (full square)
+    W = rho[:, None] * dtril[None, :]                            # [L][pq]
+    ytil = -0.5 * torch.outer(rho, rho)
+    ldx = (nao + 15) // 16 * 16
+    for c, wgt in occ_blocks:
+        nocc = c.shape[1]
+        if nocc == 0 or kscale == 0:
+            continue
+        orb, nocc_pad, ldo = df_jk.pad_orbitals(np.asarray(c, dtype=np.float64), dev)
+        c_dev = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float64)).to(dev)
+        blk = max(1, min(naux, int((2 << 30) // (nocc_pad * ldx * 8)), int((4 << 30) // (nao * nao * 8))))
+        ys = torch.empty((naux, nocc * nocc), dtype=f64, device=dev)
+        for b0 in range(0, naux, blk):
+            nb = min(blk, naux - b0)
+            X = torch.zeros((nb, nocc_pad, ldx), dtype=f64, device=dev)
+            df_jk._call(dfobj, 'e2_symm', so.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
+                        _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
+                        _c.c_int(ldx), st)
+            y = torch.matmul(X[:, :nocc, :nao], c_dev)           # y_L,ij = (C^T B_L C)_ij
+            ys[b0:b0 + nb] = y.reshape(nb, -1)
+            cyc = torch.matmul(c_dev, torch.matmul(y, c_dev.T))  # C y_L C^T
+            W[b0:b0 + nb] -= kscale * wgt * _pack_tril_dev(cyc)
+        ytil += 0.5 * kscale * wgt * (ys @ ys.T)
+    linv = torch.from_numpy(scipy.linalg.solve_triangular(low, np.eye(naux), lower=True)).to(dev)
+    z_t = torch.empty((npair, naux), dtype=f64, device=dev)      # Z_T[pq][Q] = sum_L W[L][pq] Linv[L][Q]
+    step = max(1, int((2 << 30) // (naux * 8)))
+    for p0 in range(0, npair, step):
+        torch.matmul(W[:, p0:p0 + step].T, linv, out=z_t[p0:p0 + step])
+    y_pq = linv.T @ ytil @ linv
+    return z_t, y_pq
+
+
+def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_response=True, device=None):
+    """Electronic gradient (natm, 3) of a DF-HF-type energy with total density dm_tot, exchange from
+    occ_blocks (see two_particle_densities) scaled by kscale, energy-weighted density dme."""
+    import torch
+    so = _lib_mod.load_library()
+    if dfobj._cderi_dev is None:
+        dfobj.build()
+    if dfobj.world_size > 1:
+        raise NotImplementedError('gradients with an aux-sharded tensor')
+    dev = dfobj._cderi_dev.device
+    eng = get_engine(mol, dfobj.auxmol, dev, dfobj.omega)
+    natm = mol.natm
+    nao = eng.ao.nao
+    naux = eng.aux.nao
+    j2c = eng.int2c2e().cpu().numpy()
+    try:
+        low = scipy.linalg.cholesky((j2c + j2c.T) * .5, lower=True)
+    except scipy.linalg.LinAlgError:
+        raise NotImplementedError('gradients with a linearly dependent (eigen-decomposed) fitting metric')
+    z_t, y_pq = two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, low)
+    _dbg('Z,Y built')
+    grad = torch.zeros((NREP, natm, 3), dtype=torch.float64, device=dev)
+    ao_atom = _dev(eng.ao.atom, dev)
+    aux_atom = _dev(eng.aux.atom, dev)
+    # (1) sum Z dA: 3-centre derivative blocks
+    for pc in eng.pair_classes():
+        for ac in eng.aux_classes():
+            eng.grad_launch(pc, ac, z_t, naux, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, auxbasis_response)
+            _dbg('3c class %d %d | %d' % (pc.li, pc.lj, ac.l))
+    _dbg('3c done')
+    # (2) sum Y dM: 2-centre metric
+    if auxbasis_response:
+        aux_xyz, aux_ao0 = _dev(eng.aux.xyz, dev), _dev(eng.aux.ao0, dev)
+        y_pq = y_pq.contiguous()
+        for pc in eng.pair_classes_2c():
+            for ac in eng.aux_classes():
+                eng.grad_launch(pc, ac, y_pq, naux, 0, aux_xyz, aux_ao0, aux_atom, grad, True)
+    _dbg('2c done')
+    # (3) nuclear attraction: point-charge "aux shells", Z[pq][C] = D_pq (the charge -Z_C sits in the coefficient)
+    nuc = _Shells.__new__(_Shells)
+    eta = 1e30
+    nuc.l = np.zeros(natm, np.int32)
+    nuc.xyz = mol.atom_coords()
+    nuc.exps = [np.array([eta])] * natm
+    zc = mol.atom_charges().astype(float)
+    nuc.coefs = [np.array([-zi * (eta / np.pi) ** 1.5 / c2s_matrix(0)[0, 0]]) for zi in zc]
+    nuc.ao0 = np.arange(natm, dtype=np.int32)
+    nuc.atom = np.arange(natm, dtype=np.int32)
+    nuc.n = nuc.nao = natm
+    ac = _AuxClass(nuc, 0, dev)
+    d_dev = torch.from_numpy(np.ascontiguousarray(dm_tot)).to(dev)
+    z_nuc = _pack_tril_dev(d_dev)[:, None].expand(-1, natm).contiguous()
+    eng._omega_override = 0.0
+    for pc in eng.pair_classes():
+        eng.grad_launch(pc, ac, z_nuc, natm, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, True)
+    del eng._omega_override
+    _dbg('nuc done')
+    g = grad.sum(dim=0)
+    # (4) kinetic and overlap (energy-weighted density)
+    sh = eng.ao
+    prim0 = np.cumsum([0] + [len(e) for e in sh.exps])[:-1].astype(np.int32)
+    nprim = np.array([len(e) for e in sh.exps], np.int32)
+    st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w_dev = torch.from_numpy(np.ascontiguousarray(dme)).to(dev)
+    tabs = [_dev(sh.l, dev), eng.ao_ao0, _dev(prim0, dev), _dev(nprim, dev), eng.ao_xyz,
+            _dev(np.concatenate(sh.exps), dev), _dev(np.concatenate(sh.coefs), dev), ao_atom]      # keep alive
+    _lib_mod.check(so.PAMD_int1e_grad(*[_ptr(t) for t in tabs], _c.c_int(sh.n), _c.c_int(nao), _ptr(eng.c2s),
+                                      _ptr(eng.c2s_off), _ptr(d_dev), _ptr(w_dev), _ptr(g), st))
+    torch.cuda.synchronize()
+    _dbg('1e done')
+    return g.cpu().numpy()
+
+
+class Gradients:
+    """``mf.nuc_grad_method()`` / ``mf.Gradients()`` of a converged DF-RHF or DF-UHF object
+    (pyscf/grad/rhf.py:291-458, pyscf/df/grad/rhf.py:262-320)."""
+
+    def __init__(self, mf):
+        self.base = mf
+        self.mol = mf.mol
+        self.auxbasis_response = True
+        self.de = None
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+        return self
+
+    def grad_nuc(self, mol=None, atmlst=None):
+        return grad_nuc(mol or self.mol, atmlst)
+
+    def _densities(self):
+        mf = self.base
+        mo_c, mo_e, mo_occ = np.asarray(mf.mo_coeff), np.asarray(mf.mo_energy), np.asarray(mf.mo_occ)
+        if mo_c.ndim == 2:
+            if np.any((mo_occ > 0) & (mo_occ < 2)):
+                raise NotImplementedError('ROHF gradients')
+            occ = mo_occ > 0
+            c = mo_c[:, occ]
+            dm = 2 * c.dot(c.T)
+            dme = 2 * (c * mo_e[occ]).dot(c.T)                   # make_rdm1e, grad/rhf.py:196-205
+            return dm, [(c, 2.0)], dme
+        blocks, dm, dme = [], 0, 0
+        for s in range(2):
+            occ = mo_occ[s] > 0
+            c = mo_c[s][:, occ]
+            blocks.append((c, 1.0))
+            dm = dm + c.dot(c.T)
+            dme = dme + (c * mo_e[s][occ]).dot(c.T)
+        return dm, blocks, dme
+
+    def grad_elec(self):
+        mf = self.base
+        if getattr(mf, 'with_df', None) is None:
+            raise NotImplementedError('gradients are implemented for density-fitted SCF objects')
+        if hasattr(mf, 'xc'):
+            raise NotImplementedError('XC gradients (nr_rks_grad) are not built yet')
+        dm, blocks, dme = self._densities()
+        return grad_elec_df(self.mol, mf.with_df, dm, blocks, dme, 1.0, self.auxbasis_response)
+
+    def kernel(self):
+        self.de = self.grad_elec() + self.grad_nuc()
+        return self.de
+
+    grad = kernel

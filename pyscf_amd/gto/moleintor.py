@@ -109,6 +109,13 @@ class _Args(ctypes.Structure):
                 ('tril', ctypes.c_int), ('npairs', ctypes.c_int), ('omega', ctypes.c_double)]
 
 
+class _GradArgs(ctypes.Structure):
+    """Mirror of PAMD_int3c2e_grad_args (include/pyscf_amd.h)."""
+    _fields_ = [('base', _Args), ('pp_ab', ctypes.c_void_p), ('shell_atom', ctypes.c_void_p),
+                ('aux_atom', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('nrep', ctypes.c_int),
+                ('natm', ctypes.c_int), ('aux_response', ctypes.c_int)]
+
+
 class _AuxClass:
     def __init__(self, shells, l, device, sel=None):
         idx = [i for i in range(shells.n) if shells.l[i] == l and (sel is None or sel[i])]
@@ -125,6 +132,7 @@ class _AuxClass:
             co[j, :k] = shells.coefs[i]
         self.npk = npk
         self.f0 = _dev(shells.ao0[idx], device)
+        self.atom = _dev(np.asarray(shells.atom)[idx].astype(np.int32), device) if hasattr(shells, 'atom') else None
         self.xyz = _dev(shells.xyz[idx], device)
         self.exp = _dev(ex, device)
         self.coef = _dev(co, device)
@@ -142,7 +150,7 @@ class _PairClass:
         if len(ia_all) == 0 or len(ib_all) == 0:
             return
         nprim = np.array([len(e) for e in sa.exps])
-        ish_l, jsh_l, npp_l, recs = [], [], [], []
+        ish_l, jsh_l, npp_l, recs, abs_l = [], [], [], [], []
         # vectorised over groups of shells with equal primitive counts (rectangular arrays)
         for na in np.unique(nprim[ia_all]):
             A = ia_all[nprim[ia_all] == na]
@@ -174,6 +182,7 @@ class _PairClass:
                 rec[:, 4] = np.exp(-arg[ka, kb, kp, kq]) * CA[ka, kp] * CB[kb, kq]
                 rec[:, 5:8] = P - XA[ka]
                 recs.append(rec)
+                abs_l.append(np.stack([EA[ka, kp], EB[kb, kq]], axis=1))
                 ish_l.append(A[pa])
                 jsh_l.append(B[pb])
                 npp_l.append(cnt[pa, pb])
@@ -192,6 +201,15 @@ class _PairClass:
         self.pp0 = _dev(pp0[order], device)
         self.npp = _dev(npp[order], device)
         self.pp = _dev(np.vstack(recs), device)
+        self._pp_ab_host = np.vstack(abs_l)       # primitive exponents (alpha_i, alpha_j) per record: gradients only
+        self._pp_ab = None
+        self.device = device
+
+    @property
+    def pp_ab(self):
+        if self._pp_ab is None:
+            self._pp_ab = _dev(self._pp_ab_host, self.device)
+        return self._pp_ab
 
     def subrange(self, sh0, sh1):
         """[i0, i1) of pairs whose row shell lies in [sh0, sh1)."""
@@ -251,6 +269,28 @@ class IntEngine:
         if i1 <= i0:
             return
         a = _Args()
+        self._fill_args(a, pc, i0, i1, ac, T, ldT, row_offset, tril, shell_xyz, shell_ao0)
+        st = ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+        _lib_mod.check(self.lib.PAMD_int3c2e_class(ctypes.c_int(pc.li), ctypes.c_int(pc.lj),
+                                                   ctypes.c_int(ac.l), ctypes.byref(a), st))
+
+    def grad_launch(self, pc, ac, Z, ldZ, tril, shell_xyz, shell_ao0, shell_atom, grad, aux_response):
+        """grad[rep][atom][3] += sum Z[row(pq)][Q] d(pq|Q)/dR for one (pair class, aux class): PAMD_int3c2e_grad_class."""
+        if pc.n == 0 or ac.n == 0:
+            return
+        g = _GradArgs()
+        self._fill_args(g.base, pc, 0, pc.n, ac, Z, ldZ, 0, tril, shell_xyz, shell_ao0)
+        g.pp_ab = pc.pp_ab.data_ptr()
+        g.shell_atom = shell_atom.data_ptr()
+        g.aux_atom = ac.atom.data_ptr()
+        g.grad = grad.data_ptr()
+        g.nrep, g.natm = grad.shape[0], grad.shape[1]
+        g.aux_response = int(bool(aux_response))
+        st = ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+        _lib_mod.check(self.lib.PAMD_int3c2e_grad_class(ctypes.c_int(pc.li), ctypes.c_int(pc.lj),
+                                                        ctypes.c_int(ac.l), ctypes.byref(g), st))
+
+    def _fill_args(self, a, pc, i0, i1, ac, T, ldT, row_offset, tril, shell_xyz, shell_ao0):
         a.pair_ish = pc.ish.data_ptr() + 4 * i0
         a.pair_jsh = pc.jsh.data_ptr() + 4 * i0
         a.pair_pp0 = pc.pp0.data_ptr() + 4 * i0
@@ -273,9 +313,6 @@ class IntEngine:
         a.tril = tril
         a.npairs = i1 - i0
         a.omega = getattr(self, '_omega_override', self.omega)
-        st = ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
-        _lib_mod.check(self.lib.PAMD_int3c2e_class(ctypes.c_int(pc.li), ctypes.c_int(pc.lj),
-                                                   ctypes.c_int(ac.l), ctypes.byref(a), st))
 
     # -- integrals ------------------------------------------------------------------------
     def slab_rows(self, sh0, sh1):
@@ -297,6 +334,17 @@ class IntEngine:
             i0, i1 = pc.subrange(sh0, sh1)
             for ac in self.aux_classes():
                 self._launch(pc, i0, i1, ac, out, naux, r0, 1, self.ao_xyz, self.ao_ao0)
+        return out
+
+    def pair_classes_2c(self):
+        """[(P, unit s)] pair classes over the aux shells: the 2-centre (P|Q) family."""
+        dummy = _Shells.__new__(_Shells)
+        dummy.coefs = [np.ones(1) / c2s_matrix(0)[0, 0]]
+        out = []
+        for li in range(int(self.aux.l.max()) + 1):
+            pc = _PairClass2c(self.aux, li, dummy, self.device)
+            if pc.n:
+                out.append(pc)
         return out
 
     def int2c2e(self):
@@ -331,7 +379,7 @@ class _PairClass2c(_PairClass):
         self.n = len(ia)
         if self.n == 0:
             return
-        recs, pp0, npp = [], [], []
+        recs, pp0, npp, abs_l = [], [], [], []
         nrec = 0
         for a in ia:
             e, c = shells.exps[a], shells.coefs[a] * dummy.coefs[0][0]
@@ -340,6 +388,7 @@ class _PairClass2c(_PairClass):
             rec[:, 1:4] = shells.xyz[a]
             rec[:, 4] = c
             recs.append(rec)
+            abs_l.append(np.stack([e, np.zeros(len(e))], axis=1))
             pp0.append(nrec)
             npp.append(len(e))
             nrec += len(e)
@@ -349,6 +398,9 @@ class _PairClass2c(_PairClass):
         self.pp0 = _dev(np.array(pp0, np.int32), device)
         self.npp = _dev(np.array(npp, np.int32), device)
         self.pp = _dev(np.vstack(recs), device)
+        self._pp_ab_host = np.vstack(abs_l)
+        self._pp_ab = None
+        self.device = device
 
 
 _ENGINE_CACHE = {}

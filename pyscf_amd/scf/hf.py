@@ -290,6 +290,19 @@ class SCF:
 
     scf = kernel
 
+    def run(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+        self.kernel()
+        return self
+
+    def nuc_grad_method(self):
+        """pyscf/scf/hf.py:2236 / pyscf/df/grad/rhf.py: analytic DF gradients on the device."""
+        from ..grad import Gradients
+        return Gradients(self)
+
+    Gradients = nuc_grad_method
+
 
 class RHF(SCF):
     pass

@@ -93,3 +93,15 @@ def test_long_range_df_jk_golden():
     assert abs(ref.fp(vk) - -37.78854217974532) < 5e-4
     vj1, vk1 = ref.get_jk_exact(ref.int2e(mol, omega=1.1), dm)
     assert np.abs(vj - vj1).max() < 1e-2 and np.abs(vk - vk1).max() < 1e-2
+
+
+def test_fd_gradient_oracle_pinned_by_reference_goldens():
+    """pyscf/df/test/test_df_grad.py:61-65: the finite-difference gradient of the oracle's DF-RHF energy reproduces
+    the reference's analytic-gradient fingerprint (its own tolerance is 7 places on an SCF converged to 1e-9).
+    (The UHF golden :106-110 is checked on the GPU side, where the SCF state can be handed to the oracle.)"""
+    from oracle import ref_grad
+    B = 0.52917721092
+    atoms = [('O', (0., 0., 0.)), ('H', (0., -0.757 / B, 0.587 / B)), ('H', (0., 0.757 / B, 0.587 / B))]
+    g = ref_grad.fd_gradient(atoms, '6-31g', 'ccpvdz-jkfit')
+    assert abs(ref.fp(g) - 0.005516638190173352) < 3e-7
+    assert abs(g.sum(axis=0)).max() < 1e-7
