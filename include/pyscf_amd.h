@@ -147,7 +147,7 @@ int PAMD_set_tuning(const char *key, int value);      /* benchmarking switches, 
 /* pbecke[natm][ngrids]: unnormalised Becke cell functions; radii table a[i][j] nullable */
 int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
                          const double *d_radii_table, int natm, long ngrids, void *stream);
-/* ao[comp][ldg_rows][ldao] (AO index fastest, columns nao..ldao-1 zero), comp = 1 (deriv 0) or 4 (deriv 1),
+/* ao[comp][ldg_rows][ldao] (AO index fastest, columns nao..ldao-1 zero), comp = 1 (deriv 0), 4 (deriv 1) or 10 (deriv 2: 1, x, y, z, xx, xy, xz, yy, yz, zz),
  * grid points [g0, g0+ng) of d_coords; d_fn2sh[mu] = segmented shell of AO mu.
  * d_flags (nullable; caller zeroes it): [ceil(ldg_rows/16)][ldao/16] bytes <- 1 where the 16 x 16 (grid x AO) tile
  * has a value of any component above thr: the screening table of GTO_screen_index (lib/gto/grid_ao_drv.c:32-123) */
@@ -169,6 +169,10 @@ int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double 
 int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
                      const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,
                      void *stream);
+/* XC nuclear gradient of one grid block (pyscf/grad/rks.py:197-255 get_vxc/_gga_grad_sum_/_make_dR_dao_w contracted with
+ * the density on the fly): d_out[3][nao] += sum_g {...}, d_c[k][g][mu] = sum_nu ao_k[g][nu] D[nu][mu] */
+int PAMD_xc_grad(const double *d_ao, const double *d_c, const double *d_wv, int ldao, long ldg_rows, long ldg,
+                 int gga, long ng, int nao, double *d_out, void *stream);
 int PAMD_scale_ao(const double *d_ao, const double *d_wv, int ldao, long ldg_rows, long ldg, int ncomp,
                   long ng, long nrows, double *d_aow, void *stream);     /* aow[g][ldao], rows ng..nrows-1 zero */
 int PAMD_dgemm_nt(const double *d_A, long lda, const double *d_B, long ldb, double *d_C, int ldc, int m,

@@ -263,6 +263,63 @@ def rks_energy(mol, xc_fac, hyb, gga, coords, weights, get_jk, conv_tol=1e-10, v
     return ref.rhf_kernel(mol, veff, conv_tol=conv_tol, verbose=verbose, e2_fn=lambda: state['e2'])
 
 
+def eval_ao_hess(mol, coords, h=1e-4):
+    """(3, 3, ngrids, nao) second derivatives of the AOs: central differences (step h, Richardson with 2h) of
+    the analytic first derivatives of eval_ao - accurate to ~1e-10 relative, enough for a 1e-8 gradient check
+    without a second hand-written derivative formula in the oracle."""
+    ng = len(coords)
+    nao = mol.nao_nr()
+    out = np.zeros((3, 3, ng, nao))
+    for d in range(3):
+        def g1(step):
+            cp, cm = coords.copy(), coords.copy()
+            cp[:, d] += step
+            cm[:, d] -= step
+            return (eval_ao(mol, cp, 1)[1:] - eval_ao(mol, cm, 1)[1:]) / (2 * step)
+        out[d] = (4 * g1(h) - g1(2 * h)) / 3
+    return out
+
+
+def nr_rks_grad(mol, coords, weights, fac, gga, dm):
+    """XC nuclear gradient (natm, 3) without grid response: numpy restatement of pyscf/grad/rks.py get_vxc
+    (:119-195) + the contraction de[A] = 2 sum_{mu on A, nu} vmat[x]_{mu nu} D_{mu nu} of grad/rhf.py:80-84,
+    with vmat[x] = -(nabla_x ao)^T (wv0 ao) for LDA and _gga_grad_sum_ / _make_dR_dao_w (:197-255) for GGA."""
+    dm = (dm + dm.T) * .5
+    ao = eval_ao(mol, coords, 1)
+    c0 = ao[0].dot(dm)
+    rho = np.einsum('gi,gi->g', ao[0], c0)
+    if gga:
+        grad = 2 * np.einsum('xgi,gi->xg', ao[1:], c0)
+        sigma = np.einsum('xg,xg->g', grad, grad)
+    else:
+        grad = np.zeros((3, len(rho)))
+        sigma = np.zeros_like(rho)
+    e, vr, vs = eval_xc(fac, rho, sigma)
+    nao = mol.nao_nr()
+    vmat = np.zeros((3, nao, nao))
+    if not gga:
+        aow = ao[0] * (weights * vr)[:, None]
+        for x in range(3):
+            vmat[x] = ao[1 + x].T.dot(aow)
+    else:
+        hess = eval_ao_hess(mol, coords)
+        wv = np.empty((4, len(rho)))
+        wv[0] = weights * vr * .5
+        wv[1:] = 2 * weights * vs * grad
+        aow = np.einsum('cgi,cg->gi', ao, wv)
+        for x in range(3):
+            vmat[x] = ao[1 + x].T.dot(aow)
+            aow2 = ao[1 + x] * wv[0][:, None] + np.einsum('kgi,kg->gi', hess[x], wv[1:])
+            vmat[x] += aow2.T.dot(ao[0])
+    vmat = -vmat
+    aoslices = mol.aoslice_by_atom()
+    de = np.zeros((mol.natm, 3))
+    for ia in range(mol.natm):
+        p0, p1 = aoslices[ia][2], aoslices[ia][3]
+        de[ia] = 2 * np.einsum('xij,ij->x', vmat[:, p0:p1], dm[p0:p1])
+    return de
+
+
 # ============================================================================ spin-polarised (UKS)
 _FUNCS_POL = None
 

@@ -74,6 +74,44 @@ __device__ __forceinline__ void ao_angular(double x, double y, double z, double 
         }
 }
 
+// value, gradient and Hessian (order: 1, x, y, z, xx, xy, xz, yy, yz, zz = numint.eval_ao deriv=2,
+// pyscf/dft/numint.py:51-114) of R(r^2) * sum_c m[c] x^a y^b z^c with dR/dx = x R1, d2R/dxdy = x y R2 (+ R1 on the diagonal)
+template <int L>
+__device__ __forceinline__ void ao_angular2(double x, double y, double z, double r0, double r1, double r2,
+                                            const double *__restrict__ m, double *__restrict__ o)
+{
+    double px[L + 1], py[L + 1], pz[L + 1];
+    px[0] = py[0] = pz[0] = 1;
+#pragma unroll
+    for (int i = 1; i <= L; i++) { px[i] = px[i - 1] * x; py[i] = py[i - 1] * y; pz[i] = pz[i - 1] * z; }
+#pragma unroll
+    for (int k = 0; k < 10; k++) o[k] = 0;
+    int c = 0;
+#pragma unroll
+    for (int a = L; a >= 0; a--)
+#pragma unroll
+        for (int b = L - a; b >= 0; b--, c++) {
+            const int cc = L - a - b;
+            const double f = m[c];
+            const double X0 = px[a], Y0 = py[b], Z0 = pz[cc];
+            const double X1 = a ? a * px[a ? a - 1 : 0] : 0.0, Y1 = b ? b * py[b ? b - 1 : 0] : 0.0, Z1 = cc ? cc * pz[cc ? cc - 1 : 0] : 0.0;
+            const double X2 = a > 1 ? a * (a - 1) * px[a > 1 ? a - 2 : 0] : 0.0;
+            const double Y2 = b > 1 ? b * (b - 1) * py[b > 1 ? b - 2 : 0] : 0.0;
+            const double Z2 = cc > 1 ? cc * (cc - 1) * pz[cc > 1 ? cc - 2 : 0] : 0.0;
+            const double P = X0 * Y0 * Z0, Px = X1 * Y0 * Z0, Py = X0 * Y1 * Z0, Pz = X0 * Y0 * Z1;
+            o[0] += f * P * r0;
+            o[1] += f * (Px * r0 + P * x * r1);
+            o[2] += f * (Py * r0 + P * y * r1);
+            o[3] += f * (Pz * r0 + P * z * r1);
+            o[4] += f * (X2 * Y0 * Z0 * r0 + 2 * Px * x * r1 + P * (r1 + x * x * r2));
+            o[5] += f * (X1 * Y1 * Z0 * r0 + (Px * y + Py * x) * r1 + P * x * y * r2);
+            o[6] += f * (X1 * Y0 * Z1 * r0 + (Px * z + Pz * x) * r1 + P * x * z * r2);
+            o[7] += f * (X0 * Y2 * Z0 * r0 + 2 * Py * y * r1 + P * (r1 + y * y * r2));
+            o[8] += f * (X0 * Y1 * Z1 * r0 + (Py * z + Pz * y) * r1 + P * y * z * r2);
+            o[9] += f * (X0 * Y0 * Z2 * r0 + 2 * Pz * z * r1 + P * (r1 + z * z * r2));
+        }
+}
+
 // Grid-major output ao[comp][g][ldao] (AO index fastest): one wave per grid point.  Phase 1: lanes
 // over shells evaluate the contracted radial sums (one exp per primitive, not per function) into
 // LDS; phase 2: lanes over AO functions combine them with the angular polynomials, so stores are
@@ -87,7 +125,7 @@ __global__ __launch_bounds__(256) void eval_ao_kernel(AOShells sh, int nsh, cons
                                                       double *__restrict__ ao, long ldg_rows, int ldao, int nao,
                                                       double thr, unsigned char *__restrict__ flags)
 {
-    __shared__ double s_rad[4][AO_SC][2];
+    __shared__ double s_rad[4][AO_SC][3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long gl = (long)blockIdx.x * 4 + wave;
     const bool valid = gl < ng;
@@ -100,20 +138,48 @@ __global__ __launch_bounds__(256) void eval_ao_kernel(AOShells sh, int nsh, cons
         for (int s = s0 + lane; s < s1; s += 64) {
             const double x = gx - sh.xyz[s * 3], y = gy - sh.xyz[s * 3 + 1], z = gz - sh.xyz[s * 3 + 2];
             const double r2 = x * x + y * y + z * z;
-            double rad = 0, rad1 = 0;
+            double rad = 0, rad1 = 0, rad2 = 0;
             for (int p = 0; p < sh.nprim[s]; p++) {
                 const double a = sh.exps[sh.prim0[s] + p];
                 const double e = sh.coefs[sh.prim0[s] + p] * exp(-a * r2);
                 rad += e;
                 rad1 += -2 * a * e;
+                if (DERIV == 2) rad2 += 4 * a * a * e;
             }
             s_rad[wave][s - s0][0] = rad;
             s_rad[wave][s - s0][1] = rad1;
+            s_rad[wave][s - s0][2] = rad2;
         }
         __syncthreads();
         const int mu0 = sh.ao0[s0];
         const int mu1 = (s1 < nsh) ? sh.ao0[s1] : ldao;     // last chunk also zero-fills the padding
         for (int mu = mu0 + lane; mu < mu1; mu += 64) {
+            if (DERIV == 2) {
+                double o[10];
+#pragma unroll
+                for (int k = 0; k < 10; k++) o[k] = 0;
+                if (mu < nao) {
+                    const int s = fn2sh[mu];
+                    const int l = sh.l[s];
+                    const int k = mu - sh.ao0[s];
+                    const double x = gx - sh.xyz[s * 3], y = gy - sh.xyz[s * 3 + 1], z = gz - sh.xyz[s * 3 + 2];
+                    const double r0 = s_rad[wave][s - s0][0], r1 = s_rad[wave][s - s0][1], r2 = s_rad[wave][s - s0][2];
+                    const double *m = c2s + c2s_off[l] + k * ((l + 1) * (l + 2) / 2);
+                    switch (l) {
+                    case 0: ao_angular2<0>(x, y, z, r0, r1, r2, m, o); break;
+                    case 1: ao_angular2<1>(x, y, z, r0, r1, r2, m, o); break;
+                    case 2: ao_angular2<2>(x, y, z, r0, r1, r2, m, o); break;
+                    case 3: ao_angular2<3>(x, y, z, r0, r1, r2, m, o); break;
+                    default: ao_angular2<4>(x, y, z, r0, r1, r2, m, o); break;
+                    }
+                }
+                if (valid) {
+                    double *p = ao + gl * ldao + mu;
+#pragma unroll
+                    for (int k = 0; k < 10; k++) p[k * comp_stride] = o[k];
+                }
+                continue;
+            }
             double v = 0, vx = 0, vy = 0, vz = 0;
             if (mu < nao) {
                 const int s = fn2sh[mu];
@@ -178,12 +244,15 @@ int PAMD_eval_ao(int deriv, const int *d_l, const int *d_ao0, const int *d_prim0
                  double *d_ao, long ldg_rows, int ldao, double thr, unsigned char *d_flags, void *stream)
 {
     PAMD_REQUIRE(d_flags == nullptr || ldao % 16 == 0, "eval_ao: tile flags need ldao % 16 == 0");
-    PAMD_REQUIRE(deriv == 0 || deriv == 1, "eval_ao: deriv must be 0 or 1");
+    PAMD_REQUIRE(deriv >= 0 && deriv <= 2, "eval_ao: deriv must be 0, 1 or 2");
+    PAMD_REQUIRE(deriv < 2 || d_flags == nullptr, "eval_ao: tile flags are not produced for deriv = 2");
     PAMD_REQUIRE(ldao >= nao, "eval_ao: ldao < nao");
     if (ng == 0 || nao == 0) return 0;
     AOShells sh{d_l, d_ao0, d_prim0, d_nprim, d_xyz, d_exps, d_coefs};
     dim3 grid(ceil_div(ng, 4));
-    if (deriv)
+    if (deriv == 2)
+        eval_ao_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_fn2sh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg_rows, ldao, nao, thr, d_flags);
+    else if (deriv)
         eval_ao_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_fn2sh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg_rows, ldao, nao, thr, d_flags);
     else
         eval_ao_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(sh, nsh, d_fn2sh, d_coords, g0, ng, d_c2s, d_c2s_off, d_ao, ldg_rows, ldao, nao, thr, d_flags);

@@ -426,6 +426,46 @@ __global__ __launch_bounds__(256) void scale_ao_kernel(const double *__restrict_
     aow[g * ldao + m] = v;
 }
 
+
+// XC nuclear-gradient reduction (grid response left out, as pyscf/grad/rks.py:get_vxc with grid_response=False):
+//   out[x][mu] += sum_g { d_x ao_mu (wv0 c0_mu + sum_k wv_k ck_mu) + (sum_k wv_k d_x d_k ao_mu) c0_mu }
+// with c_k[g][mu] = sum_nu ao_k[g][nu] D[nu][mu]; the caller turns it into -2 sum_{mu on A} out[x][mu]
+// (_d1_dot_ + _gga_grad_sum_ + _make_dR_dao_w of pyscf/grad/rks.py:197-255, contracted with D on the fly).
+// wv follows PAMD_eval_xc's convention (wv[0] = w vrho / 2), ao holds 4 (LDA) or 10 (GGA) components.
+__global__ __launch_bounds__(256) void xc_grad_kernel(const double *__restrict__ ao, const double *__restrict__ c,
+                                                      const double *__restrict__ wv, int ldao, long ldg_rows,
+                                                      long ldg, int gga, long ng, int nao, long rows_per_block,
+                                                      double *__restrict__ out)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= nao) return;
+    const long g0 = (long)blockIdx.y * rows_per_block;
+    const long g1 = (g0 + rows_per_block < ng) ? g0 + rows_per_block : ng;
+    const long cs = ldg_rows * ldao;
+    double sx = 0, sy = 0, sz = 0;
+    // Hessian component (x,k): xx xy xz / xy yy yz / xz yz zz = components 4 5 6 / 5 7 8 / 6 8 9
+    for (long g = g0; g < g1; g++) {
+        const long o = g * ldao + m;
+        const double w0 = 2 * wv[g];
+        const double c0 = c[o];
+        const double ax = ao[cs + o], ay = ao[2 * cs + o], az = ao[3 * cs + o];
+        double t = w0 * c0;
+        if (gga) {
+            const double w1 = wv[ldg + g], w2 = wv[2 * ldg + g], w3 = wv[3 * ldg + g];
+            t += w1 * c[cs + o] + w2 * c[2 * cs + o] + w3 * c[3 * cs + o];
+            const double hxx = ao[4 * cs + o], hxy = ao[5 * cs + o], hxz = ao[6 * cs + o];
+            const double hyy = ao[7 * cs + o], hyz = ao[8 * cs + o], hzz = ao[9 * cs + o];
+            sx += (w1 * hxx + w2 * hxy + w3 * hxz) * c0;
+            sy += (w1 * hxy + w2 * hyy + w3 * hyz) * c0;
+            sz += (w1 * hxz + w2 * hyz + w3 * hzz) * c0;
+        }
+        sx += ax * t; sy += ay * t; sz += az * t;
+    }
+    atomicAdd(out + m, sx);
+    atomicAdd(out + nao + m, sy);
+    atomicAdd(out + 2 * nao + m, sz);
+}
+
 // C[m][n] += sum_k A[m][k] B[n][k]   (both operands k-contiguous), split-K over gridDim.y
 constexpr int KB = 16, NT = 128, LDT = KB + 1;
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const double *__restrict__ A, long lda,
@@ -571,6 +611,19 @@ int PAMD_scale_ao(const double *d_ao, const double *d_wv, int ldao, long ldg_row
     if (nrows == 0) return 0;
     dim3 grid(ceil_div(ldao, 256), nrows);
     scale_ao_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_ao, d_wv, ldao, ldg_rows, ldg, ncomp, ng, d_aow);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// d_out[3][nao] += per-AO XC gradient sums of one grid block; d_c[ncomp_c][ldg_rows][ldao] (1 or 4 components,
+// same strides as d_ao), d_ao[4 or 10][ldg_rows][ldao]
+int PAMD_xc_grad(const double *d_ao, const double *d_c, const double *d_wv, int ldao, long ldg_rows, long ldg,
+                 int gga, long ng, int nao, double *d_out, void *stream)
+{
+    if (ng == 0 || nao == 0) return 0;
+    const long rows = 512;
+    dim3 grid(ceil_div(nao, 256), ceil_div(ng, rows));
+    xc_grad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_ao, d_c, d_wv, ldao, ldg_rows, ldg, gga, ng, nao, rows, d_out);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

@@ -189,7 +189,7 @@ class NumInt:
                    _c.c_double(self.screen_cutoff or 0.0), _ptr(flags) if flags is not None else _c.c_void_p(0), st)
 
     def eval_ao(self, mol, coords, deriv=0):
-        """Host convenience (tests): (ngrids, nao) or (4, ngrids, nao) like numint.eval_ao
+        """Host convenience (tests): (ngrids, nao), (4, ngrids, nao) or (10, ngrids, nao) like numint.eval_ao
         (pyscf/dft/numint.py:51-114)."""
         import torch
         dev = self._dev()
@@ -197,7 +197,7 @@ class NumInt:
         ng = len(coords)
         nao = self._shell_tables(mol, dev)['nao']
         ldao = _round_up(nao, 16)
-        ncomp = 4 if deriv else 1
+        ncomp = (1, 4, 10)[deriv]
         out = torch.zeros((ncomp, ng, ldao), dtype=torch.float64, device=dev)
         self.eval_ao_block(mol, c, 0, ng, deriv, out, ng, ldao)
         out = out[:, :, :nao].cpu().numpy()
@@ -314,6 +314,68 @@ class NumInt:
         if dms_arr.ndim == 2:
             return nelec[0], excsum[0], vmat[0]
         return nelec, excsum, vmat.reshape(shape)
+
+    def nr_rks_grad(self, mol, grids, xc_code, dm):
+        """XC part of the closed-shell nuclear gradient, (natm, 3), grid response left out: the contraction
+        -2 sum_{mu on A, nu} vmat[x]_{mu nu} D_{mu nu} of pyscf/grad/rks.py:get_vxc (:197-255; _d1_dot_,
+        _gga_grad_sum_, _make_dR_dao_w) done per grid block on the device without forming vmat[x]."""
+        import torch
+        lib = _lib_mod.load_library()
+        dev = self._dev()
+        if grids.coords is None:
+            grids.build()
+        hyb, fac = _xc.parse_xc(xc_code)
+        xctype = _xc.xc_type(xc_code)
+        natm = mol.natm
+        if xctype == 'HF':
+            return np.zeros((natm, 3))
+        gga = 1 if xctype == 'GGA' else 0
+        nao = mol.nao_nr()
+        ldao = _round_up(nao, 16)
+        ncomp_ao, ncomp_c = (10, 4) if gga else (4, 1)
+        coords_dev, weights_dev = self._grid_tables(grids, dev)
+        ngrids = grids.size
+        rank, world = self._world()
+        blk = grid_block_size(ngrids, int(self.block_bytes // ((ncomp_ao + ncomp_c) * ldao * 8)), world)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        f64 = torch.float64
+        ao = torch.zeros((ncomp_ao, blk, ldao), dtype=f64, device=dev)
+        c = torch.zeros((ncomp_c, blk, ldao), dtype=f64, device=dev)
+        rho = torch.zeros((4, blk), dtype=f64, device=dev)
+        wv = torch.empty((4, blk), dtype=f64, device=dev)
+        acc = torch.zeros(2, dtype=f64, device=dev)
+        out = torch.zeros((3, nao), dtype=f64, device=dev)
+        d_h = np.zeros((nao, ldao))
+        d_h[:, :nao] = (np.asarray(dm) + np.asarray(dm).T) * .5
+        dsym = torch.from_numpy(d_h).to(dev)
+        fac_c = (ctypes.c_double * 7)(*fac)
+        for ib, g0 in enumerate(range(0, ngrids, blk)):
+            if ib % world != rank:
+                continue
+            ng = min(blk, ngrids - g0)
+            self.eval_ao_block(mol, coords_dev, g0, ng, 2 if gga else 1, ao, blk, ldao)
+            c.zero_()
+            for k in range(ncomp_c):        # c_k[g][mu] = sum_nu ao_k[g][nu] D[mu][nu]
+                self._call('ao_dot_dm', lib.PAMD_dgemm_nt, _ptr(ao[k]), _c.c_long(ldao), _ptr(dsym), _c.c_long(ldao),
+                           _ptr(c[k]), _c.c_int(ldao), _c.c_int(ng), _c.c_int(nao), _c.c_long(nao), _c.c_int(1), st)
+            rho[0, :ng] = (ao[0, :ng] * c[0, :ng]).sum(dim=1)
+            if gga:
+                for k in range(1, 4):
+                    rho[k, :ng] = 2 * (ao[k, :ng] * c[0, :ng]).sum(dim=1)
+            self._call('eval_xc', lib.PAMD_eval_xc, fac_c, _c.c_int(gga), _ptr(rho), _ptr(weights_dev[g0:g0 + ng]),
+                       _c.c_long(ng), _c.c_long(blk), _ptr(wv), _c.c_void_p(0), _ptr(acc), st)
+            self._call('xc_grad', lib.PAMD_xc_grad, _ptr(ao), _ptr(c), _ptr(wv), _c.c_int(ldao), _c.c_long(blk),
+                       _c.c_long(blk), _c.c_int(gga), _c.c_long(ng), _c.c_int(nao), _ptr(out), st)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(out, group=self.group)
+        s = out.cpu().numpy()
+        aoslices = mol.aoslice_by_atom()
+        de = np.zeros((natm, 3))
+        for ia in range(natm):
+            p0, p1 = aoslices[ia][2], aoslices[ia][3]
+            de[ia] = -2 * s[:, p0:p1].sum(axis=1)
+        return de
 
     def nr_uks(self, mol, grids, xc_code, dms, relativity=0, hermi=1, max_memory=2000, verbose=None):
         """-> (nelec[2], excsum, vmat[2]) with the contract of numint.nr_uks (numint.py:1192-1324);

@@ -231,8 +231,6 @@ class Gradients:
         mf = self.base
         if getattr(mf, 'with_df', None) is None:
             raise NotImplementedError('gradients are implemented for density-fitted SCF objects')
-        if hasattr(mf, 'xc'):
-            raise NotImplementedError('XC gradients (nr_rks_grad) are not built yet')
         dm, blocks, dme = self._densities()
         return grad_elec_df(self.mol, mf.with_df, dm, blocks, dme, 1.0, self.auxbasis_response)
 

@@ -304,6 +304,22 @@ class Mole:
     def nao_nr(self):
         return int(self.ao_loc_nr()[-1])
 
+    def aoslice_by_atom(self, ao_loc=None):
+        """(natm, 4): shell start, shell end, AO start, AO end of every atom (pyscf/gto/mole.py:1600-1630);
+        atoms own contiguous bas rows (make_env order)."""
+        if ao_loc is None:
+            ao_loc = self.ao_loc_nr()
+        atom_of = self._bas[:, ATOM_OF]
+        out = np.zeros((self.natm, 4), dtype=np.int64)
+        for ia in range(self.natm):
+            idx = np.nonzero(atom_of == ia)[0]
+            if len(idx):
+                out[ia] = idx[0], idx[-1] + 1, ao_loc[idx[0]], ao_loc[idx[-1] + 1]
+            else:
+                prev = out[ia - 1] if ia else out[ia]
+                out[ia] = prev[1], prev[1], prev[3], prev[3]
+        return out
+
     @property
     def nao(self):
         return self.nao_nr()

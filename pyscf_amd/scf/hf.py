@@ -298,8 +298,10 @@ class SCF:
 
     def nuc_grad_method(self):
         """pyscf/scf/hf.py:2236 / pyscf/df/grad/rhf.py: analytic DF gradients on the device."""
-        from ..grad import Gradients
-        return Gradients(self)
+        from .. import grad
+        if hasattr(self, 'xc'):
+            return grad.rks.Gradients(self)
+        return grad.Gradients(self)
 
     Gradients = nuc_grad_method
 

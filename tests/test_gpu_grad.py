@@ -58,3 +58,87 @@ def test_df_rhf_gradient_higher_l_vs_fd(basis, aux):
     gfd = ref_grad.fd_gradient(_bohr(atoms), basis, aux, components=comps)
     for a, x in comps:
         assert abs(g[a, x] - gfd[a, x]) < 5e-7, (a, x, g[a, x], gfd[a, x])
+
+
+LOWSYM = [('O', (0.03, -0.02, 0.01)), ('H', (0.1, -0.757, 0.587)), ('H', (-0.2, 0.8, 0.5))]
+
+
+def test_eval_ao_deriv2_vs_oracle():
+    """AO Hessians of PAMD_eval_ao(deriv=2) (numint.eval_ao deriv=2 order: xx xy xz yy yz zz) up to f shells."""
+    from pyscf_amd import gto, dft
+    from oracle import ref_dft
+    mol = gto.M(atom=LOWSYM, basis='cc-pvtz')
+    rng = np.random.default_rng(3)
+    coords = rng.uniform(-3, 3, (200, 3))
+    ao = dft.NumInt().eval_ao(mol, coords, deriv=2)            # (10, ng, nao)
+    want1 = ref_dft.eval_ao(mol, coords, deriv=1)
+    hess = ref_dft.eval_ao_hess(mol, coords)
+    scale = max(1.0, np.abs(hess).max())
+    assert np.abs(ao[:4] - want1).max() < 1e-12 * scale
+    for comp, (x, y) in zip(range(4, 10), [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]):
+        assert np.abs(ao[comp] - hess[x, y]).max() < 2e-8 * scale, comp
+
+
+@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe'])
+def test_nr_rks_grad_vs_oracle(xc):
+    """XC gradient contraction (PAMD_eval_ao deriv 1/2, PAMD_dgemm_nt, PAMD_eval_xc, PAMD_xc_grad) against the
+    numpy restatement of pyscf/grad/rks.py:get_vxc on the same grid and density."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import libxc
+    from oracle import ref_dft
+    mol = gto.M(atom=LOWSYM, basis='cc-pvdz')
+    grids = dft.Grids(mol)
+    grids.atom_grid = (20, 50)
+    grids.build()
+    hyb, fac = libxc.parse_xc(xc)
+    gga = libxc.xc_type(xc) == 'GGA'
+    rng = np.random.default_rng(11)
+    c = np.linalg.qr(rng.standard_normal((mol.nao, mol.nao)))[0] * 0.7
+    dm = 2 * c[:, :5].dot(c[:, :5].T)
+    want = ref_dft.nr_rks_grad(mol, grids.coords, grids.weights, fac, gga, dm)
+    got = dft.NumInt().nr_rks_grad(mol, grids, xc, dm)
+    assert np.abs(got - want).max() < 2e-8 * max(1.0, np.abs(want).max()), (got, want)
+    got2 = dft.NumInt(block_bytes=14 * 32 * 8 * 700).nr_rks_grad(mol, grids, xc, dm)      # several blocks
+    assert np.abs(got2 - got).max() < 1e-11
+
+
+def test_df_rks_gradient_golden_and_fd():
+    """pyscf/grad/test/test_rks.py:285-288: DF-RKS (default 'LDA,VWN') 6-31G, lib.fp(g) = -0.04990623577718451 to 5
+    places (the golden includes the grid response, ours leaves it out like the reference's default); then B3LYP
+    against finite differences of the oracle's DF-RKS energy on a fine grid."""
+    from pyscf_amd import gto, dft, df
+    from pyscf_amd.dft import radi, libxc
+    from oracle import ref_dft
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False            # test_rks.py:227-228
+    try:
+        mol = gto.M(atom=H2O, basis='6-31g')
+        mf = dft.RKS(mol).density_fit().run(conv_tol=1e-12)
+        g = mf.nuc_grad_method().kernel()
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    assert abs(ref.fp(g) - -0.04990623577718451) < 2e-5, ref.fp(g)
+    # B3LYP, level-4 grid: analytic vs finite-difference of the oracle energy (moving grid: agreement limited by
+    # the neglected grid response)
+    mf = dft.RKS(mol, xc='b3lyp').density_fit()
+    mf.grids.level = 4
+    mf.run(conv_tol=1e-12)
+    g = mf.nuc_grad_method().kernel()
+    assert abs(g.sum(axis=0)).max() < 2e-5
+    hyb, fac = libxc.parse_xc('b3lyp')
+
+    def energy(dz):
+        atoms = [(s, np.array(r) / BOHR) for s, r in H2O]
+        atoms[0][1][2] += dz
+        m = gto.M(atom=[(s, tuple(r)) for s, r in atoms], basis='6-31g', unit='Bohr')
+        cderi = ref.cholesky_eri(m, df.make_auxmol(m, 'cc-pvdz-jkfit'))
+        coords, weights = ref_dft.build_grids(m, level=4)
+
+        def get_jk(dm, c, occ, with_k):
+            return ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
+        conv, e = ref_dft.rks_energy(m, fac, hyb, True, coords, weights, get_jk, conv_tol=1e-11)[:2]
+        assert conv
+        return e
+    h = 2e-3
+    fd = (energy(h) - energy(-h)) / (2 * h)
+    assert abs(g[0, 2] - fd) < 2e-5, (g[0, 2], fd)
