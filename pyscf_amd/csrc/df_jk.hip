@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 int rowi = p0 + wr * 64 + a * 16 + fk + 4 * r;
-                if (rowi < m) out[(long)rowi * ldc + col] += acc[a][b][r];
+                if (rowi < m) unsafeAtomicAdd(out + (long)rowi * ldc + col, acc[a][b][r]);   // no-return FP64 atomic: nothing to wait for
             }
         }
 }
@@ -453,7 +453,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
     double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n,
     const unsigned char *__restrict__ maskA, const unsigned char *__restrict__ maskB, int ntile_m)
 {
-    __shared__ double sbuf[2][2][KB * LDN];     // [buffer][panel][k][col]
+    // two separate LDS objects (not one [2][..] array): the compiler can then prove that the LDS-DMA writes of
+    // the next tile do not alias the ds_reads of the current one and leaves the DMA in flight during the MFMAs
+    __shared__ double sb0[2][KB * LDN];         // [panel][k][col]
+    __shared__ double sb1[2][KB * LDN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tm, tn;
     if (lower_only) {
@@ -481,16 +484,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
     const int fk = lane >> 4, fn = lane & 15;
 
     // wave w stages rows 4w..4w+3 of each panel: lane -> 2 doubles (16 B) of the row
-    auto stage = [&](long k0, int buf) {
+    auto stage = [&](long k0, double (*dst)[KB * LDN]) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = wave * 4 + j;
             const double *ga = A + (k0 + k) * lda + p0 + lane * 2;
             const double *gb = B + (k0 + k) * ldb + q0 + lane * 2;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ga,
-                                             (__attribute__((address_space(3))) void *)(&sbuf[buf][0][k * LDN]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(&dst[0][k * LDN]), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gb,
-                                             (__attribute__((address_space(3))) void *)(&sbuf[buf][1][k * LDN]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(&dst[1][k * LDN]), 16, 0, 0);
         }
     };
     // optional screening: k-tile kt is skipped when either 16 x 128 panel tile is negligible
@@ -523,13 +526,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
             nact = total;
         }
         auto kof = [&](int i) { return seg + (long)(maskA ? klist[i] : i) * KB; };
-        int buf = 0;
-        if (nact > 0) stage(kof(0), 0);
-        for (int i = 0; i < nact; i++) {
+        auto step = [&](double (*cur)[KB * LDN], double (*nxt)[KB * LDN], int i) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (i + 1 < nact) stage(kof(i + 1), buf ^ 1);
-            const double *sP = sbuf[buf][0], *sQ = sbuf[buf][1];
+            if (i + 1 < nact) stage(kof(i + 1), nxt);
+            const double *sP = cur[0], *sQ = cur[1];
 #pragma unroll
             for (int kk = 0; kk < KB; kk += 4) {
                 double af[4], bf[4];
@@ -542,7 +543,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
 #pragma unroll
                     for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
             }
-            buf ^= 1;
+        };
+        if (nact > 0) stage(kof(0), sb0);
+        for (int i = 0; i < nact; i += 2) {
+            step(sb0, sb1, i);
+            if (i + 1 < nact) step(sb1, sb0, i + 1);
         }
     }
     double *out = C + (long)blockIdx.y * m * ldc;
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 int rowi = p0 + wr * 64 + a * 16 + fk + 4 * r;
-                if (rowi < m) out[(long)rowi * ldc + col] += acc[a][b][r];
+                if (rowi < m) unsafeAtomicAdd(out + (long)rowi * ldc + col, acc[a][b][r]);   // no-return FP64 atomic: nothing to wait for
             }
         }
 }
@@ -626,6 +631,7 @@ __global__ void pack_dm_kernel(const double *__restrict__ dm, int nao, double *_
 // ======================================================================================
 static int g_use_glds = 1;
 static int g_e2_v3 = 0;   // opt-in: measured equal to the register-staged kernel (r01)
+static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper bound
 
 extern "C" {
 
@@ -634,6 +640,7 @@ int PAMD_set_tuning(const char *key, int value)
 {
     if (strcmp(key, "glds") == 0) { g_use_glds = value; return 0; }
     if (strcmp(key, "e2v3") == 0) { g_e2_v3 = value; return 0; }
+    if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
 }
 
@@ -693,7 +700,7 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     if (nL == 0 || nocc_pad == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int mt_total = nocc_pad / 16;
-    int nchunk = ceil_div(mt_total, 10);
+    int nchunk = ceil_div(mt_total, g_e2_mtmax);
     int mt = ceil_div(mt_total, nchunk);
     // the kernel writes rows i < nocc_pad only; chunks are mt*16 wide
     dim3 grid(ceil_div(ldx, NT), nL, nchunk);

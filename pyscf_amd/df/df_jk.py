@@ -81,13 +81,14 @@ def _allreduce(dfobj, tensors):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=dfobj.group)
 
 
-def _vj(dfobj, lib, dms_dev, nset, nao):
+def _vj_pass1(dfobj, lib, dms_dev, nset, nao):
+    """rho[s][L] = sum_pq B[L,pq] dtril[s][pq] on the current stream; returns the state _vj_pass2 needs."""
     torch = _torch()
     cderi = dfobj._cderi_dev
     naux, npair = cderi.shape
     st = _stream()
     dev = cderi.device
-    vjtril = torch.zeros((nset, npair), dtype=torch.float64, device=dev)
+    rhos = []
     for s0 in range(0, nset, 4):
         ns = min(4, nset - s0)
         dmtril = torch.empty((ns, npair), dtype=torch.float64, device=dev)
@@ -98,9 +99,25 @@ def _vj(dfobj, lib, dms_dev, nset, nao):
         work = torch.empty((max(wlen, 1),), dtype=torch.float64, device=dev)
         _call(dfobj, 'vj_pass1', lib.PAMD_df_vj_pass1, _ptr(cderi), _c.c_long(npair), _c.c_int(naux),
                                             _ptr(dmtril), _c.c_int(ns), _ptr(rho), _ptr(work), st)
+        rhos.append((s0, ns, rho, dmtril, work))
+    return rhos
+
+
+def _vj_pass2(dfobj, lib, rhos, nset):
+    """vjtril[s][pq] = sum_L rho[s][L] B[L,pq] on the current stream."""
+    torch = _torch()
+    cderi = dfobj._cderi_dev
+    naux, npair = cderi.shape
+    st = _stream()
+    vjtril = torch.zeros((nset, npair), dtype=torch.float64, device=cderi.device)
+    for s0, ns, rho, _dmtril, _work in rhos:
         _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(cderi), _c.c_long(npair), _c.c_int(naux),
                                             _ptr(rho), _c.c_int(ns), _ptr(vjtril[s0:s0 + ns]), st)
     return vjtril
+
+
+def _vj(dfobj, lib, dms_dev, nset, nao):
+    return _vj_pass2(dfobj, lib, _vj_pass1(dfobj, lib, dms_dev, nset, nao), nset)
 
 
 def _k_blocksize(dfobj, naux, rows, ldx):
@@ -108,7 +125,9 @@ def _k_blocksize(dfobj, naux, rows, ldx):
     like the reference's `blksize` (df_jk.py:359-360), but against HBM (default 16 GB)."""
     budget = dfobj.k_block_bytes
     blk = max(1, int(budget // (rows * ldx * 8)))
-    return min(blk, max(naux, 1))
+    blk = min(blk, max(naux, 1))
+    nblk = -(-max(naux, 1) // blk)
+    return -(-max(naux, 1) // nblk)          # equal blocks (the J passes are hidden behind one SYRK each)
 
 
 def pad_orbitals(orbo, device):
@@ -123,7 +142,7 @@ def pad_orbitals(orbo, device):
     return torch.from_numpy(orb_h).to(device), (nocc_pad if nocc else 0), ldo
 
 
-def _vk_mo(dfobj, lib, orb_list, nao, after_first_e2=None):
+def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None):
     """K_pq = sum_{L,i} X[L,i,p] X[L,i,q],  X[L,i,p] = sum_q B_L[p,q] orbo[q,i]
     (df_jk.py:353-380; nr_ao2mo.c:399-419,1240-1266).  orb_list: [(orb_dev, nocc_pad, ldo)]."""
     torch = _torch()
@@ -148,9 +167,8 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_first_e2=None):
             _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
                   _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
                   _c.c_int(ldx), st)
-            if after_first_e2 is not None:
-                after_first_e2()
-                after_first_e2 = None
+            if after_e2 is not None:
+                after_e2()
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
                   _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(1 | 2),
                   _c.c_int(nsplit), st)
@@ -273,17 +291,24 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
             if overlap:
                 # J is HBM-bound, the K SYRK is FP64-MFMA-bound and leaves register-file room: run J
                 # on a second HIP stream, released once the first half transform has been queued
+                # J pass 1 behind the SYRK of the first K block, pass 2 behind the SYRK of the second one
                 side = dfobj._side_stream()
                 holder = {}
 
                 def launch_j():
+                    if 'vj' in holder:
+                        return
                     ev = torch.cuda.Event()
                     ev.record()
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
-                        holder['vj'] = _vj(dfobj, lib, dms_dev, nset, nao)
-                vk_dev = _vk_mo(dfobj, lib, orb_list, nao, after_first_e2=launch_j)
-                if 'vj' not in holder:          # nothing was queued for K (empty shard / no occupied orbitals)
+                        if 'rho' not in holder:
+                            holder['rho'] = _vj_pass1(dfobj, lib, dms_dev, nset, nao)
+                            if getattr(dfobj, 'overlap_split', True):
+                                return
+                        holder['vj'] = _vj_pass2(dfobj, lib, holder['rho'], nset)
+                vk_dev = _vk_mo(dfobj, lib, orb_list, nao, after_e2=launch_j)
+                while 'vj' not in holder:       # fewer than two K blocks were queued (or none: empty shard, nocc = 0)
                     launch_j()
                 vjtril = holder['vj']
                 torch.cuda.current_stream().wait_stream(side)

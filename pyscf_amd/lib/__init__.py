@@ -24,7 +24,7 @@ def load_library(name='libpyscf_amd'):
     global _lib
     if _lib is not None:
         return _lib
-    so = os.path.join(_LIBDIR, name + '.so')
+    so = os.environ.get('PAMD_LIBRARY') or os.path.join(_LIBDIR, name + '.so')     # env: A/B builds in tools/
     if not os.path.exists(so):
         raise LibraryNotBuiltError(
             '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '

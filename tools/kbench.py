@@ -16,6 +16,7 @@ ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--tag', default='')
 ap.add_argument('--tune', default='', help='comma list key=value for PAMD_set_tuning')
 ap.add_argument('--no-overlap', action='store_true')
+ap.add_argument('--no-split', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 npair = a.nao * (a.nao + 1) // 2
@@ -27,6 +28,7 @@ for b0 in range(0, a.naux, 256):
 obj._cderi_dev.mul_(1.0 / np.sqrt(a.nao))
 obj._naux = a.naux
 obj.overlap_jk = not a.no_overlap
+obj.overlap_split = not a.no_split
 import ctypes
 from pyscf_amd import lib as _L
 for kv in filter(None, a.tune.split(',')):
