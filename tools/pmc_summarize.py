@@ -1,0 +1,79 @@
+"""Copy the rocprofv3 outputs of tools/profile_round.sh into profiles/<tag>/ and write pmc_summary.json.
+    python tools/pmc_summarize.py r01"""
+import csv, glob, json, os, re, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, 'profiles', tag)
+os.makedirs(out, exist_ok=True)
+
+
+def find(sub, name):
+    g = glob.glob(os.path.join(root, 'gpurun_out', 'prof_%s%s' % (tag, sub), '**', '*%s' % name), recursive=True)
+    return g[0] if g else None
+
+
+copies = [('', 'kernel_stats.csv', 'rocprofv3_kernel_stats_bench_h2o32.csv'),
+          ('_fetch', 'counter_collection.csv', 'rocprofv3_pmc_FETCH_SIZE.csv'),
+          ('_write', 'counter_collection.csv', 'rocprofv3_pmc_WRITE_SIZE.csv'),
+          ('_mfma', 'counter_collection.csv', 'rocprofv3_pmc_MFMA_BUSY.csv')]
+for sub, name, dst in copies:
+    f = find(sub, name)
+    if f:
+        shutil.copy(f, os.path.join(out, dst))
+SHORT = ['e2_symm', 'gemm_tn_glds_kernel', 'gemm_tn_kernel', 'vj_pass1_rows_kernel', 'vj_pass2_kernel', 'cderi_solve_kernel',
+         'eval_ao_kernel', 'int3c2e_kernel', 'scale_ao_kernel']
+
+
+def short(n):
+    if 'e2_symm_kernel' in n:
+        return 'e2_symm(orb_dot_rows, XC)' if 'true>' in n else 'e2_symm'
+    for s in SHORT:
+        if s in n:
+            return s
+    return None
+
+
+summ = {}
+for t, fn in (('FETCH_SIZE', 'rocprofv3_pmc_FETCH_SIZE.csv'), ('WRITE_SIZE', 'rocprofv3_pmc_WRITE_SIZE.csv')):
+    p = os.path.join(out, fn)
+    if not os.path.exists(p):
+        continue
+    agg = {}
+    for r in csv.DictReader(open(p)):
+        k = short(r['Kernel_Name'])
+        if k and r['Counter_Name'] == t:
+            agg.setdefault(k, []).append(float(r['Counter_Value']))
+    for k, v in agg.items():
+        d = summ.setdefault(k, {})
+        d['%s_KiB_per_launch_mean' % t] = round(sum(v) / len(v), 1)
+        d['%s_KiB_per_launch_max' % t] = round(max(v), 1)
+        d['launches_%s' % t] = len(v)
+p = os.path.join(out, 'rocprofv3_pmc_MFMA_BUSY.csv')
+if os.path.exists(p):
+    agg = {}
+    for r in csv.DictReader(open(p)):
+        k = short(r['Kernel_Name'])
+        if not k:
+            continue
+        d = agg.setdefault((k, r['Dispatch_Id']), {'dur': float(r['End_Timestamp']) - float(r['Start_Timestamp'])})
+        d[r['Counter_Name']] = float(r['Counter_Value'])
+    per = {}
+    for (k, _), v in agg.items():
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in v and v.get('GRBM_GUI_ACTIVE'):
+            cyc = v['GRBM_GUI_ACTIVE'] / 8.0                      # summed over the 8 XCDs
+            per.setdefault(k, []).append((v['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024), cyc / v['dur']))
+    for k, v in per.items():
+        if max(x[0] for x in v) < 0.01:
+            continue
+        d = summ.setdefault(k, {})
+        d['mfma_pipe_busy_frac'] = round(sum(x[0] for x in v) / len(v), 3)
+        d['clock_GHz'] = round(sum(x[1] for x in v) / len(v), 3)
+doc = {'command': 'tools/profile_round.sh %s: rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --steps 2 '
+                  '--warmup 1 --no-cpu-baseline --xc b3lyp  (one pass per counter set: FETCH_SIZE | WRITE_SIZE | '
+                  'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)' % tag,
+       'notes': ['FETCH_SIZE / WRITE_SIZE in KiB as reported; calibration: vj_pass1 streams cderi once (59.86e6 KiB algorithmic).',
+                 'mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); one v_mfma_f64_16x16x4_f64 '
+                 'counts 64 busy cycles.'],
+       'kernels': summ}
+json.dump(doc, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1)
+print(json.dumps(summ, indent=1)[:3000])
