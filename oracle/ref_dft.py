@@ -437,6 +437,44 @@ def nr_uks(mol, coords, weights, fac, gga, dma, dmb):
     return nelec, exc, np.array(vmat)
 
 
+def nr_uks_grad(mol, coords, weights, fac, gga, dma, dmb):
+    """XC nuclear gradient (natm, 3) of a spin-polarised density, grid response left out: numpy restatement of
+    pyscf/grad/uks.py get_vxc (:100-190) + the contraction with (D_alpha, D_beta) of grad/uhf.py:72-76."""
+    ao = eval_ao(mol, coords, 1)
+    dms = [(dma + dma.T) * .5, (dmb + dmb.T) * .5]
+    c0 = [ao[0].dot(d) for d in dms]
+    rho = [np.einsum('gi,gi->g', ao[0], c) for c in c0]
+    grad = [2 * np.einsum('xgi,gi->xg', ao[1:], c) if gga else np.zeros((3, len(coords))) for c in c0]
+    saa = np.einsum('xg,xg->g', grad[0], grad[0])
+    sab = np.einsum('xg,xg->g', grad[0], grad[1])
+    sbb = np.einsum('xg,xg->g', grad[1], grad[1])
+    e, (vra, vrb, vsaa, vsab, vsbb) = eval_xc_pol(fac, rho[0], rho[1], saa, sab, sbb)
+    nao = mol.nao_nr()
+    hess = eval_ao_hess(mol, coords) if gga else None
+    aoslices = mol.aoslice_by_atom()
+    de = np.zeros((mol.natm, 3))
+    for s, (vr, vss, g_same, g_other) in enumerate(((vra, vsaa, grad[0], grad[1]), (vrb, vsbb, grad[1], grad[0]))):
+        vmat = np.zeros((3, nao, nao))
+        if not gga:
+            aow = ao[0] * (weights * vr)[:, None]
+            for x in range(3):
+                vmat[x] = ao[1 + x].T.dot(aow)
+        else:
+            wv = np.empty((4, len(weights)))
+            wv[0] = weights * vr * .5
+            wv[1:] = weights * (2 * vss * g_same + vsab * g_other)
+            aow = np.einsum('cgi,cg->gi', ao, wv)
+            for x in range(3):
+                vmat[x] = ao[1 + x].T.dot(aow)
+                aow2 = ao[1 + x] * wv[0][:, None] + np.einsum('kgi,kg->gi', hess[x], wv[1:])
+                vmat[x] += aow2.T.dot(ao[0])
+        vmat = -vmat
+        for ia in range(mol.natm):
+            p0, p1 = aoslices[ia][2], aoslices[ia][3]
+            de[ia] += 2 * np.einsum('xij,ij->x', vmat[:, p0:p1], dms[s][p0:p1])
+    return de
+
+
 def uks_energy(mol, xc_fac, hyb, gga, coords, weights, eri, nelec, conv_tol=1e-10, max_cycle=100):
     """UKS SCF with exact 4-centre J/K (for the reference's non-DF goldens)."""
     import scipy.linalg

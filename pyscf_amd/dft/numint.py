@@ -377,6 +377,74 @@ class NumInt:
             de[ia] = -2 * s[:, p0:p1].sum(axis=1)
         return de
 
+    def nr_uks_grad(self, mol, grids, xc_code, dms):
+        """Spin-polarised XC nuclear gradient (natm, 3), grid response left out (pyscf/grad/uks.py:get_vxc
+        :100-190 contracted with (D_alpha, D_beta)); same device pipeline as nr_rks_grad, two spin passes per block."""
+        import torch
+        lib = _lib_mod.load_library()
+        dev = self._dev()
+        if grids.coords is None:
+            grids.build()
+        hyb, fac = _xc.parse_xc(xc_code)
+        xctype = _xc.xc_type(xc_code)
+        natm = mol.natm
+        if xctype == 'HF':
+            return np.zeros((natm, 3))
+        if fac[5] != 0 or fac[6] != 0:
+            raise NotImplementedError('spin-polarised PBE')
+        gga = 1 if xctype == 'GGA' else 0
+        nao = mol.nao_nr()
+        ldao = _round_up(nao, 16)
+        ncomp_ao, ncomp_c = (10, 4) if gga else (4, 1)
+        coords_dev, weights_dev = self._grid_tables(grids, dev)
+        ngrids = grids.size
+        rank, world = self._world()
+        blk = grid_block_size(ngrids, int(self.block_bytes // ((ncomp_ao + 2 * ncomp_c) * ldao * 8)), world)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        f64 = torch.float64
+        ao = torch.zeros((ncomp_ao, blk, ldao), dtype=f64, device=dev)
+        c = torch.zeros((2, ncomp_c, blk, ldao), dtype=f64, device=dev)
+        rho = torch.zeros((2, 4, blk), dtype=f64, device=dev)
+        wv = torch.empty((2, 4, blk), dtype=f64, device=dev)
+        acc = torch.zeros(3, dtype=f64, device=dev)
+        out = torch.zeros((3, nao), dtype=f64, device=dev)
+        dsym = []
+        for s in range(2):
+            d_h = np.zeros((nao, ldao))
+            d_h[:, :nao] = (np.asarray(dms[s]) + np.asarray(dms[s]).T) * .5
+            dsym.append(torch.from_numpy(d_h).to(dev))
+        fac_c = (ctypes.c_double * 7)(*fac)
+        for ib, g0 in enumerate(range(0, ngrids, blk)):
+            if ib % world != rank:
+                continue
+            ng = min(blk, ngrids - g0)
+            self.eval_ao_block(mol, coords_dev, g0, ng, 2 if gga else 1, ao, blk, ldao)
+            c.zero_()
+            for s in range(2):
+                for k in range(ncomp_c):
+                    self._call('ao_dot_dm', lib.PAMD_dgemm_nt, _ptr(ao[k]), _c.c_long(ldao), _ptr(dsym[s]), _c.c_long(ldao),
+                               _ptr(c[s, k]), _c.c_int(ldao), _c.c_int(ng), _c.c_int(nao), _c.c_long(nao), _c.c_int(1), st)
+                rho[s, 0, :ng] = (ao[0, :ng] * c[s, 0, :ng]).sum(dim=1)
+                if gga:
+                    for k in range(1, 4):
+                        rho[s, k, :ng] = 2 * (ao[k, :ng] * c[s, 0, :ng]).sum(dim=1)
+            self._call('eval_xc', lib.PAMD_eval_xc_pol, fac_c, _c.c_int(gga), _ptr(rho[0]), _ptr(rho[1]),
+                       _ptr(weights_dev[g0:g0 + ng]), _c.c_long(ng), _c.c_long(blk), _ptr(wv[0]), _ptr(wv[1]),
+                       _ptr(acc), st)
+            for s in range(2):
+                self._call('xc_grad', lib.PAMD_xc_grad, _ptr(ao), _ptr(c[s]), _ptr(wv[s]), _c.c_int(ldao), _c.c_long(blk),
+                           _c.c_long(blk), _c.c_int(gga), _c.c_long(ng), _c.c_int(nao), _ptr(out), st)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(out, group=self.group)
+        sv = out.cpu().numpy()
+        aoslices = mol.aoslice_by_atom()
+        de = np.zeros((natm, 3))
+        for ia in range(natm):
+            p0, p1 = aoslices[ia][2], aoslices[ia][3]
+            de[ia] = -2 * sv[:, p0:p1].sum(axis=1)
+        return de
+
     def nr_uks(self, mol, grids, xc_code, dms, relativity=0, hermi=1, max_memory=2000, verbose=None):
         """-> (nelec[2], excsum, vmat[2]) with the contract of numint.nr_uks (numint.py:1192-1324);
         dms = (dm_alpha, dm_beta), optionally tagged with mo_coeff (2, nao, nmo) / mo_occ (2, nmo)."""

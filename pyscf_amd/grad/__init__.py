@@ -1,3 +1,3 @@
 """Nuclear gradients of the density-fitted SCF path."""
-from . import rhf, rks
+from . import rhf, rks, uks
 from .rhf import Gradients, grad_nuc

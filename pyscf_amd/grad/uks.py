@@ -1,0 +1,25 @@
+"""Analytic nuclear gradients of density-fitted UKS on the MI355X path (pyscf/grad/uks.py get_veff :37-98 /
+get_vxc :100-190 with grid_response=False, on top of pyscf/df/grad/uks.py): the J / hyb*K part is
+``grad.rhf.grad_elec_df`` with the two occupied blocks, the XC part ``NumInt.nr_uks_grad``."""
+import numpy as np
+
+from . import rhf as rhf_grad
+
+
+class Gradients(rhf_grad.Gradients):
+    grid_response = False
+
+    def grad_elec(self):
+        mf = self.base
+        if getattr(mf, 'with_df', None) is None:
+            raise NotImplementedError('gradients are implemented for density-fitted SCF objects')
+        if self.grid_response:
+            raise NotImplementedError('grid response (pyscf/grad/rks.py:get_vxc_full_response)')
+        ni = mf._numint
+        omega, alpha, hyb = ni.rsh_and_hybrid_coeff(mf.xc, spin=self.mol.spin)
+        if omega:
+            raise NotImplementedError('range-separated hybrid gradients')
+        dm, blocks, dme = self._densities()
+        de = rhf_grad.grad_elec_df(self.mol, mf.with_df, dm, blocks, dme, hyb, self.auxbasis_response)
+        dms = [c.dot(c.T) for c, _w in blocks]
+        return de + ni.nr_uks_grad(self.mol, mf.grids, mf.xc, dms)

@@ -300,7 +300,7 @@ class SCF:
         """pyscf/scf/hf.py:2236 / pyscf/df/grad/rhf.py: analytic DF gradients on the device."""
         from .. import grad
         if hasattr(self, 'xc'):
-            return grad.rks.Gradients(self)
+            return (grad.uks if np.ndim(self.mo_occ) == 2 else grad.rks).Gradients(self)
         return grad.Gradients(self)
 
     Gradients = nuc_grad_method

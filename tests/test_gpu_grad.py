@@ -142,3 +142,41 @@ def test_df_rks_gradient_golden_and_fd():
     h = 2e-3
     fd = (energy(h) - energy(-h)) / (2 * h)
     assert abs(g[0, 2] - fd) < 2e-5, (g[0, 2], fd)
+
+
+@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp'])
+def test_nr_uks_grad_vs_oracle(xc):
+    """Spin-polarised XC gradient against the numpy restatement of pyscf/grad/uks.py:get_vxc."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import libxc
+    from oracle import ref_dft
+    mol = gto.M(atom=LOWSYM, basis='cc-pvdz', spin=2)
+    grids = dft.Grids(mol)
+    grids.atom_grid = (20, 50)
+    grids.build()
+    hyb, fac = libxc.parse_xc(xc)
+    gga = libxc.xc_type(xc) == 'GGA'
+    rng = np.random.default_rng(12)
+    c = np.linalg.qr(rng.standard_normal((mol.nao, mol.nao)))[0] * 0.7
+    dma, dmb = c[:, :6].dot(c[:, :6].T), c[:, 2:6].dot(c[:, 2:6].T)
+    want = ref_dft.nr_uks_grad(mol, grids.coords, grids.weights, fac, gga, dma, dmb)
+    got = dft.NumInt().nr_uks_grad(mol, grids, xc, (dma, dmb))
+    assert np.abs(got - want).max() < 2e-8 * max(1.0, np.abs(want).max()), (got, want)
+
+
+def test_df_uks_lda_gradient_goldens():
+    """pyscf/df/test/test_df_grad.py:125-144: H2O+ 6-31G UKS (default 'LDA,VWN'), density_fit(): lib.fp(g) =
+    -0.12092643506961044 without and -0.12092884149543644 with the auxiliary-basis response (7 places)."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import radi
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False            # test_df_grad.py:48-56
+    try:
+        mol = gto.M(atom=H2O, basis='631g', charge=1, spin=1)
+        mf = dft.UKS(mol).density_fit().run(conv_tol=1e-12)
+        g0 = mf.Gradients().set(auxbasis_response=False).kernel()
+        g1 = mf.Gradients().kernel()
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    assert abs(ref.fp(g0) - -0.12092643506961044) < 5e-7, ref.fp(g0)
+    assert abs(ref.fp(g1) - -0.12092884149543644) < 5e-7, ref.fp(g1)
