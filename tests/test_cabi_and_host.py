@@ -126,3 +126,36 @@ def test_grid_block_assignment():
         owners = [b % world for b in range(len(starts))]
         counts = [owners.count(r) for r in range(world)]
         assert max(counts) - min(counts) <= 1
+
+
+def test_grad_host_pieces():
+    """Host-side pieces of the gradient path: nuclear-repulsion gradient (pyscf/grad/rhf.py:148-166) against finite
+    differences of Mole.energy_nuc, aoslice_by_atom (gto/mole.py), the ctypes mirror of PAMD_int3c2e_grad_args."""
+    import ctypes
+    from pyscf_amd import gto
+    from pyscf_amd.grad import grad_nuc
+    from pyscf_amd.gto import moleintor
+    atoms = [('O', (0.03, -0.02, 0.01)), ('H', (0.1, -0.757, 0.587)), ('H', (-0.2, 0.8, 0.5))]
+    mol = gto.M(atom=atoms, basis='cc-pvdz')
+    g = grad_nuc(mol)
+    r = mol.atom_coords()
+    h = 1e-5
+    for ia in range(3):
+        for x in range(3):
+            es = []
+            for d in (h, -h):
+                rr = r.copy()
+                rr[ia, x] += d
+                m2 = gto.M(atom=[(s, tuple(rr[i])) for i, (s, _) in enumerate(atoms)], basis='sto-3g', unit='Bohr')
+                es.append(m2.energy_nuc())
+            assert abs((es[0] - es[1]) / (2 * h) - g[ia, x]) < 1e-7
+    sl = mol.aoslice_by_atom()
+    assert sl[:, 2:].tolist() == [[0, 14], [14, 19], [19, 24]] and sl[-1, 1] == mol.nbas
+    # struct layout: base block + 4 pointers + 3 ints, as declared in include/pyscf_amd.h
+    assert ctypes.sizeof(moleintor._GradArgs) == ctypes.sizeof(moleintor._Args) + 4 * 8 + 16
+    hdr = open(os.path.join(ROOT, 'include', 'pyscf_amd.h')).read()
+    body = hdr[hdr.index('typedef struct PAMD_int3c2e_grad_args'):hdr.index('} PAMD_int3c2e_grad_args;')]
+    names = [f[0] for f in moleintor._GradArgs._fields_]
+    import re
+    pos = [re.search(r'[ \*]%s;' % n, body).start() for n in names]
+    assert pos == sorted(pos), 'field order of _GradArgs differs from the header'
