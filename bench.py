@@ -156,14 +156,18 @@ def main():
         kern[name] = {'ms_total': round(tot, 4), 'launches': cnt, 'ms_avg': round(tot / cnt, 4)}
     dom = max(ksum, key=lambda k: ksum[k][0])
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    # profiles/r01/pmc_summary.json; KiB per launch as reported, no half-count correction applied because
-    # the 8-byte-per-lane streaming pattern calibrates to 1.00x on vj_pass1)
+    # profiles/r01/pmc_summary.json; KiB per launch as reported, corrected below where the access width needs it)
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))['kernels']
-        pk = {'e2_symm': 'e2_symm', 'dgemm_tn': 'gemm_tn_glds_kernel', 'vj_pass1': 'vj_pass1_rows_kernel',
+        e2k = 'e2_sq_kernel' if (getattr(dfobj, '_cderi_sq', None) is not None and 'e2_sq_kernel' in pm) else 'e2_symm'
+        pk = {'e2_symm': e2k, 'dgemm_tn': 'gemm_tn_glds_kernel', 'vj_pass1': 'vj_pass1_rows_kernel',
               'vj_pass2': 'vj_pass2_kernel'}[dom]
-        traffic = (pm[pk]['FETCH_SIZE_KiB_per_launch_mean'] + pm[pk]['WRITE_SIZE_KiB_per_launch_mean']) * 1024.0
+        # gfx950: FETCH_SIZE reports half the bytes of a 16-B/lane coalesced stream (MI355X_MICROARCH.md, HBM section);
+        # the LDS-DMA kernels and vj_pass2 read that way (calibrated: vj_pass2 0.50x, e2_sq 0.54x of their known bytes),
+        # vj_pass1 and e2_symm read 8 B/lane (calibrated 1.00x)
+        rd = 2.0 if pk in ('e2_sq_kernel', 'gemm_tn_glds_kernel', 'vj_pass2_kernel') else 1.0
+        traffic = (rd * pm[pk]['FETCH_SIZE_KiB_per_launch_mean'] + pm[pk]['WRITE_SIZE_KiB_per_launch_mean']) * 1024.0
     except Exception:
         pass
     dtot, dcnt = ksum[dom]
@@ -216,9 +220,10 @@ def main():
         'metric': 'ms per SCF iter (DF J/K build)', 'value': round(ms_per_step, 3), 'unit': 'ms',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
         'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '(H2O)_%d %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM'
+        'config': {'workload': '(H2O)_%d %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM%s'
                                % (args.nwater, args.basis, 'cc-pvtz-jkfit' if 'tz' in args.basis else 'auto',
-                                  nao, naux, nocc, 8e-9 * naux * npair),
+                                  nao, naux, nocc, 8e-9 * naux * npair,
+                                  ' + unpacked image for the K half transform' if getattr(dfobj, '_cderi_sq', None) is not None else ''),
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
                    'naux_local': naux_local},
         'roofline': roofline,

@@ -565,6 +565,94 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
         }
 }
 
+// Half transform on the *square* image of the tensor: X[L][i][p] = sum_q orb[q][i] * sq[L][q][p].
+// With 288 GB of HBM the K path can afford a second, unpacked copy of cderi (2x the packed size, written once at
+// build time by unpack_tril): the symmetric unpack leaves the hot loop and both operands become plain row panels
+// that stream HBM/L2 -> LDS by LDS-DMA exactly as in gemm_tn_glds (no staging VGPRs, no ds_write, one barrier per
+// k-tile, DMA of tile t+1 in flight under the MFMAs of tile t).  Workgroup tile: M = 32 WA orbitals x 128 AOs,
+// waves 2 x 2, each WA x 4 MFMA tiles.  Requirements (checked by the launcher): q rows padded to a multiple of
+// KB (zero orbital rows), ld and ldo even, 16-byte aligned bases, 128 readable doubles from any row start.
+template <int WA>
+__global__ __launch_bounds__(256, 2) void e2_sq_kernel(
+    const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
+    double *__restrict__ X, int nocc_pad, long ldx)
+{
+    constexpr int M = 2 * WA * 16;
+    constexpr int LDM = M + ((M % 32 == 16) ? 0 : 16);
+    constexpr int NFULL = M / 128, REM = M % 128;
+    __shared__ double sa0[KB * LDM];
+    __shared__ double sa1[KB * LDM];
+    __shared__ double sq0[KB * LDN];
+    __shared__ double sq1[KB * LDN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p0 = blockIdx.x * NT;
+    const long L = blockIdx.y;
+    const int m0 = blockIdx.z * M;
+    const double *src_sq = sq + L * lstride + p0 + lane * 2;
+    const double *src_orb = orb + m0 + lane * 2;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+
+    double4_t acc[WA][4];
+#pragma unroll
+    for (int a = 0; a < WA; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    auto stage = [&](int k0, double *da, double *db) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = wave * 4 + j;
+            const double *ga = src_orb + (long)(k0 + k) * ldo;
+            const double *gb = src_sq + (long)(k0 + k) * ld;
+#pragma unroll
+            for (int pc = 0; pc < NFULL; pc++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ga + pc * 128),
+                                                 (__attribute__((address_space(3))) void *)(da + k * LDM + pc * 128), 16, 0, 0);
+            if (REM > 0 && lane * 2 < REM)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ga + NFULL * 128),
+                                                 (__attribute__((address_space(3))) void *)(da + k * LDM + NFULL * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gb,
+                                             (__attribute__((address_space(3))) void *)(db + k * LDN), 16, 0, 0);
+        }
+    };
+    auto step = [&](const double *ca, const double *cb, double *na, double *nb, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k0 + KB < kdim) stage(k0 + KB, na, nb);
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[WA], bf[4];
+#pragma unroll
+            for (int a = 0; a < WA; a++) af[a] = ca[(kk + fk) * LDM + wr * (WA * 16) + a * 16 + fn];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = cb[(kk + fk) * LDN + wc * 64 + b * 16 + fn];
+#pragma unroll
+            for (int a = 0; a < WA; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+    };
+    stage(0, sa0, sq0);
+    for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
+        step(sa0, sq0, sa1, sq1, k0);
+        if (k0 + KB < kdim) step(sa1, sq1, sa0, sq0, k0 + KB);
+    }
+    double *out = X + L * nocc_pad * ldx;
+#pragma unroll
+    for (int a = 0; a < WA; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const long p = p0 + wc * 64 + b * 16 + fn;
+            if (p >= ldx) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = m0 + wr * (WA * 16) + a * 16 + fk + 4 * r;
+                if (i < nocc_pad) out[(long)i * ldx + p] = acc[a][b][r];
+            }
+        }
+}
+
 // flag[rt][ct] = max |src[16 rt .. 16 rt + 15][16 ct .. 16 ct + 15]| > thr   (rows >= nrows count as zero)
 __global__ __launch_bounds__(256) void tile_mask_kernel(const double *__restrict__ src, long ld, long nrows, double thr,
                                                         unsigned char *__restrict__ out, int nct)
@@ -744,6 +832,38 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     default: LAUNCH_E2(10); break;
     }
 #undef LAUNCH_E2
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// X[L][i][p] = sum_q orb[q][i] sq[L][q][p] on the unpacked (square) image sq[nL][rows][ld] of the tensor
+// (PAMD_unpack_tril with rows = round_up(nao, 16) into a zero-initialised buffer): the same contraction as
+// PAMD_nr_e2_symm (AO2MOnr_e2_drv + dsymm, pyscf/df/df_jk.py:373-379), LDS-DMA on both operands.
+//   d_sq   [nL][rows][ld], rows % 16 == 0, rows >= nao, ld even, ld >= nao, 256 doubles of slack after the buffer
+//   d_orb  [orb_rows >= rows][ldo] zero rows beyond nao, ldo even, ldo >= chunks * tile width (see PAMD_e2_sq_ldo)
+int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, const double *d_orb, int ldo,
+                      int orb_rows, int nocc_pad, double *d_out, int ldx, void *stream)
+{
+    PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
+    PAMD_REQUIRE(rows % KB == 0 && rows >= nao && orb_rows >= rows, "q rows must be padded to a multiple of 16");
+    PAMD_REQUIRE(ld % 2 == 0 && ldo % 2 == 0 && ld >= nao && ldx >= nao, "leading dimensions");
+    PAMD_REQUIRE(((uintptr_t)d_sq | (uintptr_t)d_orb) % 16 == 0, "16-byte aligned operands");
+    if (nL == 0 || nocc_pad == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int mt_total = nocc_pad / 16;                       // orbital MFMA tiles
+    const int nchunk = ceil_div(mt_total, 10);
+    const int wa = ceil_div(ceil_div(mt_total, nchunk), 2);   // MFMA tiles per wave row; workgroup covers 2 wa tiles
+    PAMD_REQUIRE(ldo >= nchunk * wa * 32, "orbital leading dimension too small for tile padding");
+    dim3 grid(ceil_div(ldx, NT), nL, nchunk);
+#define LAUNCH_SQ(W) e2_sq_kernel<W><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, ldx)
+    switch (wa) {
+    case 1: LAUNCH_SQ(1); break;
+    case 2: LAUNCH_SQ(2); break;
+    case 3: LAUNCH_SQ(3); break;
+    case 4: LAUNCH_SQ(4); break;
+    default: LAUNCH_SQ(5); break;
+    }
+#undef LAUNCH_SQ
     PAMD_CHECK_LAUNCH();
     return 0;
 }

@@ -38,6 +38,11 @@ class DF:
         self.incore_anyway = False  # mol.incore_anyway analogue (df_jk.py:282): force the tensor path
         self._eng = None
         self.overlap_jk = True     # run J (HBM-bound) on a second stream beside K (MFMA-bound)
+        # K path on an unpacked (square) second copy of the tensor, 2x the packed size, when HBM allows ('auto'),
+        # always (True) or never (False): plain row panels stream by LDS-DMA, no symmetric unpack in the hot loop
+        self.k_square = 'auto'
+        self.k_square_reserve = 48 << 30     # HBM left free after the copy (X block, partial K, XC blocks, ...)
+        self._cderi_sq = None
         self.kernel_timer = None   # df_jk.KernelTimer() to collect per-kernel HIP-event timings
         self._ws = {}
 
@@ -110,6 +115,39 @@ class DF:
             self._ws['T'] = buf
         return buf[:rows * naux].view(rows, naux)
 
+    def square_image(self):
+        """sq[L][q][p] (rows and ld rounded up to 16, zero padded) of this rank's cderi rows, or None."""
+        import torch
+        import ctypes as _c
+        from .. import lib as _lib
+        if self._cderi_sq is not None or self.k_square is False or self._cderi_dev is None:
+            return self._cderi_sq
+        naux, npair = self._cderi_dev.shape
+        nao = int((np.sqrt(8.0 * npair + 1) - 1) / 2 + .5)
+        rows = (nao + 15) // 16 * 16
+        need = (naux * rows * rows + 256) * 8
+        if naux == 0 or nao * (nao + 1) // 2 != npair:
+            return None
+        if self.k_square == 'auto':
+            free = torch.cuda.mem_get_info(self._cderi_dev.device)[0] + torch.cuda.memory_reserved(self._cderi_dev.device) \
+                - torch.cuda.memory_allocated(self._cderi_dev.device)
+            if need + self.k_square_reserve > free:
+                self.k_square = False
+                return None
+        so = _lib.load_library()
+        buf = torch.zeros(naux * rows * rows + 256, dtype=torch.float64, device=self._cderi_dev.device)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(so.PAMD_unpack_tril(_c.c_void_p(self._cderi_dev.data_ptr()), _c.c_long(npair), _c.c_int(naux),
+                                       _c.c_int(nao), _c.c_void_p(buf.data_ptr()), _c.c_int(rows), _c.c_int(rows), st))
+        self._cderi_sq = buf[:naux * rows * rows].view(naux, rows, rows)
+        return self._cderi_sq
+
+    def drop_square_image(self):
+        """Give the HBM of the square copy back (the gradient path needs it for W and Z)."""
+        import torch
+        self._cderi_sq = None
+        torch.cuda.empty_cache()
+
     def _workspace(self, name, shape):
         """Persistent HBM scratch (no per-iteration hipMalloc): returns a view of `shape`."""
         import torch
@@ -138,6 +176,7 @@ class DF:
         self.auxmol = None
         self._cderi = None
         self._cderi_dev = None
+        self._cderi_sq = None
         self._naux = None
         self._ws = {}
         self._eng = None

@@ -137,6 +137,10 @@ def pad_orbitals(orbo, device):
     nao, nocc = orbo.shape
     nocc_pad = _round_up(max(nocc, 1), 16)
     ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
+    # the square-image kernel tiles the orbitals in chunks of 32*wa columns (PAMD_nr_e2_square)
+    mt = nocc_pad // 16
+    nchunk = -(-mt // 10)
+    ldo = max(ldo, nchunk * (-(-(-(-mt // nchunk)) // 2)) * 32)
     orb_h = np.zeros((_round_up(nao, 16), ldo))          # zero rows up to a multiple of the k-tile
     orb_h[:nao, :nocc] = orbo
     return torch.from_numpy(orb_h).to(device), (nocc_pad if nocc else 0), ldo
@@ -162,11 +166,17 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None):
         X = dfobj._workspace('X', (blk, nocc_pad, ldx))
         part = dfobj._workspace('kpart', (nsplit, nao, nao))
         part.zero_()
+        sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
         for b0 in range(0, naux, blk):
             nb = min(blk, naux - b0)
-            _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
-                  _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
-                  _c.c_int(ldx), st)
+            if sq is not None:
+                _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[b0:b0 + nb]), _c.c_long(sq.shape[2]),
+                      _c.c_int(sq.shape[1]), _c.c_int(nb), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
+                      _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X), _c.c_int(ldx), st)
+            else:
+                _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
+                      _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
+                      _c.c_int(ldx), st)
             if after_e2 is not None:
                 after_e2()
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),

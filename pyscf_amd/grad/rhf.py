@@ -126,6 +126,7 @@ def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_respo
     if dfobj.world_size > 1:
         raise NotImplementedError('gradients with an aux-sharded tensor')
     dev = dfobj._cderi_dev.device
+    dfobj.drop_square_image()            # W and Z below each take the size of cderi
     eng = get_engine(mol, dfobj.auxmol, dev, dfobj.omega)
     natm = mol.natm
     nao = eng.ao.nao

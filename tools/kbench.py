@@ -17,6 +17,7 @@ ap.add_argument('--tag', default='')
 ap.add_argument('--tune', default='', help='comma list key=value for PAMD_set_tuning')
 ap.add_argument('--no-overlap', action='store_true')
 ap.add_argument('--no-split', action='store_true')
+ap.add_argument('--no-square', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 npair = a.nao * (a.nao + 1) // 2
@@ -29,6 +30,7 @@ obj._cderi_dev.mul_(1.0 / np.sqrt(a.nao))
 obj._naux = a.naux
 obj.overlap_jk = not a.no_overlap
 obj.overlap_split = not a.no_split
+if a.no_square: obj.k_square = False
 import ctypes
 from pyscf_amd import lib as _L
 for kv in filter(None, a.tune.split(',')):
