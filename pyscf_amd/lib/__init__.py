@@ -29,6 +29,12 @@ def load_library(name='libpyscf_amd'):
         raise LibraryNotBuiltError(
             '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(hipcc --offload-arch=gfx950). The DF J/K path has no CPU fallback.' % so)
+    # libpyscf_amd.so links the HIP runtime by SONAME only: torch must be imported first so that the one HIP
+    # runtime in the process is torch's bundled libamdhip64 (two runtimes -> "no ROCm-capable device" in ours)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(so)
     lib.PAMD_last_error.restype = ctypes.c_char_p
     lib.PAMD_df_vj_pass1_worksize.restype = ctypes.c_long
