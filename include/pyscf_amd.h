@@ -128,7 +128,9 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
  * round_up(nao,16)): both operands stream by LDS-DMA; spends 2x the packed size of HBM to take the symmetric unpack out
  * of the hot loop.  d_orb as for PAMD_nr_e2_symm with ldo >= chunks * 32 * wa (pyscf_amd/df/df_jk.py:pad_orbitals) */
 int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, const double *d_orb, int ldo,
-                      int orb_rows, int nocc_pad, double *d_out, int ldx, void *stream);  /* out[L][i][p] */
+                      int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, void *stream);
+/* d_rho (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] = sum_pq B_L[p][q] (orb orb^T)[p][q]: the first J pass
+ * (df_jk.py:367) of the density the orbitals stand for, taken from the accumulators in the epilogue */  /* out[L][i][p] */
 /* out[y][i][n] = sum_k src_y[n][k] orb[k][i] (plain-operand mode of the e2_symm MFMA kernel) */
 int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, long nrows, int kdim,
                       const double *d_orb, int ldo, int nocc_pad, double *d_out, long ldout,

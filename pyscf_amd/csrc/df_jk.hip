@@ -451,8 +451,13 @@ constexpr int KLMAX = 2048;             // k-tiles per compaction segment of the
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
     double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n,
-    const unsigned char *__restrict__ maskA, const unsigned char *__restrict__ maskB, int ntile_m)
+    const unsigned char *__restrict__ maskA, const unsigned char *__restrict__ maskB, int ntile_m, int nsplit)
 {
+    // grid (tiles, splits), tile index fastest: the workgroups of one k-split start together on all 8 XCDs and walk
+    // the same panel rows in lockstep, so each XCD's L2 serves its tiles from one fetch per row.  (Tried in r01: split
+    // index fastest with nsplit = 8, one k-range per XCD - no gain for the SYRK, 15 % slower for the vmat GEMM: the
+    // tiles of a split then start at different times and the L2 cannot hold a k-range.)
+    const int bsplit = blockIdx.y, btile = blockIdx.x;
     // two separate LDS objects (not one [2][..] array): the compiler can then prove that the LDS-DMA writes of
     // the next tile do not alias the ds_reads of the current one and leaves the DMA in flight during the MFMAs
     __shared__ double sb0[2][KB * LDN];         // [panel][k][col]
@@ -460,19 +465,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tm, tn;
     if (lower_only) {
-        int t = blockIdx.x;
+        int t = btile;
         tm = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
         while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
         while (tm * (tm + 1) / 2 > t) tm--;
         tn = t - tm * (tm + 1) / 2;
     } else {
-        tm = blockIdx.x / ntile_n;
-        tn = blockIdx.x - tm * ntile_n;
+        tm = btile / ntile_n;
+        tn = btile - tm * ntile_n;
     }
     const int p0 = tm * NT, q0 = tn * NT;
-    const int nsplit = gridDim.y;
     const long kchunk = ((kdim + nsplit - 1) / nsplit + KB - 1) / KB * KB;
-    const long kbeg = (long)blockIdx.y * kchunk;
+    const long kbeg = (long)bsplit * kchunk;
     const long kend = (kbeg + kchunk < kdim) ? kbeg + kchunk : kdim;
 
     double4_t acc[4][4];
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
             if (i + 1 < nact) step(sb1, sb0, i + 1);
         }
     }
-    double *out = C + (long)blockIdx.y * m * ldc;
+    double *out = C + (long)bsplit * m * ldc;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -572,10 +576,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
 // k-tile, DMA of tile t+1 in flight under the MFMAs of tile t).  Workgroup tile: M = 32 WA orbitals x 128 AOs,
 // waves 2 x 2, each WA x 4 MFMA tiles.  Requirements (checked by the launcher): q rows padded to a multiple of
 // KB (zero orbital rows), ld and ldo even, 16-byte aligned bases, 128 readable doubles from any row start.
-template <int WA>
+// RHO = true additionally accumulates rho[L] += sum_{i,p} X[L][i][p] * orb[p][i] in the epilogue.  With the density
+// D = orb orb^T of the MO branch this is rho_L = sum_pq B_L[p][q] D[p][q], the first J pass (pyscf/df/df_jk.py:367
+// `dmtril.dot(eri1.T)`): the half-transformed tile is in the accumulators anyway, so J needs one HBM pass over the
+// packed tensor instead of two.
+template <int WA, bool RHO>
 __global__ __launch_bounds__(256, 2) void e2_sq_kernel(
     const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
-    double *__restrict__ X, int nocc_pad, long ldx)
+    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho)
 {
     constexpr int M = 2 * WA * 16;
     constexpr int LDM = M + ((M % 32 == 16) ? 0 : 16);
@@ -639,6 +647,7 @@ __global__ __launch_bounds__(256, 2) void e2_sq_kernel(
         if (k0 + KB < kdim) step(sa1, sq1, sa0, sq0, k0 + KB);
     }
     double *out = X + L * nocc_pad * ldx;
+    double rho_acc = 0;
 #pragma unroll
     for (int a = 0; a < WA; a++)
 #pragma unroll
@@ -648,9 +657,17 @@ __global__ __launch_bounds__(256, 2) void e2_sq_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int i = m0 + wr * (WA * 16) + a * 16 + fk + 4 * r;
-                if (i < nocc_pad) out[(long)i * ldx + p] = acc[a][b][r];
+                if (i < nocc_pad) {
+                    out[(long)i * ldx + p] = acc[a][b][r];
+                    if (RHO) rho_acc += acc[a][b][r] * orb[p * ldo + i];     // rows p >= nao and columns i >= nocc of orb are zero
+                }
             }
         }
+    if (RHO) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rho_acc += __shfl_xor(rho_acc, off, 64);
+        if (lane == 0) unsafeAtomicAdd(rho + L, rho_acc);
+    }
 }
 
 // flag[rt][ct] = max |src[16 rt .. 16 rt + 15][16 ct .. 16 ct + 15]| > thr   (rows >= nrows count as zero)
@@ -841,8 +858,10 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
 // PAMD_nr_e2_symm (AO2MOnr_e2_drv + dsymm, pyscf/df/df_jk.py:373-379), LDS-DMA on both operands.
 //   d_sq   [nL][rows][ld], rows % 16 == 0, rows >= nao, ld even, ld >= nao, 256 doubles of slack after the buffer
 //   d_orb  [orb_rows >= rows][ldo] zero rows beyond nao, ldo even, ldo >= chunks * tile width (see PAMD_e2_sq_ldo)
+//   d_rho (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] = sum_pq B_L[p][q] (orb orb^T)[p][q], the first J pass
+//   of the density the orbitals stand for, taken from the accumulators in the epilogue
 int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, const double *d_orb, int ldo,
-                      int orb_rows, int nocc_pad, double *d_out, int ldx, void *stream)
+                      int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, void *stream)
 {
     PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
     PAMD_REQUIRE(rows % KB == 0 && rows >= nao && orb_rows >= rows, "q rows must be padded to a multiple of 16");
@@ -855,7 +874,15 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
     const int wa = ceil_div(ceil_div(mt_total, nchunk), 2);   // MFMA tiles per wave row; workgroup covers 2 wa tiles
     PAMD_REQUIRE(ldo >= nchunk * wa * 32, "orbital leading dimension too small for tile padding");
     dim3 grid(ceil_div(ldx, NT), nL, nchunk);
-#define LAUNCH_SQ(W) e2_sq_kernel<W><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, ldx)
+#define LAUNCH_SQ(W)                                                                                            \
+    do {                                                                                                        \
+        if (d_rho)                                                                                              \
+            e2_sq_kernel<W, true><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
+                                                        ldx, d_rho);                                             \
+        else                                                                                                    \
+            e2_sq_kernel<W, false><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
+                                                         ldx, nullptr);                                          \
+    } while (0)
     switch (wa) {
     case 1: LAUNCH_SQ(1); break;
     case 2: LAUNCH_SQ(2); break;
@@ -923,7 +950,7 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
                          (k % KB == 0) && (kchunk % KB == 0);
     if ((lower_only & 2) && aligned && (g_use_glds || d_maskA))
         gemm_tn_glds_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn,
-                                                  d_maskA, d_maskB, tm);
+                                                  d_maskA, d_maskB, tm, nsplit);
     else {
         PAMD_REQUIRE(d_maskA == nullptr, "masked dgemm_tn needs the aligned LDS-DMA path (flag 2, 16-byte aligned, k % 16 == 0)");
         gemm_tn_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn);

@@ -146,7 +146,7 @@ def pad_orbitals(orbo, device):
     return torch.from_numpy(orb_h).to(device), (nocc_pad if nocc else 0), ldo
 
 
-def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None):
+def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
     """K_pq = sum_{L,i} X[L,i,p] X[L,i,q],  X[L,i,p] = sum_q B_L[p,q] orbo[q,i]
     (df_jk.py:353-380; nr_ao2mo.c:399-419,1240-1266).  orb_list: [(orb_dev, nocc_pad, ldo)]."""
     torch = _torch()
@@ -157,7 +157,7 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None):
     ldx = _round_up(nao, 16)
     nsplit = dfobj.k_nsplit
     vks = []
-    for orb, nocc_pad, ldo in orb_list:
+    for iset, (orb, nocc_pad, ldo) in enumerate(orb_list):
         vk = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
         if nocc_pad == 0 or naux == 0:
             vks.append(vk)
@@ -170,15 +170,18 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None):
         for b0 in range(0, naux, blk):
             nb = min(blk, naux - b0)
             if sq is not None:
+                # fuse_j[set] = rho (naux) zeroed: the first J pass of the density orb orb^T comes out of the epilogue
+                rho_j = fuse_j[iset] if fuse_j is not None else None
                 _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[b0:b0 + nb]), _c.c_long(sq.shape[2]),
                       _c.c_int(sq.shape[1]), _c.c_int(nb), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
-                      _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X), _c.c_int(ldx), st)
+                      _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X), _c.c_int(ldx),
+                      _ptr(rho_j[b0:]) if rho_j is not None else _c.c_void_p(0), st)
             else:
                 _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
                       _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
                       _c.c_int(ldx), st)
             if after_e2 is not None:
-                after_e2()
+                after_e2(b0, nb, iset)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
                   _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(1 | 2),
                   _c.c_int(nsplit), st)
@@ -305,7 +308,34 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
                 side = dfobj._side_stream()
                 holder = {}
 
-                def launch_j():
+                sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
+                fused = (sq is not None and len(orb_list) == nset and all(o[1] > 0 for o in orb_list) and
+                         getattr(dfobj, 'fuse_j_pass1', True))
+                if fused:
+                    # the epilogue sum is the first J pass only for D_s = orb_s orb_s^T (what make_rdm1 tags): verify
+                    for s_, (orb_s, _np, _ld) in enumerate(orb_list):
+                        c_s = orb_s[:nao]
+                        if float((dms_dev[s_] - c_s @ c_s.T).abs().max()) > 1e-10 * max(1.0, float(dms_dev[s_].abs().max())):
+                            fused = False
+                if fused:
+                    # pass 1 comes out of the half transform (PAMD_nr_e2_square); pass 2 of each K block follows on
+                    # the side stream behind that block's SYRK
+                    naux_l, npair_l = dfobj._cderi_dev.shape
+                    rho_f = torch.zeros((nset, naux_l), dtype=torch.float64, device=dms_dev.device)
+                    vj_f = torch.zeros((nset, npair_l), dtype=torch.float64, device=dms_dev.device)
+
+                    def pass2_block(b0, nb, iset):
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        side.wait_event(ev)
+                        with torch.cuda.stream(side):
+                            _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(dfobj._cderi_dev[b0:b0 + nb]),
+                                  _c.c_long(npair_l), _c.c_int(nb), _ptr(rho_f[iset, b0:]), _c.c_int(1),
+                                  _ptr(vj_f[iset]), _c.c_void_p(side.cuda_stream))
+                    vk_dev = _vk_mo(dfobj, lib, orb_list, nao, after_e2=pass2_block, fuse_j=rho_f)
+                    holder['vj'] = vj_f
+
+                def launch_j(*_a):
                     if 'vj' in holder:
                         return
                     ev = torch.cuda.Event()
@@ -317,7 +347,8 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
                             if getattr(dfobj, 'overlap_split', True):
                                 return
                         holder['vj'] = _vj_pass2(dfobj, lib, holder['rho'], nset)
-                vk_dev = _vk_mo(dfobj, lib, orb_list, nao, after_e2=launch_j)
+                if not fused:
+                    vk_dev = _vk_mo(dfobj, lib, orb_list, nao, after_e2=launch_j)
                 while 'vj' not in holder:       # fewer than two K blocks were queued (or none: empty shard, nocc = 0)
                     launch_j()
                 vjtril = holder['vj']

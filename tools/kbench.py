@@ -18,6 +18,8 @@ ap.add_argument('--tune', default='', help='comma list key=value for PAMD_set_tu
 ap.add_argument('--no-overlap', action='store_true')
 ap.add_argument('--no-split', action='store_true')
 ap.add_argument('--no-square', action='store_true')
+ap.add_argument('--no-fuse', action='store_true')
+ap.add_argument('--ksplit', type=int, default=0)
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 npair = a.nao * (a.nao + 1) // 2
@@ -31,6 +33,8 @@ obj._naux = a.naux
 obj.overlap_jk = not a.no_overlap
 obj.overlap_split = not a.no_split
 if a.no_square: obj.k_square = False
+if a.no_fuse: obj.fuse_j_pass1 = False
+if a.ksplit: obj.k_nsplit = a.ksplit
 import ctypes
 from pyscf_amd import lib as _L
 for kv in filter(None, a.tune.split(',')):
