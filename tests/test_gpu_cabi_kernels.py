@@ -148,3 +148,38 @@ def test_dgemm_tn_masked_and_tile_mask(m, n, k, nsplit):
                 a[rows][:, i * 128:min((i + 1) * 128, m)].T @ b[rows][:, j * 128:min((j + 1) * 128, n)]
     assert abs(got - ref).max() < 1e-10
     assert abs(got - a[:, :m].T @ b[:, :n]).max() < 1e-10          # and the skipped work was negligible
+
+
+@pytest.mark.parametrize('nao,naux,nocc', [(130, 37, 33), (257, 20, 161), (64, 5, 16)])
+def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
+    """PAMD_unpack_tril -> PAMD_nr_e2_square (LDS-DMA half transform on the unpacked image) against numpy, including the
+    first J pass taken from the epilogue: rho_L = sum_{i,p} X[L,i,p] C[p,i] = sum_pq B_L[pq] (C C^T)[pq]."""
+    torch, so, dev, st, lib = _setup()
+    from pyscf_amd.df import df_jk
+    rng = np.random.default_rng(nao + naux)
+    npair = nao * (nao + 1) // 2
+    tril = rng.standard_normal((naux, npair))
+    c = rng.standard_normal((nao, nocc))
+    rows = (nao + 15) // 16 * 16
+    t_tril = torch.from_numpy(tril).to(dev)
+    buf = torch.zeros(naux * rows * rows + 256, dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_unpack_tril(_p(t_tril), C.c_long(npair), naux, nao, _p(buf), rows, rows, st))
+    sq = buf[:naux * rows * rows].view(naux, rows, rows)
+    full = lib.unpack_tril(tril)                                           # (naux, nao, nao) host
+    assert np.abs(sq[:, :nao, :nao].cpu().numpy() - full).max() == 0
+    orb, nocc_pad, ldo = df_jk.pad_orbitals(c, dev)
+    ldx = rows
+    x = torch.zeros((naux, nocc_pad, ldx), dtype=torch.float64, device=dev)
+    rho = torch.zeros(naux, dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_nr_e2_square(_p(sq), C.c_long(rows), rows, naux, nao, _p(orb), ldo, orb.shape[0], nocc_pad,
+                                   _p(x), ldx, _p(rho), st))
+    want = np.einsum('Lpq,qi->Lip', full, c)
+    got = x[:, :nocc, :nao].cpu().numpy()
+    assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
+    rho_want = np.einsum('Lpq,pq->L', full, c.dot(c.T))
+    assert np.abs(rho.cpu().numpy() - rho_want).max() < 1e-10 * np.abs(rho_want).max()
+    # without the fused pass (d_rho = NULL) the transform itself is unchanged
+    x2 = torch.zeros_like(x)
+    lib.check(so.PAMD_nr_e2_square(_p(sq), C.c_long(rows), rows, naux, nao, _p(orb), ldo, orb.shape[0], nocc_pad,
+                                   _p(x2), ldx, C.c_void_p(0), st))
+    assert torch.equal(x, x2)
