@@ -174,7 +174,9 @@ def main():
     if dom in ('e2_symm', 'dgemm_tn'):
         fl = flops_e2 if dom == 'e2_symm' else flops_syrk
         ach = fl / (dtot * 1e-3) / 1e12
-        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
+        kname = {'e2_symm': 'e2_sq (half transform on the unpacked image)' if getattr(dfobj, '_cderi_sq', None) is not None
+                 else 'e2_symm (half transform)', 'dgemm_tn': 'gemm_tn_glds (SYRK)'}[dom]
+        roofline = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                     'avg_launch_ms': round(dtot / dcnt, 4), 'launches': dcnt,
                     'flops_per_step': fl}
