@@ -223,7 +223,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
         'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': '(H2O)_%d %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM%s'
-                               % (args.nwater, args.basis, 'cc-pvtz-jkfit' if 'tz' in args.basis else 'auto',
+                               % (args.nwater, args.basis, str(getattr(dfobj.auxmol, 'basis', 'auto')),
                                   nao, naux, nocc, 8e-9 * naux * npair,
                                   ' + unpacked image for the K half transform' if getattr(dfobj, '_cderi_sq', None) is not None else ''),
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
