@@ -250,110 +250,6 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
         }
 }
 
-// v3 of the symmetric half transform: the orbital tile is streamed into a double-buffered LDS
-// image by LDS-DMA (global_load_lds_dwordx4, no staging VGPRs, no ds_write), the cderi operand is
-// loaded straight into MFMA B-fragment registers (its columns are private to a wave, so LDS would
-// only add a round trip) and re-loaded for the next k-tile right after its last use, and the
-// A fragments of k-step kk+4 are read from LDS while the MFMAs of k-step kk issue.  One barrier
-// per k-tile.  Requires orb rows padded to a multiple of KB (zero rows) and 16-byte aligned rows.
-template <int MT>
-__global__ __launch_bounds__(256, 2) void e2_symm_v3_kernel(
-    const double *__restrict__ cderi, long npair, int nao, const double *__restrict__ orb, int ldo,
-    double *__restrict__ X, int nocc_pad, long ldx)
-{
-    constexpr int MW = MT * 16;
-    constexpr int LDA = MW + ((MW % 32 == 16) ? 0 : 16);
-    constexpr int NFULL = MW / 128, REM = MW % 128;       // 128-double pieces per orbital-tile row
-    __shared__ double sA[2][KB * LDA];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int p0 = blockIdx.x * NT;
-    const int L = blockIdx.y;
-    const int m0 = blockIdx.z * MW;
-    const double *row = cderi + (long)L * npair;
-    const int fk = lane >> 4, fn = lane & 15;
-
-    double4_t acc[MT][2];
-#pragma unroll
-    for (int a = 0; a < MT; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = double4_t{0, 0, 0, 0};
-
-    auto stageA = [&](int q0, int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = wave * 4 + j;
-            const double *src = orb + (long)(q0 + k) * ldo + m0 + lane * 2;
-            double *dst = &sA[buf][k * LDA];
-#pragma unroll
-            for (int pc = 0; pc < NFULL; pc++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 128),
-                                                 (__attribute__((address_space(3))) void *)(dst + pc * 128), 16, 0, 0);
-            if (REM > 0 && lane * 2 < REM)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + NFULL * 128),
-                                                 (__attribute__((address_space(3))) void *)(dst + NFULL * 128), 16, 0, 0);
-        }
-    };
-    const long pcol[2] = {(long)p0 + wave * 32 + fn, (long)p0 + wave * 32 + 16 + fn};
-    auto loadB = [&](int q0, int kk, int b) -> double {
-        const long q = q0 + kk + fk, p = pcol[b];
-        if (p >= nao || q >= nao) return 0.0;
-        return (q >= p) ? row[q * (q + 1) / 2 + p] : row[p * (p + 1) / 2 + q];
-    };
-
-    double rb[4][2];
-    stageA(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) rb[ks][b] = loadB(0, ks * 4, b);
-
-    int buf = 0;
-    for (int q0 = 0; q0 < nao; q0 += KB) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const bool more = q0 + KB < nao;
-        if (more) stageA(q0 + KB, buf ^ 1);
-        const double *sa = sA[buf];
-        double a_cur[MT], a_nxt[MT];
-#pragma unroll
-        for (int a = 0; a < MT; a++) a_cur[a] = sa[fk * LDA + a * 16 + fn];
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            if (ks < 3) {
-#pragma unroll
-                for (int a = 0; a < MT; a++) a_nxt[a] = sa[((ks + 1) * 4 + fk) * LDA + a * 16 + fn];
-            }
-#pragma unroll
-            for (int a = 0; a < MT; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++) acc[a][b] = mfma_f64_16x16x4(a_cur[a], rb[ks][b], acc[a][b]);
-            if (more) {
-#pragma unroll
-                for (int b = 0; b < 2; b++) rb[ks][b] = loadB(q0 + KB, ks * 4, b);
-            }
-            if (ks < 3) {
-#pragma unroll
-                for (int a = 0; a < MT; a++) a_cur[a] = a_nxt[a];
-            }
-        }
-        buf ^= 1;
-    }
-    double *out = X + (long)L * nocc_pad * ldx;
-#pragma unroll
-    for (int a = 0; a < MT; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            long p = pcol[b];
-            if (p >= ldx) continue;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int i = m0 + a * 16 + fk + 4 * r;
-                if (i < nocc_pad) out[(long)i * ldx + p] = acc[a][b][r];
-            }
-        }
-}
-
 // C[split][m][n] += sum_{k in split range} A[k][m] * B[k][n]
 //   128x128 tile per workgroup, 64x64 per wave (4x4 MFMA tiles).
 //   grid: x = tile id (all tiles, or lower-triangular tiles when lower_only), y = k split.
@@ -735,7 +631,6 @@ __global__ void pack_dm_kernel(const double *__restrict__ dm, int nao, double *_
 // C ABI
 // ======================================================================================
 static int g_use_glds = 1;
-static int g_e2_v3 = 0;   // opt-in: measured equal to the register-staged kernel (r01)
 static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper bound
 
 extern "C" {
@@ -744,7 +639,6 @@ extern "C" {
 int PAMD_set_tuning(const char *key, int value)
 {
     if (strcmp(key, "glds") == 0) { g_use_glds = value; return 0; }
-    if (strcmp(key, "e2v3") == 0) { g_e2_v3 = value; return 0; }
     if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
 }
@@ -813,29 +707,6 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     e2_symm_kernel<MT, false><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx, 0, 0, nullptr)
     // orbital tile reads m0+i < ldo must stay in bounds: require ldo >= nchunk*mt*16
     PAMD_REQUIRE(ldo >= nchunk * mt * 16, "orbital leading dimension too small for tile padding");
-    // v3 (LDS-DMA + register B fragments) needs orb rows zero-padded to a multiple of KB and
-    // 16-byte aligned orbital rows; the caller states that with orb_rows >= round_up(nao, 16)
-    const bool v3 = g_e2_v3 && (orb_rows >= (nao + KB - 1) / KB * KB) && (ldo % 2 == 0) &&
-                    ((uintptr_t)d_orb % 16 == 0) && ((mt * 16) % 2 == 0);
-#define LAUNCH_V3(MT)                                                                         \
-    e2_symm_v3_kernel<MT><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx)
-    if (v3) {
-        switch (mt) {
-        case 1: LAUNCH_V3(1); break;
-        case 2: LAUNCH_V3(2); break;
-        case 3: LAUNCH_V3(3); break;
-        case 4: LAUNCH_V3(4); break;
-        case 5: LAUNCH_V3(5); break;
-        case 6: LAUNCH_V3(6); break;
-        case 7: LAUNCH_V3(7); break;
-        case 8: LAUNCH_V3(8); break;
-        case 9: LAUNCH_V3(9); break;
-        default: LAUNCH_V3(10); break;
-        }
-        PAMD_CHECK_LAUNCH();
-        return 0;
-    }
-#undef LAUNCH_V3
     switch (mt) {
     case 1: LAUNCH_E2(1); break;
     case 2: LAUNCH_E2(2); break;
