@@ -344,6 +344,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
 // aligned bases, every k range a multiple of KB, and 128 readable doubles from any row start
 // (edge tiles read past m/n inside the allocation; those columns are never stored).
 constexpr int KLMAX = 2048;             // k-tiles per compaction segment of the screened LDS-DMA GEMM
+// WA = MFMA tiles per wave row: workgroup tile (32 WA) x 128; WA = 4 is the square 128 x 128 tile (the only shape of the
+// lower-triangular SYRK mode), WA = 5 gives 160 x 128 and 80 instead of 64 MFMAs per wave between barriers.
+template <int WA>
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
     double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n,
@@ -356,8 +359,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
     const int bsplit = blockIdx.y, btile = blockIdx.x;
     // two separate LDS objects (not one [2][..] array): the compiler can then prove that the LDS-DMA writes of
     // the next tile do not alias the ds_reads of the current one and leaves the DMA in flight during the MFMAs
-    __shared__ double sb0[2][KB * LDN];         // [panel][k][col]
-    __shared__ double sb1[2][KB * LDN];
+    constexpr int TM = 32 * WA;
+    constexpr int LDM = TM + ((TM % 32 == 16) ? 0 : 16);
+    constexpr int NFULL = TM / 128, REM = TM % 128;
+    constexpr int PA = KB * LDM;                 // doubles of the A panel; the B panel [k][LDN] follows it
+    __shared__ double sb0[PA + KB * LDN];
+    __shared__ double sb1[PA + KB * LDN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tm, tn;
     if (lower_only) {
@@ -370,43 +377,56 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
         tm = btile / ntile_n;
         tn = btile - tm * ntile_n;
     }
-    const int p0 = tm * NT, q0 = tn * NT;
+    const int p0 = tm * TM, q0 = tn * NT;
     const long kchunk = ((kdim + nsplit - 1) / nsplit + KB - 1) / KB * KB;
     const long kbeg = (long)bsplit * kchunk;
     const long kend = (kbeg + kchunk < kdim) ? kbeg + kchunk : kdim;
 
-    double4_t acc[4][4];
+    double4_t acc[WA][4];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < WA; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
     const int wr = wave >> 1, wc = wave & 1;
     const int fk = lane >> 4, fn = lane & 15;
 
     // wave w stages rows 4w..4w+3 of each panel: lane -> 2 doubles (16 B) of the row
-    auto stage = [&](long k0, double (*dst)[KB * LDN]) {
+    auto stage = [&](long k0, double *dst) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = wave * 4 + j;
             const double *ga = A + (k0 + k) * lda + p0 + lane * 2;
             const double *gb = B + (k0 + k) * ldb + q0 + lane * 2;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ga,
-                                             (__attribute__((address_space(3))) void *)(&dst[0][k * LDN]), 16, 0, 0);
+#pragma unroll
+            for (int pc = 0; pc < NFULL; pc++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ga + pc * 128),
+                                                 (__attribute__((address_space(3))) void *)(dst + k * LDM + pc * 128), 16, 0, 0);
+            if (REM > 0 && lane * 2 < REM)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ga + NFULL * 128),
+                                                 (__attribute__((address_space(3))) void *)(dst + k * LDM + NFULL * 128), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gb,
-                                             (__attribute__((address_space(3))) void *)(&dst[1][k * LDN]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(dst + PA + k * LDN), 16, 0, 0);
         }
     };
     // optional screening: k-tile kt is skipped when either 16 x 128 panel tile is negligible
     // (maskA[kt][tm], maskB[kt][tn]; VXCdot_ao_ao_sparse's pair_mask idea, nr_numint_sparse.c:890-973).
     // The surviving k-tiles of a segment are compacted (in order) into an LDS list first so the
     // pipelined loop never waits on a mask byte.
-    __shared__ unsigned short klist[KLMAX];
-    __shared__ int s_cnt[4];
-    const long seglen = maskA ? (long)KLMAX * KB : (kend > kbeg ? kend - kbeg : 1);
+    // (the 160-row instance is never screened: its LDS image is exactly half a CU's 160 KiB, the list would not fit)
+    constexpr bool MASKED = (WA == 4);
+    unsigned short *klist = nullptr;
+    int *s_cnt = nullptr;
+    if constexpr (MASKED) {
+        __shared__ unsigned short klist_s[KLMAX];
+        __shared__ int s_cnt_s[4];
+        klist = klist_s;
+        s_cnt = s_cnt_s;
+    }
+    const long seglen = (MASKED && maskA) ? (long)KLMAX * KB : (kend > kbeg ? kend - kbeg : 1);
     for (long seg = kbeg; seg < kend; seg += seglen) {
         const long segend = (seg + seglen < kend) ? seg + seglen : kend;
         int nact = (int)((segend - seg) / KB);
-        if (maskA) {
+        if (MASKED && maskA) {
             const int nt = nact;
             const long t0g = seg / KB;
             int total = 0;
@@ -425,21 +445,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
             }
             nact = total;
         }
-        auto kof = [&](int i) { return seg + (long)(maskA ? klist[i] : i) * KB; };
-        auto step = [&](double (*cur)[KB * LDN], double (*nxt)[KB * LDN], int i) {
+        auto kof = [&](int i) { return seg + (long)((MASKED && maskA) ? klist[i] : i) * KB; };
+        auto step = [&](const double *cur, double *nxt, int i) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (i + 1 < nact) stage(kof(i + 1), nxt);
-            const double *sP = cur[0], *sQ = cur[1];
+            const double *sP = cur, *sQ = cur + PA;
 #pragma unroll
             for (int kk = 0; kk < KB; kk += 4) {
-                double af[4], bf[4];
+                double af[WA], bf[4];
 #pragma unroll
-                for (int a = 0; a < 4; a++) af[a] = sP[(kk + fk) * LDN + wr * 64 + a * 16 + fn];
+                for (int a = 0; a < WA; a++) af[a] = sP[(kk + fk) * LDM + wr * (WA * 16) + a * 16 + fn];
 #pragma unroll
                 for (int b = 0; b < 4; b++) bf[b] = sQ[(kk + fk) * LDN + wc * 64 + b * 16 + fn];
 #pragma unroll
-                for (int a = 0; a < 4; a++)
+                for (int a = 0; a < WA; a++)
 #pragma unroll
                     for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
             }
@@ -452,14 +472,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
     }
     double *out = C + (long)bsplit * m * ldc;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < WA; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             int col = q0 + wc * 64 + b * 16 + fn;
             if (col >= n) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                int rowi = p0 + wr * 64 + a * 16 + fk + 4 * r;
+                int rowi = p0 + wr * (WA * 16) + a * 16 + fk + 4 * r;
                 if (rowi < m) unsafeAtomicAdd(out + (long)rowi * ldc + col, acc[a][b][r]);   // no-return FP64 atomic: nothing to wait for
             }
         }
@@ -631,6 +651,7 @@ __global__ void pack_dm_kernel(const double *__restrict__ dm, int nao, double *_
 // C ABI
 // ======================================================================================
 static int g_use_glds = 1;
+static int g_gemm_wide = 1;
 static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper bound
 
 extern "C" {
@@ -639,6 +660,7 @@ extern "C" {
 int PAMD_set_tuning(const char *key, int value)
 {
     if (strcmp(key, "glds") == 0) { g_use_glds = value; return 0; }
+    if (strcmp(key, "gemmwide") == 0) { g_gemm_wide = value; return 0; }
     if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
 }
@@ -811,17 +833,27 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
     PAMD_REQUIRE(!(lower_only & 1) || m == n, "lower_only needs a square result");
     if (m == 0 || n == 0 || k == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    int tm = ceil_div(m, NT), tn = ceil_div(n, NT);
-    int ntiles = (lower_only & 1) ? tm * (tm + 1) / 2 : tm * tn;
-    dim3 grid(ntiles, nsplit);
-    // flags bit 1 (value 2): caller guarantees 128 readable doubles from every row start and
+    // flags bit 1 (value 2): caller guarantees 160 readable doubles from every row start and
     // k ranges that are multiples of 16 -> LDS-DMA kernel
     const long kchunk = ((k + nsplit - 1) / nsplit + KB - 1) / KB * KB;
     const bool aligned = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)d_A | (uintptr_t)d_B) % 16 == 0) &&
                          (k % KB == 0) && (kchunk % KB == 0);
-    if ((lower_only & 2) && aligned && (g_use_glds || d_maskA))
-        gemm_tn_glds_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn,
-                                                  d_maskA, d_maskB, tm, nsplit);
+    const bool glds = (lower_only & 2) && aligned && (g_use_glds || d_maskA);
+    // full (non-symmetric), unscreened products take 160 x 128 tiles: 80 instead of 64 MFMAs per wave between
+    // barriers, and exactly 2 x 80 KiB of LDS per CU (the screened variant's k-tile list would not fit beside it)
+    const bool wide = glds && !(lower_only & 1) && d_maskA == nullptr && m > 128 && g_gemm_wide;
+    const int tile_m = wide ? 160 : NT;
+    int tm = ceil_div(m, tile_m), tn = ceil_div(n, NT);
+    int ntiles = (lower_only & 1) ? tm * (tm + 1) / 2 : tm * tn;
+    dim3 grid(ntiles, nsplit);
+    if (glds)
+    {
+        if (wide)
+            gemm_tn_glds_kernel<5><<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, 0, tn, d_maskA, d_maskB, tm, nsplit);
+        else
+            gemm_tn_glds_kernel<4><<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn,
+                                                         d_maskA, d_maskB, tm, nsplit);
+    }
     else {
         PAMD_REQUIRE(d_maskA == nullptr, "masked dgemm_tn needs the aligned LDS-DMA path (flag 2, 16-byte aligned, k % 16 == 0)");
         gemm_tn_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn);

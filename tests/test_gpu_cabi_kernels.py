@@ -20,7 +20,8 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
-@pytest.mark.parametrize('m,n,k,lower', [(200, 200, 1024, 1), (130, 77, 333, 0), (128, 128, 16, 0), (300, 300, 4096, 1)])
+@pytest.mark.parametrize('m,n,k,lower', [(200, 200, 1024, 1), (130, 77, 333, 0), (128, 128, 16, 0), (300, 300, 4096, 1),
+                                          (300, 200, 2048, 0), (161, 129, 512, 0), (480, 130, 1024, 0)])   # 160 x 128-tile instance
 @pytest.mark.parametrize('glds', [0, 1])
 def test_dgemm_tn_split_k_and_lds_dma(m, n, k, lower, glds):
     torch, so, dev, st, lib = _setup()
