@@ -401,7 +401,31 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
             mo_occ = np.vstack((mo_occa, mo_occb))
         orb_list = [pad_orbitals(mo_coeff[k][:, mo_occ[k] > 0] * np.sqrt(mo_occ[k][mo_occ[k] > 0]), dev)
                     for k in range(nset)]
+    neg_sets = None
+    if with_k and orb_list is None and hermi == 1 and getattr(dfobj, 'factorize_hermitian_dm', True):
+        # No orbitals came with the density (initial guesses, user-built DMs): the reference then pays 4 naux nao^3
+        # (df_jk.py:382-407).  A symmetric D factorises on the device as D = C+ C+^T - C- C-^T (eigenvectors scaled by
+        # sqrt|w|), K is linear in D, so the MO kernels apply at 3 naux nao^2 (r+ + r-) - for the rank of a minimal-basis
+        # guess an order of magnitude less.
+        pos, neg = [], []
+        for k in range(nset):
+            w, v = torch.linalg.eigh((dms_dev[k] + dms_dev[k].T) * .5)
+            thr = 1e-13 * max(float(w.abs().max()), 1e-300)
+            cp = (v[:, w > thr] * w[w > thr].sqrt()).cpu().numpy()
+            cn = (v[:, w < -thr] * (-w[w < -thr]).sqrt()).cpu().numpy()
+            pos.append(pad_orbitals(cp, dev))
+            neg.append(pad_orbitals(cn, dev) if cn.shape[1] else None)
+        orb_list = pos
+        if any(n is not None for n in neg):
+            neg_sets = neg
     vjtril, vk_dev = get_jk_device(dfobj, dms_dev, orb_list, with_j, with_k)
+    if neg_sets is not None:
+        lib = _lib_mod.load_library()
+        idx = [k for k in range(nset) if neg_sets[k] is not None]
+        vk_neg = _vk_mo(dfobj, lib, [neg_sets[k] for k in idx], nao)
+        _allreduce(dfobj, [vk_neg])
+        for j, k in enumerate(idx):
+            vk_dev[k] -= vk_neg[j]
     vj = vk = None
     if with_j:
         vj = _lib_mod.unpack_tril(vjtril.cpu().numpy(), 1).reshape(dm_shape)

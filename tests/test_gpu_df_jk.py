@@ -194,3 +194,22 @@ def test_get_eri_ao2mo_and_npy_roundtrip(h2o, tmp_path):
     assert np.abs(obj2.get_eri() - obj.get_eri()).max() < 1e-12
     blocks = np.vstack(list(obj2.loop(40)))
     assert np.abs(blocks - cderi).max() < 1e-14
+
+
+def test_hermitian_dm_without_orbitals_is_factorized(h2o):
+    """A symmetric DM without mo_coeff (initial guess, density differences) is split on the device into
+    D = C+ C+^T - C- C-^T and sent through the MO kernels; must agree with the oracle's general formula and with the
+    reference-style general branch (hermi=0), for a positive and for an indefinite matrix."""
+    mol, aux, cderi = h2o
+    obj = _dfobj(mol, cderi)
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((mol.nao, mol.nao))
+    indefinite = a + a.T
+    psd = a[:, :6].dot(a[:, :6].T)
+    for dm in (psd, indefinite, np.array([psd, indefinite, -psd])):
+        vj0, vk0 = ref.get_jk(cderi, dm, 1)
+        vj1, vk1 = obj.get_jk(dm, hermi=1)
+        vj2, vk2 = obj.get_jk(dm, hermi=0)
+        scale = max(1.0, np.abs(vk0).max())
+        assert np.abs(vj1 - vj0).max() < 1e-11 * scale and np.abs(vk1 - vk0).max() < 1e-11 * scale
+        assert np.abs(vk2 - vk0).max() < 1e-11 * scale
