@@ -135,7 +135,11 @@ class DF:
                 self.k_square = False
                 return None
         so = _lib.load_library()
-        buf = torch.zeros(naux * rows * rows + 256, dtype=torch.float64, device=self._cderi_dev.device)
+        # unpack_tril writes every [p < nao][q < rows] entry; only the pad rows p >= nao (and the slack) need zeroing
+        buf = torch.empty(naux * rows * rows + 256, dtype=torch.float64, device=self._cderi_dev.device)
+        buf[naux * rows * rows:].zero_()
+        if rows > nao:
+            buf[:naux * rows * rows].view(naux, rows, rows)[:, nao:, :].zero_()
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(so.PAMD_unpack_tril(_c.c_void_p(self._cderi_dev.data_ptr()), _c.c_long(npair), _c.c_int(naux),
                                        _c.c_int(nao), _c.c_void_p(buf.data_ptr()), _c.c_int(rows), _c.c_int(rows), st))

@@ -156,6 +156,8 @@ class NumInt:
         rows = (ng + 15) // 16
         if rows == 0:
             return False
+        if self.vmat_screen_min_skip <= 0:
+            return True                       # no density read-back (it would stall the launch queue)
         dens = float(mpanel[:rows].float().mean())
         return 1.0 - dens * dens >= self.vmat_screen_min_skip
 
