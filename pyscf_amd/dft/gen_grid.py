@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 from .. import lib as _lib_mod
-from ..gto.mole import charge as _charge
+from ..gto.mole import element_charge as _charge        # ghost atoms get the grid of their element (gen_grid.py:297)
 from . import radi
 
 GROUP_BOX_SIZE = 1.2

@@ -7,7 +7,7 @@ Host-side restatement of ``pyscf/dft/radi.py``: ``gauss_chebyshev`` (:102-117),
 """
 import numpy as np
 
-from ..gto.mole import BOHR, charge as _charge
+from ..gto.mole import BOHR, element_charge as _charge   # radi.py:166,187: radii of the element behind a ghost label
 
 ATOM_SPECIFIC_TREUTLER_GRIDS = True     # radi.py:37
 

@@ -69,8 +69,35 @@ def _rm_digit(symb):
     return ''.join(c for c in symb if c.isalpha())
 
 
+def is_ghost_atom(symb):
+    """'ghost:H', 'GHOST-H', 'ghost_H', 'X-H', 'X:H', 'GHOST' (pyscf/data/elements.py:is_ghost_atom)."""
+    u = str(symb).upper()
+    return u.startswith('GHOST') or u.startswith(('X-', 'X:', 'X_'))
+
+
+def std_symbol_without_ghost(symb):
+    """Element symbol of an atom label with the ghost prefix and numeric suffix removed
+    (pyscf/data/elements.py:_std_symbol_without_ghost)."""
+    u = str(symb)
+    up = u.upper()
+    if up.startswith('GHOST'):
+        u = u[5:].lstrip(':-_ ')
+    elif up.startswith(('X-', 'X:', 'X_')):
+        u = u[2:]
+    u = _rm_digit(u) or 'X'
+    return u[0].upper() + u[1:].lower()
+
+
 def charge(symb):
+    """Nuclear charge of an atom label; ghost atoms carry basis functions and grids but no charge."""
+    if is_ghost_atom(symb):
+        return 0
     return _CHARGE[_rm_digit(symb).upper()]
+
+
+def element_charge(symb):
+    """Proton number of the element behind a label, ghost or not (what grids and guesses are sized by)."""
+    return _CHARGE[std_symbol_without_ghost(symb).upper()]
 
 
 def load_basis(name, symb):
@@ -81,8 +108,7 @@ def load_basis(name, symb):
         with open(fn) as f:
             _BASIS_DATA = json.load(f)
     key = _ALIAS.get(_format_basis_name(name))
-    el = _rm_digit(symb)
-    el = el[0].upper() + el[1:].lower()
+    el = std_symbol_without_ghost(symb)
     if key is None or el not in _BASIS_DATA[key]:
         raise KeyError('Basis %s not found for %s (packaged table covers H-Ne for: %s)'
                        % (name, symb, ', '.join(sorted(set(_ALIAS)))))
@@ -150,8 +176,10 @@ def make_env(atoms, basis, pre_env):
         symb = atom[0]
         if symb in basdic:
             b = basdic[symb].copy()
-        else:
+        elif _rm_digit(symb) in basdic:
             b = basdic[_rm_digit(symb)].copy()
+        else:
+            b = basdic[std_symbol_without_ghost(symb)].copy()
         b[:, ATOM_OF] = ia
         _bas.append(b)
     atm = np.asarray(np.vstack(_atm), np.int32).reshape(-1, ATM_SLOTS)
@@ -261,8 +289,8 @@ class Mole:
         for symb, b in basis.items():
             if isinstance(b, str):
                 if '\n' in b or re.search(r'\b[SPDFGHI]\b', b):
-                    out[symb] = parse_nwchem.parse(b, _rm_digit(symb)) \
-                        if _rm_digit(symb) in b else parse_nwchem.parse(b)
+                    el = std_symbol_without_ghost(symb)
+                    out[symb] = parse_nwchem.parse(b, el) if el in b else parse_nwchem.parse(b)
                 else:
                     out[symb] = load_basis(b, symb)
             else:
@@ -335,7 +363,10 @@ class Mole:
         return self._atom[ia][0]
 
     def atom_pure_symbol(self, ia):
-        s = _rm_digit(self._atom[ia][0])
+        s = self._atom[ia][0]
+        if is_ghost_atom(s):
+            return 'Ghost-' + std_symbol_without_ghost(s)
+        s = _rm_digit(s)
         return s[0].upper() + s[1:].lower()
 
     def energy_nuc(self):
@@ -345,7 +376,8 @@ class Mole:
         e = 0.0
         for i in range(len(q)):
             for j in range(i):
-                e += q[i] * q[j] / np.linalg.norm(r[i] - r[j])
+                if q[i] != 0 and q[j] != 0:            # ghost atoms may sit on top of anything
+                    e += q[i] * q[j] / np.linalg.norm(r[i] - r[j])
         return e
 
     def tot_electrons(self):

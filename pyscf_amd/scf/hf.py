@@ -372,7 +372,7 @@ def init_guess_by_minao(mol, s1e=None, device=None):
         symb = mol.atom_symbol(ia)
         if symb in basis:
             continue
-        nuc = _mole.charge(symb)
+        nuc = _mole.charge(symb)              # 0 for ghost atoms: basis functions but no atomic density (hf.py:430-436)
         if nuc >= len(NRSRHF_CONFIGURATION):
             raise NotImplementedError('minao guess: element table covers H-Ne')
         ano = _mole.load_basis('ano', symb)

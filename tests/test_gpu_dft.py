@@ -171,3 +171,23 @@ def test_df_uks_b3lyp_cation_vs_oracle_functional():
     f = h1e + vxc + vjt - hyb * vk
     assert np.linalg.norm(mf.get_grad(mf.mo_coeff, mf.mo_occ, f)) < 1e-4
     assert 0.75 < mf.spin_square() < 0.78
+
+
+def test_ghost_atom_df_rks_pbe_reference_energy():
+    """pyscf/dft/test/test_h2o.py:721-784 (test_ghost_dft_grid): H2O + ghost:H, STO-3G, DF-RKS PBE with
+    def2-universal-jkfit, (50,194) grid, three radii-adjust settings; Q-Chem reference -75.2497029684 (2e-5).
+    The only in-tree number that pins the PBE exchange-correlation restatement."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import radi
+    mol = gto.M(atom="""O 0.000000 0.000000 0.000000
+                        H 0.960000 0.000000 0.000000
+                        H -0.240000 0.930000 0.000000
+                        ghost:H -0.240000 -0.310000 0.880000""", basis='sto-3g')
+    assert mol.nelectron == 10 and mol.nao == 8 and mol.atom_charges().tolist() == [8, 1, 1, 0]
+    for adjust in (radi.treutler_atomic_radii_adjust, radi.becke_atomic_radii_adjust, None):
+        mf = dft.RKS(mol, xc='pbe').density_fit(auxbasis='def2-universal-jkfit')
+        mf.grids.atom_grid = (50, 194)
+        mf.grids.radii_adjust = adjust
+        mf.conv_tol = 1e-10
+        e = mf.kernel()
+        assert mf.converged and abs(e - -75.2497029684) < 2e-5, (adjust, e)

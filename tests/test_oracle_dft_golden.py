@@ -83,3 +83,25 @@ def test_uks_cation_energies_exact_jk(xc, e_ref):
     hyb, fac = libxc.parse_xc(xc)
     conv, e = ref_dft.uks_energy(cat, fac, hyb, libxc.xc_type(xc) == 'GGA', coords, weights, ref.int2e(cat), cat.nelec)
     assert conv and abs(e - e_ref) < 2e-8, (e, e_ref)
+
+
+def test_oracle_pbe_pinned_by_ghost_atom_reference():
+    """pyscf/dft/test/test_h2o.py:721-784: DF-RKS PBE / STO-3G / def2-universal-jkfit on H2O + ghost:H, (50,194) grid;
+    reference energy -75.2497029684 (their tolerance 2e-5).  Pins the oracle's PBE exchange and correlation (sympy
+    restatement) and the ghost-atom handling of Mole / grids."""
+    from pyscf_amd import gto, df
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom="""O 0.000000 0.000000 0.000000
+                        H 0.960000 0.000000 0.000000
+                        H -0.240000 0.930000 0.000000
+                        ghost:H -0.240000 -0.310000 0.880000""", basis='sto-3g')
+    assert mol.nelectron == 10 and mol.atom_charges().tolist() == [8, 1, 1, 0]
+    cderi = ref.cholesky_eri(mol, df.make_auxmol(mol, 'def2-universal-jkfit'))
+    coords, weights = ref_dft.build_grids(mol, atom_grid=(50, 194))
+    hyb, fac = libxc.parse_xc('pbe')
+
+    def get_jk(dm, c, occ, with_k):
+        vj, _ = ref.get_jk(cderi, dm, 1, with_k=False)
+        return vj, None
+    conv, e = ref_dft.rks_energy(mol, fac, hyb, True, coords, weights, get_jk, conv_tol=1e-10)[:2]
+    assert conv and abs(e - -75.2497029684) < 2e-5, e
