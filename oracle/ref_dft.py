@@ -13,7 +13,8 @@ Parity status: PINNED through the reference's SCF energies (tests/test_oracle_df
 LDA,VWN_RPA -76.01330948329084; B88,VWN -76.690247578608236; B3LYPG -76.384928891413438
 (pyscf/dft/test/test_h2o.py:95-115), DF B88,VWN -76.690346887915879 (:236-240), grid norms
 (pyscf/dft/test/test_grids.py:54-65).  Pointwise libxc values themselves are not available here.
-PBE is restated but has no golden in the reference tests: "parity unpinned" for PBE.
+PBE: pinned (to the 2e-5 the reference itself uses) by the DF-RKS energy -75.2497029684 of H2O + ghost:H
+(pyscf/dft/test/test_h2o.py:721-784).
 """
 import ctypes
 
@@ -174,7 +175,7 @@ def _build_functionals():
                      - (delta - 11) / 9 * gaa)
           - sp.Rational(2, 3) * rho ** 2 * sigma + 2 * (sp.Rational(2, 3) * rho ** 2 - ra ** 2) * gaa)
     out['lyp'] = t1 - a * b * omega * br
-    # PBE (unpinned)
+    # PBE (pinned through one reference energy, 2e-5)
     kappa, mu = sp.Float('0.804', 20), sp.Float('0.2195149727645171', 20)
     kf = (3 * pi ** 2 * rho) ** sp.Rational(1, 3)
     s2 = sigma / (4 * kf ** 2 * rho ** 2)
