@@ -213,3 +213,36 @@ def test_hermitian_dm_without_orbitals_is_factorized(h2o):
         scale = max(1.0, np.abs(vk0).max())
         assert np.abs(vj1 - vj0).max() < 1e-11 * scale and np.abs(vk1 - vk0).max() < 1e-11 * scale
         assert np.abs(vk2 - vk0).max() < 1e-11 * scale
+
+
+def test_golden_uhf_veff_eight_density_matrices(h2o):
+    """pyscf/df/test/test_df_jk.py:127-133: UHF veff of dm (2, 4, nao, nao), hermi=0: ||vhf|| = 413.82341595365853
+    (V_s = J[D_a + D_b] - K[D_s], pyscf/scf/uhf.py:227-300) - eight DMs through the general branch in one call."""
+    mol, aux, cderi = h2o
+    obj = _dfobj(mol, cderi)
+    np.random.seed(1)
+    dm = np.random.random((2, 4, mol.nao, mol.nao))
+    vj, vk = obj.get_jk(dm.reshape(8, mol.nao, mol.nao), hermi=0)
+    vj = vj.reshape(dm.shape)
+    vk = vk.reshape(dm.shape)
+    vhf = vj[0] + vj[1] - vk
+    assert abs(np.linalg.norm(vhf) - 413.82341595365853) < 1e-8
+
+
+def test_golden_assigned_cderi_from_exact_eri(h2o):
+    """pyscf/df/test/test_df_jk.py:135-142: a tensor assigned by the caller (eigen-factorised exact ERIs, 300 'aux'
+    rows) instead of built: DF-UHF then reproduces the exact energy -76.026765673110447."""
+    import scipy.linalg
+    from pyscf_amd import scf, df
+    mol, aux, cderi = h2o
+    nao = mol.nao
+    eri = ref.int2e(mol)
+    ti, tj = np.tril_indices(nao)
+    eri4 = eri[ti, tj][:, ti, tj]
+    w, u = scipy.linalg.eigh(eri4)
+    idx = w > 1e-9
+    mf = scf.UHF(mol).density_fit(auxbasis='weigend')
+    mf.with_df._cderi = (u[:, idx] * np.sqrt(w[idx])).T.copy()
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    assert mf.converged and abs(e - -76.026765673110447) < 1e-8, e
