@@ -1,0 +1,1 @@
+"""Deterministic benchmark geometries (water clusters of SURVEY.md 8d, benzene)."""
