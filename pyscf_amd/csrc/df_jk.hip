@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(
 template <int WA, bool RHO>
 __global__ __launch_bounds__(256, 2) void e2_sq_kernel(
     const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
-    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho)
+    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk)
 {
     constexpr int M = 2 * WA * 16;
     constexpr int LDM = M + ((M % 32 == 16) ? 0 : 16);
@@ -509,9 +509,11 @@ __global__ __launch_bounds__(256, 2) void e2_sq_kernel(
     __shared__ double sq0[KB * LDN];
     __shared__ double sq1[KB * LDN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int p0 = blockIdx.x * NT;
+    // grid.x = orbital chunk (fastest) + nchunk * AO tile: the workgroups that read the same tensor panel for
+    // different orbital chunks start together, so the panel comes from HBM once and from the Infinity Cache after
+    const int p0 = (blockIdx.x / nchunk) * NT;
     const long L = blockIdx.y;
-    const int m0 = blockIdx.z * M;
+    const int m0 = (blockIdx.x % nchunk) * M;
     const double *src_sq = sq + L * lstride + p0 + lane * 2;
     const double *src_orb = orb + m0 + lane * 2;
     const int wr = wave >> 1, wc = wave & 1;
@@ -766,15 +768,15 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
     const int nchunk = ceil_div(mt_total, 10);
     const int wa = ceil_div(ceil_div(mt_total, nchunk), 2);   // MFMA tiles per wave row; workgroup covers 2 wa tiles
     PAMD_REQUIRE(ldo >= nchunk * wa * 32, "orbital leading dimension too small for tile padding");
-    dim3 grid(ceil_div(ldx, NT), nL, nchunk);
+    dim3 grid(ceil_div(ldx, NT) * nchunk, nL);
 #define LAUNCH_SQ(W)                                                                                            \
     do {                                                                                                        \
         if (d_rho)                                                                                              \
             e2_sq_kernel<W, true><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
-                                                        ldx, d_rho);                                             \
+                                                        ldx, d_rho, nchunk);                                     \
         else                                                                                                    \
             e2_sq_kernel<W, false><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
-                                                         ldx, nullptr);                                          \
+                                                         ldx, nullptr, nchunk);                                  \
     } while (0)
     switch (wa) {
     case 1: LAUNCH_SQ(1); break;
