@@ -38,10 +38,14 @@ def test_golden_jk_fingerprints(h2o):
     assert np.abs(vj1 - vj0).max() < 1e-11 and np.abs(vk1 - vk0).max() < 1e-11
 
 
-def test_mo_branch(h2o):
+@pytest.mark.parametrize('k_square', ['auto', False])
+def test_mo_branch(h2o, k_square):
+    """k_square='auto': half transform on the unpacked image with the first J pass from its epilogue;
+    False: packed-operand half transform and the two-pass J (what a rank without spare HBM runs)."""
     from pyscf_amd import lib
     mol, aux, cderi = h2o
     obj = _dfobj(mol, cderi)
+    obj.k_square = k_square
     rng = np.random.default_rng(7)
     c = np.linalg.qr(rng.standard_normal((mol.nao, mol.nao)))[0]
     occ = np.zeros(mol.nao)
@@ -51,6 +55,7 @@ def test_mo_branch(h2o):
     vj, vk = obj.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=occ), hermi=1)
     assert np.abs(vj - vj0).max() < 1e-11
     assert np.abs(vk - vk0).max() < 1e-11
+    assert (obj._cderi_sq is not None) == (k_square == 'auto')
     # untagged DM takes the general branch and must agree
     vj2, vk2 = obj.get_jk(dm, hermi=1)
     assert np.abs(vk2 - vk0).max() < 1e-11
