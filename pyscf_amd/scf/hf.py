@@ -277,6 +277,8 @@ class SCF:
 
     def density_fit(self, auxbasis=None, with_df=None, only_dfj=False):
         """pyscf/df/df_jk.py:31-105: attach a DF object; J/K are then routed to it."""
+        if only_dfj:
+            raise NotImplementedError('only_dfj (exact 4-centre K beside DF-J, df_jk.py:52-54) is outside the DF J/K path')
         from .. import df
         if with_df is None:
             with_df = df.DF(self.mol, auxbasis)
