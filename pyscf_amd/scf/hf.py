@@ -26,6 +26,16 @@ TIGHT_GRAD_CONV_TOL = True     # hf.py:43
 OVERLAP_ZERO_EIGENVALUE_THRESHOLD = 1e-6   # hf.py:46-47
 
 
+def _eigh_sym(a, device_linalg=True):
+    """Eigen-decomposition of a real symmetric matrix: on the GPU (torch / hipSOLVER) from nao = 512 up, scipy below.
+    Driver-side O(nao^3) algebra, not part of the hot path (the reference uses scipy.linalg.eigh throughout)."""
+    if device_linalg and a.shape[0] >= 512 and _has_device():
+        import torch
+        w, v = torch.linalg.eigh(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+        return w.cpu().numpy(), v.cpu().numpy()
+    return scipy.linalg.eigh(a)
+
+
 def energy_elec(mf, dm=None, h1e=None, vhf=None):
     if dm is None: dm = mf.make_rdm1()
     if h1e is None: h1e = mf.get_hcore()
@@ -200,7 +210,7 @@ class SCF:
 
     def check_linear_dependency(self, s1e):
         """hf.py:1363-1379: x = v[:, e > 1e-6] / sqrt(e) (always returned)."""
-        e, v = scipy.linalg.eigh(s1e)
+        e, v = _eigh_sym(s1e, self.device_linalg)
         mask = e > OVERLAP_ZERO_EIGENVALUE_THRESHOLD
         return v[:, mask] / np.sqrt(e[mask])
 
@@ -399,7 +409,7 @@ def init_guess_by_minao(mol, s1e=None, device=None):
     S = S.cpu().numpy()
     nao = mol.nao_nr()
     s22, s21 = S[:nao, :nao], S[:nao, nao:]
-    e, v = scipy.linalg.eigh(s22)
+    e, v = _eigh_sym(s22)
     mask = e > OVERLAP_ZERO_EIGENVALUE_THRESHOLD
     x = v[:, mask] / np.sqrt(e[mask])
     mo = x.dot(x.T.dot(s21))
