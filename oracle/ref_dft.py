@@ -380,6 +380,33 @@ def _build_functionals_pol():
           - sp.Rational(2, 3) * rho ** 2 * sig + (sp.Rational(2, 3) * rho ** 2 - ra ** 2) * sbb
           + (sp.Rational(2, 3) * rho ** 2 - rb ** 2) * saa)
     out['lyp'] = -a * 4 / den * ra * rb / rho - a * b * omega * br
+    # PBE (Perdew, Burke, Ernzerhof, PRL 77, 3865): exchange by the spin-scaling relation, correlation with the
+    # PW92 ("pw_mod" digits) uniform-gas energy e_c(rs, zeta), phi(zeta) and H(rs, zeta, t)
+    kappa, mu = F('0.804'), F('0.2195149727645171')
+    cx_u = sp.Rational(3, 4) * (3 / pi) ** sp.Rational(1, 3)
+
+    def pbex_unpol(r, s_):
+        kf = (3 * pi ** 2 * r) ** sp.Rational(1, 3)
+        s2 = s_ / (4 * kf ** 2 * r ** 2)
+        return -cx_u * r ** sp.Rational(4, 3) * (1 + kappa - kappa / (1 + mu / kappa * s2))
+    out['pbex'] = (pbex_unpol(2 * ra, 4 * saa) + pbex_unpol(2 * rb, 4 * sbb)) / 2
+    rs = (3 / (4 * pi * rho)) ** sp.Rational(1, 3)
+
+    def pw_g(A, a1, b1, b2, b3, b4):
+        q = 2 * A * (b1 * sp.sqrt(rs) + b2 * rs + b3 * rs ** sp.Rational(3, 2) + b4 * rs ** 2)
+        return -2 * A * (1 + a1 * rs) * sp.log(1 + 1 / q)
+    e0 = pw_g(*[F(x) for x in ('0.0310907', '0.21370', '7.5957', '3.5876', '1.6382', '0.49294')])
+    e1 = pw_g(*[F(x) for x in ('0.01554535', '0.20548', '14.1189', '6.1977', '3.3662', '0.62517')])
+    mac = pw_g(*[F(x) for x in ('0.0168869', '0.11125', '10.357', '3.6231', '0.88026', '0.49671')])
+    fz20 = F('1.709920934161365617563962776245')
+    ec = e0 - mac * fz / fz20 * (1 - zeta ** 4) + (e1 - e0) * fz * zeta ** 4
+    beta_c, gamma_c = F('0.06672455060314922'), (1 - sp.log(2)) / pi ** 2
+    phi = ((1 + zeta) ** sp.Rational(2, 3) + (1 - zeta) ** sp.Rational(2, 3)) / 2
+    kf = (3 * pi ** 2 * rho) ** sp.Rational(1, 3)
+    t2 = sig / (4 * phi ** 2 * (4 * kf / pi) * rho ** 2)
+    Aa = beta_c / gamma_c / (sp.exp(-ec / (gamma_c * phi ** 3)) - 1)
+    H = gamma_c * phi ** 3 * sp.log(1 + beta_c / gamma_c * t2 * (1 + Aa * t2) / (1 + Aa * t2 + Aa ** 2 * t2 ** 2))
+    out['pbec'] = rho * (ec + H)
     fns = {}
     v = (ra, rb, saa, sab, sbb)
     for k, e in out.items():
@@ -388,13 +415,10 @@ def _build_functionals_pol():
 
 
 def eval_xc_pol(fac, ra, rb, saa, sab, sbb):
-    """-> e, (vra, vrb, vsaa, vsab, vsbb).  Components: slater, vwn5, vwnrpa, b88, lyp (PBE not restated
-    spin-polarised)."""
+    """-> e, (vra, vrb, vsaa, vsab, vsbb) for the component weights fac[7] (order of _ORDER)."""
     global _FUNCS_POL
     if _FUNCS_POL is None:
         _FUNCS_POL = _build_functionals_pol()
-    if fac[5] != 0 or fac[6] != 0:
-        raise NotImplementedError('spin-polarised PBE')
     n = len(ra)
     e = np.zeros(n)
     dv = [np.zeros(n) for _ in range(5)]
@@ -402,7 +426,7 @@ def eval_xc_pol(fac, ra, rb, saa, sab, sbb):
     args = [np.maximum(ra[ok], 1e-30), np.maximum(rb[ok], 1e-30), np.maximum(saa[ok], 1e-300), sab[ok],
             np.maximum(sbb[ok], 1e-300)]
     # sympy symbols are declared positive; sab may be negative: shift-free evaluation is fine numerically
-    for w, name in zip(fac[:5], _ORDER[:5]):
+    for w, name in zip(fac, _ORDER):
         if w == 0:
             continue
         f = _FUNCS_POL[name]

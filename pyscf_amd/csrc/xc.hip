@@ -299,6 +299,51 @@ __device__ inline D5 lyp_pol(D5 ra, D5 rb, D5 saa, D5 sab, D5 sbb)
     return -a * 4.0 / den * rab / rho - a * b * omega * br;
 }
 
+// PBE exchange of one spin channel: E_x[rho_a, rho_b] = (E_x[2 rho_a] + E_x[2 rho_b]) / 2 (spin-scaling relation)
+__device__ inline D5 pbe_x_spin(D5 r, D5 s)
+{
+    const double kappa = 0.804, mu = 0.2195149727645171;
+    const double cx = 0.75 * 0.98474502184269654;     // (3/4)(3/pi)^(1/3)
+    D5 rho = 2.0 * r, sigma = 4.0 * s;
+    D5 ex_lda = -cx * pow5(rho, 4.0 / 3.0);
+    D5 kf = pow5(3.0 * PI * PI * rho, 1.0 / 3.0);
+    D5 s2 = sigma / (4.0 * kf * kf * rho * rho);
+    D5 fx = 1.0 + kappa - kappa / (1.0 + mu / kappa * s2);
+    return 0.5 * ex_lda * fx;
+}
+// Perdew-Wang 1992 G function, "pw_mod" digits (the variant PBE is built on)
+__device__ inline D5 pw92_g5(D5 rs, double A, double a1, double b1, double b2, double b3, double b4)
+{
+    D5 srs = sqrt5(rs);
+    D5 q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
+    return -2.0 * A * (1.0 + a1 * rs) * log5(1.0 + 1.0 / q);
+}
+// PBE correlation for a spin-polarised density (Perdew, Burke, Ernzerhof 1996, eqs. 3-8)
+__device__ inline D5 pbe_c_pol(D5 rho, D5 zeta, D5 sigma)
+{
+    const double beta = 0.06672455060314922, gamma = 0.031090690869654895;
+    const double fz20 = 1.709920934161365617563962776245;
+    D5 rs = pow5(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
+    D5 e0 = pw92_g5(rs, 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+    D5 e1 = pw92_g5(rs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+    D5 mac = pw92_g5(rs, 0.0168869, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);      // -alpha_c
+    D5 f = fzeta5(zeta);
+    D5 z4 = zeta * zeta * zeta * zeta;
+    D5 ec = e0 - mac * f / fz20 * (1.0 - z4) + (e1 - e0) * f * z4;
+    D5 p = 1.0 + zeta, m = 1.0 - zeta;
+    if (p.v < 1e-14) p.v = 1e-14;
+    if (m.v < 1e-14) m.v = 1e-14;
+    D5 phi = 0.5 * (pow5(p, 2.0 / 3.0) + pow5(m, 2.0 / 3.0));
+    D5 phi3 = phi * phi * phi;
+    D5 kf = pow5(3.0 * PI * PI * rho, 1.0 / 3.0);
+    D5 ks2 = 4.0 * kf / PI;
+    D5 t2 = sigma / (4.0 * phi * phi * ks2 * rho * rho);
+    D5 Aa = beta / gamma / (exp5(-ec / (gamma * phi3)) - 1.0);
+    D5 num = 1.0 + Aa * t2;
+    D5 H = gamma * phi3 * log5(1.0 + beta / gamma * t2 * num / (1.0 + Aa * t2 + Aa * Aa * t2 * t2));
+    return rho * (ec + H);
+}
+
 // rho_a / rho_b [4][ldg]; wv_a / wv_b [4][ldg]: wv_s0 = 0.5 w vrho_s, wv_s(1..3) = w (2 vsigma_ss grad rho_s +
 // vsigma_ab grad rho_other)  (pyscf/dft/numint.py:1192-1324, xc_deriv.transform_vxc for spin = 1)
 // acc[0] += sum w rho_a, acc[1] += sum w rho_b, acc[2] += sum w e
@@ -333,6 +378,8 @@ __global__ __launch_bounds__(256) void eval_xc_pol_kernel(XCSpec spec, int gga, 
             if (spec.fac[F_VWNRPA] != 0) tot = tot + spec.fac[F_VWNRPA] * vwnrpa_pol(rho, zeta);
             if (spec.fac[F_B88] != 0) tot = tot + spec.fac[F_B88] * (b88_spin(Ra, Saa) + b88_spin(Rb, Sbb));
             if (spec.fac[F_LYP] != 0) tot = tot + spec.fac[F_LYP] * lyp_pol(Ra, Rb, Saa, Sab, Sbb);
+            if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * (pbe_x_spin(Ra, Saa) + pbe_x_spin(Rb, Sbb));
+            if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c_pol(rho, zeta, Saa + 2.0 * Sab + Sbb);
             exc = w * tot.v;
             for (int k = 0; k < 5; k++) dv[k] = tot.d[k];
         }
@@ -569,13 +616,12 @@ int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double 
     return 0;
 }
 
-// spin-polarised variant (numint.nr_uks): fac7 must not contain PBE terms (not restated spin-polarised)
+// spin-polarised variant (numint.nr_uks)
 int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
                      const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,
                      void *stream)
 {
     if (ng == 0) return 0;
-    PAMD_REQUIRE(fac7[F_PBEX] == 0 && fac7[F_PBEC] == 0, "spin-polarised PBE is not implemented");
     XCSpec spec;
     for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
     eval_xc_pol_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho_a, d_rho_b, d_weights,

@@ -406,8 +406,6 @@ class NumInt:
         natm = mol.natm
         if xctype == 'HF':
             return np.zeros((natm, 3))
-        if fac[5] != 0 or fac[6] != 0:
-            raise NotImplementedError('spin-polarised PBE')
         gga = 1 if xctype == 'GGA' else 0
         nao = mol.nao_nr()
         ldao = _round_up(nao, 16)

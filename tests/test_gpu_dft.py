@@ -116,7 +116,7 @@ def test_df_rks_b3lyp_vs_oracle():
     assert conv and abs(e - e0) < 1e-8, (e, e0)
 
 
-@pytest.mark.parametrize('xc', ['lda,vwn', 'lda,vwn_rpa', 'b88,lyp', 'b3lyp'])
+@pytest.mark.parametrize('xc', ['lda,vwn', 'lda,vwn_rpa', 'b88,lyp', 'b3lyp', 'pbe,pbe', 'pbe0'])
 def test_nr_uks_vs_oracle(xc):
     """Spin-polarised nr_uks (both branches) vs the oracle whose functionals are pinned by the UKS goldens."""
     from pyscf_amd import gto, dft, lib
@@ -191,3 +191,21 @@ def test_ghost_atom_df_rks_pbe_reference_energy():
         mf.conv_tol = 1e-10
         e = mf.kernel()
         assert mf.converged and abs(e - -75.2497029684) < 2e-5, (adjust, e)
+
+
+def test_uks_pbe_closed_shell_limit_equals_rks():
+    """Spin-polarised PBE at rho_a = rho_b must reproduce the closed-shell PBE (the one pinned by the reference's
+    ghost-atom energy): nr_uks(D/2, D/2) vs nr_rks(D)."""
+    from pyscf_amd import gto, dft
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    grids = dft.Grids(mol)
+    grids.atom_grid = (30, 110)
+    grids.build()
+    rng = np.random.default_rng(11)
+    c = np.linalg.qr(rng.standard_normal((mol.nao, mol.nao)))[0] * 0.7
+    dm = 2 * c[:, :5].dot(c[:, :5].T)
+    ni = dft.NumInt()
+    n0, e0, v0 = ni.nr_rks(mol, grids, 'pbe,pbe', dm)
+    n1, e1, v1 = ni.nr_uks(mol, grids, 'pbe,pbe', (dm * .5, dm * .5))
+    assert abs(e1 - e0) < 1e-11 * abs(e0) and abs(n1.sum() - n0) < 1e-10
+    assert np.abs(v1[0] - v0).max() < 1e-10 and np.abs(v1[1] - v0).max() < 1e-10

@@ -144,7 +144,7 @@ def test_df_rks_gradient_golden_and_fd():
     assert abs(g[0, 2] - fd) < 2e-5, (g[0, 2], fd)
 
 
-@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp'])
+@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe'])
 def test_nr_uks_grad_vs_oracle(xc):
     """Spin-polarised XC gradient against the numpy restatement of pyscf/grad/uks.py:get_vxc."""
     from pyscf_amd import gto, dft
