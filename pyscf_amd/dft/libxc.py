@@ -30,26 +30,52 @@ _XC = {
 
 
 def parse_xc(description):
-    """-> (hyb, fac[7]).  Grammar subset of libxc.parse_xc: 'X,C' with '+'-separated, optionally
-    'w*name'-weighted terms, or a single compound name."""
+    """-> (hyb, fac[7]); see parse_xc_rsh for the range-separated exact-exchange terms."""
+    hyb, alpha, omega, fac = parse_xc_rsh(description)
+    return hyb, fac
+
+
+def parse_xc_rsh(description):
+    """-> (hyb, alpha, omega, fac[7]).  Grammar subset of libxc.parse_xc (:496-720): 'X,C' with '+'-separated,
+    optionally 'w*name'-weighted terms, or a single compound name; exact exchange as 'HF' (full range: counts for
+    hyb and alpha), 'SR_HF(omega)' (hyb only) and 'LR_HF(omega)' (alpha only), so that
+    K = hyb K_full + (alpha - hyb) K_LR(omega)   (pyscf/dft/rks.py:110-127)."""
     name = description.upper().replace(' ', '')
     fac = np.zeros(7)
     hyb = 0.0
+    alpha = 0.0
+    omega = 0.0
 
     def add(table, token, allow_compound):
-        nonlocal hyb
+        nonlocal hyb, alpha, omega
         w = 1.0
         if '*' in token:
-            a, token = token.split('*')
-            w = float(a)
+            a, b = token.split('*')
+            try:
+                w, token = float(a), b
+            except ValueError:
+                w, token = float(b), a
         if token in ('', 'NONE'):
             return
         if token == 'HF':
             hyb += w
+            alpha += w
+            return
+        if token.startswith(('SR_HF', 'LR_HF')):
+            if '(' in token:
+                om = float(token[token.index('(') + 1:token.index(')')])
+                if omega not in (0.0, om):
+                    raise ValueError('different values of omega in one functional')
+                omega = om
+            if token.startswith('SR_HF'):
+                hyb += w
+            else:
+                alpha += w
             return
         if allow_compound and token in _XC and token not in table:
             h, comps = _XC[token]
             hyb += w * h
+            alpha += w * h
             for k, v in comps.items():
                 fac[k] += w * v
             return
@@ -70,7 +96,9 @@ def parse_xc(description):
                 add({}, t, True)
             else:
                 add(_X, t, True)
-    return hyb, fac
+    if omega == 0.0:
+        alpha = hyb                      # no range separation: one full-range coefficient
+    return hyb, alpha, omega, fac
 
 
 def xc_type(description):
@@ -85,8 +113,14 @@ def hybrid_coeff(description, spin=0):
 
 
 def rsh_coeff(description):
-    return 0.0, 0.0, 0.0
+    """(omega, alpha, beta) with hyb = alpha + beta: alpha weights the long-range, hyb the short-range exact exchange
+    (pyscf/dft/libxc.py rsh_coeff)."""
+    hyb, alpha, omega, _ = parse_xc_rsh(description)
+    if omega == 0.0:
+        return 0.0, 0.0, 0.0
+    return omega, alpha, hyb - alpha
 
 
 def is_hybrid_xc(description):
-    return hybrid_coeff(description) != 0
+    hyb, alpha, omega, _ = parse_xc_rsh(description)
+    return hyb != 0 or (omega != 0 and alpha != 0)

@@ -26,13 +26,17 @@ def get_veff(ks, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
     ks._log('nelec by numeric integration = %s; vxc %.4f s', n, time.perf_counter() - t0)
     omega, alpha, hyb = ni.rsh_and_hybrid_coeff(ks.xc, spin=mol.spin)
     t0 = time.perf_counter()
-    if hyb == 0:
+    if hyb == 0 and (omega == 0 or alpha == 0):
         vk = None
         vj, _ = ks.get_jk(mol, dm, hermi, with_k=False)
         vxc = vxc + vj
     else:
         vj, vk = ks.get_jk(mol, dm, hermi)
         vk = vk * hyb
+        if omega != 0:
+            # range-separated exact exchange: K = hyb K_full + (alpha - hyb) K_LR(omega)   (rks.py:110-127)
+            vklr = ks.get_jk(mol, dm, hermi, with_j=False, omega=omega)[1]
+            vk = vk + vklr * (alpha - hyb)
         vxc = vxc + vj - vk * .5
         exc -= np.einsum('ij,ji', dm, vk).real * .5 * .5
     ks._log('df vj and vk: %.4f s', time.perf_counter() - t0)

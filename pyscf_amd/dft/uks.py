@@ -29,7 +29,7 @@ class UKS(uhf.UHF):
         self._log('nelec by numeric integration = %s; vxc %.4f s', n, time.perf_counter() - t0)
         omega, alpha, hyb = ni.rsh_and_hybrid_coeff(self.xc, spin=mol.spin)
         dma = np.asarray(dm)
-        if hyb == 0:
+        if hyb == 0 and (omega == 0 or alpha == 0):
             vk = None
             vj, _ = self.get_jk(mol, dm, hermi, with_k=False)
             vj = vj[0] + vj[1]
@@ -38,6 +38,9 @@ class UKS(uhf.UHF):
             vj, vk = self.get_jk(mol, dm, hermi)
             vj = vj[0] + vj[1]
             vk = vk * hyb
+            if omega != 0:                 # K = hyb K_full + (alpha - hyb) K_LR(omega)   (uks.py:90-105)
+                vklr = self.get_jk(mol, dm, hermi, with_j=False, omega=omega)[1]
+                vk = vk + vklr * (alpha - hyb)
             vxc = vxc + vj - vk
             exc -= (np.einsum('ij,ji', dma[0], vk[0]) + np.einsum('ij,ji', dma[1], vk[1])).real * .5
         ecoul = np.einsum('ij,ji', dma[0] + dma[1], vj).real * .5

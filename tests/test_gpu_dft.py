@@ -209,3 +209,17 @@ def test_uks_pbe_closed_shell_limit_equals_rks():
     n1, e1, v1 = ni.nr_uks(mol, grids, 'pbe,pbe', (dm * .5, dm * .5))
     assert abs(e1 - e0) < 1e-11 * abs(e0) and abs(n1.sum() - n0) < 1e-10
     assert np.abs(v1[0] - v0).max() < 1e-10 and np.abs(v1[1] - v0).max() < 1e-10
+
+
+def test_golden_rsh_custom_functional_energy():
+    """pyscf/df/test/test_df.py:135-147: HF molecule, cc-pVDZ, DF-RKS with xc = 'lda+0.5*SR_HF(0.3)':
+    E = -103.4965622991 (6 places).  Slater exchange plus half of the short-range exact exchange,
+    K_SR = K_full - K_LR(0.3) from the Coulomb and the erf-attenuated tensors."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import libxc
+    assert libxc.parse_xc_rsh('lda+0.5*SR_HF(0.3)')[:3] == (0.5, 0.0, 0.3)
+    assert libxc.rsh_coeff('lda+0.5*SR_HF(0.3)') == (0.3, 0.0, 0.5)
+    mol = gto.M(atom='H 0 0 0; F 0 0 1.1', basis='ccpvdz')
+    mf = dft.RKS(mol, xc='lda+0.5*SR_HF(0.3)').density_fit()
+    e = mf.kernel()
+    assert mf.converged and abs(e - -103.4965622991) < 2e-6, e
