@@ -27,6 +27,13 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix peak (vendor spec; 256 CU 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def _aux_label(b):
+    if isinstance(b, dict):
+        names = sorted({v if isinstance(v, str) else 'even-tempered' for v in b.values()})
+        return '/'.join(names)
+    return str(b)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -223,7 +230,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
         'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': '(H2O)_%d %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM%s'
-                               % (args.nwater, args.basis, str(getattr(dfobj.auxmol, 'basis', 'auto')),
+                               % (args.nwater, args.basis, _aux_label(getattr(dfobj.auxmol, 'basis', 'auto')),
                                   nao, naux, nocc, 8e-9 * naux * npair,
                                   ' + unpacked image for the K half transform' if getattr(dfobj, '_cderi_sq', None) is not None else ''),
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',

@@ -159,3 +159,25 @@ def test_grad_host_pieces():
     import re
     pos = [re.search(r'[ \*]%s;' % n, body).start() for n in names]
     assert pos == sorted(pos), 'field order of _GradArgs differs from the header'
+
+
+def test_aux_basis_selection_and_even_tempered_generation():
+    """pyscf/df/test/test_addons.py:28-41,73-101: aug_etb shell counts (USE_VERSION_26_AUXBASIS branch), make_auxbasis per
+    atom label incl. ghost atoms and mixed AO bases, even-tempered fallback when no JK-fit set is tabulated."""
+    from pyscf_amd import gto, df
+    from pyscf_amd.df import addons
+    mol = gto.M(atom='O 0 0 0; 1 0 -0.757 0.587; 1 0 0.757 0.587', basis='cc-pvdz')
+    etb = addons.aug_etb(mol)
+    assert len(etb['O']) == 36 and len(etb['H']) == 12
+    assert addons.expand_etbs([(1, 3, 1.5, 2)]) == [[1, [6.0, 1]], [1, [3.0, 1]], [1, [1.5, 1]]]
+    mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587; GHOST-H 0 0 0.587', basis='cc-pvdz')
+    ab = addons.make_auxbasis(mol)
+    assert ab == {'O': 'cc-pvdz-jkfit', 'H': 'cc-pvdz-jkfit', 'GHOST-H': 'cc-pvdz-jkfit'}
+    assert df.make_auxmol(mol).nao_nr() == 116 + 23 and mol.nelectron == 10
+    mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis={'O': 'cc-pvdz', 'H': 'cc-pvtz'})
+    assert addons.make_auxbasis(mol) == {'O': 'cc-pvdz-jkfit', 'H': 'cc-pvtz-jkfit'}
+    mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis='ano')      # no tabulated fitting set
+    ab = addons.make_auxbasis(mol)
+    assert all(isinstance(v, list) for v in ab.values())
+    aux = df.make_auxmol(mol)
+    assert aux.nao_nr() > mol.nao_nr() and int(aux._bas[:, 1].max()) <= 4
