@@ -285,17 +285,26 @@ class Mole:
                 full = {a: d for a in uniq}
                 full.update(basis)
                 basis = full
-        out = {}
-        for symb, b in basis.items():
+        def one(b, symb):
+            """name | NWChem text | [[l, [e, c...], ...], ...] | tuple of those (concatenated, mole.py:440-470)."""
             if isinstance(b, str):
                 if '\n' in b or re.search(r'\b[SPDFGHI]\b', b):
                     el = std_symbol_without_ghost(symb)
-                    out[symb] = parse_nwchem.parse(b, el) if el in b else parse_nwchem.parse(b)
-                else:
-                    out[symb] = load_basis(b, symb)
-            else:
-                # internal format: sort by l (mole.py:463-469)
-                out[symb] = sorted([list(x) for x in b], key=lambda x: x[0])
+                    return parse_nwchem.parse(b, el) if el in b else parse_nwchem.parse(b)
+                return load_basis(b, symb)
+            b = list(b)
+            if b and isinstance(b[0], (int, np.integer)):          # a single raw shell [l, (e, c), ...]
+                return [[b[0]] + [list(x) for x in b[1:]]]
+            if b and all(isinstance(x, (list, tuple)) and x and isinstance(x[0], (int, np.integer)) for x in b):
+                return [[x[0]] + [list(y) if not isinstance(y, (int, np.integer)) else y for y in x[1:]] for x in b]
+            shells = []
+            for part in b:
+                shells += one(part, symb)
+            return shells
+        out = {}
+        for symb, b in basis.items():
+            # sorted by l, stable (mole.py:463-469)
+            out[symb] = sorted(one(b, symb), key=lambda x: x[0])
         return out
 
     def copy(self, deep=True):

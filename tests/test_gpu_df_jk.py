@@ -251,3 +251,18 @@ def test_golden_assigned_cderi_from_exact_eri(h2o):
     mf.conv_tol = 1e-10
     e = mf.kernel()
     assert mf.converged and abs(e - -76.026765673110447) < 1e-8, e
+
+
+def test_lindep_metric_eig_fallback_reference_case():
+    """pyscf/df/test/test_incore.py:171-179: an auxiliary basis with every H function listed twice makes the metric
+    exactly singular; the eigen-decomposition fallback (lindep 1e-7, df/incore.py:153-158,263-270) must give the same
+    fitted integrals cderi^T cderi as the non-redundant basis."""
+    from pyscf_amd import gto, df
+    mol = gto.M(atom=[('O', (0., 0., 0.)), ('H', (0., -0.757, 0.587)), ('H', (0., 0.757, 0.587))], basis='cc-pvdz')
+    out = []
+    for auxbasis in ('weigend', {'O': 'weigend', 'H': ('weigend', 'weigend')}):
+        obj = df.DF(mol, auxbasis)
+        obj.build()
+        out.append(obj.get_eri())
+    assert out[0].shape == out[1].shape
+    assert np.abs(out[0] - out[1]).max() < 1e-9
