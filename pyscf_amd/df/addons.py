@@ -6,7 +6,8 @@ from ..gto import mole as _mole
 DEFAULT_AUXBASIS = {
     'ccpvdz': 'cc-pvdz-jkfit', 'ccpvtz': 'cc-pvtz-jkfit',
     'def2svp': 'def2-svp-jkfit', 'def2tzvp': 'def2-tzvp-jkfit',
-    'sto3g': 'def2-svp-jkfit', '631g': 'cc-pvdz-jkfit',
+    'sto3g': 'def2-svp-jkfit', '631g': 'cc-pvdz-jkfit', '321g': 'def2-svp-jkfit', '6311g': 'cc-pvtz-jkfit',
+    'augccpvdz': 'aug-cc-pvdz-jkfit', 'augccpvtz': 'aug-cc-pvtz-jkfit',
 }
 
 

@@ -57,6 +57,11 @@ _ALIAS = {
     'def2svpjfit': 'def2universaljfit', 'def2tzvpjfit': 'def2universaljfit',
     'weigend': 'def2universaljfit', 'weigendjfit': 'def2universaljfit',
     'weigendcfit': 'def2universaljfit', 'weigendjkfit': 'def2universaljkfit',
+    'ccpvqz': 'ccpvqz', 'augccpvdz': 'augccpvdz', 'augccpvtz': 'augccpvtz',
+    'augccpvdzjkfit': 'augccpvdzjkfit', 'augccpvtzjkfit': 'augccpvtzjkfit', 'ccpvtzri': 'ccpvtzri',
+    '321g': '321g', '631gs': '631gs', '631g*': '631gs', '631g(d)': '631gs',
+    '631gss': '631gss', '631g**': '631gss', '631g(d,p)': '631gss',
+    '6311g': '6311g', '6311gss': '6311gss', '6311g**': '6311gss', '6311g(d,p)': '6311gss',
 }
 
 

@@ -223,3 +223,16 @@ def test_golden_rsh_custom_functional_energy():
     mf = dft.RKS(mol, xc='lda+0.5*SR_HF(0.3)').density_fit()
     e = mf.kernel()
     assert mf.converged and abs(e - -103.4965622991) < 2e-6, e
+
+
+def test_golden_eval_gto_fingerprints():
+    """pyscf/gto/test/test_eval_gto.py:51-62 on the device: GTOval and GTOval_ip of H2 / cc-pVQZ at 100 seeded points
+    (lib.fp = -3.0283379087553808 and -14.526634330008513)."""
+    from pyscf_amd import gto, dft
+    mol = gto.M(atom='H 0. 0. 0.; H 8. 0. 0.', basis='ccpvqz')
+    np.random.seed(1)
+    r = np.random.random((100, 3)) * 2
+    ao = dft.NumInt().eval_ao(mol, r, deriv=1)
+    assert ao.shape == (4, 100, 60)
+    assert abs(ref.fp(ao[0]) - -3.0283379087553808) < 1e-10
+    assert abs(ref.fp(ao[1:]) - -14.526634330008513) < 1e-9

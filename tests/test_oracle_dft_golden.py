@@ -105,3 +105,16 @@ def test_oracle_pbe_pinned_by_ghost_atom_reference():
         return vj, None
     conv, e = ref_dft.rks_energy(mol, fac, hyb, True, coords, weights, get_jk, conv_tol=1e-10)[:2]
     assert conv and abs(e - -75.2497029684) < 2e-5, e
+
+
+def test_oracle_eval_ao_reference_fingerprints():
+    """pyscf/gto/test/test_eval_gto.py:25-32,51-62: H2 (8 Bohr... 8 A apart) cc-pVQZ (s-f shells), 100 seeded points:
+    lib.fp(GTOval) = -3.0283379087553808, lib.fp(GTOval_ip) = -14.526634330008513."""
+    from pyscf_amd import gto
+    mol = gto.M(atom='H 0. 0. 0.; H 8. 0. 0.', basis='ccpvqz')
+    assert mol.nao == 60
+    np.random.seed(1)
+    r = np.random.random((100, 3)) * 2
+    ao = ref_dft.eval_ao(mol, r, 1)
+    assert abs(ref.fp(ao[0]) - -3.0283379087553808) < 1e-11
+    assert abs(ref.fp(ao[1:]) - -14.526634330008513) < 1e-10
