@@ -123,7 +123,7 @@ int PAMD_df_vj_pass1(const double *d_cderi, long npair, int naux, const double *
 int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *d_rho, int nset,
                      double *d_vjtril, void *stream);                     /* vjtril[s] += rho_s^T B  */
 int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
-                    int orb_rows, int nocc_pad, double *d_out, int ldx, void *stream);
+                    int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, void *stream);
 /* the same contraction on the unpacked image sq[nL][rows][ld] (PAMD_unpack_tril into a zeroed buffer, rows = ld =
  * round_up(nao,16)): both operands stream by LDS-DMA; spends 2x the packed size of HBM to take the symmetric unpack out
  * of the hot loop.  d_orb as for PAMD_nr_e2_symm with ldo >= chunks * 32 * wa (pyscf_amd/df/df_jk.py:pad_orbitals) */

@@ -138,7 +138,7 @@ template <int MT, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
     const double *__restrict__ cderi, long npair, int nao, const double *__restrict__ orb, int ldo,
     double *__restrict__ X, int nocc_pad, long ldx, long src_stride, long ncols,
-    const unsigned char *__restrict__ kmask)
+    const unsigned char *__restrict__ kmask, double *__restrict__ rho)
 {
     constexpr int MW = MT * 16;                         // orbitals per workgroup
     constexpr int LDA = MW + ((MW % 32 == 16) ? 0 : 16);  // == 16 mod 32
@@ -234,8 +234,11 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
         __syncthreads();
         q0 = qn;
     }
-    // ---- store: D[m = (lane>>4)+4r][n = lane&15]
+    // ---- store: D[m = (lane>>4)+4r][n = lane&15]; rho (symmetric mode, nullable): rho[L] += sum_{i,p} X[L][i][p] orb[p][i],
+    // the first J pass of the density orb orb^T (see e2_sq_kernel)
     double *out = X + (long)L * nocc_pad * ldx;
+    const bool do_rho = !PLAIN && rho != nullptr;
+    double rho_acc = 0;
 #pragma unroll
     for (int a = 0; a < MT; a++)
 #pragma unroll
@@ -245,9 +248,17 @@ __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 int i = m0 + a * 16 + fk + 4 * r;
-                if (i < nocc_pad) out[(long)i * ldx + p] = acc[a][b][r];
+                if (i < nocc_pad) {
+                    out[(long)i * ldx + p] = acc[a][b][r];
+                    if (do_rho && p < nao) rho_acc += acc[a][b][r] * orb[p * ldo + i];
+                }
             }
         }
+    if (do_rho) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rho_acc += __shfl_xor(rho_acc, off, 64);
+        if (lane == 0) unsafeAtomicAdd(rho + L, rho_acc);
+    }
 }
 
 // C[split][m][n] += sum_{k in split range} A[k][m] * B[k][n]
@@ -715,8 +726,9 @@ int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *
 //   d_orb   [orb_rows][ldo] row-major, columns >= norb zero-padded up to nocc_pad (multiple of 16);
 //           orb_rows >= nao allocated rows (rows >= nao zero) - round_up(nao,16) enables the LDS-DMA kernel
 //   d_out   [nL][nocc_pad][ldx]
+//   d_rho   (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] (first J pass of the density orb orb^T)
 int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
-                    int orb_rows, int nocc_pad, double *d_out, int ldx, void *stream)
+                    int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, void *stream)
 {
     PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
     PAMD_REQUIRE(ldx >= nao, "ldx < nao");
@@ -728,7 +740,7 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     // the kernel writes rows i < nocc_pad only; chunks are mt*16 wide
     dim3 grid(ceil_div(ldx, NT), nL, nchunk);
 #define LAUNCH_E2(MT)                                                                         \
-    e2_symm_kernel<MT, false><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx, 0, 0, nullptr)
+    e2_symm_kernel<MT, false><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx, 0, 0, nullptr, d_rho)
     // orbital tile reads m0+i < ldo must stay in bounds: require ldo >= nchunk*mt*16
     PAMD_REQUIRE(ldo >= nchunk * mt * 16, "orbital leading dimension too small for tile padding");
     switch (mt) {
@@ -807,7 +819,7 @@ int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, lo
     PAMD_REQUIRE(ldo >= nchunk * mt * 16, "orbital leading dimension too small for tile padding");
     dim3 grid(ceil_div(nrows, NT), ny, nchunk);
 #define LAUNCH_P(MT)                                                                          \
-    e2_symm_kernel<MT, true><<<grid, 256, 0, st>>>(d_src, lds, kdim, d_orb, ldo, d_out, nocc_pad, ldout, src_stride, nrows, d_kmask)
+    e2_symm_kernel<MT, true><<<grid, 256, 0, st>>>(d_src, lds, kdim, d_orb, ldo, d_out, nocc_pad, ldout, src_stride, nrows, d_kmask, nullptr)
     switch (mt) {
     case 1: LAUNCH_P(1); break;
     case 2: LAUNCH_P(2); break;

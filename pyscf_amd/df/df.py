@@ -289,7 +289,8 @@ class DF:
             X = torch.zeros((nb, ni_pad, ldx), dtype=torch.float64, device=dev)
             df_jk._call(self, 'e2_symm', so.PAMD_nr_e2_symm, _c.c_void_p(cderi[b0:b0 + nb].data_ptr()), _c.c_long(npair),
                         _c.c_int(nb), _c.c_int(nao), _c.c_void_p(orb.data_ptr()), _c.c_int(ldo),
-                        _c.c_int(orb.shape[0]), _c.c_int(ni_pad), _c.c_void_p(X.data_ptr()), _c.c_int(ldx), st)
+                        _c.c_int(orb.shape[0]), _c.c_int(ni_pad), _c.c_void_p(X.data_ptr()), _c.c_int(ldx),
+                        _c.c_void_p(0), st)
             y = torch.matmul(X[:, :ni, :nao], cj_dev).reshape(nb, ni * nj)      # second index: plain library GEMM
             out[b0:b0 + nb] = y[:, sel] if same else y
         return out

@@ -179,7 +179,7 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
             else:
                 _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
                       _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
-                      _c.c_int(ldx), st)
+                      _c.c_int(ldx), _ptr(fuse_j[iset][b0:]) if fuse_j is not None else _c.c_void_p(0), st)
             if after_e2 is not None:
                 after_e2(b0, nb, iset)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
@@ -217,7 +217,7 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
             nb = min(blk, naux - b0)
             sub = cderi[b0:b0 + nb]
             _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
-                  _ptr(orb), _c.c_int(ldo), _c.c_int(rows), _c.c_int(rows), _ptr(X), _c.c_int(ldx), st)
+                  _ptr(orb), _c.c_int(ldo), _c.c_int(rows), _c.c_int(rows), _ptr(X), _c.c_int(ldx), _c.c_void_p(0), st)
             _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
                                                 _ptr(full), _c.c_int(ldx), _c.c_int(rows), st)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(full), _c.c_int(ldx), _ptr(part),
@@ -309,7 +309,7 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
                 holder = {}
 
                 sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
-                fused = (sq is not None and len(orb_list) == nset and all(o[1] > 0 for o in orb_list) and
+                fused = (len(orb_list) == nset and all(o[1] > 0 for o in orb_list) and
                          getattr(dfobj, 'fuse_j_pass1', True))
                 if fused:
                     # the epilogue sum is the first J pass only for D_s = orb_s orb_s^T (what make_rdm1 tags): verify

@@ -101,7 +101,7 @@ def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, low):
             X = torch.zeros((nb, nocc_pad, ldx), dtype=f64, device=dev)
             df_jk._call(dfobj, 'e2_symm', so.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
                         _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
-                        _c.c_int(ldx), st)
+                        _c.c_int(ldx), _c.c_void_p(0), st)
             y = torch.matmul(X[:, :nocc, :nao], c_dev)           # y_L,ij = (C^T B_L C)_ij
             ys[b0:b0 + nb] = y.reshape(nb, -1)
             cyc = torch.matmul(c_dev, torch.matmul(y, c_dev.T))  # C y_L C^T
