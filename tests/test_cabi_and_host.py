@@ -181,3 +181,23 @@ def test_aux_basis_selection_and_even_tempered_generation():
     assert all(isinstance(v, list) for v in ab.values())
     aux = df.make_auxmol(mol)
     assert aux.nao_nr() > mol.nao_nr() and int(aux._bas[:, 1].max()) <= 4
+
+
+def test_xc_description_parser():
+    """Host-side functional parser (subset of pyscf/dft/libxc.py:parse_xc): component weights in the kernel's order
+    {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C}, hybrid and range-separation coefficients."""
+    from pyscf_amd.dft import libxc
+    hyb, fac = libxc.parse_xc('b3lyp')                      # id 402: VWN_RPA flavour (libxc.py:175)
+    assert hyb == 0.2 and np.allclose(fac, [0.08, 0, 0.19, 0.72, 0.81, 0, 0])
+    assert np.allclose(libxc.parse_xc('b3lyp5')[1], [0.08, 0.19, 0, 0.72, 0.81, 0, 0])
+    assert np.allclose(libxc.parse_xc('lda,vwn')[1], libxc.parse_xc('SLATER , VWN5')[1])
+    assert np.allclose(libxc.parse_xc('LDA,VWN')[1], [1, 1, 0, 0, 0, 0, 0]) and libxc.xc_type('lda,vwn') == 'LDA'
+    assert libxc.xc_type('b88,lyp') == 'GGA' and libxc.xc_type('hf') == 'HF'
+    assert np.allclose(libxc.parse_xc('pbe0')[1], [0, 0, 0, 0, 0, 0.75, 1]) and libxc.parse_xc('pbe0')[0] == 0.25
+    assert np.allclose(libxc.parse_xc('0.5*b88+0.5*lda,lyp')[1], [0.5, 0, 0, 0.5, 1, 0, 0])
+    assert libxc.parse_xc_rsh('lda+0.5*SR_HF(0.3)')[:3] == (0.5, 0.0, 0.3)
+    assert libxc.rsh_coeff('lda+0.5*SR_HF(0.3)') == (0.3, 0.0, 0.5)
+    assert libxc.rsh_coeff('b3lyp') == (0.0, 0.0, 0.0) and libxc.is_hybrid_xc('b3lyp') and not libxc.is_hybrid_xc('pbe')
+    assert libxc.parse_xc_rsh('0.2*LR_HF(0.4)+b88,lyp')[:3] == (0.0, 0.2, 0.4) and libxc.is_hybrid_xc('0.2*LR_HF(0.4)+b88,lyp')
+    with pytest.raises(NotImplementedError):
+        libxc.parse_xc('scan')
