@@ -140,17 +140,6 @@ class NumInt:
             _lib_mod.check(fn(*args))
 
     # -- value-based screening (the role of non0tab / pair_mask, numint.py:2845, eval_gto.py:146+) -------
-    def _tile_flags(self, src, ld, total_rows):
-        """uint8 [total_rows/16][ld/16]: 16 x 16 tiles of src[total_rows][ld] holding an element > cutoff
-        (stand-alone pass; the AO flags come fused out of PAMD_eval_ao instead)."""
-        import torch
-        lib = _lib_mod.load_library()
-        flags = torch.empty((total_rows // 16, ld // 16), dtype=torch.uint8, device=src.device)
-        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
-        self._call('tile_mask', lib.PAMD_tile_mask, _ptr(src), _c.c_long(ld), _c.c_long(total_rows),
-                   _c.c_double(self.screen_cutoff), _ptr(flags), st)
-        return flags
-
     def _vmat_use_masks(self, mpanel, ng):
         """Screen the vmat GEMM only if the product of the two panel-tile densities leaves enough k-tiles out."""
         rows = (ng + 15) // 16
