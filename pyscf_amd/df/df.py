@@ -43,9 +43,9 @@ class DF:
         self.k_square = 'auto'
         self.k_square_reserve = 48 << 30     # HBM left free after the copy (X block, partial K, XC blocks, ...)
         self._cderi_sq = None
-        self.fuse_j_pass1 = True
-        self.overlap_split = True
-        self.factorize_hermitian_dm = True
+        self.fuse_j_pass1 = True            # MO branch: first J pass from the half transform's epilogue
+        self.overlap_split = True           # two-pass J: pass 1 / pass 2 behind the first / second SYRK block
+        self.factorize_hermitian_dm = True  # hermi=1 DMs without orbitals: eigen-factorise, use the MO kernels
         self.kernel_timer = None   # df_jk.KernelTimer() to collect per-kernel HIP-event timings
         self._ws = {}
 
