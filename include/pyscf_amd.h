@@ -175,11 +175,18 @@ int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double 
 /* spin-polarised variant for nr_uks (dft/numint.py:1192-1324): d_acc3 = {nelec_a, nelec_b, exc} */
 int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
                      const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,
-                     void *stream);
+                     double *d_evol /* nullable: energy density per volume */, void *stream);
 /* XC nuclear gradient of one grid block (pyscf/grad/rks.py:197-255 get_vxc/_gga_grad_sum_/_make_dR_dao_w contracted with
  * the density on the fly): d_out[3][nao] += sum_g {...}, d_c[k][g][mu] = sum_nu ao_k[g][nu] D[nu][mu] */
 int PAMD_xc_grad(const double *d_ao, const double *d_c, const double *d_wv, int ldao, long ldg_rows, long ldg,
                  int gga, long ng, int nao, double *d_out, void *stream);
+/* grid response of the XC gradient (pyscf/grad/rks.py:257-340 get_vxc_full_response): per-point row sums of the same
+ * integrand (the points' own motion) and the Becke weight derivatives contracted with the energy density */
+int PAMD_xc_grad_rows(const double *d_ao, const double *d_c, const double *d_wv, int ldao, long ldg_rows, long ldg,
+                      int gga, long ng, int nao, double *d_rows, void *stream);
+int PAMD_becke_response(const double *d_coords, const int *d_owner, const double *d_weights, const double *d_e,
+                        const double *d_pb, const double *d_atm_coords, const double *d_radii_table, int natm,
+                        long ng, double *d_out, void *stream);
 int PAMD_scale_ao(const double *d_ao, const double *d_wv, int ldao, long ldg_rows, long ldg, int ncomp,
                   long ng, long nrows, double *d_aow, void *stream);     /* aow[g][ldao], rows ng..nrows-1 zero */
 int PAMD_dgemm_nt(const double *d_A, long lda, const double *d_B, long ldb, double *d_C, int ldc, int m,

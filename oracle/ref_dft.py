@@ -44,6 +44,65 @@ def becke_partition(coords, atm_coords, radii_table):
     return pb
 
 
+def becke_weight_response(coords, owner, weights, atm_coords, radii_table):
+    """dw[natm][3][ngrids] = d w_g / d R_C of the Becke quadrature weights, the grid point moving rigidly with its
+    owner atom (restatement of pyscf/grad/rks.py:grids_response_cc / get_vxc_full_response weight1; formulas of
+    Johnson, Gill, Pople, JCP 98, 5612).  For C != owner the point is fixed:
+        d ln P_B / dR_C = sum_{D != B} g_BD d mu_BD/dR_C,   g_BD = -p3'(nu_BD) (1 - 2 a_BD mu_BD) / (2 f_BD),
+        d w / dR_C = w [ d ln P_owner/dR_C - sum_B (P_B / Z) d ln P_B/dR_C ];
+    the owner's own derivative follows from translational invariance."""
+    natm = len(atm_coords)
+    ng = len(coords)
+    vec = coords[None, :, :] - atm_coords[:, None, :]                          # [natm][ng][3]
+    d = np.linalg.norm(vec, axis=2) + 1e-200
+    uhat = vec / d[:, :, None]
+    f = np.ones((natm, natm, ng))
+    gfac = np.zeros((natm, natm, ng))
+    mu = np.zeros((natm, natm, ng))
+    for b in range(natm):
+        for dd in range(natm):
+            if b == dd:
+                continue
+            rbd = np.linalg.norm(atm_coords[b] - atm_coords[dd])
+            m = (d[b] - d[dd]) / rbd
+            a = 0.0 if radii_table is None else radii_table[b, dd]
+            nu = m + a * (1 - m * m)
+            p1 = (3 - nu * nu) * nu * .5
+            p2 = (3 - p1 * p1) * p1 * .5
+            p3 = (3 - p2 * p2) * p2 * .5
+            dp3 = 1.5 * (1 - p2 * p2) * 1.5 * (1 - p1 * p1) * 1.5 * (1 - nu * nu)
+            f[b, dd] = .5 * (1 - p3)
+            gfac[b, dd] = -.5 * dp3 * (1 - 2 * a * m) / (f[b, dd] + 1e-200)
+            mu[b, dd] = m
+    P = np.prod(f, axis=1)                                                      # [natm][ng]
+    Z = P.sum(axis=0)
+    dw = np.zeros((natm, 3, ng))
+    for c in range(natm):
+        dlnP = np.zeros((natm, ng, 3))
+        for b in range(natm):
+            if b == c:
+                for dd in range(natm):
+                    if dd == c:
+                        continue
+                    n_cd = atm_coords[c] - atm_coords[dd]
+                    rcd = np.linalg.norm(n_cd)
+                    dmu = -uhat[c] / rcd - mu[c, dd][:, None] * (n_cd / rcd)[None, :] / rcd     # d mu_CD / dR_C
+                    dlnP[c] += gfac[c, dd][:, None] * dmu
+            else:
+                n_bc = atm_coords[b] - atm_coords[c]
+                rbc = np.linalg.norm(n_bc)
+                dmu = uhat[c] / rbc + mu[b, c][:, None] * (n_bc / rbc)[None, :] / rbc           # d mu_BC / dR_C
+                dlnP[b] = gfac[b, c][:, None] * dmu
+        avg = np.einsum('bg,bgx->gx', P / Z, dlnP)
+        own = dlnP[owner, np.arange(ng)]
+        dw[c] = (weights[:, None] * (own - avg)).T
+    fixed = dw.copy()
+    for a in range(natm):
+        sel = owner == a
+        dw[a][:, sel] = -(fixed.sum(axis=0) - fixed[a])[:, sel]
+    return dw
+
+
 def build_grids(mol, atom_grid=None, radi_method=None, prune='nwchem', radii_adjust='treutler', level=3,
                 sort_grids=True, alignment=8):
     """coords, weights (host).  Atomic (radial x Lebedev) tables come from the host-side generator
@@ -281,11 +340,10 @@ def eval_ao_hess(mol, coords, h=1e-4):
     return out
 
 
-def nr_rks_grad(mol, coords, weights, fac, gga, dm):
-    """XC nuclear gradient (natm, 3) without grid response: numpy restatement of pyscf/grad/rks.py get_vxc
-    (:119-195) + the contraction de[A] = 2 sum_{mu on A, nu} vmat[x]_{mu nu} D_{mu nu} of grad/rhf.py:80-84,
-    with vmat[x] = -(nabla_x ao)^T (wv0 ao) for LDA and _gga_grad_sum_ / _make_dR_dao_w (:197-255) for GGA."""
-    dm = (dm + dm.T) * .5
+def _vmat_grad(mol, coords, weights, fac, gga, dm):
+    """(vmat[3][nao][nao], e[g]): the derivative matrices of pyscf/grad/rks.py get_vxc (:119-195; vmat[x] =
+    -(nabla_x ao)^T (wv0 ao) for LDA, _gga_grad_sum_ / _make_dR_dao_w :197-255 for GGA) on the given points, and the
+    XC energy density per unit volume at those points."""
     ao = eval_ao(mol, coords, 1)
     c0 = ao[0].dot(dm)
     rho = np.einsum('gi,gi->g', ao[0], c0)
@@ -312,12 +370,35 @@ def nr_rks_grad(mol, coords, weights, fac, gga, dm):
             vmat[x] = ao[1 + x].T.dot(aow)
             aow2 = ao[1 + x] * wv[0][:, None] + np.einsum('kgi,kg->gi', hess[x], wv[1:])
             vmat[x] += aow2.T.dot(ao[0])
-    vmat = -vmat
+    return -vmat, e
+
+
+def nr_rks_grad(mol, coords, weights, fac, gga, dm):
+    """XC nuclear gradient (natm, 3) without grid response: numpy restatement of pyscf/grad/rks.py get_vxc
+    (:119-195) + the contraction de[A] = 2 sum_{mu on A, nu} vmat[x]_{mu nu} D_{mu nu} of grad/rhf.py:80-84."""
+    dm = (dm + dm.T) * .5
+    vmat, _ = _vmat_grad(mol, coords, weights, fac, gga, dm)
     aoslices = mol.aoslice_by_atom()
     de = np.zeros((mol.natm, 3))
     for ia in range(mol.natm):
         p0, p1 = aoslices[ia][2], aoslices[ia][3]
         de[ia] = 2 * np.einsum('xij,ij->x', vmat[:, p0:p1], dm[p0:p1])
+    return de
+
+
+def nr_rks_grad_response(mol, coords, weights, owner, radii_table, fac, gga, dm):
+    """The two grid-response terms of pyscf/grad/rks.py get_vxc_full_response (:257-340) to be added to nr_rks_grad:
+    sum_g e_g dw_g/dR_C (Becke weights follow the nuclei) and, for the points owned by atom C, the motion of the point
+    itself: -2 sum_{mu nu} vmat_C[x]_{mu nu} D_{mu nu} with vmat_C restricted to C's points."""
+    dm = (dm + dm.T) * .5
+    de = np.zeros((mol.natm, 3))
+    _, e = _vmat_grad(mol, coords, weights, fac, gga, dm)
+    dw = becke_weight_response(coords, owner, weights, mol.atom_coords(), radii_table)
+    de += np.einsum('g,cxg->cx', e, dw)
+    for ia in range(mol.natm):
+        sel = owner == ia
+        vmat_c, _ = _vmat_grad(mol, coords[sel], weights[sel], fac, gga, dm)
+        de[ia] -= 2 * np.einsum('xij,ij->x', vmat_c, dm)
     return de
 
 

@@ -40,6 +40,93 @@ __global__ __launch_bounds__(256) void becke_kernel(double *__restrict__ out, co
     }
 }
 
+// Grid response of the Becke weights contracted with a per-point scalar e[g] (the XC energy density per volume):
+//   out[C][x] += sum_g e[g] d w_g / d R_C,x        (pyscf/grad/rks.py get_vxc_full_response: excsum += exc rho weight1)
+// the point moving rigidly with its owner atom.  For C != owner (point fixed)
+//   d w/dR_C = w [ d ln P_own/dR_C - sum_B (P_B/Z) d ln P_B/dR_C ],
+//   d ln P_B/dR_C = [B != C] g_BC dmu_BC/dR_C + [B == C] sum_{D != C} g_CD dmu_CD/dR_C,
+//   g_BD = -p3'(nu_BD) (1 - 2 a_BD mu_BD) / (2 f_BD),  f_BD = (1 - p3(nu_BD))/2,  nu = mu + a (1 - mu^2),
+// and the owner's derivative is minus the sum over the other atoms (translational invariance).
+// One thread per grid point, O(natm^2) pair terms recomputed on the fly; P_B/Z from the partition kernel's output.
+__device__ inline void becke_pair(double dB, double dD, double rBD, double a, double &mu, double &gfac)
+{
+    mu = (dB - dD) / rBD;
+    const double nu = mu + a * (1 - mu * mu);
+    const double p1 = (3 - nu * nu) * nu * .5;
+    const double p2 = (3 - p1 * p1) * p1 * .5;
+    const double p3 = (3 - p2 * p2) * p2 * .5;
+    const double dp3 = 3.375 * (1 - p2 * p2) * (1 - p1 * p1) * (1 - nu * nu);
+    const double f = .5 * (1 - p3);
+    gfac = -.5 * dp3 * (1 - 2 * a * mu) / (f + 1e-200);
+}
+
+__global__ __launch_bounds__(256) void becke_response_kernel(
+    const double *__restrict__ coords, const int *__restrict__ owner, const double *__restrict__ weights,
+    const double *__restrict__ e, const double *__restrict__ pb, const double *__restrict__ atm,
+    const double *__restrict__ radii, int natm, long ng, double *__restrict__ out)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = g < ng;
+    const long gg = valid ? g : 0;
+    const double x = coords[gg * 3], y = coords[gg * 3 + 1], z = coords[gg * 3 + 2];
+    const int own = owner[gg];
+    const double we = valid ? weights[gg] * e[gg] : 0.0;
+    double zsum = 0;
+    for (int b = 0; b < natm; b++) zsum += pb[(long)b * ng + gg];
+    const double zinv = 1.0 / (zsum + 1e-300);
+    double acc_own[3] = {0, 0, 0};
+    __shared__ double red[4][3];
+    for (int c = 0; c < natm; c++) {
+        const double cx = atm[c * 3], cy = atm[c * 3 + 1], cz = atm[c * 3 + 2];
+        const double ucx = x - cx, ucy = y - cy, ucz = z - cz;
+        const double dC = sqrt(ucx * ucx + ucy * ucy + ucz * ucz) + 1e-200;
+        const double uhx = ucx / dC, uhy = ucy / dC, uhz = ucz / dC;
+        double ownt[3] = {0, 0, 0}, avg[3] = {0, 0, 0}, self[3] = {0, 0, 0};
+        for (int b = 0; b < natm; b++) {
+            if (b == c) continue;
+            const double bx = atm[b * 3], by = atm[b * 3 + 1], bz = atm[b * 3 + 2];
+            const double dB = sqrt((x - bx) * (x - bx) + (y - by) * (y - by) + (z - bz) * (z - bz));
+            const double nx = bx - cx, ny = by - cy, nz = bz - cz;             // R_B - R_C
+            const double rbc = sqrt(nx * nx + ny * ny + nz * nz);
+            const double rinv = 1.0 / rbc;
+            // B's cell function seen from C: d mu_BC / dR_C = u_C / R + mu_BC n_BC / R^2
+            double mu, gf;
+            becke_pair(dB, dC, rbc, radii ? radii[b * natm + c] : 0.0, mu, gf);
+            const double tbx = gf * (uhx * rinv + mu * nx * rinv * rinv);
+            const double tby = gf * (uhy * rinv + mu * ny * rinv * rinv);
+            const double tbz = gf * (uhz * rinv + mu * nz * rinv * rinv);
+            const double wb = pb[(long)b * ng + gg] * zinv;
+            avg[0] += wb * tbx; avg[1] += wb * tby; avg[2] += wb * tbz;
+            if (b == own) { ownt[0] = tbx; ownt[1] = tby; ownt[2] = tbz; }
+            // C's own cell function: d mu_CB / dR_C = -u_C / R - mu_CB n_CB / R^2, n_CB = R_C - R_B = -n
+            becke_pair(dC, dB, rbc, radii ? radii[c * natm + b] : 0.0, mu, gf);
+            self[0] += gf * (-uhx * rinv + mu * nx * rinv * rinv);
+            self[1] += gf * (-uhy * rinv + mu * ny * rinv * rinv);
+            self[2] += gf * (-uhz * rinv + mu * nz * rinv * rinv);
+        }
+        const double wc = pb[(long)c * ng + gg] * zinv;
+        double v[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            v[k] = (c == own) ? 0.0 : we * (ownt[k] - avg[k] - wc * self[k]);
+            acc_own[k] -= v[k];
+        }
+        // block reduction of the contribution to atom c
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = v[0]; red[threadIdx.x >> 6][1] = v[1]; red[threadIdx.x >> 6][2] = v[2]; }
+        __syncthreads();
+        if (threadIdx.x < 3)
+            atomicAdd(out + c * 3 + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+    // owner: minus the sum over the other atoms (different owners within the block: per-thread atomics)
+    if (valid && we != 0.0)
+#pragma unroll
+        for (int k = 0; k < 3; k++) atomicAdd(out + own * 3 + k, acc_own[k]);
+}
+
 constexpr int AO_LMAX = 4;
 constexpr int AO_NC = (AO_LMAX + 1) * (AO_LMAX + 2) / 2;
 
@@ -229,6 +316,20 @@ int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_
     if (ngrids == 0) return 0;
     becke_kernel<<<ceil_div(ngrids, 256), 256, 0, (hipStream_t)stream>>>(d_out, d_coords, d_atm_coords,
                                                                          d_radii_table, natm, ngrids);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// d_out[natm][3] += sum_g e[g] d w_g/dR: weight response of the Becke partition (points follow their owner atoms);
+// d_pb[natm][ng] from PAMD_becke_partition on the same points, d_owner[ng] atom index of every point, d_e[ng] per-point
+// scalar (XC energy per volume).  pyscf/grad/rks.py:257-340 (get_vxc_full_response, grids_response_cc).
+int PAMD_becke_response(const double *d_coords, const int *d_owner, const double *d_weights, const double *d_e,
+                        const double *d_pb, const double *d_atm_coords, const double *d_radii_table, int natm,
+                        long ng, double *d_out, void *stream)
+{
+    if (ng == 0 || natm == 0) return 0;
+    becke_response_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(d_coords, d_owner, d_weights, d_e, d_pb,
+                                                                              d_atm_coords, d_radii_table, natm, ng, d_out);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

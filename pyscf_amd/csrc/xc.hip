@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void eval_xc_pol_kernel(XCSpec spec, int gga, 
                                                           const double *__restrict__ rho_b,
                                                           const double *__restrict__ weights, long ng, long ldg,
                                                           double *__restrict__ wv_a, double *__restrict__ wv_b,
-                                                          double *__restrict__ acc)
+                                                          double *__restrict__ acc, double *__restrict__ evol_out)
 {
     long g = (long)blockIdx.x * 256 + threadIdx.x;
     double na = 0, nb = 0, exc = 0;
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256) void eval_xc_pol_kernel(XCSpec spec, int gga, 
             exc = w * tot.v;
             for (int k = 0; k < 5; k++) dv[k] = tot.d[k];
         }
+        if (evol_out) evol_out[g] = (w != 0.0) ? exc / w : 0.0;      // energy density per unit volume
         wv_a[g] = 0.5 * w * dv[0];
         wv_b[g] = 0.5 * w * dv[1];
         if (gga)
@@ -513,6 +514,39 @@ __global__ __launch_bounds__(256) void xc_grad_kernel(const double *__restrict__
     atomicAdd(out + 2 * nao + m, sz);
 }
 
+// Per-point row sums of the same integrand: rows[x][g] = sum_mu { d_x ao_mu (w0 c0 + sum_k w_k c_k) + (sum_k w_k d_x d_k ao_mu) c0 }
+// (the motion of a grid point with its owner atom, pyscf/grad/rks.py:303-318: excsum[atom] += 2 vtmp . dm on the
+// atom's own points).  One workgroup per point and 256 AO columns.
+__global__ __launch_bounds__(256) void xc_grad_rows_kernel(const double *__restrict__ ao, const double *__restrict__ c,
+                                                           const double *__restrict__ wv, int ldao, long ldg_rows,
+                                                           long ldg, int gga, long ng, int nao, double *__restrict__ rows)
+{
+    const int m = blockIdx.y * 256 + threadIdx.x;
+    const long g = blockIdx.x;                           // grid.x: up to 2^31 points per block
+    double s[3] = {0, 0, 0};
+    if (m < nao) {
+        const long cs = ldg_rows * ldao;
+        const long o = g * ldao + m;
+        const double w0 = 2 * wv[g];
+        const double c0 = c[o];
+        double t = w0 * c0;
+        if (gga) {
+            const double w1 = wv[ldg + g], w2 = wv[2 * ldg + g], w3 = wv[3 * ldg + g];
+            t += w1 * c[cs + o] + w2 * c[2 * cs + o] + w3 * c[3 * cs + o];
+            s[0] = (w1 * ao[4 * cs + o] + w2 * ao[5 * cs + o] + w3 * ao[6 * cs + o]) * c0;
+            s[1] = (w1 * ao[5 * cs + o] + w2 * ao[7 * cs + o] + w3 * ao[8 * cs + o]) * c0;
+            s[2] = (w1 * ao[6 * cs + o] + w2 * ao[8 * cs + o] + w3 * ao[9 * cs + o]) * c0;
+        }
+        s[0] += ao[cs + o] * t; s[1] += ao[2 * cs + o] * t; s[2] += ao[3 * cs + o] * t;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off, 64);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 3; k++) atomicAdd(rows + k * ldg + g, s[k]);
+}
+
 // C[m][n] += sum_k A[m][k] B[n][k]   (both operands k-contiguous), split-K over gridDim.y
 constexpr int KB = 16, NT = 128, LDT = KB + 1;
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const double *__restrict__ A, long lda,
@@ -617,15 +651,16 @@ int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double 
 }
 
 // spin-polarised variant (numint.nr_uks)
+// d_evol (nullable) [ng]: XC energy density per unit volume (for the grid-response term of the gradient)
 int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
                      const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,
-                     void *stream)
+                     double *d_evol, void *stream)
 {
     if (ng == 0) return 0;
     XCSpec spec;
     for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
     eval_xc_pol_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho_a, d_rho_b, d_weights,
-                                                                           ng, ldg, d_wv_a, d_wv_b, d_acc3);
+                                                                           ng, ldg, d_wv_a, d_wv_b, d_acc3, d_evol);
     PAMD_CHECK_LAUNCH();
     return 0;
 }
@@ -670,6 +705,18 @@ int PAMD_xc_grad(const double *d_ao, const double *d_c, const double *d_wv, int 
     const long rows = 512;
     dim3 grid(ceil_div(nao, 256), ceil_div(ng, rows));
     xc_grad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_ao, d_c, d_wv, ldao, ldg_rows, ldg, gga, ng, nao, rows, d_out);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// d_rows[3][ldg] += per-point sums over the AO index of the XC gradient integrand (grid-response term of the points'
+// own motion); same operands as PAMD_xc_grad
+int PAMD_xc_grad_rows(const double *d_ao, const double *d_c, const double *d_wv, int ldao, long ldg_rows, long ldg,
+                      int gga, long ng, int nao, double *d_rows, void *stream)
+{
+    if (ng == 0 || nao == 0) return 0;
+    dim3 grid(ng, ceil_div(nao, 256));
+    xc_grad_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_ao, d_c, d_wv, ldao, ldg_rows, ldg, gga, ng, nao, d_rows);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

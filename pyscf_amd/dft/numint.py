@@ -16,6 +16,7 @@ GEMMs) instead of being stored; with several ranks the grid blocks are dealt rou
 vmat / nelec / exc are all-reduced.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -138,6 +139,10 @@ class NumInt:
             _lib_mod.check(self.kernel_timer.call(name, fn, *args))
         else:
             _lib_mod.check(fn(*args))
+        if os.environ.get('PAMD_SYNC_DEBUG'):          # debugging aid: surface a device fault at the launch that caused it
+            import torch
+            torch.cuda.synchronize()
+            print('[numint] %s ok' % name, flush=True)
 
     # -- value-based screening (the role of non0tab / pair_mask, numint.py:2845, eval_gto.py:146+) -------
     def _vmat_use_masks(self, mpanel, ng):
@@ -320,7 +325,7 @@ class NumInt:
             return nelec[0], excsum[0], vmat[0]
         return nelec, excsum, vmat.reshape(shape)
 
-    def nr_rks_grad(self, mol, grids, xc_code, dm):
+    def nr_rks_grad(self, mol, grids, xc_code, dm, grid_response=False):
         """XC part of the closed-shell nuclear gradient, (natm, 3), grid response left out: the contraction
         -2 sum_{mu on A, nu} vmat[x]_{mu nu} D_{mu nu} of pyscf/grad/rks.py:get_vxc (:197-255; _d1_dot_,
         _gga_grad_sum_, _make_dR_dao_w) done per grid block on the device without forming vmat[x]."""
@@ -350,6 +355,7 @@ class NumInt:
         wv = torch.empty((4, blk), dtype=f64, device=dev)
         acc = torch.zeros(2, dtype=f64, device=dev)
         out = torch.zeros((3, nao), dtype=f64, device=dev)
+        resp = self._response_setup(mol, grids, dev, blk) if grid_response else None
         d_h = np.zeros((nao, ldao))
         d_h[:, :nao] = (np.asarray(dm) + np.asarray(dm).T) * .5
         dsym = torch.from_numpy(d_h).to(dev)
@@ -368,9 +374,13 @@ class NumInt:
                 for k in range(1, 4):
                     rho[k, :ng] = 2 * (ao[k, :ng] * c[0, :ng]).sum(dim=1)
             self._call('eval_xc', lib.PAMD_eval_xc, fac_c, _c.c_int(gga), _ptr(rho), _ptr(weights_dev[g0:g0 + ng]),
-                       _c.c_long(ng), _c.c_long(blk), _ptr(wv), _c.c_void_p(0), _ptr(acc), st)
+                       _c.c_long(ng), _c.c_long(blk), _ptr(wv), _ptr(resp['exc']) if resp else _c.c_void_p(0),
+                       _ptr(acc), st)
             self._call('xc_grad', lib.PAMD_xc_grad, _ptr(ao), _ptr(c), _ptr(wv), _c.c_int(ldao), _c.c_long(blk),
                        _c.c_long(blk), _c.c_int(gga), _c.c_long(ng), _c.c_int(nao), _ptr(out), st)
+            if resp:
+                resp['evol'][:ng] = resp['exc'][:ng] * rho[0, :ng]             # per particle -> per volume
+                self._response_block(resp, coords_dev, weights_dev, g0, ng, [(ao, c, wv)], gga, ldao, blk, nao, st)
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(out, group=self.group)
@@ -380,9 +390,57 @@ class NumInt:
         for ia in range(natm):
             p0, p1 = aoslices[ia][2], aoslices[ia][3]
             de[ia] = -2 * s[:, p0:p1].sum(axis=1)
+        if resp:
+            de += self._response_finish(resp, world)
         return de
 
-    def nr_uks_grad(self, mol, grids, xc_code, dms):
+    # -- grid response of the XC gradient (pyscf/grad/rks.py:257-340) -------------------------------------------
+    def _response_setup(self, mol, grids, dev, blk):
+        import torch
+        natm = mol.natm
+        owner = np.zeros(grids.size, np.int32)
+        owner[:len(grids.atm_idx)] = grids.atm_idx                    # alignment padding: weight 0, any owner
+        table = None
+        if callable(grids.radii_adjust) and grids.atomic_radii is not None:
+            table = grids.radii_adjust(mol, grids.atomic_radii)
+        f64 = torch.float64
+        return dict(natm=natm, owner=torch.from_numpy(owner).to(dev),
+                    atm=torch.from_numpy(np.ascontiguousarray(mol.atom_coords())).to(dev),
+                    table=None if table is None else torch.from_numpy(np.ascontiguousarray(table)).to(dev),
+                    pb=torch.empty((natm, blk), dtype=f64, device=dev), exc=torch.zeros(blk, dtype=f64, device=dev),
+                    evol=torch.zeros(blk, dtype=f64, device=dev), rows=torch.zeros((3, blk), dtype=f64, device=dev),
+                    de_w=torch.zeros((natm, 3), dtype=f64, device=dev), de_move=torch.zeros((natm, 3), dtype=f64, device=dev))
+
+    def _response_block(self, resp, coords_dev, weights_dev, g0, ng, operands, gga, ldao, blk, nao, st):
+        """Weight-derivative term (PAMD_becke_response) and the points' own motion (PAMD_xc_grad_rows, summed per owner
+        atom) for grid points [g0, g0 + ng); operands = [(ao, c, wv)] per spin."""
+        lib = _lib_mod.load_library()
+        natm = resp['natm']
+        pbv = resp['pb'].view(-1)[:natm * ng].view(natm, ng)
+        tptr = _ptr(resp['table']) if resp['table'] is not None else _c.c_void_p(0)
+        self._call('becke', lib.PAMD_becke_partition, _ptr(pbv), _ptr(coords_dev[g0:g0 + ng]), _ptr(resp['atm']), tptr,
+                   _c.c_int(natm), _c.c_long(ng), st)
+        self._call('becke_response', lib.PAMD_becke_response, _ptr(coords_dev[g0:g0 + ng]), _ptr(resp['owner'][g0:g0 + ng]),
+                   _ptr(weights_dev[g0:g0 + ng]), _ptr(resp['evol']), _ptr(pbv), _ptr(resp['atm']), tptr,
+                   _c.c_int(natm), _c.c_long(ng), _ptr(resp['de_w']), st)
+        resp['rows'].zero_()
+        for ao, c, wv in operands:
+            self._call('xc_grad_rows', lib.PAMD_xc_grad_rows, _ptr(ao), _ptr(c), _ptr(wv), _c.c_int(ldao), _c.c_long(blk),
+                       _c.c_long(blk), _c.c_int(gga), _c.c_long(ng), _c.c_int(nao), _ptr(resp['rows']), st)
+        # per-owner sums as a small dense product (torch's index_add_ faults on this ROCm build for ng > ~30 k)
+        import torch
+        own = resp['owner'][g0:g0 + ng].long()
+        onehot = (own[:, None] == torch.arange(natm, device=own.device)[None, :]).to(torch.float64)
+        resp['de_move'] += onehot.T @ resp['rows'][:, :ng].T
+
+    def _response_finish(self, resp, world):
+        tot = resp['de_w'] + 2 * resp['de_move']
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(tot, group=self.group)
+        return tot.cpu().numpy()
+
+    def nr_uks_grad(self, mol, grids, xc_code, dms, grid_response=False):
         """Spin-polarised XC nuclear gradient (natm, 3), grid response left out (pyscf/grad/uks.py:get_vxc
         :100-190 contracted with (D_alpha, D_beta)); same device pipeline as nr_rks_grad, two spin passes per block."""
         import torch
@@ -411,6 +469,8 @@ class NumInt:
         wv = torch.empty((2, 4, blk), dtype=f64, device=dev)
         acc = torch.zeros(3, dtype=f64, device=dev)
         out = torch.zeros((3, nao), dtype=f64, device=dev)
+        resp = self._response_setup(mol, grids, dev, blk) if grid_response else None
+        evol = resp['evol'] if resp else None
         dsym = []
         for s in range(2):
             d_h = np.zeros((nao, ldao))
@@ -433,10 +493,13 @@ class NumInt:
                         rho[s, k, :ng] = 2 * (ao[k, :ng] * c[s, 0, :ng]).sum(dim=1)
             self._call('eval_xc', lib.PAMD_eval_xc_pol, fac_c, _c.c_int(gga), _ptr(rho[0]), _ptr(rho[1]),
                        _ptr(weights_dev[g0:g0 + ng]), _c.c_long(ng), _c.c_long(blk), _ptr(wv[0]), _ptr(wv[1]),
-                       _ptr(acc), st)
+                       _ptr(acc), _ptr(evol) if evol is not None else _c.c_void_p(0), st)
             for s in range(2):
                 self._call('xc_grad', lib.PAMD_xc_grad, _ptr(ao), _ptr(c[s]), _ptr(wv[s]), _c.c_int(ldao), _c.c_long(blk),
                            _c.c_long(blk), _c.c_int(gga), _c.c_long(ng), _c.c_int(nao), _ptr(out), st)
+            if resp:
+                self._response_block(resp, coords_dev, weights_dev, g0, ng, [(ao, c[0], wv[0]), (ao, c[1], wv[1])], gga,
+                                     ldao, blk, nao, st)
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(out, group=self.group)
@@ -446,6 +509,8 @@ class NumInt:
         for ia in range(natm):
             p0, p1 = aoslices[ia][2], aoslices[ia][3]
             de[ia] = -2 * sv[:, p0:p1].sum(axis=1)
+        if resp:
+            de += self._response_finish(resp, world)
         return de
 
     def nr_uks(self, mol, grids, xc_code, dms, relativity=0, hermi=1, max_memory=2000, verbose=None):
@@ -505,6 +570,7 @@ class NumInt:
                 ops.append((torch.from_numpy(d_h).to(dev), ldd, torch.empty((nao, blk), dtype=f64, device=dev)))
         part = torch.zeros((2, nsplit_max, nao, nao), dtype=f64, device=dev)
         acc = torch.zeros(3, dtype=f64, device=dev)
+        evol = None
         for ib, g0 in enumerate(range(0, ngrids, blk)):
             if ib % world != rank:
                 continue
@@ -535,7 +601,7 @@ class NumInt:
                                _c.c_long(blk), st)
             self._call('eval_xc', lib.PAMD_eval_xc_pol, fac_c, _c.c_int(gga), _ptr(rho[0]), _ptr(rho[1]),
                        _ptr(weights_dev[g0:g0 + ng]), _c.c_long(ng), _c.c_long(blk), _ptr(wv[0]), _ptr(wv[1]),
-                       _ptr(acc), st)
+                       _ptr(acc), _ptr(evol) if evol is not None else _c.c_void_p(0), st)
             use_masks = screen and self._vmat_use_masks(mpanel, ng)
             for s in range(2):
                 self._call('scale_ao', lib.PAMD_scale_ao, _ptr(ao), _ptr(wv[s]), _c.c_int(ldao), _c.c_long(blk),

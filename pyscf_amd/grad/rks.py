@@ -16,8 +16,6 @@ class Gradients(rhf_grad.Gradients):
         mf = self.base
         if getattr(mf, 'with_df', None) is None:
             raise NotImplementedError('gradients are implemented for density-fitted SCF objects')
-        if self.grid_response:
-            raise NotImplementedError('grid response (pyscf/grad/rks.py:get_vxc_full_response)')
         mo_occ = np.asarray(mf.mo_occ)
         if mo_occ.ndim != 1:
             raise NotImplementedError('UKS gradients')
@@ -27,4 +25,4 @@ class Gradients(rhf_grad.Gradients):
             raise NotImplementedError('range-separated hybrid gradients')
         dm, blocks, dme = self._densities()
         de = rhf_grad.grad_elec_df(self.mol, mf.with_df, dm, blocks, dme, hyb, self.auxbasis_response)
-        return de + ni.nr_rks_grad(self.mol, mf.grids, mf.xc, dm)
+        return de + ni.nr_rks_grad(self.mol, mf.grids, mf.xc, dm, self.grid_response)

@@ -13,8 +13,6 @@ class Gradients(rhf_grad.Gradients):
         mf = self.base
         if getattr(mf, 'with_df', None) is None:
             raise NotImplementedError('gradients are implemented for density-fitted SCF objects')
-        if self.grid_response:
-            raise NotImplementedError('grid response (pyscf/grad/rks.py:get_vxc_full_response)')
         ni = mf._numint
         omega, alpha, hyb = ni.rsh_and_hybrid_coeff(mf.xc, spin=self.mol.spin)
         if omega:
@@ -22,4 +20,4 @@ class Gradients(rhf_grad.Gradients):
         dm, blocks, dme = self._densities()
         de = rhf_grad.grad_elec_df(self.mol, mf.with_df, dm, blocks, dme, hyb, self.auxbasis_response)
         dms = [c.dot(c.T) for c, _w in blocks]
-        return de + ni.nr_uks_grad(self.mol, mf.grids, mf.xc, dms)
+        return de + ni.nr_uks_grad(self.mol, mf.grids, mf.xc, dms, self.grid_response)
