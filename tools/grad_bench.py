@@ -12,6 +12,7 @@ ap.add_argument('--nwater', type=int, default=8)
 ap.add_argument('--basis', default='cc-pvtz')
 ap.add_argument('--fd', action='store_true')
 ap.add_argument('--xc', default='')
+ap.add_argument('--grid-response', action='store_true')
 a = ap.parse_args()
 atoms = clusters.water_cluster(a.nwater)
 mol = gto.M(atom=atoms, basis=a.basis)
@@ -19,10 +20,12 @@ t0 = time.perf_counter()
 mf = (dft.RKS(mol, xc=a.xc) if a.xc else scf.RHF(mol)).density_fit().run(conv_tol=1e-11)
 t_scf = time.perf_counter() - t0
 t0 = time.perf_counter()
-g = mf.nuc_grad_method().kernel()
+gm = mf.nuc_grad_method()
+if a.grid_response: gm.grid_response = True
+g = gm.kernel()
 torch.cuda.synchronize()
 t_grad = time.perf_counter() - t0
-out = {'xc': a.xc or 'hf', 'nwater': a.nwater, 'nao': mol.nao, 'naux': mf.with_df.get_naoaux(), 'e_tot': mf.e_tot, 'scf_s': round(t_scf, 2),
+out = {'xc': a.xc or 'hf', 'grid_response': a.grid_response, 'nwater': a.nwater, 'nao': mol.nao, 'naux': mf.with_df.get_naoaux(), 'e_tot': mf.e_tot, 'scf_s': round(t_scf, 2),
        'cycles': mf.cycles, 'grad_s': round(t_grad, 2), 'sum_over_atoms': np.abs(g.sum(0)).max(),
        'max_abs_grad': float(np.abs(g).max()), 'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2**30, 1)}
 if a.fd:
