@@ -178,6 +178,9 @@ def main():
     except Exception:
         pass
     dtot, dcnt = ksum[dom]
+    if traffic is not None and dom == 'e2_symm':
+        # the PMC pass ran at N = 1 (2224 aux rows per launch); a rank's launch moves bytes in proportion to its rows
+        traffic *= (naux_local / max(dcnt, 1)) / 2224.0
     if dom in ('e2_symm', 'dgemm_tn'):
         fl = flops_e2 if dom == 'e2_symm' else flops_syrk
         ach = fl / (dtot * 1e-3) / 1e12
