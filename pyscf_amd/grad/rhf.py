@@ -211,9 +211,16 @@ class Gradients:
     def _densities(self):
         mf = self.base
         mo_c, mo_e, mo_occ = np.asarray(mf.mo_coeff), np.asarray(mf.mo_energy), np.asarray(mf.mo_occ)
+        if mo_c.ndim == 2 and np.any((mo_occ > 0) & (mo_occ < 2)):
+            # ROHF (pyscf/grad/rohf.py:30-42): UHF machinery with the blocks occ > 0 / occ == 2 of the one coefficient
+            # matrix; the orbitals do not diagonalise F_alpha / F_beta, so W = sum_s D_s F_s D_s, D_s = C_s C_s^T
+            ca, cb = mo_c[:, mo_occ > 0], mo_c[:, mo_occ == 2]
+            da, db = ca.dot(ca.T), cb.dot(cb.T)
+            vhf = mf.get_veff(self.mol, np.array((da, db)))
+            h1e = mf.get_hcore()
+            dme = da.dot(h1e + vhf[0]).dot(da) + db.dot(h1e + vhf[1]).dot(db)
+            return da + db, [(ca, 1.0), (cb, 1.0)], dme
         if mo_c.ndim == 2:
-            if np.any((mo_occ > 0) & (mo_occ < 2)):
-                raise NotImplementedError('ROHF gradients')
             occ = mo_occ > 0
             c = mo_c[:, occ]
             dm = 2 * c.dot(c.T)

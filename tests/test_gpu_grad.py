@@ -254,3 +254,30 @@ def test_df_ks_gradients_with_grid_response_goldens():
     h = 2e-3
     fd = (4 * (energy(h) - energy(-h)) / (2 * h) - (energy(2 * h) - energy(-2 * h)) / (4 * h)) / 3
     assert abs(g[0, 2] - fd) < 1e-6, (g[0, 2], fd)
+
+
+def test_df_rohf_gradient_vs_finite_difference():
+    """DF-ROHF gradient (pyscf/grad/rohf.py: UHF formulas on the occ > 0 / occ == 2 blocks, W = sum_s D_s F_s D_s) of the
+    H2O+ cation whose energy is pinned by the reference (-75.626515724371814, test_df_jk.py:72-78), against
+    Richardson-extrapolated finite differences of that energy; translational invariance."""
+    from pyscf_amd import gto, scf
+    atoms = [('O', (0.03, -0.02, 0.01)), ('H', (0.1, -0.757, 0.587)), ('H', (-0.2, 0.8, 0.5))]
+
+    def run(at, unit='Angstrom'):
+        mol = gto.M(atom=at, basis='cc-pvdz', charge=1, spin=1, unit=unit)
+        mf = scf.ROHF(mol).density_fit(auxbasis='weigend')
+        mf.conv_tol = 1e-12
+        mf.kernel()
+        assert mf.converged
+        return mf
+    mf = run(atoms)
+    g = mf.nuc_grad_method().kernel()
+    assert abs(g.sum(axis=0)).max() < 1e-9
+    h = 2e-3
+    for a, x in ((0, 2), (1, 1)):
+        def e(d):
+            at = [(s, np.array(r) / BOHR) for s, r in atoms]
+            at[a][1][x] += d
+            return run([(s, tuple(r)) for s, r in at], 'Bohr').e_tot
+        fd = (4 * (e(h) - e(-h)) / (2 * h) - (e(2 * h) - e(-2 * h)) / (4 * h)) / 3
+        assert abs(g[a, x] - fd) < 5e-7, (a, x, g[a, x], fd)
