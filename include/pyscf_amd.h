@@ -21,6 +21,8 @@
  *   PAMD_dgemm_tn        lib/np_helper/npdot.c:32 NPdgemm as used by lib.dot(buf1.T, buf1), df/df_jk.py:380,407
  *   PAMD_unpack_tril     lib/np_helper/pack_tril.c:150-273 NPdunpack_tril_2d
  *   PAMD_becke_partition lib/dft/grid_basis.c:32-101 VXCgen_grid
+ *   PAMD_grid_partition  dft/gen_grid.py:341-419 get_partition with becke_scheme = original_becke / stratmann (:203-212) /
+ *                        becke_lko (lib/dft/grid_basis.c:266-384 VXCgen_grid_lko)
  *   PAMD_eval_ao         gto/eval_gto.py:31-144 -> lib/gto/grid_ao_drv.c:222-284,415-459 (GTOval_sph_deriv0/1)
  *   PAMD_rho_from_mo/_dm dft/numint.py:116-469 eval_rho / eval_rho2 (VXCdot_ao_dm, VXCdcontract_rho)
  *   PAMD_eval_xc         lib/dft/libxc_itrf.c:968-1024 LIBXC_eval_xc (+ libxc 7.1.2) and dft/xc_deriv.py:32-85
@@ -154,6 +156,9 @@ int PAMD_set_tuning(const char *key, int value);      /* benchmarking switches, 
 /* pbecke[natm][ngrids]: unnormalised Becke cell functions; radii table a[i][j] nullable */
 int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
                          const double *d_radii_table, int natm, long ngrids, void *stream);
+/* same, cell function by scheme: 0 original Becke, 1 Stratmann-Scuseria-Frisch, 2 Laqua-Kussmann-Ochsenfeld */
+int PAMD_grid_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
+                        const double *d_radii_table, int natm, long ngrids, int scheme, void *stream);
 /* ao[comp][ldg_rows][ldao] (AO index fastest, columns nao..ldao-1 zero), comp = 1 (deriv 0), 4 (deriv 1) or 10 (deriv 2: 1, x, y, z, xx, xy, xz, yy, yz, zz),
  * grid points [g0, g0+ng) of d_coords; d_fn2sh[mu] = segmented shell of AO mu.
  * d_flags (nullable; caller zeroes it): [ceil(ldg_rows/16)][ldao/16] bytes <- 1 where the 16 x 16 (grid x AO) tile

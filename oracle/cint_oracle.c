@@ -184,7 +184,8 @@ static void hermite_E(int la, int lb, double a, double b, double Ax, double Bx, 
 typedef struct { double v[NR][NR][NR]; } Rarr;
 
 /* long-range attenuation erf(omega r12)/r12 (env[PTR_RANGE_OMEGA], pyscf/gto/mole.py:76-84): the Boys
- * moments become theta^(n+1/2) F_n(theta x) with theta = omega^2/(omega^2 + alpha).  Set only around
+ * moments become theta^(n+1/2) F_n(theta x) with theta = omega^2/(omega^2 + alpha); omega < 0 selects the
+ * short-range complement erfc(|omega| r12)/r12 (libcint's sign convention), F_n(x) minus the above.  Set only around
  * the 2e integral calls by oracle/ref.py (never for the nuclear attraction). */
 static double g_omega = 0.0;
 void oracle_set_omega(double omega) { g_omega = omega; }
@@ -196,11 +197,16 @@ static void hermite_R(int N, double alpha, const double *PQ, Rarr *R)
 #define TMP(n, t, u, v) tmp[((((size_t)(n)) * n1 + (t)) * n1 + (u)) * n1 + (v)]
     double f[NR + 2];
     double x = alpha * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
-    if (g_omega > 0) {
+    if (g_omega != 0) {
         double theta = g_omega * g_omega / (g_omega * g_omega + alpha);
         boys(N, x * theta, f);
         double th = sqrt(theta);
         for (int n = 0; n <= N; n++) { f[n] *= th; th *= theta; }
+        if (g_omega < 0) {                  /* short range erfc(|omega| r12)/r12 = Coulomb - long range */
+            double fc[NR + 2];
+            boys(N, x, fc);
+            for (int n = 0; n <= N; n++) f[n] = fc[n] - f[n];
+        }
     } else {
         boys(N, x, f);
     }

@@ -25,20 +25,38 @@ from . import ref
 # ----------------------------------------------------------------------------- grids
 
 
-def becke_partition(coords, atm_coords, radii_table):
-    """pbecke[natm][ngrids], original Becke cell functions (grid_basis.c:32-101)."""
+def _lko_saturate(r):
+    """grid_basis.c:236-247: R_c (1 - exp(-sum_{m=1..12} (r/R_c)^m / m)), R_c = 5."""
+    x = r / 5.0
+    return 5.0 * (1 - np.exp(-sum(x ** m / m for m in range(1, 13))))
+
+
+def becke_partition(coords, atm_coords, radii_table, scheme='becke'):
+    """pbecke[natm][ngrids]: original Becke cell functions (grid_basis.c:32-101), 'stratmann' (gen_grid.py:203-212 in the
+    generic loop :388-404) or 'lko' (grid_basis.c:266-384)."""
     natm = len(atm_coords)
     d = np.linalg.norm(coords[None, :, :] - atm_coords[:, None, :], axis=2)   # [natm][ng]
     pb = np.ones((natm, len(coords)))
     for i in range(natm):
         for j in range(i):
-            g = (d[i] - d[j]) / np.linalg.norm(atm_coords[i] - atm_coords[j])
+            rij = np.linalg.norm(atm_coords[i] - atm_coords[j])
+            g = (d[i] - d[j]) / (_lko_saturate(rij) if scheme == 'lko' else rij)
+            if scheme == 'lko':
+                g = np.clip(g, -1, 1)
             if radii_table is not None:
                 g = g + radii_table[i, j] * (1 - g * g)
-            s = g
-            s = (3 - s * s) * s * .5
-            s = (3 - s * s) * s * .5
-            s = ((3 - s * s) * s * .5) * .5
+            if scheme == 'stratmann':
+                ma = g / .64
+                ma2 = ma * ma
+                s = (1 / 16.) * (ma * (35 + ma2 * (-35 + ma2 * (21 - 5 * ma2))))
+                s[g <= -.64] = -1
+                s[g >= .64] = 1
+                s = .5 * s
+            else:
+                s = g
+                s = (3 - s * s) * s * .5
+                s = (3 - s * s) * s * .5
+                s = ((3 - s * s) * s * .5) * .5
             pb[i] *= .5 - s
             pb[j] *= .5 + s
     return pb
@@ -104,24 +122,27 @@ def becke_weight_response(coords, owner, weights, atm_coords, radii_table):
 
 
 def build_grids(mol, atom_grid=None, radi_method=None, prune='nwchem', radii_adjust='treutler', level=3,
-                sort_grids=True, alignment=8):
+                sort_grids=True, alignment=8, atomic_radii=None, scheme='becke'):
     """coords, weights (host).  Atomic (radial x Lebedev) tables come from the host-side generator
     (pure numpy restatement of gen_grid.gen_atomic_grids, pinned by the grid-norm goldens); the
     partition is done here in numpy."""
     from pyscf_amd.dft import gen_grid, radi
-    prune_fn = {'nwchem': gen_grid.nwchem_prune, 'treutler': gen_grid.treutler_prune, None: None}[prune]
+    prune_fn = {'nwchem': gen_grid.nwchem_prune, 'treutler': gen_grid.treutler_prune, 'sg1': gen_grid.sg1_prune,
+                None: None}[prune]
     tab = gen_grid.gen_atomic_grids(mol, atom_grid or {}, radi_method or radi.treutler, level, prune_fn)
+    if atomic_radii is None:
+        atomic_radii = radi.BRAGG_RADII
     table = None
     if radii_adjust == 'treutler':
-        table = radi.treutler_atomic_radii_adjust(mol, radi.BRAGG_RADII)
+        table = radi.treutler_atomic_radii_adjust(mol, atomic_radii)
     elif radii_adjust == 'becke':
-        table = radi.becke_atomic_radii_adjust(mol, radi.BRAGG_RADII)
+        table = radi.becke_atomic_radii_adjust(mol, atomic_radii)
     atm = mol.atom_coords()
     cs, ws = [], []
     for ia in range(mol.natm):
         c, vol = tab[mol.atom_symbol(ia)]
         c = c + atm[ia]
-        pb = becke_partition(c, atm, table)
+        pb = becke_partition(c, atm, table, scheme)
         cs.append(c)
         ws.append(vol * pb[ia] / pb.sum(axis=0))
     coords, weights = np.vstack(cs), np.hstack(ws)

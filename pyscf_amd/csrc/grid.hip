@@ -1,5 +1,6 @@
 // DFT grid kernels: Becke partition weights and AO (+ gradient) values on grid points.
 //   PAMD_becke_partition <- VXCgen_grid  (pyscf/lib/dft/grid_basis.c:32-101)
+//   PAMD_grid_partition  <- get_partition's three cell functions (pyscf/dft/gen_grid.py:341-419)
 //   PAMD_eval_ao         <- GTOval_sph_deriv0 / GTOval_sph_deriv1 (pyscf/gto/eval_gto.py:31-144;
 //                           pyscf/lib/gto/grid_ao_drv.c:222-284 GTOeval_sph_iter, :125-141 GTOnabla1,
 //                           pyscf/lib/gto/deriv1.c:129-520)
@@ -11,7 +12,24 @@ using namespace pamd;
 
 namespace {
 
+// Saturated interatomic distance of the Laqua-Kussmann-Ochsenfeld partition, R_c (1 - exp(-sum_{m<=12} (R/R_c)^m / m)),
+// R_c = 5 Bohr (grid_basis.c:236-247).
+__device__ inline double lko_saturate(double r)
+{
+    const double x = r / 5.0;
+    double xm = 1, tot = 0;
+    for (int m = 1; m <= 12; m++) {
+        xm *= x;
+        tot += xm / m;
+    }
+    return 5.0 * (1 - exp(-tot));
+}
+
 // out[ia][g] = prod_{j != ia} s(mu_ij)-type cell function of atom ia (unnormalised)
+// SCHEME 0: Becke's thrice-iterated polynomial (VXCgen_grid, grid_basis.c:32-101); 1: the Stratmann-Scuseria-Frisch
+// piecewise septic with a = 0.64 (gen_grid.py:203-212 through the generic branch of get_partition :388-404);
+// 2: Becke's polynomial on mu clamped to [-1, 1] with the saturated distance (VXCgen_grid_lko, grid_basis.c:266-384).
+template <int SCHEME>
 __global__ __launch_bounds__(256) void becke_kernel(double *__restrict__ out, const double *__restrict__ coords,
                                                     const double *__restrict__ atm, const double *__restrict__ radii,
                                                     int natm, long ngrids)
@@ -28,11 +46,19 @@ __global__ __launch_bounds__(256) void becke_kernel(double *__restrict__ out, co
             const double dxj = x - atm[j * 3], dyj = y - atm[j * 3 + 1], dzj = z - atm[j * 3 + 2];
             const double dj = sqrt(dxj * dxj + dyj * dyj + dzj * dzj);
             const double ax = atm[i * 3] - atm[j * 3], ay = atm[i * 3 + 1] - atm[j * 3 + 1], az = atm[i * 3 + 2] - atm[j * 3 + 2];
-            double s = (di - dj) / sqrt(ax * ax + ay * ay + az * az);
+            const double rij = sqrt(ax * ax + ay * ay + az * az);
+            double s = (di - dj) / (SCHEME == 2 ? lko_saturate(rij) : rij);
+            if (SCHEME == 2) s = fmin(1.0, fmax(-1.0, s));
             if (radii) s += radii[i * natm + j] * (1 - s * s);
-            s = (3 - s * s) * s * .5;
-            s = (3 - s * s) * s * .5;
-            s = ((3 - s * s) * s * .5) * .5;
+            if (SCHEME == 1) {
+                const double ma = s / .64, ma2 = ma * ma;
+                const double g1 = (1 / 16.) * (ma * (35 + ma2 * (-35 + ma2 * (21 - 5 * ma2))));
+                s = .5 * (s <= -.64 ? -1.0 : (s >= .64 ? 1.0 : g1));
+            } else {
+                s = (3 - s * s) * s * .5;
+                s = (3 - s * s) * s * .5;
+                s = ((3 - s * s) * s * .5) * .5;
+            }
             pi *= .5 - s;
             out[(long)j * ngrids + g] *= .5 + s;
         }
@@ -310,12 +336,27 @@ __global__ __launch_bounds__(256) void eval_ao_kernel(AOShells sh, int nsh, cons
 
 extern "C" {
 
+int PAMD_grid_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
+                        const double *d_radii_table, int natm, long ngrids, int scheme, void *stream);
+
 int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
                          const double *d_radii_table, int natm, long ngrids, void *stream)
 {
+    return PAMD_grid_partition(d_out, d_coords, d_atm_coords, d_radii_table, natm, ngrids, 0, stream);
+}
+
+// Same with the cell function chosen by scheme: 0 original Becke, 1 Stratmann-Scuseria-Frisch, 2 Laqua-Kussmann-
+// Ochsenfeld (gen_grid.py:203-234 stratmann / original_becke / becke_lko).
+int PAMD_grid_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
+                        const double *d_radii_table, int natm, long ngrids, int scheme, void *stream)
+{
+    PAMD_REQUIRE(scheme >= 0 && scheme <= 2, "grid_partition: scheme must be 0 (becke), 1 (stratmann) or 2 (lko)");
     if (ngrids == 0) return 0;
-    becke_kernel<<<ceil_div(ngrids, 256), 256, 0, (hipStream_t)stream>>>(d_out, d_coords, d_atm_coords,
-                                                                         d_radii_table, natm, ngrids);
+    const dim3 grid(ceil_div(ngrids, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (scheme == 0) becke_kernel<0><<<grid, 256, 0, st>>>(d_out, d_coords, d_atm_coords, d_radii_table, natm, ngrids);
+    else if (scheme == 1) becke_kernel<1><<<grid, 256, 0, st>>>(d_out, d_coords, d_atm_coords, d_radii_table, natm, ngrids);
+    else becke_kernel<2><<<grid, 256, 0, st>>>(d_out, d_coords, d_atm_coords, d_radii_table, natm, ngrids);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

@@ -33,7 +33,7 @@ class DF:
         self.k_block_bytes = 8 << 30
         self.k_nsplit = 4
         self.lindep = 1e-7         # pyscf/df/incore.py:33
-        self.omega = 0.0           # > 0: long-range tensor (set by range_coulomb)
+        self.omega = 0.0           # > 0: long-range, < 0: short-range tensor (set by range_coulomb)
         self._rsh_df = {}
         self.incore_anyway = False  # mol.incore_anyway analogue (df_jk.py:282): force the tensor path
         self._eng = None
@@ -325,12 +325,10 @@ class DF:
         return path
 
     def range_coulomb(self, omega):
-        """DF object holding the long-range (erf(omega r12)/r12) tensor, cached per omega
-        (pyscf/df/df.py:298-333)."""
+        """DF object holding the long-range (omega > 0, erf(omega r12)/r12) or short-range (omega < 0,
+        erfc(|omega| r12)/r12) tensor, cached per omega (pyscf/df/df.py:298-333)."""
         if omega is None or omega == 0:
             return self
-        if omega < 0:
-            raise NotImplementedError('short-range (omega < 0) density fitting')
         key = '%.6f' % omega
         if key not in self._rsh_df:
             obj = DF(self.mol, self.auxbasis, self.device, self.group)

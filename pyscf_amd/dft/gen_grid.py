@@ -4,8 +4,8 @@ Mirror of ``pyscf/dft/gen_grid.py``: ``nwchem_prune`` (:90-134), ``treutler_prun
 ``sg1_prune`` (:50-88), ``gen_atomic_grids`` (:254-338), ``get_partition`` (:341-419),
 ``arg_group_grids`` (:449-471), ``Grids`` (:487-744), level tables (:747-785).  Atomic grids
 are assembled on the host (one-time, small); the Becke partition - O(ngrids * natm^2), the only
-heavy step - runs on the device (``PAMD_becke_partition``, the analogue of ``VXCgen_grid``,
-pyscf/lib/dft/grid_basis.c:32-101).  Lebedev tables: pyscf_amd/dft/lebedev.npz.
+heavy step - runs on the device (``PAMD_grid_partition``, the analogue of ``VXCgen_grid`` /
+``VXCgen_grid_lko``, pyscf/lib/dft/grid_basis.c:32-101,266-384, and of the generic Stratmann branch :388-404).  Lebedev tables: pyscf_amd/dft/lebedev.npz.
 """
 import ctypes
 import os
@@ -42,12 +42,21 @@ def MakeAngularGrid(n):
     return _lebedev()['n%d' % n]
 
 
-def sg1_prune(nuc, rads, n_ang, radii=None):
-    raise NotImplementedError('sg1_prune')
+_PRUNE_ALPHAS = np.array(((0.25, 0.5, 1.0, 4.5), (0.1667, 0.5, 0.9, 3.5), (0.1, 0.4, 0.8, 2.5)))
+
+
+def _prune_region(nuc, rads, radii):
+    """Index 0..4 of the radial region each shell falls in (inner core ... outer tail) for H-He / Li-Ne / heavier."""
+    row = 0 if nuc <= 2 else (1 if nuc <= 10 else 2)
+    return ((rads / (radii[nuc] + 1e-200)).reshape(-1, 1) > _PRUNE_ALPHAS[row]).sum(axis=1)
+
+
+def sg1_prune(nuc, rads, n_ang, radii=radi.SG1RADII):
+    """SG-1 angular orders 6/38/86/194/86 over the five regions, whatever n_ang is (gen_grid.py:53-88)."""
+    return np.array([6, 38, 86, 194, 86])[_prune_region(nuc, rads, radii)]
 
 
 def nwchem_prune(nuc, rads, n_ang, radii=radi.BRAGG_RADII):
-    alphas = np.array(((0.25, 0.5, 1.0, 4.5), (0.1667, 0.5, 0.9, 3.5), (0.1, 0.4, 0.8, 2.5)))
     leb_ngrid = LEBEDEV_NGRID[4:]
     if n_ang < 50:
         return np.repeat(n_ang, len(rads))
@@ -56,10 +65,7 @@ def nwchem_prune(nuc, rads, n_ang, radii=radi.BRAGG_RADII):
     else:
         idx = np.where(leb_ngrid == n_ang)[0][0]
         leb_l = np.array([1, 3, idx - 1, idx, idx - 1])
-    r_atom = radii[nuc] + 1e-200
-    row = 0 if nuc <= 2 else (1 if nuc <= 10 else 2)
-    place = ((rads / r_atom).reshape(-1, 1) > alphas[row]).sum(axis=1)
-    return leb_ngrid[leb_l[place]]
+    return leb_ngrid[leb_l[_prune_region(nuc, rads, radii)]]
 
 
 def treutler_prune(nuc, rads, n_ang, radii=None):
@@ -107,7 +113,9 @@ def gen_atomic_grids(mol, atom_grid={}, radi_method=radi.gauss_chebyshev, level=
         if conf is not None:
             n_rad, n_ang = conf
             if n_ang not in LEBEDEV_NGRID:
-                raise ValueError('Unsupported angular grids %d' % n_ang)
+                if n_ang not in _order_table():
+                    raise ValueError('Unsupported angular grids %d' % n_ang)
+                n_ang = _order_table()[n_ang]           # a Lebedev order was given: use its point count (gen_grid.py:301-306)
         else:
             n_rad, n_ang = _default_rad(chg, level), _default_ang(chg, level)
         rad, dr = radi_method(n_rad, chg, ia)
@@ -125,8 +133,34 @@ def gen_atomic_grids(mol, atom_grid={}, radi_method=radi.gauss_chebyshev, level=
     return tab
 
 
-def becke_partition_gpu(coords, atm_coords, radii_table, device):
-    """pbecke[natm][ngrids] on the device (VXCgen_grid analogue, original Becke polynomial)."""
+def original_becke(g):
+    """Marker for Becke's thrice-iterated cell polynomial (gen_grid.py:214-221); evaluated in the partition kernel."""
+    raise NotImplementedError('original_becke selects a device kernel; it is not evaluated on the host')
+
+
+def stratmann(g):
+    """Marker for the Stratmann-Scuseria-Frisch cell function, a = 0.64 (gen_grid.py:203-212)."""
+    raise NotImplementedError('stratmann selects a device kernel; it is not evaluated on the host')
+
+
+def becke_lko(g):
+    """Marker for the Laqua-Kussmann-Ochsenfeld partition (gen_grid.py:223-237, grid_basis.c:266-384)."""
+    raise NotImplementedError('becke_lko selects a device kernel; it is not evaluated on the host')
+
+
+_SCHEME_ID = {original_becke: 0, 'original_becke': 0, 'becke': 0, stratmann: 1, 'stratmann': 1, becke_lko: 2, 'becke_lko': 2,
+              'lko': 2}
+
+
+def scheme_id(becke_scheme):
+    try:
+        return _SCHEME_ID[becke_scheme]
+    except (KeyError, TypeError):
+        raise NotImplementedError('becke_scheme %r: original_becke, stratmann and becke_lko are built' % (becke_scheme,))
+
+
+def becke_partition_gpu(coords, atm_coords, radii_table, device, scheme=0):
+    """pbecke[natm][ngrids] on the device (VXCgen_grid / VXCgen_grid_lko / generic get_partition analogue)."""
     import torch
     lib = _lib_mod.load_library()
     ngrids, natm = len(coords), len(atm_coords)
@@ -139,9 +173,9 @@ def becke_partition_gpu(coords, atm_coords, radii_table, device):
         rt = torch.from_numpy(np.ascontiguousarray(radii_table)).to(device)
         rt_ptr = ctypes.c_void_p(rt.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib_mod.check(lib.PAMD_becke_partition(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(c.data_ptr()),
-                                            ctypes.c_void_p(a.data_ptr()), rt_ptr, ctypes.c_int(natm),
-                                            ctypes.c_long(ngrids), st))
+    _lib_mod.check(lib.PAMD_grid_partition(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(c.data_ptr()),
+                                           ctypes.c_void_p(a.data_ptr()), rt_ptr, ctypes.c_int(natm),
+                                           ctypes.c_long(ngrids), ctypes.c_int(scheme), st))
     return out
 
 
@@ -167,7 +201,7 @@ class Grids:
         self.atomic_radii = radi.BRAGG_RADII
         self.radii_adjust = radi.treutler_atomic_radii_adjust
         self.radi_method = radi.treutler
-        self.becke_scheme = 'original_becke'
+        self.becke_scheme = original_becke
         self.prune = nwchem_prune
         self.level = 3
         self.alignment = ALIGNMENT_UNIT
@@ -195,8 +229,7 @@ class Grids:
         return torch.device('cuda', torch.cuda.current_device())
 
     def get_partition(self, mol, atom_grids_tab):
-        if self.becke_scheme != 'original_becke':
-            raise NotImplementedError('only the original Becke scheme (gen_grid.py:203-207)')
+        scheme = scheme_id(self.becke_scheme)
         table = None
         if callable(self.radii_adjust) and self.atomic_radii is not None:
             table = self.radii_adjust(mol, self.atomic_radii)
@@ -206,7 +239,7 @@ class Grids:
         for ia in range(mol.natm):
             c, vol = atom_grids_tab[mol.atom_symbol(ia)]
             c = c + atm_coords[ia]
-            pb = becke_partition_gpu(c, atm_coords, table, dev)
+            pb = becke_partition_gpu(c, atm_coords, table, dev, scheme)
             w = (pb[ia] / pb.sum(dim=0)).cpu().numpy() * vol
             coords_all.append(c)
             weights_all.append(w)

@@ -398,6 +398,9 @@ class NumInt:
     def _response_setup(self, mol, grids, dev, blk):
         import torch
         natm = mol.natm
+        from . import gen_grid
+        if gen_grid.scheme_id(grids.becke_scheme) != 0:
+            raise NotImplementedError('grid response is built for the original Becke partition only (grad/rks.py:457-560)')
         owner = np.zeros(grids.size, np.int32)
         owner[:len(grids.atm_idx)] = grids.atm_idx                    # alignment padding: weight 0, any owner
         table = None

@@ -3,7 +3,7 @@
 Host-side restatement of ``pyscf/dft/radi.py``: ``gauss_chebyshev`` (:102-117),
 ``treutler_ahlrichs`` (:139-158, per-element xi table :119-137), ``becke`` (:50-68),
 ``delley`` (:72-84), ``mura_knowles`` (:87-99), ``becke_atomic_radii_adjust`` (:162-179),
-``treutler_atomic_radii_adjust`` (:181-199); Bragg radii from ``pyscf/data/radii.py:23``.
+``treutler_atomic_radii_adjust`` (:181-199); Bragg / covalent radii from ``pyscf/data/radii.py:23,53``, SG-1 radii :40.
 """
 import numpy as np
 
@@ -11,7 +11,7 @@ from ..gto.mole import BOHR, element_charge as _charge   # radi.py:166,187: radi
 
 ATOM_SPECIFIC_TREUTLER_GRIDS = True     # radi.py:37
 
-_U = 1.75
+_U = 1.999999                            # data/radii.py:19 (slot 0, never indexed: ghosts use their element)
 BRAGG_RADII = 1 / BOHR * np.array((
     _U,
     0.35, 1.40,
@@ -20,6 +20,23 @@ BRAGG_RADII = 1 / BOHR * np.array((
     2.20, 1.80,
     1.60, 1.40, 1.35, 1.40, 1.40, 1.40, 1.35, 1.35, 1.35, 1.35,
     1.30, 1.25, 1.15, 1.15, 1.15, 1.90))
+
+# Cordero et al. covalent radii, H-Kr (pyscf/data/radii.py:53-59)
+COVALENT_RADII = 1 / BOHR * np.array((
+    _U,
+    0.31, 0.28,
+    1.28, 0.96, 0.84, 0.73, 0.71, 0.66, 0.57, 0.58,
+    1.66, 1.41, 1.21, 1.11, 1.07, 1.05, 1.02, 1.06,
+    2.03, 1.76,
+    1.70, 1.60, 1.53, 1.39, 1.50, 1.42, 1.38, 1.24, 1.32, 1.22,
+    1.22, 1.20, 1.19, 1.20, 1.20, 1.16))
+
+# SG-1 atomic radii in Bohr, H-Ar (radi.py:40-44; Gill, Johnson, Pople, CPL 209, 506)
+SG1RADII = np.array((
+    1.0000,
+    1.0000, 0.5882,
+    3.0769, 2.0513, 1.5385, 1.2308, 1.0256, 0.8791, 0.7692, 0.6838,
+    4.0909, 3.1579, 2.5714, 2.1687, 1.8750, 1.6514, 1.4754, 1.3333))
 
 _treutler_ahlrichs_xi = [1.0,
     0.8, 0.9,

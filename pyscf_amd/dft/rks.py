@@ -31,12 +31,19 @@ def get_veff(ks, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
         vj, _ = ks.get_jk(mol, dm, hermi, with_k=False)
         vxc = vxc + vj
     else:
-        vj, vk = ks.get_jk(mol, dm, hermi)
-        vk = vk * hyb
-        if omega != 0:
-            # range-separated exact exchange: K = hyb K_full + (alpha - hyb) K_LR(omega)   (rks.py:110-127)
-            vklr = ks.get_jk(mol, dm, hermi, with_j=False, omega=omega)[1]
-            vk = vk + vklr * (alpha - hyb)
+        # range-separated exact exchange, the reference's four branches (rks.py:110-127)
+        if omega == 0:
+            vj, vk = ks.get_jk(mol, dm, hermi)
+            vk = vk * hyb
+        elif alpha == 0:                    # short-range exchange only: the erfc-attenuated tensor
+            vj = ks.get_jk(mol, dm, hermi, with_k=False)[0]
+            vk = ks.get_jk(mol, dm, hermi, with_j=False, omega=-omega)[1] * hyb
+        elif hyb == 0:                      # long-range exchange only
+            vj = ks.get_jk(mol, dm, hermi, with_k=False)[0]
+            vk = ks.get_jk(mol, dm, hermi, with_j=False, omega=omega)[1] * alpha
+        else:                               # K = hyb K_full + (alpha - hyb) K_LR(omega)
+            vj, vk = ks.get_jk(mol, dm, hermi)
+            vk = vk * hyb + ks.get_jk(mol, dm, hermi, with_j=False, omega=omega)[1] * (alpha - hyb)
         vxc = vxc + vj - vk * .5
         exc -= np.einsum('ij,ji', dm, vk).real * .5 * .5
     ks._log('df vj and vk: %.4f s', time.perf_counter() - t0)

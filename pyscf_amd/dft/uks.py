@@ -35,12 +35,20 @@ class UKS(uhf.UHF):
             vj = vj[0] + vj[1]
             vxc = vxc + vj
         else:
-            vj, vk = self.get_jk(mol, dm, hermi)
+            # range-separated exact exchange, the reference's four branches (uks.py:84-105)
+            if omega == 0:
+                vj, vk = self.get_jk(mol, dm, hermi)
+                vk = vk * hyb
+            elif alpha == 0:               # short-range exchange only: the erfc-attenuated tensor
+                vj = self.get_jk(mol, dm, hermi, with_k=False)[0]
+                vk = self.get_jk(mol, dm, hermi, with_j=False, omega=-omega)[1] * hyb
+            elif hyb == 0:                 # long-range exchange only
+                vj = self.get_jk(mol, dm, hermi, with_k=False)[0]
+                vk = self.get_jk(mol, dm, hermi, with_j=False, omega=omega)[1] * alpha
+            else:                          # K = hyb K_full + (alpha - hyb) K_LR(omega)
+                vj, vk = self.get_jk(mol, dm, hermi)
+                vk = vk * hyb + self.get_jk(mol, dm, hermi, with_j=False, omega=omega)[1] * (alpha - hyb)
             vj = vj[0] + vj[1]
-            vk = vk * hyb
-            if omega != 0:                 # K = hyb K_full + (alpha - hyb) K_LR(omega)   (uks.py:90-105)
-                vklr = self.get_jk(mol, dm, hermi, with_j=False, omega=omega)[1]
-                vk = vk + vklr * (alpha - hyb)
             vxc = vxc + vj - vk
             exc -= (np.einsum('ij,ji', dma[0], vk[0]) + np.einsum('ij,ji', dma[1], vk[1])).real * .5
         ecoul = np.einsum('ij,ji', dma[0] + dma[1], vj).real * .5

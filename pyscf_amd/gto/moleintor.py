@@ -224,8 +224,8 @@ class IntEngine:
         import torch
         self.torch = torch
         self.device = device
-        if omega < 0:
-            raise NotImplementedError('short-range (omega < 0) integrals')
+        # omega > 0: erf(omega r12)/r12; omega < 0: the short-range complement erfc(|omega| r12)/r12, as libcint reads
+        # env[PTR_RANGE_OMEGA] (pyscf/gto/mole.py:76-84) - generated as Coulomb minus long-range, two kernel passes
         self.omega = float(omega)
         self.lib = _lib_mod.load_library()
         self.ao = _Shells(mol._atm, mol._bas, mol._env)
@@ -313,6 +313,9 @@ class IntEngine:
         a.tril = tril
         a.npairs = i1 - i0
         a.omega = getattr(self, '_omega_override', self.omega)
+        if a.omega < 0:
+            raise NotImplementedError('short-range (omega < 0) integrals are generated by int3c2e_slab / int2c2e as Coulomb '
+                                      'minus long-range; the gradient kernels have no such second pass')
 
     # -- integrals ------------------------------------------------------------------------
     def slab_rows(self, sh0, sh1):
@@ -321,8 +324,21 @@ class IntEngine:
         p1 = int(self.ao.ao0[sh1]) if sh1 < self.ao.n else self.ao.nao
         return p0 * (p0 + 1) // 2, p1 * (p1 + 1) // 2
 
+    def _short_range(self, fn, *args, out=None):
+        """Coulomb pass into out, long-range pass (|omega|) into a scratch tensor, difference in place."""
+        try:
+            self._omega_override = 0.0
+            full = fn(*args, out=out)
+            self._omega_override = -self.omega
+            full -= fn(*args, out=None)
+        finally:
+            del self._omega_override
+        return full
+
     def int3c2e_slab(self, sh0, sh1, out=None):
         """T[pq - r0][Q] = (pq|Q) for the AO rows of shells [sh0, sh1); device tensor."""
+        if self.omega < 0 and not hasattr(self, '_omega_override'):
+            return self._short_range(self.int3c2e_slab, sh0, sh1, out=out)
         r0, r1 = self.slab_rows(sh0, sh1)
         naux = self.aux.nao
         if out is None:
@@ -347,8 +363,10 @@ class IntEngine:
                 out.append(pc)
         return out
 
-    def int2c2e(self):
+    def int2c2e(self, out=None):
         """(P|Q) over the aux basis, (naux, naux) device tensor (GTOint2c analogue)."""
+        if self.omega < 0 and not hasattr(self, '_omega_override'):
+            return self._short_range(self.int2c2e)
         torch = self.torch
         naux = self.aux.nao
         out = torch.zeros((naux, naux), dtype=torch.float64, device=self.device)

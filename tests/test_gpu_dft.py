@@ -213,8 +213,8 @@ def test_uks_pbe_closed_shell_limit_equals_rks():
 
 def test_golden_rsh_custom_functional_energy():
     """pyscf/df/test/test_df.py:135-147: HF molecule, cc-pVDZ, DF-RKS with xc = 'lda+0.5*SR_HF(0.3)':
-    E = -103.4965622991 (6 places).  Slater exchange plus half of the short-range exact exchange,
-    K_SR = K_full - K_LR(0.3) from the Coulomb and the erf-attenuated tensors."""
+    E = -103.4965622991 (6 places).  Slater exchange plus half of the short-range exact exchange from the
+    erfc-attenuated tensor (get_k(omega=-0.3), dft/rks.py:114-117)."""
     from pyscf_amd import gto, dft
     from pyscf_amd.dft import libxc
     assert libxc.parse_xc_rsh('lda+0.5*SR_HF(0.3)')[:3] == (0.5, 0.0, 0.3)
@@ -222,7 +222,8 @@ def test_golden_rsh_custom_functional_energy():
     mol = gto.M(atom='H 0 0 0; F 0 0 1.1', basis='ccpvdz')
     mf = dft.RKS(mol, xc='lda+0.5*SR_HF(0.3)').density_fit()
     e = mf.kernel()
-    assert mf.converged and abs(e - -103.4965622991) < 2e-6, e
+    assert mf.converged and abs(e - -103.4965622991) < 5e-7, e
+    assert '-0.300000' in mf.with_df._rsh_df                 # the short-range tensor was the one built
 
 
 def test_golden_eval_gto_fingerprints():
@@ -236,3 +237,53 @@ def test_golden_eval_gto_fingerprints():
     assert ao.shape == (4, 100, 60)
     assert abs(ref.fp(ao[0]) - -3.0283379087553808) < 1e-10
     assert abs(ref.fp(ao[1:]) - -14.526634330008513) < 1e-9
+
+
+def _grid_cases():
+    from tests.test_oracle_dft_golden import GRID_GOLDENS
+    return GRID_GOLDENS
+
+
+@pytest.mark.parametrize('name,conf,gold', _grid_cases(), ids=[g[0] for g in _grid_cases()])
+def test_grid_scheme_goldens_device(name, conf, gold):
+    """pyscf/dft/test/test_grids.py:54-115,187-207 through Grids.build (partition on the device, PAMD_grid_partition)."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import gen_grid, radi
+    from tests.test_oracle_dft_golden import H2O_GRID, check_grid_golden
+    mol = gto.M(atom=H2O, basis='6-31g')
+    g = dft.Grids(mol)
+    g.atom_grid = conf.get('atom_grid', H2O_GRID)
+    g.radi_method = getattr(radi, conf.get('radi', 'treutler'))
+    g.prune = {None: None, 'sg1': gen_grid.sg1_prune, 'nwchem': gen_grid.nwchem_prune}[conf['prune']]
+    adjust = conf.get('adjust', 'treutler')
+    g.radii_adjust = None if adjust is None else getattr(radi, adjust + '_atomic_radii_adjust')
+    if conf.get('radii') == 'covalent':
+        g.atomic_radii = radi.COVALENT_RADII
+    g.becke_scheme = {'becke': gen_grid.original_becke, 'stratmann': gen_grid.stratmann}[conf.get('scheme', 'becke')]
+    g.alignment = conf.get('alignment', 8)
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = conf.get('specific', False)
+    try:
+        g.build()
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    check_grid_golden(g.coords, g.weights, gold)
+
+
+@pytest.mark.parametrize('scheme', ['stratmann', 'lko'])
+def test_partition_schemes_vs_oracle(scheme):
+    """The Stratmann and Laqua-Kussmann-Ochsenfeld cell functions of PAMD_grid_partition against the numpy restatement
+    (gen_grid.py:203-212,388-404; grid_basis.c:236-247,266-384) on a four-element cluster, default grids."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import gen_grid
+    mol = gto.M(atom='H 0 0 -0.5; C 0 1 .1; O 0 0 .5; F 1 .3 .5', unit='B', basis='sto-3g')
+    g = dft.Grids(mol)
+    g.becke_scheme = {'stratmann': gen_grid.stratmann, 'lko': gen_grid.becke_lko}[scheme]
+    g.build()
+    c, w = ref_dft.build_grids(mol, scheme=scheme)
+    assert g.size == len(w)
+    assert np.abs(g.coords - c).max() < 1e-12
+    assert np.abs(g.weights - w).max() < 1e-11 * np.abs(w).max()
+    # quadrature sanity: a normalised s-Gaussian on the carbon atom integrates to 1 with either partition
+    r2 = ((g.coords - mol.atom_coords()[1]) ** 2).sum(axis=1)
+    assert abs((g.weights * np.exp(-1.3 * r2)).sum() * (1.3 / np.pi) ** 1.5 - 1) < 1e-5

@@ -84,5 +84,36 @@ def test_long_range_integrals_and_rsh_get_jk(h2o_dz):
     assert abs(ref.fp(vk) - -37.78854217974532) < 5e-4
     vj0, vk0 = obj.get_jk(dm, hermi=0)                       # the Coulomb tensor is a separate object
     assert abs(ref.fp(vj0) - ref.fp(vj)) > 1.0
-    with pytest.raises(NotImplementedError):
-        obj.get_jk(dm, hermi=0, omega=-0.5)
+
+
+def test_short_range_integrals_and_get_jk():
+    """omega < 0 (libcint's convention for erfc(|omega| r12)/r12, pyscf/gto/mole.py:76-84 - what get_veff asks for when
+    a functional has short-range exact exchange only, dft/rks.py:114-117): 3- and 2-centre integrals vs the oracle,
+    SR + LR = Coulomb at the integral level, DF.get_jk(omega < 0) and the integral-direct J vs the oracle's short-range
+    Cholesky tensor."""
+    from pyscf_amd import gto, df
+    from pyscf_amd.df import incore, df_jk
+    from pyscf_amd.gto.moleintor import IntEngine
+    from tests.conftest import H2O
+    mol = gto.M(atom=LOWSYM, basis='cc-pvtz', spin=1)
+    aux = gto.M(atom=LOWSYM, basis='cc-pvtz-jkfit', spin=1)
+    got = incore.aux_e2_gpu(mol, aux, _dev(), omega=-0.3).cpu().numpy()
+    want = ref.pack_tril(ref.int3c2e(mol, aux, -0.3))
+    assert np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max())
+    full = incore.aux_e2_gpu(mol, aux, _dev()).cpu().numpy()
+    lr = incore.aux_e2_gpu(mol, aux, _dev(), omega=0.3).cpu().numpy()
+    assert np.abs(got + lr - full).max() < 1e-12 * np.abs(full).max()
+    j2c = IntEngine(mol, aux, _dev(), -0.3).int2c2e().cpu().numpy()
+    w2 = ref.int2c2e(aux, -0.3)
+    assert np.abs(j2c - w2).max() < 1e-11 * np.abs(w2).max()
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    obj = df.DF(mol)
+    np.random.seed(1)
+    dm = np.random.random((2, mol.nao, mol.nao))
+    vj, vk = obj.get_jk(dm, hermi=0, omega=-0.5)
+    cd = ref.cholesky_eri(mol, df.make_auxmol(mol), omega=-0.5)
+    vj1, vk1 = ref.get_jk(cd, dm, hermi=0)
+    assert np.abs(vj - vj1).max() < 1e-9 and np.abs(vk - vk1).max() < 1e-9
+    dsym = dm[0] + dm[0].T
+    vjd = df_jk.get_j(obj.range_coulomb(-0.5), dsym)          # integral-direct J generates the same short-range slabs
+    assert np.abs(vjd - ref.get_jk(cd, dsym, hermi=1, with_k=False)[0]).max() < 1e-9

@@ -118,3 +118,93 @@ def test_oracle_eval_ao_reference_fingerprints():
     ao = ref_dft.eval_ao(mol, r, 1)
     assert abs(ref.fp(ao[0]) - -3.0283379087553808) < 1e-11
     assert abs(ref.fp(ao[1:]) - -14.526634330008513) < 1e-10
+
+
+# (radial scheme, pruning, radii adjust, atomic radii, atom_grid, cell function, alignment, atom-specific Treutler xi) -> golden
+# norms / fingerprints of pyscf/dft/test/test_grids.py:54-115,187-207.  None = not pinned by the reference.
+H2O_GRID = {'H': (10, 50), 'O': (10, 50)}
+GRID_GOLDENS = [
+    ('gc_stratmann', dict(radi='gauss_chebyshev', prune=None, adjust='becke', scheme='stratmann', alignment=0),
+     dict(nw=1730.3692983091271)),                                                                      # :67-69
+    ('gc_stratmann_noadjust', dict(radi='gauss_chebyshev', prune=None, adjust=None, scheme='stratmann', alignment=0,
+                                   atom_grid={'O': (10, 50)}), dict(nw=2559.0064040257907)),            # :71-75
+    ('gc_order11', dict(radi='gauss_chebyshev', prune=None, adjust=None, alignment=0, atom_grid=(10, 11)),
+     dict(nw=1712.3069450297105)),                                                                      # :77-81
+    ('mura_knowles_covalent', dict(radi='mura_knowles', prune=None, adjust='becke', radii='covalent'),
+     dict(nw=1804.5437331817291)),                                                                      # :83-91
+    ('delley_covalent', dict(radi='delley', prune=None, adjust='becke', radii='covalent'), dict(nw=1686.3482864673697)),
+    ('becke_covalent', dict(radi='becke', prune=None, adjust='becke', radii='covalent'), dict(fw=780.7183109298)),
+    ('sg1', dict(prune='sg1', alignment=0), dict(nc=202.17732600266302, nw=442.54536463517167)),        # :101-107
+    ('nwchem', dict(prune='nwchem', alignment=0), dict(nc=149.55023044392638, nw=586.36841824004455)),  # :109-112
+    ('treutler_specific', dict(prune=None, alignment=0, specific=True),
+     dict(fc=90.68472244567415, fw=-72.48186431034912)),                                                # :187-196
+    ('treutler_specific_sg1', dict(prune='sg1', alignment=0, specific=True),
+     dict(fc=-64.2641450749045, fw=-26.8795084011127)),                                                 # :198-206
+]
+
+
+def check_grid_golden(coords, weights, gold):
+    for key, val in gold.items():
+        arr = coords if key[1] == 'c' else weights
+        got = np.linalg.norm(arr) if key[0] == 'n' else ref.fp(arr)
+        assert abs(got - val) < 2e-9, (key, got, val)
+
+
+@pytest.mark.parametrize('name,conf,gold', GRID_GOLDENS, ids=[g[0] for g in GRID_GOLDENS])
+def test_grid_scheme_goldens(name, conf, gold):
+    """Radial schemes, pruning schemes, covalent radii, Lebedev-order input and the Stratmann cell function of the
+    oracle grid builder against the reference's own numbers."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import radi
+    mol = gto.M(atom=H2O, basis='6-31g')
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = conf.get('specific', False)         # test_grids.py:46-49,183-185
+    try:
+        c, w = ref_dft.build_grids(mol, conf.get('atom_grid', H2O_GRID), radi_method=getattr(radi, conf.get('radi', 'treutler')),
+                                   prune=conf['prune'], radii_adjust=conf.get('adjust', 'treutler'),
+                                   alignment=conf.get('alignment', 8), scheme=conf.get('scheme', 'becke'),
+                                   atomic_radii=radi.COVALENT_RADII if conf.get('radii') == 'covalent' else None)
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    check_grid_golden(c, w, gold)
+
+
+def test_prune_tables_and_bad_angular_grid():
+    """test_grids.py:114-129: SG-1 / NWChem angular orders for sulfur on a 50-point Gauss-Chebyshev axis; an angular count
+    that is neither a Lebedev point count nor an order is refused."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import gen_grid, radi
+    rad = radi.gauss_chebyshev(50)[0]
+    assert abs(ref.fp(gen_grid.sg1_prune(16, rad, 434, radii=radi.SG1RADII)) - -291.0794420982329) < 1e-9
+    assert abs(ref.fp(gen_grid.nwchem_prune(16, rad, 434, radii=radi.BRAGG_RADII)) - -180.12023039394498) < 1e-9
+    assert np.all(gen_grid.nwchem_prune(16, rad, 26, radii=radi.BRAGG_RADII) == 26)
+    mol = gto.M(atom=H2O, basis='6-31g')
+    with pytest.raises(ValueError):
+        gen_grid.gen_atomic_grids(mol, {'default': (10, 58), 'O': (10, 50)}, radi.treutler, 3, None)
+
+
+@pytest.mark.parametrize('adjust,gold', [('treutler', -13.101186585274547), ('becke', -163.85086096365865)])
+def test_weight_response_oracle_pinned(adjust, gold):
+    """pyscf/grad/test/test_rks.py:440-451,502-517: fingerprint of d w_g / d R_A (points riding on their owner atoms) of the
+    default grids of an H, C, O, F cluster with the Treutler and the Becke radii adjustment."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import gen_grid, radi
+    mol = gto.M(atom='H 0 0 -0.5; C 0 1 .1; O 0 0 .5; F 1 .3 .5', unit='B', basis='sto-3g')
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False                                # test_rks.py:224-226
+    try:
+        tab = gen_grid.gen_atomic_grids(mol, {}, radi.treutler, 3, gen_grid.nwchem_prune)
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    table = getattr(radi, adjust + '_atomic_radii_adjust')(mol, radi.BRAGG_RADII)
+    atm = mol.atom_coords()
+    cs, ws, ow = [], [], []
+    for ia in range(mol.natm):
+        c, vol = tab[mol.atom_symbol(ia)]
+        c = c + atm[ia]
+        pb = ref_dft.becke_partition(c, atm, table)
+        cs.append(c)
+        ws.append(vol * pb[ia] / pb.sum(axis=0))
+        ow.append(np.full(len(vol), ia))
+    dw = ref_dft.becke_weight_response(np.vstack(cs), np.hstack(ow), np.hstack(ws), atm, table)
+    assert abs(ref.fp(dw) - gold) < 1e-9, ref.fp(dw)

@@ -95,6 +95,32 @@ def test_long_range_df_jk_golden():
     assert np.abs(vj - vj1).max() < 1e-2 and np.abs(vk - vk1).max() < 1e-2
 
 
+def test_short_range_oracle_integrals_and_rsh_golden():
+    """omega < 0 = erfc(|omega| r12)/r12: short-range + long-range = Coulomb for the 4-, 3- and 2-centre oracle integrals,
+    and the reference's DF-RKS energy with short-range exact exchange only, xc = 'lda+0.5*SR_HF(0.3)' on HF / cc-pVDZ:
+    -103.4965622991 to the reference's 6 places (pyscf/df/test/test_df.py:135-147; K from the short-range tensor as
+    dft/rks.py:114-117)."""
+    from pyscf_amd import gto, df
+    from pyscf_amd.dft import libxc
+    from oracle import ref_dft
+    mol = gto.M(atom='H 0 0 0; F 0 0 1.1', basis='ccpvdz')
+    auxmol = df.make_auxmol(mol)
+    for fn, args in ((ref.int2e, (mol,)), (ref.int3c2e, (mol, auxmol)), (ref.int2c2e, (auxmol,))):
+        full, sr, lr = fn(*args), fn(*args, omega=-0.3), fn(*args, omega=0.3)
+        assert np.abs(sr + lr - full).max() < 1e-13 * np.abs(full).max()
+        assert np.abs(sr).max() > 1e-3 and np.abs(lr).max() > 1e-3
+    cd0 = ref.cholesky_eri(mol, auxmol)
+    cdsr = ref.cholesky_eri(mol, auxmol, omega=-0.3)
+    hyb, fac = libxc.parse_xc('lda+0.5*SR_HF(0.3)')
+    assert hyb == 0.5 and libxc.rsh_coeff('lda+0.5*SR_HF(0.3)') == (0.3, 0.0, 0.5)
+    coords, weights = ref_dft.build_grids(mol)
+
+    def get_jk(dm, c, occ, with_k):
+        return ref.get_jk(cd0, dm, 1, with_k=False)[0], ref.get_jk(cdsr, dm, 1)[1]
+    conv, e = ref_dft.rks_energy(mol, fac, hyb, False, coords, weights, get_jk)[:2]
+    assert conv and abs(e - -103.4965622991) < 5e-7, e
+
+
 def test_fd_gradient_oracle_pinned_by_reference_goldens():
     """pyscf/df/test/test_df_grad.py:61-65: the finite-difference gradient of the oracle's DF-RHF energy reproduces
     the reference's analytic-gradient fingerprint (its own tolerance is 7 places on an SCF converged to 1e-9).
