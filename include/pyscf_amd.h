@@ -192,6 +192,11 @@ int PAMD_xc_grad_rows(const double *d_ao, const double *d_c, const double *d_wv,
 int PAMD_becke_response(const double *d_coords, const int *d_owner, const double *d_weights, const double *d_e,
                         const double *d_pb, const double *d_atm_coords, const double *d_radii_table, int natm,
                         long ng, double *d_out, void *stream);
+/* same for the cell function `scheme` of PAMD_grid_partition: grad/rks.py grids_response_becke (0, 1 with the Stratmann
+ * switch) / grids_response_lko (2; lib/dft/grid_basis.c:386-560 VXCgen_grid_lko_deriv) */
+int PAMD_grid_response(const double *d_coords, const int *d_owner, const double *d_weights, const double *d_e,
+                       const double *d_pb, const double *d_atm_coords, const double *d_radii_table, int natm,
+                       long ng, int scheme, double *d_out, void *stream);
 int PAMD_scale_ao(const double *d_ao, const double *d_wv, int ldao, long ldg_rows, long ldg, int ncomp,
                   long ng, long nrows, double *d_aow, void *stream);     /* aow[g][ldao], rows ng..nrows-1 zero */
 int PAMD_dgemm_nt(const double *d_A, long lda, const double *d_B, long ldb, double *d_C, int ldc, int m,

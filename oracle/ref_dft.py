@@ -62,13 +62,37 @@ def becke_partition(coords, atm_coords, radii_table, scheme='becke'):
     return pb
 
 
-def becke_weight_response(coords, owner, weights, atm_coords, radii_table):
+def _lko_saturate_deriv(r):
+    """d/dr of _lko_saturate (grid_basis.c:249-264)."""
+    x = r / 5.0
+    tot = sum(x ** m / m for m in range(1, 13))
+    return np.exp(-tot) * sum(x ** (m - 1) for m in range(1, 13))
+
+
+def _cell_function(nu, scheme):
+    """h(nu) in [-1, 1] and h'(nu): P_B = prod_D (1 - h(nu_BD)) / 2."""
+    if scheme == 'stratmann':
+        ma = nu / .64
+        ma2 = ma * ma
+        h = (1 / 16.) * (ma * (35 + ma2 * (-35 + ma2 * (21 - 5 * ma2))))
+        dh = (35 / 16.) * (1 - ma2) ** 3 / .64
+        out = np.abs(nu) >= .64
+        return np.where(out, np.sign(nu), h), np.where(out, 0.0, dh)
+    p1 = (3 - nu * nu) * nu * .5
+    p2 = (3 - p1 * p1) * p1 * .5
+    p3 = (3 - p2 * p2) * p2 * .5
+    return p3, 1.5 * (1 - p2 * p2) * 1.5 * (1 - p1 * p1) * 1.5 * (1 - nu * nu)
+
+
+def becke_weight_response(coords, owner, weights, atm_coords, radii_table, scheme='becke'):
     """dw[natm][3][ngrids] = d w_g / d R_C of the Becke quadrature weights, the grid point moving rigidly with its
     owner atom (restatement of pyscf/grad/rks.py:grids_response_cc / get_vxc_full_response weight1; formulas of
     Johnson, Gill, Pople, JCP 98, 5612).  For C != owner the point is fixed:
         d ln P_B / dR_C = sum_{D != B} g_BD d mu_BD/dR_C,   g_BD = -p3'(nu_BD) (1 - 2 a_BD mu_BD) / (2 f_BD),
         d w / dR_C = w [ d ln P_owner/dR_C - sum_B (P_B / Z) d ln P_B/dR_C ];
-    the owner's own derivative follows from translational invariance."""
+    the owner's own derivative follows from translational invariance.  scheme 'stratmann' swaps the cell polynomial,
+    'lko' divides by the saturated distance S(R_BD) (so mu also moves through S'(R)) and clamps mu to [-1, 1]
+    (grids_response_lko, VXCgen_grid_lko_deriv grid_basis.c:386-560)."""
     natm = len(atm_coords)
     ng = len(coords)
     vec = coords[None, :, :] - atm_coords[:, None, :]                          # [natm][ng][3]
@@ -77,20 +101,24 @@ def becke_weight_response(coords, owner, weights, atm_coords, radii_table):
     f = np.ones((natm, natm, ng))
     gfac = np.zeros((natm, natm, ng))
     mu = np.zeros((natm, natm, ng))
+    sdist = np.ones((natm, natm))               # S(R_BD): the distance mu is scaled by
+    sfac = np.zeros((natm, natm))               # S'(R_BD) / S(R_BD)
     for b in range(natm):
         for dd in range(natm):
             if b == dd:
                 continue
             rbd = np.linalg.norm(atm_coords[b] - atm_coords[dd])
-            m = (d[b] - d[dd]) / rbd
+            sdist[b, dd] = _lko_saturate(rbd) if scheme == 'lko' else rbd
+            sfac[b, dd] = (_lko_saturate_deriv(rbd) if scheme == 'lko' else 1.0) / sdist[b, dd]
+            m = (d[b] - d[dd]) / sdist[b, dd]
+            inside = 1.0
+            if scheme == 'lko':
+                inside = (np.abs(m) < 1).astype(float)
+                m = np.clip(m, -1, 1)
             a = 0.0 if radii_table is None else radii_table[b, dd]
-            nu = m + a * (1 - m * m)
-            p1 = (3 - nu * nu) * nu * .5
-            p2 = (3 - p1 * p1) * p1 * .5
-            p3 = (3 - p2 * p2) * p2 * .5
-            dp3 = 1.5 * (1 - p2 * p2) * 1.5 * (1 - p1 * p1) * 1.5 * (1 - nu * nu)
-            f[b, dd] = .5 * (1 - p3)
-            gfac[b, dd] = -.5 * dp3 * (1 - 2 * a * m) / (f[b, dd] + 1e-200)
+            h, dh = _cell_function(m + a * (1 - m * m), scheme)
+            f[b, dd] = .5 * (1 - h)
+            gfac[b, dd] = -.5 * dh * (1 - 2 * a * m) / (f[b, dd] + 1e-200) * inside
             mu[b, dd] = m
     P = np.prod(f, axis=1)                                                      # [natm][ng]
     Z = P.sum(axis=0)
@@ -104,12 +132,12 @@ def becke_weight_response(coords, owner, weights, atm_coords, radii_table):
                         continue
                     n_cd = atm_coords[c] - atm_coords[dd]
                     rcd = np.linalg.norm(n_cd)
-                    dmu = -uhat[c] / rcd - mu[c, dd][:, None] * (n_cd / rcd)[None, :] / rcd     # d mu_CD / dR_C
+                    dmu = -uhat[c] / sdist[c, dd] - mu[c, dd][:, None] * (n_cd / rcd)[None, :] * sfac[c, dd]   # d mu_CD / dR_C
                     dlnP[c] += gfac[c, dd][:, None] * dmu
             else:
                 n_bc = atm_coords[b] - atm_coords[c]
                 rbc = np.linalg.norm(n_bc)
-                dmu = uhat[c] / rbc + mu[b, c][:, None] * (n_bc / rbc)[None, :] / rbc           # d mu_BC / dR_C
+                dmu = uhat[c] / sdist[b, c] + mu[b, c][:, None] * (n_bc / rbc)[None, :] * sfac[b, c]         # d mu_BC / dR_C
                 dlnP[b] = gfac[b, c][:, None] * dmu
         avg = np.einsum('bg,bgx->gx', P / Z, dlnP)
         own = dlnP[owner, np.arange(ng)]
@@ -407,14 +435,14 @@ def nr_rks_grad(mol, coords, weights, fac, gga, dm):
     return de
 
 
-def nr_rks_grad_response(mol, coords, weights, owner, radii_table, fac, gga, dm):
+def nr_rks_grad_response(mol, coords, weights, owner, radii_table, fac, gga, dm, scheme='becke'):
     """The two grid-response terms of pyscf/grad/rks.py get_vxc_full_response (:257-340) to be added to nr_rks_grad:
     sum_g e_g dw_g/dR_C (Becke weights follow the nuclei) and, for the points owned by atom C, the motion of the point
     itself: -2 sum_{mu nu} vmat_C[x]_{mu nu} D_{mu nu} with vmat_C restricted to C's points."""
     dm = (dm + dm.T) * .5
     de = np.zeros((mol.natm, 3))
     _, e = _vmat_grad(mol, coords, weights, fac, gga, dm)
-    dw = becke_weight_response(coords, owner, weights, mol.atom_coords(), radii_table)
+    dw = becke_weight_response(coords, owner, weights, mol.atom_coords(), radii_table, scheme)
     de += np.einsum('g,cxg->cx', e, dw)
     for ia in range(mol.natm):
         sel = owner == ia

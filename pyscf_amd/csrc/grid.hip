@@ -74,18 +74,49 @@ __global__ __launch_bounds__(256) void becke_kernel(double *__restrict__ out, co
 //   g_BD = -p3'(nu_BD) (1 - 2 a_BD mu_BD) / (2 f_BD),  f_BD = (1 - p3(nu_BD))/2,  nu = mu + a (1 - mu^2),
 // and the owner's derivative is minus the sum over the other atoms (translational invariance).
 // One thread per grid point, O(natm^2) pair terms recomputed on the fly; P_B/Z from the partition kernel's output.
-__device__ inline void becke_pair(double dB, double dD, double rBD, double a, double &mu, double &gfac)
+// With SCHEME 1 the cell polynomial p3 is the Stratmann septic h (h' = 35/(16 a) (1 - (nu/a)^2)^3 inside |nu| < a);
+// with SCHEME 2 mu is scaled by the saturated distance S(R_BD) instead of R_BD, so the atom derivatives of mu become
+// -+ u/S -+ mu S'(R)/S n/R, and mu is clamped to [-1, 1] (no derivative outside) - VXCgen_grid_lko_deriv,
+// grid_basis.c:386-560.
+template <int SCHEME>
+__device__ inline void becke_pair(double dB, double dD, double sBD, double a, double &mu, double &gfac)
 {
-    mu = (dB - dD) / rBD;
+    mu = (dB - dD) / sBD;
+    bool inside = true;
+    if (SCHEME == 2) {
+        inside = fabs(mu) < 1.0;
+        mu = fmin(1.0, fmax(-1.0, mu));
+    }
     const double nu = mu + a * (1 - mu * mu);
-    const double p1 = (3 - nu * nu) * nu * .5;
-    const double p2 = (3 - p1 * p1) * p1 * .5;
-    const double p3 = (3 - p2 * p2) * p2 * .5;
-    const double dp3 = 3.375 * (1 - p2 * p2) * (1 - p1 * p1) * (1 - nu * nu);
-    const double f = .5 * (1 - p3);
-    gfac = -.5 * dp3 * (1 - 2 * a * mu) / (f + 1e-200);
+    double h, dh;
+    if (SCHEME == 1) {
+        const double ma = nu / .64, ma2 = ma * ma;
+        const bool out = fabs(nu) >= .64;
+        h = out ? (nu > 0 ? 1.0 : -1.0) : (1 / 16.) * (ma * (35 + ma2 * (-35 + ma2 * (21 - 5 * ma2))));
+        dh = out ? 0.0 : (35 / 16.) * (1 - ma2) * (1 - ma2) * (1 - ma2) / .64;
+    } else {
+        const double p1 = (3 - nu * nu) * nu * .5;
+        const double p2 = (3 - p1 * p1) * p1 * .5;
+        h = (3 - p2 * p2) * p2 * .5;
+        dh = 3.375 * (1 - p2 * p2) * (1 - p1 * p1) * (1 - nu * nu);
+    }
+    const double f = .5 * (1 - h);
+    gfac = inside ? -.5 * dh * (1 - 2 * a * mu) / (f + 1e-200) : 0.0;
 }
 
+__device__ inline double lko_saturate_deriv(double r)
+{
+    const double x = r / 5.0;
+    double xm = 1, tot = 0, dtot = 0;
+    for (int m = 1; m <= 12; m++) {
+        dtot += xm;
+        xm *= x;
+        tot += xm / m;
+    }
+    return exp(-tot) * dtot;
+}
+
+template <int SCHEME>
 __global__ __launch_bounds__(256) void becke_response_kernel(
     const double *__restrict__ coords, const int *__restrict__ owner, const double *__restrict__ weights,
     const double *__restrict__ e, const double *__restrict__ pb, const double *__restrict__ atm,
@@ -114,21 +145,23 @@ __global__ __launch_bounds__(256) void becke_response_kernel(
             const double dB = sqrt((x - bx) * (x - bx) + (y - by) * (y - by) + (z - bz) * (z - bz));
             const double nx = bx - cx, ny = by - cy, nz = bz - cz;             // R_B - R_C
             const double rbc = sqrt(nx * nx + ny * ny + nz * nz);
-            const double rinv = 1.0 / rbc;
-            // B's cell function seen from C: d mu_BC / dR_C = u_C / R + mu_BC n_BC / R^2
+            const double sbc = (SCHEME == 2) ? lko_saturate(rbc) : rbc;        // S(R)
+            const double rinv = 1.0 / sbc;                                     // 1 / S
+            const double kinv = ((SCHEME == 2) ? lko_saturate_deriv(rbc) : 1.0) / (sbc * rbc);   // S'(R) / (S R)
+            // B's cell function seen from C: d mu_BC / dR_C = u_C / S + mu_BC S'/S n_BC / R
             double mu, gf;
-            becke_pair(dB, dC, rbc, radii ? radii[b * natm + c] : 0.0, mu, gf);
-            const double tbx = gf * (uhx * rinv + mu * nx * rinv * rinv);
-            const double tby = gf * (uhy * rinv + mu * ny * rinv * rinv);
-            const double tbz = gf * (uhz * rinv + mu * nz * rinv * rinv);
+            becke_pair<SCHEME>(dB, dC, sbc, radii ? radii[b * natm + c] : 0.0, mu, gf);
+            const double tbx = gf * (uhx * rinv + mu * nx * kinv);
+            const double tby = gf * (uhy * rinv + mu * ny * kinv);
+            const double tbz = gf * (uhz * rinv + mu * nz * kinv);
             const double wb = pb[(long)b * ng + gg] * zinv;
             avg[0] += wb * tbx; avg[1] += wb * tby; avg[2] += wb * tbz;
             if (b == own) { ownt[0] = tbx; ownt[1] = tby; ownt[2] = tbz; }
             // C's own cell function: d mu_CB / dR_C = -u_C / R - mu_CB n_CB / R^2, n_CB = R_C - R_B = -n
-            becke_pair(dC, dB, rbc, radii ? radii[c * natm + b] : 0.0, mu, gf);
-            self[0] += gf * (-uhx * rinv + mu * nx * rinv * rinv);
-            self[1] += gf * (-uhy * rinv + mu * ny * rinv * rinv);
-            self[2] += gf * (-uhz * rinv + mu * nz * rinv * rinv);
+            becke_pair<SCHEME>(dC, dB, sbc, radii ? radii[c * natm + b] : 0.0, mu, gf);
+            self[0] += gf * (-uhx * rinv + mu * nx * kinv);
+            self[1] += gf * (-uhy * rinv + mu * ny * kinv);
+            self[2] += gf * (-uhz * rinv + mu * nz * kinv);
         }
         const double wc = pb[(long)c * ng + gg] * zinv;
         double v[3];
@@ -338,6 +371,9 @@ extern "C" {
 
 int PAMD_grid_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
                         const double *d_radii_table, int natm, long ngrids, int scheme, void *stream);
+int PAMD_grid_response(const double *d_coords, const int *d_owner, const double *d_weights, const double *d_e,
+                       const double *d_pb, const double *d_atm_coords, const double *d_radii_table, int natm,
+                       long ng, int scheme, double *d_out, void *stream);
 
 int PAMD_becke_partition(double *d_out, const double *d_coords, const double *d_atm_coords,
                          const double *d_radii_table, int natm, long ngrids, void *stream)
@@ -368,9 +404,25 @@ int PAMD_becke_response(const double *d_coords, const int *d_owner, const double
                         const double *d_pb, const double *d_atm_coords, const double *d_radii_table, int natm,
                         long ng, double *d_out, void *stream)
 {
+    return PAMD_grid_response(d_coords, d_owner, d_weights, d_e, d_pb, d_atm_coords, d_radii_table, natm, ng, 0, d_out, stream);
+}
+
+// Same for the cell function `scheme` of PAMD_grid_partition (d_pb from that call with the same scheme): 0 Becke
+// (grids_response_becke), 1 Stratmann (same routine with the Stratmann switch), 2 LKO (grids_response_lko).
+int PAMD_grid_response(const double *d_coords, const int *d_owner, const double *d_weights, const double *d_e,
+                       const double *d_pb, const double *d_atm_coords, const double *d_radii_table, int natm,
+                       long ng, int scheme, double *d_out, void *stream)
+{
+    PAMD_REQUIRE(scheme >= 0 && scheme <= 2, "grid_response: scheme must be 0 (becke), 1 (stratmann) or 2 (lko)");
     if (ng == 0 || natm == 0) return 0;
-    becke_response_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(d_coords, d_owner, d_weights, d_e, d_pb,
-                                                                              d_atm_coords, d_radii_table, natm, ng, d_out);
+    const dim3 grid(ceil_div(ng, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (scheme == 0)
+        becke_response_kernel<0><<<grid, 256, 0, st>>>(d_coords, d_owner, d_weights, d_e, d_pb, d_atm_coords, d_radii_table, natm, ng, d_out);
+    else if (scheme == 1)
+        becke_response_kernel<1><<<grid, 256, 0, st>>>(d_coords, d_owner, d_weights, d_e, d_pb, d_atm_coords, d_radii_table, natm, ng, d_out);
+    else
+        becke_response_kernel<2><<<grid, 256, 0, st>>>(d_coords, d_owner, d_weights, d_e, d_pb, d_atm_coords, d_radii_table, natm, ng, d_out);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

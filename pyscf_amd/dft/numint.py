@@ -399,15 +399,14 @@ class NumInt:
         import torch
         natm = mol.natm
         from . import gen_grid
-        if gen_grid.scheme_id(grids.becke_scheme) != 0:
-            raise NotImplementedError('grid response is built for the original Becke partition only (grad/rks.py:457-560)')
+        scheme = gen_grid.scheme_id(grids.becke_scheme)
         owner = np.zeros(grids.size, np.int32)
         owner[:len(grids.atm_idx)] = grids.atm_idx                    # alignment padding: weight 0, any owner
         table = None
         if callable(grids.radii_adjust) and grids.atomic_radii is not None:
             table = grids.radii_adjust(mol, grids.atomic_radii)
         f64 = torch.float64
-        return dict(natm=natm, owner=torch.from_numpy(owner).to(dev),
+        return dict(natm=natm, scheme=scheme, owner=torch.from_numpy(owner).to(dev),
                     atm=torch.from_numpy(np.ascontiguousarray(mol.atom_coords())).to(dev),
                     table=None if table is None else torch.from_numpy(np.ascontiguousarray(table)).to(dev),
                     pb=torch.empty((natm, blk), dtype=f64, device=dev), exc=torch.zeros(blk, dtype=f64, device=dev),
@@ -421,11 +420,11 @@ class NumInt:
         natm = resp['natm']
         pbv = resp['pb'].view(-1)[:natm * ng].view(natm, ng)
         tptr = _ptr(resp['table']) if resp['table'] is not None else _c.c_void_p(0)
-        self._call('becke', lib.PAMD_becke_partition, _ptr(pbv), _ptr(coords_dev[g0:g0 + ng]), _ptr(resp['atm']), tptr,
-                   _c.c_int(natm), _c.c_long(ng), st)
-        self._call('becke_response', lib.PAMD_becke_response, _ptr(coords_dev[g0:g0 + ng]), _ptr(resp['owner'][g0:g0 + ng]),
+        self._call('becke', lib.PAMD_grid_partition, _ptr(pbv), _ptr(coords_dev[g0:g0 + ng]), _ptr(resp['atm']), tptr,
+                   _c.c_int(natm), _c.c_long(ng), _c.c_int(resp['scheme']), st)
+        self._call('becke_response', lib.PAMD_grid_response, _ptr(coords_dev[g0:g0 + ng]), _ptr(resp['owner'][g0:g0 + ng]),
                    _ptr(weights_dev[g0:g0 + ng]), _ptr(resp['evol']), _ptr(pbv), _ptr(resp['atm']), tptr,
-                   _c.c_int(natm), _c.c_long(ng), _ptr(resp['de_w']), st)
+                   _c.c_int(natm), _c.c_long(ng), _c.c_int(resp['scheme']), _ptr(resp['de_w']), st)
         resp['rows'].zero_()
         for ao, c, wv in operands:
             self._call('xc_grad_rows', lib.PAMD_xc_grad_rows, _ptr(ao), _ptr(c), _ptr(wv), _c.c_int(ldao), _c.c_long(blk),

@@ -210,6 +210,36 @@ def test_xc_grid_response_vs_oracle(xc):
     assert np.abs(got2 - got).max() < 1e-10
 
 
+@pytest.mark.parametrize('scheme,scale', [('stratmann', 1.0), ('lko', 1.0), ('lko', 2.5)])
+def test_xc_grid_response_other_partitions(scheme, scale):
+    """grid_response with the Stratmann and the LKO cell functions (PAMD_grid_partition / PAMD_grid_response, scheme 1 / 2)
+    against the numpy restatement, itself equal to finite differences of the weights (tests/test_oracle_dft_golden.py;
+    the reference checks the same way, grad/test/test_rks.py:519-570).  The stretched geometry puts the interatomic
+    distances where the LKO saturation S(R) != R matters."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import libxc, gen_grid
+    from oracle import ref_dft
+    atoms = [(a, tuple(scale * x for x in xyz)) for a, xyz in
+             (('O', (0.1, -0.2, 0.05)), ('C', (0.25, 0.4, 1.15)), ('H', (0.95, -0.3, -0.35)))]
+    mol = gto.M(atom=atoms, basis='cc-pvdz')
+    grids = dft.Grids(mol)
+    grids.atom_grid = (20, 50)
+    grids.becke_scheme = {'stratmann': gen_grid.stratmann, 'lko': gen_grid.becke_lko}[scheme]
+    grids.build()
+    hyb, fac = libxc.parse_xc('lda,vwn')
+    rng = np.random.default_rng(11)
+    c = np.linalg.qr(rng.standard_normal((mol.nao, mol.nao)))[0] * 0.7
+    dm = 2 * c[:, :5].dot(c[:, :5].T)
+    n = len(grids.atm_idx)
+    table = grids.radii_adjust(mol, grids.atomic_radii)
+    want = (ref_dft.nr_rks_grad(mol, grids.coords[:n], grids.weights[:n], fac, False, dm) +
+            ref_dft.nr_rks_grad_response(mol, grids.coords[:n], grids.weights[:n], grids.atm_idx, table, fac, False, dm,
+                                         scheme=scheme))
+    got = dft.NumInt().nr_rks_grad(mol, grids, 'lda,vwn', dm, grid_response=True)
+    assert np.abs(got - want).max() < 5e-8 * max(1.0, np.abs(want).max()), (got, want)
+    assert abs(got.sum(axis=0)).max() < 1e-9
+
+
 def test_df_ks_gradients_with_grid_response_goldens():
     """grid_response=True: pyscf/grad/test/test_rks.py:285-288 (DF-RKS LDA,VWN 6-31G: lib.fp(g) = -0.04990623577718451,
     5 places) and pyscf/df/test/test_df_grad.py:144-145 (DF-UKS H2O+ : -0.12093220332146028, 7 places); the RKS gradient

@@ -208,3 +208,42 @@ def test_weight_response_oracle_pinned(adjust, gold):
         ow.append(np.full(len(vol), ia))
     dw = ref_dft.becke_weight_response(np.vstack(cs), np.hstack(ow), np.hstack(ws), atm, table)
     assert abs(ref.fp(dw) - gold) < 1e-9, ref.fp(dw)
+
+
+@pytest.mark.parametrize('scheme,scale,adjust', [('becke', 1.0, True), ('stratmann', 1.0, True), ('stratmann', 1.0, False),
+                                                 ('lko', 1.0, True), ('lko', 3.0, True)])
+def test_weight_response_oracle_vs_finite_differences(scheme, scale, adjust):
+    """d w_g / d R_A of the three cell functions against central differences of the weights (the reference's own check of
+    its Stratmann response, grad/test/test_rks.py:519-570, same cluster and step; 5e-7 there).  scale 3 stretches the
+    cluster so that the LKO saturated distance differs from the plain one."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import gen_grid, radi
+    atoms = ['H', 'C', 'O', 'F']
+    xyz0 = scale * np.array([(0., 0., -0.49999), (0., 1., .1), (0., 0., .5), (1., .3, .5)])
+
+    def weights(xyz):
+        mol = gto.M(atom=[(a, tuple(x)) for a, x in zip(atoms, xyz)], unit='B', basis='sto-3g')
+        tab = gen_grid.gen_atomic_grids(mol, {'default': (15, 26)}, radi.treutler, 3, None)
+        table = radi.treutler_atomic_radii_adjust(mol, radi.BRAGG_RADII) if adjust else None
+        atm = mol.atom_coords()
+        cs, ws, ow = [], [], []
+        for ia in range(mol.natm):
+            c, vol = tab[mol.atom_symbol(ia)]
+            c = c + atm[ia]
+            pb = ref_dft.becke_partition(c, atm, table, scheme)
+            cs.append(c)
+            ws.append(vol * pb[ia] / pb.sum(axis=0))
+            ow.append(np.full(len(vol), ia))
+        return np.vstack(cs), np.hstack(ws), np.hstack(ow), atm, table
+    c, w, ow, atm, table = weights(xyz0)
+    dw = ref_dft.becke_weight_response(c, ow, w, atm, table, scheme)
+    h = 5e-6
+    for ia, k in ((0, 2), (1, 1), (2, 0), (3, 2)):
+        xp, xm = xyz0.copy(), xyz0.copy()
+        xp[ia, k] += h
+        xm[ia, k] -= h
+        fd = (weights(xp)[1] - weights(xm)[1]) / (2 * h)
+        assert np.abs(fd - dw[ia, k]).max() < 5e-7 * max(1.0, np.abs(dw).max() / 100), (ia, k)
+    if scheme == 'lko':
+        plain = ref_dft.becke_weight_response(c, ow, w, atm, table, 'becke')
+        assert (np.abs(plain - dw).max() > 1e-3) == (scale > 1)      # the saturation only matters at long distances
