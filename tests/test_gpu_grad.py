@@ -221,7 +221,7 @@ def test_xc_grid_response_other_partitions(scheme, scale):
     from oracle import ref_dft
     atoms = [(a, tuple(scale * x for x in xyz)) for a, xyz in
              (('O', (0.1, -0.2, 0.05)), ('C', (0.25, 0.4, 1.15)), ('H', (0.95, -0.3, -0.35)))]
-    mol = gto.M(atom=atoms, basis='cc-pvdz')
+    mol = gto.M(atom=atoms, basis='cc-pvdz', spin=1)
     grids = dft.Grids(mol)
     grids.atom_grid = (20, 50)
     grids.becke_scheme = {'stratmann': gen_grid.stratmann, 'lko': gen_grid.becke_lko}[scheme]
