@@ -33,6 +33,7 @@ class DF:
         self.k_block_bytes = 8 << 30
         self.k_nsplit = 4
         self.lindep = 1e-7         # pyscf/df/incore.py:33
+        self.decompose_j2c = 'CD'  # 'ED': eigen-decompose the metric even when it is positive definite (df/grad/rhf.py:45)
         self.omega = 0.0           # > 0: long-range, < 0: short-range tensor (set by range_coulomb)
         self._rsh_df = {}
         self.incore_anyway = False  # mol.incore_anyway analogue (df_jk.py:282): force the tensor path
@@ -217,7 +218,8 @@ class DF:
         self._naux = self.auxmol.nao_nr()
         l0, l1 = self.shard_range(self._naux, self.rank, self.world_size)
         self._cderi_dev = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1,
-                                                  lindep=self.lindep, omega=self.omega)
+                                                  lindep=self.lindep, omega=self.omega,
+                                                  decompose_j2c=self.decompose_j2c)
         if isinstance(self._cderi_to_save, str):
             self.save(self._cderi_to_save)
         return self
@@ -335,6 +337,7 @@ class DF:
             obj.omega = float(omega)
             obj.auxmol = self.auxmol
             obj.k_block_bytes, obj.k_nsplit, obj.lindep = self.k_block_bytes, self.k_nsplit, self.lindep
+            obj.decompose_j2c = self.decompose_j2c
             self._rsh_df[key] = obj
         return self._rsh_df[key]
 

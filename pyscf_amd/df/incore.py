@@ -18,21 +18,24 @@ from ..gto.moleintor import IntEngine, get_engine
 LINEAR_DEP_THR = 1e-7   # pyscf/df/incore.py:33
 
 
-def _decompose_j2c(j2c, lindep):
-    """-> (M^T with cderi = M (Q|pq), triangular flag).  M = L^-1 or the eig fallback."""
-    try:
-        low = scipy.linalg.cholesky(j2c, lower=True)
-        linv = scipy.linalg.solve_triangular(low, np.eye(len(low)), lower=True, check_finite=False)
-        return linv, True
-    except scipy.linalg.LinAlgError:
-        w, v = scipy.linalg.eigh(j2c)
-        mask = w > lindep
-        v = v[:, mask] / np.sqrt(w[mask])
-        return v.T, False
+def _decompose_j2c(j2c, lindep, decompose='CD'):
+    """-> (M with cderi = M (Q|pq), triangular flag).  M = L^-1 or, when the Cholesky factorisation fails or 'ED' is
+    asked for (the decompose_j2c switch of pyscf/df/grad/rhf.py:423-443), (V / sqrt(w))^T over the eigenvalues > lindep."""
+    if decompose.upper() == 'CD':
+        try:
+            low = scipy.linalg.cholesky(j2c, lower=True)
+            linv = scipy.linalg.solve_triangular(low, np.eye(len(low)), lower=True, check_finite=False)
+            return linv, True
+        except scipy.linalg.LinAlgError:
+            pass
+    w, v = scipy.linalg.eigh(j2c)
+    mask = w > lindep
+    v = v[:, mask] / np.sqrt(w[mask])
+    return v.T, False
 
 
 def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_THR,
-                     slab_bytes=24 << 30, engine=None, return_engine=False, omega=0.0):
+                     slab_bytes=24 << 30, engine=None, return_engine=False, omega=0.0, decompose_j2c='CD'):
     """Rows [l0, l1) of cderi (naux, nao_pair) as a torch CUDA tensor."""
     import torch
     lib = _lib_mod.load_library()
@@ -42,7 +45,7 @@ def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_TH
     npair = nao * (nao + 1) // 2
     j2c = eng.int2c2e().cpu().numpy()
     j2c = (j2c + j2c.T) * .5
-    M, tri = _decompose_j2c(j2c, lindep)
+    M, tri = _decompose_j2c(j2c, lindep, decompose_j2c)
     nrow_total = M.shape[0]
     if l0 is None:
         l0, l1 = 0, nrow_total

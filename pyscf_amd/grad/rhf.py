@@ -22,10 +22,10 @@ The derivative on the third centre comes from translational invariance inside th
 import ctypes as _c
 
 import numpy as np
-import scipy.linalg
 
 from .. import lib as _lib_mod
 from ..df import df_jk
+from ..df.incore import _decompose_j2c
 from ..gto.moleintor import _AuxClass, _Shells, _dev, c2s_matrix, get_engine
 
 NREP = 64          # replicated accumulators: spreads the FP64 atomics of the contraction kernel
@@ -66,11 +66,14 @@ def _pack_tril_dev(m):
     return m.reshape(*m.shape[:-2], nao * nao)[..., idx]
 
 
-def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, low):
-    """Z_T[pq][Q] (nao_pair, naux) and Y[P][Q] (naux, naux) of the module docstring, on the device.
+def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale=1.0):
+    """Z_T[pq][Q] (nao_pair, naux) and Y[P][Q] (naux, naux) of the module docstring, on the device; the Coulomb part
+    scaled by jscale (0 for the exchange-only terms of range-separated hybrids).
 
     occ_blocks: [(C (nao, nocc) with D_s = C C^T, weight)], e.g. RHF [(C_occ, 2)], UHF [(Ca, 1), (Cb, 1)].
-    low: lower Cholesky factor of the metric (host)."""
+    mh: (rows of cderi, naux) host matrix with cderi = mh (Q|pq), i.e. L^-1 of the metric's Cholesky factor or, for a
+    linearly dependent metric, (V / sqrt(w))^T - then M^-1 of the docstring is the pseudo-inverse mh^T mh held fixed, as
+    in the reference's 'ED' solver (df/grad/rhf.py:434-443)."""
     import torch
     so = _lib_mod.load_library()
     cderi = dfobj._cderi_dev
@@ -84,9 +87,9 @@ def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, low):
     dsum = dtril * 2
     diag = torch.from_numpy(np.arange(nao) * (np.arange(nao) + 1) // 2 + np.arange(nao)).to(dev)
     dsum[diag] *= .5
-    rho = cderi @ dsum                                           # rho_L = sum_pq B_L,pq D_pq (full square)
+    rho = cderi @ dsum * jscale                                  # rho_L = sum_pq B_L,pq D_pq (full square)
     W = rho[:, None] * dtril[None, :]                            # [L][pq]
-    ytil = -0.5 * torch.outer(rho, rho)
+    ytil = -0.5 / jscale * torch.outer(rho, rho) if jscale else torch.zeros((naux, naux), dtype=f64, device=dev)
     ldx = (nao + 15) // 16 * 16
     for c, wgt in occ_blocks:
         nocc = c.shape[1]
@@ -107,20 +110,21 @@ def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, low):
             cyc = torch.matmul(c_dev, torch.matmul(y, c_dev.T))  # C y_L C^T
             W[b0:b0 + nb] -= kscale * wgt * _pack_tril_dev(cyc)
         ytil += 0.5 * kscale * wgt * (ys @ ys.T)
-    linv = torch.from_numpy(scipy.linalg.solve_triangular(low, np.eye(naux), lower=True)).to(dev)
-    z_t = torch.empty((npair, naux), dtype=f64, device=dev)      # Z_T[pq][Q] = sum_L W[L][pq] Linv[L][Q]
-    step = max(1, int((2 << 30) // (naux * 8)))
+    linv = torch.from_numpy(np.ascontiguousarray(mh)).to(dev)
+    nq = linv.shape[1]
+    z_t = torch.empty((npair, nq), dtype=f64, device=dev)        # Z_T[pq][Q] = sum_L W[L][pq] Linv[L][Q]
+    step = max(1, int((2 << 30) // (nq * 8)))
     for p0 in range(0, npair, step):
         torch.matmul(W[:, p0:p0 + step].T, linv, out=z_t[p0:p0 + step])
     y_pq = linv.T @ ytil @ linv
     return z_t, y_pq
 
 
-def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_response=True, device=None):
-    """Electronic gradient (natm, 3) of a DF-HF-type energy with total density dm_tot, exchange from
-    occ_blocks (see two_particle_densities) scaled by kscale, energy-weighted density dme."""
+def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, grad):
+    """grad[rep][atom][3] += sum Z dA + sum Y dM of the DF two-electron energy jscale J - kscale K carried by dfobj's
+    tensor; returns the integral engine.  A long-range tensor (dfobj.omega > 0) differentiates the erf-attenuated
+    integrals; a short-range one (omega < 0) the Coulomb integrals with (Z, Y) and the long-range ones with (-Z, -Y)."""
     import torch
-    so = _lib_mod.load_library()
     if dfobj._cderi_dev is None:
         dfobj.build()
     if dfobj.world_size > 1:
@@ -128,33 +132,61 @@ def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_respo
     dev = dfobj._cderi_dev.device
     dfobj.drop_square_image()            # W and Z below each take the size of cderi
     eng = get_engine(mol, dfobj.auxmol, dev, dfobj.omega)
-    natm = mol.natm
-    nao = eng.ao.nao
     naux = eng.aux.nao
     j2c = eng.int2c2e().cpu().numpy()
-    try:
-        low = scipy.linalg.cholesky((j2c + j2c.T) * .5, lower=True)
-    except scipy.linalg.LinAlgError:
-        raise NotImplementedError('gradients with a linearly dependent (eigen-decomposed) fitting metric')
-    z_t, y_pq = two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, low)
+    mh = _decompose_j2c((j2c + j2c.T) * .5, dfobj.lindep, getattr(dfobj, 'decompose_j2c', 'CD'))[0]     # as in the tensor build
+    if mh.shape[0] != dfobj._cderi_dev.shape[0]:
+        raise RuntimeError('the tensor has %d rows, the metric decomposes into %d' % (dfobj._cderi_dev.shape[0], mh.shape[0]))
+    z_t, y_pq = two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale)
+    y_pq = y_pq.contiguous()
     _dbg('Z,Y built')
-    grad = torch.zeros((NREP, natm, 3), dtype=torch.float64, device=dev)
     ao_atom = _dev(eng.ao.atom, dev)
     aux_atom = _dev(eng.aux.atom, dev)
-    # (1) sum Z dA: 3-centre derivative blocks
-    for pc in eng.pair_classes():
-        for ac in eng.aux_classes():
-            eng.grad_launch(pc, ac, z_t, naux, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, auxbasis_response)
-            _dbg('3c class %d %d | %d' % (pc.li, pc.lj, ac.l))
-    _dbg('3c done')
-    # (2) sum Y dM: 2-centre metric
-    if auxbasis_response:
-        aux_xyz, aux_ao0 = _dev(eng.aux.xyz, dev), _dev(eng.aux.ao0, dev)
-        y_pq = y_pq.contiguous()
-        for pc in eng.pair_classes_2c():
-            for ac in eng.aux_classes():
-                eng.grad_launch(pc, ac, y_pq, naux, 0, aux_xyz, aux_ao0, aux_atom, grad, True)
-    _dbg('2c done')
+    aux_xyz, aux_ao0 = _dev(eng.aux.xyz, dev), _dev(eng.aux.ao0, dev)
+    passes = [None] if dfobj.omega >= 0 else [0.0, -dfobj.omega]
+    try:
+        for ip, om in enumerate(passes):
+            if om is not None:
+                eng._omega_override = om
+            if ip == 1:
+                z_t.neg_()
+                y_pq.neg_()
+            # (1) sum Z dA: 3-centre derivative blocks
+            for pc in eng.pair_classes():
+                for ac in eng.aux_classes():
+                    eng.grad_launch(pc, ac, z_t, naux, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, auxbasis_response)
+                    _dbg('3c class %d %d | %d' % (pc.li, pc.lj, ac.l))
+            # (2) sum Y dM: 2-centre metric
+            if auxbasis_response:
+                for pc in eng.pair_classes_2c():
+                    for ac in eng.aux_classes():
+                        eng.grad_launch(pc, ac, y_pq, naux, 0, aux_xyz, aux_ao0, aux_atom, grad, True)
+        torch.cuda.synchronize()         # z_t / y_pq are released on return
+    finally:
+        if hasattr(eng, '_omega_override'):
+            del eng._omega_override
+    _dbg('2e done')
+    return eng
+
+
+def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_response=True, device=None, exchange_terms=()):
+    """Electronic gradient (natm, 3) of a DF-HF-type energy with total density dm_tot, exchange from
+    occ_blocks (see two_particle_densities) scaled by kscale, energy-weighted density dme.
+    exchange_terms: [(range-separated DF object, scale)] further -scale K terms on other tensors (the long- or short-range
+    exact exchange of range-separated hybrids, pyscf/df/grad/rks.py:84-110)."""
+    import torch
+    so = _lib_mod.load_library()
+    if dfobj._cderi_dev is None:
+        dfobj.build()
+    dev = dfobj._cderi_dev.device
+    natm = mol.natm
+    grad = torch.zeros((NREP, natm, 3), dtype=torch.float64, device=dev)
+    eng = _grad_2e(mol, dfobj, dm_tot, occ_blocks, 1.0, kscale, auxbasis_response, grad)
+    for rs_df, scale in exchange_terms:
+        if scale != 0:
+            _grad_2e(mol, rs_df, dm_tot, occ_blocks, 0.0, scale, auxbasis_response, grad)
+    nao = eng.ao.nao
+    ao_atom = _dev(eng.ao.atom, dev)
     # (3) nuclear attraction: point-charge "aux shells", Z[pq][C] = D_pq (the charge -Z_C sits in the coefficient)
     nuc = _Shells.__new__(_Shells)
     eta = 1e30
@@ -188,6 +220,19 @@ def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_respo
     torch.cuda.synchronize()
     _dbg('1e done')
     return g.cpu().numpy()
+
+
+def rsh_exchange_terms(dfobj, omega, alpha, hyb):
+    """(scale of K on the Coulomb tensor, [(range-separated DF object, scale)]): the four exchange branches of
+    get_veff (dft/rks.py:108-127, df/grad/rks.py:84-110) - full-range hybrid; short-range only (erfc tensor x hyb);
+    long-range only (erf tensor x alpha); both, K = hyb K_full + (alpha - hyb) K_LR."""
+    if omega == 0:
+        return hyb, ()
+    if alpha == 0:
+        return 0.0, [(dfobj.range_coulomb(-omega), hyb)]
+    if hyb == 0:
+        return 0.0, [(dfobj.range_coulomb(omega), alpha)]
+    return hyb, [(dfobj.range_coulomb(omega), alpha - hyb)]
 
 
 class Gradients:

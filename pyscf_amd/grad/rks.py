@@ -21,8 +21,8 @@ class Gradients(rhf_grad.Gradients):
             raise NotImplementedError('UKS gradients')
         ni = mf._numint
         omega, alpha, hyb = ni.rsh_and_hybrid_coeff(mf.xc, spin=self.mol.spin)
-        if omega:
-            raise NotImplementedError('range-separated hybrid gradients')
         dm, blocks, dme = self._densities()
-        de = rhf_grad.grad_elec_df(self.mol, mf.with_df, dm, blocks, dme, hyb, self.auxbasis_response)
+        kfull, extra = rhf_grad.rsh_exchange_terms(mf.with_df, omega, alpha, hyb)
+        de = rhf_grad.grad_elec_df(self.mol, mf.with_df, dm, blocks, dme, kfull, self.auxbasis_response,
+                                   exchange_terms=extra)
         return de + ni.nr_rks_grad(self.mol, mf.grids, mf.xc, dm, self.grid_response)

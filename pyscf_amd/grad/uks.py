@@ -15,9 +15,9 @@ class Gradients(rhf_grad.Gradients):
             raise NotImplementedError('gradients are implemented for density-fitted SCF objects')
         ni = mf._numint
         omega, alpha, hyb = ni.rsh_and_hybrid_coeff(mf.xc, spin=self.mol.spin)
-        if omega:
-            raise NotImplementedError('range-separated hybrid gradients')
         dm, blocks, dme = self._densities()
-        de = rhf_grad.grad_elec_df(self.mol, mf.with_df, dm, blocks, dme, hyb, self.auxbasis_response)
+        kfull, extra = rhf_grad.rsh_exchange_terms(mf.with_df, omega, alpha, hyb)
+        de = rhf_grad.grad_elec_df(self.mol, mf.with_df, dm, blocks, dme, kfull, self.auxbasis_response,
+                                   exchange_terms=extra)
         dms = [c.dot(c.T) for c, _w in blocks]
         return de + ni.nr_uks_grad(self.mol, mf.grids, mf.xc, dms, self.grid_response)
