@@ -26,6 +26,7 @@
  *   PAMD_eval_ao         gto/eval_gto.py:31-144 -> lib/gto/grid_ao_drv.c:222-284,415-459 (GTOval_sph_deriv0/1)
  *   PAMD_rho_from_mo/_dm dft/numint.py:116-469 eval_rho / eval_rho2 (VXCdot_ao_dm, VXCdcontract_rho)
  *   PAMD_eval_xc         lib/dft/libxc_itrf.c:968-1024 LIBXC_eval_xc (+ libxc 7.1.2) and dft/xc_deriv.py:32-85
+ *   PAMD_eval_fxc        the fxc part of the same (deriv = 2) contracted with a first-order density, dft/numint.py:1418-1576
  *   PAMD_scale_ao        dft/numint.py:803-834 (VXCdscale_ao_sparse, lib/dft/nr_numint_sparse.c:1103)
  *   PAMD_dgemm_nt        dft/numint.py:836-874 (VXCdot_ao_ao_sparse, lib/dft/nr_numint_sparse.c:890-973)
  *
@@ -177,6 +178,10 @@ int PAMD_rho_from_dm(const double *d_ao, const double *d_c0t, int nao, int ldao,
  * d_acc[0] += sum w rho, d_acc[1] += sum w e_xc; d_exc nullable */
 int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double *d_weights, long ng,
                  long ldg, double *d_wv, double *d_exc, double *d_acc, void *stream);
+/* closed-shell response kernel, numint.nr_rks_fxc (dft/numint.py:1418-1530, weights of _rks_gga_wv1 :1560-1576):
+ * wv1[4][ldg] = w (d vrho / 2, 2 [d vsigma grad rho0 + vsigma grad rho1]) along the first-order density d_rho1[4][ldg] */
+int PAMD_eval_fxc(const double *fac7, int gga, const double *d_rho0, const double *d_rho1, const double *d_weights,
+                  long ng, long ldg, double *d_wv1, void *stream);
 /* spin-polarised variant for nr_uks (dft/numint.py:1192-1324): d_acc3 = {nelec_a, nelec_b, exc} */
 int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
                      const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,

@@ -300,7 +300,10 @@ def _build_functionals():
     fns = {}
     for k, e in out.items():
         fns[k] = (sp.lambdify((rho, sigma), e, 'numpy'), sp.lambdify((rho, sigma), sp.diff(e, rho), 'numpy'),
-                  sp.lambdify((rho, sigma), sp.diff(e, sigma), 'numpy'))
+                  sp.lambdify((rho, sigma), sp.diff(e, sigma), 'numpy'),
+                  sp.lambdify((rho, sigma), sp.diff(e, rho, 2), 'numpy'),
+                  sp.lambdify((rho, sigma), sp.diff(e, rho, sigma), 'numpy'),
+                  sp.lambdify((rho, sigma), sp.diff(e, sigma, 2), 'numpy'))
     return fns
 
 
@@ -321,11 +324,58 @@ def eval_xc(fac, rho, sigma):
     for w, name in zip(fac, _ORDER):
         if w == 0:
             continue
-        f, fr, fs = _FUNCS[name]
+        f, fr, fs = _FUNCS[name][:3]
         e[ok] += w * f(r, s)
         vr[ok] += w * fr(r, s)
         vs[ok] += w * fs(r, s) * np.ones_like(r)
     return e, vr, vs
+
+
+def eval_fxc(fac, rho, sigma):
+    """-> v2rho2, v2rhosigma, v2sigma2 (second derivatives of the energy per volume; zero where rho <= 1e-14)."""
+    global _FUNCS
+    if _FUNCS is None:
+        _FUNCS = _build_functionals()
+    out = [np.zeros_like(rho) for _ in range(3)]
+    ok = rho > 1e-14
+    r = rho[ok]
+    s = np.maximum(sigma[ok], 1e-300)
+    for w, name in zip(fac, _ORDER):
+        if w == 0:
+            continue
+        for k in range(3):
+            out[k][ok] += w * _FUNCS[name][3 + k](r, s) * np.ones_like(r)
+    return out
+
+
+def nr_rks_fxc(mol, coords, weights, fac, gga, dm0, dm1):
+    """Closed-shell XC kernel contracted with a first-order density matrix: dense restatement of numint.nr_rks_fxc
+    (numint.py:1418-1530) with the weights of _rks_gga_wv1 (:1560-1576).  Only the symmetric part of dm1 has a density."""
+    dm0 = (dm0 + dm0.T) * .5
+    dm1 = (dm1 + dm1.T) * .5
+    ao = eval_ao(mol, coords, 1 if gga else 0)
+    if not gga:
+        ao = ao[None] if ao.ndim == 2 else ao
+    c0, c1 = ao[0].dot(dm0), ao[0].dot(dm1)
+    rho0 = np.einsum('gi,gi->g', ao[0], c0)
+    rho1 = np.einsum('gi,gi->g', ao[0], c1)
+    if gga:
+        g0 = 2 * np.einsum('xgi,gi->xg', ao[1:4], c0)
+        g1 = 2 * np.einsum('xgi,gi->xg', ao[1:4], c1)
+        sigma = np.einsum('xg,xg->g', g0, g0)
+        sig1 = 2 * np.einsum('xg,xg->g', g0, g1)
+    else:
+        sigma = np.zeros_like(rho0)
+    vs = eval_xc(fac, rho0, sigma)[2]
+    frr, frs, fss = eval_fxc(fac, rho0, sigma)
+    if not gga:
+        aow = ao[0] * (.5 * weights * frr * rho1)[:, None]
+    else:
+        aow = ao[0] * (.5 * weights * (frr * rho1 + frs * sig1))[:, None]
+        for d in range(3):
+            aow += ao[1 + d] * (2 * weights * ((frs * rho1 + fss * sig1) * g0[d] + vs * g1[d]))[:, None]
+    m = ao[0].T.dot(aow)
+    return m + m.T
 
 
 def nr_rks(mol, coords, weights, fac, gga, dm):

@@ -18,88 +18,123 @@ using namespace pamd;
 namespace {
 
 // ---------------------------------------------------------------------------- dual numbers
-struct Dual {            // value, d/d rho, d/d sigma
-    double v, r, s;
+// Scalar with a first-order part along one direction (the first-order density of the response kernel, PAMD_eval_fxc).
+struct Eps {
+    double v, e;
 };
-__device__ inline Dual mk(double v, double r = 0, double s = 0) { return Dual{v, r, s}; }
-__device__ inline Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.r + b.r, a.s + b.s}; }
-__device__ inline Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.r - b.r, a.s - b.s}; }
-__device__ inline Dual operator-(Dual a) { return {-a.v, -a.r, -a.s}; }
-__device__ inline Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.r * b.v + a.v * b.r, a.s * b.v + a.v * b.s}; }
-__device__ inline Dual operator/(Dual a, Dual b)
+__device__ inline Eps operator+(Eps a, Eps b) { return {a.v + b.v, a.e + b.e}; }
+__device__ inline Eps operator-(Eps a, Eps b) { return {a.v - b.v, a.e - b.e}; }
+__device__ inline Eps operator-(Eps a) { return {-a.v, -a.e}; }
+__device__ inline Eps operator*(Eps a, Eps b) { return {a.v * b.v, a.e * b.v + a.v * b.e}; }
+__device__ inline Eps operator/(Eps a, Eps b) { double iv = 1.0 / b.v, q = a.v * iv; return {q, (a.e - q * b.e) * iv}; }
+__device__ inline Eps operator+(Eps a, double b) { return {a.v + b, a.e}; }
+__device__ inline Eps operator+(double a, Eps b) { return {a + b.v, b.e}; }
+__device__ inline Eps operator-(Eps a, double b) { return {a.v - b, a.e}; }
+__device__ inline Eps operator-(double a, Eps b) { return {a - b.v, -b.e}; }
+__device__ inline Eps operator*(Eps a, double b) { return {a.v * b, a.e * b}; }
+__device__ inline Eps operator*(double a, Eps b) { return {a * b.v, a * b.e}; }
+__device__ inline Eps operator/(Eps a, double b) { return {a.v / b, a.e / b}; }
+__device__ inline Eps operator/(double a, Eps b) { double q = a / b.v; return {q, -q * b.e / b.v}; }
+__device__ inline double s_pow(double a, double p) { return pow(a, p); }
+__device__ inline double s_sqrt(double a) { return sqrt(a); }
+__device__ inline double s_log(double a) { return log(a); }
+__device__ inline double s_exp(double a) { return exp(a); }
+__device__ inline double s_atan(double a) { return atan(a); }
+__device__ inline double s_asinh(double a) { return asinh(a); }
+__device__ inline Eps s_pow(Eps a, double p) { double f = pow(a.v, p); return {f, p * f / a.v * a.e}; }
+__device__ inline Eps s_sqrt(Eps a) { double f = sqrt(a.v); return {f, 0.5 / f * a.e}; }
+__device__ inline Eps s_log(Eps a) { return {log(a.v), a.e / a.v}; }
+__device__ inline Eps s_exp(Eps a) { double f = exp(a.v); return {f, f * a.e}; }
+__device__ inline Eps s_atan(Eps a) { return {atan(a.v), a.e / (1.0 + a.v * a.v)}; }
+__device__ inline Eps s_asinh(Eps a) { return {asinh(a.v), a.e / sqrt(1.0 + a.v * a.v)}; }
+template <class S> __device__ inline S lift(double v);
+template <> __device__ inline double lift<double>(double v) { return v; }
+template <> __device__ inline Eps lift<Eps>(double v) { return Eps{v, 0.0}; }
+
+// value, d/d rho, d/d sigma over the scalar S: double (energy and potential) or Eps (their first-order change)
+template <class S>
+struct DualT {
+    S v, r, s;
+};
+template <class S> __device__ inline DualT<S> mk(double v) { return DualT<S>{lift<S>(v), lift<S>(0.0), lift<S>(0.0)}; }
+template <class S> __device__ inline DualT<S> operator+(DualT<S> a, DualT<S> b) { return {a.v + b.v, a.r + b.r, a.s + b.s}; }
+template <class S> __device__ inline DualT<S> operator-(DualT<S> a, DualT<S> b) { return {a.v - b.v, a.r - b.r, a.s - b.s}; }
+template <class S> __device__ inline DualT<S> operator-(DualT<S> a) { return {-a.v, -a.r, -a.s}; }
+template <class S> __device__ inline DualT<S> operator*(DualT<S> a, DualT<S> b) { return {a.v * b.v, a.r * b.v + a.v * b.r, a.s * b.v + a.v * b.s}; }
+template <class S> __device__ inline DualT<S> operator/(DualT<S> a, DualT<S> b)
 {
-    double iv = 1.0 / b.v, q = a.v * iv;
+    S iv = 1.0 / b.v, q = a.v * iv;
     return {q, (a.r - q * b.r) * iv, (a.s - q * b.s) * iv};
 }
-__device__ inline Dual operator+(Dual a, double b) { return {a.v + b, a.r, a.s}; }
-__device__ inline Dual operator+(double a, Dual b) { return {a + b.v, b.r, b.s}; }
-__device__ inline Dual operator-(Dual a, double b) { return {a.v - b, a.r, a.s}; }
-__device__ inline Dual operator-(double a, Dual b) { return {a - b.v, -b.r, -b.s}; }
-__device__ inline Dual operator*(Dual a, double b) { return {a.v * b, a.r * b, a.s * b}; }
-__device__ inline Dual operator*(double a, Dual b) { return b * a; }
-__device__ inline Dual operator/(Dual a, double b) { return a * (1.0 / b); }
-__device__ inline Dual operator/(double a, Dual b) { return mk(a) / b; }
-__device__ inline Dual chain(Dual a, double f, double df) { return {f, df * a.r, df * a.s}; }
-__device__ inline Dual dpow(Dual a, double p) { double f = pow(a.v, p); return chain(a, f, p * f / a.v); }
-__device__ inline Dual dsqrt(Dual a) { double f = sqrt(a.v); return chain(a, f, 0.5 / f); }
-__device__ inline Dual dlog(Dual a) { return chain(a, log(a.v), 1.0 / a.v); }
-__device__ inline Dual dexp(Dual a) { double f = exp(a.v); return chain(a, f, f); }
-__device__ inline Dual datan(Dual a) { return chain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
-__device__ inline Dual dasinh(Dual a) { return chain(a, asinh(a.v), 1.0 / sqrt(1.0 + a.v * a.v)); }
+template <class S> __device__ inline DualT<S> operator+(DualT<S> a, double b) { return {a.v + b, a.r, a.s}; }
+template <class S> __device__ inline DualT<S> operator+(double a, DualT<S> b) { return {a + b.v, b.r, b.s}; }
+template <class S> __device__ inline DualT<S> operator-(DualT<S> a, double b) { return {a.v - b, a.r, a.s}; }
+template <class S> __device__ inline DualT<S> operator-(double a, DualT<S> b) { return {a - b.v, -b.r, -b.s}; }
+template <class S> __device__ inline DualT<S> operator*(DualT<S> a, double b) { return {a.v * b, a.r * b, a.s * b}; }
+template <class S> __device__ inline DualT<S> operator*(double a, DualT<S> b) { return b * a; }
+template <class S> __device__ inline DualT<S> operator/(DualT<S> a, double b) { return a * (1.0 / b); }
+template <class S> __device__ inline DualT<S> operator/(double a, DualT<S> b) { return DualT<S>{lift<S>(a), lift<S>(0.0), lift<S>(0.0)} / b; }
+template <class S> __device__ inline DualT<S> chain(DualT<S> a, S f, S df) { return {f, df * a.r, df * a.s}; }
+template <class S> __device__ inline DualT<S> dpow(DualT<S> a, double p) { S f = s_pow(a.v, p); return chain(a, f, p * f / a.v); }
+template <class S> __device__ inline DualT<S> dsqrt(DualT<S> a) { S f = s_sqrt(a.v); return chain(a, f, 0.5 / f); }
+template <class S> __device__ inline DualT<S> dlog(DualT<S> a) { return chain(a, s_log(a.v), 1.0 / a.v); }
+template <class S> __device__ inline DualT<S> dexp(DualT<S> a) { S f = s_exp(a.v); return chain(a, f, f); }
+template <class S> __device__ inline DualT<S> datan(DualT<S> a) { return chain(a, s_atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+template <class S> __device__ inline DualT<S> dasinh(DualT<S> a) { return chain(a, s_asinh(a.v), 1.0 / s_sqrt(1.0 + a.v * a.v)); }
 
 // ---------------------------------------------------------------------------- functionals
 // All return the energy density per unit volume e(rho, sigma) for a closed-shell density.
 constexpr double PI = 3.14159265358979323846;
 
-__device__ inline Dual slater_x(Dual rho)
+template <class S> __device__ inline DualT<S> slater_x(DualT<S> rho)
 {
     const double cx = 0.75 * 0.98474502184269654;     // (3/4)(3/pi)^(1/3)
     return -cx * dpow(rho, 4.0 / 3.0);
 }
 
 // VWN paramagnetic correlation energy per particle; params (A, x0, b, c)
-__device__ inline Dual vwn_eps(Dual rho, double A, double x0, double b, double c)
+template <class S> __device__ inline DualT<S> vwn_eps(DualT<S> rho, double A, double x0, double b, double c)
 {
-    Dual rs = dpow(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
-    Dual x = dsqrt(rs);
+    DualT<S> rs = dpow(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
+    DualT<S> x = dsqrt(rs);
     const double Q = sqrt(4 * c - b * b);
-    Dual X = x * x + b * x + c;
+    DualT<S> X = x * x + b * x + c;
     const double X0 = x0 * x0 + b * x0 + c;
-    Dual at = datan(Q / (2.0 * x + b));
-    Dual t1 = dlog(x * x / X) + (2 * b / Q) * at;
-    Dual t2 = dlog((x - x0) * (x - x0) / X) + (2 * (b + 2 * x0) / Q) * at;
+    DualT<S> at = datan(Q / (2.0 * x + b));
+    DualT<S> t1 = dlog(x * x / X) + (2 * b / Q) * at;
+    DualT<S> t2 = dlog((x - x0) * (x - x0) / X) + (2 * (b + 2 * x0) / Q) * at;
     return A * (t1 - (b * x0 / X0) * t2);
 }
-__device__ inline Dual vwn5_c(Dual rho) { return rho * vwn_eps(rho, 0.0310907, -0.10498, 3.72744, 12.9352); }
-__device__ inline Dual vwnrpa_c(Dual rho) { return rho * vwn_eps(rho, 0.0310907, -0.409286, 13.0720, 42.7198); }
+template <class S> __device__ inline DualT<S> vwn5_c(DualT<S> rho) { return rho * vwn_eps(rho, 0.0310907, -0.10498, 3.72744, 12.9352); }
+template <class S> __device__ inline DualT<S> vwnrpa_c(DualT<S> rho) { return rho * vwn_eps(rho, 0.0310907, -0.409286, 13.0720, 42.7198); }
 
 // B88 exchange, spin-scaled to the closed-shell case (rho_s = rho/2, sigma_ss = sigma/4)
-__device__ inline Dual b88_x(Dual rho, Dual sigma)
+template <class S> __device__ inline DualT<S> b88_x(DualT<S> rho, DualT<S> sigma)
 {
     const double beta = 0.0042;
     const double cx = 1.5 * 0.62035049089940001;      // (3/2)(3/(4 pi))^(1/3)
-    Dual rs = 0.5 * rho;
-    Dual r43 = dpow(rs, 4.0 / 3.0);
-    Dual g = dsqrt(0.25 * sigma + 1e-300);
-    Dual x = g / r43;
-    Dual e = -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * dasinh(x));
+    DualT<S> rs = 0.5 * rho;
+    DualT<S> r43 = dpow(rs, 4.0 / 3.0);
+    DualT<S> g = dsqrt(0.25 * sigma + 1e-300);
+    DualT<S> x = g / r43;
+    DualT<S> e = -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * dasinh(x));
     return 2.0 * e;
 }
 
 // LYP correlation, closed shell (Miehlich et al. form)
-__device__ inline Dual lyp_c(Dual rho, Dual sigma)
+template <class S> __device__ inline DualT<S> lyp_c(DualT<S> rho, DualT<S> sigma)
 {
     const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349;
     const double CF = 0.3 * 9.5707800006273392;       // (3/10)(3 pi^2)^(2/3)
-    Dual rm13 = dpow(rho, -1.0 / 3.0);
-    Dual den = 1.0 + d * rm13;
-    Dual omega = dexp(-c * rm13) / den * dpow(rho, -11.0 / 3.0);
-    Dual delta = c * rm13 + d * rm13 / den;
-    Dual ra = 0.5 * rho;                               // = rb
-    Dual saa = 0.25 * sigma;                           // |grad rho_a|^2 = |grad rho_b|^2, total sigma
-    Dual rab = ra * ra;
-    Dual t1 = -a * 4.0 / den * rab / rho;
-    Dual br = rab * (pow(2.0, 11.0 / 3.0) * CF * 2.0 * dpow(ra, 8.0 / 3.0)
+    DualT<S> rm13 = dpow(rho, -1.0 / 3.0);
+    DualT<S> den = 1.0 + d * rm13;
+    DualT<S> omega = dexp(-c * rm13) / den * dpow(rho, -11.0 / 3.0);
+    DualT<S> delta = c * rm13 + d * rm13 / den;
+    DualT<S> ra = 0.5 * rho;                               // = rb
+    DualT<S> saa = 0.25 * sigma;                           // |grad rho_a|^2 = |grad rho_b|^2, total sigma
+    DualT<S> rab = ra * ra;
+    DualT<S> t1 = -a * 4.0 / den * rab / rho;
+    DualT<S> br = rab * (pow(2.0, 11.0 / 3.0) * CF * 2.0 * dpow(ra, 8.0 / 3.0)
                      + (47.0 / 18.0 - 7.0 / 18.0 * delta) * sigma
                      - (2.5 - delta / 18.0) * (2.0 * saa)
                      - (delta - 11.0) / 9.0 * (saa))       // (ra/rho + rb/rho) saa = saa
@@ -109,35 +144,37 @@ __device__ inline Dual lyp_c(Dual rho, Dual sigma)
 }
 
 // PBE exchange (closed shell) and correlation (zeta = 0)
-__device__ inline Dual pbe_x(Dual rho, Dual sigma)
+template <class S> __device__ inline DualT<S> pbe_x(DualT<S> rho, DualT<S> sigma)
 {
     const double kappa = 0.804, mu = 0.2195149727645171;
-    Dual ex_lda = slater_x(rho);
-    Dual kf = dpow(3.0 * PI * PI * rho, 1.0 / 3.0);
-    Dual s2 = sigma / (4.0 * kf * kf * rho * rho);
-    Dual fx = 1.0 + kappa - kappa / (1.0 + mu / kappa * s2);
+    DualT<S> ex_lda = slater_x(rho);
+    DualT<S> kf = dpow(3.0 * PI * PI * rho, 1.0 / 3.0);
+    DualT<S> s2 = sigma / (4.0 * kf * kf * rho * rho);
+    DualT<S> fx = 1.0 + kappa - kappa / (1.0 + mu / kappa * s2);
     return ex_lda * fx;
 }
-__device__ inline Dual pw92_eps(Dual rs)
+template <class S> __device__ inline DualT<S> pw92_eps(DualT<S> rs)
 {   // PW92 paramagnetic, libxc "pw_mod" parameters
     const double A = 0.0310907, a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
-    Dual srs = dsqrt(rs);
-    Dual q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
+    DualT<S> srs = dsqrt(rs);
+    DualT<S> q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
     return -2.0 * A * (1.0 + a1 * rs) * dlog(1.0 + 1.0 / q);
 }
-__device__ inline Dual pbe_c(Dual rho, Dual sigma)
+template <class S> __device__ inline DualT<S> pbe_c(DualT<S> rho, DualT<S> sigma)
 {
     const double beta = 0.06672455060314922, gamma = 0.031090690869654895;   // (1 - ln 2)/pi^2
-    Dual rs = dpow(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
-    Dual ec = pw92_eps(rs);
-    Dual kf = dpow(3.0 * PI * PI * rho, 1.0 / 3.0);
-    Dual ks = dsqrt(4.0 * kf / PI);
-    Dual t2 = sigma / (4.0 * ks * ks * rho * rho);
-    Dual Aa = beta / gamma / (dexp(-ec / gamma) - 1.0);
-    Dual num = 1.0 + Aa * t2;
-    Dual H = gamma * dlog(1.0 + beta / gamma * t2 * num / (1.0 + Aa * t2 + Aa * Aa * t2 * t2));
+    DualT<S> rs = dpow(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
+    DualT<S> ec = pw92_eps(rs);
+    DualT<S> kf = dpow(3.0 * PI * PI * rho, 1.0 / 3.0);
+    DualT<S> ks = dsqrt(4.0 * kf / PI);
+    DualT<S> t2 = sigma / (4.0 * ks * ks * rho * rho);
+    DualT<S> Aa = beta / gamma / (dexp(-ec / gamma) - 1.0);
+    DualT<S> num = 1.0 + Aa * t2;
+    DualT<S> H = gamma * dlog(1.0 + beta / gamma * t2 * num / (1.0 + Aa * t2 + Aa * Aa * t2 * t2));
     return rho * (ec + H);
 }
+
+using Dual = DualT<double>;
 
 enum { F_SLATER = 0, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC, F_NUM };
 
@@ -165,8 +202,8 @@ __global__ __launch_bounds__(256) void eval_xc_kernel(XCSpec spec, int gga, cons
         }
         double e = 0, vr = 0, vs = 0;
         if (r > 1e-14) {
-            Dual dr = mk(r, 1, 0), ds = mk(sig, 0, 1);
-            Dual tot = mk(0);
+            Dual dr{r, 1.0, 0.0}, ds{sig, 0.0, 1.0};
+            Dual tot = mk<double>(0);
             if (spec.fac[F_SLATER] != 0) tot = tot + spec.fac[F_SLATER] * slater_x(dr);
             if (spec.fac[F_VWN5] != 0) tot = tot + spec.fac[F_VWN5] * vwn5_c(dr);
             if (spec.fac[F_VWNRPA] != 0) tot = tot + spec.fac[F_VWNRPA] * vwnrpa_c(dr);
@@ -192,6 +229,48 @@ __global__ __launch_bounds__(256) void eval_xc_kernel(XCSpec spec, int gga, cons
     if (threadIdx.x < 2) {
         double v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
         atomicAdd(acc + threadIdx.x, v);
+    }
+}
+
+// First-order change of the XC potential weights along a first-order density rho1 (numint.nr_rks_fxc, numint.py:1418-1530,
+// weights of _rks_gga_wv1 :1560-1576): the functionals are evaluated on DualT<Eps>, value and (d/d rho, d/d sigma) parts
+// each carrying the derivative along (rho1, sigma1 = 2 grad rho0 . grad rho1) - forward over forward AD, no hand-written
+// second derivatives.
+//   wv1[0] = 0.5 w d(vrho),   wv1[k] = 2 w [ d(vsigma) grad_k rho0 + vsigma grad_k rho1 ]
+__global__ __launch_bounds__(256) void eval_fxc_kernel(XCSpec spec, int gga, const double *__restrict__ rho0,
+                                                       const double *__restrict__ rho1,
+                                                       const double *__restrict__ weights, long ng, long ldg,
+                                                       double *__restrict__ wv)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ng) return;
+    const double r = rho0[g], r1 = rho1[g];
+    const double w = weights[g];
+    double gx = 0, gy = 0, gz = 0, hx = 0, hy = 0, hz = 0, sig = 0, sig1 = 0;
+    if (gga) {
+        gx = rho0[ldg + g]; gy = rho0[2 * ldg + g]; gz = rho0[3 * ldg + g];
+        hx = rho1[ldg + g]; hy = rho1[2 * ldg + g]; hz = rho1[3 * ldg + g];
+        sig = gx * gx + gy * gy + gz * gz;
+        sig1 = 2 * (gx * hx + gy * hy + gz * hz);
+    }
+    double dvr = 0, vs = 0, dvs = 0;
+    if (r > 1e-14) {
+        DualT<Eps> dr{{r, r1}, {1.0, 0.0}, {0.0, 0.0}}, ds{{sig, sig1}, {0.0, 0.0}, {1.0, 0.0}};
+        DualT<Eps> tot = mk<Eps>(0);
+        if (spec.fac[F_SLATER] != 0) tot = tot + spec.fac[F_SLATER] * slater_x(dr);
+        if (spec.fac[F_VWN5] != 0) tot = tot + spec.fac[F_VWN5] * vwn5_c(dr);
+        if (spec.fac[F_VWNRPA] != 0) tot = tot + spec.fac[F_VWNRPA] * vwnrpa_c(dr);
+        if (spec.fac[F_B88] != 0) tot = tot + spec.fac[F_B88] * b88_x(dr, ds);
+        if (spec.fac[F_LYP] != 0) tot = tot + spec.fac[F_LYP] * lyp_c(dr, ds);
+        if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * pbe_x(dr, ds);
+        if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c(dr, ds);
+        dvr = tot.r.e; vs = tot.s.v; dvs = tot.s.e;
+    }
+    wv[g] = 0.5 * w * dvr;
+    if (gga) {
+        wv[ldg + g] = 2.0 * w * (dvs * gx + vs * hx);
+        wv[2 * ldg + g] = 2.0 * w * (dvs * gy + vs * hy);
+        wv[3 * ldg + g] = 2.0 * w * (dvs * gz + vs * hz);
     }
 }
 
@@ -646,6 +725,20 @@ int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double 
     for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
     eval_xc_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho, d_weights, ng, ldg, d_wv,
                                                                        d_exc, d_acc);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// Response kernel: d_wv1[4][ldg] from the zeroth- and first-order densities d_rho0 / d_rho1 [4][ldg] (rho, grad rho)
+// of grid points [0, ng); same fac7 / gga as PAMD_eval_xc.  numint.nr_rks_fxc (dft/numint.py:1418-1530).
+int PAMD_eval_fxc(const double *fac7, int gga, const double *d_rho0, const double *d_rho1, const double *d_weights,
+                  long ng, long ldg, double *d_wv1, void *stream)
+{
+    if (ng == 0) return 0;
+    XCSpec spec;
+    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
+    eval_fxc_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho0, d_rho1, d_weights, ng, ldg,
+                                                                        d_wv1);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

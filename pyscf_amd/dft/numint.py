@@ -325,6 +325,96 @@ class NumInt:
             return nelec[0], excsum[0], vmat[0]
         return nelec, excsum, vmat.reshape(shape)
 
+    def nr_rks_fxc(self, mol, grids, xc_code, dm0, dms, relativity=0, hermi=0, rho0=None, vxc=None, fxc=None,
+                   max_memory=2000, verbose=None):
+        """Closed-shell XC kernel contracted with first-order density matrices, the contract of numint.nr_rks_fxc
+        (numint.py:1418-1530): vmat[i] = sum_g w [fxc : rho1_i] ao ao.  Per grid block: AO values once, rho0 from dm0 and
+        rho1 from every dms[i] (``PAMD_rho_from_dm``; a density only sees the symmetric part of a matrix, so any hermi
+        gives the same, symmetric, result), first-order weights from ``PAMD_eval_fxc`` (forward-over-forward AD of the
+        same functional code as ``PAMD_eval_xc``), then the scale + GEMM of nr_rks.  The reference's cached rho0 / vxc /
+        fxc arrays are accepted for signature compatibility and not used: the kernel is re-evaluated from dm0."""
+        import torch
+        lib = _lib_mod.load_library()
+        dev = self._dev()
+        if grids.coords is None:
+            grids.build()
+        hyb, fac = _xc.parse_xc(xc_code)
+        xctype = _xc.xc_type(xc_code)
+        dms_arr = np.asarray(dms)
+        if np.iscomplexobj(dms_arr):
+            raise NotImplementedError('complex density matrix')
+        nao = dms_arr.shape[-1]
+        shape = dms_arr.shape
+        dms2 = dms_arr.reshape(-1, nao, nao)
+        nset = len(dms2)
+        vmat = np.zeros((nset, nao, nao))
+        if xctype == 'HF':
+            return vmat.reshape(shape)
+        gga = 1 if xctype == 'GGA' else 0
+        ncomp = 4 if gga else 1
+        coords_dev, weights_dev = self._grid_tables(grids, dev)
+        ngrids = grids.size
+        ldao = _round_up(nao, 16)
+        rank, world = self._world()
+        blk = grid_block_size(ngrids, int(self.block_bytes // (ncomp * ldao * 8)), world)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        f64 = torch.float64
+        ao = torch.zeros(ncomp * blk * ldao + 256, dtype=f64, device=dev)[:ncomp * blk * ldao].view(ncomp, blk, ldao)
+        aow = torch.zeros(blk * ldao + 256, dtype=f64, device=dev)[:blk * ldao].view(blk, ldao)
+        rho_0 = torch.zeros((4, blk), dtype=f64, device=dev)
+        rho_1 = torch.zeros((4, blk), dtype=f64, device=dev)
+        wv = torch.empty((4, blk), dtype=f64, device=dev)
+        c0t = torch.empty((nao, blk), dtype=f64, device=dev)
+        nsplit = self.vmat_nsplit or pick_nsplit(((nao + 159) // 160) * ((nao + 127) // 128))
+        fac_c = (ctypes.c_double * 7)(*fac)
+        ldd = _round_up(nao, 128)
+
+        def padded(d):
+            d_h = np.zeros((nao, ldd))
+            d_h[:, :nao] = (d + d.T) * .5
+            return torch.from_numpy(d_h).to(dev)
+        d0 = padded(np.asarray(dm0, dtype=np.float64))
+        d1 = [padded(d) for d in dms2]
+        parts = torch.zeros((nset, nsplit, nao, nao), dtype=f64, device=dev)
+
+        def density(dmat, ng, out):
+            self._call('dm_dot_ao', lib.PAMD_cderi_solve, _ptr(dmat), _c.c_int(ldd), _ptr(ao[0]), _c.c_long(ldao),
+                       _ptr(c0t), _c.c_long(blk), _c.c_int(nao), _c.c_long(ng), _c.c_int(nao), _c.c_int(0), _c.c_int(0), st)
+            self._call('rho', lib.PAMD_rho_from_dm, _ptr(ao), _ptr(c0t), _c.c_int(nao), _c.c_int(ldao), _c.c_long(blk),
+                       _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _ptr(out), _c.c_long(blk), st)
+        for ib, g0 in enumerate(range(0, ngrids, blk)):
+            if ib % world != rank:
+                continue
+            ng = min(blk, ngrids - g0)
+            ng16 = _round_up(ng, 16)
+            self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk, ldao, None)
+            density(d0, ng, rho_0)
+            for i in range(nset):
+                density(d1[i], ng, rho_1)
+                self._call('eval_fxc', lib.PAMD_eval_fxc, fac_c, _c.c_int(gga), _ptr(rho_0), _ptr(rho_1),
+                           _ptr(weights_dev[g0:g0 + ng]), _c.c_long(ng), _c.c_long(blk), _ptr(wv), st)
+                self._call('scale_ao', lib.PAMD_scale_ao, _ptr(ao), _ptr(wv), _c.c_int(ldao), _c.c_long(blk),
+                           _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _c.c_long(ng16), _ptr(aow), st)
+                self._call('ao_dot_aow', lib.PAMD_dgemm_tn, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow), _c.c_int(ldao),
+                           _ptr(parts[i]), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(ng16), _c.c_int(2),
+                           _c.c_int(nsplit), st)
+        v = torch.empty((nao, nao), dtype=f64, device=dev)
+        for i in range(nset):
+            self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(parts[i]), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
+                       _ptr(v), st)
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(v, group=self.group)
+            vmat[i] = v.cpu().numpy()
+        return vmat.reshape(shape)
+
+    def nr_fxc(self, mol, grids, xc_code, dm0, dms, spin=0, relativity=0, hermi=0, rho0=None, vxc=None, fxc=None,
+               max_memory=2000, verbose=None):
+        """numint.nr_fxc (numint.py:2846-2860): spin 0 dispatches to nr_rks_fxc; the spin-polarised kernel is not built."""
+        if spin != 0:
+            raise NotImplementedError('nr_uks_fxc')
+        return self.nr_rks_fxc(mol, grids, xc_code, dm0, dms, relativity, hermi, rho0, vxc, fxc, max_memory, verbose)
+
     def nr_rks_grad(self, mol, grids, xc_code, dm, grid_response=False):
         """XC part of the closed-shell nuclear gradient, (natm, 3), grid response left out: the contraction
         -2 sum_{mu on A, nu} vmat[x]_{mu nu} D_{mu nu} of pyscf/grad/rks.py:get_vxc (:197-255; _d1_dot_,

@@ -287,3 +287,45 @@ def test_partition_schemes_vs_oracle(scheme):
     # quadrature sanity: a normalised s-Gaussian on the carbon atom integrates to 1 with either partition
     r2 = ((g.coords - mol.atom_coords()[1]) ** 2).sum(axis=1)
     assert abs((g.weights * np.exp(-1.3 * r2)).sum() * (1.3 / np.pi) ** 1.5 - 1) < 1e-5
+
+
+@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe'])
+def test_nr_rks_fxc_vs_oracle_and_finite_differences(xc):
+    """NumInt.nr_rks_fxc (numint.py:1418-1530): the XC kernel contracted with first-order density matrices, from
+    PAMD_eval_fxc (forward-over-forward AD), against (i) the numpy restatement with sympy second derivatives and (ii)
+    central differences of the device's own nr_rks potential; hermi = 0 input (only the symmetric part carries a density),
+    several matrices per call, HF-only functional = 0."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    mf = dft.RKS(mol, xc='lda,vwn').density_fit().run()
+    dm0 = mf.make_rdm1()
+    occ = mf.mo_occ > 0
+    co, cv = mf.mo_coeff[:, occ], mf.mo_coeff[:, ~occ]
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((co.shape[1], co.shape[1]))
+    x = rng.standard_normal((co.shape[1], cv.shape[1]))
+    d_oo = co.dot(a + a.T).dot(co.T)                      # same decay as rho0: valid for finite differences
+    d_ov = co.dot(x).dot(cv.T)                            # non-symmetric occupied-virtual transition density
+    grids = dft.Grids(mol)
+    grids.atom_grid = (40, 110)
+    grids.build()
+    ni = dft.NumInt()
+    v = ni.nr_rks_fxc(mol, grids, xc, dm0, np.array([d_oo, d_ov, d_ov + d_ov.T]), hermi=0)
+    assert v.shape == (3, mol.nao, mol.nao)
+    assert np.abs(v - v.transpose(0, 2, 1)).max() < 1e-12
+    assert np.abs(v[2] - 2 * v[1]).max() < 1e-10 * np.abs(v[2]).max()
+    hyb, fac = libxc.parse_xc(xc)
+    gga = libxc.xc_type(xc) == 'GGA'
+    n = len(grids.atm_idx)
+    for i, d1 in enumerate((d_oo, d_ov)):
+        want = ref_dft.nr_rks_fxc(mol, grids.coords[:n], grids.weights[:n], fac, gga, dm0, d1)
+        assert np.abs(v[i] - want).max() < 1e-8 * max(1.0, np.abs(want).max()), (xc, i, np.abs(v[i] - want).max())
+    eps = 1e-4
+    vp = ni.nr_rks(mol, grids, xc, dm0 + eps * d_oo)[2]
+    vm = ni.nr_rks(mol, grids, xc, dm0 - eps * d_oo)[2]
+    fd = (vp - vm) / (2 * eps)
+    assert np.abs(fd - v[0]).max() < 2e-6 * max(1.0, np.abs(v[0]).max()), np.abs(fd - v[0]).max()
+    single = ni.nr_rks_fxc(mol, grids, xc, dm0, d_oo, hermi=1)
+    assert single.shape == (mol.nao, mol.nao) and np.abs(single - v[0]).max() < 1e-12
+    assert np.abs(ni.nr_fxc(mol, grids, 'HF', dm0, d_oo)).max() == 0

@@ -247,3 +247,41 @@ def test_weight_response_oracle_vs_finite_differences(scheme, scale, adjust):
     if scheme == 'lko':
         plain = ref_dft.becke_weight_response(c, ow, w, atm, table, 'becke')
         assert (np.abs(plain - dw).max() > 1e-3) == (scale > 1)      # the saturation only matters at long distances
+
+
+def test_oracle_fxc_reference_fingerprints_and_finite_differences():
+    """numint.nr_rks_fxc restated with sympy second derivatives.  pyscf/dft/test/test_numint.py:313-349 contracts the
+    kernel of an H4 chain (cc-pVTZ, default grids) with random first-order matrices on a zeroth-order matrix that has two
+    NEGATIVE occupations: the density changes sign in space and the result depends on libxc's density cut-offs there, so
+    its fingerprints (-3.0008266036125315 'LDA,', -7.571122737701957 'B88,') are reproduced only to 2e-6 and 2.4e-4
+    (relative 7e-7 and 3e-5) - recorded as loose pins.  The tight check is against central differences of the oracle's own
+    nr_rks potential, which is pinned by the reference's DFT energies."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import libxc
+    mol1 = gto.M(atom=[('h', (0, 0, i * 3)) for i in range(4)], basis='ccpvtz')
+    np.random.seed(10)
+    nao = mol1.nao_nr()
+    dm0 = np.random.random((nao, nao))
+    _, mo_coeff = np.linalg.eigh(dm0)
+    mo_occ = np.ones(nao)
+    mo_occ[-2:] = -1
+    dm0 = np.einsum('pi,i,qi->pq', mo_coeff, mo_occ, mo_coeff)
+    dms = np.random.random((2, nao, nao))
+    coords, weights = ref_dft.build_grids(mol1)
+    v = ref_dft.nr_rks_fxc(mol1, coords, weights, libxc.parse_xc('LDA,')[1], False, dm0, dms[0])
+    assert abs(ref.fp(v) - -3.0008266036125315) < 5e-6, ref.fp(v)
+    v = np.array([ref_dft.nr_rks_fxc(mol1, coords, weights, libxc.parse_xc('B88,')[1], True, dm0, d) for d in dms])
+    assert abs(ref.fp(v) - -7.571122737701957) < 5e-4, ref.fp(v)
+    # physical density, first-order matrix inside the occupied space (rho1 / rho0 bounded): kernel = d vxc / d eps
+    rng = np.random.default_rng(3)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0][:, :2]
+    a = rng.standard_normal((2, 2))
+    dmp, d1 = 2 * c.dot(c.T), c.dot(a + a.T).dot(c.T)
+    eps = 1e-4
+    for xc in ('lda,vwn', 'b3lyp', 'pbe,pbe'):
+        fac = libxc.parse_xc(xc)[1]
+        gga = libxc.xc_type(xc) == 'GGA'
+        vp = ref_dft.nr_rks(mol1, coords, weights, fac, gga, dmp + eps * d1)[2]
+        vm = ref_dft.nr_rks(mol1, coords, weights, fac, gga, dmp - eps * d1)[2]
+        v1 = ref_dft.nr_rks_fxc(mol1, coords, weights, fac, gga, dmp, d1)
+        assert np.abs((vp - vm) / (2 * eps) - v1).max() < 2e-6 * max(1.0, np.abs(v1).max()), xc
