@@ -182,6 +182,10 @@ int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double 
  * wv1[4][ldg] = w (d vrho / 2, 2 [d vsigma grad rho0 + vsigma grad rho1]) along the first-order density d_rho1[4][ldg] */
 int PAMD_eval_fxc(const double *fac7, int gga, const double *d_rho0, const double *d_rho1, const double *d_weights,
                   long ng, long ldg, double *d_wv1, void *stream);
+/* spin-polarised response kernel, numint.nr_uks_fxc (dft/numint.py:1690-1832, weights of _uks_gga_wv1 :1834-1915) */
+int PAMD_eval_fxc_pol(const double *fac7, int gga, const double *d_rho0_a, const double *d_rho0_b, const double *d_rho1_a,
+                      const double *d_rho1_b, const double *d_weights, long ng, long ldg, double *d_wv1_a,
+                      double *d_wv1_b, void *stream);
 /* spin-polarised variant for nr_uks (dft/numint.py:1192-1324): d_acc3 = {nelec_a, nelec_b, exc} */
 int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
                      const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,

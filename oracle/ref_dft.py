@@ -642,6 +642,18 @@ def nr_uks(mol, coords, weights, fac, gga, dma, dmb):
     return nelec, exc, np.array(vmat)
 
 
+def nr_uks_fxc(mol, coords, weights, fac, gga, dm0a, dm0b, dm1a, dm1b, h=2e-4):
+    """(2, nao, nao): the spin-polarised XC kernel contracted with first-order spin density matrices, numint.nr_uks_fxc
+    (numint.py:1690-1832), as what it is - the derivative of the nr_uks potential along (dm1a, dm1b) - by central
+    differences with Richardson extrapolation (h, 2h -> O(h^4)); no second hand-written set of second derivatives.
+    Valid where the first-order densities are small against the zeroth-order ones (physical perturbations)."""
+    def v(t):
+        return nr_uks(mol, coords, weights, fac, gga, dm0a + t * dm1a, dm0b + t * dm1b)[2]
+    d1 = (v(h) - v(-h)) / (2 * h)
+    d2 = (v(2 * h) - v(-2 * h)) / (4 * h)
+    return (4 * d1 - d2) / 3
+
+
 def nr_uks_grad(mol, coords, weights, fac, gga, dma, dmb):
     """XC nuclear gradient (natm, 3) of a spin-polarised density, grid response left out: numpy restatement of
     pyscf/grad/uks.py get_vxc (:100-190) + the contraction with (D_alpha, D_beta) of grad/uhf.py:72-76."""

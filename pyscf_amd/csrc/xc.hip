@@ -276,100 +276,102 @@ __global__ __launch_bounds__(256) void eval_fxc_kernel(XCSpec spec, int gga, con
 
 // ============================================================================ spin-polarised (UKS)
 // forward-mode AD with 5 directions: d/d(rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb)
-struct D5 {
-    double v, d[5];
+template <class S>
+struct D5T {
+    S v, d[5];
 };
-__device__ inline D5 c5(double v) { D5 r; r.v = v; for (int i = 0; i < 5; i++) r.d[i] = 0; return r; }
-__device__ inline D5 var5(double v, int k) { D5 r = c5(v); r.d[k] = 1; return r; }
-__device__ inline D5 operator+(D5 a, D5 b) { D5 r; r.v = a.v + b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
-__device__ inline D5 operator-(D5 a, D5 b) { D5 r; r.v = a.v - b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
-__device__ inline D5 operator-(D5 a) { D5 r; r.v = -a.v; for (int i = 0; i < 5; i++) r.d[i] = -a.d[i]; return r; }
-__device__ inline D5 operator*(D5 a, D5 b) { D5 r; r.v = a.v * b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-__device__ inline D5 operator/(D5 a, D5 b)
+template <class S> __device__ inline D5T<S> c5(double v) { D5T<S> r; r.v = lift<S>(v); for (int i = 0; i < 5; i++) r.d[i] = lift<S>(0.0); return r; }
+__device__ inline void floor_at(double &x, double f) { if (x < f) x = f; }
+__device__ inline void floor_at(Eps &x, double f) { if (x.v < f) { x.v = f; x.e = 0.0; } }
+template <class S> __device__ inline D5T<S> operator+(D5T<S> a, D5T<S> b) { D5T<S> r; r.v = a.v + b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <class S> __device__ inline D5T<S> operator-(D5T<S> a, D5T<S> b) { D5T<S> r; r.v = a.v - b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <class S> __device__ inline D5T<S> operator-(D5T<S> a) { D5T<S> r; r.v = -a.v; for (int i = 0; i < 5; i++) r.d[i] = -a.d[i]; return r; }
+template <class S> __device__ inline D5T<S> operator*(D5T<S> a, D5T<S> b) { D5T<S> r; r.v = a.v * b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <class S> __device__ inline D5T<S> operator/(D5T<S> a, D5T<S> b)
 {
-    D5 r; double iv = 1.0 / b.v; r.v = a.v * iv;
+    D5T<S> r; S iv = 1.0 / b.v; r.v = a.v * iv;
     for (int i = 0; i < 5; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * iv;
     return r;
 }
-__device__ inline D5 operator+(D5 a, double b) { a.v += b; return a; }
-__device__ inline D5 operator+(double a, D5 b) { b.v += a; return b; }
-__device__ inline D5 operator-(D5 a, double b) { a.v -= b; return a; }
-__device__ inline D5 operator-(double a, D5 b) { return c5(a) - b; }
-__device__ inline D5 operator*(D5 a, double b) { a.v *= b; for (int i = 0; i < 5; i++) a.d[i] *= b; return a; }
-__device__ inline D5 operator*(double a, D5 b) { return b * a; }
-__device__ inline D5 operator/(D5 a, double b) { return a * (1.0 / b); }
-__device__ inline D5 operator/(double a, D5 b) { return c5(a) / b; }
-__device__ inline D5 chain5(D5 a, double f, double df) { D5 r; r.v = f; for (int i = 0; i < 5; i++) r.d[i] = df * a.d[i]; return r; }
-__device__ inline D5 pow5(D5 a, double p) { double f = pow(a.v, p); return chain5(a, f, p * f / a.v); }
-__device__ inline D5 sqrt5(D5 a) { double f = sqrt(a.v); return chain5(a, f, 0.5 / f); }
-__device__ inline D5 log5(D5 a) { return chain5(a, log(a.v), 1.0 / a.v); }
-__device__ inline D5 exp5(D5 a) { double f = exp(a.v); return chain5(a, f, f); }
-__device__ inline D5 atan5(D5 a) { return chain5(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
-__device__ inline D5 asinh5(D5 a) { return chain5(a, asinh(a.v), 1.0 / sqrt(1.0 + a.v * a.v)); }
+template <class S> __device__ inline D5T<S> operator+(D5T<S> a, double b) { a.v = a.v + b; return a; }
+template <class S> __device__ inline D5T<S> operator+(double a, D5T<S> b) { b.v = b.v + a; return b; }
+template <class S> __device__ inline D5T<S> operator-(D5T<S> a, double b) { a.v = a.v - b; return a; }
+template <class S> __device__ inline D5T<S> operator-(double a, D5T<S> b) { return c5<S>(a) - b; }
+template <class S> __device__ inline D5T<S> operator*(D5T<S> a, double b) { a.v = a.v * b; for (int i = 0; i < 5; i++) a.d[i] = a.d[i] * b; return a; }
+template <class S> __device__ inline D5T<S> operator*(double a, D5T<S> b) { return b * a; }
+template <class S> __device__ inline D5T<S> operator/(D5T<S> a, double b) { return a * (1.0 / b); }
+template <class S> __device__ inline D5T<S> operator/(double a, D5T<S> b) { return c5<S>(a) / b; }
+template <class S> __device__ inline D5T<S> chain5(D5T<S> a, S f, S df) { D5T<S> r; r.v = f; for (int i = 0; i < 5; i++) r.d[i] = df * a.d[i]; return r; }
+template <class S> __device__ inline D5T<S> pow5(D5T<S> a, double p) { S f = s_pow(a.v, p); return chain5(a, f, p * f / a.v); }
+template <class S> __device__ inline D5T<S> sqrt5(D5T<S> a) { S f = s_sqrt(a.v); return chain5(a, f, 0.5 / f); }
+template <class S> __device__ inline D5T<S> log5(D5T<S> a) { return chain5(a, s_log(a.v), 1.0 / a.v); }
+template <class S> __device__ inline D5T<S> exp5(D5T<S> a) { S f = s_exp(a.v); return chain5(a, f, f); }
+template <class S> __device__ inline D5T<S> atan5(D5T<S> a) { return chain5(a, s_atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+template <class S> __device__ inline D5T<S> asinh5(D5T<S> a) { return chain5(a, s_asinh(a.v), 1.0 / s_sqrt(1.0 + a.v * a.v)); }
 
-__device__ inline D5 slater_pol(D5 ra, D5 rb)
+template <class S> __device__ inline D5T<S> slater_pol(D5T<S> ra, D5T<S> rb)
 {
     const double cx = 1.5 * 0.62035049089940001;       // (3/2)(3/(4 pi))^(1/3)
     return -cx * (pow5(ra, 4.0 / 3.0) + pow5(rb, 4.0 / 3.0));
 }
-__device__ inline D5 vwn_eps5(D5 rho, double A, double x0, double b, double c)
+template <class S> __device__ inline D5T<S> vwn_eps5(D5T<S> rho, double A, double x0, double b, double c)
 {
-    D5 rs = pow5(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
-    D5 x = sqrt5(rs);
+    D5T<S> rs = pow5(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
+    D5T<S> x = sqrt5(rs);
     const double Q = sqrt(4 * c - b * b);
-    D5 X = x * x + b * x + c;
+    D5T<S> X = x * x + b * x + c;
     const double X0 = x0 * x0 + b * x0 + c;
-    D5 at = atan5(Q / (2.0 * x + b));
-    D5 t1 = log5(x * x / X) + (2 * b / Q) * at;
-    D5 t2 = log5((x - x0) * (x - x0) / X) + (2 * (b + 2 * x0) / Q) * at;
+    D5T<S> at = atan5(Q / (2.0 * x + b));
+    D5T<S> t1 = log5(x * x / X) + (2 * b / Q) * at;
+    D5T<S> t2 = log5((x - x0) * (x - x0) / X) + (2 * (b + 2 * x0) / Q) * at;
     return A * (t1 - (b * x0 / X0) * t2);
 }
-__device__ inline D5 fzeta5(D5 zeta)
+template <class S> __device__ inline D5T<S> fzeta5(D5T<S> zeta)
 {
     // guard the fully polarised limit: (1 -+ zeta)^(4/3) with a tiny floor keeps the derivative finite
-    D5 p = 1.0 + zeta, m = 1.0 - zeta;
-    if (p.v < 1e-14) p.v = 1e-14;
-    if (m.v < 1e-14) m.v = 1e-14;
+    D5T<S> p = 1.0 + zeta, m = 1.0 - zeta;
+    floor_at(p.v, 1e-14);
+    floor_at(m.v, 1e-14);
     return (pow5(p, 4.0 / 3.0) + pow5(m, 4.0 / 3.0) - 2.0) / (2.5198420997897464 - 2.0);
 }
 // VWN5: para + spin stiffness + ferro (Vosko, Wilk, Nusair 1980, eq. 4.4 interpolation)
-__device__ inline D5 vwn5_pol(D5 rho, D5 zeta)
+template <class S> __device__ inline D5T<S> vwn5_pol(D5T<S> rho, D5T<S> zeta)
 {
-    D5 eP = vwn_eps5(rho, 0.0310907, -0.10498, 3.72744, 12.9352);
-    D5 eF = vwn_eps5(rho, 0.01554535, -0.32500, 7.06042, 18.0578);
-    D5 eA = vwn_eps5(rho, -1.0 / (6.0 * PI * PI), -0.0047584, 1.13107, 13.0045);
+    D5T<S> eP = vwn_eps5(rho, 0.0310907, -0.10498, 3.72744, 12.9352);
+    D5T<S> eF = vwn_eps5(rho, 0.01554535, -0.32500, 7.06042, 18.0578);
+    D5T<S> eA = vwn_eps5(rho, -1.0 / (6.0 * PI * PI), -0.0047584, 1.13107, 13.0045);
     const double fpp = 4.0 / (9.0 * (1.2599210498948732 - 1.0));
-    D5 f = fzeta5(zeta);
-    D5 z4 = zeta * zeta * zeta * zeta;
+    D5T<S> f = fzeta5(zeta);
+    D5T<S> z4 = zeta * zeta * zeta * zeta;
     return rho * (eP + eA * f / fpp * (1.0 - z4) + (eF - eP) * f * z4);
 }
 // VWN-RPA (libxc LDA_C_VWN_RPA): linear interpolation in f(zeta) between para and ferro RPA fits
-__device__ inline D5 vwnrpa_pol(D5 rho, D5 zeta)
+template <class S> __device__ inline D5T<S> vwnrpa_pol(D5T<S> rho, D5T<S> zeta)
 {
-    D5 eP = vwn_eps5(rho, 0.0310907, -0.409286, 13.0720, 42.7198);
-    D5 eF = vwn_eps5(rho, 0.01554535, -0.743294, 20.1231, 101.578);
-    D5 f = fzeta5(zeta);
+    D5T<S> eP = vwn_eps5(rho, 0.0310907, -0.409286, 13.0720, 42.7198);
+    D5T<S> eF = vwn_eps5(rho, 0.01554535, -0.743294, 20.1231, 101.578);
+    D5T<S> f = fzeta5(zeta);
     return rho * (eP * (1.0 - f) + eF * f);
 }
-__device__ inline D5 b88_spin(D5 r, D5 s)
+template <class S> __device__ inline D5T<S> b88_spin(D5T<S> r, D5T<S> s)
 {
     const double beta = 0.0042, cx = 1.5 * 0.62035049089940001;
-    D5 r43 = pow5(r, 4.0 / 3.0);
-    D5 x = sqrt5(s + 1e-300) / r43;
+    D5T<S> r43 = pow5(r, 4.0 / 3.0);
+    D5T<S> x = sqrt5(s + 1e-300) / r43;
     return -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * asinh5(x));
 }
-__device__ inline D5 lyp_pol(D5 ra, D5 rb, D5 saa, D5 sab, D5 sbb)
+template <class S> __device__ inline D5T<S> lyp_pol(D5T<S> ra, D5T<S> rb, D5T<S> saa, D5T<S> sab, D5T<S> sbb)
 {
     const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349;
     const double CF = 0.3 * 9.5707800006273392;
-    D5 rho = ra + rb;
-    D5 sig = saa + 2.0 * sab + sbb;
-    D5 rm13 = pow5(rho, -1.0 / 3.0);
-    D5 den = 1.0 + d * rm13;
-    D5 omega = exp5(-c * rm13) / den * pow5(rho, -11.0 / 3.0);
-    D5 delta = c * rm13 + d * rm13 / den;
-    D5 rab = ra * rb;
-    D5 br = rab * (pow(2.0, 11.0 / 3.0) * CF * (pow5(ra, 8.0 / 3.0) + pow5(rb, 8.0 / 3.0))
+    D5T<S> rho = ra + rb;
+    D5T<S> sig = saa + 2.0 * sab + sbb;
+    D5T<S> rm13 = pow5(rho, -1.0 / 3.0);
+    D5T<S> den = 1.0 + d * rm13;
+    D5T<S> omega = exp5(-c * rm13) / den * pow5(rho, -11.0 / 3.0);
+    D5T<S> delta = c * rm13 + d * rm13 / den;
+    D5T<S> rab = ra * rb;
+    D5T<S> br = rab * (pow(2.0, 11.0 / 3.0) * CF * (pow5(ra, 8.0 / 3.0) + pow5(rb, 8.0 / 3.0))
                    + (47.0 / 18.0 - 7.0 / 18.0 * delta) * sig
                    - (2.5 - delta / 18.0) * (saa + sbb)
                    - (delta - 11.0) / 9.0 * (ra / rho * saa + rb / rho * sbb))
@@ -379,49 +381,52 @@ __device__ inline D5 lyp_pol(D5 ra, D5 rb, D5 saa, D5 sab, D5 sbb)
 }
 
 // PBE exchange of one spin channel: E_x[rho_a, rho_b] = (E_x[2 rho_a] + E_x[2 rho_b]) / 2 (spin-scaling relation)
-__device__ inline D5 pbe_x_spin(D5 r, D5 s)
+template <class S> __device__ inline D5T<S> pbe_x_spin(D5T<S> r, D5T<S> s)
 {
     const double kappa = 0.804, mu = 0.2195149727645171;
     const double cx = 0.75 * 0.98474502184269654;     // (3/4)(3/pi)^(1/3)
-    D5 rho = 2.0 * r, sigma = 4.0 * s;
-    D5 ex_lda = -cx * pow5(rho, 4.0 / 3.0);
-    D5 kf = pow5(3.0 * PI * PI * rho, 1.0 / 3.0);
-    D5 s2 = sigma / (4.0 * kf * kf * rho * rho);
-    D5 fx = 1.0 + kappa - kappa / (1.0 + mu / kappa * s2);
+    D5T<S> rho = 2.0 * r, sigma = 4.0 * s;
+    D5T<S> ex_lda = -cx * pow5(rho, 4.0 / 3.0);
+    D5T<S> kf = pow5(3.0 * PI * PI * rho, 1.0 / 3.0);
+    D5T<S> s2 = sigma / (4.0 * kf * kf * rho * rho);
+    D5T<S> fx = 1.0 + kappa - kappa / (1.0 + mu / kappa * s2);
     return 0.5 * ex_lda * fx;
 }
 // Perdew-Wang 1992 G function, "pw_mod" digits (the variant PBE is built on)
-__device__ inline D5 pw92_g5(D5 rs, double A, double a1, double b1, double b2, double b3, double b4)
+template <class S> __device__ inline D5T<S> pw92_g5(D5T<S> rs, double A, double a1, double b1, double b2, double b3, double b4)
 {
-    D5 srs = sqrt5(rs);
-    D5 q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
+    D5T<S> srs = sqrt5(rs);
+    D5T<S> q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
     return -2.0 * A * (1.0 + a1 * rs) * log5(1.0 + 1.0 / q);
 }
 // PBE correlation for a spin-polarised density (Perdew, Burke, Ernzerhof 1996, eqs. 3-8)
-__device__ inline D5 pbe_c_pol(D5 rho, D5 zeta, D5 sigma)
+template <class S> __device__ inline D5T<S> pbe_c_pol(D5T<S> rho, D5T<S> zeta, D5T<S> sigma)
 {
     const double beta = 0.06672455060314922, gamma = 0.031090690869654895;
     const double fz20 = 1.709920934161365617563962776245;
-    D5 rs = pow5(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
-    D5 e0 = pw92_g5(rs, 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
-    D5 e1 = pw92_g5(rs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
-    D5 mac = pw92_g5(rs, 0.0168869, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);      // -alpha_c
-    D5 f = fzeta5(zeta);
-    D5 z4 = zeta * zeta * zeta * zeta;
-    D5 ec = e0 - mac * f / fz20 * (1.0 - z4) + (e1 - e0) * f * z4;
-    D5 p = 1.0 + zeta, m = 1.0 - zeta;
-    if (p.v < 1e-14) p.v = 1e-14;
-    if (m.v < 1e-14) m.v = 1e-14;
-    D5 phi = 0.5 * (pow5(p, 2.0 / 3.0) + pow5(m, 2.0 / 3.0));
-    D5 phi3 = phi * phi * phi;
-    D5 kf = pow5(3.0 * PI * PI * rho, 1.0 / 3.0);
-    D5 ks2 = 4.0 * kf / PI;
-    D5 t2 = sigma / (4.0 * phi * phi * ks2 * rho * rho);
-    D5 Aa = beta / gamma / (exp5(-ec / (gamma * phi3)) - 1.0);
-    D5 num = 1.0 + Aa * t2;
-    D5 H = gamma * phi3 * log5(1.0 + beta / gamma * t2 * num / (1.0 + Aa * t2 + Aa * Aa * t2 * t2));
+    D5T<S> rs = pow5(3.0 / (4.0 * PI) / rho, 1.0 / 3.0);
+    D5T<S> e0 = pw92_g5(rs, 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+    D5T<S> e1 = pw92_g5(rs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+    D5T<S> mac = pw92_g5(rs, 0.0168869, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);      // -alpha_c
+    D5T<S> f = fzeta5(zeta);
+    D5T<S> z4 = zeta * zeta * zeta * zeta;
+    D5T<S> ec = e0 - mac * f / fz20 * (1.0 - z4) + (e1 - e0) * f * z4;
+    D5T<S> p = 1.0 + zeta, m = 1.0 - zeta;
+    floor_at(p.v, 1e-14);
+    floor_at(m.v, 1e-14);
+    D5T<S> phi = 0.5 * (pow5(p, 2.0 / 3.0) + pow5(m, 2.0 / 3.0));
+    D5T<S> phi3 = phi * phi * phi;
+    D5T<S> kf = pow5(3.0 * PI * PI * rho, 1.0 / 3.0);
+    D5T<S> ks2 = 4.0 * kf / PI;
+    D5T<S> t2 = sigma / (4.0 * phi * phi * ks2 * rho * rho);
+    D5T<S> Aa = beta / gamma / (exp5(-ec / (gamma * phi3)) - 1.0);
+    D5T<S> num = 1.0 + Aa * t2;
+    D5T<S> H = gamma * phi3 * log5(1.0 + beta / gamma * t2 * num / (1.0 + Aa * t2 + Aa * Aa * t2 * t2));
     return rho * (ec + H);
 }
+
+using D5 = D5T<double>;
+__device__ inline D5 var5(double v, int k) { D5 r = c5<double>(v); r.d[k] = 1; return r; }
 
 // rho_a / rho_b [4][ldg]; wv_a / wv_b [4][ldg]: wv_s0 = 0.5 w vrho_s, wv_s(1..3) = w (2 vsigma_ss grad rho_s +
 // vsigma_ab grad rho_other)  (pyscf/dft/numint.py:1192-1324, xc_deriv.transform_vxc for spin = 1)
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(256) void eval_xc_pol_kernel(XCSpec spec, int gga, 
             D5 Sbb = var5(gb[0] * gb[0] + gb[1] * gb[1] + gb[2] * gb[2], 4);
             D5 rho = Ra + Rb;
             D5 zeta = (Ra - Rb) / rho;
-            D5 tot = c5(0);
+            D5 tot = c5<double>(0);
             if (spec.fac[F_SLATER] != 0) tot = tot + spec.fac[F_SLATER] * slater_pol(Ra, Rb);
             if (spec.fac[F_VWN5] != 0) tot = tot + spec.fac[F_VWN5] * vwn5_pol(rho, zeta);
             if (spec.fac[F_VWNRPA] != 0) tot = tot + spec.fac[F_VWNRPA] * vwnrpa_pol(rho, zeta);
@@ -481,6 +486,64 @@ __global__ __launch_bounds__(256) void eval_xc_pol_kernel(XCSpec spec, int gga, 
         double v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
         atomicAdd(acc + threadIdx.x, v);
     }
+}
+
+// Spin-polarised response weights (numint.nr_uks_fxc, numint.py:1690-1832, weights of _uks_gga_wv1 :1834-1915): the
+// first-order change of (v_rho_a, v_rho_b, v_sigma_aa, v_sigma_ab, v_sigma_bb) along the first-order spin densities,
+// from the functionals evaluated on D5T<Eps>;
+//   wv1_a[0] = 0.5 w d v_rho_a,  wv1_a[k] = w [2 d v_aa grad_k rho0_a + d v_ab grad_k rho0_b + 2 v_aa grad_k rho1_a + v_ab grad_k rho1_b]
+__global__ __launch_bounds__(256) void eval_fxc_pol_kernel(XCSpec spec, int gga, const double *__restrict__ rho0_a,
+                                                           const double *__restrict__ rho0_b,
+                                                           const double *__restrict__ rho1_a,
+                                                           const double *__restrict__ rho1_b,
+                                                           const double *__restrict__ weights, long ng, long ldg,
+                                                           double *__restrict__ wv_a, double *__restrict__ wv_b)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ng) return;
+    const double w = weights[g];
+    double ra = rho0_a[g], rb = rho0_b[g];
+    const double ta = rho1_a[g], tb = rho1_b[g];
+    double ga[3] = {0, 0, 0}, gb[3] = {0, 0, 0}, ha[3] = {0, 0, 0}, hb[3] = {0, 0, 0};
+    if (gga)
+        for (int x = 0; x < 3; x++) {
+            ga[x] = rho0_a[(x + 1) * ldg + g]; gb[x] = rho0_b[(x + 1) * ldg + g];
+            ha[x] = rho1_a[(x + 1) * ldg + g]; hb[x] = rho1_b[(x + 1) * ldg + g];
+        }
+    double dv[5] = {0, 0, 0, 0, 0}, v[5] = {0, 0, 0, 0, 0};
+    if (ra + rb > 1e-14) {
+        if (ra < 1e-30) ra = 1e-30;
+        if (rb < 1e-30) rb = 1e-30;
+        const double val[5] = {ra, rb, ga[0] * ga[0] + ga[1] * ga[1] + ga[2] * ga[2],
+                               ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2], gb[0] * gb[0] + gb[1] * gb[1] + gb[2] * gb[2]};
+        const double dir[5] = {ta, tb, 2 * (ga[0] * ha[0] + ga[1] * ha[1] + ga[2] * ha[2]),
+                               ga[0] * hb[0] + ga[1] * hb[1] + ga[2] * hb[2] + gb[0] * ha[0] + gb[1] * ha[1] + gb[2] * ha[2],
+                               2 * (gb[0] * hb[0] + gb[1] * hb[1] + gb[2] * hb[2])};
+        D5T<Eps> X[5];
+        for (int k = 0; k < 5; k++) {
+            X[k] = c5<Eps>(val[k]);
+            X[k].v.e = dir[k];
+            X[k].d[k].v = 1.0;
+        }
+        D5T<Eps> rho = X[0] + X[1];
+        D5T<Eps> zeta = (X[0] - X[1]) / rho;
+        D5T<Eps> tot = c5<Eps>(0);
+        if (spec.fac[F_SLATER] != 0) tot = tot + spec.fac[F_SLATER] * slater_pol(X[0], X[1]);
+        if (spec.fac[F_VWN5] != 0) tot = tot + spec.fac[F_VWN5] * vwn5_pol(rho, zeta);
+        if (spec.fac[F_VWNRPA] != 0) tot = tot + spec.fac[F_VWNRPA] * vwnrpa_pol(rho, zeta);
+        if (spec.fac[F_B88] != 0) tot = tot + spec.fac[F_B88] * (b88_spin(X[0], X[2]) + b88_spin(X[1], X[4]));
+        if (spec.fac[F_LYP] != 0) tot = tot + spec.fac[F_LYP] * lyp_pol(X[0], X[1], X[2], X[3], X[4]);
+        if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * (pbe_x_spin(X[0], X[2]) + pbe_x_spin(X[1], X[4]));
+        if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c_pol(rho, zeta, X[2] + 2.0 * X[3] + X[4]);
+        for (int k = 0; k < 5; k++) { v[k] = tot.d[k].v; dv[k] = tot.d[k].e; }
+    }
+    wv_a[g] = 0.5 * w * dv[0];
+    wv_b[g] = 0.5 * w * dv[1];
+    if (gga)
+        for (int x = 0; x < 3; x++) {
+            wv_a[(x + 1) * ldg + g] = w * (2.0 * dv[2] * ga[x] + dv[3] * gb[x] + 2.0 * v[2] * ha[x] + v[3] * hb[x]);
+            wv_b[(x + 1) * ldg + g] = w * (2.0 * dv[4] * gb[x] + dv[3] * ga[x] + 2.0 * v[4] * hb[x] + v[3] * ha[x]);
+        }
 }
 
 // rho from c[comp][i][ldc] = sum_mu C_occ[mu][i] ao_comp[g][mu]   (orbital rows, grid index fastest)
@@ -739,6 +802,21 @@ int PAMD_eval_fxc(const double *fac7, int gga, const double *d_rho0, const doubl
     for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
     eval_fxc_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho0, d_rho1, d_weights, ng, ldg,
                                                                         d_wv1);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// Spin-polarised response kernel: first-order weights d_wv1_a / d_wv1_b [4][ldg] from the zeroth-order (d_rho0_a/b) and
+// first-order (d_rho1_a/b) spin densities [4][ldg].  numint.nr_uks_fxc (dft/numint.py:1690-1915).
+int PAMD_eval_fxc_pol(const double *fac7, int gga, const double *d_rho0_a, const double *d_rho0_b, const double *d_rho1_a,
+                      const double *d_rho1_b, const double *d_weights, long ng, long ldg, double *d_wv1_a,
+                      double *d_wv1_b, void *stream)
+{
+    if (ng == 0) return 0;
+    XCSpec spec;
+    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
+    eval_fxc_pol_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho0_a, d_rho0_b, d_rho1_a,
+                                                                            d_rho1_b, d_weights, ng, ldg, d_wv1_a, d_wv1_b);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

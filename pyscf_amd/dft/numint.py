@@ -408,12 +408,104 @@ class NumInt:
             vmat[i] = v.cpu().numpy()
         return vmat.reshape(shape)
 
+    def nr_uks_fxc(self, mol, grids, xc_code, dm0, dms, relativity=0, hermi=0, rho0=None, vxc=None, fxc=None,
+                   max_memory=2000, verbose=None):
+        """Spin-polarised XC kernel contracted with first-order spin density matrices, the contract of numint.nr_uks_fxc
+        (numint.py:1690-1832): dm0 = (dm0_alpha, dm0_beta); dms = (dm1_alpha, dm1_beta), each (nao, nao) or
+        (nset, nao, nao); returns vmat (2, nao, nao) or (2, nset, nao, nao).  Same pipeline as nr_rks_fxc with
+        ``PAMD_eval_fxc_pol``; cached rho0 / vxc / fxc are not used."""
+        import torch
+        lib = _lib_mod.load_library()
+        dev = self._dev()
+        if grids.coords is None:
+            grids.build()
+        hyb, fac = _xc.parse_xc(xc_code)
+        xctype = _xc.xc_type(xc_code)
+        dma, dmb = np.asarray(dms[0], dtype=np.float64), np.asarray(dms[1], dtype=np.float64)
+        nao = dma.shape[-1]
+        single = dma.ndim == 2
+        dma, dmb = dma.reshape(-1, nao, nao), dmb.reshape(-1, nao, nao)
+        nset = len(dma)
+        vmat = np.zeros((2, nset, nao, nao))
+        if xctype != 'HF':
+            gga = 1 if xctype == 'GGA' else 0
+            ncomp = 4 if gga else 1
+            coords_dev, weights_dev = self._grid_tables(grids, dev)
+            ngrids = grids.size
+            ldao = _round_up(nao, 16)
+            rank, world = self._world()
+            blk = grid_block_size(ngrids, int(self.block_bytes // (ncomp * ldao * 8)), world)
+            st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+            f64 = torch.float64
+            ao = torch.zeros(ncomp * blk * ldao + 256, dtype=f64, device=dev)[:ncomp * blk * ldao].view(ncomp, blk, ldao)
+            aow = torch.zeros(blk * ldao + 256, dtype=f64, device=dev)[:blk * ldao].view(blk, ldao)
+            rho_0 = torch.zeros((2, 4, blk), dtype=f64, device=dev)
+            rho_1 = torch.zeros((2, 4, blk), dtype=f64, device=dev)
+            wv = torch.empty((2, 4, blk), dtype=f64, device=dev)
+            c0t = torch.empty((nao, blk), dtype=f64, device=dev)
+            nsplit = self.vmat_nsplit or pick_nsplit(((nao + 159) // 160) * ((nao + 127) // 128))
+            fac_c = (ctypes.c_double * 7)(*fac)
+            ldd = _round_up(nao, 128)
+
+            def padded(d):
+                d_h = np.zeros((nao, ldd))
+                d_h[:, :nao] = (d + d.T) * .5
+                return torch.from_numpy(d_h).to(dev)
+            d0 = [padded(np.asarray(dm0[s], dtype=np.float64)) for s in range(2)]
+            d1 = [[padded(d) for d in dma], [padded(d) for d in dmb]]
+            parts = torch.zeros((2, nset, nsplit, nao, nao), dtype=f64, device=dev)
+
+            def density(dmat, ng, out):
+                self._call('dm_dot_ao', lib.PAMD_cderi_solve, _ptr(dmat), _c.c_int(ldd), _ptr(ao[0]), _c.c_long(ldao),
+                           _ptr(c0t), _c.c_long(blk), _c.c_int(nao), _c.c_long(ng), _c.c_int(nao), _c.c_int(0), _c.c_int(0), st)
+                self._call('rho', lib.PAMD_rho_from_dm, _ptr(ao), _ptr(c0t), _c.c_int(nao), _c.c_int(ldao), _c.c_long(blk),
+                           _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _ptr(out), _c.c_long(blk), st)
+            for ib, g0 in enumerate(range(0, ngrids, blk)):
+                if ib % world != rank:
+                    continue
+                ng = min(blk, ngrids - g0)
+                ng16 = _round_up(ng, 16)
+                self.eval_ao_block(mol, coords_dev, g0, ng, gga, ao, blk, ldao, None)
+                for s in range(2):
+                    density(d0[s], ng, rho_0[s])
+                for i in range(nset):
+                    for s in range(2):
+                        density(d1[s][i], ng, rho_1[s])
+                    self._call('eval_fxc', lib.PAMD_eval_fxc_pol, fac_c, _c.c_int(gga), _ptr(rho_0[0]), _ptr(rho_0[1]),
+                               _ptr(rho_1[0]), _ptr(rho_1[1]), _ptr(weights_dev[g0:g0 + ng]), _c.c_long(ng), _c.c_long(blk),
+                               _ptr(wv[0]), _ptr(wv[1]), st)
+                    for s in range(2):
+                        self._call('scale_ao', lib.PAMD_scale_ao, _ptr(ao), _ptr(wv[s]), _c.c_int(ldao), _c.c_long(blk),
+                                   _c.c_long(blk), _c.c_int(ncomp), _c.c_long(ng), _c.c_long(ng16), _ptr(aow), st)
+                        self._call('ao_dot_aow', lib.PAMD_dgemm_tn, _ptr(ao[0]), _c.c_int(ldao), _ptr(aow), _c.c_int(ldao),
+                                   _ptr(parts[s, i]), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(ng16),
+                                   _c.c_int(2), _c.c_int(nsplit), st)
+            v = torch.empty((nao, nao), dtype=f64, device=dev)
+            for s in range(2):
+                for i in range(nset):
+                    self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(parts[s, i]), _c.c_int(nsplit), _c.c_int(nao),
+                               _c.c_int(nao), _ptr(v), st)
+                    if world > 1:
+                        import torch.distributed as dist
+                        dist.all_reduce(v, group=self.group)
+                    vmat[s, i] = v.cpu().numpy()
+        return vmat[:, 0] if single else vmat
+
+    def nr_rks_fxc_st(self, mol, grids, xc_code, dm0, dms_alpha, relativity=0, hermi=0, singlet=True, rho0=None, vxc=None,
+                      fxc=None, max_memory=2000, verbose=None):
+        """Singlet / triplet kernel of a closed-shell reference contracted with ALPHA first-order density matrices
+        (numint.py:1532-1549: fxc_aa +- fxc_ab): the alpha response of the spin-polarised kernel at (dm0/2, dm0/2) to
+        (dm1, +dm1) or (dm1, -dm1)."""
+        half = np.asarray(dm0, dtype=np.float64) * .5
+        d1 = np.asarray(dms_alpha, dtype=np.float64)
+        return self.nr_uks_fxc(mol, grids, xc_code, (half, half), (d1, d1 if singlet else -d1), relativity, hermi,
+                               max_memory=max_memory)[0]
+
     def nr_fxc(self, mol, grids, xc_code, dm0, dms, spin=0, relativity=0, hermi=0, rho0=None, vxc=None, fxc=None,
                max_memory=2000, verbose=None):
-        """numint.nr_fxc (numint.py:2846-2860): spin 0 dispatches to nr_rks_fxc; the spin-polarised kernel is not built."""
-        if spin != 0:
-            raise NotImplementedError('nr_uks_fxc')
-        return self.nr_rks_fxc(mol, grids, xc_code, dm0, dms, relativity, hermi, rho0, vxc, fxc, max_memory, verbose)
+        """numint.nr_fxc (numint.py:2846-2860): dispatch on spin."""
+        fn = self.nr_rks_fxc if spin == 0 else self.nr_uks_fxc
+        return fn(mol, grids, xc_code, dm0, dms, relativity, hermi, rho0, vxc, fxc, max_memory, verbose)
 
     def nr_rks_grad(self, mol, grids, xc_code, dm, grid_response=False):
         """XC part of the closed-shell nuclear gradient, (natm, 3), grid response left out: the contraction

@@ -329,3 +329,47 @@ def test_nr_rks_fxc_vs_oracle_and_finite_differences(xc):
     single = ni.nr_rks_fxc(mol, grids, xc, dm0, d_oo, hermi=1)
     assert single.shape == (mol.nao, mol.nao) and np.abs(single - v[0]).max() < 1e-12
     assert np.abs(ni.nr_fxc(mol, grids, 'HF', dm0, d_oo)).max() == 0
+
+
+@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe'])
+def test_nr_uks_fxc_and_singlet_triplet(xc):
+    """NumInt.nr_uks_fxc / nr_rks_fxc_st (numint.py:1532-1549,1690-1915) from PAMD_eval_fxc_pol (the spin-polarised
+    functionals on nested dual numbers): (i) on a closed-shell reference the singlet kernel equals the closed-shell one,
+    nr_rks_fxc(2 dm1) - two independent functional codes; (ii) open-shell cation against the derivative of the oracle's
+    nr_uks potential (Richardson finite differences of the sympy restatement); (iii) triplet kernel against the same
+    oracle with (dm1, -dm1)."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    mf = dft.RKS(mol, xc='lda,vwn').density_fit().run()
+    dm0 = mf.make_rdm1()
+    occ = mf.mo_occ > 0
+    co = mf.mo_coeff[:, occ]
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((co.shape[1], co.shape[1]))
+    b = rng.standard_normal((co.shape[1], co.shape[1]))
+    d1, d2 = co.dot(a + a.T).dot(co.T), co.dot(b + b.T).dot(co.T)
+    grids = dft.Grids(mol)
+    grids.atom_grid = (40, 110)
+    grids.build()
+    ni = dft.NumInt()
+    hyb, fac = libxc.parse_xc(xc)
+    gga = libxc.xc_type(xc) == 'GGA'
+    n = len(grids.atm_idx)
+    c, w = grids.coords[:n], grids.weights[:n]
+    singlet = ni.nr_rks_fxc_st(mol, grids, xc, dm0, np.array([d1, d2]), singlet=True)
+    closed = ni.nr_rks_fxc(mol, grids, xc, dm0, 2 * np.array([d1, d2]))
+    assert np.abs(singlet - closed).max() < 1e-9 * max(1.0, np.abs(closed).max()), np.abs(singlet - closed).max()
+    triplet = ni.nr_rks_fxc_st(mol, grids, xc, dm0, d1, singlet=False)
+    want = ref_dft.nr_uks_fxc(mol, c, w, fac, gga, dm0 * .5, dm0 * .5, d1, -d1)[0]
+    assert np.abs(triplet - want).max() < 2e-6 * max(1.0, np.abs(want).max()), np.abs(triplet - want).max()
+    # open shell: alpha has one more occupied orbital than beta
+    da = co.dot(co.T)
+    db = co[:, :-1].dot(co[:, :-1].T)
+    d1b = co[:, :-1].dot((b + b.T)[:-1, :-1]).dot(co[:, :-1].T)
+    v = ni.nr_uks_fxc(mol, grids, xc, (da, db), (d1, d1b))
+    assert v.shape == (2, mol.nao, mol.nao)
+    want = ref_dft.nr_uks_fxc(mol, c, w, fac, gga, da, db, d1, d1b)
+    assert np.abs(v - want).max() < 2e-6 * max(1.0, np.abs(want).max()), np.abs(v - want).max()
+    vs = ni.nr_fxc(mol, grids, xc, (da, db), (np.array([d1, d2]), np.array([d1b, d1b])), spin=1)
+    assert vs.shape == (2, 2, mol.nao, mol.nao) and np.abs(vs[:, 0] - v).max() < 1e-12

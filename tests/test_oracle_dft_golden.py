@@ -285,3 +285,25 @@ def test_oracle_fxc_reference_fingerprints_and_finite_differences():
         vm = ref_dft.nr_rks(mol1, coords, weights, fac, gga, dmp - eps * d1)[2]
         v1 = ref_dft.nr_rks_fxc(mol1, coords, weights, fac, gga, dmp, d1)
         assert np.abs((vp - vm) / (2 * eps) - v1).max() < 2e-6 * max(1.0, np.abs(v1).max()), xc
+
+
+def test_oracle_uks_fxc_reduces_to_closed_shell_kernel():
+    """The finite-difference restatement of nr_uks_fxc (spin-polarised sympy functionals) against the closed-shell kernel
+    with sympy second derivatives: alpha response of (dm0/2, dm0/2) to (d1, d1) = nr_rks_fxc(dm0, 2 d1)
+    (numint.py:1532-1549, singlet combination fxc_aa + fxc_ab)."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom=H2O, basis='6-31g')
+    coords, weights = ref_dft.build_grids(mol, {'H': (20, 50), 'O': (20, 50)})
+    nao = mol.nao_nr()
+    rng = np.random.default_rng(3)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0][:, :5]
+    a = rng.standard_normal((5, 5))
+    dm0, d1 = 2 * c.dot(c.T), c.dot(a + a.T).dot(c.T)
+    for xc in ('lda,vwn', 'b3lyp', 'pbe,pbe'):
+        fac = libxc.parse_xc(xc)[1]
+        gga = libxc.xc_type(xc) == 'GGA'
+        vu = ref_dft.nr_uks_fxc(mol, coords, weights, fac, gga, dm0 * .5, dm0 * .5, d1, d1)
+        vr = ref_dft.nr_rks_fxc(mol, coords, weights, fac, gga, dm0, 2 * d1)
+        assert np.abs(vu[0] - vr).max() < 2e-6 * max(1.0, np.abs(vr).max()), (xc, np.abs(vu[0] - vr).max())
+        assert np.abs(vu[1] - vr).max() < 2e-6 * max(1.0, np.abs(vr).max())
