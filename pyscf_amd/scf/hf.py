@@ -317,6 +317,11 @@ class SCF:
 
     Gradients = nuc_grad_method
 
+    def gen_response(self, *args, **kwargs):
+        """vind(dm1): response of the Fock matrix to a first-order density (pyscf/scf/_response_functions.py)."""
+        from . import _response_functions
+        return _response_functions.gen_response(self, *args, **kwargs)
+
 
 class RHF(SCF):
     pass
