@@ -325,6 +325,11 @@ class NumInt:
             return nelec[0], excsum[0], vmat[0]
         return nelec, excsum, vmat.reshape(shape)
 
+    def nr_vxc(self, mol, grids, xc_code, dms, spin=0, relativity=0, hermi=1, max_memory=2000, verbose=None):
+        """numint.nr_vxc (numint.py:1052-1072): dispatch on spin to nr_rks / nr_uks."""
+        fn = self.nr_rks if spin == 0 else self.nr_uks
+        return fn(mol, grids, xc_code, dms, relativity, hermi, max_memory, verbose)
+
     def nr_rks_fxc(self, mol, grids, xc_code, dm0, dms, relativity=0, hermi=0, rho0=None, vxc=None, fxc=None,
                    max_memory=2000, verbose=None):
         """Closed-shell XC kernel contracted with first-order density matrices, the contract of numint.nr_rks_fxc
