@@ -1,0 +1,187 @@
+"""Linear-response excitation energies of closed-shell DF-RHF / DF-RKS references: TDA and TDDFT (RPA).
+
+Host-side drivers in the place of ``pyscf/tdscf/rhf.py`` (``TDA`` :694-806, ``TDHF`` :890-1003, ``get_ab`` :137-216,
+``gen_tda_operation`` :47-104) and ``pyscf/tdscf/rks.py``; all electron-repulsion and grid work is one call of
+``mf.gen_response(singlet=..., hermi=0)`` per batch of trial vectors, i.e. the device path (multi-matrix ``DF.get_jk`` on
+the general-DM branch + ``nr_rks_fxc`` / ``nr_rks_fxc_st``).  For a trial amplitude X[i,a] the first-order density is
+dm1 = 2 C_occ X C_vir^T and, with v = vind(dm1),
+
+    (A X)_ia = (e_a - e_i) X_ia + (C_occ^T v   C_vir)_ia        (B X)_ia = (C_occ^T v^T C_vir)_ia
+
+so one response call gives both blocks.  TDA diagonalises A (Davidson with the orbital-energy-difference preconditioner;
+dense when the single-excitation space is small), TDDFT solves (A - B)(A + B) Z = w^2 Z, Z = X + Y.
+Amplitudes are normalised like the reference: <X|X> - <Y|Y> = 1/2.
+"""
+import numpy as np
+
+DENSE_MAX = 2000          # single-excitation dimension up to which A (and B) are formed and diagonalised directly
+
+
+class TDA:
+    """``tdscf.TDA(mf)``; attributes of the reference that drivers set: singlet, nstates, conv_tol, max_cycle."""
+
+    def __init__(self, mf):
+        mo_occ = np.asarray(mf.mo_occ)
+        if mo_occ.ndim != 1 or np.any((mo_occ > 0) & (mo_occ < 2)):
+            raise NotImplementedError('TDA / TDDFT drivers are built for closed-shell references')
+        self._scf = mf
+        self.mol = mf.mol
+        self.singlet = True
+        self.nstates = 3
+        self.conv_tol = 1e-7
+        self.max_cycle = 100
+        self.max_space = 40
+        self.batch = 64               # trial vectors per response call
+        self.e = None
+        self.xy = None
+        self.converged = None
+
+    # -- the linear operator ----------------------------------------------------------------
+    def _orbitals(self):
+        mf = self._scf
+        occ = np.asarray(mf.mo_occ) > 0
+        co, cv = np.asarray(mf.mo_coeff)[:, occ], np.asarray(mf.mo_coeff)[:, ~occ]
+        de = np.asarray(mf.mo_energy)[~occ][None, :] - np.asarray(mf.mo_energy)[occ][:, None]
+        return co, cv, de
+
+    def gen_ab_operation(self):
+        """-> (f, de): f(X[n, nocc, nvir]) = (A X, B X), de = orbital energy differences (nocc, nvir)."""
+        co, cv, de = self._orbitals()
+        vind = self._scf.gen_response(singlet=self.singlet, hermi=0)
+
+        def f(xs):
+            xs = np.asarray(xs).reshape(-1, *de.shape)
+            ax, bx = np.empty_like(xs), np.empty_like(xs)
+            for p0 in range(0, len(xs), self.batch):
+                x = xs[p0:p0 + self.batch]
+                dm1 = 2 * np.einsum('pi,nia,qa->npq', co, x, cv)
+                v = vind(dm1)
+                ax[p0:p0 + len(x)] = de * x + np.einsum('pi,npq,qa->nia', co, v, cv)
+                bx[p0:p0 + len(x)] = np.einsum('pi,nqp,qa->nia', co, v, cv)
+            return ax, bx
+        return f, de
+
+    def get_ab(self):
+        """Dense A, B as (nocc, nvir, nocc, nvir) arrays (tdscf/rhf.py:137-216)."""
+        f, de = self.gen_ab_operation()
+        nov = de.size
+        ax, bx = f(np.eye(nov).reshape(nov, *de.shape))
+        a = ax.reshape(nov, nov).T.reshape(*de.shape, *de.shape)
+        b = bx.reshape(nov, nov).T.reshape(*de.shape, *de.shape)
+        return a, b
+
+    # -- solvers -------------------------------------------------------------------------------
+    def kernel(self, nstates=None):
+        if nstates is not None:
+            self.nstates = nstates
+        f, de = self.gen_ab_operation()
+        nov = de.size
+        n = min(self.nstates, nov)
+        if nov <= DENSE_MAX:
+            a = self.get_ab()[0].reshape(nov, nov)
+            w, v = np.linalg.eigh((a + a.T) * .5)
+            e, x = w[:n], v[:, :n].T
+            self.converged = np.ones(n, bool)
+        else:
+            e, x, self.converged = _davidson(lambda xs: f(xs)[0].reshape(len(xs), nov), de.ravel(), n, self.conv_tol,
+                                             self.max_cycle, self.max_space, symmetric=True)
+        self.e = e
+        self.xy = [(xi.reshape(de.shape) * np.sqrt(.5), 0) for xi in x]
+        return self.e, self.xy
+
+    run = kernel
+
+
+class TDDFT(TDA):
+    """Full linear response (RPA / TDHF / TDDFT), ``tdscf.TDDFT(mf)`` / ``tdscf.TDHF(mf)`` (tdscf/rhf.py:890-1003)."""
+
+    def kernel(self, nstates=None):
+        if nstates is not None:
+            self.nstates = nstates
+        f, de = self.gen_ab_operation()
+        nov = de.size
+        n = min(self.nstates, nov)
+
+        def apb_amb(zs):                 # ((A + B) Z, (A - B) Z)
+            ax, bx = f(zs)
+            return (ax + bx).reshape(len(zs), nov), (ax - bx).reshape(len(zs), nov)
+        if nov <= DENSE_MAX:
+            a, b = self.get_ab()
+            a, b = a.reshape(nov, nov), b.reshape(nov, nov)
+            w2, z = np.linalg.eig((a - b).dot(a + b))
+            order = np.argsort(w2.real)
+            w2, z = w2.real[order][:n], z.real[:, order][:, :n].T
+            self.converged = np.ones(n, bool)
+        else:
+            def m(zs):
+                return apb_amb(apb_amb(zs)[0])[1]
+            w2, z, self.converged = _davidson(m, de.ravel() ** 2, n, self.conv_tol, self.max_cycle, self.max_space,
+                                              symmetric=False)
+        if np.any(w2 <= 0):
+            raise RuntimeError('TDDFT: the reference is unstable (w^2 <= 0)')
+        e = np.sqrt(w2)
+        xy = []
+        for wi, zi in zip(e, z):
+            apb_z = apb_amb(zi[None])[0][0]
+            xmy = apb_z / wi                 # (A + B)(X + Y) = w (X - Y)
+            x, y = (zi + xmy) * .5, (zi - xmy) * .5
+            norm = np.sqrt(.5 / abs(x.dot(x) - y.dot(y)))
+            xy.append((x.reshape(de.shape) * norm, y.reshape(de.shape) * norm))
+        self.e, self.xy = e, xy
+        return self.e, self.xy
+
+    run = kernel
+
+
+TDHF = TDDFT
+RPA = TDDFT
+
+
+def _davidson(matvec, diag, nroots, tol, max_cycle, max_space, symmetric):
+    """Lowest eigenpairs of the operator rows -> matvec(rows) with diagonal estimate diag.  Block Davidson with the
+    (diag - theta)^-1 preconditioner; symmetric=False solves the small projected problem with a general eigensolver
+    (the (A - B)(A + B) product is similar to a symmetric positive matrix, its spectrum is real)."""
+    n = diag.size
+    order = np.argsort(diag)
+    nguess = min(n, max(nroots + 3, 2 * nroots))
+    vs = np.zeros((nguess, n))
+    vs[np.arange(nguess), order[:nguess]] = 1.0
+    avs = matvec(vs)
+    conv = np.zeros(nroots, bool)
+    theta = x = None
+    for _ in range(max_cycle):
+        h = vs.dot(avs.T)
+        if symmetric:
+            w, u = np.linalg.eigh((h + h.T) * .5)
+        else:
+            w, u = np.linalg.eig(h)
+            idx = np.argsort(w.real)
+            w, u = w.real[idx], u.real[:, idx]
+        theta, u = w[:nroots], u[:, :nroots]
+        x = u.T.dot(vs)
+        r = u.T.dot(avs) - theta[:, None] * x
+        rn = np.linalg.norm(r, axis=1)
+        conv = rn < tol
+        if conv.all():
+            break
+        new = []
+        for k in np.where(~conv)[0]:
+            d = diag - theta[k]
+            d[np.abs(d) < 1e-6] = 1e-6
+            new.append(r[k] / d)
+        if len(vs) + len(new) > max_space * nroots:            # restart from the current Ritz vectors
+            vs = np.linalg.qr(x.T)[0].T
+            avs = matvec(vs)
+        t = np.array(new)
+        for _pass in range(2):
+            t -= t.dot(vs.T).dot(vs)
+        q = np.linalg.qr(t.T)[0].T
+        q -= q.dot(vs.T).dot(vs)
+        keep = np.linalg.norm(q, axis=1) > 1e-8
+        if not keep.any():
+            break
+        q = q[keep] / np.linalg.norm(q[keep], axis=1)[:, None]
+        vs = np.vstack([vs, q])
+        avs = np.vstack([avs, matvec(q)])
+    xn = x / np.linalg.norm(x, axis=1)[:, None]
+    return theta, xn, conv
