@@ -117,3 +117,17 @@ def test_short_range_integrals_and_get_jk():
     dsym = dm[0] + dm[0].T
     vjd = df_jk.get_j(obj.range_coulomb(-0.5), dsym)          # integral-direct J generates the same short-range slabs
     assert np.abs(vjd - ref.get_jk(cd, dsym, hermi=1, with_k=False)[0]).max() < 1e-9
+
+
+def test_benzene_overlap_and_2c2e_reference_fingerprints_device():
+    """pyscf/gto/test/test_moleintor.py:94-96,331-333 on the device kernels: sum |S| = 622.29059965181796 and
+    lib.fp(int2c2e over the AO shells of labelled benzene / cc-pVDZ) = -460.83033192375615."""
+    from pyscf_amd import gto
+    from pyscf_amd.gto.moleintor import IntEngine
+    from pyscf_amd.scf.hf import int1e_gpu
+    from tests.test_oracle_golden import BENZENE_LABELLED, BENZENE_BASIS
+    mol = gto.M(atom=BENZENE_LABELLED, basis=BENZENE_BASIS)
+    s = int1e_gpu(mol, _dev())[0]
+    assert abs(np.abs(s).sum() - 622.29059965181796) < 1e-9
+    j2c = IntEngine(mol, mol, _dev()).int2c2e().cpu().numpy()
+    assert abs(ref.fp(j2c) - -460.83033192375615) < 1e-8

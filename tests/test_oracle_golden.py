@@ -131,3 +131,24 @@ def test_fd_gradient_oracle_pinned_by_reference_goldens():
     g = ref_grad.fd_gradient(atoms, '6-31g', 'ccpvdz-jkfit')
     assert abs(ref.fp(g) - 0.005516638190173352) < 3e-7
     assert abs(g.sum(axis=0)).max() < 1e-7
+
+
+BENZENE_LABELLED = [["C", (-0.65830719, 0.61123287, -0.00800148)], ["C1", (0.73685281, 0.61123287, -0.00800148)],
+                    ["C2", (1.43439081, 1.81898387, -0.00800148)], ["C3", (0.73673681, 3.02749287, -0.00920048)],
+                    ["C4", (-0.65808819, 3.02741487, -0.00967948)], ["C5", (-1.35568919, 1.81920887, -0.00868348)],
+                    ["H", (-1.20806619, -0.34108413, -0.00755148)], ["H", (1.28636081, -0.34128013, -0.00668648)],
+                    ["H", (2.53407081, 1.81906387, -0.00736748)], ["H", (1.28693681, 3.97963587, -0.00925948)],
+                    ["H", (-1.20821019, 3.97969587, -0.01063248)], ["H", (-2.45529319, 1.81939187, -0.00886348)]]
+BENZENE_BASIS = {'H': 'cc-pvdz', 'C1': 'CC PVDZ', 'C2': 'CC PVDZ', 'C3': 'cc-pVDZ', 'C4': 'cc-pvdz', 'C': 'CC PVDZ'}
+
+
+def test_benzene_overlap_and_2c2e_reference_fingerprints():
+    """pyscf/gto/test/test_moleintor.py:22-66,94-96,331-333: benzene with labelled atoms (C, C1 ... C5; C5 takes the 'C'
+    entry) and per-label basis names in three spellings, cc-pVDZ everywhere: sum |S| = 622.29059965181796 (11 places) and
+    lib.fp(int2c2e over the AO shells) = -460.83033192375615 (9 places) - s, p and d shells through the 1-electron and the
+    2-centre 2-electron oracle."""
+    from pyscf_amd import gto
+    mol = gto.M(atom=BENZENE_LABELLED, basis=BENZENE_BASIS)
+    assert mol.nao_nr() == 114
+    assert abs(np.abs(ref.int1e(mol, 'ovlp')).sum() - 622.29059965181796) < 1e-10
+    assert abs(ref.fp(ref.int2c2e(mol)) - -460.83033192375615) < 1e-9
