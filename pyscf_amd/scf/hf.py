@@ -317,6 +317,11 @@ class SCF:
 
     Gradients = nuc_grad_method
 
+    def newton(self):
+        """Second-order (augmented-Hessian Newton) solver wrapping this object (pyscf/soscf/newton_ah.py:1034)."""
+        from .. import soscf
+        return soscf.newton(self)
+
     def gen_response(self, *args, **kwargs):
         """vind(dm1): response of the Fock matrix to a first-order density (pyscf/scf/_response_functions.py)."""
         from . import _response_functions
