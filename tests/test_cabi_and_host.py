@@ -201,3 +201,34 @@ def test_xc_description_parser():
     assert libxc.parse_xc_rsh('0.2*LR_HF(0.4)+b88,lyp')[:3] == (0.0, 0.2, 0.4) and libxc.is_hybrid_xc('0.2*LR_HF(0.4)+b88,lyp')
     with pytest.raises(NotImplementedError):
         libxc.parse_xc('scan')
+
+
+def test_host_eigensolvers_of_the_response_drivers():
+    """The host-side iterative solvers of tdscf (block Davidson, symmetric and product-form) and soscf (augmented-Hessian
+    step) on model matrices with known answers."""
+    import numpy as np
+    from pyscf_amd.tdscf import _davidson
+    from pyscf_amd.soscf import _augmented_hessian_step
+    rng = np.random.default_rng(0)
+    n = 300
+    d = np.sort(rng.random(n) * 10 + 1)
+    off = rng.standard_normal((n, n)) * 0.05
+    a = np.diag(d) + off + off.T
+    th, x, conv = _davidson(lambda v: v.dot(a.T), np.diag(a).copy(), 4, 1e-8, 100, 40, True)
+    assert conv.all() and np.abs(th - np.linalg.eigvalsh(a)[:4]).max() < 1e-10
+    assert np.abs(x.dot(a) - th[:, None] * x).max() < 1e-6
+    b = rng.standard_normal((n, n)) * 0.03
+    c = rng.standard_normal((n, n)) * 0.03
+    m = (np.diag(d) + b + b.T).dot(np.diag(d) + c + c.T)            # (A - B)(A + B): real positive spectrum
+    th, x, conv = _davidson(lambda v: v.dot(m.T), np.diag(m).copy(), 4, 1e-8, 200, 40, False)
+    assert conv.all() and np.abs(th - np.sort(np.linalg.eigvals(m).real)[:4]).max() < 1e-8
+    n = 60
+    h = np.diag(rng.random(n) * 2 + 0.5)
+    o = rng.standard_normal((n, n)) * 0.02
+    h = h + o + o.T
+    g = rng.standard_normal(n) * 0.05
+    step, w, nhop = _augmented_hessian_step(g, lambda v: h.dot(v), np.diag(h).copy(), 1e-9, 50)
+    aug = np.block([[np.zeros((1, 1)), g[None]], [g[:, None], h]])
+    wa, va = np.linalg.eigh(aug)
+    assert abs(w - wa[0]) < 1e-12 and np.abs(step - va[1:, 0] / va[0, 0]).max() < 1e-8
+    assert g.dot(step) < 0                                           # a descent direction
