@@ -74,6 +74,18 @@ def _augmented_hessian_step(g, h_op, h_diag, tol, max_cycle):
     return vec[1:] / vec[0], w, nhop
 
 
+def _canonicalize(mo_coeff, mo_occ, fock):
+    """Diagonalise the Fock matrix inside the occupied and inside the virtual space (hf.py canonicalize :1095-1118)."""
+    mo_coeff = np.array(mo_coeff)
+    mo_energy = np.empty(mo_coeff.shape[1])
+    for idx in (np.where(mo_occ > 0)[0], np.where(mo_occ == 0)[0]):
+        c = mo_coeff[:, idx]
+        e, u = np.linalg.eigh(c.T.dot(fock).dot(c))
+        mo_coeff[:, idx] = c.dot(u)
+        mo_energy[idx] = e
+    return mo_coeff, mo_energy
+
+
 class NewtonSCF:
     """``mf.newton()``: same attributes as the wrapped object after ``kernel()`` (mo_coeff, mo_energy, mo_occ, e_tot)."""
     max_cycle = 50
@@ -81,6 +93,7 @@ class NewtonSCF:
     ah_conv_tol = 1e-3            # relative to the gradient norm (tightened as the gradient falls)
     ah_max_cycle = 30
     conv_tol_grad = None
+    max_reoccupations = 5         # Aufbau re-assignments at non-Aufbau stationary points
 
     def __init__(self, mf):
         mo_occ = getattr(mf, 'mo_occ', None)
@@ -113,16 +126,29 @@ class NewtonSCF:
             raise NotImplementedError('second-order SCF is built for closed-shell references')
         tol_g = self.conv_tol_grad or np.sqrt(self.conv_tol)
         e_last = None
+        nswap = 0
         for cycle in range(self.max_cycle):
             dm = mf.make_rdm1(mo_coeff, mo_occ)
             vhf = mf.get_veff(mol, dm)
             e_tot = mf.energy_tot(dm, h1e, vhf)
             fock = h1e + np.asarray(vhf)
+            self.cycles = cycle + 1
             g, h_op, h_diag = gen_g_hop_rhf(mf, mo_coeff, mo_occ, fock)
             gnorm = np.linalg.norm(g)
             mf._log('macro iter %d  E = %.12f  |g| = %.3e', cycle, e_tot, gnorm)
-            self.cycles = cycle + 1
             if gnorm < tol_g and (e_last is None or abs(e_tot - e_last) < self.conv_tol):
+                # stationary point: is it the Aufbau one?  A rotation between orbitals of different symmetry has zero
+                # gradient, so a wrongly occupied orbital can only be exchanged through the occupations - from the
+                # pseudo-canonical orbital energies, as the reference does every cycle (newton_ah.py:573-579); here only
+                # at a stationary point, where those energies mean something
+                c_can, e_can = _canonicalize(mo_coeff, mo_occ, fock)
+                new_occ = mf.get_occ(e_can, c_can)
+                if np.any(new_occ != mo_occ) and nswap < self.max_reoccupations:
+                    mf._log('stationary point is not Aufbau (E = %.12f): occupations re-assigned', e_tot)
+                    mo_coeff, mo_occ = c_can, new_occ
+                    nswap += 1
+                    e_last = None
+                    continue
                 self.converged = True
                 break
             e_last = e_tot
@@ -143,12 +169,7 @@ class NewtonSCF:
         dm = mf.make_rdm1(mo_coeff, mo_occ)
         vhf = mf.get_veff(mol, dm)
         fock = h1e + np.asarray(vhf)
-        mo_energy = np.empty(mo_coeff.shape[1])
-        for idx in (np.where(mo_occ > 0)[0], np.where(mo_occ == 0)[0]):
-            c = mo_coeff[:, idx]
-            e, u = np.linalg.eigh(c.T.dot(fock).dot(c))
-            mo_coeff[:, idx] = c.dot(u)
-            mo_energy[idx] = e
+        mo_coeff, mo_energy = _canonicalize(mo_coeff, mo_occ, fock)
         order = np.argsort(mo_energy, kind='stable')
         mf.mo_coeff, mf.mo_energy, mf.mo_occ = mo_coeff[:, order], mo_energy[order], mo_occ[order]
         mf.e_tot = mf.energy_tot(dm, h1e, vhf)
