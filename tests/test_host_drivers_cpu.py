@@ -122,3 +122,26 @@ def test_response_and_ab_matrices_against_explicit_integrals(hf_molecule):
     with pytest.raises(TypeError):
         from pyscf_amd.scf._response_functions import gen_uhf_response
         gen_uhf_response(mf)
+
+
+def test_newton_from_a_reasonable_start_and_restart():
+    """The flow of tests/test_gpu_soscf.py on oracle integrals: a stretched water from two DIIS cycles, quadratic
+    convergence to the DIIS energy, and a restart from converged orbitals that needs one Fock build and no step."""
+    from pyscf_amd import gto
+    atoms = [('O', (0., 0., 0.)), ('H', (0., -0.757, 0.587)), ('H', (0.3, 1.1, 0.7))]
+    mol = gto.M(atom=atoms, basis='cc-pvdz')
+    ref_mf = _oracle_rhf(mol)
+    ref_mf.conv_tol = 1e-11
+    ref_mf.kernel()
+    mf = _oracle_rhf(mol)
+    mf.conv_tol = 1e-11
+    mf.max_cycle = 2
+    mf.kernel()
+    assert not mf.converged
+    nt = mf.newton()
+    e = nt.kernel(mf.mo_coeff, mf.mo_occ)
+    assert nt.converged and abs(e - ref_mf.e_tot) < 1e-9 and nt.cycles <= 9 and nt.hessian_products < 80
+    assert mf.converged and abs(mf.e_tot - e) < 1e-12
+    nt2 = mf.newton()
+    e2 = nt2.kernel(mf.mo_coeff, mf.mo_occ)
+    assert nt2.cycles == 1 and abs(e2 - e) < 1e-10
