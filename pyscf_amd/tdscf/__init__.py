@@ -54,10 +54,11 @@ class TDA:
             ax, bx = np.empty_like(xs), np.empty_like(xs)
             for p0 in range(0, len(xs), self.batch):
                 x = xs[p0:p0 + self.batch]
-                dm1 = 2 * np.einsum('pi,nia,qa->npq', co, x, cv)
+                # BLAS matmul chains (a three-operand einsum would run an O(n nao^2 nocc nvir) scalar loop)
+                dm1 = 2 * np.matmul(co, np.matmul(x, cv.T))
                 v = vind(dm1)
-                ax[p0:p0 + len(x)] = de * x + np.einsum('pi,npq,qa->nia', co, v, cv)
-                bx[p0:p0 + len(x)] = np.einsum('pi,nqp,qa->nia', co, v, cv)
+                ax[p0:p0 + len(x)] = de * x + np.matmul(co.T, np.matmul(v, cv))
+                bx[p0:p0 + len(x)] = np.matmul(co.T, np.matmul(v.transpose(0, 2, 1), cv))
             return ax, bx
         return f, de
 

@@ -49,7 +49,7 @@ for hermi, label in ((1, 'orbital_hessian_product_s'), (0, 'tddft_product_s')):
     out[label] = round(t, 3)
     if hermi == 0:
         xs = rng.standard_normal((a.nvec, co.shape[1], cv.shape[1])) * 1e-2
-        dms = 2 * np.einsum('pi,nia,qa->npq', co, xs, cv)
+        dms = 2 * np.matmul(co, np.matmul(xs, cv.T))
         v, t = timed(vind, dms)
         out['tddft_batch_of_%d_s' % a.nvec] = round(t, 3)
 out['peak_hbm_gb'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
