@@ -204,9 +204,10 @@ class SCF:
         h1e = self.get_hcore()
         if s1e is None:
             s1e = self.get_ovlp()
-        mo_energy, mo_coeff = self.eig(h1e, s1e)
-        mo_occ = self.get_occ(mo_energy, mo_coeff)
-        return self.make_rdm1(mo_coeff, mo_occ)
+        # closed-shell occupation of the core-Hamiltonian orbitals whatever the subclass (UHF / ROHF split or re-tag it)
+        mo_energy, mo_coeff = SCF.eig(self, h1e, s1e)
+        mo_occ = SCF.get_occ(self, mo_energy, mo_coeff)
+        return SCF.make_rdm1(self, mo_coeff, mo_occ)
 
     def check_linear_dependency(self, s1e):
         """hf.py:1363-1379: x = v[:, e > 1e-6] / sqrt(e) (always returned)."""

@@ -1,4 +1,4 @@
-"""Linear-response excitation energies of closed-shell DF-RHF / DF-RKS references: TDA and TDDFT (RPA).
+"""Linear-response excitation energies of DF-RHF / DF-RKS (closed shell) and DF-UHF / DF-UKS references: TDA and TDDFT (RPA).
 
 Host-side drivers in the place of ``pyscf/tdscf/rhf.py`` (``TDA`` :694-806, ``TDHF`` :890-1003, ``get_ab`` :137-216,
 ``gen_tda_operation`` :47-104) and ``pyscf/tdscf/rks.py``; all electron-repulsion and grid work is one call of
@@ -10,7 +10,8 @@ dm1 = 2 C_occ X C_vir^T and, with v = vind(dm1),
 
 so one response call gives both blocks.  TDA diagonalises A (Davidson with the orbital-energy-difference preconditioner;
 dense when the single-excitation space is small), TDDFT solves (A - B)(A + B) Z = w^2 Z, Z = X + Y.
-Amplitudes are normalised like the reference: <X|X> - <Y|Y> = 1/2.
+Amplitudes are normalised like the reference: <X|X> - <Y|Y> = 1/2 (restricted) or 1 (unrestricted, ``tdscf/uhf.py``, where the
+first-order spin densities are C_occ,s X_s C_vir,s^T and the amplitude vector is (X_alpha, X_beta) side by side).
 """
 import numpy as np
 
@@ -22,8 +23,9 @@ class TDA:
 
     def __init__(self, mf):
         mo_occ = np.asarray(mf.mo_occ)
-        if mo_occ.ndim != 1 or np.any((mo_occ > 0) & (mo_occ < 2)):
-            raise NotImplementedError('TDA / TDDFT drivers are built for closed-shell references')
+        if mo_occ.ndim == 1 and np.any((mo_occ > 0) & (mo_occ < 2)):
+            raise NotImplementedError('TDA / TDDFT on an ROHF reference (use the UHF form of the orbitals)')
+        self.unrestricted = mo_occ.ndim == 2          # UHF / UKS reference: amplitudes (X_alpha, X_beta) side by side
         self._scf = mf
         self.mol = mf.mol
         self.singlet = True
@@ -32,6 +34,7 @@ class TDA:
         self.max_cycle = 100
         self.max_space = 40
         self.batch = 64               # trial vectors per response call
+        self.positive_eig_threshold = 1e-3   # roots below are dropped (near-zero modes of symmetry-broken references; tdscf/rhf.py:713)
         self.e = None
         self.xy = None
         self.converged = None
@@ -45,7 +48,10 @@ class TDA:
         return co, cv, de
 
     def gen_ab_operation(self):
-        """-> (f, de): f(X[n, nocc, nvir]) = (A X, B X), de = orbital energy differences (nocc, nvir)."""
+        """-> (f, de): f(X[n, ...]) = (A X, B X), de = orbital energy differences; restricted: X is (nocc, nvir);
+        unrestricted (tdscf/uhf.py:46-139): X is the flat concatenation of the alpha and beta blocks."""
+        if self.unrestricted:
+            return self._gen_ab_operation_uhf()
         co, cv, de = self._orbitals()
         vind = self._scf.gen_response(singlet=self.singlet, hermi=0)
 
@@ -62,14 +68,46 @@ class TDA:
             return ax, bx
         return f, de
 
+    def _gen_ab_operation_uhf(self):
+        mf = self._scf
+        orbs = []
+        for s in range(2):
+            occ = np.asarray(mf.mo_occ[s]) > 0
+            c, e = np.asarray(mf.mo_coeff[s]), np.asarray(mf.mo_energy[s])
+            orbs.append((c[:, occ], c[:, ~occ], e[~occ][None, :] - e[occ][:, None]))
+        na = orbs[0][2].size
+        de = np.concatenate([o[2].ravel() for o in orbs])
+        vind = mf.gen_response(hermi=0)
+
+        def f(xs):
+            xs = np.asarray(xs).reshape(-1, de.size)
+            ax, bx = np.empty_like(xs), np.empty_like(xs)
+            for p0 in range(0, len(xs), self.batch):
+                x = xs[p0:p0 + self.batch]
+                blocks = [x[:, :na].reshape(len(x), *orbs[0][2].shape), x[:, na:].reshape(len(x), *orbs[1][2].shape)]
+                dm1 = np.array([np.matmul(co, np.matmul(xb, cv.T)) for (co, cv, _), xb in zip(orbs, blocks)])
+                v = vind(dm1)                                     # (2, n, nao, nao)
+                for out, vt in ((ax, v), (bx, v.transpose(0, 1, 3, 2))):
+                    parts = [np.matmul(co.T, np.matmul(vt[s], cv)).reshape(len(x), -1) for s, (co, cv, _) in enumerate(orbs)]
+                    out[p0:p0 + len(x)] = np.concatenate(parts, axis=1)
+                ax[p0:p0 + len(x)] += de * x
+            return ax, bx
+        return f, de
+
     def get_ab(self):
-        """Dense A, B as (nocc, nvir, nocc, nvir) arrays (tdscf/rhf.py:137-216)."""
+        """Dense A, B: restricted (nocc, nvir, nocc, nvir) arrays (tdscf/rhf.py:137-216); unrestricted (nov, nov) matrices
+        over the concatenated (alpha, beta) single excitations."""
         f, de = self.gen_ab_operation()
         nov = de.size
         ax, bx = f(np.eye(nov).reshape(nov, *de.shape))
+        if self.unrestricted:
+            return ax.reshape(nov, nov).T, bx.reshape(nov, nov).T
         a = ax.reshape(nov, nov).T.reshape(*de.shape, *de.shape)
         b = bx.reshape(nov, nov).T.reshape(*de.shape, *de.shape)
         return a, b
+
+    def _norm(self):
+        return 1.0 if self.unrestricted else .5          # <X|X> - <Y|Y> (tdscf/uhf.py:727, rhf.py:800)
 
     # -- solvers -------------------------------------------------------------------------------
     def kernel(self, nstates=None):
@@ -79,15 +117,19 @@ class TDA:
         nov = de.size
         n = min(self.nstates, nov)
         if nov <= DENSE_MAX:
-            a = self.get_ab()[0].reshape(nov, nov)
+            a = np.asarray(self.get_ab()[0]).reshape(nov, nov)
             w, v = np.linalg.eigh((a + a.T) * .5)
-            e, x = w[:n], v[:, :n].T
-            self.converged = np.ones(n, bool)
+            keep = np.where(w > self.positive_eig_threshold)[0][:n]
+            e, x = w[keep], v[:, keep].T
+            self.converged = np.ones(len(e), bool)
         else:
-            e, x, self.converged = _davidson(lambda xs: f(xs)[0].reshape(len(xs), nov), de.ravel(), n, self.conv_tol,
-                                             self.max_cycle, self.max_space, symmetric=True)
+            nextra = min(nov, n + 3)
+            e, x, conv = _davidson(lambda xs: f(xs)[0].reshape(len(xs), nov), de.ravel(), nextra, self.conv_tol,
+                                   self.max_cycle, self.max_space, symmetric=True)
+            keep = np.where(e > self.positive_eig_threshold)[0][:n]
+            e, x, self.converged = e[keep], x[keep], conv[keep]
         self.e = e
-        self.xy = [(xi.reshape(de.shape) * np.sqrt(.5), 0) for xi in x]
+        self.xy = [(xi.reshape(de.shape) * np.sqrt(self._norm()), 0) for xi in x]
         return self.e, self.xy
 
     run = kernel
@@ -108,25 +150,31 @@ class TDDFT(TDA):
             return (ax + bx).reshape(len(zs), nov), (ax - bx).reshape(len(zs), nov)
         if nov <= DENSE_MAX:
             a, b = self.get_ab()
-            a, b = a.reshape(nov, nov), b.reshape(nov, nov)
+            a, b = np.asarray(a).reshape(nov, nov), np.asarray(b).reshape(nov, nov)
             w2, z = np.linalg.eig((a - b).dot(a + b))
             order = np.argsort(w2.real)
-            w2, z = w2.real[order][:n], z.real[:, order][:, :n].T
-            self.converged = np.ones(n, bool)
+            w2, z = w2.real[order], z.real[:, order].T
+            if w2[0] < -self.positive_eig_threshold ** 2:
+                raise RuntimeError('TDDFT: the reference is unstable (w^2 = %.3g)' % w2[0])
+            keep = np.where(w2 > self.positive_eig_threshold ** 2)[0][:n]
+            w2, z = w2[keep], z[keep]
+            self.converged = np.ones(len(w2), bool)
         else:
             def m(zs):
                 return apb_amb(apb_amb(zs)[0])[1]
-            w2, z, self.converged = _davidson(m, de.ravel() ** 2, n, self.conv_tol, self.max_cycle, self.max_space,
-                                              symmetric=False)
-        if np.any(w2 <= 0):
-            raise RuntimeError('TDDFT: the reference is unstable (w^2 <= 0)')
+            w2, z, conv = _davidson(m, de.ravel() ** 2, min(nov, n + 3), self.conv_tol, self.max_cycle, self.max_space,
+                                    symmetric=False)
+            if w2[0] < -self.positive_eig_threshold ** 2:
+                raise RuntimeError('TDDFT: the reference is unstable (w^2 = %.3g)' % w2[0])
+            keep = np.where(w2 > self.positive_eig_threshold ** 2)[0][:n]
+            w2, z, self.converged = w2[keep], z[keep], conv[keep]
         e = np.sqrt(w2)
         xy = []
         for wi, zi in zip(e, z):
             apb_z = apb_amb(zi[None])[0][0]
             xmy = apb_z / wi                 # (A + B)(X + Y) = w (X - Y)
             x, y = (zi + xmy) * .5, (zi - xmy) * .5
-            norm = np.sqrt(.5 / abs(x.dot(x) - y.dot(y)))
+            norm = np.sqrt(self._norm() / abs(x.dot(x) - y.dot(y)))
             xy.append((x.reshape(de.shape) * norm, y.reshape(de.shape) * norm))
         self.e, self.xy = e, xy
         return self.e, self.xy

@@ -145,3 +145,53 @@ def test_newton_from_a_reasonable_start_and_restart():
     nt2 = mf.newton()
     e2 = nt2.kernel(mf.mo_coeff, mf.mo_occ)
     assert nt2.cycles == 1 and abs(e2 - e) < 1e-10
+
+
+def _oracle_uhf(mol):
+    from pyscf_amd import scf
+
+    class OracleUHF(scf.UHF):
+        """UHF on the oracle's exact integrals (test double)."""
+
+        def __init__(self, mol):
+            super().__init__(mol)
+            self.with_df = 'oracle'
+            self.init_guess = '1e'
+            self._eri = ref.int2e(mol)
+
+        def _get_int1e(self):
+            if self._int1e is None:
+                self._int1e = tuple(ref.int1e(self.mol, k) for k in ('ovlp', 'kin', 'nuc'))
+            return self._int1e
+
+        def get_jk(self, mol=None, dm=None, hermi=1, with_j=True, with_k=True, omega=None):
+            vj, vk = ref.get_jk_exact(self._eri, np.asarray(dm))
+            return (vj if with_j else None), (vk if with_k else None)
+    return OracleUHF(mol)
+
+
+def test_unrestricted_tda_tdhf_reference_excitation_energies(hf_molecule):
+    """pyscf/tdscf/test/test_tduhf.py:48-82 (HF molecule, 6-31G): UHF-based TDA / TDHF of the closed-shell molecule (singlets
+    and triplets interleaved) and of the spin = 2 state, 4 places in eV; amplitudes normalised to <X|X> - <Y|Y> = 1."""
+    from pyscf_amd import gto, tdscf
+    mol = gto.M(atom=[['H', (0., 0., .917)], ['F', (0., 0., 0.)]], basis='631g')
+    mf = _oracle_uhf(mol)
+    mf.conv_tol = 1e-11
+    mf.kernel()
+    assert mf.converged and abs(mf.e_tot - hf_molecule.e_tot) < 1e-9
+    e = tdscf.TDA(mf).kernel(nstates=5)[0] * 27.2114
+    assert np.abs(e - [11.01748568, 11.01748568, 11.90277134, 11.90277134, 13.16955369]).max() < 1e-4, e
+    td = tdscf.TDHF(mf)
+    e, xy = td.kernel(nstates=5)
+    assert np.abs(e * 27.2114 - [10.89192986, 10.89192986, 11.83487865, 11.83487865, 12.6344099]).max() < 1e-4, e * 27.2114
+    for x, y in xy:
+        assert abs((x * x).sum() - (y * y).sum() - 1) < 1e-10
+    mol1 = gto.M(atom=[['H', (0., 0., .917)], ['F', (0., 0., 0.)]], basis='631g', spin=2)
+    mf1 = _oracle_uhf(mol1)
+    mf1.conv_tol = 1e-11
+    mf1.kernel()
+    assert mf1.converged
+    e = tdscf.TDA(mf1).kernel(nstates=5)[0] * 27.2114
+    assert np.abs(e - [3.32113736, 18.55977052, 21.01474222, 21.61501962, 25.0938973]).max() < 1e-4, e
+    e = tdscf.TDHF(mf1).kernel(nstates=4)[0] * 27.2114
+    assert np.abs(e - [3.31267103, 18.4954748, 20.84935404, 21.54808392]).max() < 1e-4, e
