@@ -188,3 +188,17 @@ class NewtonSCF:
 
 def newton(mf):
     return NewtonSCF(mf)
+
+
+def stability_rhf_internal(mf, nroots=1, tol=1e-5):
+    """Lowest eigenvalue(s) of the closed-shell orbital Hessian (real RHF -> real RHF rotations; the 'internal' analysis of
+    pyscf/scf/stability.py:116-180) at the orbitals held by ``mf``: (eigenvalues, stable).  A stationary point reached
+    with the wrong occupations, or a symmetry-broken minimum elsewhere, shows as a negative eigenvalue."""
+    from ..tdscf import _davidson
+    mo_coeff, mo_occ = np.asarray(mf.mo_coeff), np.asarray(mf.mo_occ)
+    dm = mf.make_rdm1(mo_coeff, mo_occ)
+    fock = mf.get_hcore() + np.asarray(mf.get_veff(mf.mol, dm))
+    g, h_op, h_diag = gen_g_hop_rhf(mf, mo_coeff, mo_occ, fock)
+    w, _x, _conv = _davidson(lambda xs: np.array([h_op(x) for x in xs]), h_diag, min(nroots, h_diag.size), tol, 100, 40,
+                             symmetric=True)
+    return w, bool(w[0] > -1e-5)

@@ -195,3 +195,60 @@ def test_unrestricted_tda_tdhf_reference_excitation_energies(hf_molecule):
     assert np.abs(e - [3.32113736, 18.55977052, 21.01474222, 21.61501962, 25.0938973]).max() < 1e-4, e
     e = tdscf.TDHF(mf1).kernel(nstates=4)[0] * 27.2114
     assert np.abs(e - [3.31267103, 18.4954748, 20.84935404, 21.54808392]).max() < 1e-4, e
+
+
+def test_cphf_against_finite_field():
+    """scf.cphf.solve + gen_vind (pyscf/scf/cphf.py:29-87) on the oracle-integral double: the first-order density of a
+    one-electron perturbation equals the finite-field derivative of the SCF density, and 4 sum h1 mo1 the second
+    derivative of the energy."""
+    from pyscf_amd import gto
+    from pyscf_amd.scf import cphf
+    from tests.conftest import H2O
+    mol = gto.M(atom=H2O, basis='6-31g')
+    pert = ref.int1e(mol, 'kin') * 0.3                      # any symmetric one-electron operator
+
+    def scf_at(lam):
+        mf = _oracle_rhf(mol)
+        mf.conv_tol = 1e-13
+        base = tuple(ref.int1e(mol, k) for k in ('ovlp', 'kin', 'nuc'))
+        mf._int1e = (base[0], base[1] + lam * pert, base[2])
+        mf.kernel()
+        assert mf.converged
+        return mf
+    mf = scf_at(0.0)
+    occ = mf.mo_occ > 0
+    co, cv = mf.mo_coeff[:, occ], mf.mo_coeff[:, ~occ]
+    h1 = cv.T.dot(pert).dot(co)
+    mo1, _ = cphf.solve(cphf.gen_vind(mf), mf.mo_energy, mf.mo_occ, h1, tol=1e-11)
+    c1 = cv.dot(mo1)
+    dm1 = 2 * (c1.dot(co.T) + co.dot(c1.T))
+    lam = 1e-4
+    mp, mm = scf_at(lam), scf_at(-lam)
+    fd = (np.asarray(mp.make_rdm1()) - np.asarray(mm.make_rdm1())) / (2 * lam)
+    assert np.abs(fd - dm1).max() < 1e-6, np.abs(fd - dm1).max()
+    e2 = (mp.e_tot - 2 * mf.e_tot + mm.e_tot) / lam ** 2
+    assert abs(e2 - 4 * (h1 * mo1).sum()) < 2e-4 * abs(e2), (e2, 4 * (h1 * mo1).sum())
+    both, _ = cphf.solve(cphf.gen_vind(mf), mf.mo_energy, mf.mo_occ, np.array([h1, -2 * h1]), tol=1e-11)
+    assert np.abs(both[0] - mo1).max() < 1e-9 and np.abs(both[1] + 2 * mo1).max() < 1e-9
+
+
+def test_internal_stability_of_ground_state_and_saddle_point():
+    """soscf.stability_rhf_internal: the Aufbau solution of water is a minimum; the stationary point the Newton solver
+    reaches from the core-Hamiltonian guess when re-occupation is switched off (E = -75.0747) has a negative Hessian
+    eigenvalue."""
+    from pyscf_amd import gto, soscf
+    from tests.conftest import H2O
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    mf = _oracle_rhf(mol)
+    mf.conv_tol = 1e-11
+    mf.kernel()
+    w, stable = soscf.stability_rhf_internal(mf)
+    assert stable and w[0] > 0.1
+    mf2 = _oracle_rhf(mol)
+    mf2.conv_tol = 1e-11
+    nt = mf2.newton()
+    nt.max_reoccupations = 0
+    e = nt.kernel()
+    assert nt.converged and abs(e - -75.074736446469) < 1e-8
+    w, stable = soscf.stability_rhf_internal(mf2)
+    assert not stable and w[0] < -0.1, w
