@@ -219,8 +219,11 @@ def format_atom(atom, unit='angstrom'):
             if not line or line.startswith('#'):
                 continue
             t = line.split()
-            if len(t) < 4:
+            if len(t) == 1 and t[0][0].isalpha():  # a bare symbol: one atom at the origin (mole.py:424-426)
+                rows.append((t[0], [0.0, 0.0, 0.0]))
                 continue
+            if len(t) < 4:
+                raise ValueError('atom line %r: expected "symbol x y z"' % line)
             rows.append((t[0], [float(x) for x in t[1:4]]))
     else:
         rows = []

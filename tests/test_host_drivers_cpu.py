@@ -252,3 +252,23 @@ def test_internal_stability_of_ground_state_and_saddle_point():
     assert nt.converged and abs(e - -75.074736446469) < 1e-8
     w, stable = soscf.stability_rhf_internal(mf2)
     assert not stable and w[0] < -0.1, w
+
+
+def test_uhf_driver_reference_energies():
+    """pyscf/scf/test/test_uhf.py:229-240,478-486 through the product's UHF loop on oracle integrals: the beta-rich triplet
+    of water (spin = -2, 6-31G) -75.726396909036637, the helium atom (bare-symbol atom string, STO-3G) -2.8077839575399737,
+    and the electron-free He2+ (energy 0)."""
+    from pyscf_amd import gto
+    from tests.conftest import H2O
+    mol = gto.M(atom=H2O, basis='6-31g', spin=-2)
+    assert mol.nelec == (4, 6)
+    mf = _oracle_uhf(mol)
+    mf.conv_tol = 1e-11
+    e = mf.kernel()
+    assert mf.converged and abs(e - -75.726396909036637) < 1e-9 and mf.mo_occ[1].sum() == 6
+    mf = _oracle_uhf(gto.M(atom='He', basis='sto-3g'))
+    assert abs(mf.kernel() - -2.8077839575399737) < 1e-12
+    mf = _oracle_uhf(gto.M(atom='He', basis='sto-3g', charge=2))
+    assert mf.kernel() == 0 and mf.converged
+    with pytest.raises(ValueError):
+        gto.M(atom='O 0 0', basis='sto-3g')
