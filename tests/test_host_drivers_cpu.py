@@ -272,3 +272,43 @@ def test_uhf_driver_reference_energies():
     assert mf.kernel() == 0 and mf.converged
     with pytest.raises(ValueError):
         gto.M(atom='O 0 0', basis='sto-3g')
+
+
+def _oracle_rohf(mol):
+    from pyscf_amd import scf
+
+    class OracleROHF(scf.ROHF):
+        """ROHF on the oracle's exact integrals (test double)."""
+
+        def __init__(self, mol):
+            super().__init__(mol)
+            self.with_df = 'oracle'
+            self.init_guess = '1e'
+            self._eri = ref.int2e(mol)
+
+        def _get_int1e(self):
+            if self._int1e is None:
+                self._int1e = tuple(ref.int1e(self.mol, k) for k in ('ovlp', 'kin', 'nuc'))
+            return self._int1e
+
+        def get_jk(self, mol=None, dm=None, hermi=1, with_j=True, with_k=True, omega=None):
+            vj, vk = ref.get_jk_exact(self._eri, np.asarray(dm))
+            return (vj if with_j else None), (vk if with_k else None)
+    return OracleROHF(mol)
+
+
+def test_rohf_driver_reference_energies():
+    """pyscf/scf/test/test_h2o_vdz.py:47-61 (H2O+ cc-pVDZ ROHF, exact integrals: -75.627354109594179) and
+    test_rhf.py:279-280 (hydrogen atom, STO-3G: -0.46658184955727555) through the product's ROHF loop (Roothaan effective
+    Fock matrix, scf/rohf.py) on oracle integrals."""
+    from pyscf_amd import gto
+    from tests.conftest import H2O
+    neutral = _oracle_rhf(gto.M(atom=H2O, basis='cc-pvdz'))
+    neutral.kernel()
+    dm = np.asarray(neutral.make_rdm1()) * .5       # start from the neutral molecule's density (the reference starts from
+    mf = _oracle_rohf(gto.M(atom=H2O, basis='cc-pvdz', charge=1, spin=1))      # minao; the core guess ends on another hole)
+    mf.conv_tol = 1e-11
+    e = mf.kernel(dm0=np.array((dm, dm)))
+    assert mf.converged and abs(e - -75.627354109594179) < 1e-9, e
+    mf = _oracle_rohf(gto.M(atom='H', basis='sto-3g', spin=1))
+    assert abs(mf.kernel() - -0.46658184955727555) < 1e-12
