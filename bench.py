@@ -41,14 +41,35 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--nwater', type=int, default=32)
     ap.add_argument('--basis', default='cc-pvtz')
-    ap.add_argument('--cpu-sample-rows', type=int, default=240)
+    ap.add_argument('--cpu-sample-rows', type=int, default=1200)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--xc', default='b3lyp', help="XC functional of the secondary nr_rks timing ('' to skip)")
+    ap.add_argument('--backend', default=None, help="torch.distributed backend ('nccl' = RCCL; 'gloo' for the "
+                    "single-device self-test where several ranks share one GPU)")
     args = ap.parse_args()
+    if args.backend:
+        os.environ['PAMD_DIST_BACKEND'] = args.backend
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Launched as plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1) so that a scaling run can never silently fall back to one GPU.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` (self-launching) or '
+                         '`torchrun --nproc-per-node N bench.py --gpus N`' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     ndev = torch.cuda.device_count()
@@ -59,9 +80,13 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('PAMD_DIST_BACKEND', 'nccl')        # 'nccl' = RCCL on ROCm
         if backend == 'nccl':
+            if ndev < world:
+                raise SystemExit('bench.py: %d ranks but %d visible GPUs (RCCL needs one device per rank; '
+                                 '--backend gloo shares a device for the self-test)' % (world, ndev))
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        world = dist.get_world_size()          # n_gpus below = the ranks the process group really has
 
     from pyscf_amd import gto, df, lib
     from pyscf_amd.data import clusters
@@ -115,6 +140,29 @@ def main():
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
 
+    # the reference's own timer ('df vj and vk', pyscf/df/df_jk.py:412) brackets with_df.get_jk(dm) with numpy in/out:
+    # dm upload, J/K build, download and host unpack_tril.  Reported beside `value` (device-resident), never as it.
+    dm_tag = lib.tag_array(dm, mo_coeff=c, mo_occ=mo_occ)
+    dfobj.get_jk(dm_tag, hermi=1)
+    fence()
+    nh = max(1, min(args.steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(nh):
+        vj_h, vk_h = dfobj.get_jk(dm_tag, hermi=1)
+    fence()
+    host_api_ms = (time.perf_counter() - t0) / nh * 1e3
+    if world > 1:
+        tmax = torch.tensor([host_api_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        host_api_ms = float(tmax.item())
+        rows_t = torch.zeros(world, dtype=torch.int64, device=dev)
+        rows_t[rank] = naux_local
+        dist.all_reduce(rows_t)
+        naux_per_rank = [int(v) for v in rows_t.cpu()]
+    else:
+        naux_per_rank = [int(naux_local)]
+    assert sum(naux_per_rank) == naux, 'aux rows of the ranks do not add up to naux'
+
     # per-kernel durations (one extra, untimed step with HIP events around every launch)
     # (J and K are issued back-to-back on one stream for this pass so that each kernel is timed alone;
     # the timed steps above overlap the HBM-bound J kernels with the MFMA-bound SYRK on a second stream)
@@ -147,6 +195,13 @@ def main():
         xc_info = {'xc': args.xc, 'nr_rks_ms_per_call': round(xc_ms, 1), 'ngrids': int(grids.size),
                    'grid_build_s': round(grid_s, 2), 'nelec': float(nel),
                    'kernels_ms': {k: round(t, 2) for k, (t, n_) in xs.items()}}
+        if ni.sparse:
+            plan = ni.sparse_plan(mol, grids, dft.libxc.xc_type(args.xc) == 'GGA')
+            xc_info['block_sparse'] = {'tile_points': plan.G, 'tiles': int(plan.nloc), 'cutoff': ni.sparse_cutoff,
+                                       'ao_density_mean': round(plan.density, 4),
+                                       'ao_density_sq_mean': round(plan.density2, 4),
+                                       'compact_ao_GB': round(plan.ao_total * 8e-9, 2),
+                                       'ao_cached_in_hbm': plan.ao_c is not None}
 
     if rank != 0:
         if world > 1:
@@ -165,15 +220,19 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     # profiles/r01/pmc_summary.json; KiB per launch as reported, corrected below where the access width needs it)
     traffic = None
+    traffic_src = None
     try:
-        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))['kernels']
+        pmc_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, 'profiles'))
+                          if os.path.exists(os.path.join(ROOT, 'profiles', d, 'pmc_summary.json')))
+        traffic_src = 'profiles/%s/pmc_summary.json' % pmc_dirs[-1]
+        pm = json.load(open(os.path.join(ROOT, traffic_src)))['kernels']
         e2k = 'e2_sq_kernel' if (getattr(dfobj, '_cderi_sq', None) is not None and 'e2_sq_kernel' in pm) else 'e2_symm'
         pk = {'e2_symm': e2k, 'dgemm_tn': 'gemm_tn_glds_kernel', 'vj_pass1': 'vj_pass1_rows_kernel',
               'vj_pass2': 'vj_pass2_kernel'}[dom]
-        # gfx950: FETCH_SIZE reports half the bytes of a 16-B/lane coalesced stream (MI355X_MICROARCH.md, HBM section);
-        # the LDS-DMA kernels and vj_pass2 read that way (calibrated: vj_pass2 0.50x, e2_sq 0.54x of their known bytes),
-        # vj_pass1 and e2_symm read 8 B/lane (calibrated 1.00x)
-        rd = 2.0 if pk in ('e2_sq_kernel', 'gemm_tn_glds_kernel', 'vj_pass2_kernel') else 1.0
+        # gfx950: FETCH_SIZE reports half the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM section).
+        # Calibrated on kernels whose byte count is known (profiles/r01): vj_pass1 0.53x and vj_pass2 0.50x of their
+        # 61.3 GB, e2_sq 0.54x; the packed-operand e2_symm (8-B/lane scattered reads) reports 1.00x
+        rd = 1.0 if pk == 'e2_symm' else 2.0
         traffic = (rd * pm[pk]['FETCH_SIZE_KiB_per_launch_mean'] + pm[pk]['WRITE_SIZE_KiB_per_launch_mean']) * 1024.0
     except Exception:
         pass
@@ -188,12 +247,15 @@ def main():
                  else 'e2_symm (half transform)', 'dgemm_tn': 'gemm_tn_glds (SYRK)'}[dom]
         roofline = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                    'traffic_source': '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; '
+                                      'not re-measured in this run)' % traffic_src if traffic is not None else None,
                     'avg_launch_ms': round(dtot / dcnt, 4), 'launches': dcnt,
                     'flops_per_step': fl}
     else:
         ach = bytes_j / (dtot * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'traffic_source': traffic_src if traffic is not None else None,
                     'avg_launch_ms': round(dtot / dcnt, 4), 'launches': dcnt}
     # HBM GB/s of the J kernels (the metric's second figure): one algorithmic read of B per pass
     j_gbs = {}
@@ -212,13 +274,17 @@ def main():
         from oracle import ref
         nrow = min(args.cpu_sample_rows, naux_local)
         sample = dfobj._cderi_dev[:nrow].cpu().numpy()
+        ncore = os.cpu_count()
+        ref.get_jk_rows_parallel(sample[:min(nrow, 64)], dm, c, mo_occ, nthreads=ncore)      # warm the BLAS threads
         t0 = time.perf_counter()
-        vj0, vk0 = ref.get_jk(sample, dm, 1, mo_coeff=c, mo_occ=mo_occ)
+        vj0, vk0, cpu_flops = ref.get_jk_rows_parallel(sample, dm, c, mo_occ, nthreads=ncore)
         cpu_s = time.perf_counter() - t0
         cpu = {'value': round(cpu_s / nrow * naux * 1e3, 1), 'unit': 'ms/iter (extrapolated to all %d aux rows)' % naux,
-               'cores': os.cpu_count(), 'kind': 'port',
-               'sample': 'oracle/ref.get_jk (numpy/OpenBLAS restatement of df_jk.py:329-381) on %d of %d aux rows '
-                         'of the GPU-built tensor: %.2f s' % (nrow, naux, cpu_s)}
+               'cores': ncore, 'kind': 'port', 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1),
+               'sample': 'oracle/ref.get_jk_rows_parallel (restatement of df_jk.py:329-381 parallelised like '
+                         'AO2MOnr_e2_drv, nr_ao2mo.c:1253-1265: aux rows across %d threads, one single-threaded dsymm per '
+                         'row, threaded dgemm for buf1^T buf1) on %d of %d aux rows of the GPU-built tensor: %.2f s'
+                         % (ncore, nrow, naux, cpu_s)}
         # parity at full size: the same rows through the HIP path
         sub = df.DF(mol)
         sub._cderi_dev = dfobj._cderi_dev[:nrow]
@@ -237,7 +303,8 @@ def main():
                                   nao, naux, nocc, 8e-9 * naux * npair,
                                   ' + unpacked image for the K half transform' if getattr(dfobj, '_cderi_sq', None) is not None else ''),
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
-                   'naux_local': naux_local},
+                   'naux_local': naux_local, 'naux_per_rank': naux_per_rank},
+        'value_host_api_ms': round(host_api_ms, 3),
         'roofline': roofline,
         'cpu_baseline': cpu,
         'kernels': kern, 'j_hbm_GBs': j_gbs, 'k_mfma_TFLOPs': k_tflops,

@@ -126,14 +126,19 @@ int PAMD_df_vj_pass1(const double *d_cderi, long npair, int naux, const double *
 int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *d_rho, int nset,
                      double *d_vjtril, void *stream);                     /* vjtril[s] += rho_s^T B  */
 int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
-                    int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, void *stream);
+                    int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work,
+                    void *stream);
+long PAMD_nr_e2_rho_worksize(int nL, int ldx, int nocc_pad);             /* doubles of d_rho_work */
 /* the same contraction on the unpacked image sq[nL][rows][ld] (PAMD_unpack_tril into a zeroed buffer, rows = ld =
  * round_up(nao,16)): both operands stream by LDS-DMA; spends 2x the packed size of HBM to take the symmetric unpack out
  * of the hot loop.  d_orb as for PAMD_nr_e2_symm with ldo >= chunks * 32 * wa (pyscf_amd/df/df_jk.py:pad_orbitals) */
 int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, const double *d_orb, int ldo,
-                      int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, void *stream);
+                      int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work,
+                      void *stream);
 /* d_rho (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] = sum_pq B_L[p][q] (orb orb^T)[p][q]: the first J pass
- * (df_jk.py:367) of the density the orbitals stand for, taken from the accumulators in the epilogue */  /* out[L][i][p] */
+ * (df_jk.py:367) of the density the orbitals stand for, taken from the accumulators in the epilogue.  Deterministic: every
+ * wave leaves one partial in d_rho_work (PAMD_nr_e2_rho_worksize doubles, required with d_rho) and a fixed-order reduction
+ * adds them to d_rho - no floating-point atomics on the energy path */  /* out[L][i][p] */
 /* out[y][i][n] = sum_k src_y[n][k] orb[k][i] (plain-operand mode of the e2_symm MFMA kernel) */
 int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, long nrows, int kdim,
                       const double *d_orb, int ldo, int nocc_pad, double *d_out, long ldout,
@@ -171,7 +176,8 @@ int PAMD_eval_ao(int deriv, const int *d_l, const int *d_ao0, const int *d_prim0
 /* rho[4][ldg] (rho, grad rho) from c[comp][i][ldc] = C_occ^T ao_comp^T (orbital rows), or from ao and
  * c0t[mu][ldc] = (D ao0^T) */
 int PAMD_rho_from_mo(const double *d_c, long comp_stride, long ldc, int nocc, int ncomp, long ng,
-                     double *d_rho, long ldg, void *stream);
+                     double *d_rho, long ldg, const double *d_occ_sign /* nullable [nocc]: +-1 weights of the rows,
+                     for a symmetric matrix factorised as C diag(sign) C^T */, void *stream);
 int PAMD_rho_from_dm(const double *d_ao, const double *d_c0t, int nao, int ldao, long ldg_rows, long ldc,
                      int ncomp, long ng, double *d_rho, long ldg, void *stream);
 /* fac7: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C}.  wv[4][ldg] = w (vrho/2, 2 vsigma grad rho);
@@ -211,6 +217,25 @@ int PAMD_scale_ao(const double *d_ao, const double *d_wv, int ldao, long ldg_row
 int PAMD_dgemm_nt(const double *d_A, long lda, const double *d_B, long ldb, double *d_C, int ldc, int m,
                   int n, long k, int nsplit, void *stream);                /* C[s] += A B^T (k split s) */
 int PAMD_reduce_sym(const double *d_part, int nsplit, int m, int ldc, double *d_out, void *stream);
+
+/* ---- block-sparse XC on compact AO subsets (csrc/xc_sparse.hip) ------------------------------------------------------
+ * The role of numint's non0tab / screen_index shell lists (dft/numint.py:2845, lib/gto/grid_ao_drv.c:32-123
+ * GTO_screen_index) and of the sparse products VXCdot_ao_dm_sparse / VXCdot_ao_ao_sparse
+ * (lib/dft/nr_numint_sparse.c:226-304, :890-973).  The grid is cut into tiles of G points; tile t stores the AO values of
+ * its active functions compacted, ao_c[t] = [ncomp][G][ld_t] at d_ao_c + d_ao_off[t] (ld_t = d_ld[t], a multiple of 16),
+ * and d_idx[d_idx_off[t] + mu] is the AO index of compact column mu (>= nao for padding).  One launch per product covers
+ * all `ntile` tiles handed to the call. */
+int PAMD_sub_gather_ao(const double *d_dense, long dense_rows, int ldao, int ncomp, long row0, long nrows_valid,
+                       const long *d_ao_off, const long *d_idx_off, const int *d_ld, const int *d_idx, int ntile, int G,
+                       int ld_max, int nao, double *d_ao_c, void *stream);     /* ao_c <- columns of a PAMD_eval_ao block */
+int PAMD_sub_orb_dot(const double *d_ao_c, const long *d_ao_off, const long *d_idx_off, const int *d_ld, const int *d_idx,
+                     int ntile, int G, int ncomp, const double *d_orb, int ldo, int nocc_pad, double *d_cmo,
+                     long comp_stride, long ldc, void *stream);   /* cmo[c][i][t G + g] = sum_mu orb[idx[mu]][i] ao_c[t][c][g][mu] */
+int PAMD_sub_scale_ao(const double *d_ao_c, const long *d_ao_off, const long *d_aow_off, const int *d_ld, int ntile, int G,
+                      int ncomp, int ld_max, const double *d_wv, long ldg, double *d_aow_c, void *stream);
+int PAMD_sub_vmat(const double *d_ao_c, const long *d_ao_off, const double *d_aow_c, const long *d_aow_off,
+                  const long *d_idx_off, const int *d_ld, const int *d_idx, const int *d_work /* {tile, tm, tn} x nwork */,
+                  int nwork, int G, int nao, double *d_vmat, long ldv, void *stream);  /* vmat[idx][idx] += ao_c[0]^T aow_c */
 
 #ifdef __cplusplus
 }

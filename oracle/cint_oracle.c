@@ -433,6 +433,45 @@ void oracle_int3c2e(double *out, const int *atm, int natm, const int *bas, int n
     free(loc);
 }
 
+/* Packed (s2ij) slab of the same integrals: AO shells i in [ish0, ish1), every j <= i, every aux function.
+ * out[k][pq - pq0], pq = p(p+1)/2 + q (p >= q), pq0 = p0(p0+1)/2 with p0 the first function of shell ish0; the row length
+ * `ld` must be >= p1(p1+1)/2 - pq0.  This is the layout of the reference's `_cderi` rows before the metric solve
+ * (pyscf/df/incore.py:178-199: getints3c with aosym='s2ij' over shell-range slabs). */
+void oracle_int3c2e_slab(double *out, long ld, const int *atm, int natm, const int *bas, int nbas_ao,
+                         int nbas_aux, const double *env, int ish0, int ish1)
+{
+    int nbas = nbas_ao + nbas_aux;
+    int *loc = malloc(sizeof(int) * (nbas + 1));
+    make_ao_loc(bas, nbas, loc);
+    int nao = loc[nbas_ao];
+    long p0 = loc[ish0];
+    long pq0 = p0 * (p0 + 1) / 2;
+#pragma omp parallel for schedule(dynamic) collapse(2)
+    for (int ks = 0; ks < nbas_aux; ks++)
+    for (int is = ish0; is < ish1; is++) {
+        Shell K = get_shell(atm, bas, env, nbas_ao + ks);
+        Shell Kd = dummy_shell(K.r);
+        Shell I = get_shell(atm, bas, env, is);
+        int dk = nsph(&K), di = nsph(&I);
+        int k0 = loc[nbas_ao + ks] - nao, i0 = loc[is];
+        for (int js = 0; js <= is; js++) {
+            Shell J = get_shell(atm, bas, env, js);
+            int dj = nsph(&J), j0 = loc[js];
+            double *buf = malloc(sizeof(double) * di * dj * dk);
+            eri_sph(&I, &J, &K, &Kd, buf);   /* buf[k][j][i] */
+            for (int k = 0; k < dk; k++)
+                for (int j = 0; j < dj; j++)
+                    for (int i = 0; i < di; i++) {
+                        long p = i0 + i, q = j0 + j;
+                        if (q > p) continue;             /* diagonal shell block: lower triangle only */
+                        out[(size_t)(k0 + k) * ld + (p * (p + 1) / 2 + q - pq0)] = buf[((size_t)k * dj + j) * di + i];
+                    }
+            free(buf);
+        }
+    }
+    free(loc);
+}
+
 /* (i|k) over the shells [sh0, sh1) of a bas table: out[i][k] symmetric, n x n */
 void oracle_int2c2e(double *out, const int *atm, int natm, const int *bas, int sh0, int sh1,
                     const double *env)

@@ -117,6 +117,36 @@ def int3c2e(mol, auxmol, omega=0.0):
     return out
 
 
+def ao_loc(mol):
+    """Function offset of every AO shell (segmented or general contraction): mol.ao_loc_nr()."""
+    bas = np.asarray(mol._bas)
+    return np.concatenate([[0], np.cumsum((2 * bas[:, 1] + 1) * bas[:, 3])]).astype(int)
+
+
+def int3c2e_slab(mol, auxmol, ish0, ish1, omega=0.0, out=None):
+    """Packed raw integrals (Q|pq) for the AO rows p of shells [ish0, ish1), all q <= p, all aux Q:
+    (naux, p1(p1+1)/2 - p0(p0+1)/2), the column slab [pq0, pq1) of the reference's s2ij tensor
+    (pyscf/df/incore.py:178-199)."""
+    from pyscf_amd.gto import conc_env
+    atm, bas, env = conc_env(mol._atm, mol._bas, mol._env, auxmol._atm, auxmol._bas, auxmol._env)
+    atm = np.ascontiguousarray(atm, np.int32)
+    bas = np.ascontiguousarray(bas, np.int32)
+    env = np.ascontiguousarray(env)
+    loc = ao_loc(mol)
+    p0, p1 = int(loc[ish0]), int(loc[ish1])
+    ncol = p1 * (p1 + 1) // 2 - p0 * (p0 + 1) // 2
+    naux = auxmol.nao_nr()
+    if out is None:
+        out = np.zeros((naux, ncol))
+    assert out.shape == (naux, ncol) and out.flags.c_contiguous
+    lib().oracle_set_omega(ctypes.c_double(omega))
+    lib().oracle_int3c2e_slab(_p(out), ctypes.c_long(ncol), _p(atm), ctypes.c_int(len(atm)), _p(bas),
+                              ctypes.c_int(mol.nbas), ctypes.c_int(auxmol.nbas), _p(env), ctypes.c_int(ish0),
+                              ctypes.c_int(ish1))
+    lib().oracle_set_omega(ctypes.c_double(0.0))
+    return out
+
+
 def int2e(mol, omega=0.0):
     atm, bas, env = _tables(mol)
     n = mol.nao_nr()
@@ -188,6 +218,52 @@ def get_jk(cderi, dm, hermi=1, with_j=True, with_k=True, mo_coeff=None, mo_occ=N
         vj = None
     vk = vk.reshape(shape) if with_k else None
     return vj, vk
+
+
+def get_jk_rows_parallel(cderi, dm, mo_coeff, mo_occ, nthreads=None, blockdim=240):
+    """MO-branch J/K (pyscf/df/df_jk.py:329-381) with the reference's own parallel structure, for the CPU baseline of
+    bench.py: ``AO2MOnr_e2_drv`` runs its OpenMP loop over the aux rows of a block, every thread unpacking one row and
+    calling a single-threaded ``dsymm`` on it (pyscf/lib/ao2mo/nr_ao2mo.c:1253-1265, :399-419, :1016-1031); the J dot
+    products (df_jk.py:367) and the final ``lib.dot(buf1.T, buf1)`` (df_jk.py:380 -> NPdgemm) are multi-threaded BLAS.
+    Returns (vj, vk, flops) for one closed-shell density."""
+    import concurrent.futures
+    from scipy.linalg import blas
+    from threadpoolctl import threadpool_limits
+    dm = np.asarray(dm)
+    nao = dm.shape[-1]
+    mo_occ = np.asarray(mo_occ)
+    orbo = np.asarray(mo_coeff)[:, mo_occ > 0] * np.sqrt(mo_occ[mo_occ > 0])
+    nocc = orbo.shape[1]
+    orbo_f = np.asfortranarray(orbo)
+    nthreads = nthreads or os.cpu_count()
+    naux = cderi.shape[0]
+    idx = np.arange(nao)
+    dmtril = pack_tril(dm + dm.T)
+    dmtril[idx * (idx + 1) // 2 + idx] *= .5
+    vj = np.zeros(cderi.shape[1])
+    vk = np.zeros((nao, nao))
+
+    def rows(args):
+        full, buf1, r0, r1 = args
+        for r in range(r0, r1):
+            # C(nao, nocc) = B_L (symmetric) . orbo: Fortran dsymm, side = left; stored transposed as buf1[r] (nocc, nao)
+            buf1[r] = blas.dsymm(1.0, full[r].T, orbo_f, lower=0).T
+        return r1 - r0
+
+    with concurrent.futures.ThreadPoolExecutor(nthreads) as pool:
+        for b0 in range(0, naux, blockdim):
+            eri1 = np.ascontiguousarray(cderi[b0:b0 + blockdim])
+            nb = eri1.shape[0]
+            vj += dmtril.dot(eri1.T).dot(eri1)                       # threaded BLAS
+            full = unpack_tril(eri1)                                  # C, OpenMP over the rows (NPdunpack_tril per row)
+            buf1 = np.empty((nb, nocc, nao))
+            per = max(1, -(-nb // nthreads))
+            with threadpool_limits(limits=1, user_api='blas'):
+                list(pool.map(rows, [(full, buf1, r, min(r + per, nb)) for r in range(0, nb, per)]))
+            b2 = buf1.reshape(-1, nao)
+            vk += b2.T.dot(b2)                                        # threaded dgemm (lib.dot, df_jk.py:380)
+    flops = 2.0 * naux * nao * nao * nocc * 2 + 4.0 * naux * cderi.shape[1]
+    return unpack_tril(vj[None], 1)[0], vk, flops
 
 
 def get_jk_exact(eri, dm):

@@ -404,8 +404,10 @@ def nr_rks(mol, coords, weights, fac, gga, dm):
     return nelec, exc, m + m.T
 
 
-def rks_energy(mol, xc_fac, hyb, gga, coords, weights, get_jk, conv_tol=1e-10, verbose=False):
-    """RKS SCF with the oracle pieces.  get_jk(dm, c, occ, with_k) -> (vj, vk|None)."""
+def rks_energy(mol, xc_fac, hyb, gga, coords, weights, get_jk, conv_tol=1e-10, verbose=False, dm0=None, h1e=None,
+               s1e=None):
+    """RKS SCF with the oracle pieces.  get_jk(dm, c, occ, with_k) -> (vj, vk|None).  dm0: optional start density (the
+    orbitals handed to get_jk are then None on the first call)."""
     state = {}
 
     def veff(dm, c, occ):
@@ -419,7 +421,8 @@ def rks_energy(mol, xc_fac, hyb, gga, coords, weights, get_jk, conv_tol=1e-10, v
         state['e2'] = e2
         state['nelec'] = n
         return v
-    return ref.rhf_kernel(mol, veff, conv_tol=conv_tol, verbose=verbose, e2_fn=lambda: state['e2'])
+    return ref.rhf_kernel(mol, veff, conv_tol=conv_tol, verbose=verbose, e2_fn=lambda: state['e2'], dm0=dm0, h1e=h1e,
+                          s1e=s1e)
 
 
 def eval_ao_hess(mol, coords, h=1e-4):

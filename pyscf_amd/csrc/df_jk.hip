@@ -15,6 +15,7 @@
 //   gemm_tn    C[m][n]    += sum_k  A[k][m] * B[k][n]                 (FP64 MFMA; lower-tri
 //              tiles only for the K = X^T X  SYRK)
 #include "common.h"
+#include "mfma_e2.h"
 
 using namespace pamd;
 
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(J1_THREADS) void vj_pass1_rows_kernel(
     }
 }
 
+template <bool ACCUMULATE>
 __global__ void vj_pass1_reduce_kernel(const double *__restrict__ partial, double *__restrict__ rho,
                                        int n, int nchunk)
 {
@@ -84,7 +86,7 @@ __global__ void vj_pass1_reduce_kernel(const double *__restrict__ partial, doubl
     double v = 0;
     for (int c = lane; c < nchunk; c += 64) v += partial[(long)i * nchunk + c];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) rho[i] = v;
+    if (lane == 0) rho[i] = ACCUMULATE ? rho[i] + v : v;
 }
 
 template <int NSET>
@@ -118,147 +120,20 @@ __global__ __launch_bounds__(256) void vj_pass2_kernel(
 }
 
 // ------------------------------------------------------------------------------------ K
-// LDS row strides (in doubles).  A fragment read is ds_read_b64 with lanes 0-15 on row k and
-// lanes 16-31 on row k+1: conflict-free when the row stride is == 16 (mod 32) doubles.
-constexpr int KB = 16;          // k-depth of one LDS tile
-constexpr int NT = 128;         // columns per workgroup tile
-constexpr int LDN = NT + 16;    // 144 == 16 mod 32
-constexpr int LDT = KB + 1;     // transposed tile [n][k], odd stride -> conflict-free b64 reads
-
-// X[L][i][p] = sum_q Bsym_L[q][p] * orb[q][i]
-//   grid: x = p tile (128 cols), y = L, z = chunk of MT*16 orbitals
-//   MFMA roles: m = orbital i (A operand from orb), n = AO index p (B operand from cderi row)
-//   The packed row is read directly: tiles below the diagonal (q >= p) are row-contiguous,
-//   tiles above it are read through the transposed element row[p(p+1)/2+q] (q-contiguous) and
-//   kept transposed in LDS.  Next tile is prefetched into registers during the MFMA phase.
-//   PLAIN = true: the same MFMA structure for a plain operand src[n][k] (k contiguous, leading
-//   dimension npair): out[y][i][n] = sum_k src_y[n][k] orb[k][i]  (used for c = C_occ^T ao^T in nr_rks);
-//   then `nao` is the k extent, `ncols` the n extent and `npair` doubles as the row stride of src.
+// X[L][i][p] = sum_q Bsym_L[q][p] * orb[q][i]: grid x = p tile (128 cols), y = L, z = chunk of MT*16 orbitals
+// (body and operand conventions: mfma_e2.h)
 template <int MT, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void e2_symm_kernel(
     const double *__restrict__ cderi, long npair, int nao, const double *__restrict__ orb, int ldo,
     double *__restrict__ X, int nocc_pad, long ldx, long src_stride, long ncols,
     const unsigned char *__restrict__ kmask, double *__restrict__ rho)
 {
-    constexpr int MW = MT * 16;                         // orbitals per workgroup
-    constexpr int LDA = MW + ((MW % 32 == 16) ? 0 : 16);  // == 16 mod 32
-    __shared__ double sA[KB * LDA];
-    __shared__ double sB[(NT * LDT > KB * LDN) ? NT * LDT : KB * LDN];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int p0 = blockIdx.x * NT;
     const int L = blockIdx.y;
-    const int m0 = blockIdx.z * MW;
     const double *row = PLAIN ? cderi + (long)L * src_stride : cderi + (long)L * npair;
-
-    double4_t acc[MT][2];
-#pragma unroll
-    for (int a = 0; a < MT; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = double4_t{0, 0, 0, 0};
-
-    const int fk = lane >> 4, fn = lane & 15;
-    const int sk = tid >> 4, sc = tid & 15;             // staging coordinates (row-major tiles)
-    const int tn = tid >> 1, tk = (tid & 1) * 8;        // staging coordinates (transposed tiles)
-    double ra[MT], rb[8];
-
-    auto tile_above = [&](int q0) { return PLAIN || q0 + KB - 1 <= p0; };
-    auto fetch = [&](int q0) {
-        const int q = q0 + sk;
-        const double *orow = orb + (long)q * ldo + m0 + sc;
-#pragma unroll
-        for (int j = 0; j < MT; j++) ra[j] = (q < nao) ? orow[16 * j] : 0.0;
-        if (PLAIN) {
-            const long p = p0 + tn;
-            const double *src = row + p * npair + q0 + tk;
-#pragma unroll
-            for (int j = 0; j < 8; j++) rb[j] = (p < ncols && q0 + tk + j < nao) ? src[j] : 0.0;
-        } else if (tile_above(q0)) {
-            const long p = p0 + tn;
-            const double *src = row + p * (p + 1) / 2 + q0 + tk;
-#pragma unroll
-            for (int j = 0; j < 8; j++) rb[j] = (p < nao && q0 + tk + j < nao) ? src[j] : 0.0;
-        } else if (q0 >= p0 + NT - 1) {
-            const double *src = row + (long)q * (q + 1) / 2 + p0 + sc;
-#pragma unroll
-            for (int j = 0; j < 8; j++) rb[j] = (q < nao && p0 + sc + 16 * j < nao) ? src[16 * j] : 0.0;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const long p = p0 + sc + 16 * j, qq = q;
-                double v = 0.0;
-                if (p < nao && qq < nao) v = (qq >= p) ? row[qq * (qq + 1) / 2 + p] : row[p * (p + 1) / 2 + qq];
-                rb[j] = v;
-            }
-        }
-    };
-
-    // optional screening (PLAIN mode): kmask[(y * ntiles + tile) * nk + k-tile] == 0 -> the 128 x 16 operand
-    // tile is negligible and its k-tile is skipped (numint's non0tab idea, pyscf/gto/eval_gto.py:146+)
     const unsigned char *km = kmask ? kmask + ((long)L * gridDim.x + blockIdx.x) * ((nao + KB - 1) / KB) : nullptr;
-    auto next_active = [&](int q) {
-        if (km) while (q < nao && !km[q / KB]) q += KB;
-        return q;
-    };
-    int q0 = next_active(0);
-    if (q0 < nao) fetch(q0);
-    while (q0 < nao) {
-        const bool above = tile_above(q0);
-#pragma unroll
-        for (int j = 0; j < MT; j++) sA[sk * LDA + sc + 16 * j] = ra[j];
-        if (above) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) sB[tn * LDT + tk + j] = rb[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) sB[sk * LDN + sc + 16 * j] = rb[j];
-        }
-        __syncthreads();
-        const int qn = next_active(q0 + KB);
-        if (qn < nao) fetch(qn);
-#pragma unroll
-        for (int kk = 0; kk < KB; kk += 4) {
-            double bf[2];
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                int n = wave * 32 + b * 16 + fn;
-                bf[b] = above ? sB[n * LDT + kk + fk] : sB[(kk + fk) * LDN + n];
-            }
-#pragma unroll
-            for (int a = 0; a < MT; a++) {
-                double af = sA[(kk + fk) * LDA + a * 16 + fn];
-#pragma unroll
-                for (int b = 0; b < 2; b++) acc[a][b] = mfma_f64_16x16x4(af, bf[b], acc[a][b]);
-            }
-        }
-        __syncthreads();
-        q0 = qn;
-    }
-    // ---- store: D[m = (lane>>4)+4r][n = lane&15]; rho (symmetric mode, nullable): rho[L] += sum_{i,p} X[L][i][p] orb[p][i],
-    // the first J pass of the density orb orb^T (see e2_sq_kernel)
-    double *out = X + (long)L * nocc_pad * ldx;
-    const bool do_rho = !PLAIN && rho != nullptr;
-    double rho_acc = 0;
-#pragma unroll
-    for (int a = 0; a < MT; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            long p = p0 + wave * 32 + b * 16 + fn;
-            if (p >= (PLAIN ? ncols : ldx)) continue;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int i = m0 + a * 16 + fk + 4 * r;
-                if (i < nocc_pad) {
-                    out[(long)i * ldx + p] = acc[a][b][r];
-                    if (do_rho && p < nao) rho_acc += acc[a][b][r] * orb[p * ldo + i];
-                }
-            }
-        }
-    if (do_rho) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) rho_acc += __shfl_xor(rho_acc, off, 64);
-        if (lane == 0) unsafeAtomicAdd(rho + L, rho_acc);
-    }
+    double *slot = rho ? rho + ((long)L * gridDim.z * gridDim.x + (long)blockIdx.z * gridDim.x + blockIdx.x) * 4 : nullptr;
+    e2_symm_body<MT, PLAIN, false>(row, npair, nao, orb, ldo, X + (long)L * nocc_pad * ldx, nocc_pad, ldx, ncols, km, slot,
+                                   nullptr, blockIdx.x * NT, blockIdx.z * (MT * 16));
 }
 
 // C[split][m][n] += sum_{k in split range} A[k][m] * B[k][n]
@@ -593,9 +468,10 @@ __global__ __launch_bounds__(256, 2) void e2_sq_kernel(
             }
         }
     if (RHO) {
+        // one partial per wave (no atomics): rho[L][workgroup][wave], reduced in a fixed order afterwards
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) rho_acc += __shfl_xor(rho_acc, off, 64);
-        if (lane == 0) unsafeAtomicAdd(rho + L, rho_acc);
+        if (lane == 0) rho[(L * gridDim.x + blockIdx.x) * 4 + wave] = rho_acc;
     }
 }
 
@@ -699,7 +575,7 @@ int PAMD_df_vj_pass1(const double *d_cderi, long npair, int naux, const double *
     }
     PAMD_CHECK_LAUNCH();
     int n = nset * naux;
-    vj_pass1_reduce_kernel<<<ceil_div(n, 4), 256, 0, st>>>(d_work, d_rho, n, nchunk);
+    vj_pass1_reduce_kernel<false><<<ceil_div(n, 4), 256, 0, st>>>(d_work, d_rho, n, nchunk);
     PAMD_CHECK_LAUNCH();
     return 0;
 }
@@ -727,9 +603,24 @@ int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *
 //           orb_rows >= nao allocated rows (rows >= nao zero) - round_up(nao,16) enables the LDS-DMA kernel
 //   d_out   [nL][nocc_pad][ldx]
 //   d_rho   (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] (first J pass of the density orb orb^T)
-int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
-                    int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, void *stream)
+// Doubles of workspace the fused first J pass needs (d_rho_work): one partial per wave of every workgroup of a row.
+long PAMD_nr_e2_rho_worksize(int nL, int ldx, int nocc_pad)
 {
+    const int nchunk = ceil_div(ceil_div(nocc_pad, 16), g_e2_mtmax);      // g_e2_mtmax <= 10 = the square kernel's chunking
+    return (long)nL * ceil_div(ldx, NT) * nchunk * 4;
+}
+
+static int reduce_rho_partials(const double *d_work, double *d_rho, int nL, int nslot, hipStream_t st)
+{
+    vj_pass1_reduce_kernel<true><<<ceil_div(nL, 4), 256, 0, st>>>(d_work, d_rho, nL, nslot);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
+                    int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream)
+{
+    PAMD_REQUIRE(d_rho == nullptr || d_rho_work != nullptr, "d_rho needs d_rho_work (PAMD_nr_e2_rho_worksize doubles)");
     PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
     PAMD_REQUIRE(ldx >= nao, "ldx < nao");
     if (nL == 0 || nocc_pad == 0) return 0;
@@ -740,7 +631,7 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     // the kernel writes rows i < nocc_pad only; chunks are mt*16 wide
     dim3 grid(ceil_div(ldx, NT), nL, nchunk);
 #define LAUNCH_E2(MT)                                                                         \
-    e2_symm_kernel<MT, false><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx, 0, 0, nullptr, d_rho)
+    e2_symm_kernel<MT, false><<<grid, 256, 0, st>>>(d_cderi, npair, nao, d_orb, ldo, d_out, nocc_pad, ldx, 0, 0, nullptr, d_rho ? d_rho_work : nullptr)
     // orbital tile reads m0+i < ldo must stay in bounds: require ldo >= nchunk*mt*16
     PAMD_REQUIRE(ldo >= nchunk * mt * 16, "orbital leading dimension too small for tile padding");
     switch (mt) {
@@ -757,6 +648,8 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     }
 #undef LAUNCH_E2
     PAMD_CHECK_LAUNCH();
+    // the partial layout needs the MT actually launched to cover the chunk count used by the worksize query
+    if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, (int)(grid.x * grid.z * 4), st);
     return 0;
 }
 
@@ -768,8 +661,9 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
 //   d_rho (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] = sum_pq B_L[p][q] (orb orb^T)[p][q], the first J pass
 //   of the density the orbitals stand for, taken from the accumulators in the epilogue
 int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, const double *d_orb, int ldo,
-                      int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, void *stream)
+                      int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream)
 {
+    PAMD_REQUIRE(d_rho == nullptr || d_rho_work != nullptr, "d_rho needs d_rho_work (PAMD_nr_e2_rho_worksize doubles)");
     PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
     PAMD_REQUIRE(rows % KB == 0 && rows >= nao && orb_rows >= rows, "q rows must be padded to a multiple of 16");
     PAMD_REQUIRE(ld % 2 == 0 && ldo % 2 == 0 && ld >= nao && ldx >= nao, "leading dimensions");
@@ -785,7 +679,7 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
     do {                                                                                                        \
         if (d_rho)                                                                                              \
             e2_sq_kernel<W, true><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
-                                                        ldx, d_rho, nchunk);                                     \
+                                                        ldx, d_rho_work, nchunk);                                \
         else                                                                                                    \
             e2_sq_kernel<W, false><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
                                                          ldx, nullptr, nchunk);                                  \
@@ -799,6 +693,7 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
     }
 #undef LAUNCH_SQ
     PAMD_CHECK_LAUNCH();
+    if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, (int)(grid.x * 4), st);
     return 0;
 }
 

@@ -547,16 +547,18 @@ __global__ __launch_bounds__(256) void eval_fxc_pol_kernel(XCSpec spec, int gga,
 }
 
 // rho from c[comp][i][ldc] = sum_mu C_occ[mu][i] ao_comp[g][mu]   (orbital rows, grid index fastest)
+// sign (nullable): +-1 per row - a symmetric matrix D = C diag(sign) C^T (eigen-factorised, not positive) as "orbitals"
 __global__ __launch_bounds__(256) void rho_from_mo_kernel(const double *__restrict__ c, long comp_stride, long ldc,
                                                           int nocc, int ncomp, long ng, double *__restrict__ rho,
-                                                          long ldg)
+                                                          long ldg, const double *__restrict__ sign)
 {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
     if (g >= ng) return;
     double s0 = 0, sx = 0, sy = 0, sz = 0;
     for (int i = 0; i < nocc; i++) {
-        const double c0 = c[(long)i * ldc + g];
-        s0 += c0 * c0;
+        const double cv = c[(long)i * ldc + g];
+        const double c0 = sign ? sign[i] * cv : cv;
+        s0 += c0 * cv;
         if (ncomp == 4) {
             sx += c0 * c[comp_stride + (long)i * ldc + g];
             sy += c0 * c[2 * comp_stride + (long)i * ldc + g];
@@ -837,11 +839,11 @@ int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const d
 }
 
 int PAMD_rho_from_mo(const double *d_c, long comp_stride, long ldc, int nocc, int ncomp, long ng, double *d_rho,
-                     long ldg, void *stream)
+                     long ldg, const double *d_occ_sign, void *stream)
 {
     if (ng == 0) return 0;
     rho_from_mo_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(d_c, comp_stride, ldc, nocc, ncomp, ng,
-                                                                           d_rho, ldg);
+                                                                           d_rho, ldg, d_occ_sign);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

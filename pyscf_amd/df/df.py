@@ -8,6 +8,8 @@ pyscf/df/df_jk.py:31,77-105) routes ``_DFHF.get_jk`` (df_jk.py:150-179) onto the
 The tensor lives in HBM as the row shard ``cderi[l0:l1, :nao_pair]`` of this rank
 (aux-index sharding); with one process it is the whole ``_cderi``.
 """
+import os
+
 import numpy as np
 
 from . import addons, df_jk
@@ -188,6 +190,8 @@ class DF:
         self._naux = None
         self._ws = {}
         self._eng = None
+        self._rsh_df = {}          # pyscf/df/df.py:210: the range-separated children hold the old mol / auxmol
+        self._side = None
         return self
 
     def _device(self):
@@ -203,10 +207,21 @@ class DF:
         import torch
         dev = self._device()
         if isinstance(self._cderi, str):
-            with open(self._cderi, 'rb') as f:
+            shard = self._shard_path(self._cderi)
+            if self.world_size > 1 and os.path.exists(shard):
+                # written by save() of a run with the same world size: this rank's rows, no re-sharding
+                with np.load(shard) as z:
+                    rows, l0, l1, naux = z['j3c'], int(z['l0']), int(z['l1']), int(z['naux'])
+                if (l0, l1) != self.shard_range(naux, self.rank, self.world_size):
+                    raise RuntimeError('%s holds aux rows [%d, %d) of %d: not the shard of rank %d of %d'
+                                       % (shard, l0, l1, naux, self.rank, self.world_size))
+                self._cderi_dev = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
+                self._naux = naux
+                return self
+            with open(self._cderi, 'rb') as f:        # one file = the FULL tensor (written by a single-rank run)
                 self._cderi = np.load(f)
         if self._cderi is not None and isinstance(self._cderi, np.ndarray):
-            # pre-computed tensor handed over by the caller (pyscf/df/df.py:153-155)
+            # pre-computed FULL tensor handed over by the caller (pyscf/df/df.py:153-155); each rank keeps its rows
             naux = self._cderi.shape[0]
             l0, l1 = self.shard_range(naux, self.rank, self.world_size)
             self._cderi_dev = torch.from_numpy(np.ascontiguousarray(self._cderi[l0:l1])).to(dev)
@@ -295,7 +310,7 @@ class DF:
             df_jk._call(self, 'e2_symm', so.PAMD_nr_e2_symm, _c.c_void_p(cderi[b0:b0 + nb].data_ptr()), _c.c_long(npair),
                         _c.c_int(nb), _c.c_int(nao), _c.c_void_p(orb.data_ptr()), _c.c_int(ldo),
                         _c.c_int(orb.shape[0]), _c.c_int(ni_pad), _c.c_void_p(X.data_ptr()), _c.c_int(ldx),
-                        _c.c_void_p(0), st)
+                        _c.c_void_p(0), _c.c_void_p(0), st)
             y = torch.matmul(X[:, :ni, :nao], cj_dev).reshape(nb, ni * nj)      # second index: plain library GEMM
             out[b0:b0 + nb] = y[:, sel] if same else y
         return out
@@ -315,13 +330,22 @@ class DF:
         return self._pair_gram(lij, lkl).cpu().numpy()
     get_mo_eri = ao2mo
 
+    def _shard_path(self, path):
+        return '%s.rank%dof%d.npz' % (path, self.rank, self.world_size)
+
     def save(self, path=None):
-        """Write the rank-local rows as a .npy file (the reference writes the HDF5 dataset 'j3c',
-        pyscf/df/df.py:97-99,185-199; h5py is not available in this image).  `DF(mol)._cderi = path`
-        loads it back in build()."""
+        """Write the tensor to disk (the reference writes the HDF5 dataset 'j3c', pyscf/df/df.py:97-99,185-199; h5py is
+        not available in this image).  One rank: `path` is a .npy file holding the full (naux, nao_pair) array.  Several
+        ranks: every rank writes its own rows to `path.rank<r>of<w>.npz` together with (l0, l1, naux) - never the shared
+        `path` - and `DF(mol)._cderi = path` loads them back in build() without re-sharding."""
         path = path or self._cderi_to_save
         if self._cderi_dev is None:
             self.build()
+        if self.world_size > 1:
+            l0, l1 = self.shard_range(self._naux, self.rank, self.world_size)
+            out = self._shard_path(path)
+            np.savez(out, j3c=self._cderi_dev.cpu().numpy(), l0=l0, l1=l1, naux=self._naux)
+            return out
         with open(path, 'wb') as f:
             np.save(f, self._cderi_dev.cpu().numpy())
         return path

@@ -130,6 +130,12 @@ def _k_blocksize(dfobj, naux, rows, ldx):
     return -(-max(naux, 1) // nblk)          # equal blocks (the J passes are hidden behind one SYRK each)
 
 
+def _rho_work(dfobj, lib, nb, ldx, nocc_pad):
+    """Per-wave partials of the fused first J pass (summed in a fixed order: J is bitwise reproducible)."""
+    n = lib.PAMD_nr_e2_rho_worksize(_c.c_int(nb), _c.c_int(ldx), _c.c_int(nocc_pad))
+    return _ptr(dfobj._workspace('rho_work', (max(int(n), 1),)))
+
+
 def pad_orbitals(orbo, device):
     """Host (nao, nocc) occupied-orbital block C_occ*sqrt(occ) -> zero-padded device operand
     (orb[nao][ldo], nocc_pad) in the layout PAMD_nr_e2_symm expects."""
@@ -175,11 +181,13 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
                 _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[b0:b0 + nb]), _c.c_long(sq.shape[2]),
                       _c.c_int(sq.shape[1]), _c.c_int(nb), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
                       _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X), _c.c_int(ldx),
-                      _ptr(rho_j[b0:]) if rho_j is not None else _c.c_void_p(0), st)
+                      _ptr(rho_j[b0:]) if rho_j is not None else _c.c_void_p(0),
+                      _rho_work(dfobj, lib, nb, ldx, nocc_pad) if rho_j is not None else _c.c_void_p(0), st)
             else:
                 _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
                       _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
-                      _c.c_int(ldx), _ptr(fuse_j[iset][b0:]) if fuse_j is not None else _c.c_void_p(0), st)
+                      _c.c_int(ldx), _ptr(fuse_j[iset][b0:]) if fuse_j is not None else _c.c_void_p(0),
+                      _rho_work(dfobj, lib, nb, ldx, nocc_pad) if fuse_j is not None else _c.c_void_p(0), st)
             if after_e2 is not None:
                 after_e2(b0, nb, iset)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
@@ -217,7 +225,8 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
             nb = min(blk, naux - b0)
             sub = cderi[b0:b0 + nb]
             _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
-                  _ptr(orb), _c.c_int(ldo), _c.c_int(rows), _c.c_int(rows), _ptr(X), _c.c_int(ldx), _c.c_void_p(0), st)
+                  _ptr(orb), _c.c_int(ldo), _c.c_int(rows), _c.c_int(rows), _ptr(X), _c.c_int(ldx), _c.c_void_p(0),
+                  _c.c_void_p(0), st)
             _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
                                                 _ptr(full), _c.c_int(ldx), _c.c_int(rows), st)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(full), _c.c_int(ldx), _ptr(part),

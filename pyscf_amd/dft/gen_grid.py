@@ -209,6 +209,7 @@ class Grids:
         self.device = None
         self.coords = self.weights = self.atm_idx = self.quadrature_weights = None
         self.non0tab = self.screen_index = None
+        self._build_id = 0          # bumped by build() / reset(): device-side caches of coords / weights key on it
 
     @property
     def size(self):
@@ -218,6 +219,7 @@ class Grids:
         if mol is not None:
             self.mol = mol
         self.coords = self.weights = self.atm_idx = self.quadrature_weights = None
+        self._build_id = getattr(self, '_build_id', 0) + 1
         return self
 
     def _device(self):
@@ -248,6 +250,7 @@ class Grids:
     def build(self, mol=None, with_non0tab=False, sort_grids=True):
         if mol is None:
             mol = self.mol
+        self._build_id = getattr(self, '_build_id', 0) + 1
         tab = gen_atomic_grids(mol, self.atom_grid, self.radi_method, self.level, self.prune)
         self.coords, self.weights = self.get_partition(mol, tab)
         atm_idx = np.empty(len(self.weights), np.int32)

@@ -75,6 +75,13 @@ class NumInt:
         self.group = group
         self._cache = {}
         self.kernel_timer = None
+        # block-sparse path (dft/sparse_grid.py, csrc/xc_sparse.hip): compact AO subsets per grid tile
+        self.sparse = True              # False: the dense tile-masked pipeline below (kept for comparison / tests)
+        self.sparse_tile = 1024         # grid points per tile (multiple of 128)
+        self.sparse_cutoff = 1e-14      # a shell is active on a tile if some value / gradient component exceeds this
+        self.sparse_chunk_points = 131072   # grid points per launch group (bounds the c = ao . C workspace)
+        self.ao_cache = 'auto'          # keep the compact AO image in HBM across calls: True / False / 'auto' (if it fits)
+        self.ao_cache_reserve = 40 << 30    # HBM left free after caching ('auto')
 
     # -- functional properties --------------------------------------------------------------
     def _xc_type(self, xc_code):
@@ -112,7 +119,8 @@ class NumInt:
         return 0, 1
 
     def _shell_tables(self, mol, dev):
-        key = ('shells', id(mol))
+        from ..gto.moleintor import mol_fingerprint
+        key = ('shells', mol_fingerprint(mol), str(dev))       # content key: survives mol.build(atom=...) in place
         if key not in self._cache:
             from ..gto.moleintor import get_engine, _dev
             eng = get_engine(mol, None, dev)
@@ -128,11 +136,20 @@ class NumInt:
 
     def _grid_tables(self, grids, dev):
         import torch
-        key = ('grids', id(grids), grids.size)
+        # keyed on the grid object's build counter (Grids.build / reset bump it), not only on id / size: a rebuild with
+        # another partition scheme or geometry keeps the size but changes coords and weights
+        key = ('grids', id(grids), getattr(grids, '_build_id', 0), grids.size, str(dev))
         if key not in self._cache:
+            for k in [k for k in self._cache if k[0] == 'grids' and k[1] == id(grids)]:
+                del self._cache[k]
             self._cache[key] = (torch.from_numpy(np.ascontiguousarray(grids.coords)).to(dev),
                                 torch.from_numpy(np.ascontiguousarray(grids.weights)).to(dev))
         return self._cache[key]
+
+    def reset(self):
+        """Drop every device-side cache (shell tables, grid tables, sparse-grid plans)."""
+        self._cache = {}
+        return self
 
     def _call(self, name, fn, *args):
         if self.kernel_timer is not None:
@@ -211,6 +228,117 @@ class NumInt:
         out = out[:, :, :nao].cpu().numpy()
         return out[0] if deriv == 0 else out
 
+    # -- block-sparse pipeline ------------------------------------------------------------------------------------
+    def sparse_plan(self, mol, grids, gga):
+        """SparsePlan of (mol, grids, LDA|GGA) on this rank, cached on the content of mol and the build of grids."""
+        from ..gto.moleintor import mol_fingerprint
+        from .sparse_grid import SparsePlan
+        dev = self._dev()
+        rank, world = self._world()
+        key = ('plan', mol_fingerprint(mol), id(grids), getattr(grids, '_build_id', 0), grids.size, int(bool(gga)),
+               str(dev), rank, world, self.sparse_tile, self.sparse_cutoff)
+        if key not in self._cache:
+            for k in [k for k in self._cache if k[0] == 'plan']:      # one plan at a time: it may hold tens of GB
+                del self._cache[k]
+            plan = SparsePlan(self, mol, grids, gga, dev, rank, world)
+            if plan.ao_c is not None:
+                plan.release_dense()
+            self._cache[key] = plan
+        return self._cache[key]
+
+    def _orbital_operand(self, dm, mo_coeff, mo_occ, nao, dev):
+        """(orb_dev [rows][ldo], nocc, nocc_pad, ldo, sign_dev | None): occupied orbitals scaled by sqrt(occ) when the
+        density is tagged (numint.py:2930-2994 _gen_rho_evaluator's MO branch), else the eigen-factorisation
+        D_sym = C diag(sign) C^T of the symmetric part (a density only sees that part) - every density then goes
+        through the same orbital-based kernels."""
+        import torch
+        sign = None
+        if mo_coeff is not None:
+            occ = np.asarray(mo_occ)
+            orbo = np.asarray(mo_coeff)[:, occ > 0] * np.sqrt(occ[occ > 0])
+        else:
+            d = torch.from_numpy(np.ascontiguousarray((dm + dm.T) * .5)).to(dev)
+            w, v = torch.linalg.eigh(d)
+            thr = 1e-14 * max(float(w.abs().max()), 1e-300)
+            keep = w.abs() > thr
+            orbo = (v[:, keep] * w[keep].abs().sqrt()).cpu().numpy()
+            sg = torch.sign(w[keep])
+            if bool((sg < 0).any()):
+                sign = sg.contiguous()
+        nocc = orbo.shape[1]
+        nocc_pad = _round_up(max(nocc, 1), 16)
+        ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
+        orb_h = np.zeros((_round_up(nao + 1, 16), ldo))        # row nao (and beyond): zeros - padding columns gather it
+        orb_h[:nao, :nocc] = orbo
+        return torch.from_numpy(orb_h).to(dev), nocc, nocc_pad, ldo, sign
+
+    def _sparse_xc(self, mol, grids, fac, gga, orbsets, spin):
+        """nelec / exc / vmat of nr_rks (spin = 0, one orbital set) or nr_uks (spin = 1, two sets) on the compact AO
+        subsets: per chunk of tiles  c = ao_c . C (sub_orb_dot) -> rho -> eval_xc -> aow_c (sub_scale) ->
+        M[idx, idx] += ao_c^T aow_c (sub_vmat); finally V = M + M^T (numint.py:1157)."""
+        import torch
+        lib = _lib_mod.load_library()
+        dev = self._dev()
+        plan = self.sparse_plan(mol, grids, gga)
+        G, ncomp, nao = plan.G, plan.ncomp, plan.nao
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        f64 = torch.float64
+        nset = len(orbsets)
+        ldg = plan.max_chunk_points
+        fac_c = (ctypes.c_double * 7)(*fac)
+        M = torch.zeros((nset, nao, nao), dtype=f64, device=dev)
+        acc = torch.zeros(3 if spin else 2, dtype=f64, device=dev)
+        rho = torch.zeros((nset, 4, max(ldg, 1)), dtype=f64, device=dev)
+        wv = torch.empty((nset, 4, max(ldg, 1)), dtype=f64, device=dev)
+        nocc_pad_max = max(o[2] for o in orbsets)
+        cmo = torch.empty(ncomp * nocc_pad_max * max(ldg, 1), dtype=f64, device=dev)
+        aow = torch.zeros(plan.max_aow_chunk + 256, dtype=f64, device=dev)
+        aoc_buf = None
+        if plan.ao_c is None:
+            aoc_buf = torch.zeros(plan.max_ao_chunk + 256, dtype=f64, device=dev)
+        for ch in plan.chunks:
+            t0, nt = ch['t0'], ch['t1'] - ch['t0']
+            npts = nt * G
+            if plan.ao_c is not None:
+                aoc = plan.ao_c[ch['ao_base']:]
+            else:
+                plan.fill_chunk(ch, aoc_buf)
+                aoc = aoc_buf
+            tabs = (_ptr(plan.ao_off[t0:]), _ptr(plan.aow_off[t0:]), _ptr(plan.idx_off[t0:]), _ptr(plan.ld[t0:]))
+            w_ch = plan.weights[t0 * G:(t0 + nt) * G]
+            for s, (orb, nocc, nocc_pad, ldo, sign) in enumerate(orbsets):
+                if nocc == 0:
+                    rho[s].zero_()
+                    continue
+                self._call('ao_dot_mo', lib.PAMD_sub_orb_dot, _ptr(aoc), tabs[0], tabs[2], tabs[3], _ptr(plan.idx),
+                           _c.c_int(nt), _c.c_int(G), _c.c_int(ncomp), _ptr(orb), _c.c_int(ldo), _c.c_int(nocc_pad),
+                           _ptr(cmo), _c.c_long(nocc_pad * npts), _c.c_long(npts), st)
+                self._call('rho', lib.PAMD_rho_from_mo, _ptr(cmo), _c.c_long(nocc_pad * npts), _c.c_long(npts),
+                           _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(npts), _ptr(rho[s]), _c.c_long(ldg),
+                           _ptr(sign) if sign is not None else _c.c_void_p(0), st)
+            if spin:
+                self._call('eval_xc', lib.PAMD_eval_xc_pol, fac_c, _c.c_int(gga), _ptr(rho[0]), _ptr(rho[1]), _ptr(w_ch),
+                           _c.c_long(npts), _c.c_long(ldg), _ptr(wv[0]), _ptr(wv[1]), _ptr(acc), _c.c_void_p(0), st)
+            else:
+                self._call('eval_xc', lib.PAMD_eval_xc, fac_c, _c.c_int(gga), _ptr(rho[0]), _ptr(w_ch), _c.c_long(npts),
+                           _c.c_long(ldg), _ptr(wv[0]), _c.c_void_p(0), _ptr(acc), st)
+            for s in range(nset):
+                self._call('scale_ao', lib.PAMD_sub_scale_ao, _ptr(aoc), tabs[0], tabs[1], tabs[3], _c.c_int(nt),
+                           _c.c_int(G), _c.c_int(ncomp), _c.c_int(ch['ld_max']), _ptr(wv[s]), _c.c_long(ldg), _ptr(aow), st)
+                self._call('ao_dot_aow', lib.PAMD_sub_vmat, _ptr(aoc), tabs[0], _ptr(aow), tabs[1], tabs[2], tabs[3],
+                           _ptr(plan.idx), _ptr(ch['work']), _c.c_int(ch['nwork']), _c.c_int(G), _c.c_int(nao),
+                           _ptr(M[s]), _c.c_long(nao), st)
+        v = torch.empty((nset, nao, nao), dtype=f64, device=dev)
+        for s in range(nset):
+            self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(M[s]), _c.c_int(1), _c.c_int(nao), _c.c_int(nao),
+                       _ptr(v[s]), st)
+        rank, world = self._world()
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(v, group=self.group)
+            dist.all_reduce(acc, group=self.group)
+        return acc.cpu().numpy(), v.cpu().numpy()
+
     # -- the hot entry point ----------------------------------------------------------------------
     def nr_rks(self, mol, grids, xc_code, dms, relativity=0, hermi=1, max_memory=2000, verbose=None):
         """-> (nelec, excsum, vmat) with the contract of numint.nr_rks (numint.py:1074-1190)."""
@@ -235,6 +363,15 @@ class NumInt:
             return (nelec[0], excsum[0], vmat[0]) if dms_arr.ndim == 2 else (nelec, excsum, vmat)
         gga = 1 if xctype == 'GGA' else 0
         ncomp = 4 if gga else 1
+        if self.sparse:
+            tagged = mo_coeff is not None and np.ndim(mo_occ) == 1 and nset == 1
+            for iset in range(nset):
+                ops = [self._orbital_operand(dms2[iset], mo_coeff if tagged else None, mo_occ, nao, dev)]
+                a, v = self._sparse_xc(mol, grids, fac, gga, ops, 0)
+                nelec[iset], excsum[iset], vmat[iset] = a[0], a[1], v[0]
+            if dms_arr.ndim == 2:
+                return nelec[0], excsum[0], vmat[0]
+            return nelec, excsum, vmat.reshape(shape)
         coords_dev, weights_dev = self._grid_tables(grids, dev)
         ngrids = grids.size
         ldao = _round_up(nao, 16)
@@ -289,7 +426,7 @@ class NumInt:
                                _c.c_int(nocc_pad), _ptr(cmo), _c.c_long(blk),
                                _ptr(kmask) if screen else _c.c_void_p(0), st)
                     self._call('rho', lib.PAMD_rho_from_mo, _ptr(cmo), _c.c_long(nocc_pad * blk), _c.c_long(blk),
-                               _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho), _c.c_long(blk), st)
+                               _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho), _c.c_long(blk), _c.c_void_p(0), st)
                 else:
                     # c0t[mu][g] = sum_nu D[nu][mu] ao0[g][nu]
                     self._call('dm_dot_ao', lib.PAMD_cderi_solve, _ptr(dsym), _c.c_int(ldd), _ptr(ao[0]),
@@ -722,6 +859,11 @@ class NumInt:
         mo_coeff = getattr(dms, 'mo_coeff', None)
         mo_occ = getattr(dms, 'mo_occ', None)
         use_mo = mo_coeff is not None and np.ndim(mo_occ) == 2
+        if self.sparse:
+            ops = [self._orbital_operand(dms_arr[s], np.asarray(mo_coeff[s]) if use_mo else None,
+                                         np.asarray(mo_occ[s]) if use_mo else None, nao, dev) for s in range(2)]
+            a, v = self._sparse_xc(mol, grids, fac, gga, ops, 1)
+            return a[:2].copy(), float(a[2]), v
         coords_dev, weights_dev = self._grid_tables(grids, dev)
         ngrids = grids.size
         ldao = _round_up(nao, 16)
@@ -779,7 +921,8 @@ class NumInt:
                                _c.c_int(nocc_pad), _ptr(cmo), _c.c_long(blk),
                                _ptr(kmask) if screen else _c.c_void_p(0), st)
                     self._call('rho', lib.PAMD_rho_from_mo, _ptr(cmo), _c.c_long(nocc_pad * blk), _c.c_long(blk),
-                               _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho[s]), _c.c_long(blk), st)
+                               _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(ng), _ptr(rho[s]), _c.c_long(blk), _c.c_void_p(0),
+                               st)
                 else:
                     dsym, ldd, c0t = ops[s]
                     self._call('dm_dot_ao', lib.PAMD_cderi_solve, _ptr(dsym), _c.c_int(ldd), _ptr(ao[0]),

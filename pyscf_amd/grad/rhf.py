@@ -39,7 +39,7 @@ def grad_nuc(mol, atmlst=None):
     g = np.zeros((natm, 3))
     for i in range(natm):
         for j in range(natm):
-            if i != j:
+            if i != j and z[i] != 0 and z[j] != 0:      # ghost atoms may sit on top of real ones (cf. energy_nuc)
                 d = r[i] - r[j]
                 g[i] -= z[i] * z[j] * d / np.linalg.norm(d) ** 3
     return g if atmlst is None else g[atmlst]
@@ -104,7 +104,7 @@ def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale=1.0):
             X = torch.zeros((nb, nocc_pad, ldx), dtype=f64, device=dev)
             df_jk._call(dfobj, 'e2_symm', so.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
                         _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
-                        _c.c_int(ldx), _c.c_void_p(0), st)
+                        _c.c_int(ldx), _c.c_void_p(0), _c.c_void_p(0), st)
             y = torch.matmul(X[:, :nocc, :nao], c_dev)           # y_L,ij = (C^T B_L C)_ij
             ys[b0:b0 + nb] = y.reshape(nb, -1)
             cyc = torch.matmul(c_dev, torch.matmul(y, c_dev.T))  # C y_L C^T
@@ -202,9 +202,11 @@ def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_respo
     d_dev = torch.from_numpy(np.ascontiguousarray(dm_tot)).to(dev)
     z_nuc = _pack_tril_dev(d_dev)[:, None].expand(-1, natm).contiguous()
     eng._omega_override = 0.0
-    for pc in eng.pair_classes():
-        eng.grad_launch(pc, ac, z_nuc, natm, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, True)
-    del eng._omega_override
+    try:
+        for pc in eng.pair_classes():
+            eng.grad_launch(pc, ac, z_nuc, natm, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, True)
+    finally:
+        del eng._omega_override
     _dbg('nuc done')
     g = grad.sum(dim=0)
     # (4) kinetic and overlap (energy-weighted density)

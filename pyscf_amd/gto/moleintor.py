@@ -424,22 +424,38 @@ class _PairClass2c(_PairClass):
 _ENGINE_CACHE = {}
 
 
+def mol_fingerprint(mol):
+    """Content key of a molecule's integral tables (_atm, _bas, _env): caches keyed on it survive neither an in-place
+    ``mol.build(atom=...)`` nor the reuse of an ``id()`` by a new object."""
+    import hashlib
+    if mol is None:
+        return None
+    h = hashlib.sha1()
+    for a in (mol._atm, mol._bas, mol._env):
+        a = np.ascontiguousarray(a)
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
 def get_engine(mol, auxmol, device, omega=0.0):
-    """IntEngine cached per (mol, auxmol, device, omega): the shell-pair tables are the expensive host part."""
+    """IntEngine cached per (mol tables, auxmol tables, device, omega): the shell-pair tables are the expensive host part.
+    The key is the content of the integral tables, not the object identity."""
     import torch
-    key = (id(mol), id(auxmol) if auxmol is not None else None, str(torch.device(device)) + '|%.6f' % omega)
-    ent = _ENGINE_CACHE.get(key)
-    if ent is not None and ent[0] is mol and ent[1] is auxmol:
-        return ent[2]
+    devkey = str(torch.device(device))
+    key = (mol_fingerprint(mol), mol_fingerprint(auxmol), devkey + '|%.6f' % omega)
+    eng = _ENGINE_CACHE.get(key)
+    if eng is not None:
+        return eng
     # an engine built for the same mol with another aux basis can lend its AO pair tables
     eng = IntEngine(mol, auxmol, device, omega)
-    for (k0, k1, k2), (m, a, e) in list(_ENGINE_CACHE.items()):
-        if m is mol and k2.split('|')[0] == key[2].split('|')[0] and e._pair_classes is not None:
+    for (k0, k1, k2), e in list(_ENGINE_CACHE.items()):
+        if k0 == key[0] and k2.split('|')[0] == devkey and e._pair_classes is not None:
             eng._pair_classes = e._pair_classes
             break
     if len(_ENGINE_CACHE) > 8:
         _ENGINE_CACHE.clear()
-    _ENGINE_CACHE[key] = (mol, auxmol, eng)
+    _ENGINE_CACHE[key] = eng
     return eng
 
 

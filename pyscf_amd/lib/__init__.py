@@ -38,6 +38,7 @@ def load_library(name='libpyscf_amd'):
     lib = ctypes.CDLL(so)
     lib.PAMD_last_error.restype = ctypes.c_char_p
     lib.PAMD_df_vj_pass1_worksize.restype = ctypes.c_long
+    lib.PAMD_nr_e2_rho_worksize.restype = ctypes.c_long
     _lib = lib
     return lib
 

@@ -116,6 +116,14 @@ def kernel(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, callback=None, conv
         mf_diis.Corth = x_orth
     mf.cycles = 0
     fock = None
+    if mf.max_cycle <= 0:
+        # pyscf/scf/hf.py:150-156: no iteration requested - one eig / get_occ on the initial Fock matrix,
+        # the initial-guess energy is returned
+        fock = mf.get_fock(h1e, s1e, vhf, dm)
+        mo_energy, mo_coeff = mf.eig(fock, s1e, x=x_orth)
+        mo_occ = mf.get_occ(mo_energy, mo_coeff)
+        return scf_conv, e_tot, mo_energy, mo_coeff, mo_occ
+    cycle = -1
     for cycle in range(mf.max_cycle):
         t0 = time.perf_counter()
         dm_last = dm
@@ -182,6 +190,22 @@ class SCF:
     def _log(self, fmt, *args):
         if self.verbose >= 4:
             print(fmt % args, file=self.stdout)
+
+    def reset(self, mol=None):
+        """pyscf/scf/hf.py:2060-2070 (+ _DFHF.reset, df_jk.py:124-127; KohnShamDFT.reset, dft/rks.py:409-415): drop
+        everything derived from the old molecule - cached one-electron integrals, the DF tensor, the grids."""
+        if mol is not None:
+            self.mol = mol
+        self._int1e = None
+        if self.with_df is not None:
+            self.with_df.reset(mol)
+        grids = getattr(self, 'grids', None)
+        if grids is not None:
+            grids.reset(mol)
+        ni = getattr(self, '_numint', None)
+        if ni is not None and hasattr(ni, 'reset'):
+            ni.reset()
+        return self
 
     # -- one-electron part (device integral engine) ----------------------------------------
     def _get_int1e(self):
@@ -451,9 +475,11 @@ def int1e_gpu(mol, device=None):
     npair = nao * (nao + 1) // 2
     V3 = torch.zeros((npair, natm), dtype=torch.float64, device=device)
     eng._omega_override = 0.0            # nuclear attraction is always the bare Coulomb operator
-    for pc in eng.pair_classes():
-        eng._launch(pc, 0, pc.n, ac, V3, natm, 0, 1, eng.ao_xyz, eng.ao_ao0)
-    del eng._omega_override
+    try:
+        for pc in eng.pair_classes():
+            eng._launch(pc, 0, pc.n, ac, V3, natm, 0, 1, eng.ao_xyz, eng.ao_ao0)
+    finally:
+        del eng._omega_override
     vtril = V3.sum(dim=1).cpu().numpy()
     V = _lib_mod.unpack_tril(vtril, 1)
     return S.cpu().numpy(), T.cpu().numpy(), V

@@ -1,0 +1,40 @@
+"""bench.py starts its own ranks: `python bench.py --gpus 2` must produce an n_gpus = 2 line whose ranks hold disjoint
+aux-row shards (two ranks share the one device of the test box through gloo; on a multi-GPU node the same launch uses
+RCCL, one device per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--nwater', '8', '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline', '--xc', ''] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    return json.loads(line)
+
+
+def test_bench_gpus2_launches_two_ranks():
+    one = _run(['--gpus', '1'])
+    two = _run(['--gpus', '2', '--backend', 'gloo'])
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2
+    rows = two['config']['naux_per_rank']
+    assert len(rows) == 2 and sum(rows) == one['config']['naux_per_rank'][0] and abs(rows[0] - rows[1]) <= 1
+    assert two['config']['naux_local'] == rows[0]
+    assert two['value'] > 0 and two['value_host_api_ms'] >= two['value'] * 0.5
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--nwater', '2'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and 'WORLD_SIZE' in (out.stderr + out.stdout)

@@ -172,8 +172,10 @@ def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
     ldx = rows
     x = torch.zeros((naux, nocc_pad, ldx), dtype=torch.float64, device=dev)
     rho = torch.zeros(naux, dtype=torch.float64, device=dev)
+    so.PAMD_nr_e2_rho_worksize.restype = C.c_long
+    work = torch.zeros(so.PAMD_nr_e2_rho_worksize(naux, ldx, nocc_pad), dtype=torch.float64, device=dev)
     lib.check(so.PAMD_nr_e2_square(_p(sq), C.c_long(rows), rows, naux, nao, _p(orb), ldo, orb.shape[0], nocc_pad,
-                                   _p(x), ldx, _p(rho), st))
+                                   _p(x), ldx, _p(rho), _p(work), st))
     want = np.einsum('Lpq,qi->Lip', full, c)
     got = x[:, :nocc, :nao].cpu().numpy()
     assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
@@ -182,5 +184,16 @@ def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
     # without the fused pass (d_rho = NULL) the transform itself is unchanged
     x2 = torch.zeros_like(x)
     lib.check(so.PAMD_nr_e2_square(_p(sq), C.c_long(rows), rows, naux, nao, _p(orb), ldo, orb.shape[0], nocc_pad,
-                                   _p(x2), ldx, C.c_void_p(0), st))
+                                   _p(x2), ldx, C.c_void_p(0), C.c_void_p(0), st))
     assert torch.equal(x, x2)
+    # the fused pass is deterministic (per-wave partials + fixed-order reduction, no FP atomics): bitwise repeatable,
+    # also through the packed-operand kernel
+    for fn, args in ((so.PAMD_nr_e2_square, (_p(sq), C.c_long(rows), rows, naux, nao)),
+                     (so.PAMD_nr_e2_symm, (_p(t_tril), C.c_long(npair), naux, nao))):
+        runs = []
+        for _ in range(3):
+            r = torch.zeros(naux, dtype=torch.float64, device=dev)
+            lib.check(fn(*args, _p(orb), ldo, orb.shape[0], nocc_pad, _p(x2), ldx, _p(r), _p(work), st))
+            runs.append(r.clone())
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+        assert np.abs(runs[0].cpu().numpy() - rho_want).max() < 1e-10 * np.abs(rho_want).max()

@@ -312,3 +312,41 @@ def test_rohf_driver_reference_energies():
     assert mf.converged and abs(e - -75.627354109594179) < 1e-9, e
     mf = _oracle_rohf(gto.M(atom='H', basis='sto-3g', spin=1))
     assert abs(mf.kernel() - -0.46658184955727555) < 1e-12
+
+
+def test_max_cycle_zero_returns_the_initial_guess_energy():
+    """pyscf/scf/hf.py:150-156: max_cycle <= 0 does one eig / get_occ on the initial Fock matrix and returns the
+    initial-guess energy (used to crash with UnboundLocalError)."""
+    from pyscf_amd import gto
+    from tests.conftest import H2O
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    mf = _oracle_rhf(mol)
+    mf.max_cycle = 0
+    e = mf.kernel()
+    assert not mf.converged and mf.mo_coeff is not None and mf.mo_occ.sum() == mol.nelectron
+    dm0 = mf.get_init_guess(mol, '1e')
+    assert abs(e - mf.energy_tot(dm0, mf.get_hcore(), mf.get_veff(mol, dm0))) < 1e-12
+
+
+def test_scf_reset_drops_cached_integrals():
+    """SCF.reset(mol) (pyscf/scf/hf.py:2060-2070): cached one-electron integrals do not survive a new molecule."""
+    from pyscf_amd import gto
+    from tests.conftest import H2O
+    mf = _oracle_rhf(gto.M(atom=H2O, basis='sto-3g'))
+    s_a = mf.get_ovlp().copy()
+    mol_b = gto.M(atom='O 0 0 0; H 0 -0.9 0.6; H 0 0.9 0.6', basis='sto-3g')
+    mf.with_df = None
+    mf.reset(mol_b)
+    s_b = mf.get_ovlp()
+    assert s_a.shape == s_b.shape and np.abs(s_a - s_b).max() > 1e-3
+
+
+def test_grad_nuc_with_ghost_atom_on_a_nucleus():
+    """A ghost atom on top of a real one has zero charge: no 0 * d / 0 in the nuclear repulsion gradient."""
+    from pyscf_amd import gto
+    from pyscf_amd.grad import rhf as grad_rhf
+    mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587; ghost:H 0 0 0', basis='sto-3g')
+    g = grad_rhf.grad_nuc(mol)
+    assert np.all(np.isfinite(g)) and np.abs(g[3]).max() == 0
+    ref_mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis='sto-3g')
+    assert np.abs(g[:3] - grad_rhf.grad_nuc(ref_mol)).max() < 1e-14

@@ -1,0 +1,174 @@
+"""Golden vectors at the BASELINE target size, computed by the CPU oracle alone (no GPU, no product code on the
+numerical path): (H2O)_n cc-pVTZ / cc-pvtz-jkfit
+
+  * the oracle's own Cholesky-decomposed tensor (McMurchie-Davidson integrals, oracle/cint_oracle.c), streamed to a
+    scratch file column slab by column slab (pyscf/df/incore.py:129-220),
+  * J/K of a seeded synthetic density (oracle/golden_util.synthetic_orbitals) -> fingerprints + 4096 sampled entries,
+  * the converged DF-RHF energy (oracle/ref.rhf_kernel, CDIIS, conv_tol 1e-10),
+  * optionally the converged DF-RKS energy (oracle/ref_dft, sympy functionals; grid blocks of 8192 points).
+
+    python tools/gen_golden_fullsize.py --nwater 32 --scratch /tmp/oracle_h2o32 [--rks b3lyp --dm0 dm.npy]
+
+Writes tests/golden/h2o<n>_ccpvtz_oracle.json.  (H2O)_32: 61 GB scratch file, about an hour on 8 cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.linalg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref, golden_util          # noqa: E402
+from pyscf_amd import gto                     # noqa: E402  (host-only: molecule tables, basis data)
+from pyscf_amd.data import clusters           # noqa: E402
+from pyscf_amd.df import addons               # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--nwater', type=int, default=32)
+ap.add_argument('--basis', default='cc-pvtz')
+ap.add_argument('--scratch', default='/tmp/oracle_golden')
+ap.add_argument('--slab-bytes', type=float, default=3e9)
+ap.add_argument('--skip-scf', action='store_true')
+ap.add_argument('--rks', default='', help="also converge DF-RKS with this functional (e.g. b3lyp)")
+ap.add_argument('--dm0', default='', help='.npy start density for the SCF runs (any source: the converged energy does not '
+                'depend on it beyond conv_tol)')
+ap.add_argument('--conv-tol', type=float, default=1e-10)
+a = ap.parse_args()
+os.makedirs(a.scratch, exist_ok=True)
+t00 = time.time()
+
+
+def log(*args):
+    print('[%7.1fs]' % (time.time() - t00), *args, flush=True)
+
+
+mol = gto.M(atom=clusters.water_cluster(a.nwater), basis=a.basis)
+auxmol = addons.make_auxmol(mol, None)
+nao, naux = mol.nao, auxmol.nao_nr()
+npair = nao * (nao + 1) // 2
+nocc = mol.nelectron // 2
+tag = 'h2o%d_%s' % (a.nwater, a.basis.replace('-', ''))
+out_json = os.path.join(ROOT, 'tests', 'golden', tag + '_oracle.json')
+res = json.load(open(out_json)) if os.path.exists(out_json) else {}
+res.update({'system': '(H2O)_%d %s / cc-pvtz-jkfit (pyscf_amd.data.clusters.water_cluster)' % (a.nwater, a.basis),
+            'nao': nao, 'naux': naux, 'nocc': nocc,
+            'generator': 'tools/gen_golden_fullsize.py (CPU oracle only)'})
+log('nao', nao, 'naux', naux, 'npair', npair, 'tensor GB', 8e-9 * naux * npair)
+
+
+def save():
+    with open(out_json, 'w') as f:
+        json.dump(res, f, indent=1)
+
+
+# ---------------------------------------------------------------------------------------------- tensor
+cd_path = os.path.join(a.scratch, tag + '_cderi.dat')
+done_flag = cd_path + '.done'
+if not os.path.exists(done_flag):
+    j2c = ref.int2c2e(auxmol)
+    low = scipy.linalg.cholesky(j2c, lower=True)
+    res['j2c_fp'] = golden_util.fp(j2c)
+    cderi = np.memmap(cd_path, dtype=np.float64, mode='w+', shape=(naux, npair))
+    loc = ref.ao_loc(mol)
+    ish0 = 0
+    while ish0 < mol.nbas:
+        ish1 = ish0 + 1
+        def ncol(s0, s1):
+            return loc[s1] * (loc[s1] + 1) // 2 - loc[s0] * (loc[s0] + 1) // 2
+        while ish1 < mol.nbas and ncol(ish0, ish1 + 1) * naux * 8 <= a.slab_bytes:
+            ish1 += 1
+        slab = ref.int3c2e_slab(mol, auxmol, ish0, ish1)
+        slab = scipy.linalg.solve_triangular(low, slab, lower=True, overwrite_b=True, check_finite=False)
+        pq0 = loc[ish0] * (loc[ish0] + 1) // 2
+        cderi[:, pq0:pq0 + slab.shape[1]] = slab
+        log('slab shells [%d,%d) cols %d' % (ish0, ish1, slab.shape[1]))
+        ish0 = ish1
+    cderi.flush()
+    del cderi
+    open(done_flag, 'w').write('ok')
+    save()
+cderi = np.memmap(cd_path, dtype=np.float64, mode='r', shape=(naux, npair))
+log('tensor ready')
+
+# ---------------------------------------------------------------------------------------------- J/K sample
+if 'vj_fp' not in res:
+    c = golden_util.synthetic_orbitals(nao, nocc)
+    occ = np.full(nocc, 2.0)
+    dm = 2 * c.dot(c.T)
+    vj, vk, _ = ref.get_jk_rows_parallel(cderi, dm, c, occ)
+    ri, ci = golden_util.sample_positions(nao, 4096)
+    res.update({'jk_density': 'D = 2 C C^T, C = oracle.golden_util.synthetic_orbitals(nao, nocc, seed=7)',
+                'vj_fp': golden_util.fp(vj), 'vk_fp': golden_util.fp(vk),
+                'vj_norm': float(np.linalg.norm(vj)), 'vk_norm': float(np.linalg.norm(vk)),
+                'vj_absmax': float(abs(vj).max()), 'vk_absmax': float(abs(vk).max()),
+                'tr_d_vj': float(np.einsum('ij,ji', dm, vj)), 'tr_d_vk': float(np.einsum('ij,ji', dm, vk)),
+                'sample_seed': 11, 'vj_sample': [float(v) for v in vj[ri, ci]],
+                'vk_sample': [float(v) for v in vk[ri, ci]]})
+    save()
+    log('J/K golden written: fp(vj) %.12f fp(vk) %.12f' % (res['vj_fp'], res['vk_fp']))
+
+if a.skip_scf:
+    sys.exit(0)
+
+# ---------------------------------------------------------------------------------------------- SCF energies
+h1e = ref.int1e(mol, 'kin') + ref.int1e(mol, 'nuc')
+s1e = ref.int1e(mol, 'ovlp')
+dm0 = np.load(a.dm0) if a.dm0 else None
+
+
+def jk(dm, c, occ, with_k=True):
+    if c is None:                      # start density without orbitals: factorise (D is symmetric positive here)
+        w, v = np.linalg.eigh((dm + dm.T) * .5)
+        keep = w > 1e-12
+        c, occ = v[:, keep], w[keep]
+    t = time.time()
+    vj, vk, _ = ref.get_jk_rows_parallel(cderi, dm, c, occ)
+    log('  J/K %.1f s' % (time.time() - t))
+    return vj, vk
+
+
+if 'e_rhf' not in res:
+    conv, e, mo_e, mo_c, mo_occ, dm = ref.rhf_kernel(mol, lambda d, c, o: (lambda v: v[0] - .5 * v[1])(jk(d, c, o)),
+                                                     conv_tol=a.conv_tol, dm0=dm0, h1e=h1e, s1e=s1e, verbose=True)
+    assert conv
+    res['e_rhf'] = float(e)
+    res['e_rhf_note'] = 'DF-RHF, oracle/ref.rhf_kernel, conv_tol %g' % a.conv_tol
+    np.save(os.path.join(a.scratch, tag + '_rhf_dm.npy'), dm)
+    save()
+    log('E(DF-RHF) = %.12f' % e)
+
+if a.rks and ('e_rks_' + a.rks) not in res:
+    from oracle import ref_dft
+    from pyscf_amd.dft import libxc
+    hyb, fac = libxc.parse_xc(a.rks)
+    gga = libxc.xc_type(a.rks) == 'GGA'
+    t = time.time()
+    coords, weights = ref_dft.build_grids(mol)[:2]
+    log('grids', len(weights), '%.1f s' % (time.time() - t))
+
+    dense_nr_rks = ref_dft.nr_rks
+
+    def nr_rks_blocked(dm, blk=8192):
+        """the dense oracle nr_rks summed over grid blocks (nelec, exc and vmat are additive over grid points)"""
+        t = time.time()
+        n = e = 0.0
+        v = np.zeros((nao, nao))
+        for g0 in range(0, len(weights), blk):
+            nb, eb, vb = dense_nr_rks(mol, coords[g0:g0 + blk], weights[g0:g0 + blk], fac, gga, dm)
+            n += nb
+            e += eb
+            v += vb
+        log('  nr_rks %.1f s nelec %.8f' % (time.time() - t, n))
+        return n, e, v
+    ref_dft.nr_rks = lambda m, c_, w_, f_, g_, dm: nr_rks_blocked(dm)       # rks_energy calls nr_rks(mol, coords, ...)
+    start = dm0 if dm0 is not None else np.load(os.path.join(a.scratch, tag + '_rhf_dm.npy'))
+    e = ref_dft.rks_energy(mol, fac, hyb, gga, coords, weights, lambda d, c, o, wk: jk(d, c, o), conv_tol=a.conv_tol,
+                           verbose=True, dm0=start, h1e=h1e, s1e=s1e)[1]
+    res['e_rks_' + a.rks] = float(e)
+    res['ngrids'] = int(len(weights))
+    save()
+    log('E(DF-RKS %s) = %.12f' % (a.rks, e))

@@ -16,6 +16,8 @@ ap.add_argument('--xc', default='b3lyp')
 ap.add_argument('--steps', type=int, default=2)
 ap.add_argument('--nsplit', type=int, default=0)
 ap.add_argument('--dense', action='store_true')
+ap.add_argument('--tile', type=int, default=0)
+ap.add_argument('--cutoff', type=float, default=0)
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 mol = gto.M(atom=clusters.water_cluster(a.nwater), basis=a.basis)
@@ -32,7 +34,9 @@ occ = np.zeros(nao); occ[:nocc] = 2
 dm = lib.tag_array((c[:, :nocc] * 2).dot(c[:, :nocc].T), mo_coeff=c, mo_occ=occ)
 ni = dft.NumInt()
 if a.nsplit: ni.vmat_nsplit = a.nsplit
-if a.dense: ni.screen_cutoff = None
+if a.dense: ni.sparse = False
+if a.tile: ni.sparse_tile = a.tile
+if a.cutoff: ni.sparse_cutoff = a.cutoff
 n, e, vm = ni.nr_rks(mol, grids, a.xc, dm)
 torch.cuda.synchronize()
 ni.kernel_timer = df_jk.KernelTimer()
@@ -48,4 +52,10 @@ out = {'nsplit': a.nsplit, 'dense': a.dense, 'nao': nao, 'nocc': nocc, 'ngrids':
 ng = grids.size
 out['TF'] = {'ao_dot_mo': round(4 * 2.0 * ng * nao * ((nocc + 15) // 16 * 16) / (s['ao_dot_mo'][0] / a.steps) / 1e9, 1),
              'ao_dot_aow': round(2.0 * ng * nao * nao / (s['ao_dot_aow'][0] / a.steps) / 1e9, 1)}
+if ni.sparse:
+    plan = ni.sparse_plan(mol, grids, True)
+    out['plan'] = {'G': plan.G, 'tiles': plan.nloc, 'density': plan.density, 'density2': plan.density2,
+                   'compact_GB': plan.ao_total * 8e-9, 'cached': plan.ao_c is not None}
+    out['TF']['ao_dot_mo'] = round(out['TF']['ao_dot_mo'] * plan.density, 1)
+    out['TF']['ao_dot_aow'] = round(out['TF']['ao_dot_aow'] * plan.density2, 1)
 print(json.dumps(out))
