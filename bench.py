@@ -43,6 +43,7 @@ def main():
     ap.add_argument('--basis', default='cc-pvtz')
     ap.add_argument('--cpu-sample-rows', type=int, default=1200)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the CPU baseline (default: all host cores)')
     ap.add_argument('--xc', default='b3lyp', help="XC functional of the secondary nr_rks timing ('' to skip)")
     ap.add_argument('--backend', default=None, help="torch.distributed backend ('nccl' = RCCL; 'gloo' for the "
                     "single-device self-test where several ranks share one GPU)")
@@ -274,13 +275,14 @@ def main():
         from oracle import ref
         nrow = min(args.cpu_sample_rows, naux_local)
         sample = dfobj._cderi_dev[:nrow].cpu().numpy()
-        ncore = os.cpu_count()
+        ncore = args.cpu_threads or os.cpu_count()
         ref.get_jk_rows_parallel(sample[:min(nrow, 64)], dm, c, mo_occ, nthreads=ncore)      # warm the BLAS threads
         t0 = time.perf_counter()
         vj0, vk0, cpu_flops = ref.get_jk_rows_parallel(sample, dm, c, mo_occ, nthreads=ncore)
         cpu_s = time.perf_counter() - t0
         cpu = {'value': round(cpu_s / nrow * naux * 1e3, 1), 'unit': 'ms/iter (extrapolated to all %d aux rows)' % naux,
                'cores': ncore, 'kind': 'port', 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1),
+               'phases_s': getattr(ref.get_jk_rows_parallel, 'last_phases', None),
                'sample': 'oracle/ref.get_jk_rows_parallel (restatement of df_jk.py:329-381 parallelised like '
                          'AO2MOnr_e2_drv, nr_ao2mo.c:1253-1265: aux rows across %d threads, one single-threaded dsymm per '
                          'row, threaded dgemm for buf1^T buf1) on %d of %d aux rows of the GPU-built tensor: %.2f s'

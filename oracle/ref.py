@@ -227,16 +227,16 @@ def get_jk_rows_parallel(cderi, dm, mo_coeff, mo_occ, nthreads=None, blockdim=24
     products (df_jk.py:367) and the final ``lib.dot(buf1.T, buf1)`` (df_jk.py:380 -> NPdgemm) are multi-threaded BLAS.
     Returns (vj, vk, flops) for one closed-shell density."""
     import concurrent.futures
-    from scipy.linalg import blas
     from threadpoolctl import threadpool_limits
     dm = np.asarray(dm)
     nao = dm.shape[-1]
     mo_occ = np.asarray(mo_occ)
     orbo = np.asarray(mo_coeff)[:, mo_occ > 0] * np.sqrt(mo_occ[mo_occ > 0])
     nocc = orbo.shape[1]
-    orbo_f = np.asfortranarray(orbo)
+    orbo_t = np.ascontiguousarray(orbo.T)
     nthreads = nthreads or os.cpu_count()
     naux = cderi.shape[0]
+    blockdim = max(blockdim, nthreads)          # at least one row per thread in a block
     idx = np.arange(nao)
     dmtril = pack_tril(dm + dm.T)
     dmtril[idx * (idx + 1) // 2 + idx] *= .5
@@ -246,23 +246,37 @@ def get_jk_rows_parallel(cderi, dm, mo_coeff, mo_occ, nthreads=None, blockdim=24
     def rows(args):
         full, buf1, r0, r1 = args
         for r in range(r0, r1):
-            # C(nao, nocc) = B_L (symmetric) . orbo: Fortran dsymm, side = left; stored transposed as buf1[r] (nocc, nao)
-            buf1[r] = blas.dsymm(1.0, full[r].T, orbo_f, lower=0).T
+            # buf1[r] (nocc, nao) = orbo^T . B_L: the reference calls dsymm on the symmetric B_L (nr_ao2mo.c:399-419); the
+            # same product and flop count through numpy's dgemm, which - unlike scipy's f2py BLAS wrappers - releases the
+            # GIL, so the worker threads really run side by side
+            np.dot(orbo_t, full[r], out=buf1[r])
         return r1 - r0
 
+    import time
+    tm = {'j': 0.0, 'unpack': 0.0, 'dsymm': 0.0, 'dgemm': 0.0}
     with concurrent.futures.ThreadPoolExecutor(nthreads) as pool:
         for b0 in range(0, naux, blockdim):
             eri1 = np.ascontiguousarray(cderi[b0:b0 + blockdim])
             nb = eri1.shape[0]
+            t0 = time.perf_counter()
             vj += dmtril.dot(eri1.T).dot(eri1)                       # threaded BLAS
+            t1 = time.perf_counter()
             full = unpack_tril(eri1)                                  # C, OpenMP over the rows (NPdunpack_tril per row)
+            t2 = time.perf_counter()
             buf1 = np.empty((nb, nocc, nao))
             per = max(1, -(-nb // nthreads))
             with threadpool_limits(limits=1, user_api='blas'):
                 list(pool.map(rows, [(full, buf1, r, min(r + per, nb)) for r in range(0, nb, per)]))
+            t3 = time.perf_counter()
             b2 = buf1.reshape(-1, nao)
             vk += b2.T.dot(b2)                                        # threaded dgemm (lib.dot, df_jk.py:380)
+            t4 = time.perf_counter()
+            tm['j'] += t1 - t0
+            tm['unpack'] += t2 - t1
+            tm['dsymm'] += t3 - t2
+            tm['dgemm'] += t4 - t3
     flops = 2.0 * naux * nao * nao * nocc * 2 + 4.0 * naux * cderi.shape[1]
+    get_jk_rows_parallel.last_phases = {k: round(v, 3) for k, v in tm.items()}
     return unpack_tril(vj[None], 1)[0], vk, flops
 
 

@@ -475,6 +475,210 @@ __global__ __launch_bounds__(256, 2) void e2_sq_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// v2 of the two LDS-DMA MFMA kernels (r02).  What the ISA of v1 showed: every global_load_lds carried ~9 VALU/SALU
+// instructions of 64-bit address arithmetic (per-lane pointers), all 12 (8) of them issued in one burst right after the
+// barrier, so each wave spent ~115 issue slots plus an exposed first ds_read latency before its first MFMA of a k-tile.
+// v2: (i) the wave index is made uniform (readfirstlane) and the panels are addressed through buffer resources - row
+// offset in an SGPR (soffset), lane offset in one loop-invariant VGPR - so a DMA is `s_mov m0; s_add; buffer_load ... lds`,
+// no VALU; (ii) the DMA rows of tile t+1 are issued one per k-group BETWEEN the MFMA groups of tile t (the matrix pipe
+// has free issue slots there), not in a burst before them.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const double *p)
+{
+    // raw buffer, stride 0, 4 GiB window from p (every panel of one workgroup lies inside: checked by the launchers)
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 0xffffffff, 0x00020000);
+}
+
+__device__ __forceinline__ void dma_row(__amdgpu_buffer_rsrc_t r, double *lds_dst, int voff_bytes, int soff_bytes)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
+}
+
+// Half transform on the square image, 160 orbitals x 128 AOs per workgroup (the WA = 5 shape of e2_sq_kernel).
+// LDS image of a k-tile: orbital columns 0..127 as [16][144] rows (one full 1 KiB DMA each), orbital columns 128..159 of
+// all 16 rows as one contiguous [16][32] block - each wave fetches the remainders of its 4 rows with ONE DMA whose
+// per-lane source addresses pick (row, column pair), odd rows rotated by 16 doubles so that the two 16-lane halves of a
+// fragment read hit different banks - and the tensor panel as [16][144].  9 DMAs per wave and k-tile (v1: 12, four of
+// them exec-masked), no branch inside the k-tile body, so the compiler keeps prefetching the fragments of k-group
+// g+1 under the MFMAs of group g.  Wave (wr, wc) owns orbital tiles {64 wr + 16 a, a < 4} and {128 + 16 wr}.
+template <bool RHO>
+__global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
+    const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
+    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk)
+{
+    constexpr int M = 160;
+    __shared__ double sa0[KB * LDN + KB * 32];
+    __shared__ double sa1[KB * LDN + KB * 32];
+    __shared__ double sq0[KB * LDN];
+    __shared__ double sq1[KB * LDN];
+    constexpr int RB = KB * LDN;                         // start of the remainder block inside sa*
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p0 = (blockIdx.x / nchunk) * NT;
+    const long L = blockIdx.y;
+    const int m0 = (blockIdx.x % nchunk) * M;
+    const __amdgpu_buffer_rsrc_t r_sq = make_rsrc(sq + L * lstride + p0);
+    const __amdgpu_buffer_rsrc_t r_orb = make_rsrc(orb + m0);
+    const int ldb8 = (int)ld * 8, ldo8 = ldo * 8;
+    const int voff = lane * 16;
+    // remainder DMA: lane -> LDS doubles [2 lane, 2 lane + 1] of the wave's 4 x 32 block = row (lane >> 4), rotated column
+    const int rrow = lane >> 4;
+    const int voff_rem = rrow * ldo8 + (128 + ((((lane & 15) * 2) - 16 * (rrow & 1)) & 31)) * 8;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+    const int offa = fk * LDN + wr * 64 + fn;                                   // + kk * LDN + 16 a
+    const int offr = RB + fk * 32 + ((wr * 16 + fn + 16 * (fk & 1)) & 31);        // + kk * 32
+    const int offb = fk * LDN + wc * 64 + fn;                                   // + kk * LDN + 16 b
+
+    double4_t acc[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    auto stage_row = [&](int k0, double *da, double *db, int j) {
+        const int k = wave * 4 + j;
+        dma_row(r_orb, da + k * LDN, voff, (k0 + k) * ldo8);
+        dma_row(r_sq, db + k * LDN, voff, (k0 + k) * ldb8);
+        if (j == 0) dma_row(r_orb, da + RB + wave * 128, voff_rem, (k0 + wave * 4) * ldo8);
+    };
+    auto step = [&](const double *ca, const double *cb, double *na, double *nb, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // last k-tile: a harmless reload of the current tile into the idle buffer keeps the body branch-free
+        const int kn = (k0 + KB < kdim) ? k0 + KB : k0;
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[5], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
+            af[4] = ca[offr + kk * 32];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = cb[offb + kk * LDN + b * 16];
+            stage_row(kn, na, nb, kk >> 2);
+#pragma unroll
+            for (int a = 0; a < 5; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
+    for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
+        step(sa0, sq0, sa1, sq1, k0);
+        if (k0 + KB < kdim) step(sa1, sq1, sa0, sq0, k0 + KB);
+    }
+    double *out = X + L * nocc_pad * ldx;
+    double rho_acc = 0;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const long p = p0 + wc * 64 + b * 16 + fn;
+            if (p >= ldx) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = m0 + (a < 4 ? wr * 64 + a * 16 : 128 + wr * 16) + fk + 4 * r;
+                if (i < nocc_pad) {
+                    out[(long)i * ldx + p] = acc[a][b][r];
+                    if (RHO) rho_acc += acc[a][b][r] * orb[p * ldo + i];
+                }
+            }
+        }
+    if (RHO) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rho_acc += __shfl_xor(rho_acc, off, 64);
+        if (lane == 0) rho[(L * gridDim.x + blockIdx.x) * 4 + wave] = rho_acc;
+    }
+}
+
+// 128 x 128 tile of C[split] += A^T B (all tiles, or the lower-triangular ones of the SYRK), v2 DMA scheme
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
+    const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
+    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, int nsplit)
+{
+    const int bsplit = blockIdx.y, btile = blockIdx.x;
+    constexpr int PA = KB * LDN;
+    __shared__ double sb0[2 * PA];
+    __shared__ double sb1[2 * PA];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    if (lower_only) {
+        int t = btile;
+        tm = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
+        while (tm * (tm + 1) / 2 > t) tm--;
+        tn = t - tm * (tm + 1) / 2;
+    } else {
+        tm = btile / ntile_n;
+        tn = btile - tm * ntile_n;
+    }
+    const int p0 = tm * NT, q0 = tn * NT;
+    const long kchunk = ((kdim + nsplit - 1) / nsplit + KB - 1) / KB * KB;
+    const long kbeg = (long)bsplit * kchunk;
+    const long kend = (kbeg + kchunk < kdim) ? kbeg + kchunk : kdim;
+    const int nk = (int)(kend - kbeg);                 // rows of this split: row offsets stay below 4 GiB (launcher)
+    const __amdgpu_buffer_rsrc_t r_a = make_rsrc(A + kbeg * lda + p0);
+    const __amdgpu_buffer_rsrc_t r_b = make_rsrc(B + kbeg * ldb + q0);
+    const int voff = lane * 16;
+    const int lda8 = lda * 8, ldb8 = ldb * 8;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+    const int offa = fk * LDN + wr * 64 + fn, offb = PA + fk * LDN + wc * 64 + fn;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    auto stage_row = [&](int k0, double *dst, int j) {
+        const int k = wave * 4 + j;
+        dma_row(r_a, dst + k * LDN, voff, (k0 + k) * lda8);
+        dma_row(r_b, dst + PA + k * LDN, voff, (k0 + k) * ldb8);
+    };
+    auto step = [&](const double *cur, double *nxt, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kn = (k0 + KB < nk) ? k0 + KB : k0;
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = cur[offa + kk * LDN + a * 16];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = cur[offb + kk * LDN + b * 16];
+            stage_row(kn, nxt, kk >> 2);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+    };
+    if (nk > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) stage_row(0, sb0, j);
+    }
+    for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
+        step(sb0, sb1, k0);
+        if (k0 + KB < nk) step(sb1, sb0, k0 + KB);
+    }
+    double *out = C + (long)bsplit * m * ldc;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int col = q0 + wc * 64 + b * 16 + fn;
+            if (col >= n) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int rowi = p0 + wr * 64 + a * 16 + fk + 4 * r;
+                if (rowi < m) unsafeAtomicAdd(out + (long)rowi * ldc + col, acc[a][b][r]);
+            }
+        }
+}
+
 // flag[rt][ct] = max |src[16 rt .. 16 rt + 15][16 ct .. 16 ct + 15]| > thr   (rows >= nrows count as zero)
 __global__ __launch_bounds__(256) void tile_mask_kernel(const double *__restrict__ src, long ld, long nrows, double thr,
                                                         unsigned char *__restrict__ out, int nct)
@@ -542,6 +746,7 @@ __global__ void pack_dm_kernel(const double *__restrict__ dm, int nao, double *_
 static int g_use_glds = 1;
 static int g_gemm_wide = 1;
 static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper bound
+static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
 
 extern "C" {
 
@@ -550,6 +755,7 @@ int PAMD_set_tuning(const char *key, int value)
 {
     if (strcmp(key, "glds") == 0) { g_use_glds = value; return 0; }
     if (strcmp(key, "gemmwide") == 0) { g_gemm_wide = value; return 0; }
+    if (strcmp(key, "dmav2") == 0) { g_dma_v2 = value; return 0; }
     if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
 }
@@ -675,9 +881,17 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
     const int wa = ceil_div(ceil_div(mt_total, nchunk), 2);   // MFMA tiles per wave row; workgroup covers 2 wa tiles
     PAMD_REQUIRE(ldo >= nchunk * wa * 32, "orbital leading dimension too small for tile padding");
     dim3 grid(ceil_div(ldx, NT) * nchunk, nL);
+    PAMD_REQUIRE((long)rows * ld * 8 < (1L << 32) && (long)orb_rows * ldo * 8 < (1L << 32), "panel offsets exceed 32 bits");
 #define LAUNCH_SQ(W)                                                                                            \
     do {                                                                                                        \
-        if (d_rho)                                                                                              \
+        if (g_dma_v2 && W == 5) {                                                                               \
+            if (d_rho)                                                                                          \
+                e2_sq2_kernel<true><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
+                                                          ldx, d_rho_work, nchunk);                              \
+            else                                                                                                \
+                e2_sq2_kernel<false><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
+                                                           ldx, nullptr, nchunk);                                \
+        } else if (d_rho)                                                                                       \
             e2_sq_kernel<W, true><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
                                                         ldx, d_rho_work, nchunk);                                \
         else                                                                                                    \
@@ -755,7 +969,11 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
     int tm = ceil_div(m, tile_m), tn = ceil_div(n, NT);
     int ntiles = (lower_only & 1) ? tm * (tm + 1) / 2 : tm * tn;
     dim3 grid(ntiles, nsplit);
-    if (glds)
+    const bool v2 = glds && g_dma_v2 && !wide && d_maskA == nullptr &&
+                    (kchunk + KB) * (long)((lda > ldb) ? lda : ldb) * 8 < (1L << 32);
+    if (v2)
+        gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, nsplit);
+    else if (glds)
     {
         if (wide)
             gemm_tn_glds_kernel<5><<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, 0, tn, d_maskA, d_maskB, tm, nsplit);

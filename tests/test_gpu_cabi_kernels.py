@@ -151,7 +151,8 @@ def test_dgemm_tn_masked_and_tile_mask(m, n, k, nsplit):
     assert abs(got - a[:, :m].T @ b[:, :n]).max() < 1e-10          # and the skipped work was negligible
 
 
-@pytest.mark.parametrize('nao,naux,nocc', [(130, 37, 33), (257, 20, 161), (64, 5, 16)])
+@pytest.mark.parametrize('nao,naux,nocc', [(130, 37, 33), (257, 20, 161), (64, 5, 16), (200, 9, 150), (145, 4, 310),
+                                           (272, 3, 139)])
 def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
     """PAMD_unpack_tril -> PAMD_nr_e2_square (LDS-DMA half transform on the unpacked image) against numpy, including the
     first J pass taken from the epilogue: rho_L = sum_{i,p} X[L,i,p] C[p,i] = sum_pq B_L[pq] (C C^T)[pq]."""
