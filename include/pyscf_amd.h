@@ -178,6 +178,10 @@ int PAMD_eval_ao(int deriv, const int *d_l, const int *d_ao0, const int *d_prim0
 int PAMD_rho_from_mo(const double *d_c, long comp_stride, long ldc, int nocc, int ncomp, long ng,
                      double *d_rho, long ldg, const double *d_occ_sign /* nullable [nocc]: +-1 weights of the rows,
                      for a symmetric matrix factorised as C diag(sign) C^T */, void *stream);
+/* first-order density of a factorised matrix A B^T (rank-nocc trial densities of the response solvers): rho = coef sum_i
+ * a_i b_i, grad rho = coef sum_i (grad a_i b_i + a_i grad b_i); d_ca / d_cb in the layout of PAMD_rho_from_mo */
+int PAMD_rho_from_mo_pair(const double *d_ca, const double *d_cb, long comp_stride, long ldc, int nocc, int ncomp, long ng,
+                          double coef, double *d_rho, long ldg, void *stream);
 int PAMD_rho_from_dm(const double *d_ao, const double *d_c0t, int nao, int ldao, long ldg_rows, long ldc,
                      int ncomp, long ng, double *d_rho, long ldg, void *stream);
 /* fac7: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C}.  wv[4][ldg] = w (vrho/2, 2 vsigma grad rho);

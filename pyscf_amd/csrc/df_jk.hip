@@ -94,29 +94,31 @@ __global__ __launch_bounds__(256) void vj_pass2_kernel(
     const double *__restrict__ cderi, long npair, int naux, const double *__restrict__ rho,
     double *__restrict__ vj)
 {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npair) return;
-    double acc[NSET];
+    // grid-stride over the packed columns: with a capped grid (tuning key "j2wg") the pass becomes a thin background
+    // stream beside the MFMA-bound SYRK instead of a burst that takes its issue slots and memory queue
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npair; i += (long)gridDim.x * 256) {
+        double acc[NSET];
 #pragma unroll
-    for (int s = 0; s < NSET; s++) acc[s] = 0;
-    const double *col = cderi + i;
-    int L = 0;
-    for (; L + 8 <= naux; L += 8) {
-        double b[8];
+        for (int s = 0; s < NSET; s++) acc[s] = 0;
+        const double *col = cderi + i;
+        int L = 0;
+        for (; L + 8 <= naux; L += 8) {
+            double b[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) b[u] = __builtin_nontemporal_load(col + (long)(L + u) * npair);
+            for (int u = 0; u < 8; u++) b[u] = __builtin_nontemporal_load(col + (long)(L + u) * npair);
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+            for (int u = 0; u < 8; u++)
 #pragma unroll
-            for (int s = 0; s < NSET; s++) acc[s] += rho[s * naux + L + u] * b[u];
+                for (int s = 0; s < NSET; s++) acc[s] += rho[s * naux + L + u] * b[u];
+        }
+        for (; L < naux; L++) {
+            double b = col[(long)L * npair];
+#pragma unroll
+            for (int s = 0; s < NSET; s++) acc[s] += rho[s * naux + L] * b;
+        }
+#pragma unroll
+        for (int s = 0; s < NSET; s++) vj[(long)s * npair + i] += acc[s];
     }
-    for (; L < naux; L++) {
-        double b = col[(long)L * npair];
-#pragma unroll
-        for (int s = 0; s < NSET; s++) acc[s] += rho[s * naux + L] * b;
-    }
-#pragma unroll
-    for (int s = 0; s < NSET; s++) vj[(long)s * npair + i] += acc[s];
 }
 
 // ------------------------------------------------------------------------------------ K
@@ -501,10 +503,12 @@ __device__ __forceinline__ void dma_row(__amdgpu_buffer_rsrc_t r, double *lds_ds
 // fragment read hit different banks - and the tensor panel as [16][144].  9 DMAs per wave and k-tile (v1: 12, four of
 // them exec-masked), no branch inside the k-tile body, so the compiler keeps prefetching the fragments of k-group
 // g+1 under the MFMAs of group g.  Wave (wr, wc) owns orbital tiles {64 wr + 16 a, a < 4} and {128 + 16 wr}.
+// A wave whose 64 AO columns all lie beyond `ncol` (the 128-column tile overhangs the matrix) only stages its DMA rows:
+// its matrix-pipe time goes to the co-resident workgroup.
 template <bool RHO>
 __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
-    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk)
+    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int ncol)
 {
     constexpr int M = 160;
     __shared__ double sa0[KB * LDN + KB * 32];
@@ -562,11 +566,26 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
                 for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
         }
     };
+    auto step_idle = [&](double *na, double *nb, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kn = (k0 + KB < kdim) ? k0 + KB : k0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) stage_row(kn, na, nb, j);
+    };
 #pragma unroll
     for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
-    for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
-        step(sa0, sq0, sa1, sq1, k0);
-        if (k0 + KB < kdim) step(sa1, sq1, sa0, sq0, k0 + KB);
+    if (p0 + wc * 64 < ncol) {
+        for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
+            step(sa0, sq0, sa1, sq1, k0);
+            if (k0 + KB < kdim) step(sa1, sq1, sa0, sq0, k0 + KB);
+        }
+    } else {
+        for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
+            step_idle(sa1, sq1, k0);
+            if (k0 + KB < kdim) step_idle(sa0, sq0, k0 + KB);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     double *out = X + L * nocc_pad * ldx;
     double rho_acc = 0;
@@ -656,13 +675,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
                 for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
         }
     };
+    auto step_idle = [&](double *nxt, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kn = (k0 + KB < nk) ? k0 + KB : k0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) stage_row(kn, nxt, j);
+    };
     if (nk > 0) {
 #pragma unroll
         for (int j = 0; j < 4; j++) stage_row(0, sb0, j);
     }
-    for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
-        step(sb0, sb1, k0);
-        if (k0 + KB < nk) step(sb1, sb0, k0 + KB);
+    // a wave whose 64 x 64 block lies entirely beyond the matrix (edge tiles), or entirely above the diagonal of a
+    // diagonal SYRK tile, only stages its DMA rows
+    const bool idle = p0 + wr * 64 >= m || q0 + wc * 64 >= n || (lower_only && tm == tn && wc > wr);
+    if (!idle) {
+        for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
+            step(sb0, sb1, k0);
+            if (k0 + KB < nk) step(sb1, sb0, k0 + KB);
+        }
+    } else {
+        for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
+            step_idle(sb1, k0);
+            if (k0 + KB < nk) step_idle(sb0, k0 + KB);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
     }
     double *out = C + (long)bsplit * m * ldc;
 #pragma unroll
@@ -746,6 +784,7 @@ __global__ void pack_dm_kernel(const double *__restrict__ dm, int nao, double *_
 static int g_use_glds = 1;
 static int g_gemm_wide = 1;
 static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper bound
+static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: one per 256 columns)
 static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
 
 extern "C" {
@@ -756,6 +795,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "glds") == 0) { g_use_glds = value; return 0; }
     if (strcmp(key, "gemmwide") == 0) { g_gemm_wide = value; return 0; }
     if (strcmp(key, "dmav2") == 0) { g_dma_v2 = value; return 0; }
+    if (strcmp(key, "j2wg") == 0 && value >= 0) { g_j2_maxwg = value; return 0; }
     if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
 }
@@ -793,6 +833,7 @@ int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *
     if (naux == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int grid = ceil_div(npair, 256);
+    if (g_j2_maxwg > 0 && grid > g_j2_maxwg) grid = g_j2_maxwg;
     switch (nset) {
     case 1: vj_pass2_kernel<1><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
     case 2: vj_pass2_kernel<2><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
@@ -887,10 +928,10 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
         if (g_dma_v2 && W == 5) {                                                                               \
             if (d_rho)                                                                                          \
                 e2_sq2_kernel<true><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
-                                                          ldx, d_rho_work, nchunk);                              \
+                                                          ldx, d_rho_work, nchunk, nao);                         \
             else                                                                                                \
                 e2_sq2_kernel<false><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
-                                                           ldx, nullptr, nchunk);                                \
+                                                           ldx, nullptr, nchunk, nao);                           \
         } else if (d_rho)                                                                                       \
             e2_sq_kernel<W, true><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
                                                         ldx, d_rho_work, nchunk);                                \

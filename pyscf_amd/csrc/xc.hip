@@ -569,6 +569,29 @@ __global__ __launch_bounds__(256) void rho_from_mo_kernel(const double *__restri
     if (ncomp == 4) { rho[ldg + g] = 2 * sx; rho[2 * ldg + g] = 2 * sy; rho[3 * ldg + g] = 2 * sz; }
 }
 
+// first-order density of a factorised matrix D = A B^T: rho = coef sum_i a_i b_i, grad rho = coef sum_i (grad a_i b_i + a_i grad b_i)
+// with a = A^T ao, b = B^T ao in the [comp][i][ldc] layout of rho_from_mo (a trial density C_occ x C_vir^T of the response
+// solvers has rank nocc: two orbital products replace the nao^2 matrix, numint.py:1418-1530 eval_rho on dm1)
+__global__ __launch_bounds__(256) void rho_from_mo_pair_kernel(const double *__restrict__ ca, const double *__restrict__ cb,
+                                                               long comp_stride, long ldc, int nocc, int ncomp, long ng,
+                                                               double coef, double *__restrict__ rho, long ldg)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ng) return;
+    double s0 = 0, sx = 0, sy = 0, sz = 0;
+    for (int i = 0; i < nocc; i++) {
+        const double a0 = ca[(long)i * ldc + g], b0 = cb[(long)i * ldc + g];
+        s0 += a0 * b0;
+        if (ncomp == 4) {
+            sx += a0 * cb[comp_stride + (long)i * ldc + g] + ca[comp_stride + (long)i * ldc + g] * b0;
+            sy += a0 * cb[2 * comp_stride + (long)i * ldc + g] + ca[2 * comp_stride + (long)i * ldc + g] * b0;
+            sz += a0 * cb[3 * comp_stride + (long)i * ldc + g] + ca[3 * comp_stride + (long)i * ldc + g] * b0;
+        }
+    }
+    rho[g] = coef * s0;
+    if (ncomp == 4) { rho[ldg + g] = coef * sx; rho[2 * ldg + g] = coef * sy; rho[3 * ldg + g] = coef * sz; }
+}
+
 // rho[g] = sum_mu ao0[g][mu] c0t[mu][g], grad = 2 sum_mu ao_x[g][mu] c0t[mu][g]   (c0t = (D ao0^T), [mu][ldc])
 // one wave per grid point (general-DM branch; not a hot path)
 __global__ __launch_bounds__(256) void rho_from_dm_kernel(const double *__restrict__ ao, const double *__restrict__ c0t,
@@ -844,6 +867,16 @@ int PAMD_rho_from_mo(const double *d_c, long comp_stride, long ldc, int nocc, in
     if (ng == 0) return 0;
     rho_from_mo_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(d_c, comp_stride, ldc, nocc, ncomp, ng,
                                                                            d_rho, ldg, d_occ_sign);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int PAMD_rho_from_mo_pair(const double *d_ca, const double *d_cb, long comp_stride, long ldc, int nocc, int ncomp, long ng,
+                          double coef, double *d_rho, long ldg, void *stream)
+{
+    if (ng == 0) return 0;
+    rho_from_mo_pair_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(d_ca, d_cb, comp_stride, ldc, nocc, ncomp,
+                                                                                ng, coef, d_rho, ldg);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

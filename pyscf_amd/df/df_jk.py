@@ -237,6 +237,76 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
     return vk
 
 
+def _half_transform(dfobj, lib, b0, nb, orb, nocc_pad, ldo, nao, out, ldx, st):
+    """out[L][i][p] = sum_q B_L[p,q] orb[q,i] for aux rows [b0, b0 + nb): square-image kernel when the image exists."""
+    cderi = dfobj._cderi_dev
+    sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
+    if sq is not None:
+        _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[b0:b0 + nb]), _c.c_long(sq.shape[2]), _c.c_int(sq.shape[1]),
+              _c.c_int(nb), _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(out),
+              _c.c_int(ldx), _c.c_void_p(0), _c.c_void_p(0), st)
+    else:
+        _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(cderi.shape[1]), _c.c_int(nb),
+              _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(out), _c.c_int(ldx),
+              _c.c_void_p(0), _c.c_void_p(0), st)
+
+
+def _vk_lowrank(dfobj, lib, lefts, rights, sym, nao):
+    """Exchange of factorised densities D_k = L_k R_k^T (+ R_k L_k^T when sym): K(D_k) = sum_L (B_L L_k)(B_L R_k)^T, two
+    MO-branch half transforms and one full X^T Y product per density - 6 naux nao^2 r flops instead of the 4 naux nao^3 of
+    the general branch (pyscf/df/df_jk.py:382-407).  This is what a TDA / TDDFT / CPHF / Newton trial density
+    C_occ x C_vir^T (rank nocc) needs (pyscf/scf/_response_functions.py:29-247 feeds get_jk with such matrices); densities
+    that share their left factor (the occupied orbitals of one reference state) share its half transform."""
+    torch = _torch()
+    cderi = dfobj._cderi_dev
+    naux = cderi.shape[0]
+    dev = cderi.device
+    st = _stream()
+    nset = len(lefts)
+    ldx = _round_up(nao, 16)
+    nsplit = dfobj.k_nsplit
+    vk = torch.zeros((nset, nao, nao), dtype=torch.float64, device=dev)
+    if naux == 0:
+        return vk
+    # group the densities by the identity of their left factor
+    groups = []
+    for k in range(nset):
+        if groups and groups[-1][0] is lefts[k]:
+            groups[-1][1].append(k)
+        else:
+            groups.append((lefts[k], [k]))
+    rpad_max = max(_round_up(max(l.shape[1], 1), 16) for l in lefts)
+    blk = max(1, _k_blocksize(dfobj, naux, rpad_max, ldx) // 2)
+    X = dfobj._workspace('X', (blk, rpad_max, ldx))
+    Y = dfobj._workspace('Y', (blk, rpad_max, ldx))
+    for lf, members in groups:
+        r = lf.shape[1]
+        if r == 0:
+            continue
+        orb_l, rpad, ldo = pad_orbitals(np.ascontiguousarray(lf, dtype=np.float64), dev)
+        orbs_r = [pad_orbitals(np.ascontiguousarray(rights[k], dtype=np.float64), dev) for k in members]
+        assert all(o[1] == rpad for o in orbs_r), 'left and right factors need the same number of columns'
+        Xv = X.view(-1)[:blk * rpad * ldx].view(blk, rpad, ldx)
+        Yv = Y.view(-1)[:blk * rpad * ldx].view(blk, rpad, ldx)
+        parts = dfobj._workspace('kpart_lr', (len(members), nsplit, nao, nao))
+        parts.zero_()
+        for b0 in range(0, naux, blk):
+            nb = min(blk, naux - b0)
+            _half_transform(dfobj, lib, b0, nb, orb_l, rpad, ldo, nao, Xv, ldx, st)      # shared by the group
+            for ik in range(len(members)):
+                orb_r, _, ldo_r = orbs_r[ik]
+                _half_transform(dfobj, lib, b0, nb, orb_r, rpad, ldo_r, nao, Yv, ldx, st)
+                _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(Xv), _c.c_int(ldx), _ptr(Yv), _c.c_int(ldx),
+                      _ptr(parts[ik]), _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * rpad), _c.c_int(0 | 2),
+                      _c.c_int(nsplit), st)
+        for ik, k in enumerate(members):
+            _call(dfobj, 'reduce_splits', lib.PAMD_reduce_splits, _ptr(parts[ik]), _c.c_int(nsplit), _c.c_int(nao),
+                  _c.c_int(nao), _ptr(vk[k]), _c.c_int(nao), _c.c_int(0), st)
+    if sym:
+        vk = vk + vk.transpose(1, 2)
+    return vk
+
+
 def get_j(dfobj, dm, hermi=0, direct_scf_tol=1e-13):
     """Integral-direct J without the 3-index tensor (pyscf/df/df_jk.py:415-506): pass 1
     gamma_Q = sum_pq (pq|Q) D_pq over freshly generated AO-row slabs (:473-478), rho = j2c^-1 gamma by
@@ -395,6 +465,17 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
     nset = dms.shape[0]
     dev = dfobj._cderi_dev.device
     dms_dev = torch.from_numpy(dms).to(dev)
+    lowrank = getattr(dm, 'lowrank', None)
+    if with_k and lowrank is not None and getattr(dfobj, 'lowrank_exchange', True):
+        # factorised trial densities (tag: lowrank = (lefts, rights, sym), D_k = L_k R_k^T [+ h.c.]): J from the full
+        # matrices as usual, K from the factors
+        lib = _lib_mod.load_library()
+        lefts, rights, sym = lowrank
+        assert len(lefts) == nset == len(rights)
+        vjtril = _vj(dfobj, lib, dms_dev, nset, nao) if with_j else None
+        vk_dev = _vk_lowrank(dfobj, lib, lefts, rights, sym, nao)
+        _allreduce(dfobj, [t for t in (vjtril, vk_dev) if t is not None])
+        return _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k)
     orb_list = None
     mo_coeff = getattr(dm, 'mo_coeff', None)
     if with_k and mo_coeff is not None:
@@ -435,9 +516,42 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         _allreduce(dfobj, [vk_neg])
         for j, k in enumerate(idx):
             vk_dev[k] -= vk_neg[j]
-    vj = vk = None
+    return _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k)
+
+
+def _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k):
+    """Results to the host: J is unpacked on the device (PAMD_unpack_tril), J and K leave through one pinned staging
+    buffer (a pageable download runs at a fraction of the PCIe rate; the host-side unpack cost another 10 ms at nao 1856)."""
+    torch = _torch()
+    dev = (vjtril if with_j else vk_dev).device
+    parts = []
     if with_j:
-        vj = _lib_mod.unpack_tril(vjtril.cpu().numpy(), 1).reshape(dm_shape)
+        vj_dev = torch.empty((nset, nao, nao), dtype=torch.float64, device=dev)
+        lib = _lib_mod.load_library()
+        _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(vjtril), _c.c_long(vjtril.shape[1]), _c.c_int(nset),
+              _c.c_int(nao), _ptr(vj_dev), _c.c_int(nao), _c.c_int(nao), _stream())
+        parts.append(vj_dev)
     if with_k:
-        vk = vk_dev.cpu().numpy().reshape(dm_shape)
+        parts.append(vk_dev)
+    host = _download(dfobj, parts)
+    vj = host.pop(0).reshape(dm_shape) if with_j else None
+    vk = host.pop(0).reshape(dm_shape) if with_k else None
     return vj, vk
+
+
+def _download(dfobj, tensors):
+    """Device tensors -> fresh numpy arrays through a persistent pinned buffer (one async copy per tensor, one sync)."""
+    torch = _torch()
+    n = sum(t.numel() for t in tensors)
+    pin = getattr(dfobj, '_pinned', None)
+    if pin is None or pin.numel() < n:
+        pin = torch.empty(n, dtype=torch.float64, pin_memory=True)
+        dfobj._pinned = pin
+    off, views = 0, []
+    for t in tensors:
+        v = pin[off:off + t.numel()].view(t.shape)
+        v.copy_(t, non_blocking=True)
+        views.append(v)
+        off += t.numel()
+    torch.cuda.current_stream().synchronize()
+    return [v.numpy().copy() for v in views]

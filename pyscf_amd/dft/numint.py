@@ -339,6 +339,127 @@ class NumInt:
             dist.all_reduce(acc, group=self.group)
         return acc.cpu().numpy(), v.cpu().numpy()
 
+    def _first_order_terms(self, dms2, lowrank, nao, dev):
+        """Per first-order density: ('pair', opA, opB, coef) when the caller tagged its factors (D = L R^T [+ h.c.], see
+        df_jk._vk_lowrank), else ('op', operand) from the signed eigen-factorisation of the symmetric part."""
+        import torch
+        terms, cache = [], {}
+
+        def operand(mat):
+            key = id(mat)
+            if key not in cache:
+                m = np.ascontiguousarray(mat, dtype=np.float64)
+                r = m.shape[1]
+                rpad = _round_up(max(r, 1), 16)
+                ldo = _round_up(rpad, 160) if rpad > 160 else rpad
+                h = np.zeros((_round_up(nao + 1, 16), ldo))
+                h[:nao, :r] = m
+                cache[key] = (torch.from_numpy(h).to(dev), r, rpad, ldo, None)
+            return cache[key]
+        for k, d in enumerate(dms2):
+            if lowrank is not None:
+                lefts, rights, sym = lowrank
+                terms.append(('pair', operand(lefts[k]), operand(rights[k]), 2.0 if sym else 1.0))
+            else:
+                terms.append(('op', self._orbital_operand(d, None, None, nao, dev)))
+        return terms
+
+    def _sparse_fxc(self, mol, grids, fac, gga, ops0, terms, spin):
+        """vmat[s][i] of nr_rks_fxc (spin = 0: ops0 = [op], terms[i] = term) / nr_uks_fxc (spin = 1: ops0 = [op_a, op_b],
+        terms[i] = (term_a, term_b)) on the compact AO subsets: rho0 and every rho1 from orbital products (sub_orb_dot),
+        first-order weights from PAMD_eval_fxc / _pol, then the scale + scatter GEMM of the ground-state pipeline."""
+        import torch
+        lib = _lib_mod.load_library()
+        dev = self._dev()
+        plan = self.sparse_plan(mol, grids, gga)
+        G, ncomp, nao = plan.G, plan.ncomp, plan.nao
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        f64 = torch.float64
+        nspin = 2 if spin else 1
+        nvec = len(terms)
+        ldg = max(plan.max_chunk_points, 1)
+        fac_c = (ctypes.c_double * 7)(*fac)
+        M = torch.zeros((nspin, nvec, nao, nao), dtype=f64, device=dev)
+        rho0 = torch.zeros((nspin, 4, ldg), dtype=f64, device=dev)
+        rho1 = torch.zeros((nspin, 4, ldg), dtype=f64, device=dev)
+        wv = torch.empty((nspin, 4, ldg), dtype=f64, device=dev)
+        all_ops = list(ops0)
+        for t in terms:
+            for tt in (t if spin else (t,)):
+                all_ops += [tt[1]] if tt[0] == 'op' else [tt[1], tt[2]]
+        pad_max = max(o[2] for o in all_ops)
+        bufs = [torch.empty(ncomp * pad_max * ldg, dtype=f64, device=dev) for _ in range(3)]   # c0 / cached left / right
+        aow = torch.zeros(plan.max_aow_chunk + 256, dtype=f64, device=dev)
+        aoc_buf = torch.zeros(plan.max_ao_chunk + 256, dtype=f64, device=dev) if plan.ao_c is None else None
+        for ch in plan.chunks:
+            t0, nt = ch['t0'], ch['t1'] - ch['t0']
+            npts = nt * G
+            if plan.ao_c is not None:
+                aoc = plan.ao_c[ch['ao_base']:]
+            else:
+                plan.fill_chunk(ch, aoc_buf)
+                aoc = aoc_buf
+            tabs = (_ptr(plan.ao_off[t0:]), _ptr(plan.aow_off[t0:]), _ptr(plan.idx_off[t0:]), _ptr(plan.ld[t0:]))
+            w_ch = plan.weights[t0 * G:(t0 + nt) * G]
+
+            def orb_dot(op, out):
+                orb, nocc, nocc_pad, ldo, sign = op
+                self._call('ao_dot_mo', lib.PAMD_sub_orb_dot, _ptr(aoc), tabs[0], tabs[2], tabs[3], _ptr(plan.idx),
+                           _c.c_int(nt), _c.c_int(G), _c.c_int(ncomp), _ptr(orb), _c.c_int(ldo), _c.c_int(nocc_pad),
+                           _ptr(out), _c.c_long(nocc_pad * npts), _c.c_long(npts), st)
+
+            def density(op, out):
+                orb, nocc, nocc_pad, ldo, sign = op
+                if nocc == 0:
+                    out.zero_()
+                    return
+                orb_dot(op, bufs[0])
+                self._call('rho', lib.PAMD_rho_from_mo, _ptr(bufs[0]), _c.c_long(nocc_pad * npts), _c.c_long(npts),
+                           _c.c_int(nocc), _c.c_int(ncomp), _c.c_long(npts), _ptr(out), _c.c_long(ldg),
+                           _ptr(sign) if sign is not None else _c.c_void_p(0), st)
+            for s in range(nspin):
+                density(ops0[s], rho0[s])
+            left_in_buf = None
+            for i, term in enumerate(terms):
+                for s, tt in enumerate(term if spin else (term,)):
+                    if tt[0] == 'op':
+                        density(tt[1], rho1[s])
+                        continue
+                    _, opa, opb, coef = tt
+                    if opa[1] == 0:
+                        rho1[s].zero_()
+                        continue
+                    if left_in_buf is not opa:           # densities of one reference share their left factor
+                        orb_dot(opa, bufs[1])
+                        left_in_buf = opa
+                    orb_dot(opb, bufs[2])
+                    self._call('rho', lib.PAMD_rho_from_mo_pair, _ptr(bufs[1]), _ptr(bufs[2]), _c.c_long(opa[2] * npts),
+                               _c.c_long(npts), _c.c_int(opa[1]), _c.c_int(ncomp), _c.c_long(npts), _c.c_double(coef),
+                               _ptr(rho1[s]), _c.c_long(ldg), st)
+                if spin:
+                    self._call('eval_fxc', lib.PAMD_eval_fxc_pol, fac_c, _c.c_int(gga), _ptr(rho0[0]), _ptr(rho0[1]),
+                               _ptr(rho1[0]), _ptr(rho1[1]), _ptr(w_ch), _c.c_long(npts), _c.c_long(ldg), _ptr(wv[0]),
+                               _ptr(wv[1]), st)
+                else:
+                    self._call('eval_fxc', lib.PAMD_eval_fxc, fac_c, _c.c_int(gga), _ptr(rho0[0]), _ptr(rho1[0]), _ptr(w_ch),
+                               _c.c_long(npts), _c.c_long(ldg), _ptr(wv[0]), st)
+                for s in range(nspin):
+                    self._call('scale_ao', lib.PAMD_sub_scale_ao, _ptr(aoc), tabs[0], tabs[1], tabs[3], _c.c_int(nt),
+                               _c.c_int(G), _c.c_int(ncomp), _c.c_int(ch['ld_max']), _ptr(wv[s]), _c.c_long(ldg), _ptr(aow), st)
+                    self._call('ao_dot_aow', lib.PAMD_sub_vmat, _ptr(aoc), tabs[0], _ptr(aow), tabs[1], tabs[2], tabs[3],
+                               _ptr(plan.idx), _ptr(ch['work']), _c.c_int(ch['nwork']), _c.c_int(G), _c.c_int(nao),
+                               _ptr(M[s, i]), _c.c_long(nao), st)
+        v = torch.empty((nspin, nvec, nao, nao), dtype=f64, device=dev)
+        for s in range(nspin):
+            for i in range(nvec):
+                self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(M[s, i]), _c.c_int(1), _c.c_int(nao), _c.c_int(nao),
+                           _ptr(v[s, i]), st)
+        rank, world = self._world()
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(v, group=self.group)
+        return v.cpu().numpy()
+
     # -- the hot entry point ----------------------------------------------------------------------
     def nr_rks(self, mol, grids, xc_code, dms, relativity=0, hermi=1, max_memory=2000, verbose=None):
         """-> (nelec, excsum, vmat) with the contract of numint.nr_rks (numint.py:1074-1190)."""
@@ -494,6 +615,12 @@ class NumInt:
             return vmat.reshape(shape)
         gga = 1 if xctype == 'GGA' else 0
         ncomp = 4 if gga else 1
+        if self.sparse:
+            dm0a = np.asarray(dm0, dtype=np.float64)
+            tagged = getattr(dm0, 'mo_coeff', None) is not None and np.ndim(getattr(dm0, 'mo_occ', None)) == 1
+            op0 = self._orbital_operand(dm0a, dm0.mo_coeff if tagged else None, dm0.mo_occ if tagged else None, nao, dev)
+            terms = self._first_order_terms(dms2, getattr(dms, 'lowrank', None), nao, dev)
+            return self._sparse_fxc(mol, grids, fac, gga, [op0], terms, 0)[0].reshape(shape)
         coords_dev, weights_dev = self._grid_tables(grids, dev)
         ngrids = grids.size
         ldao = _round_up(nao, 16)
@@ -569,6 +696,22 @@ class NumInt:
         dma, dmb = dma.reshape(-1, nao, nao), dmb.reshape(-1, nao, nao)
         nset = len(dma)
         vmat = np.zeros((2, nset, nao, nao))
+        if xctype != 'HF' and self.sparse:
+            gga = 1 if xctype == 'GGA' else 0
+            mo0, occ0 = getattr(dm0, 'mo_coeff', None), getattr(dm0, 'mo_occ', None)
+            tagged = mo0 is not None and np.ndim(occ0) == 2
+            ops0 = [self._orbital_operand(np.asarray(dm0[s], dtype=np.float64), np.asarray(mo0[s]) if tagged else None,
+                                          np.asarray(occ0[s]) if tagged else None, nao, dev) for s in range(2)]
+            lr = getattr(dms, 'lowrank', None)          # factors listed alpha densities first, then beta
+            if lr is not None:
+                lr_a = (lr[0][:nset], lr[1][:nset], lr[2])
+                lr_b = (lr[0][nset:], lr[1][nset:], lr[2])
+            else:
+                lr_a = lr_b = None
+            ta = self._first_order_terms(dma, lr_a, nao, dev)
+            tb = self._first_order_terms(dmb, lr_b, nao, dev)
+            vmat = self._sparse_fxc(mol, grids, fac, gga, ops0, list(zip(ta, tb)), 1)
+            return vmat[:, 0] if single else vmat
         if xctype != 'HF':
             gga = 1 if xctype == 'GGA' else 0
             ncomp = 4 if gga else 1
@@ -640,8 +783,18 @@ class NumInt:
         (dm1, +dm1) or (dm1, -dm1)."""
         half = np.asarray(dm0, dtype=np.float64) * .5
         d1 = np.asarray(dms_alpha, dtype=np.float64)
-        return self.nr_uks_fxc(mol, grids, xc_code, (half, half), (d1, d1 if singlet else -d1), relativity, hermi,
-                               max_memory=max_memory)[0]
+        dm0_ab, dms_ab = (half, half), (d1, d1 if singlet else -d1)
+        mo0, occ0 = getattr(dm0, 'mo_coeff', None), getattr(dm0, 'mo_occ', None)
+        if mo0 is not None and np.ndim(occ0) == 1:          # keep the orbital tag: (c, c) with half occupations
+            dm0_ab = _lib_mod.tag_array(np.array(dm0_ab), mo_coeff=np.array([mo0, mo0]),
+                                        mo_occ=np.array([occ0, occ0]) * .5)
+        lr = getattr(dms_alpha, 'lowrank', None)
+        if lr is not None:                                  # alpha factors, then beta factors (+- the same)
+            lefts, rights, sym = lr
+            sgn = 1.0 if singlet else -1.0
+            dms_ab = _lib_mod.tag_array(np.array(dms_ab), lowrank=(list(lefts) * 2,
+                                                                   list(rights) + [r * sgn for r in rights], sym))
+        return self.nr_uks_fxc(mol, grids, xc_code, dm0_ab, dms_ab, relativity, hermi, max_memory=max_memory)[0]
 
     def nr_fxc(self, mol, grids, xc_code, dm0, dms, spin=0, relativity=0, hermi=0, rho0=None, vxc=None, fxc=None,
                max_memory=2000, verbose=None):

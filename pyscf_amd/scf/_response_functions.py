@@ -15,10 +15,14 @@ hermi = 2 (anti-symmetric dm1) keeps only the exchange, as in the reference.
 import numpy as np
 
 
-def _coulomb_exchange(mf, dm1, hermi, with_j, omega, alpha, hyb):
-    """(J or None, exact-exchange matrix already scaled) for dm1 of any leading shape."""
+def _coulomb_exchange(mf, dm1, hermi, with_j, omega, alpha, hyb, lowrank=None):
+    """(J or None, exact-exchange matrix already scaled) for dm1 of any leading shape.  lowrank: the factors of the trial
+    densities (tag of the caller's dm1, see df_jk._vk_lowrank), handed on to get_jk."""
     mol = mf.mol
     h = 0 if hermi == 2 else hermi
+    if lowrank is not None:
+        from ..lib import tag_array
+        dm1 = tag_array(dm1, lowrank=lowrank)
     vj = None
     if hyb == 0 and (omega == 0 or alpha == 0):            # no exact exchange at all
         if with_j:
@@ -58,18 +62,27 @@ def gen_rhf_response(mf, mo_coeff=None, mo_occ=None, singlet=None, hermi=0, max_
         raise TypeError('gen_rhf_response needs restricted orbitals')
     mol = mf.mol
     ni, omega, alpha, hyb = _xc_coefficients(mf)
-    dm0 = (mo_coeff * mo_occ).dot(mo_coeff.T)
+    from ..lib import tag_array
+    dm0 = tag_array((mo_coeff * mo_occ).dot(mo_coeff.T), mo_coeff=mo_coeff, mo_occ=mo_occ)
     triplet = singlet is not None and not singlet
 
+    def retag(d, scale=1.0, lowrank=None):
+        if lowrank is None:
+            return d * scale if scale != 1.0 else d
+        lefts, rights, sym = lowrank
+        return tag_array(d * scale if scale != 1.0 else d,
+                         lowrank=(lefts, [r * scale for r in rights] if scale != 1.0 else rights, sym))
+
     def vind(dm1):
+        lowrank = getattr(dm1, 'lowrank', None)
         dm1 = np.asarray(dm1)
         v1 = np.zeros_like(dm1, dtype=np.float64)
         if ni is not None and hermi != 2:
             if triplet:                      # nr_rks_fxc_st takes the alpha part of the first-order density
-                v1 = v1 + ni.nr_rks_fxc_st(mol, mf.grids, mf.xc, dm0, dm1 * .5, hermi=hermi, singlet=False)
+                v1 = v1 + ni.nr_rks_fxc_st(mol, mf.grids, mf.xc, dm0, retag(dm1, .5, lowrank), hermi=hermi, singlet=False)
             else:
-                v1 = v1 + ni.nr_rks_fxc(mol, mf.grids, mf.xc, dm0, dm1, hermi=hermi)
-        vj, vk = _coulomb_exchange(mf, dm1, hermi, not triplet and hermi != 2, omega, alpha, hyb)
+                v1 = v1 + ni.nr_rks_fxc(mol, mf.grids, mf.xc, dm0, retag(dm1, 1.0, lowrank), hermi=hermi)
+        vj, vk = _coulomb_exchange(mf, dm1, hermi, not triplet and hermi != 2, omega, alpha, hyb, lowrank)
         if vj is not None:
             v1 = v1 + vj
         if vk is not None:
@@ -88,14 +101,18 @@ def gen_uhf_response(mf, mo_coeff=None, mo_occ=None, with_j=True, hermi=0, max_m
         raise TypeError('gen_uhf_response needs (alpha, beta) orbitals')
     mol = mf.mol
     ni, omega, alpha, hyb = _xc_coefficients(mf)
-    dm0 = np.array([(mo_coeff[s] * mo_occ[s]).dot(mo_coeff[s].T) for s in range(2)])
+    from ..lib import tag_array
+    dm0 = tag_array(np.array([(mo_coeff[s] * mo_occ[s]).dot(mo_coeff[s].T) for s in range(2)]), mo_coeff=mo_coeff,
+                    mo_occ=mo_occ)
 
     def vind(dm1):
+        lowrank = getattr(dm1, 'lowrank', None)
         dm1 = np.asarray(dm1)
         v1 = np.zeros_like(dm1, dtype=np.float64)
         if ni is not None and hermi != 2:
-            v1 = v1 + ni.nr_uks_fxc(mol, mf.grids, mf.xc, dm0, dm1, hermi=hermi)
-        vj, vk = _coulomb_exchange(mf, dm1, hermi, with_j and hermi != 2, omega, alpha, hyb)
+            v1 = v1 + ni.nr_uks_fxc(mol, mf.grids, mf.xc, dm0,
+                                    dm1 if lowrank is None else tag_array(dm1, lowrank=lowrank), hermi=hermi)
+        vj, vk = _coulomb_exchange(mf, dm1, hermi, with_j and hermi != 2, omega, alpha, hyb, lowrank)
         if vj is not None:
             v1 = v1 + (vj[0] + vj[1])
         if vk is not None:

@@ -11,6 +11,8 @@ one symmetric first-order density through the device J/K + XC-kernel path.  The 
 ``lib.krylov``); several perturbations are solved one after the other.
 """
 import numpy as np
+
+from ..lib import tag_array
 import scipy.sparse.linalg
 
 
@@ -27,8 +29,9 @@ def gen_vind(mf, mo_coeff=None, mo_occ=None):
         mo1 = np.asarray(mo1)
         shape = mo1.shape
         m = mo1.reshape(-1, orbv.shape[1], orbo.shape[1])
-        d1 = np.matmul(orbv, np.matmul(m * 2, orbo.T))            # * 2: double occupancy
-        v1 = vind(d1 + d1.transpose(0, 2, 1))
+        lefts = np.matmul(orbv, m * 2)                            # * 2: double occupancy; d1_k = left_k orbo^T (rank nocc)
+        d1 = np.matmul(lefts, orbo.T)
+        v1 = vind(tag_array(d1 + d1.transpose(0, 2, 1), lowrank=([orbo] * len(lefts), list(lefts), True)))
         return np.matmul(orbv.T, np.matmul(v1, orbo)).reshape(shape)
     return fx
 

@@ -12,6 +12,8 @@ step limited to ``max_stepsize``, and stops on the orbital gradient.  The conver
 diagonalisation of the final Fock matrix, so the object can be used wherever a DIIS-converged one can (gradients, TDDFT).
 """
 import numpy as np
+
+from ..lib import tag_array
 import scipy.linalg
 
 
@@ -27,8 +29,9 @@ def gen_g_hop_rhf(mf, mo_coeff, mo_occ, fock_ao):
 
     def h_op(x):
         x = x.reshape(g.shape)
-        d1 = orbv.dot(x * 2).dot(orbo.T)                   # * 2: double occupancy
-        v1 = vind(d1 + d1.T)
+        left = orbv.dot(x * 2)                             # * 2: double occupancy; d1 = left orbo^T has rank nocc
+        d1 = left.dot(orbo.T)
+        v1 = vind(tag_array(d1 + d1.T, lowrank=([orbo], [left], True)))
         return ((fvv.dot(x) - x.dot(foo) + orbv.T.dot(v1).dot(orbo)) * 2).ravel()
     return g.ravel(), h_op, h_diag.ravel()
 

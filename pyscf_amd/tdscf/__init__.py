@@ -15,6 +15,8 @@ first-order spin densities are C_occ,s X_s C_vir,s^T and the amplitude vector is
 """
 import numpy as np
 
+from ..lib import tag_array
+
 DENSE_MAX = 2000          # single-excitation dimension up to which A (and B) are formed and diagonalised directly
 
 
@@ -61,7 +63,8 @@ class TDA:
             for p0 in range(0, len(xs), self.batch):
                 x = xs[p0:p0 + self.batch]
                 # BLAS matmul chains (a three-operand einsum would run an O(n nao^2 nocc nvir) scalar loop)
-                dm1 = 2 * np.matmul(co, np.matmul(x, cv.T))
+                rs = 2 * np.matmul(cv, x.transpose(0, 2, 1))            # dm1_k = C_occ (2 C_vir x_k^T)^T: rank nocc
+                dm1 = tag_array(np.matmul(co, rs.transpose(0, 2, 1)), lowrank=([co] * len(x), list(rs), False))
                 v = vind(dm1)
                 ax[p0:p0 + len(x)] = de * x + np.matmul(co.T, np.matmul(v, cv))
                 bx[p0:p0 + len(x)] = np.matmul(co.T, np.matmul(v.transpose(0, 2, 1), cv))
@@ -85,7 +88,9 @@ class TDA:
             for p0 in range(0, len(xs), self.batch):
                 x = xs[p0:p0 + self.batch]
                 blocks = [x[:, :na].reshape(len(x), *orbs[0][2].shape), x[:, na:].reshape(len(x), *orbs[1][2].shape)]
-                dm1 = np.array([np.matmul(co, np.matmul(xb, cv.T)) for (co, cv, _), xb in zip(orbs, blocks)])
+                rs = [np.matmul(cv, xb.transpose(0, 2, 1)) for (co, cv, _), xb in zip(orbs, blocks)]
+                dm1 = np.array([np.matmul(co, r.transpose(0, 2, 1)) for (co, cv, _), r in zip(orbs, rs)])
+                dm1 = tag_array(dm1, lowrank=([orbs[0][0]] * len(x) + [orbs[1][0]] * len(x), list(rs[0]) + list(rs[1]), False))
                 v = vind(dm1)                                     # (2, n, nao, nao)
                 for out, vt in ((ax, v), (bx, v.transpose(0, 1, 3, 2))):
                     parts = [np.matmul(co.T, np.matmul(vt[s], cv)).reshape(len(x), -1) for s, (co, cv, _) in enumerate(orbs)]

@@ -75,3 +75,32 @@ def test_triplet_and_uks_response(xc):
     fd = (np.asarray(mfc.get_veff(molc, np.array((da + eps * d1a, db + eps * d1b)))) -
           np.asarray(mfc.get_veff(molc, np.array((da - eps * d1a, db - eps * d1b))))) / (2 * eps)
     assert np.abs(fd - v1).max() < 3e-6 * max(1.0, np.abs(v1).max()), np.abs(fd - v1).max()
+
+
+def test_lowrank_exchange_equals_general_branch():
+    """K of factorised trial densities D = L R^T (+ h.c.) through two MO-branch half transforms + one X^T Y product
+    (df_jk._vk_lowrank) against the general-DM branch (pyscf/df/df_jk.py:382-407) on the same matrices; shared left
+    factors, several densities, symmetric and plain forms, the square-image and the packed-operand half transforms."""
+    import numpy as np
+    from pyscf_amd import gto, df, lib
+    from pyscf_amd.data import clusters
+    mol = gto.M(atom=clusters.water_cluster(3), basis='cc-pvdz')
+    nao, nocc = mol.nao, mol.nelectron // 2
+    rng = np.random.default_rng(9)
+    co = np.linalg.qr(rng.standard_normal((nao, nocc)))[0]
+    co2 = np.linalg.qr(rng.standard_normal((nao, nocc)))[0]
+    rs = rng.standard_normal((3, nao, nocc)) * 0.1
+    for square in ('auto', False):
+        obj = df.DF(mol)
+        obj.k_square = square
+        obj.build()
+        for sym in (False, True):
+            lefts = [co, co, co2]
+            dms = np.array([l.dot(r.T) for l, r in zip(lefts, rs)])
+            if sym:
+                dms = dms + dms.transpose(0, 2, 1)
+            vj0, vk0 = obj.get_jk(dms, hermi=0)
+            vj1, vk1 = obj.get_jk(lib.tag_array(dms, lowrank=(lefts, list(rs), sym)), hermi=0)
+            assert np.abs(vj1 - vj0).max() < 1e-11 and np.abs(vk1 - vk0).max() < 1e-11 * max(1.0, np.abs(vk0).max())
+            vk2 = obj.get_jk(lib.tag_array(dms, lowrank=(lefts, list(rs), sym)), hermi=0, with_j=False)[1]
+            assert np.abs(vk2 - vk0).max() < 1e-11 * max(1.0, np.abs(vk0).max())

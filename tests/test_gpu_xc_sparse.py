@@ -201,3 +201,47 @@ def test_sparse_plan_follows_the_molecule(water4):
     ref = dft.NumInt()
     ref.sparse = False
     assert abs(e2 - ref.nr_rks(mol2, g2, 'lda,vwn', dm)[1]) < 1e-10 and abs(e1 - e2) > 1e-6
+
+
+@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp'])
+def test_fxc_sparse_equals_dense(water4, xc):
+    """nr_rks_fxc / nr_uks_fxc / nr_rks_fxc_st on the compact AO subsets - first-order densities eigen-factorised, or taken
+    from the factors the response solvers tag them with (D = L R^T [+ h.c.]) - against the dense pipeline, 1e-10."""
+    from pyscf_amd import dft, lib
+    mol, grids = water4
+    nao, nocc = mol.nao, mol.nelectron // 2
+    rng = np.random.default_rng(8)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0] * 0.4
+    occ = np.zeros(nao)
+    occ[:nocc] = 2
+    co, cv = c[:, :nocc], c[:, nocc:]
+    dm0 = (co * 2).dot(co.T)
+    xs = rng.standard_normal((2, nocc, nao - nocc)) * 0.05
+    rights = [2 * cv.dot(x.T) for x in xs]
+    dm1 = np.array([co.dot(r.T) for r in rights])                      # non-symmetric trial densities
+    dense = dft.NumInt()
+    dense.sparse = False
+    ni = dft.NumInt()
+    ni.sparse_tile = 256
+    ni.sparse_chunk_points = 8192
+    want = dense.nr_rks_fxc(mol, grids, xc, dm0, dm1, hermi=0)
+    got_plain = ni.nr_rks_fxc(mol, grids, xc, dm0, dm1, hermi=0)
+    got_tag = ni.nr_rks_fxc(mol, grids, xc, lib.tag_array(dm0, mo_coeff=c, mo_occ=occ),
+                            lib.tag_array(dm1, lowrank=([co, co], rights, False)), hermi=0)
+    assert np.abs(got_plain - want).max() < 1e-10 and np.abs(got_tag - want).max() < 1e-10
+    dsym = dm1 + dm1.transpose(0, 2, 1)
+    want = dense.nr_rks_fxc(mol, grids, xc, dm0, dsym, hermi=1)
+    got = ni.nr_rks_fxc(mol, grids, xc, dm0, lib.tag_array(dsym, lowrank=([co, co], rights, True)), hermi=1)
+    assert np.abs(got - want).max() < 1e-10
+    for singlet in (True, False):
+        want = dense.nr_rks_fxc_st(mol, grids, xc, dm0, dm1 * .5, singlet=singlet)
+        got = ni.nr_rks_fxc_st(mol, grids, xc, lib.tag_array(dm0, mo_coeff=c, mo_occ=occ),
+                               lib.tag_array(dm1 * .5, lowrank=([co, co], [r * .5 for r in rights], False)), singlet=singlet)
+        got2 = ni.nr_rks_fxc_st(mol, grids, xc, dm0, dm1 * .5, singlet=singlet)
+        assert np.abs(got - want).max() < 1e-10 and np.abs(got2 - want).max() < 1e-10, singlet
+    # open shell
+    dm0u = np.array([(co[:, :nocc] ).dot(co[:, :nocc].T), (co[:, :nocc - 2]).dot(co[:, :nocc - 2].T)])
+    d1u = np.array([dm1[0] * .5, dm1[1] * .3])
+    want = dense.nr_uks_fxc(mol, grids, xc, dm0u, d1u)
+    got = ni.nr_uks_fxc(mol, grids, xc, dm0u, d1u)
+    assert np.abs(got - want).max() < 1e-10

@@ -20,8 +20,9 @@ for sub, name, dst in copies:
     f = find(sub, name)
     if f:
         shutil.copy(f, os.path.join(out, dst))
-SHORT = ['e2_sq_kernel', 'e2_symm', 'gemm_tn_glds_kernel', 'gemm_tn_kernel', 'vj_pass1_rows_kernel', 'vj_pass2_kernel', 'cderi_solve_kernel',
-         'eval_ao_kernel', 'int3c2e_kernel', 'scale_ao_kernel']
+SHORT = ['e2_sq2_kernel', 'e2_sq_kernel', 'e2_symm', 'gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel', 'gemm_tn_kernel',
+         'vj_pass1_rows_kernel', 'vj_pass2_kernel', 'cderi_solve_kernel', 'eval_ao_kernel', 'int3c2e_kernel', 'scale_ao_kernel',
+         'sub_orb_dot_kernel', 'sub_vmat_kernel', 'sub_scale_kernel', 'sub_gather_kernel']
 
 
 def short(n):
@@ -71,9 +72,10 @@ if os.path.exists(p):
 doc = {'command': 'tools/profile_round.sh %s: rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --steps 2 '
                   '--warmup 1 --no-cpu-baseline --xc b3lyp  (one pass per counter set: FETCH_SIZE | WRITE_SIZE | '
                   'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)' % tag,
-       'notes': ['FETCH_SIZE / WRITE_SIZE in KiB as reported (uncorrected). Calibration on known byte counts: vj_pass1 (8 B/lane) streams cderi once, '
-                 '59.86e6 KiB algorithmic, and reports 1.00x; vj_pass2 and the LDS-DMA kernels (16 B/lane) report 0.50-0.54x: the gfx950 '
-                 'half-count of MI355X_MICROARCH.md (HBM section) - double their FETCH_SIZE before comparing with byte counts.',
+       'notes': ['FETCH_SIZE / WRITE_SIZE in KiB as reported (uncorrected). Calibration on known byte counts: vj_pass1 and vj_pass2 each stream '
+                 'cderi once (59.86e6 KiB algorithmic) and report 0.50-0.53x of it, the LDS-DMA kernels 0.50-0.54x: the gfx950 '
+                 'half-count of MI355X_MICROARCH.md (HBM section) - double the FETCH_SIZE of every streaming kernel before comparing '
+                 'with byte counts (the r01 note that claimed 1.00x for vj_pass1 was wrong: its committed row reads 31.8e6 KiB).',
                  'mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); one v_mfma_f64_16x16x4_f64 '
                  'counts 64 busy cycles.'],
        'kernels': summ}
