@@ -47,15 +47,43 @@ def energy_elec(mf, dm=None, h1e=None, vhf=None):
     return e1 + e_coul, e_coul
 
 
+_DEV_CONST = {}
+
+
+def _dev_const(a):
+    """Device copy of a host matrix that does not change during an SCF run (overlap, orthogonaliser), cached per array."""
+    import torch
+    ent = _DEV_CONST.get(id(a))
+    if ent is None or ent[0] is not a:
+        if len(_DEV_CONST) > 8:
+            _DEV_CONST.clear()
+        ent = (a, torch.from_numpy(np.ascontiguousarray(a)).cuda())
+        _DEV_CONST[id(a)] = ent
+    return ent[1]
+
+
 class CDIIS:
     """pyscf/scf/diis.py:40-96 + pyscf/lib/diis.py:225-290 (space 8, min_space 1)."""
 
     def __init__(self, space=8):
         self.space = space
         self.Corth = None
+        self.device_linalg = True
         self._f, self._e = [], []
 
     def _errvec(self, s, d, f):
+        if self.device_linalg and s.shape[0] >= 512 and not np.iscomplexobj(f) and _has_device():
+            # the five nao^3 products of the commutator on the GPU (driver-side algebra, as SCF.eig): at nao = 1856 the
+            # host BLAS needed ~0.15 s per cycle for them, more than the whole J/K build
+            import torch
+            sd, dd, fd = _dev_const(s), torch.from_numpy(np.ascontiguousarray(d)).cuda(), \
+                torch.from_numpy(np.ascontiguousarray(f)).cuda()
+            sdf = sd @ dd @ fd
+            err = sdf.T - sdf
+            if self.Corth is not None:
+                cd = _dev_const(self.Corth)
+                err = cd.T @ err @ cd
+            return err.cpu().numpy()
         sdf = s.dot(d).dot(f)
         err = sdf.conj().T - sdf
         if self.Corth is not None:
@@ -114,6 +142,7 @@ def kernel(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, callback=None, conv
     if mf.diis:
         mf_diis = CDIIS(mf.diis_space)
         mf_diis.Corth = x_orth
+        mf_diis.device_linalg = getattr(mf, 'device_linalg', True)
     mf.cycles = 0
     fock = None
     if mf.max_cycle <= 0:
@@ -246,7 +275,7 @@ class SCF:
             # O(nao^3) dense algebra of the driver on the GPU (hipSOLVER through torch): not part of the
             # hot path, but once J/K takes 0.14 s the host eigh (0.5 s at nao = 1856) would dominate
             import torch
-            xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+            xd = _dev_const(x)
             hd = torch.from_numpy(np.ascontiguousarray(h)).cuda()
             ed, cd = torch.linalg.eigh(xd.T @ hd @ xd)
             e, c = ed.cpu().numpy(), (xd @ cd).cpu().numpy()

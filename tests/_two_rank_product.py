@@ -1,0 +1,73 @@
+"""Worker of tests/test_gpu_bench_launch.py::test_two_rank_product_path: launched by torch.distributed.run with two ranks
+sharing one GPU (gloo).  The aux-sharded PRODUCT path (tensor build per shard, J/K, nr_rks, save / reload of the shards)
+against the CPU oracle; prints TWO_RANK_OK on rank 0."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import ref, ref_dft
+    from pyscf_amd import gto, df, dft, lib
+    from pyscf_amd.data import clusters
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom=clusters.water_cluster(3), basis='cc-pvdz')
+    obj = df.DF(mol).build()
+    naux = obj.get_naoaux()
+    l0, l1 = obj.shard_range(naux, rank, world)
+    assert obj.world_size == world and obj._cderi_dev.shape[0] == l1 - l0 < naux
+    cderi = ref.cholesky_eri(mol, df.make_auxmol(mol))
+    assert np.abs(obj._cderi_dev.cpu().numpy() - cderi[l0:l1]).max() < 1e-9        # this rank's rows of the tensor
+    nao, nocc = mol.nao, mol.nelectron // 2
+    rng = np.random.default_rng(4)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao)
+    occ[:nocc] = 2
+    dm = (c[:, :nocc] * 2).dot(c[:, :nocc].T)
+    vj0, vk0 = ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
+    vj, vk = obj.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=occ), hermi=1)       # MO branch, all-reduced over the shards
+    assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9
+    dms = rng.standard_normal((2, nao, nao))
+    vj0, vk0 = ref.get_jk(cderi, dms, 0)
+    vj, vk = obj.get_jk(dms, hermi=0)                                              # general-DM branch
+    assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9
+    # shards written per rank, reloaded without re-sharding
+    tmp = os.path.join(tempfile.gettempdir(), 'pamd_two_rank_cderi')
+    out = obj.save(tmp)
+    assert out.endswith('.rank%dof%d.npz' % (rank, world))
+    dist.barrier()
+    obj2 = df.DF(mol)
+    obj2._cderi = tmp
+    obj2.build()
+    assert obj2.get_naoaux() == naux and torch.equal(obj2._cderi_dev, obj._cderi_dev)
+    vj2, vk2 = obj2.get_jk(dms, hermi=0)
+    assert np.abs(vk2 - vk).max() < 1e-12
+    # XC: grid tiles dealt round-robin, vmat / nelec / exc all-reduced
+    grids = dft.Grids(mol)
+    grids.level = 1
+    grids.build()
+    ni = dft.NumInt()
+    ni.sparse_tile = 256
+    n, e, v = ni.nr_rks(mol, grids, 'b3lyp', lib.tag_array(dm, mo_coeff=c, mo_occ=occ))
+    hyb, fac = libxc.parse_xc('b3lyp')
+    n0, e0, v0 = ref_dft.nr_rks(mol, grids.coords, grids.weights, fac, True, dm)
+    assert abs(n - n0) < 1e-9 and abs(e - e0) < 1e-9 and np.abs(v - v0).max() < 1e-9
+    assert ni.sparse_plan(mol, grids, True).nloc < -(-grids.size // 256)         # this rank holds only its tiles
+    dist.barrier()
+    if rank == 0:
+        print('TWO_RANK_OK', flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

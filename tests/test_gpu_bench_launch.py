@@ -38,3 +38,20 @@ def test_bench_refuses_a_world_size_mismatch():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--nwater', '2'], env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and 'WORLD_SIZE' in (out.stderr + out.stdout)
+
+
+def test_two_rank_product_path():
+    """The N > 1 arithmetic through the PRODUCT on the GPU (two gloo ranks on one device): sharded tensor build, J/K of
+    both branches, the rank-local save / reload, round-robin grid tiles of nr_rks - all against the CPU oracle."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port),
+                          os.path.join(ROOT, 'tests', '_two_rank_product.py')], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and 'TWO_RANK_OK' in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
