@@ -390,12 +390,13 @@ class Mole:
         """E_nuc = sum_{i<j} Z_i Z_j / r_ij  (mole.py:1524-1548)."""
         q = self.atom_charges().astype(float)
         r = self.atom_coords()
-        e = 0.0
-        for i in range(len(q)):
-            for j in range(i):
-                if q[i] != 0 and q[j] != 0:            # ghost atoms may sit on top of anything
-                    e += q[i] * q[j] / np.linalg.norm(r[i] - r[j])
-        return e
+        real = q != 0                                  # ghost atoms may sit on top of anything
+        q, r = q[real], r[real]
+        if len(q) < 2:
+            return 0.0
+        d = np.sqrt(((r[:, None, :] - r[None, :, :]) ** 2).sum(axis=2))
+        i, j = np.tril_indices(len(q), -1)
+        return float((q[i] * q[j] / d[i, j]).sum())
 
     def tot_electrons(self):
         return self.nelectron

@@ -70,6 +70,7 @@ class CDIIS:
         self.Corth = None
         self.device_linalg = True
         self._f, self._e = [], []
+        self._h = np.zeros((0, 0))
 
     def _errvec(self, s, d, f):
         if self.device_linalg and s.shape[0] >= 512 and not np.iscomplexobj(f) and _has_device():
@@ -95,17 +96,26 @@ class CDIIS:
             err = np.hstack([self._errvec(s, d[i], f[i]).ravel() for i in range(len(f))])
         else:
             err = self._errvec(s, d, f)
+        err = err.ravel()
+        # overlaps of the stored error vectors: only the row of the new vector is computed (the full double loop cost
+        # 36 dot products of nao^2 elements per cycle, 0.1 s at nao = 1856)
+        row = [np.dot(e.conj(), err).real for e in self._e] + [np.dot(err.conj(), err).real]
         self._f.append(f.copy())
-        self._e.append(err.ravel())
+        self._e.append(err)
+        nold = len(self._e) - 1
+        hnew = np.zeros((nold + 1, nold + 1))
+        if nold:
+            hnew[:nold, :nold] = self._h
+        hnew[nold, :] = hnew[:, nold] = row
+        self._h = hnew
         if len(self._f) > self.space:
             self._f.pop(0)
             self._e.pop(0)
+            self._h = self._h[1:, 1:]
         n = len(self._f)
         h = np.zeros((n + 1, n + 1))
         h[0, 1:] = h[1:, 0] = 1
-        for i in range(n):
-            for j in range(i + 1):
-                h[i + 1, j + 1] = h[j + 1, i + 1] = np.dot(self._e[i].conj(), self._e[j]).real
+        h[1:, 1:] = self._h
         g = np.zeros(n + 1)
         g[0] = 1
         w, v = scipy.linalg.eigh(h)
