@@ -14,6 +14,7 @@
 //              packed row directly: the symmetric unpack is fused into the LDS fill)
 //   gemm_tn    C[m][n]    += sum_k  A[k][m] * B[k][n]                 (FP64 MFMA; lower-tri
 //              tiles only for the K = X^T X  SYRK)
+#include <type_traits>
 #include "common.h"
 #include "mfma_e2.h"
 
@@ -611,6 +612,183 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     }
 }
 
+// Half transform straight from the PACKED rows (no unpacked image), all operands by LDS-DMA: what e2_sq2 does, for ranks
+// that cannot spend 2x the tensor size on the square copy.  X[L][i][p] = sum_q B_L[max(p,q)(max+1)/2 + min(p,q)] C[q][i].
+// Workgroup = (aux row L, 128 AO columns p0.., 160 orbitals).  The q loop runs over VIRTUAL 16-deep k-tiles:
+//   * q-tiles entirely above the diagonal (q0 + 15 < p0): source B_L[p][q], contiguous in q for a fixed p.  One DMA moves
+//     eight p-rows x 16 q (1 KiB) with per-lane source addresses; the tile lands transposed in LDS as [p][q-pair] 16-byte
+//     chunks, XOR-swizzled (chunk = (p ^ blk) & 7 rows, (q-pair ^ p) columns) so that fragment reads spread over the banks.
+//   * q-tiles entirely below (q0 >= p0 + 128): source B_L[q][p], one row-contiguous DMA per q as in e2_sq2.
+//   * the up to eight q-tiles that cross the diagonal are visited twice, once per layout, and every fragment element is
+//     kept only where it is valid (row layout: q >= p, transposed layout: q < p) by a per-lane select with 0.
+// The keep-test  t = q - p  (row: t >= 0, transposed: t < 0) is evaluated for every virtual tile - it is all-true on the pure
+// ones - and the DMA operands / fragment addresses of the two layouts are chosen by selects, so the k-tile body stays one
+// basic block.  Cost against the square image: +ncross/(kdim/16) MFMA work (6.9 % at nao = 1856), ~90 VALU per tile in the
+// matrix pipe's shadow; gain: the tensor is read once (30.7 GB per build instead of 61.3) and 2 x its size of HBM is free.
+// Reads beyond a packed row (pad rows q >= nao, pad columns p >= nao of the last tile) stay inside the buffer resource
+// (num_records = bytes to the end of the block, out-of-range -> 0) and only meet zero orbital rows or never-stored columns.
+template <bool RHO>
+__global__ __launch_bounds__(256, 2) void e2_pk_kernel(
+    const double *__restrict__ cderi, long npair, int nL, int kdim, const double *__restrict__ orb, int ldo,
+    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int nao)
+{
+    constexpr int M = 160;
+    __shared__ double sa0[KB * LDN + KB * 32];
+    __shared__ double sa1[KB * LDN + KB * 32];
+    __shared__ double sq0[KB * LDN];
+    __shared__ double sq1[KB * LDN];
+    constexpr int RB = KB * LDN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p0 = (blockIdx.x / nchunk) * NT;
+    const long L = blockIdx.y;
+    const int m0 = (blockIdx.x % nchunk) * M;
+    const long bytes_left = (long)(nL - L) * npair * 8;
+    const __amdgpu_buffer_rsrc_t r_pk = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(cderi + L * npair), 0, bytes_left > 0xffffffffL ? 0xffffffff : (unsigned)bytes_left, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_orb = make_rsrc(orb + m0);
+    const int ldo8 = ldo * 8;
+    const int voff = lane * 16;
+    const int rrow = lane >> 4;
+    const int voff_rem = rrow * ldo8 + (128 + ((((lane & 15) * 2) - 16 * (rrow & 1)) & 31)) * 8;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+    const int offa = fk * LDN + wr * 64 + fn;
+    const int offr = RB + fk * 32 + ((wr * 16 + fn + 16 * (fk & 1)) & 31);
+    // fragment addresses (doubles) of the two B layouts for b = 0, kk = 0; the b / kk strides differ per layout
+    const int offb_row = fk * LDN + wc * 64 + fn;                                          // + kk * LDN + 16 b
+    const int pl = fn & 7, bodd = (fn >> 3) & 1;
+    const int offb_tr = (wc * 8 + (fn >> 3)) * 128 + (((pl ^ bodd) * 8) + ((fk >> 1) ^ (pl & 1))) * 2 + (fk & 1);   // + k-group term + 256 b
+    int atr[4];                                            // transposed-layout fragment address of k-group g (b = 0)
+#pragma unroll
+    for (int g = 0; g < 4; g++) atr[g] = offb_tr + (((2 * g) ^ (pl & 6))) * 2;
+    // transposed-layout DMA j of this wave fills LDS block blk = 4 wave + j: lane -> chunk ci = lane:
+    //   row slot prow = ci >> 3 holds p-row  pl_s = prow ^ (blk & 1), column slot ci & 7 holds q-pair kp = (ci & 7) ^ pl_s
+    int voff_tr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int blk = wave * 4 + j;
+        const int pl_s = (lane >> 3) ^ (blk & 1);
+        const int kp = (lane & 7) ^ pl_s;
+        const long pp = p0 + blk * 8 + pl_s;
+        voff_tr[j] = (int)((pp * (pp + 1) / 2 + 2 * kp) * 8);
+    }
+    // keep-test bases: t(kk, b) = (q0 - p0) + tb[b] + kk  with  tb[b] = fk - fn - 64 wc - 16 b
+    int tb[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) tb[b] = fk - fn - wc * 64 - b * 16;
+
+    double4_t acc[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    // virtual tile v -> (q0, transposed? as 0 / 1), by integer arithmetic only: any branch here would split the k-tile
+    // body into several scheduling regions (and did: hipcc turns the obvious ternaries into s_cbranch)
+    const int nA = p0 / KB;
+    const int ncross = (kdim - p0) / KB < 8 ? (kdim - p0) / KB : 8;
+    const int nvirt = kdim / KB + ncross;
+    auto tile_q0 = [&](int v) {
+        int adj = (v - nA + 1) >> 1;                       // tiles visited twice so far
+        adj = adj < 0 ? 0 : adj;
+        adj = adj > ncross ? ncross : adj;
+        return (v - adj) * KB;
+    };
+    auto tile_tr = [&](int v) {
+        const int u = v - nA;
+        return (int)(u < 0) | ((int)(u < 2 * ncross) & (u & 1) & (int)(u >= 0));
+    };
+    int dvo[4];                                            // (transposed - row) difference of the DMA lane offsets
+#pragma unroll
+    for (int j = 0; j < 4; j++) dvo[j] = voff_tr[j] - voff;
+
+    auto stage_row = [&](int v, double *da, double *db, int j) {
+        const int q0 = tile_q0(v);
+        const int tr = tile_tr(v);
+        const int k = wave * 4 + j;
+        dma_row(r_orb, da + k * LDN, voff, (q0 + k) * ldo8);
+        const int q = q0 + k;
+        const int soff_row = (q * (q + 1) / 2 + p0) * 8;
+        const int soff = soff_row + tr * (q0 * 8 - soff_row);
+        dma_row(r_pk, db + k * (LDN - tr * (LDN - 128)), voff + tr * dvo[j], soff);
+        if (j == 0) dma_row(r_orb, da + RB + wave * 128, voff_rem, (q0 + wave * 4) * ldo8);
+    };
+    // One k-tile body per (layout, masked?) pair, each a single basic block: measured with a layout-generic body, ~100 VALU
+    // selects per tile in a layout-generic body cost 12 % - a VALU between two FP64 MFMAs is not free (~6 cycles each) - so
+    // the fragment addresses of a body are immediates again and the keep-masks exist only in the (<= 16) crossing tiles.
+    auto step = [&](auto TRc, auto MKc, const double *ca, const double *cb, double *na, double *nb, int v) {
+        constexpr bool TR = decltype(TRc)::value, MK = decltype(MKc)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int vn = (v + 1 < nvirt - 1) ? v + 1 : nvirt - 1;   // last tile: harmless reload into the idle buffer
+        const int d = tile_q0(v) - p0;
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[5], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
+            af[4] = ca[offr + kk * 32];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const double val = TR ? cb[atr[kk >> 2] + b * 256] : cb[offb_row + kk * LDN + b * 16];
+                if (MK) {
+                    const bool below = (d + tb[b] + kk) >= 0;      // q >= p
+                    bf[b] = (below != TR) ? val : 0.0;
+                } else {
+                    bf[b] = val;
+                }
+            }
+            stage_row(vn, na, nb, kk >> 2);
+#pragma unroll
+            for (int a = 0; a < 5; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+#pragma unroll
+    for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
+    // the three phases start on even tiles (nA is a multiple of 8, the crossing tiles come in pairs), so the buffer of
+    // every call is a compile-time constant: with run-time buffer pointers hipcc needs waterfall loops for m0
+    int v = 0;
+    for (; v < nA; v += 2) {                                         // above the diagonal: transposed layout
+        step(T_{}, F_{}, sa0, sq0, sa1, sq1, v);
+        step(T_{}, F_{}, sa1, sq1, sa0, sq0, v + 1);
+    }
+    for (; v < nA + 2 * ncross; v += 2) {                            // crossing tiles: row half, then transposed half
+        step(F_{}, T_{}, sa0, sq0, sa1, sq1, v);
+        step(T_{}, T_{}, sa1, sq1, sa0, sq0, v + 1);
+    }
+    for (; v < nvirt; v += 2) {                                      // below: row layout
+        step(F_{}, F_{}, sa0, sq0, sa1, sq1, v);
+        if (v + 1 < nvirt) step(F_{}, F_{}, sa1, sq1, sa0, sq0, v + 1);
+    }
+    double *out = X + L * nocc_pad * ldx;
+    double rho_acc = 0;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const long p = p0 + wc * 64 + b * 16 + fn;
+            if (p >= ldx) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = m0 + (a < 4 ? wr * 64 + a * 16 : 128 + wr * 16) + fk + 4 * r;
+                if (i < nocc_pad) {
+                    out[(long)i * ldx + p] = acc[a][b][r];
+                    if (RHO && p < nao) rho_acc += acc[a][b][r] * orb[p * ldo + i];
+                }
+            }
+        }
+    if (RHO) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rho_acc += __shfl_xor(rho_acc, off, 64);
+        if (lane == 0) rho[(L * gridDim.x + blockIdx.x) * 4 + wave] = rho_acc;
+    }
+}
+
 // 128 x 128 tile of C[split] += A^T B (all tiles, or the lower-triangular ones of the SYRK), v2 DMA scheme
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
@@ -785,6 +963,8 @@ static int g_use_glds = 1;
 static int g_gemm_wide = 1;
 static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper bound
 static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: one per 256 columns)
+static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
+static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
 static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
 
 extern "C" {
@@ -795,6 +975,8 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "glds") == 0) { g_use_glds = value; return 0; }
     if (strcmp(key, "gemmwide") == 0) { g_gemm_wide = value; return 0; }
     if (strcmp(key, "dmav2") == 0) { g_dma_v2 = value; return 0; }
+    if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
+    if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
     if (strcmp(key, "j2wg") == 0 && value >= 0) { g_j2_maxwg = value; return 0; }
     if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
@@ -873,6 +1055,26 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     if (nL == 0 || nocc_pad == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int mt_total = nocc_pad / 16;
+    {
+        // all-DMA packed-operand kernel: 160-orbital chunks (as PAMD_nr_e2_square), q rows padded to a multiple of 16
+        const int nch = ceil_div(mt_total, 10);
+        const int wa = ceil_div(ceil_div(mt_total, nch), 2);
+        const int kdim = ceil_div(nao, KB) * KB;
+        if (g_pk_dma && wa == 5 && ldo >= nch * 160 && orb_rows >= kdim && ldo % 2 == 0 && ldx <= kdim &&
+            (long)kdim * (kdim + 1) / 2 * 8 + 4096 < (1L << 31) && (long)orb_rows * ldo * 8 < (1L << 32) &&
+            ((uintptr_t)d_orb % 16 == 0) && ((uintptr_t)d_cderi % 8 == 0)) {
+            dim3 gpk(ceil_div(ldx, NT) * nch, nL);
+            if (d_rho)
+                e2_pk_kernel<true><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, d_rho_work,
+                                                        nch, nao);
+            else
+                e2_pk_kernel<false><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, nullptr,
+                                                         nch, nao);
+            PAMD_CHECK_LAUNCH();
+            if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, (int)(gpk.x * 4), st);
+            return 0;
+        }
+    }
     int nchunk = ceil_div(mt_total, g_e2_mtmax);
     int mt = ceil_div(mt_total, nchunk);
     // the kernel writes rows i < nocc_pad only; chunks are mt*16 wide
@@ -916,6 +1118,7 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
     PAMD_REQUIRE(ld % 2 == 0 && ldo % 2 == 0 && ld >= nao && ldx >= nao, "leading dimensions");
     PAMD_REQUIRE(((uintptr_t)d_sq | (uintptr_t)d_orb) % 16 == 0, "16-byte aligned operands");
     if (nL == 0 || nocc_pad == 0) return 0;
+    d_sq += g_sq_shift;            // (probe: misaligned DMA source; results are then meaningless)
     hipStream_t st = (hipStream_t)stream;
     const int mt_total = nocc_pad / 16;                       // orbital MFMA tiles
     const int nchunk = ceil_div(mt_total, 10);

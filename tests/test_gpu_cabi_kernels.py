@@ -198,3 +198,38 @@ def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
             runs.append(r.clone())
         assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
         assert np.abs(runs[0].cpu().numpy() - rho_want).max() < 1e-10 * np.abs(rho_want).max()
+
+
+@pytest.mark.parametrize('nao,naux,nocc', [(200, 9, 150), (145, 4, 310), (272, 3, 139), (100, 3, 150), (1000, 2, 160),
+                                           (129, 5, 160)])
+def test_nr_e2_symm_packed_dma_kernel(nao, naux, nocc):
+    """PAMD_nr_e2_symm on the shapes that take the all-DMA packed-operand kernel (160-orbital chunks): transposed tiles above
+    the diagonal, row tiles below, the crossing tiles visited twice with the keep-masks - against numpy and against the
+    register-staged kernel (tuning key pkdma = 0), including the fused first J pass and ragged nao (pad rows / columns)."""
+    torch, so, dev, st, lib = _setup()
+    from pyscf_amd.df import df_jk
+    rng = np.random.default_rng(nao * 7 + nocc)
+    npair = nao * (nao + 1) // 2
+    tril = rng.standard_normal((naux, npair))
+    c = rng.standard_normal((nao, nocc))
+    full = lib.unpack_tril(tril)
+    want = np.einsum('Lpq,qi->Lip', full, c)
+    rho_want = np.einsum('Lpq,pq->L', full, c.dot(c.T))
+    t_tril = torch.from_numpy(tril).to(dev)
+    orb, nocc_pad, ldo = df_jk.pad_orbitals(c, dev)
+    ldx = (nao + 15) // 16 * 16
+    so.PAMD_nr_e2_rho_worksize.restype = C.c_long
+    work = torch.zeros(max(1, so.PAMD_nr_e2_rho_worksize(naux, ldx, nocc_pad)), dtype=torch.float64, device=dev)
+    outs = {}
+    for flag in (1, 0):
+        lib.check(so.PAMD_set_tuning(b'pkdma', flag))
+        x = torch.full((naux, nocc_pad, ldx), 7.0, dtype=torch.float64, device=dev)
+        rho = torch.zeros(naux, dtype=torch.float64, device=dev)
+        lib.check(so.PAMD_nr_e2_symm(_p(t_tril), C.c_long(npair), naux, nao, _p(orb), ldo, orb.shape[0], nocc_pad, _p(x), ldx,
+                                     _p(rho), _p(work), st))
+        got = x[:, :nocc, :nao].cpu().numpy()
+        assert np.abs(got - want).max() < 1e-11 * np.abs(want).max(), flag
+        assert np.abs(rho.cpu().numpy() - rho_want).max() < 1e-10 * np.abs(rho_want).max(), flag
+        outs[flag] = got
+    lib.check(so.PAMD_set_tuning(b'pkdma', 1))
+    assert np.abs(outs[0] - outs[1]).max() < 1e-11 * np.abs(want).max()
