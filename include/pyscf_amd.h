@@ -229,6 +229,7 @@ int PAMD_reduce_sym(const double *d_part, int nsplit, int m, int ldc, double *d_
  * its active functions compacted, ao_c[t] = [ncomp][G][ld_t] at d_ao_c + d_ao_off[t] (ld_t = d_ld[t], a multiple of 16),
  * and d_idx[d_idx_off[t] + mu] is the AO index of compact column mu (>= nao for padding).  One launch per product covers
  * all `ntile` tiles handed to the call. */
+int PAMD_set_tuning_xc(const char *key, int value);      /* benchmarking switch: "orbdotdma" = 0/1 */
 int PAMD_sub_gather_ao(const double *d_dense, long dense_rows, int ldao, int ncomp, long row0, long nrows_valid,
                        const long *d_ao_off, const long *d_idx_off, const int *d_ld, const int *d_idx, int ntile, int G,
                        int ld_max, int nao, double *d_ao_c, void *stream);     /* ao_c <- columns of a PAMD_eval_ao block */

@@ -14,10 +14,13 @@
 //   sub_vmat      M[idx[mu]][idx[nu]] += sum_{g in tile} ao_c[0][g][mu] aow_c[g][nu]  (LDS-DMA GEMM, scatter-add)
 //
 // idx[tile][ld_t] maps a compact column to its AO index (>= nao for padding columns).
+#include <type_traits>
 #include "common.h"
 #include "mfma_e2.h"
 
 using namespace pamd;
+
+static int g_orb_dot_dma = 1;
 
 namespace {
 
@@ -43,6 +46,109 @@ __global__ __launch_bounds__(256, 2) void sub_orb_dot_kernel(const double *__res
                                  blockIdx.x * NT, chunk * (MT * 16));
 }
 
+// The same product for 160-orbital chunks with every operand by buffer-resource LDS-DMA (the scheme of e2_sq2 / e2_pk in
+// df_jk.hip).  MFMA roles: m = orbital (A: gathered rows orb[idx[mu]], 128 columns by one row DMA + the 32 remainder
+// columns of the wave's four rows by one DMA with per-lane row addresses), n = grid point, k = compact AO index.  The B
+// operand ao_c[c][g][mu] is contiguous in k for a fixed n - the "transposed" case of e2_pk: one DMA moves eight grid
+// rows x 16 mu with per-lane source addresses into XOR-swizzled 16-byte chunks.  grid: x = 128-point slice, y = component,
+// z = tile * nchunk + chunk.
+__global__ __launch_bounds__(256, 2) void sub_orb_dot2_kernel(const double *__restrict__ ao_c, SubTiles tl, int G, int nchunk,
+                                                              const double *__restrict__ orb, int ldo, int nocc_pad,
+                                                              double *__restrict__ cmo, long comp_stride, long ldc)
+{
+    __shared__ double sa0[KB * LDN + KB * 32];
+    __shared__ double sa1[KB * LDN + KB * 32];
+    __shared__ double sq0[KB * LDN];
+    __shared__ double sq1[KB * LDN];
+    constexpr int RB = KB * LDN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = blockIdx.z / nchunk, chunk = blockIdx.z - t * nchunk;
+    const int ld = tl.ld[t];
+    const int n0 = blockIdx.x * NT, m0 = chunk * 160;
+    const int *idx = tl.idx + tl.idx_off[t];
+    const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(ao_c + tl.ao_off[t] + ((long)blockIdx.y * G + n0) * ld), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_orb = __builtin_amdgcn_make_buffer_rsrc((void *)(orb + m0), 0, 0xffffffff, 0x00020000);
+    const int ldo8 = ldo * 8;
+    const int voff = lane * 16;
+    const int rrow = lane >> 4;
+    const int voff_remcol = (128 + ((((lane & 15) * 2) - 16 * (rrow & 1)) & 31)) * 8;      // + idx[row] * ldo8 per k-tile
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+    const int offa = fk * LDN + wr * 64 + fn;
+    const int offr = RB + fk * 32 + ((wr * 16 + fn + 16 * (fk & 1)) & 31);
+    const int pl = fn & 7, bodd = (fn >> 3) & 1;
+    const int offb_tr = (wc * 8 + (fn >> 3)) * 128 + (((pl ^ bodd) * 8) + ((fk >> 1) ^ (pl & 1))) * 2 + (fk & 1);
+    int atr[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) atr[g] = offb_tr + (((2 * g) ^ (pl & 6))) * 2;
+    int voff_tr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int blk = wave * 4 + j;
+        const int pl_s = (lane >> 3) ^ (blk & 1);
+        const int kp = (lane & 7) ^ pl_s;
+        voff_tr[j] = ((blk * 8 + pl_s) * ld + 2 * kp) * 8;
+    }
+
+    double4_t acc[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    auto stage_row = [&](int k0, double *da, double *db, int j) {
+        const int k = wave * 4 + j;
+        const int row = idx[k0 + k];                                   // wave-uniform: a scalar load
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_orb, (__attribute__((address_space(3))) void *)(da + k * LDN), 16, voff, row * ldo8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_b, (__attribute__((address_space(3))) void *)(db + k * 128), 16, voff_tr[j], k0 * 8, 0, 0);
+        if (j == 0) {
+            const int rowl = idx[k0 + wave * 4 + rrow];               // per 16-lane group: its own gathered row
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_orb, (__attribute__((address_space(3))) void *)(da + RB + wave * 128), 16,
+                                                     rowl * ldo8 + voff_remcol, 0, 0, 0);
+        }
+    };
+    auto step = [&](const double *ca, const double *cb, double *na, double *nb, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kn = (k0 + KB < ld) ? k0 + KB : k0;
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[5], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
+            af[4] = ca[offr + kk * 32];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = cb[atr[kk >> 2] + b * 256];
+            stage_row(kn, na, nb, kk >> 2);
+#pragma unroll
+            for (int a = 0; a < 5; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
+    for (int k0 = 0; k0 < ld; k0 += 2 * KB) {
+        step(sa0, sq0, sa1, sq1, k0);
+        if (k0 + KB < ld) step(sa1, sq1, sa0, sq0, k0 + KB);
+    }
+    double *out = cmo + (long)blockIdx.y * comp_stride + (long)t * G;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int n = n0 + wc * 64 + b * 16 + fn;
+            if (n >= G) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = m0 + (a < 4 ? wr * 64 + a * 16 : 128 + wr * 16) + fk + 4 * r;
+                if (i < nocc_pad) out[(long)i * ldc + n] = acc[a][b][r];
+            }
+        }
+}
+
 // aow_c[tile][g][mu] = sum_c wv[c][tile*G + g] ao_c[tile][c][g][mu];  grid: x = column chunk, y = g, z = tile
 __global__ __launch_bounds__(256) void sub_scale_kernel(const double *__restrict__ ao_c, SubTiles tl, int G, int ncomp,
                                                         const double *__restrict__ wv, long ldg, double *__restrict__ aow_c)
@@ -61,10 +167,9 @@ __global__ __launch_bounds__(256) void sub_scale_kernel(const double *__restrict
 }
 
 // One 128 x 128 block of  ao_c[0]^T aow_c  of one tile per workgroup (work item = {tile, tm, tn}), k = the tile's G grid
-// points; both panels stream HBM/L2 -> LDS by LDS-DMA, double-buffered, one barrier per 16-point k-tile (the loop of
-// gemm_tn_glds_kernel).  MFMA tiles that lie entirely beyond the tile's ld_t columns are skipped (wave-uniform
-// predicates), so the padding of ld_t to the 128-wide block costs loads but no matrix-pipe time.  Epilogue: FP64
-// no-return atomics into M[idx[mu]][idx[nu]].
+// points; both panels stream HBM/L2 -> LDS by buffer-resource LDS-DMA, double-buffered, one barrier per 16-point k-tile
+// (the loop of gemm_tn_glds2_kernel).  MFMA tiles beyond the tile's ld_t columns are skipped at 16-column granularity
+// (one loop instance per live-group count).  Epilogue: FP64 no-return atomics into M[idx[mu]][idx[nu]].
 __global__ __launch_bounds__(256, 2) void sub_vmat_kernel(const double *__restrict__ ao_c, const double *__restrict__ aow_c,
                                                           SubTiles tl, const int *__restrict__ work, int G, int nao,
                                                           double *__restrict__ vmat, long ldv)
@@ -72,20 +177,26 @@ __global__ __launch_bounds__(256, 2) void sub_vmat_kernel(const double *__restri
     __shared__ double sb0[2 * KB * LDN];
     __shared__ double sb1[2 * KB * LDN];
     constexpr int PA = KB * LDN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = work[3 * blockIdx.x], tm = work[3 * blockIdx.x + 1], tn = work[3 * blockIdx.x + 2];
     const int ld = tl.ld[t];
     const int p0 = tm * NT, q0 = tn * NT;
-    const double *A = ao_c + tl.ao_off[t] + p0 + lane * 2;
-    const double *B = aow_c + tl.aow_off[t] + q0 + lane * 2;
+    // buffer-resource LDS-DMA as in gemm_tn_glds2 (df_jk.hip): scalar row offsets, no per-lane address arithmetic, the
+    // rows of k-tile t+1 issued between the MFMA groups of tile t, branch-free k-tile body
+    const __amdgpu_buffer_rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc((void *)(ao_c + tl.ao_off[t] + p0), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc((void *)(aow_c + tl.aow_off[t] + q0), 0, 0xffffffff, 0x00020000);
+    const int voff = lane * 16, ld8 = ld * 8;
     const int wr = wave >> 1, wc = wave & 1;
     const int fk = lane >> 4, fn = lane & 15;
+    const int offa = fk * LDN + wr * 64 + fn, offb = PA + fk * LDN + wc * 64 + fn;
 
-    bool va[4], vb[4];
-#pragma unroll
-    for (int a = 0; a < 4; a++) va[a] = p0 + wr * 64 + a * 16 < ld;
-#pragma unroll
-    for (int b = 0; b < 4; b++) vb[b] = q0 + wc * 64 + b * 16 < ld;
+    // MFMA tiles entirely beyond the tile's ld_t columns are skipped at 16-column granularity: the wave's numbers of live
+    // row / column groups (na, nb in 0..4) are wave-uniform and fixed for the whole k-loop, so the loop is instantiated for
+    // each (na, nb) and chosen once - every instance keeps its k-tile body a single basic block.
+    int na = (ld - (p0 + wr * 64) + 15) / 16, nb = (ld - (q0 + wc * 64) + 15) / 16;
+    na = na < 0 ? 0 : (na > 4 ? 4 : na);
+    nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
 
     double4_t acc[4][4];
 #pragma unroll
@@ -93,39 +204,61 @@ __global__ __launch_bounds__(256, 2) void sub_vmat_kernel(const double *__restri
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
 
-    auto stage = [&](int k0, double *dst) {
+    auto stage_row = [&](int k0, double *dst, int j) {
+        const int k = wave * 4 + j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(dst + k * LDN), 16, voff, (k0 + k) * ld8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_b, (__attribute__((address_space(3))) void *)(dst + PA + k * LDN), 16, voff, (k0 + k) * ld8, 0, 0);
+    };
+    auto kloop = [&](auto NAc, auto NBc) {
+        constexpr int NA = decltype(NAc)::value, NB = decltype(NBc)::value;
+        auto step = [&](const double *cur, double *nxt, int k0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int kn = (k0 + KB < G) ? k0 + KB : k0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = wave * 4 + j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A + (long)(k0 + k) * ld),
-                                             (__attribute__((address_space(3))) void *)(dst + k * LDN), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B + (long)(k0 + k) * ld),
-                                             (__attribute__((address_space(3))) void *)(dst + PA + k * LDN), 16, 0, 0);
+            for (int kk = 0; kk < KB; kk += 4) {
+                double af[4], bf[4];
+#pragma unroll
+                for (int a = 0; a < NA; a++) af[a] = cur[offa + kk * LDN + a * 16];
+#pragma unroll
+                for (int b = 0; b < NB; b++) bf[b] = cur[offb + kk * LDN + b * 16];
+                stage_row(kn, nxt, kk >> 2);
+#pragma unroll
+                for (int a = 0; a < NA; a++)
+#pragma unroll
+                    for (int b = 0; b < NB; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+            }
+        };
+        for (int k0 = 0; k0 < G; k0 += 2 * KB) {
+            step(sb0, sb1, k0);
+            if (k0 + KB < G) step(sb1, sb0, k0 + KB);
         }
     };
-    auto step = [&](const double *cur, double *nxt, int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) stage_row(0, sb0, j);
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    auto pick_b = [&](auto NAc) {
+        switch (nb) {
+        case 1: kloop(NAc, I1{}); break;
+        case 2: kloop(NAc, I2{}); break;
+        case 3: kloop(NAc, I3{}); break;
+        default: kloop(NAc, I4{}); break;
+        }
+    };
+    if (na == 0 || nb == 0) {
+        kloop(I0{}, I0{});                 // nothing to compute: stage the DMA rows only
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (k0 + KB < G) stage(k0 + KB, nxt);
-        const double *sP = cur, *sQ = cur + PA;
-#pragma unroll
-        for (int kk = 0; kk < KB; kk += 4) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int a = 0; a < 4; a++) af[a] = sP[(kk + fk) * LDN + wr * 64 + a * 16 + fn];
-#pragma unroll
-            for (int b = 0; b < 4; b++) bf[b] = sQ[(kk + fk) * LDN + wc * 64 + b * 16 + fn];
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-                    if (va[a] && vb[b]) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
-        }
-    };
-    stage(0, sb0);
-    for (int k0 = 0; k0 < G; k0 += 2 * KB) {
-        step(sb0, sb1, k0);
-        if (k0 + KB < G) step(sb1, sb0, k0 + KB);
+        return;
+    }
+    switch (na) {
+    case 1: pick_b(I1{}); break;
+    case 2: pick_b(I2{}); break;
+    case 3: pick_b(I3{}); break;
+    default: pick_b(I4{}); break;
     }
     const int *idx = tl.idx + tl.idx_off[t];
 #pragma unroll
@@ -168,6 +301,12 @@ __global__ __launch_bounds__(256) void sub_gather_kernel(const double *__restric
 
 extern "C" {
 
+int PAMD_set_tuning_xc(const char *key, int value)
+{
+    if (strcmp(key, "orbdotdma") == 0) { g_orb_dot_dma = value; return 0; }
+    return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
+}
+
 // Tile tables (device): d_ao_off / d_aow_off / d_idx_off [ntile] (doubles / doubles / ints), d_ld [ntile], d_idx.
 // The tile arrays passed to each call are those of the `ntile` tiles the call works on (tile t of the call = entry t).
 
@@ -189,6 +328,14 @@ int PAMD_sub_orb_dot(const double *d_ao_c, const long *d_ao_off, const long *d_i
     SubTiles tl{d_ao_off, nullptr, d_idx_off, d_ld, d_idx};
     dim3 grid(G / NT, ncomp, ntile * nchunk);
     hipStream_t st = (hipStream_t)stream;
+    if (g_orb_dot_dma && mt >= 8 && ldo >= nchunk * 160 && ldo % 2 == 0 && (uintptr_t)d_orb % 16 == 0 &&
+        (uintptr_t)d_ao_c % 16 == 0) {
+        // 160-orbital chunks: all-DMA kernel (padding columns of a tile gather the zero row of d_orb: row index nao, which
+        // must stay below 2^31 / ldo8 - checked by the caller's allocation of d_orb)
+        sub_orb_dot2_kernel<<<grid, 256, 0, st>>>(d_ao_c, tl, G, nchunk, d_orb, ldo, nocc_pad, d_cmo, comp_stride, ldc);
+        PAMD_CHECK_LAUNCH();
+        return 0;
+    }
 #define LAUNCH_S(MT) sub_orb_dot_kernel<MT><<<grid, 256, 0, st>>>(d_ao_c, tl, G, nchunk, d_orb, ldo, nocc_pad, d_cmo, comp_stride, ldc)
     switch (mt) {
     case 1: LAUNCH_S(1); break;
