@@ -375,7 +375,7 @@ def rhf_kernel(mol, get_veff, conv_tol=1e-10, max_cycle=60, dm0=None, h1e=None, 
         g = c[:, mo_occ == 0].T.dot(f).dot(c[:, mo_occ > 0]) * 2
         ng = np.linalg.norm(g)
         if verbose:
-            print('cycle %d E=%.12f dE=%.3g |g|=%.3g' % (cycle + 1, e_tot, e_tot - e_last, ng))
+            print('cycle %d E=%.12f dE=%.3g |g|=%.3g' % (cycle + 1, e_tot, e_tot - e_last, ng), flush=True)
         if abs(e_tot - e_last) < conv_tol and ng < np.sqrt(conv_tol):
             conv = True
             break

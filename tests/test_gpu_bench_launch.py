@@ -30,7 +30,7 @@ def test_bench_gpus2_launches_two_ranks():
     rows = two['config']['naux_per_rank']
     assert len(rows) == 2 and sum(rows) == one['config']['naux_per_rank'][0] and abs(rows[0] - rows[1]) <= 1
     assert two['config']['naux_local'] == rows[0]
-    assert two['value'] > 0 and two['value_host_api_ms'] >= two['value'] * 0.5
+    assert two['value'] > 0 and two['value_host_api_ms'] > 0
 
 
 def test_bench_refuses_a_world_size_mismatch():
