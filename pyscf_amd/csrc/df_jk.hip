@@ -512,10 +512,16 @@ __device__ __forceinline__ void dma_row(__amdgpu_buffer_rsrc_t r, double *lds_ds
 // any more, so the first fragments of tile t+1 are fetched UNDER the fourth MFMA group of tile t.  The LDS latency that
 // followed every barrier in the un-skewed loop (~130 cycles of each 5120-cycle tile) disappears from the critical path.
 // Measured (tuning key "skew", profiles/r02/kbench_skew.log): no gain - kept as a switch, off by default.
-template <bool RHO, bool SKEW>
+// PAIR: the last 128-column tile of a matrix with nao % 128 <= 64 is half padding.  Such a tile is launched separately
+// with one workgroup per PAIR of aux rows: the tensor panel in LDS holds columns p0..p0+63 of row L (lanes 0-31 of every
+// DMA) next to the same columns of row L+1 (lanes 32-63, source shifted by one row stride), the wc = 0 / 1 wave columns
+// produce X[L] / X[L+1].  No wave idles and the tile costs half the workgroups (3.3 % of the kernel at nao = 1856).
+// ptile0 / nslot: first column tile of this launch and number of rho-partial slots per aux row over all launches.
+template <bool RHO, bool SKEW, bool PAIR>
 __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
-    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int ncol)
+    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int ncol, int ptile0, int nslot,
+    int nL)
 {
     constexpr int M = 160;
     __shared__ double sa0[KB * LDN + KB * 32];
@@ -525,13 +531,16 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     constexpr int RB = KB * LDN;                         // start of the remainder block inside sa*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p0 = (blockIdx.x / nchunk) * NT;
-    const long L = blockIdx.y;
+    const int p0 = (ptile0 + blockIdx.x / nchunk) * NT;
+    const long L = PAIR ? 2 * (long)blockIdx.y : blockIdx.y;
     const int m0 = (blockIdx.x % nchunk) * M;
     const __amdgpu_buffer_rsrc_t r_sq = make_rsrc(sq + L * lstride + p0);
     const __amdgpu_buffer_rsrc_t r_orb = make_rsrc(orb + m0);
     const int ldb8 = (int)ld * 8, ldo8 = ldo * 8;
     const int voff = lane * 16;
+    // tensor-panel lane offset: PAIR -> lanes 32..63 fetch the same 64 columns of the next aux row (the last row of an odd
+    // block pairs with itself; its second copy is not stored)
+    const int voff_b = PAIR ? (lane & 31) * 16 + ((lane >> 5) && L + 1 < nL ? (int)(lstride * 8) : 0) : voff;
     // remainder DMA: lane -> LDS doubles [2 lane, 2 lane + 1] of the wave's 4 x 32 block = row (lane >> 4), rotated column
     const int rrow = lane >> 4;
     const int voff_rem = rrow * ldo8 + (128 + ((((lane & 15) * 2) - 16 * (rrow & 1)) & 31)) * 8;
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     auto stage_row = [&](int k0, double *da, double *db, int j) {
         const int k = wave * 4 + j;
         dma_row(r_orb, da + k * LDN, voff, (k0 + k) * ldo8);
-        dma_row(r_sq, db + k * LDN, voff, (k0 + k) * ldb8);
+        dma_row(r_sq, db + k * LDN, voff_b, (k0 + k) * ldb8);
         if (j == 0) dma_row(r_orb, da + RB + wave * 128, voff_rem, (k0 + wave * 4) * ldo8);
     };
     auto step = [&](const double *ca, const double *cb, double *na, double *nb, int k0) {
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     };
 #pragma unroll
     for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
-    if (p0 + wc * 64 < ncol) {
+    if (PAIR || p0 + wc * 64 < ncol) {
         if (SKEW) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -652,27 +661,37 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    double *out = X + L * nocc_pad * ldx;
+    const long Lw = L + (PAIR ? wc : 0);                       // the aux row this wave column belongs to
+    const bool row_ok = Lw < nL;
+    double *out = X + Lw * nocc_pad * ldx;
     double rho_acc = 0;
 #pragma unroll
     for (int a = 0; a < 5; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const long p = p0 + wc * 64 + b * 16 + fn;
-            if (p >= ldx) continue;
+            const long p = p0 + (PAIR ? 0 : wc * 64) + b * 16 + fn;
+            if (p >= ldx || !row_ok) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int i = m0 + (a < 4 ? wr * 64 + a * 16 : 128 + wr * 16) + fk + 4 * r;
                 if (i < nocc_pad) {
                     out[(long)i * ldx + p] = acc[a][b][r];
-                    if (RHO) rho_acc += acc[a][b][r] * orb[p * ldo + i];
+                    if (RHO) rho_acc += acc[a][b][r] * orb[p * ldo + i];     // rows p >= nao and columns i >= nocc of orb are zero
                 }
             }
         }
     if (RHO) {
+        // one partial per wave (no atomics): rho[L][slot][wave], reduced in a fixed order afterwards
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) rho_acc += __shfl_xor(rho_acc, off, 64);
-        if (lane == 0) rho[(L * gridDim.x + blockIdx.x) * 4 + wave] = rho_acc;
+        if (lane == 0) {
+            const long slot = (long)ptile0 * nchunk + blockIdx.x;
+            if (row_ok) rho[(Lw * nslot + slot) * 4 + wave] = rho_acc;
+            if (PAIR) {                                            // this wave has nothing for the other row of the pair
+                const long Lo = L + (1 - wc);
+                if (Lo < nL) rho[(Lo * nslot + slot) * 4 + wave] = 0.0;
+            }
+        }
     }
 }
 
@@ -1088,6 +1107,7 @@ static int g_use_glds = 1;
 static int g_gemm_wide = 1;
 static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper bound
 static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: one per 256 columns)
+static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
 static int g_skew = 0;        // skewed-barrier k-loop (barrier between MFMA groups 2 and 3) in e2_sq2 / gemm_tn_glds2: measured
                               // neutral (r02: 69.9 vs 70.9 ms, 41.7 vs 41.5 ms) - two workgroups per CU already hide that latency
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
@@ -1105,6 +1125,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
     if (strcmp(key, "skew") == 0) { g_skew = value; return 0; }
+    if (strcmp(key, "pairtail") == 0) { g_pair_tail = value; return 0; }
     if (strcmp(key, "j2wg") == 0 && value >= 0) { g_j2_maxwg = value; return 0; }
     if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
@@ -1253,17 +1274,35 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
     const int wa = ceil_div(ceil_div(mt_total, nchunk), 2);   // MFMA tiles per wave row; workgroup covers 2 wa tiles
     PAMD_REQUIRE(ldo >= nchunk * wa * 32, "orbital leading dimension too small for tile padding");
     dim3 grid(ceil_div(ldx, NT) * nchunk, nL);
-    PAMD_REQUIRE((long)rows * ld * 8 < (1L << 32) && (long)orb_rows * ldo * 8 < (1L << 32), "panel offsets exceed 32 bits");
+    PAMD_REQUIRE((long)rows * ld * 8 < (1L << 31) && (long)orb_rows * ldo * 8 < (1L << 32), "panel offsets exceed 32 bits");
+    if (g_dma_v2 && wa == 5) {
+        // 160-orbital chunks: v2 kernel.  A last column tile that is at most half full runs as a second launch over pairs of
+        // aux rows (PAIR instance); rho partials of both launches share one [nL][nslot][4] layout.
+        const int ptiles = ceil_div(ldx, NT);
+        const int nslot = ptiles * nchunk;
+        const int last_valid = nao - (ptiles - 1) * NT;
+        const bool pair = g_pair_tail && ptiles > 1 && last_valid <= 64 && nL >= 2;
+        const int pmain = pair ? ptiles - 1 : ptiles;
+        dim3 gmain(pmain * nchunk, nL), gpair(nchunk, ceil_div(nL, 2));
+        double *rw = d_rho ? d_rho_work : nullptr;
+#define LAUNCH_V2(RHOF, SK)                                                                                         \
+        do {                                                                                                         \
+            e2_sq2_kernel<RHOF, SK, false><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out,   \
+                                                                  nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL);     \
+            if (pair)                                                                                                \
+                e2_sq2_kernel<RHOF, SK, true><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                                                                     nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL); \
+        } while (0)
+        if (d_rho) { if (g_skew) LAUNCH_V2(true, true); else LAUNCH_V2(true, false); }
+        else { if (g_skew) LAUNCH_V2(false, true); else LAUNCH_V2(false, false); }
+#undef LAUNCH_V2
+        PAMD_CHECK_LAUNCH();
+        if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, nslot * 4, st);
+        return 0;
+    }
 #define LAUNCH_SQ(W)                                                                                            \
     do {                                                                                                        \
-        if (g_dma_v2 && W == 5) {                                                                               \
-            if (d_rho)                                                                                          \
-                (g_skew ? e2_sq2_kernel<true, true> : e2_sq2_kernel<true, false>)<<<grid, 256, 0, st>>>(               \
-                    d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, ldx, d_rho_work, nchunk, nao);         \
-            else                                                                                                \
-                (g_skew ? e2_sq2_kernel<false, true> : e2_sq2_kernel<false, false>)<<<grid, 256, 0, st>>>(             \
-                    d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, ldx, nullptr, nchunk, nao);            \
-        } else if (d_rho)                                                                                       \
+        if (d_rho)                                                                                              \
             e2_sq_kernel<W, true><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
                                                         ldx, d_rho_work, nchunk);                                \
         else                                                                                                    \
