@@ -554,4 +554,9 @@ def _download(dfobj, tensors):
         views.append(v)
         off += t.numel()
     torch.cuda.current_stream().synchronize()
-    return [v.numpy().copy() for v in views]
+    outs = []
+    for v in views:                      # staging buffer -> caller-owned arrays (torch's copy is multi-threaded for large tensors)
+        o = np.empty(tuple(v.shape))
+        torch.from_numpy(o).copy_(v)
+        outs.append(o)
+    return outs

@@ -110,6 +110,8 @@ class NumInt:
         return torch.device('cuda', torch.cuda.current_device())
 
     def _world(self):
+        if getattr(self, '_world_override', None) is not None:      # (rank, world) without collectives: tools / tests
+            return self._world_override
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
