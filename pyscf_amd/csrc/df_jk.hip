@@ -506,18 +506,7 @@ __device__ __forceinline__ void dma_row(__amdgpu_buffer_rsrc_t r, double *lds_ds
 // g+1 under the MFMAs of group g.  Wave (wr, wc) owns orbital tiles {64 wr + 16 a, a < 4} and {128 + 16 wr}.
 // A wave whose 64 AO columns all lie beyond `ncol` (the 128-column tile overhangs the matrix) only stages its DMA rows:
 // its matrix-pipe time goes to the co-resident workgroup.
-// SKEW: the barrier of a k-tile sits between its third and fourth MFMA group instead of in front of the first one.  All
-// nine DMAs of tile t+1 are issued during groups 0-2 of tile t; before group 3 the wave waits for them (and for its own
-// last fragment reads of tile t) and meets the others at the barrier; after it tile t+1 is visible and nobody reads tile t
-// any more, so the first fragments of tile t+1 are fetched UNDER the fourth MFMA group of tile t.  The LDS latency that
-// followed every barrier in the un-skewed loop (~130 cycles of each 5120-cycle tile) disappears from the critical path.
-// Measured (tuning key "skew", profiles/r02/kbench_skew.log): no gain - kept as a switch, off by default.
-// PAIR: the last 128-column tile of a matrix with nao % 128 <= 64 is half padding.  Such a tile is launched separately
-// with one workgroup per PAIR of aux rows: the tensor panel in LDS holds columns p0..p0+63 of row L (lanes 0-31 of every
-// DMA) next to the same columns of row L+1 (lanes 32-63, source shifted by one row stride), the wc = 0 / 1 wave columns
-// produce X[L] / X[L+1].  No wave idles and the tile costs half the workgroups (3.3 % of the kernel at nao = 1856).
-// ptile0 / nslot: first column tile of this launch and number of rho-partial slots per aux row over all launches.
-template <bool RHO, bool SKEW, bool PAIR>
+template <bool RHO, bool PAIR>
 __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
     double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int ncol, int ptile0, int nslot,
@@ -589,70 +578,12 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
 #pragma unroll
         for (int j = 0; j < 4; j++) stage_row(kn, na, nb, j);
     };
-    // ---- skewed-barrier form -------------------------------------------------------------------------------------
-    double fa[2][5], fb[2][4];
-    auto frags = [&](const double *ca, const double *cb, int kk, double *af, double *bf) {
-#pragma unroll
-        for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
-        af[4] = ca[offr + kk * 32];
-#pragma unroll
-        for (int b = 0; b < 4; b++) bf[b] = cb[offb + kk * LDN + b * 16];
-    };
-    auto mfmas = [&](const double *af, const double *bf) {
-#pragma unroll
-        for (int a = 0; a < 5; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
-    };
-    auto tile_skew = [&](const double *ca, const double *cb, double *na, double *nb, int k0) {
-        const int kn = (k0 + KB < kdim) ? k0 + KB : k0;
-        frags(ca, cb, 4, fa[1], fb[1]);
-        stage_row(kn, na, nb, 0);
-        mfmas(fa[0], fb[0]);
-        frags(ca, cb, 8, fa[0], fb[0]);
-        stage_row(kn, na, nb, 1);
-        mfmas(fa[1], fb[1]);
-        frags(ca, cb, 12, fa[1], fb[1]);
-        stage_row(kn, na, nb, 2);
-        stage_row(kn, na, nb, 3);
-        mfmas(fa[0], fb[0]);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        frags(na, nb, 0, fa[0], fb[0]);           // first fragments of the next tile, under the last group of this one
-        mfmas(fa[1], fb[1]);
-    };
 #pragma unroll
     for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
     if (PAIR || p0 + wc * 64 < ncol) {
-        if (SKEW) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            frags(sa0, sq0, 0, fa[0], fb[0]);
-            for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
-                tile_skew(sa0, sq0, sa1, sq1, k0);
-                if (k0 + KB < kdim) tile_skew(sa1, sq1, sa0, sq0, k0 + KB);
-            }
-        } else
         for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
             step(sa0, sq0, sa1, sq1, k0);
             if (k0 + KB < kdim) step(sa1, sq1, sa0, sq0, k0 + KB);
-        }
-    } else if (SKEW) {
-        // idle wave, skewed loop: the same barrier sequence as the computing waves (one before the first tile, one per tile
-        // AFTER the DMAs of the next tile have been issued and have landed)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int k0 = 0; k0 < kdim; k0 += KB) {
-            const int kn = (k0 + KB < kdim) ? k0 + KB : k0;
-            if ((k0 / KB) & 1) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) stage_row(kn, sa0, sq0, j);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) stage_row(kn, sa1, sq1, j);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
         }
     } else {
         for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
@@ -873,7 +804,6 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
 }
 
 // 128 x 128 tile of C[split] += A^T B (all tiles, or the lower-triangular ones of the SYRK), v2 DMA scheme
-template <bool SKEW>
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
     double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, int nsplit)
@@ -951,71 +881,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     // a wave whose 64 x 64 block lies entirely beyond the matrix (edge tiles), or entirely above the diagonal of a
     // diagonal SYRK tile, only stages its DMA rows
     const bool idle = p0 + wr * 64 >= m || q0 + wc * 64 >= n || (lower_only && tm == tn && wc > wr);
-    // skewed-barrier form (see e2_sq2_kernel): barrier between MFMA groups 2 and 3, first fragments of tile t+1 under group 3
-    double fa[2][4], fb[2][4];
-    auto frags = [&](const double *cur, int kk, double *af, double *bf) {
-#pragma unroll
-        for (int a = 0; a < 4; a++) af[a] = cur[offa + kk * LDN + a * 16];
-#pragma unroll
-        for (int b = 0; b < 4; b++) bf[b] = cur[offb + kk * LDN + b * 16];
-    };
-    auto mfmas = [&](const double *af, const double *bf) {
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
-    };
-    auto tile_skew = [&](const double *cur, double *nxt, int k0) {
-        const int kn = (k0 + KB < nk) ? k0 + KB : k0;
-        frags(cur, 4, fa[1], fb[1]);
-        stage_row(kn, nxt, 0);
-        mfmas(fa[0], fb[0]);
-        frags(cur, 8, fa[0], fb[0]);
-        stage_row(kn, nxt, 1);
-        mfmas(fa[1], fb[1]);
-        frags(cur, 12, fa[1], fb[1]);
-        stage_row(kn, nxt, 2);
-        stage_row(kn, nxt, 3);
-        mfmas(fa[0], fb[0]);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        frags(nxt, 0, fa[0], fb[0]);
-        mfmas(fa[1], fb[1]);
-    };
     if (!idle) {
-        if (SKEW) {
-            if (nk > 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                frags(sb0, 0, fa[0], fb[0]);
-            }
-            for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
-                tile_skew(sb0, sb1, k0);
-                if (k0 + KB < nk) tile_skew(sb1, sb0, k0 + KB);
-            }
-        } else
         for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
             step(sb0, sb1, k0);
             if (k0 + KB < nk) step(sb1, sb0, k0 + KB);
         }
-    } else if (SKEW) {
-        if (nk > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        for (int k0 = 0; k0 < nk; k0 += KB) {
-            const int kn = (k0 + KB < nk) ? k0 + KB : k0;
-            if ((k0 / KB) & 1) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) stage_row(kn, sb0, j);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) stage_row(kn, sb1, j);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        return;
     } else {
         for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
             step_idle(sb1, k0);
@@ -1108,8 +978,6 @@ static int g_gemm_wide = 1;
 static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper bound
 static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: one per 256 columns)
 static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
-static int g_skew = 0;        // skewed-barrier k-loop (barrier between MFMA groups 2 and 3) in e2_sq2 / gemm_tn_glds2: measured
-                              // neutral (r02: 69.9 vs 70.9 ms, 41.7 vs 41.5 ms) - two workgroups per CU already hide that latency
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
 static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
 static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
@@ -1124,7 +992,6 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "dmav2") == 0) { g_dma_v2 = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
-    if (strcmp(key, "skew") == 0) { g_skew = value; return 0; }
     if (strcmp(key, "pairtail") == 0) { g_pair_tail = value; return 0; }
     if (strcmp(key, "j2wg") == 0 && value >= 0) { g_j2_maxwg = value; return 0; }
     if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
@@ -1285,16 +1152,16 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
         const int pmain = pair ? ptiles - 1 : ptiles;
         dim3 gmain(pmain * nchunk, nL), gpair(nchunk, ceil_div(nL, 2));
         double *rw = d_rho ? d_rho_work : nullptr;
-#define LAUNCH_V2(RHOF, SK)                                                                                         \
+#define LAUNCH_V2(RHOF)                                                                                             \
         do {                                                                                                         \
-            e2_sq2_kernel<RHOF, SK, false><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out,   \
+            e2_sq2_kernel<RHOF, false><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out,   \
                                                                   nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL);     \
             if (pair)                                                                                                \
-                e2_sq2_kernel<RHOF, SK, true><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                e2_sq2_kernel<RHOF, true><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
                                                                      nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL); \
         } while (0)
-        if (d_rho) { if (g_skew) LAUNCH_V2(true, true); else LAUNCH_V2(true, false); }
-        else { if (g_skew) LAUNCH_V2(false, true); else LAUNCH_V2(false, false); }
+        if (d_rho) LAUNCH_V2(true);
+        else LAUNCH_V2(false);
 #undef LAUNCH_V2
         PAMD_CHECK_LAUNCH();
         if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, nslot * 4, st);
@@ -1383,8 +1250,7 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
     const bool v2 = glds && g_dma_v2 && !wide && d_maskA == nullptr &&
                     (kchunk + KB) * (long)((lda > ldb) ? lda : ldb) * 8 < (1L << 32);
     if (v2)
-        (g_skew ? gemm_tn_glds2_kernel<true> : gemm_tn_glds2_kernel<false>)<<<grid, 256, 0, st>>>(
-            d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, nsplit);
+        gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, nsplit);
     else if (glds)
     {
         if (wide)
