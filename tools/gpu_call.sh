@@ -1,8 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_cabi_kernels.py tests/test_gpu_df_jk.py -m gpu -q -x 2>&1 | tail -4 > gpurun_out/pytest_r02o.log
-tail -2 gpurun_out/pytest_r02o.log
-for t in "dmafront=0,xcdmap=0" "dmafront=1,xcdmap=0" "dmafront=0,xcdmap=1" "dmafront=1,xcdmap=1"; do timeout 300 python tools/kbench.py --steps 3 --no-overlap --tag $t --tune $t 2>/dev/null | tail -1 | cut -c1-330; done > gpurun_out/kbench_r02o.log
-cat gpurun_out/kbench_r02o.log
-for t in "dmafront=0" "dmafront=1"; do timeout 300 python tools/kbench.py --steps 3 --no-overlap --no-square --tag nosq_$t --tune $t 2>/dev/null | tail -1 | cut -c1-330; done >> gpurun_out/kbench_r02o.log
-tail -2 gpurun_out/kbench_r02o.log
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/pytest_r02p.log
+tail -6 gpurun_out/pytest_r02p.log
+timeout 600 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r02p.json 2> gpurun_out/bench_r02p.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_r02p.json'))
+print(d['value'], d['value_host_api_ms'], d['roofline']['achieved'], d['roofline']['frac'], {k:v['ms_total'] for k,v in d['kernels'].items()}, d['cpu_baseline']['value'], d['xc_path']['nr_rks_ms_per_call'])
+PY
