@@ -87,9 +87,28 @@ def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale=1.0):
     dsum = dtril * 2
     diag = torch.from_numpy(np.arange(nao) * (np.arange(nao) + 1) // 2 + np.arange(nao)).to(dev)
     dsum[diag] *= .5
+    # aux-sharded tensor (world > 1): this rank holds rows [l0, l1) of cderi.  rho, W, y are row-local; ytil needs the
+    # rho and y of ALL rows (gathered by an all-reduce of zero-padded buffers: works on RCCL and gloo alike), and the
+    # (Z, Y) built below are this rank's PARTIAL sums over its rows - the gradient is linear in them, so every rank
+    # contracts its partials with the derivative integrals and the (natm, 3) results are all-reduced (_grad_2e).
+    world = dfobj.world_size if getattr(dfobj, '_shard_override', None) is None else 1
+    naux_all = mh.shape[0]
+    l0, l1 = dfobj.shard_range(naux_all, dfobj.rank, dfobj.world_size) if world > 1 else (0, naux)
+    assert l1 - l0 == naux
+
+    def gather_rows(x):
+        """[naux_local, ...] -> [naux_all, ...] over the ranks"""
+        if world == 1:
+            return x
+        import torch.distributed as dist
+        full = torch.zeros((naux_all,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        full[l0:l1] = x
+        dist.all_reduce(full, group=dfobj.group)
+        return full
     rho = cderi @ dsum * jscale                                  # rho_L = sum_pq B_L,pq D_pq (full square)
     W = rho[:, None] * dtril[None, :]                            # [L][pq]
-    ytil = -0.5 / jscale * torch.outer(rho, rho) if jscale else torch.zeros((naux, naux), dtype=f64, device=dev)
+    rho_all = gather_rows(rho)
+    ytil = -0.5 / jscale * torch.outer(rho, rho_all) if jscale else torch.zeros((naux, naux_all), dtype=f64, device=dev)
     ldx = (nao + 15) // 16 * 16
     for c, wgt in occ_blocks:
         nocc = c.shape[1]
@@ -109,14 +128,15 @@ def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale=1.0):
             ys[b0:b0 + nb] = y.reshape(nb, -1)
             cyc = torch.matmul(c_dev, torch.matmul(y, c_dev.T))  # C y_L C^T
             W[b0:b0 + nb] -= kscale * wgt * _pack_tril_dev(cyc)
-        ytil += 0.5 * kscale * wgt * (ys @ ys.T)
-    linv = torch.from_numpy(np.ascontiguousarray(mh)).to(dev)
+        ytil += 0.5 * kscale * wgt * (ys @ gather_rows(ys).T)
+    linv = torch.from_numpy(np.ascontiguousarray(mh)).to(dev)    # all rows: [naux_all][nq]
+    linv_loc = linv[l0:l1]
     nq = linv.shape[1]
-    z_t = torch.empty((npair, nq), dtype=f64, device=dev)        # Z_T[pq][Q] = sum_L W[L][pq] Linv[L][Q]
+    z_t = torch.empty((npair, nq), dtype=f64, device=dev)        # Z_T[pq][Q] = sum_L W[L][pq] Linv[L][Q] over the local rows
     step = max(1, int((2 << 30) // (nq * 8)))
     for p0 in range(0, npair, step):
-        torch.matmul(W[:, p0:p0 + step].T, linv, out=z_t[p0:p0 + step])
-    y_pq = linv.T @ ytil @ linv
+        torch.matmul(W[:, p0:p0 + step].T, linv_loc, out=z_t[p0:p0 + step])
+    y_pq = linv_loc.T @ (ytil @ linv)
     return z_t, y_pq
 
 
@@ -127,16 +147,27 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     import torch
     if dfobj._cderi_dev is None:
         dfobj.build()
-    if dfobj.world_size > 1:
-        raise NotImplementedError('gradients with an aux-sharded tensor')
     dev = dfobj._cderi_dev.device
     dfobj.drop_square_image()            # W and Z below each take the size of cderi
+    sharded = dfobj.world_size > 1 and getattr(dfobj, '_shard_override', None) is None
     eng = get_engine(mol, dfobj.auxmol, dev, dfobj.omega)
     naux = eng.aux.nao
+    if sharded:
+        # every rank holds the partial Z_T of its aux rows at FULL size (nao_pair x naux): fine up to BASELINE config 4 on
+        # 288 GB, not at config-5 size - there the W tensor has to be re-sharded by pq slabs first
+        need = eng.ao.nao * (eng.ao.nao + 1) // 2 * naux * 8
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        if need + (16 << 30) > free:
+            raise NotImplementedError('aux-sharded gradient: the partial two-particle density (%.0f GB per rank) does not fit; '
+                                      'the pq-slab re-sharding of W is not built' % (need * 1e-9))
+        grad_total, grad = grad, torch.zeros_like(grad)
     j2c = eng.int2c2e().cpu().numpy()
-    mh = _decompose_j2c((j2c + j2c.T) * .5, dfobj.lindep, getattr(dfobj, 'decompose_j2c', 'CD'))[0]     # as in the tensor build
-    if mh.shape[0] != dfobj._cderi_dev.shape[0]:
-        raise RuntimeError('the tensor has %d rows, the metric decomposes into %d' % (dfobj._cderi_dev.shape[0], mh.shape[0]))
+    mh = _decompose_j2c((j2c + j2c.T) * .5, dfobj.lindep, getattr(dfobj, 'decompose_j2c', 'CD'), dev)[0]     # as in the tensor build
+    nrow_local = dfobj._cderi_dev.shape[0]
+    l0, l1 = dfobj.shard_range(mh.shape[0], dfobj.rank, dfobj.world_size) if sharded else (0, mh.shape[0])
+    if l1 - l0 != nrow_local:
+        raise RuntimeError('the tensor has %d rows here, the metric decomposes into %d (this rank: %d)'
+                           % (nrow_local, mh.shape[0], l1 - l0))
     z_t, y_pq = two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale)
     y_pq = y_pq.contiguous()
     _dbg('Z,Y built')
@@ -165,6 +196,10 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     finally:
         if hasattr(eng, '_omega_override'):
             del eng._omega_override
+    if sharded:
+        import torch.distributed as dist
+        dist.all_reduce(grad, group=dfobj.group)            # sum of the ranks' partial two-electron gradients
+        grad_total += grad
     _dbg('2e done')
     return eng
 

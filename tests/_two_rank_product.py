@@ -63,6 +63,28 @@ def main():
     n0, e0, v0 = ref_dft.nr_rks(mol, grids.coords, grids.weights, fac, True, dm)
     assert abs(n - n0) < 1e-9 and abs(e - e0) < 1e-9 and np.abs(v - v0).max() < 1e-9
     assert ni.sparse_plan(mol, grids, True).nloc < -(-grids.size // 256)         # this rank holds only its tiles
+    # analytic gradients with the aux-sharded tensor (every rank contracts its partial two-particle densities, (natm, 3)
+    # all-reduce) against the same gradient from an unsharded tensor on this rank (shard override: no collectives)
+    from pyscf_amd import scf
+    for xc in ('', 'b3lyp'):
+        mf = (dft.RKS(mol, xc=xc) if xc else scf.RHF(mol)).density_fit(with_df=obj)
+        if xc:
+            mf.grids.level = 1
+        mf.conv_tol = 1e-11
+        mf.kernel()
+        g_shard = mf.nuc_grad_method().kernel()
+        full = df.DF(mol)
+        full._shard_override = (0, 1)
+        full.build()
+        mf1 = (dft.RKS(mol, xc=xc) if xc else scf.RHF(mol)).density_fit(with_df=full)
+        if xc:
+            mf1.grids.level = 1
+            mf1._numint._world_override = (0, 1)
+        mf1.mo_coeff, mf1.mo_occ, mf1.mo_energy, mf1.e_tot, mf1.converged = mf.mo_coeff, mf.mo_occ, mf.mo_energy, mf.e_tot, True
+        g_full = mf1.nuc_grad_method().kernel()
+        assert np.abs(g_shard - g_full).max() < 1e-9, (xc, np.abs(g_shard - g_full).max())
+        if not xc:                                   # (without grid response the XC part is not translationally invariant)
+            assert np.abs(g_shard.sum(axis=0)).max() < 1e-8
     dist.barrier()
     if rank == 0:
         print('TWO_RANK_OK', flush=True)
