@@ -62,6 +62,16 @@ def _dev_const(a):
     return ent[1]
 
 
+def level_shift(s, d, f, factor):
+    """F + factor * S (1 - D S) - the shift acts on the virtual space (hf.py:781-801); d: density of ONE spin."""
+    return f + (s - s.dot(d).dot(s)) * factor
+
+
+def damping(f, f_prev, factor):
+    """hf.py:804-805"""
+    return f * (1 - factor) + f_prev * factor
+
+
 class CDIIS:
     """pyscf/scf/diis.py:40-96 + pyscf/lib/diis.py:225-290 (space 8, min_space 1)."""
 
@@ -154,7 +164,7 @@ def kernel(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, callback=None, conv
         mf_diis.Corth = x_orth
         mf_diis.device_linalg = getattr(mf, 'device_linalg', True)
     mf.cycles = 0
-    fock = None
+    fock = fock_last = None
     if mf.max_cycle <= 0:
         # pyscf/scf/hf.py:150-156: no iteration requested - one eig / get_occ on the initial Fock matrix,
         # the initial-guess energy is returned
@@ -167,12 +177,13 @@ def kernel(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, callback=None, conv
         t0 = time.perf_counter()
         dm_last = dm
         last_hf_e = e_tot
-        fock = mf.get_fock(h1e, s1e, vhf, dm, cycle, mf_diis)
+        fock = mf.get_fock(h1e, s1e, vhf, dm, cycle, mf_diis, fock_last=fock_last)
         mo_energy, mo_coeff = mf.eig(fock, s1e, x=x_orth)
         mo_occ = mf.get_occ(mo_energy, mo_coeff)
         dm = mf.make_rdm1(mo_coeff, mo_occ)
         vhf = mf.get_veff(mol, dm, dm_last, vhf)
         e_tot = mf.energy_tot(dm, h1e, vhf)
+        fock_last = fock                                # the (damped / extrapolated / shifted) matrix that was diagonalised
         fock = mf.get_fock(h1e, s1e, vhf, dm)
         norm_gorb = np.linalg.norm(mf.get_grad(mo_coeff, mo_occ, fock))
         norm_ddm = np.linalg.norm(dm - dm_last)
@@ -209,6 +220,9 @@ class SCF:
     init_guess = 'minao'       # hf.py:1737-1760
     diis = True
     diis_space = 8
+    diis_start_cycle = 1       # hf.py:1752
+    damp = 0                   # hf.py:1756: Fock damping factor before DIIS starts
+    level_shift = 0            # hf.py:1757: shift of the virtual space (a.u.; UHF: a pair)
     direct_scf = True
     direct_scf_tol = 1e-13
     conv_check = True
@@ -262,6 +276,8 @@ class SCF:
     def get_init_guess(self, mol=None, key='1e', s1e=None):
         if key.lower() == 'minao':
             return init_guess_by_minao(mol or self.mol, s1e)
+        if key.lower().startswith('chk'):
+            return self.init_guess_by_chkfile()
         if key.lower() not in ('1e', 'hcore'):
             raise NotImplementedError("init_guess %s ('minao' and '1e' are restated; hf.py:354-498)" % key)
         h1e = self.get_hcore()
@@ -310,12 +326,17 @@ class SCF:
         dm = (mocc * mo_occ[mo_occ > 0]).dot(mocc.conj().T)
         return tag_array(dm, mo_coeff=mo_coeff, mo_occ=mo_occ)
 
-    def get_fock(self, h1e, s1e, vhf, dm, cycle=-1, diis=None):
+    def get_fock(self, h1e, s1e, vhf, dm, cycle=-1, diis=None, fock_last=None):
+        """hf.py:1098-1146: damping before DIIS starts, DIIS from diis_start_cycle, level shift of the virtual space."""
         f = h1e + vhf
-        if cycle < 0 or diis is None:
+        if cycle < 0 and diis is None:
             return f
-        if cycle >= 1:                                   # diis_start_cycle = 1
+        if 0 <= cycle < self.diis_start_cycle - 1 and abs(self.damp) > 1e-4 and fock_last is not None:
+            f = damping(f, fock_last, self.damp)
+        if diis is not None and cycle >= self.diis_start_cycle:
             f = diis.update(s1e, dm, f)
+        if abs(self.level_shift) > 1e-4:
+            f = level_shift(s1e, np.asarray(dm) * .5, f, self.level_shift)
         return f
 
     def get_grad(self, mo_coeff, mo_occ, fock):
@@ -362,7 +383,29 @@ class SCF:
     def kernel(self, dm0=None):
         self.converged, self.e_tot, self.mo_energy, self.mo_coeff, self.mo_occ = kernel(
             self, self.conv_tol, self.conv_tol_grad, dm0=dm0, conv_check=self.conv_check)
+        if self.chkfile:
+            self.dump_chk()
         return self.e_tot
+
+    chkfile = None             # path: results are written there after kernel() (the reference keeps an HDF5 chkfile,
+                               # scf/chkfile.py; h5py is absent here, so the same fields go into an .npz archive)
+
+    def dump_chk(self, path=None):
+        """scf/chkfile.py:dump_scf: e_tot, mo_energy, mo_coeff, mo_occ (+ the integral tables of the molecule)."""
+        path = path or self.chkfile
+        with open(path, 'wb') as f:
+            np.savez(f, e_tot=self.e_tot, mo_energy=self.mo_energy, mo_coeff=self.mo_coeff, mo_occ=self.mo_occ,
+                     atm=self.mol._atm, bas=self.mol._bas, env=self.mol._env)
+        return path
+
+    def init_guess_by_chkfile(self, path=None):
+        """Density of the orbitals stored by dump_chk, for the SAME molecule and basis (hf.py:679-742 restart without the
+        basis projection of scf/addons.project_mo_nr2nr); tagged with the orbitals like make_rdm1."""
+        path = path or self.chkfile
+        with np.load(path) as z:
+            if z['bas'].shape != self.mol._bas.shape or not np.array_equal(z['bas'][:, :4], self.mol._bas[:, :4]):
+                raise NotImplementedError('chkfile restart across different basis sets (orbital projection)')
+            return self.make_rdm1(z['mo_coeff'], z['mo_occ'])
 
     scf = kernel
 

@@ -81,7 +81,7 @@ class ROHF(hf.SCF):
         self._log('df vj and vk: %.4f s', time.perf_counter() - t0)
         return vj[0] + vj[1] - vk
 
-    def get_fock(self, h1e, s1e, vhf, dm, cycle=-1, diis=None):
+    def get_fock(self, h1e, s1e, vhf, dm, cycle=-1, diis=None, fock_last=None):
         dm = np.asarray(dm)
         if dm.ndim == 2:
             dm = np.array((dm * .5, dm * .5))
@@ -89,7 +89,7 @@ class ROHF(hf.SCF):
         f = get_roothaan_fock((focka, fockb), dm, s1e)
         if cycle < 0 or diis is None:
             return f
-        if cycle >= 1:
+        if cycle >= self.diis_start_cycle:
             f = tag_array(diis.update(s1e, dm[0] + dm[1], np.asarray(f)), focka=focka, fockb=fockb)
         return f
 

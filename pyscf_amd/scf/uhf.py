@@ -60,12 +60,20 @@ class UHF(hf.SCF):
         ecoul = np.einsum('nij,ji->', np.asarray(dm), vj).real * .5
         return tag_array(vhf, ecoul=ecoul)
 
-    def get_fock(self, h1e, s1e, vhf, dm, cycle=-1, diis=None):
+    def get_fock(self, h1e, s1e, vhf, dm, cycle=-1, diis=None, fock_last=None):
+        """uhf.py:297-337: as the restricted form per spin; level_shift may be a pair (alpha, beta)."""
         f = h1e + vhf
-        if cycle < 0 or diis is None:
+        if cycle < 0 and diis is None:
             return f
-        if cycle >= 1:
+        shift = self.level_shift
+        shifta, shiftb = shift if isinstance(shift, (tuple, list, np.ndarray)) else (shift, shift)
+        if 0 <= cycle < self.diis_start_cycle - 1 and abs(self.damp) > 1e-4 and fock_last is not None:
+            f = hf.damping(f, np.asarray(fock_last), self.damp)
+        if diis is not None and cycle >= self.diis_start_cycle:
             f = diis.update(s1e, dm, f)
+        if abs(shifta) + abs(shiftb) > 1e-4:
+            dm = np.asarray(dm)
+            f = np.array((hf.level_shift(s1e, dm[0], f[0], shifta), hf.level_shift(s1e, dm[1], f[1], shiftb)))
         return f
 
     def get_grad(self, mo_coeff, mo_occ, fock):

@@ -350,3 +350,46 @@ def test_grad_nuc_with_ghost_atom_on_a_nucleus():
     assert np.all(np.isfinite(g)) and np.abs(g[3]).max() == 0
     ref_mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis='sto-3g')
     assert np.abs(g[:3] - grad_rhf.grad_nuc(ref_mol)).max() < 1e-14
+
+
+def test_level_shift_and_damping_reach_the_same_energy():
+    """get_fock with damping before DIIS starts and a level shift of the virtual space (pyscf/scf/hf.py:1098-1146,
+    :781-805): the converged energy is the exact-RHF golden whatever the convergence aids; the shifted Fock matrix itself
+    is F + shift * S (1 - D/2 S)."""
+    from pyscf_amd import gto
+    from pyscf_amd.scf import hf
+    from tests.conftest import H2O
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    for kw in (dict(level_shift=0.3), dict(damp=0.5, diis_start_cycle=4), dict(level_shift=0.2, damp=0.3, diis_start_cycle=3)):
+        mf = _oracle_rhf(mol)
+        mf.conv_tol = 1e-11
+        mf.max_cycle = 100
+        for k, v in kw.items():
+            setattr(mf, k, v)
+        e = mf.kernel()
+        assert mf.converged and abs(e - -76.026765673119627) < 1e-9, (kw, e)
+    s, dm = mf.get_ovlp(), mf.make_rdm1()
+    f0 = mf.get_hcore() + mf.get_veff(mol, dm)
+    f1 = hf.level_shift(s, dm * .5, f0, 0.7)
+    c = mf.mo_coeff
+    fmo0, fmo1 = c.T.dot(f0).dot(c), c.T.dot(f1).dot(c)
+    nocc = mol.nelectron // 2
+    assert np.abs(np.diag(fmo1 - fmo0)[:nocc]).max() < 1e-10 and np.abs(np.diag(fmo1 - fmo0)[nocc:] - 0.7).max() < 1e-10
+
+
+def test_chkfile_restart(tmp_path):
+    """mf.chkfile / init_guess='chkfile' (pyscf/scf/hf.py:679-742, same basis): a restart from the stored orbitals converges
+    at once to the same energy."""
+    from pyscf_amd import gto
+    from tests.conftest import H2O
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    mf = _oracle_rhf(mol)
+    mf.chkfile = str(tmp_path / 'scf.npz')
+    mf.conv_tol = 1e-11
+    e = mf.kernel()
+    mf2 = _oracle_rhf(mol)
+    mf2.chkfile = mf.chkfile
+    mf2.init_guess = 'chkfile'
+    mf2.conv_tol = 1e-11
+    e2 = mf2.kernel()
+    assert mf2.converged and abs(e2 - e) < 1e-10 and mf2.cycles <= 2
