@@ -207,6 +207,21 @@ class DF:
         import torch
         dev = self._device()
         if isinstance(self._cderi, str):
+            from ..lib import hdf5
+            if hdf5.is_hdf5(self._cderi):
+                # the reference's own format: dataset 'j3c' (naux, nao_pair) (pyscf/df/df.py:97-99, outcore.py:217-221);
+                # every rank reads exactly its aux rows
+                with hdf5.File(self._cderi) as f:
+                    d = f['j3c']
+                    naux = d.shape[0]
+                    l0, l1 = self.shard_range(naux, self.rank, self.world_size)
+                    self._cderi_dev = torch.empty((l1 - l0, d.shape[1]), dtype=torch.float64, device=dev)
+                    step = max(1, (1 << 30) // (d.shape[1] * 8))
+                    for r0 in range(l0, l1, step):
+                        r1 = min(r0 + step, l1)
+                        self._cderi_dev[r0 - l0:r1 - l0] = torch.from_numpy(d.read_rows(r0, r1)).to(dev)
+                self._naux = naux
+                return self
             shard = self._shard_path(self._cderi)
             if self.world_size > 1 and os.path.exists(shard):
                 # written by save() of a run with the same world size: this rank's rows, no re-sharding
@@ -333,14 +348,33 @@ class DF:
     def _shard_path(self, path):
         return '%s.rank%dof%d.npz' % (path, self.rank, self.world_size)
 
-    def save(self, path=None):
-        """Write the tensor to disk (the reference writes the HDF5 dataset 'j3c', pyscf/df/df.py:97-99,185-199; h5py is
-        not available in this image).  One rank: `path` is a .npy file holding the full (naux, nao_pair) array.  Several
-        ranks: every rank writes its own rows to `path.rank<r>of<w>.npz` together with (l0, l1, naux) - never the shared
-        `path` - and `DF(mol)._cderi = path` loads them back in build() without re-sharding."""
+    def save(self, path=None, fmt=None):
+        """Write the tensor to disk.  fmt 'hdf5' (default when libhdf5 is found and the path does not end in .npy): ONE file
+        with the dataset 'j3c' (naux, nao_pair) - the reference's `_cderi` file (pyscf/df/df.py:97-99,185-199,
+        outcore.py:217-221; readable by stock PySCF / h5py); with several ranks rank 0 creates it and the ranks write their
+        row ranges one after the other.  fmt 'npy': a .npy file of the full array (one rank), or per-rank
+        `path.rank<r>of<w>.npz` archives with (l0, l1, naux).  `DF(mol)._cderi = path` loads either back in build()."""
+        from ..lib import hdf5
         path = path or self._cderi_to_save
         if self._cderi_dev is None:
             self.build()
+        if fmt is None:
+            fmt = 'hdf5' if (hdf5.available() and not path.endswith(('.npy', '.npz'))) else 'npy'
+        if fmt == 'hdf5':
+            naux, npair = self._naux, self._cderi_dev.shape[1]
+            l0, l1 = self.shard_range(naux, self.rank, self.world_size) if self.world_size > 1 else (0, naux)
+            step = max(1, (1 << 30) // (npair * 8))
+            for turn in range(self.world_size):
+                if turn == self.rank:
+                    with hdf5.File(path, 'w' if turn == 0 else 'r+') as f:
+                        d = f.create_dataset('j3c', (naux, npair)) if turn == 0 else f['j3c']
+                        for r0 in range(l0, l1, step):
+                            r1 = min(r0 + step, l1)
+                            d.write_rows(r0, self._cderi_dev[r0 - l0:r1 - l0].cpu().numpy())
+                if self.world_size > 1 and getattr(self, '_shard_override', None) is None:
+                    import torch.distributed as dist
+                    dist.barrier(group=self.group)
+            return path
         if self.world_size > 1:
             l0, l1 = self.shard_range(self._naux, self.rank, self.world_size)
             out = self._shard_path(path)

@@ -43,7 +43,7 @@ def main():
     assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9
     # shards written per rank, reloaded without re-sharding
     tmp = os.path.join(tempfile.gettempdir(), 'pamd_two_rank_cderi')
-    out = obj.save(tmp)
+    out = obj.save(tmp, fmt='npy')
     assert out.endswith('.rank%dof%d.npz' % (rank, world))
     dist.barrier()
     obj2 = df.DF(mol)
@@ -52,6 +52,20 @@ def main():
     assert obj2.get_naoaux() == naux and torch.equal(obj2._cderi_dev, obj._cderi_dev)
     vj2, vk2 = obj2.get_jk(dms, hermi=0)
     assert np.abs(vk2 - vk).max() < 1e-12
+    # the reference's format: ONE HDF5 file, dataset 'j3c' (naux, nao_pair); the ranks write / read their row ranges
+    from pyscf_amd.lib import hdf5
+    if hdf5.available():
+        h5 = tmp + '.h5'
+        obj.save(h5)
+        if rank == 0:
+            with hdf5.File(h5) as f:
+                d = f['j3c']
+                assert d.shape == cderi.shape and np.abs(d.read_rows(0, naux) - cderi).max() < 1e-9
+        dist.barrier()
+        obj3 = df.DF(mol)
+        obj3._cderi = h5
+        obj3.build()
+        assert obj3.get_naoaux() == naux and torch.equal(obj3._cderi_dev, obj._cderi_dev)
     # XC: grid tiles dealt round-robin, vmat / nelec / exc all-reduced
     grids = dft.Grids(mol)
     grids.level = 1

@@ -232,3 +232,27 @@ def test_host_eigensolvers_of_the_response_drivers():
     wa, va = np.linalg.eigh(aug)
     assert abs(w - wa[0]) < 1e-12 and np.abs(step - va[1:, 0] / va[0, 0]).max() < 1e-8
     assert g.dot(step) < 0                                           # a descent direction
+
+
+def test_hdf5_j3c_roundtrip_through_libhdf5(tmp_path):
+    """lib/hdf5.py (ctypes on libhdf5, no h5py): the 'j3c' dataset written in row blocks reads back exactly, also by
+    arbitrary row ranges - the access pattern of DF.loop and of the aux-row shards."""
+    from pyscf_amd.lib import hdf5
+    if not hdf5.available():
+        pytest.skip('libhdf5 not found')
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((53, 301))
+    path = str(tmp_path / 'cderi.h5')
+    with hdf5.File(path, 'w') as f:
+        d = f.create_dataset('j3c', a.shape)
+        for r0 in range(0, 53, 16):
+            d.write_rows(r0, a[r0:r0 + 16])
+    assert hdf5.is_hdf5(path) and not hdf5.is_hdf5(__file__)
+    with hdf5.File(path) as f:
+        d = f['j3c']
+        assert d.shape == a.shape
+        assert np.array_equal(d.read_rows(0, 53), a) and np.array_equal(d.read_rows(17, 40), a[17:40])
+    with hdf5.File(path, 'r+') as f:
+        f['j3c'].write_rows(10, a[:5] * 2)
+    with hdf5.File(path) as f:
+        assert np.array_equal(f['j3c'].read_rows(10, 15), a[:5] * 2)

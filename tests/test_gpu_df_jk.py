@@ -199,6 +199,21 @@ def test_get_eri_ao2mo_and_npy_roundtrip(h2o, tmp_path):
     assert np.abs(obj2.get_eri() - obj.get_eri()).max() < 1e-12
     blocks = np.vstack(list(obj2.loop(40)))
     assert np.abs(blocks - cderi).max() < 1e-14
+    # HDF5 'j3c' (the reference's _cderi file, pyscf/df/df.py:97-99,185-199) through libhdf5
+    from pyscf_amd.lib import hdf5
+    if hdf5.available():
+        h5 = str(tmp_path / 'cderi.h5')
+        assert obj.save(h5) == h5 and hdf5.is_hdf5(h5)
+        with hdf5.File(h5) as f:
+            assert f['j3c'].shape == cderi.shape
+        obj3 = df.DF(mol)
+        obj3._cderi = h5
+        assert obj3.get_naoaux() == cderi.shape[0]
+        assert np.abs(np.vstack(list(obj3.loop(33))) - cderi).max() < 1e-14
+        obj4 = df.DF(mol)
+        obj4._cderi_to_save = str(tmp_path / 'auto.h5')           # written by build(), as the reference does
+        obj4.build()
+        assert hdf5.is_hdf5(obj4._cderi_to_save)
 
 
 def test_hermitian_dm_without_orbitals_is_factorized(h2o):
