@@ -256,3 +256,24 @@ def test_hdf5_j3c_roundtrip_through_libhdf5(tmp_path):
         f['j3c'].write_rows(10, a[:5] * 2)
     with hdf5.File(path) as f:
         assert np.array_equal(f['j3c'].read_rows(10, 15), a[:5] * 2)
+
+
+def test_hdf5_interoperates_with_h5py(tmp_path):
+    """Files written by lib/hdf5.py open in h5py (what stock PySCF uses for `_cderi`) and the other way round.  h5py is not
+    importable by this interpreter; the image's conda python3.9 has it - skipped where that is missing."""
+    import subprocess
+    from pyscf_amd.lib import hdf5
+    py = '/opt/conda/bin/python3.9'
+    if not hdf5.available() or not os.path.exists(py) or subprocess.run([py, '-c', 'import h5py']).returncode != 0:
+        pytest.skip('no interpreter with h5py')
+    a = np.arange(84.0).reshape(12, 7) / 7
+    ours, theirs = str(tmp_path / 'ours.h5'), str(tmp_path / 'theirs.h5')
+    with hdf5.File(ours, 'w') as f:
+        f.create_dataset('j3c', a.shape).write_rows(0, a)
+    code = ("import h5py, numpy as np\\n"
+            "f = h5py.File(%r, 'r'); d = f['j3c']\\n"
+            "assert d.shape == (12, 7) and d.dtype == np.float64 and abs(d[5, 3] - (5 * 7 + 3) / 7) < 1e-15\\n"
+            "g = h5py.File(%r, 'w'); g['j3c'] = d[()] * 2; g.close()\\n" % (ours, theirs))
+    assert subprocess.run([py, '-c', code]).returncode == 0
+    with hdf5.File(theirs) as f:
+        assert np.array_equal(f['j3c'].read_rows(0, 12), a * 2)
