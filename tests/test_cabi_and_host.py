@@ -270,10 +270,10 @@ def test_hdf5_interoperates_with_h5py(tmp_path):
     ours, theirs = str(tmp_path / 'ours.h5'), str(tmp_path / 'theirs.h5')
     with hdf5.File(ours, 'w') as f:
         f.create_dataset('j3c', a.shape).write_rows(0, a)
-    code = ("import h5py, numpy as np\\n"
-            "f = h5py.File(%r, 'r'); d = f['j3c']\\n"
-            "assert d.shape == (12, 7) and d.dtype == np.float64 and abs(d[5, 3] - (5 * 7 + 3) / 7) < 1e-15\\n"
-            "g = h5py.File(%r, 'w'); g['j3c'] = d[()] * 2; g.close()\\n" % (ours, theirs))
+    code = '\n'.join(["import h5py, numpy as np",
+                      "f = h5py.File(%r, 'r'); d = f['j3c']" % ours,
+                      "assert d.shape == (12, 7) and d.dtype == np.float64 and abs(d[5, 3] - (5 * 7 + 3) / 7) < 1e-15",
+                      "g = h5py.File(%r, 'w'); g['j3c'] = d[()] * 2; g.close()" % theirs])
     assert subprocess.run([py, '-c', code]).returncode == 0
     with hdf5.File(theirs) as f:
         assert np.array_equal(f['j3c'].read_rows(0, 12), a * 2)
