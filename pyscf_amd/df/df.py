@@ -33,7 +33,7 @@ class DF:
         self.group = group
         # HBM budget for the half-transformed block X (MI355X: 288 GB per GPU)
         self.k_block_bytes = 8 << 30
-        self.k_nsplit = 4
+        self.k_nsplit = None       # k-splits of the K = X^T X product; None: df_jk.syrk_plan picks tile shape and splits
         self.lindep = 1e-7         # pyscf/df/incore.py:33
         self.decompose_j2c = 'CD'  # 'ED': eigen-decompose the metric even when it is positive definite (df/grad/rhf.py:45)
         self.omega = 0.0           # > 0: long-range, < 0: short-range tensor (set by range_coulomb)

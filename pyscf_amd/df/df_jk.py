@@ -136,6 +136,16 @@ def _rho_work(dfobj, lib, nb, ldx, nocc_pad):
     return _ptr(dfobj._workspace('rho_work', (max(int(n), 1),)))
 
 
+def syrk_plan(nao, nsplit=None, slots=512):
+    """(flags, nsplit) of the K = X^T X product on 128 x 128 lower-triangular tiles: as many k-splits as keep tiles x splits
+    within ONE round of the chip's workgroup slots (256 CUs x 2; nao = 1856: 120 tiles x 4 = 480).  Measured alternatives
+    that lost (profiles/r02): 17 splits in four full rounds (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits = 510 slots
+    (42.0 vs 41.6 ms)."""
+    t128 = -(-nao // 128)
+    n_sq = t128 * (t128 + 1) // 2
+    return 1 | 2, nsplit or max(1, min(8, slots // n_sq))
+
+
 def pad_orbitals(orbo, device):
     """Host (nao, nocc) occupied-orbital block C_occ*sqrt(occ) -> zero-padded device operand
     (orb[nao][ldo], nocc_pad) in the layout PAMD_nr_e2_symm expects."""
@@ -161,7 +171,7 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
     dev = cderi.device
     st = _stream()
     ldx = _round_up(nao, 16)
-    nsplit = dfobj.k_nsplit
+    syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit)
     vks = []
     for iset, (orb, nocc_pad, ldo) in enumerate(orb_list):
         vk = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
@@ -191,7 +201,7 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
             if after_e2 is not None:
                 after_e2(b0, nb, iset)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
-                  _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(1 | 2),
+                  _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(syrk_flags),
                   _c.c_int(nsplit), st)
         _call(dfobj, 'reduce_splits', lib.PAMD_reduce_splits, _ptr(part), _c.c_int(nsplit), _c.c_int(nao),
               _c.c_int(nao), _ptr(vk), _c.c_int(nao), _c.c_int(1), st)
@@ -209,7 +219,7 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
     ldx = _round_up(nao, 16)
     rows = _round_up(nao, 16)
     ldo = _round_up(rows, 160) if rows > 160 else rows
-    nsplit = dfobj.k_nsplit
+    nsplit = dfobj.k_nsplit or 4
     blk = max(1, _k_blocksize(dfobj, naux, rows, ldx) // 2)
     vk = torch.zeros((nset, nao, nao), dtype=torch.float64, device=dev)
     if naux == 0:
@@ -264,7 +274,7 @@ def _vk_lowrank(dfobj, lib, lefts, rights, sym, nao):
     st = _stream()
     nset = len(lefts)
     ldx = _round_up(nao, 16)
-    nsplit = dfobj.k_nsplit
+    nsplit = dfobj.k_nsplit or 4
     vk = torch.zeros((nset, nao, nao), dtype=torch.float64, device=dev)
     if naux == 0:
         return vk
