@@ -136,14 +136,11 @@ def _rho_work(dfobj, lib, nb, ldx, nocc_pad):
     return _ptr(dfobj._workspace('rho_work', (max(int(n), 1),)))
 
 
-def syrk_plan(nao, nsplit=None, slots=512):
-    """(flags, nsplit) of the K = X^T X product on 128 x 128 lower-triangular tiles: as many k-splits as keep tiles x splits
-    within ONE round of the chip's workgroup slots (256 CUs x 2; nao = 1856: 120 tiles x 4 = 480).  Measured alternatives
-    that lost (profiles/r02): 17 splits in four full rounds (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits = 510 slots
-    (42.0 vs 41.6 ms)."""
-    t128 = -(-nao // 128)
-    n_sq = t128 * (t128 + 1) // 2
-    return 1 | 2, nsplit or max(1, min(8, slots // n_sq))
+def syrk_plan(nao, nsplit=None):
+    """(flags, nsplit) of the K = X^T X product: 128 x 128 lower-triangular tiles, 4 k-splits (nao = 1856: 120 tiles x 4 = 480
+    of the chip's 512 workgroup slots, one round).  Measured alternatives that lost (profiles/r02): 17 splits in four full
+    rounds (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits = 510 slots (42.0 vs 41.6 ms)."""
+    return 1 | 2, nsplit or 4
 
 
 def pad_orbitals(orbo, device):
