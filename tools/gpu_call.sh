@@ -1,6 +1,9 @@
+#!/bin/bash
+# scratch: full GPU pass
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_cabi_kernels.py tests/test_gpu_df_jk.py tests/test_gpu_fullsize.py -m gpu -q -x 2>&1 | tail -6 | cut -c1-250
-for t in "syrktall=0" "syrktall=1"; do timeout 300 python tools/kbench.py --steps 3 --tag $t --tune $t 2>/dev/null | tail -1 | cut -c1-330; done > gpurun_out/kbench_r02s.log
-timeout 300 python tools/kbench.py --steps 3 --tag ksplit4_square --ksplit 4 --tune syrktall=0 2>/dev/null | tail -1 | cut -c1-330 >> gpurun_out/kbench_r02s.log
-cat gpurun_out/kbench_r02s.log
+timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > gpurun_out/pytest_gpu_final.log 2>&1
+tail -25 gpurun_out/pytest_gpu_final.log
+timeout 400 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+cat gpurun_out/bench_final.json | cut -c1-1500
+bash tools/profile_round.sh r02
