@@ -253,7 +253,7 @@ template <int LI, int LJ, int LK>
 struct GradCfg {
     using GG = GG3<LI, LJ, LK>;
     static constexpr int NIJ = ncart(LI) * ncart(LJ);
-    static constexpr int S0 = NIJ >= 100 ? 32 : NIJ >= 36 ? 16 : NIJ >= 18 ? 8 : NIJ >= 9 ? 4 : NIJ >= 6 ? 2 : 1;
+    static constexpr int S0 = NIJ >= 150 ? 64 : NIJ >= 100 ? 32 : NIJ >= 36 ? 16 : NIJ >= 18 ? 8 : NIJ >= 9 ? 4 : NIJ >= 6 ? 2 : 1;
     static constexpr int ES = GG::ESTRIDE;
     static constexpr int NTHREADS = ((256 / S0) * ES * 8 <= 60 * 1024) ? 256 : (((128 / S0) * ES * 8 <= 60 * 1024) ? 128 : 64);
     // more lanes per triple (fewer triples per workgroup) until the workgroup's LDS fits

@@ -310,7 +310,7 @@ int launch_int3c2e(const Int3c2eArgs &a, hipStream_t st)
 template <int LI, int LJ, int LK>
 struct ClassCfg {
     static constexpr int NIJ = ncart(LI) * ncart(LJ);
-    static constexpr int S = NIJ >= 100 ? 32 : NIJ >= 36 ? 16 : NIJ >= 18 ? 8 : NIJ >= 9 ? 4 : NIJ >= 6 ? 2 : 1;
+    static constexpr int S = NIJ >= 150 ? 64 : NIJ >= 100 ? 32 : NIJ >= 36 ? 16 : NIJ >= 18 ? 8 : NIJ >= 9 ? 4 : NIJ >= 6 ? 2 : 1;
     using G = G3<LI, LJ, LK>;
     static constexpr int TS = (G::GT + 2 * G::NR) | 1;
     static constexpr int ST = G::NIJ * G::NSK + G::NCI * G::NSJ * G::NSK;

@@ -8,6 +8,9 @@ DEFAULT_AUXBASIS = {
     'def2svp': 'def2-svp-jkfit', 'def2tzvp': 'def2-tzvp-jkfit',
     'sto3g': 'def2-svp-jkfit', '631g': 'cc-pvdz-jkfit', '321g': 'def2-svp-jkfit', '6311g': 'cc-pvtz-jkfit',
     'augccpvdz': 'aug-cc-pvdz-jkfit', 'augccpvtz': 'aug-cc-pvtz-jkfit',
+    'ccpvqz': 'cc-pvqz-jkfit', 'augccpvqz': 'aug-cc-pvqz-jkfit',
+    'def2svpd': 'def2-svp-jkfit', 'def2tzvpd': 'def2-tzvp-jkfit', 'def2tzvpp': 'def2-tzvpp-jkfit',
+    'def2qzvp': 'def2-qzvp-jkfit', 'def2qzvpp': 'def2-qzvpp-jkfit',
 }
 
 
@@ -17,9 +20,10 @@ def predefined_auxbasis(mol, basis, xc='HF'):
     return DEFAULT_AUXBASIS.get(_mole._format_basis_name(basis))
 
 
-# electrons per l of the ground-state atom, H-Ne (pyscf/data/elements.py:457-468 CONFIGURATION)
+# electrons per l of the ground-state atom, H-Ar (pyscf/data/elements.py:457-468 CONFIGURATION)
 _CONFIGURATION = [[0, 0, 0, 0], [1, 0, 0, 0], [2, 0, 0, 0], [3, 0, 0, 0], [4, 0, 0, 0], [4, 1, 0, 0],
-                  [4, 2, 0, 0], [4, 3, 0, 0], [4, 4, 0, 0], [4, 5, 0, 0], [4, 6, 0, 0]]
+                  [4, 2, 0, 0], [4, 3, 0, 0], [4, 4, 0, 0], [4, 5, 0, 0], [4, 6, 0, 0],
+                  [5, 6, 0, 0], [6, 6, 0, 0], [6, 7, 0, 0], [6, 8, 0, 0], [6, 9, 0, 0], [6, 10, 0, 0], [6, 11, 0, 0], [6, 12, 0, 0]]
 ETB_BETA = 2.0          # pyscf/df/addons.py:33
 
 

@@ -62,6 +62,10 @@ _ALIAS = {
     '321g': '321g', '631gs': '631gs', '631g*': '631gs', '631g(d)': '631gs',
     '631gss': '631gss', '631g**': '631gss', '631g(d,p)': '631gss',
     '6311g': '6311g', '6311gss': '6311gss', '6311g**': '6311gss', '6311g(d,p)': '6311gss',
+    'ccpvqzjkfit': 'ccpvqzjkfit', 'augccpvqz': 'augccpvqz', 'augccpvqzjkfit': 'augccpvqzjkfit', 'ccpvqzri': 'ccpvqzri',
+    'def2qzvp': 'def2qzvp', 'def2qzvpp': 'def2qzvpp', 'def2tzvpp': 'def2tzvpp', 'def2svpd': 'def2svpd',
+    'def2tzvpd': 'def2tzvpd', 'def2qzvppjkfit': 'def2universaljkfit', 'def2svpdjkfit': 'def2universaljkfit',
+    'def2tzvpdjkfit': 'def2universaljkfit',
 }
 
 
@@ -115,7 +119,7 @@ def load_basis(name, symb):
     key = _ALIAS.get(_format_basis_name(name))
     el = std_symbol_without_ghost(symb)
     if key is None or el not in _BASIS_DATA[key]:
-        raise KeyError('Basis %s not found for %s (packaged table covers H-Ne for: %s)'
+        raise KeyError('Basis %s not found for %s (packaged table covers H-Ar for: %s)'
                        % (name, symb, ', '.join(sorted(set(_ALIAS)))))
     return [[sh[0]] + [list(ec) for ec in sh[1:]] for sh in _BASIS_DATA[key][el]]
 

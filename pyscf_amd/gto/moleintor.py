@@ -19,8 +19,8 @@ from .. import lib as _lib_mod
 from . import mole as _mole
 
 EXPCUTOFF = 60.0          # primitive-pair screening: drop exp(-mu R^2) < e^-60 (libcint default)
-LMAX_AO = 3
-LMAX_AUX = 4
+LMAX_AO = 4
+LMAX_AUX = 5
 
 
 # --------------------------------------------------------------------------- cart -> sph

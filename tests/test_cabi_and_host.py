@@ -20,7 +20,7 @@ def test_header_symbols_exported():
         assert hasattr(so, n), 'missing symbol %s' % n
     assert so.PAMD_version() >= 100
     assert so.PAMD_device_count() >= 0            # no compute call without a GPU
-    assert so.PAMD_rys_table_len() == 28224
+    assert so.PAMD_rys_table_len() == 38976
 
 
 def test_args_struct_matches_header():

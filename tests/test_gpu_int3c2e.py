@@ -45,10 +45,12 @@ def test_int2c2e_and_cderi(h2o_dz):
 
 
 @pytest.mark.parametrize('basis,auxbasis', [('cc-pvtz', 'cc-pvtz-jkfit'), ('def2-tzvp', 'def2-universal-jkfit'),
-                                            ('sto-3g', 'weigend')])
+                                            ('sto-3g', 'weigend'), ('cc-pvqz', 'cc-pvqz-jkfit'),
+                                            ('def2-qzvpp', 'def2-universal-jkfit')])
 def test_all_classes_low_symmetry(basis, auxbasis):
-    """AO l<=3 (f) and aux l<=4 (g), contracted aux primitives, no symmetry in the geometry:
-    exercises every (l_i, l_j | l_k) kernel of the family."""
+    """AO l<=3 (f) and aux l<=4 (g) for the triple-zeta sets, AO l<=4 (g) and aux l<=5 (h) for the quadruple-zeta ones
+    (7 Rys roots for (gg|h)); contracted aux primitives, no symmetry in the geometry: exercises every (l_i, l_j | l_k)
+    kernel of the family."""
     from pyscf_amd import gto
     from pyscf_amd.df import incore
     mol = gto.M(atom=LOWSYM, basis=basis, spin=1)

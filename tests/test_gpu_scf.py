@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 H2O = 'O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587'
 
 
-def test_int1e_vs_oracle():
+@pytest.mark.parametrize('basis', ['cc-pvtz', 'cc-pvqz'])
+def test_int1e_vs_oracle(basis):
     from pyscf_amd import gto
     from pyscf_amd.scf import hf
-    mol = gto.M(atom='O 0.1 -0.2 0.05; C 0.25 0.4 1.15; H 0.95 -0.3 -0.35', basis='cc-pvtz', spin=1)
+    mol = gto.M(atom='O 0.1 -0.2 0.05; C 0.25 0.4 1.15; H 0.95 -0.3 -0.35', basis=basis, spin=1)
     s, t, v = hf.int1e_gpu(mol)
     assert np.abs(s - ref.int1e(mol, 'ovlp')).max() < 1e-12
     assert np.abs(t - ref.int1e(mol, 'kin')).max() < 1e-11
@@ -50,6 +51,56 @@ def test_df_rhf_tz_vs_oracle():
         return vj - .5 * vk
     conv, e0 = ref.rhf_kernel(mol, veff, conv_tol=1e-10)[:2]
     assert conv and abs(e - e0) < 1e-8, (e, e0)
+
+
+def test_df_rhf_qz_vs_oracle():
+    """cc-pVQZ / cc-pvqz-jkfit (g AOs, h fitting functions; the default pairing of pyscf/df/addons.py:42-72): energy
+    within 1e-8 Eh of the oracle SCF, and the tensor itself against the oracle's."""
+    from pyscf_amd import gto, scf, df
+    mol = gto.M(atom=H2O, basis='cc-pvqz')
+    mf = scf.RHF(mol).density_fit()
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    aux = df.make_auxmol(mol, 'cc-pvqz-jkfit')
+    assert mf.converged and mol.nao == 115 and mf.with_df.get_naoaux() == aux.nao == 208
+    assert mol._bas[:, 1].max() == 4 and aux._bas[:, 1].max() == 5
+    cderi = ref.cholesky_eri(mol, aux)
+    assert np.abs(mf.with_df._cderi_dev.cpu().numpy() - cderi).max() < 1e-9
+
+    def veff(dm, c, occ):
+        vj, vk = ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
+        return vj - .5 * vk
+    conv, e0 = ref.rhf_kernel(mol, veff, conv_tol=1e-10)[:2]
+    assert conv and abs(e - e0) < 1e-8, (e, e0)
+
+
+def test_second_row_rhf_and_b3lyp_vs_oracle():
+    """Na-Ar: basis tables, MINAO guess occupations (pyscf/data/elements.py:457-475), Bragg / Treutler radii and the
+    period-dependent default grids (pyscf/dft/gen_grid.py:43-60) - H2S, DF-RHF and DF-RKS B3LYP against the oracle
+    (own integrals, own grids)."""
+    from oracle import ref_dft
+    from pyscf_amd import gto, scf, dft, df
+    from pyscf_amd.dft import libxc
+    mol = gto.M(atom='S 0 0 0.1; H 0 0.96 -0.82; H 0 -0.96 -0.82', basis='cc-pvdz')
+    cderi = ref.cholesky_eri(mol, df.make_auxmol(mol, 'cc-pvdz-jkfit'))
+    mf = scf.RHF(mol).density_fit()
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+
+    def veff(dm, c, occ):
+        vj, vk = ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
+        return vj - .5 * vk
+    conv, e0 = ref.rhf_kernel(mol, veff, conv_tol=1e-10)[:2]
+    assert mf.converged and conv and abs(e - e0) < 1e-8, (e, e0)
+    ks = dft.RKS(mol, xc='b3lyp').density_fit()
+    ks.conv_tol = 1e-10
+    e = ks.kernel()
+    coords, weights = ref_dft.build_grids(mol)
+    assert ks.grids.size == len(weights) and abs(ks.grids.weights.sum() - weights.sum()) < 1e-7 * weights.sum()
+    hyb, fac = libxc.parse_xc('b3lyp')
+    conv, e0 = ref_dft.rks_energy(mol, fac, hyb, True, coords, weights,
+                                  lambda dm, c, occ, with_k: ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ))[:2]
+    assert ks.converged and conv and abs(e - e0) < 1e-8, (e, e0)
 
 
 def test_golden_minao_guess():

@@ -8,7 +8,7 @@ from scipy.special import gammainc, gamma
 
 from pyscf_amd import lib as plib
 
-NMAX, DEG, WIDTH = 7, 13, 2.0
+NMAX, DEG, WIDTH = 8, 13, 2.0
 
 
 def _tables():

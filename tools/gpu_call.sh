@@ -1,9 +1,6 @@
 #!/bin/bash
-# scratch: full GPU pass
+# scratch: QZ / second-row tests
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > gpurun_out/pytest_gpu_final.log 2>&1
-tail -25 gpurun_out/pytest_gpu_final.log
-timeout 400 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-cat gpurun_out/bench_final.json | cut -c1-1500
-bash tools/profile_round.sh r02
+timeout 900 python -m pytest tests/test_gpu_int3c2e.py tests/test_gpu_scf.py "tests/test_gpu_grad.py::test_df_rhf_gradient_higher_l_vs_fd" -m gpu -q -x --durations=8 > gpurun_out/pytest_qz.log 2>&1
+tail -25 gpurun_out/pytest_qz.log
