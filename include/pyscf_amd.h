@@ -12,6 +12,8 @@
  * Reference interfaces replaced (paths relative to the reference tree pyscf/):
  *   PAMD_int3c2e_class   lib/gto/fill_nr_3c.c:196-225 GTOnr3c_drv + :127-185 GTOnr3c_fill_s2ij
  *                        (+ libcint int3c2e_sph), and lib/gto/fill_int2c.c GTOint2c (int2c2e_sph)
+ *   PAMD_int2e_class     lib/gto/fill_int2e.c:538 GTOnr2e_fill_drv (+ libcint int2e_sph) as called through
+ *                        mol.intor('int2e') by RHF.get_jk, scf/hf.py:2499-2511 (in-core 4-centre path, config 1)
  *   PAMD_int1e_ovlp_kin  lib/gto/fill_int2c.c GTOint2c with int1e_ovlp_sph / int1e_kin_sph
  *   PAMD_cderi_solve     df/incore.py:204-213 (BLAS trsm), :216 (lib.dot, eig fallback)
  *   PAMD_pack_dm_tril    df/df_jk.py:329-332 (lib.pack_tril + halved diagonal; lib/np_helper/pack_tril.c:59-112)
@@ -95,6 +97,35 @@ typedef struct PAMD_int3c2e_grad_args {
     int aux_response;            /* 0: omit the third-centre derivative (auxbasis_response=False, df/grad/rhf.py:133) */
 } PAMD_int3c2e_grad_args;
 int PAMD_int3c2e_grad_class(int li, int lj, int lk, const PAMD_int3c2e_grad_args *args, void *stream);
+
+/* 4-centre integrals (ij|kl) of one angular class (l_i >= l_j | l_k >= l_l), AO l <= 3, into the dense
+ * d_eri[nao][nao][nao][nao] (all 8 permutational images).  Bra and ket lists are shell-pair tables with the same
+ * records as PAMD_int3c2e_args.  In-core path of small molecules: scf/hf.py:2499-2511 builds `_eri` once with
+ * mol.intor('int2e') and contracts it with dot_eri_dm (:902) every iteration. */
+typedef struct PAMD_int2e_args {
+    const int *bra_ish;         /* [nbra] shell i of the pair (l = li)                           */
+    const int *bra_jsh;         /* [nbra] shell j (l = lj)                                       */
+    const int *bra_pp0;         /* [nbra] first primitive-pair record                            */
+    const int *bra_npp;         /* [nbra] number of primitive-pair records                       */
+    const double *bra_pp;       /* [..][8]: zeta, Px,Py,Pz, K_ab c_i c_j, PAx,PAy,PAz            */
+    const int *ket_ish;
+    const int *ket_jsh;
+    const int *ket_pp0;
+    const int *ket_npp;
+    const double *ket_pp;
+    const double *shell_xyz;    /* [nshell][3]                                                   */
+    const int *shell_ao0;       /* [nshell] first AO function of the shell                       */
+    const double *rys_table;
+    const double *c2s;
+    const int *c2s_off;
+    double *eri;                /* [nao][nao][nao][nao]                                          */
+    int nbra, nket;
+    int li, lj, lk, ll;
+    int nao;
+    int same_class;             /* bra list == ket list: only ket <= bra is computed             */
+    double omega;               /* > 0: erf(omega r12)/r12; 0: 1/r12                             */
+} PAMD_int2e_args;
+int PAMD_int2e_class(const PAMD_int2e_args *args, void *stream);
 /* d_grad[natm][3] += Tr(Dt dT/dR) - Tr(Ws dS/dR): int1e_ipkin / int1e_ipovlp contractions of
  * pyscf/grad/rhf.py:62-75; Dt, Ws symmetric (nao, nao) */
 int PAMD_int1e_grad(const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,

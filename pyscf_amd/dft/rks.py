@@ -78,8 +78,6 @@ class RKS(hf.RHF):
         return energy_elec(self, dm, h1e, vhf)
 
     def density_fit(self, auxbasis=None, with_df=None, only_dfj=False):
-        if only_dfj:
-            raise NotImplementedError('only_dfj (exact 4-centre K beside DF-J, df_jk.py:52-54) is outside the DF J/K path')
         from .. import df
         if with_df is None:
             if auxbasis is None and not numint._xc.is_hybrid_xc(self.xc):
@@ -88,4 +86,5 @@ class RKS(hf.RHF):
                 pass
             with_df = df.DF(self.mol, auxbasis)
         self.with_df = with_df
+        self.only_dfj = bool(only_dfj)
         return self

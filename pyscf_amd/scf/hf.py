@@ -250,6 +250,7 @@ class SCF:
         if mol is not None:
             self.mol = mol
         self._int1e = None
+        self._eri = None
         if self.with_df is not None:
             self.with_df.reset(mol)
         grids = getattr(self, 'grids', None)
@@ -346,10 +347,33 @@ class SCF:
 
     # -- two-electron part -------------------------------------------------------------------
     def get_jk(self, mol=None, dm=None, hermi=1, with_j=True, with_k=True, omega=None):
+        """Without a DF object: the in-core 4-centre branch of RHF.get_jk (hf.py:2499-2511; scf/_vhf.py here).  With one:
+        _DFHF.get_jk (df/df_jk.py:150-177) - J and K from the fitted tensor, or with ``only_dfj`` the fitted J beside the
+        exact 4-centre K."""
+        if dm is None: dm = self.make_rdm1()
         if self.with_df is None:
-            raise NotImplementedError('4-centre J/K is out of scope (SURVEY.md §8 A20): call '
-                                      '.density_fit() first')
-        return self.with_df.get_jk(dm, hermi, with_j, with_k, self.direct_scf_tol, omega)
+            return self._get_jk_incore(dm, hermi, with_j, with_k, omega)
+        with_dfk = with_k and not self.only_dfj
+        vj = vk = None
+        if with_j or with_dfk:
+            vj, vk = self.with_df.get_jk(dm, hermi, with_j, with_dfk, self.direct_scf_tol, omega)
+        if with_k and not with_dfk:
+            vk = self._get_jk_incore(dm, hermi, False, True, omega)[1]
+        return vj, vk
+
+    only_dfj = False
+    _eri = None                # {omega: (nao, nao, nao, nao) device tensor}, built on first use like mf._eri (hf.py:2506-2507)
+
+    def _get_jk_incore(self, dm, hermi, with_j, with_k, omega):
+        from . import _vhf
+        key = float(omega or 0.0)
+        if self._eri is None:
+            self._eri = {}
+        if key not in self._eri:
+            t0 = time.perf_counter()
+            self._eri[key] = _vhf.int2e_gpu(self.mol, None, key)
+            self._log('int2e (in-core, omega %g): %.4f s', key, time.perf_counter() - t0)
+        return _vhf.dot_eri_dm(self._eri[key], dm, hermi, with_j, with_k)
 
     def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
         """hf.py:2172-2201 - _DFHF sets direct_scf falsy (df_jk.py:138): full build each cycle."""
@@ -372,12 +396,11 @@ class SCF:
 
     def density_fit(self, auxbasis=None, with_df=None, only_dfj=False):
         """pyscf/df/df_jk.py:31-105: attach a DF object; J/K are then routed to it."""
-        if only_dfj:
-            raise NotImplementedError('only_dfj (exact 4-centre K beside DF-J, df_jk.py:52-54) is outside the DF J/K path')
         from .. import df
         if with_df is None:
             with_df = df.DF(self.mol, auxbasis)
         self.with_df = with_df
+        self.only_dfj = bool(only_dfj)         # fitted J, exact in-core K (df_jk.py:52-54, RIJONX)
         return self
 
     def kernel(self, dm0=None):

@@ -1,0 +1,105 @@
+"""GPU parity of the in-core 4-centre path (BASELINE config 1: ``scf.RHF(mol)`` without density fitting): the Rys
+(ij|kl) kernel and ``dot_eri_dm`` vs the McMurchie-Davidson oracle, and the reference's exact-J/K golden energies
+(pyscf/scf/test/test_rhf.py, pyscf/dft/test/test_h2o.py:86-115) through the product."""
+import numpy as np
+import pytest
+
+from oracle import ref
+from tests.conftest import H2O
+
+pytestmark = pytest.mark.gpu
+
+LOWSYM = 'O 0.1 -0.2 0.05; C 0.25 0.4 1.15; H 0.95 -0.3 -0.35'
+
+
+@pytest.mark.parametrize('atom,basis,spin', [(H2O, 'sto-3g', 0), (H2O, 'cc-pvdz', 0), (LOWSYM, '6-31g**', 1),
+                                             (LOWSYM, 'cc-pvtz', 1)])
+def test_int2e_vs_oracle(atom, basis, spin):
+    """Every (l_i l_j | l_k l_l) class up to (ff|ff), contracted shells, no symmetry in the geometry; all 8 images."""
+    from pyscf_amd import gto
+    from pyscf_amd.scf import _vhf
+    mol = gto.M(atom=atom, basis=basis, spin=spin)
+    got = _vhf.int2e_gpu(mol).cpu().numpy()
+    want = ref.int2e(mol)
+    assert got.shape == want.shape == (mol.nao,) * 4
+    assert np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max())
+    assert np.abs(got - got.transpose(1, 0, 2, 3)).max() == 0 and np.abs(got - got.transpose(2, 3, 0, 1)).max() == 0
+
+
+def test_range_separated_int2e_and_dot_eri_dm():
+    from pyscf_amd import gto
+    from pyscf_amd.scf import _vhf
+    mol = gto.M(atom=LOWSYM, basis='6-31g', spin=1)
+    for omega in (0.4, -0.4):
+        got = _vhf.int2e_gpu(mol, omega=omega).cpu().numpy()
+        want = ref.int2e(mol, omega)
+        assert np.abs(got - want).max() < 1e-11
+    eri = _vhf.int2e_gpu(mol)
+    rng = np.random.default_rng(1)
+    dms = rng.standard_normal((3, mol.nao, mol.nao))                  # non-symmetric, several at once
+    vj, vk = _vhf.dot_eri_dm(eri, dms, hermi=0)
+    e = ref.int2e(mol)
+    assert np.abs(vj - np.einsum('ijkl,xlk->xij', e, dms)).max() < 1e-11
+    assert np.abs(vk - np.einsum('ijkl,xjk->xil', e, dms)).max() < 1e-11
+    vj1, vk1 = _vhf.dot_eri_dm(eri, dms[0] + 1j * dms[1])
+    assert np.abs(vj1 - (vj[0] + 1j * vj[1])).max() < 1e-12 and np.abs(vk1 - (vk[0] + 1j * vk[1])).max() < 1e-12
+
+
+def test_config1_rhf_goldens():
+    """H2O RHF without density fitting: cc-pVDZ -76.026765673119627 (pyscf/scf/test/test_rhf.py), STO-3G
+    (BASELINE config 1) against the oracle's exact-ERI SCF; UHF on the closed shell reproduces the RHF energy."""
+    from pyscf_amd import gto, scf
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    mf = scf.RHF(mol)
+    mf.conv_tol = 1e-11
+    e = mf.kernel()
+    assert mf.converged and mf.with_df is None and abs(e - -76.026765673119627) < 1e-9, e
+    assert abs(scf.UHF(mol).run(conv_tol=1e-11).e_tot - e) < 1e-9
+    mol = gto.M(atom=H2O, basis='sto-3g')
+    e = scf.RHF(mol).run(conv_tol=1e-11).e_tot
+    eri = ref.int2e(mol)
+
+    def veff(dm, c, occ):
+        vj, vk = ref.get_jk_exact(eri, dm)
+        return vj - .5 * vk
+    conv, e0 = ref.rhf_kernel(mol, veff, conv_tol=1e-11)[:2]
+    assert conv and abs(e - e0) < 1e-9, (e, e0)
+
+
+@pytest.mark.parametrize('xc,e_ref', [('lda,vwn_rpa', -76.01330948329084), ('b88,vwn', -76.690247578608236),
+                                      ('b3lypg', -76.384928891413438)])
+def test_rks_exact_jk_goldens(xc, e_ref):
+    """pyscf/dft/test/test_h2o.py:86-115 (6-31g, (50, 194) grids, Treutler pruning, no atom-specific radial scaling)."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import radi
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
+    try:
+        mol = gto.M(atom=H2O, basis='6-31g')
+        mf = dft.RKS(mol, xc=xc)
+        mf.grids.atom_grid = {'H': (50, 194), 'O': (50, 194)}
+        mf.grids.prune = dft.gen_grid.treutler_prune
+        mf.conv_tol = 1e-10
+        e = mf.kernel()
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    assert mf.converged and abs(e - e_ref) < 2e-8, (xc, e, e_ref)
+
+
+def test_only_dfj():
+    """density_fit(only_dfj=True) (df/df_jk.py:52-54,150-177): fitted J beside the exact 4-centre K."""
+    from pyscf_amd import gto, scf, df
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    mf = scf.RHF(mol).density_fit(only_dfj=True)
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    cderi = ref.cholesky_eri(mol, df.make_auxmol(mol))
+    eri = ref.int2e(mol)
+
+    def veff(dm, c, occ):
+        return ref.get_jk(cderi, dm, 1, with_k=False)[0] - .5 * ref.get_jk_exact(eri, dm)[1]
+    conv, e0 = ref.rhf_kernel(mol, veff, conv_tol=1e-10)[:2]
+    assert mf.converged and conv and abs(e - e0) < 1e-8, (e, e0)
+    e_df = scf.RHF(mol).density_fit().run(conv_tol=1e-10).e_tot
+    e_exact = scf.RHF(mol).run(conv_tol=1e-10).e_tot
+    assert abs(e - e_df) > 1e-7 and abs(e - e_exact) > 1e-7          # a third, distinct approximation
