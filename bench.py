@@ -227,14 +227,18 @@ def main():
                           if os.path.exists(os.path.join(ROOT, 'profiles', d, 'pmc_summary.json')))
         traffic_src = 'profiles/%s/pmc_summary.json' % pmc_dirs[-1]
         pm = json.load(open(os.path.join(ROOT, traffic_src)))['kernels']
-        e2k = 'e2_sq_kernel' if (getattr(dfobj, '_cderi_sq', None) is not None and 'e2_sq_kernel' in pm) else 'e2_symm'
-        pk = {'e2_symm': e2k, 'dgemm_tn': 'gemm_tn_glds_kernel', 'vj_pass1': 'vj_pass1_rows_kernel',
-              'vj_pass2': 'vj_pass2_kernel'}[dom]
+        square = getattr(dfobj, '_cderi_sq', None) is not None
+        cands = {'e2_symm': ['e2_sq2_kernel', 'e2_sq_kernel'] if square else ['e2_pk_kernel', 'e2_symm_kernel', 'e2_symm'],
+                 'dgemm_tn': ['gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel'], 'vj_pass1': ['vj_pass1_rows_kernel'],
+                 'vj_pass2': ['vj_pass2_kernel']}[dom]
+        pk = [k for k in cands if k in pm][0]
         # gfx950: FETCH_SIZE reports half the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM section).
         # Calibrated on kernels whose byte count is known (profiles/r01): vj_pass1 0.53x and vj_pass2 0.50x of their
         # 61.3 GB, e2_sq 0.54x; the packed-operand e2_symm (8-B/lane scattered reads) reports 1.00x
-        rd = 1.0 if pk == 'e2_symm' else 2.0
-        traffic = (rd * pm[pk]['FETCH_SIZE_KiB_per_launch_mean'] + pm[pk]['WRITE_SIZE_KiB_per_launch_mean']) * 1024.0
+        # the profiled command also launches the kernel on fewer rows (parity sample, warm-up of the XC leg): the largest
+        # launch is the full 2224-row one of the timed region
+        rd = 1.0 if pk in ('e2_symm', 'e2_symm_kernel') else 2.0
+        traffic = (rd * pm[pk]['FETCH_SIZE_KiB_per_launch_max'] + pm[pk]['WRITE_SIZE_KiB_per_launch_max']) * 1024.0
     except Exception:
         pass
     dtot, dcnt = ksum[dom]
