@@ -7,6 +7,7 @@ branch) per step with the DM / orbitals already resident on the device.  With N 
 index is sharded over the ranks and the partial J/K are all-reduced (RCCL): strong scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--nwater 32] [--basis cc-pvtz]
+    python bench.py --molecule taxol          # BASELINE config 4 on one GPU: C47H51NO14 def2-TZVP (data/taxol.xyz)
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (HIP events on the launch
 stream); `cpu_baseline` times the oracle's numpy restatement of the reference algorithm
@@ -40,7 +41,9 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--nwater', type=int, default=32)
-    ap.add_argument('--basis', default='cc-pvtz')
+    ap.add_argument('--basis', default=None, help='default: cc-pvtz (water clusters), def2-tzvp (taxol)')
+    ap.add_argument('--molecule', default='water', choices=['water', 'taxol'],
+                    help="'water': (H2O)_nwater (configs 3 and 5); 'taxol': C47H51NO14 of config 4")
     ap.add_argument('--cpu-sample-rows', type=int, default=1200)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the CPU baseline (default: all host cores)')
@@ -94,7 +97,10 @@ def main():
     from pyscf_amd.df import df_jk
     from pyscf_amd.scf import hf
 
-    mol = gto.M(atom=clusters.water_cluster(args.nwater), basis=args.basis)
+    if args.basis is None:
+        args.basis = 'def2-tzvp' if args.molecule == 'taxol' else 'cc-pvtz'
+    label = 'taxol C47H51NO14' if args.molecule == 'taxol' else '(H2O)_%d' % args.nwater
+    mol = gto.M(atom=clusters.taxol() if args.molecule == 'taxol' else clusters.water_cluster(args.nwater), basis=args.basis)
     nao, nocc = mol.nao, mol.nelectron // 2
     dfobj = df.DF(mol)                      # aux basis by the reference's rule (cc-pvtz -> cc-pvtz-jkfit)
     t0 = time.perf_counter()
@@ -304,8 +310,8 @@ def main():
         'metric': 'ms per SCF iter (DF J/K build)', 'value': round(ms_per_step, 3), 'unit': 'ms',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
         'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '(H2O)_%d %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM%s'
-                               % (args.nwater, args.basis, _aux_label(getattr(dfobj.auxmol, 'basis', 'auto')),
+        'config': {'workload': '%s %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM%s'
+                               % (label, args.basis, _aux_label(getattr(dfobj.auxmol, 'basis', 'auto')),
                                   nao, naux, nocc, 8e-9 * naux * npair,
                                   ' + unpacked image for the K half transform' if getattr(dfobj, '_cderi_sq', None) is not None else ''),
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',

@@ -506,15 +506,16 @@ __device__ __forceinline__ void dma_row(__amdgpu_buffer_rsrc_t r, double *lds_ds
 // g+1 under the MFMAs of group g.  Wave (wr, wc) owns orbital tiles {64 wr + 16 a, a < 4} and {128 + 16 wr}.
 // A wave whose 64 AO columns all lie beyond `ncol` (the 128-column tile overhangs the matrix) only stages its DMA rows:
 // its matrix-pipe time goes to the co-resident workgroup.
-template <bool RHO, bool PAIR>
+template <int NA, bool RHO, bool PAIR>
 __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
     double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int ncol, int ptile0, int nslot,
     int nL)
 {
-    constexpr int M = 160;
-    __shared__ double sa0[KB * LDN + KB * 32];
-    __shared__ double sa1[KB * LDN + KB * 32];
+    static_assert(NA == 4 || NA == 5, "128- or 160-orbital tile");
+    constexpr int M = NA * 32;                           // NA = 4: no remainder block
+    __shared__ double sa0[KB * LDN + (NA == 5 ? KB * 32 : 0)];
+    __shared__ double sa1[KB * LDN + (NA == 5 ? KB * 32 : 0)];
     __shared__ double sq0[KB * LDN];
     __shared__ double sq1[KB * LDN];
     constexpr int RB = KB * LDN;                         // start of the remainder block inside sa*
@@ -539,9 +540,9 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     const int offr = RB + fk * 32 + ((wr * 16 + fn + 16 * (fk & 1)) & 31);        // + kk * 32
     const int offb = fk * LDN + wc * 64 + fn;                                   // + kk * LDN + 16 b
 
-    double4_t acc[5][4];
+    double4_t acc[NA][4];
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < NA; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
 
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
         const int k = wave * 4 + j;
         dma_row(r_orb, da + k * LDN, voff, (k0 + k) * ldo8);
         dma_row(r_sq, db + k * LDN, voff_b, (k0 + k) * ldb8);
-        if (j == 0) dma_row(r_orb, da + RB + wave * 128, voff_rem, (k0 + wave * 4) * ldo8);
+        if (NA == 5 && j == 0) dma_row(r_orb, da + RB + wave * 128, voff_rem, (k0 + wave * 4) * ldo8);
     };
     auto step = [&](const double *ca, const double *cb, double *na, double *nb, int k0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -558,15 +559,15 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
         const int kn = (k0 + KB < kdim) ? k0 + KB : k0;
 #pragma unroll
         for (int kk = 0; kk < KB; kk += 4) {
-            double af[5], bf[4];
+            double af[NA], bf[4];
 #pragma unroll
             for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
-            af[4] = ca[offr + kk * 32];
+            if constexpr (NA == 5) af[4] = ca[offr + kk * 32];
 #pragma unroll
             for (int b = 0; b < 4; b++) bf[b] = cb[offb + kk * LDN + b * 16];
             stage_row(kn, na, nb, kk >> 2);
 #pragma unroll
-            for (int a = 0; a < 5; a++)
+            for (int a = 0; a < NA; a++)
 #pragma unroll
                 for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
         }
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     double *out = X + Lw * nocc_pad * ldx;
     double rho_acc = 0;
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < NA; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const long p = p0 + (PAIR ? 0 : wc * 64) + b * 16 + fn;
@@ -641,14 +642,15 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
 // matrix pipe's shadow; gain: the tensor is read once (30.7 GB per build instead of 61.3) and 2 x its size of HBM is free.
 // Reads beyond a packed row (pad rows q >= nao, pad columns p >= nao of the last tile) stay inside the buffer resource
 // (num_records = bytes to the end of the block, out-of-range -> 0) and only meet zero orbital rows or never-stored columns.
-template <bool RHO>
+template <int NA, bool RHO>
 __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     const double *__restrict__ cderi, long npair, int nL, int kdim, const double *__restrict__ orb, int ldo,
     double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int nao)
 {
-    constexpr int M = 160;
-    __shared__ double sa0[KB * LDN + KB * 32];
-    __shared__ double sa1[KB * LDN + KB * 32];
+    static_assert(NA == 4 || NA == 5, "128- or 160-orbital tile");
+    constexpr int M = NA * 32;
+    __shared__ double sa0[KB * LDN + (NA == 5 ? KB * 32 : 0)];
+    __shared__ double sa1[KB * LDN + (NA == 5 ? KB * 32 : 0)];
     __shared__ double sq0[KB * LDN];
     __shared__ double sq1[KB * LDN];
     constexpr int RB = KB * LDN;
@@ -692,9 +694,9 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
 #pragma unroll
     for (int b = 0; b < 4; b++) tb[b] = fk - fn - wc * 64 - b * 16;
 
-    double4_t acc[5][4];
+    double4_t acc[NA][4];
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < NA; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
 
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
         const int soff_row = (q * (q + 1) / 2 + p0) * 8;
         const int soff = soff_row + tr * (q0 * 8 - soff_row);
         dma_row(r_pk, db + k * (LDN - tr * (LDN - 128)), voff + tr * dvo[j], soff);
-        if (j == 0) dma_row(r_orb, da + RB + wave * 128, voff_rem, (q0 + wave * 4) * ldo8);
+        if (NA == 5 && j == 0) dma_row(r_orb, da + RB + wave * 128, voff_rem, (q0 + wave * 4) * ldo8);
     };
     // One k-tile body per (layout, masked?) pair, each a single basic block: measured with a layout-generic body, ~100 VALU
     // selects per tile in a layout-generic body cost 12 % - a VALU between two FP64 MFMAs is not free (~6 cycles each) - so
@@ -739,10 +741,10 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
         const int d = tile_q0(v) - p0;
 #pragma unroll
         for (int kk = 0; kk < KB; kk += 4) {
-            double af[5], bf[4];
+            double af[NA], bf[4];
 #pragma unroll
             for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
-            af[4] = ca[offr + kk * 32];
+            if constexpr (NA == 5) af[4] = ca[offr + kk * 32];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const double val = TR ? cb[atr[kk >> 2] + b * 256] : cb[offb_row + kk * LDN + b * 16];
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
             }
             stage_row(vn, na, nb, kk >> 2);
 #pragma unroll
-            for (int a = 0; a < 5; a++)
+            for (int a = 0; a < NA; a++)
 #pragma unroll
                 for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
         }
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     double *out = X + L * nocc_pad * ldx;
     double rho_acc = 0;
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < NA; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const long p = p0 + wc * 64 + b * 16 + fn;
@@ -1049,9 +1051,21 @@ int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *
 //   d_out   [nL][nocc_pad][ldx]
 //   d_rho   (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] (first J pass of the density orb orb^T)
 // Doubles of workspace the fused first J pass needs (d_rho_work): one partial per wave of every workgroup of a row.
+// Orbital tiling of the v2 half-transform kernels: chunks of 160 (NA = 5) or 128 (NA = 4) orbitals, whichever pads
+// nocc_pad less (ties: 160, the shape with the better MFMA : fragment-load ratio); *waste = padded / exact - 1.
+static void v2_tile(int nocc_pad, int *na, int *nchunk, double *waste)
+{
+    const int c160 = ceil_div(nocc_pad, 160) * 160, c128 = ceil_div(nocc_pad, 128) * 128;
+    if (c128 < c160) { *na = 4; *nchunk = c128 / 128; *waste = (double)c128 / nocc_pad - 1.0; }
+    else             { *na = 5; *nchunk = c160 / 160; *waste = (double)c160 / nocc_pad - 1.0; }
+}
+// padded MFMA work a v2 kernel may spend before the exact-tile kernels (lower matrix-pipe efficiency) are the better choice
+static const double V2_WASTE_SQUARE = 0.13, V2_WASTE_PACKED = 0.30;
+
 long PAMD_nr_e2_rho_worksize(int nL, int ldx, int nocc_pad)
 {
-    const int nchunk = ceil_div(ceil_div(nocc_pad, 16), g_e2_mtmax);      // g_e2_mtmax <= 10 = the square kernel's chunking
+    int nchunk = ceil_div(ceil_div(nocc_pad, 16), g_e2_mtmax);      // g_e2_mtmax <= 10 = the square kernel's chunking
+    if (ceil_div(nocc_pad, 128) > nchunk) nchunk = ceil_div(nocc_pad, 128);
     return (long)nL * ceil_div(ldx, NT) * nchunk * 4;
 }
 
@@ -1072,20 +1086,20 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     hipStream_t st = (hipStream_t)stream;
     int mt_total = nocc_pad / 16;
     {
-        // all-DMA packed-operand kernel: 160-orbital chunks (as PAMD_nr_e2_square), q rows padded to a multiple of 16
-        const int nch = ceil_div(mt_total, 10);
-        const int wa = ceil_div(ceil_div(mt_total, nch), 2);
+        // all-DMA packed-operand kernel: 160- or 128-orbital chunks (as PAMD_nr_e2_square), q rows padded to a multiple of 16
+        int na, nch;
+        double waste;
+        v2_tile(nocc_pad, &na, &nch, &waste);
         const int kdim = ceil_div(nao, KB) * KB;
-        if (g_pk_dma && wa == 5 && ldo >= nch * 160 && orb_rows >= kdim && ldo % 2 == 0 && ldx <= kdim &&
+        if (g_pk_dma && waste <= V2_WASTE_PACKED && ldo >= nch * na * 32 && orb_rows >= kdim && ldo % 2 == 0 && ldx <= kdim &&
             (long)kdim * (kdim + 1) / 2 * 8 + 4096 < (1L << 31) && (long)orb_rows * ldo * 8 < (1L << 32) &&
             ((uintptr_t)d_orb % 16 == 0) && ((uintptr_t)d_cderi % 8 == 0)) {
             dim3 gpk(ceil_div(ldx, NT) * nch, nL);
-            if (d_rho)
-                e2_pk_kernel<true><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, d_rho_work,
-                                                        nch, nao);
-            else
-                e2_pk_kernel<false><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, nullptr,
-                                                         nch, nao);
+            double *rw = d_rho ? d_rho_work : nullptr;
+#define LAUNCH_PK(NAV, RHOF) e2_pk_kernel<NAV, RHOF><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, rw, nch, nao)
+            if (na == 5) { if (d_rho) LAUNCH_PK(5, true); else LAUNCH_PK(5, false); }
+            else         { if (d_rho) LAUNCH_PK(4, true); else LAUNCH_PK(4, false); }
+#undef LAUNCH_PK
             PAMD_CHECK_LAUNCH();
             if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, (int)(gpk.x * 4), st);
             return 0;
@@ -1142,9 +1156,13 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
     PAMD_REQUIRE(ldo >= nchunk * wa * 32, "orbital leading dimension too small for tile padding");
     dim3 grid(ceil_div(ldx, NT) * nchunk, nL);
     PAMD_REQUIRE((long)rows * ld * 8 < (1L << 31) && (long)orb_rows * ldo * 8 < (1L << 32), "panel offsets exceed 32 bits");
-    if (g_dma_v2 && wa == 5) {
-        // 160-orbital chunks: v2 kernel.  A last column tile that is at most half full runs as a second launch over pairs of
-        // aux rows (PAIR instance); rho partials of both launches share one [nL][nslot][4] layout.
+    int na2, nch2;
+    double waste2;
+    v2_tile(nocc_pad, &na2, &nch2, &waste2);
+    if (g_dma_v2 && waste2 <= V2_WASTE_SQUARE && ldo >= nch2 * na2 * 32) {
+        // 160- or 128-orbital chunks: v2 kernel.  A last column tile that is at most half full runs as a second launch over
+        // pairs of aux rows (PAIR instance); rho partials of both launches share one [nL][nslot][4] layout.
+        const int nchunk = nch2;
         const int ptiles = ceil_div(ldx, NT);
         const int nslot = ptiles * nchunk;
         const int last_valid = nao - (ptiles - 1) * NT;
@@ -1152,16 +1170,16 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
         const int pmain = pair ? ptiles - 1 : ptiles;
         dim3 gmain(pmain * nchunk, nL), gpair(nchunk, ceil_div(nL, 2));
         double *rw = d_rho ? d_rho_work : nullptr;
-#define LAUNCH_V2(RHOF)                                                                                             \
+#define LAUNCH_V2(NAV, RHOF)                                                                                        \
         do {                                                                                                         \
-            e2_sq2_kernel<RHOF, false><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out,   \
-                                                                  nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL);     \
+            e2_sq2_kernel<NAV, RHOF, false><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                                                                   nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL);    \
             if (pair)                                                                                                \
-                e2_sq2_kernel<RHOF, true><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
-                                                                     nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL); \
+                e2_sq2_kernel<NAV, RHOF, true><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                                                                      nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL); \
         } while (0)
-        if (d_rho) LAUNCH_V2(true);
-        else LAUNCH_V2(false);
+        if (na2 == 5) { if (d_rho) LAUNCH_V2(5, true); else LAUNCH_V2(5, false); }
+        else          { if (d_rho) LAUNCH_V2(4, true); else LAUNCH_V2(4, false); }
 #undef LAUNCH_V2
         PAMD_CHECK_LAUNCH();
         if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, nslot * 4, st);

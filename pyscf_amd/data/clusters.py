@@ -49,3 +49,18 @@ H  -2.172991468538160 -1.254577209307266  0.000000000000000
 C   0.000000000000000 -1.406124906933854  0.000000000000000
 H   0.000000000000000 -2.509154418614532  0.000000000000000
 '''
+
+
+def taxol():
+    """-> list of (symbol, (x, y, z)) in Angstrom for paclitaxel C47H51NO14 (BASELINE config 4): the molecule's connectivity
+    embedded in 3-D by tools/make_taxol_xyz.py (data/taxol.xyz).  Right atoms, bonds and rings - not an optimised geometry."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'taxol.xyz')
+    with open(path) as f:
+        lines = f.read().splitlines()
+    n = int(lines[0])
+    atoms = []
+    for ln in lines[2:2 + n]:
+        s, x, y, z = ln.split()
+        atoms.append((s, (float(x), float(y), float(z))))
+    return atoms

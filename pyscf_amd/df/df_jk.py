@@ -154,6 +154,8 @@ def pad_orbitals(orbo, device):
     mt = nocc_pad // 16
     nchunk = -(-mt // 10)
     ldo = max(ldo, nchunk * (-(-(-(-mt // nchunk)) // 2)) * 32)
+    # the v2 DMA kernels tile the orbitals in chunks of 160 or 128 columns, whichever pads less (df_jk.hip::v2_tile)
+    ldo = max(ldo, min(_round_up(nocc_pad, 160), _round_up(nocc_pad, 128)))
     orb_h = np.zeros((_round_up(nao, 16), ldo))          # zero rows up to a multiple of the k-tile
     orb_h[:nao, :nocc] = orbo
     return torch.from_numpy(orb_h).to(device), (nocc_pad if nocc else 0), ldo

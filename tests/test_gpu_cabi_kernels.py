@@ -152,9 +152,10 @@ def test_dgemm_tn_masked_and_tile_mask(m, n, k, nsplit):
 
 
 @pytest.mark.parametrize('nao,naux,nocc', [(130, 37, 33), (257, 20, 161), (64, 5, 16), (200, 9, 150), (145, 4, 310),
-                                           (272, 3, 139)])
+                                           (272, 3, 139), (200, 6, 240), (150, 7, 120), (145, 4, 500), (320, 3, 226)])
 def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
-    """PAMD_unpack_tril -> PAMD_nr_e2_square (LDS-DMA half transform on the unpacked image) against numpy, including the
+    """(nocc 240, 120, 500, 226: the 128-orbital instance of the v2 kernel, one to four chunks, with the pair-tail launch.)
+    PAMD_unpack_tril -> PAMD_nr_e2_square (LDS-DMA half transform on the unpacked image) against numpy, including the
     first J pass taken from the epilogue: rho_L = sum_{i,p} X[L,i,p] C[p,i] = sum_pq B_L[pq] (C C^T)[pq]."""
     torch, so, dev, st, lib = _setup()
     from pyscf_amd.df import df_jk
@@ -201,9 +202,11 @@ def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
 
 
 @pytest.mark.parametrize('nao,naux,nocc', [(200, 9, 150), (145, 4, 310), (272, 3, 139), (100, 3, 150), (1000, 2, 160),
-                                           (129, 5, 160)])
+                                           (129, 5, 160), (200, 9, 240), (150, 4, 120), (100, 3, 100), (145, 4, 500),
+                                           (320, 3, 226)])
 def test_nr_e2_symm_packed_dma_kernel(nao, naux, nocc):
-    """PAMD_nr_e2_symm on the shapes that take the all-DMA packed-operand kernel (160-orbital chunks): transposed tiles above
+    """PAMD_nr_e2_symm on the shapes that take the all-DMA packed-operand kernel (160- or 128-orbital chunks, whichever pads
+    the occupied block less): transposed tiles above
     the diagonal, row tiles below, the crossing tiles visited twice with the keep-masks - against numpy and against the
     register-staged kernel (tuning key pkdma = 0), including the fused first J pass and ragged nao (pad rows / columns)."""
     torch, so, dev, st, lib = _setup()

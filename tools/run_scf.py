@@ -1,5 +1,6 @@
 """End-to-end DF-SCF on a water cluster through the reference-style API.
-    python tools/run_scf.py --nwater 32 --basis cc-pvtz --xc b3lyp     (xc '' -> RHF)"""
+    python tools/run_scf.py --nwater 32 --basis cc-pvtz --xc b3lyp     (xc '' -> RHF)
+    python tools/run_scf.py --molecule taxol --basis def2-tzvp --xc b3lyp"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyscf_amd import gto, scf, dft
@@ -9,10 +10,15 @@ ap.add_argument('--nwater', type=int, default=32)
 ap.add_argument('--basis', default='cc-pvtz')
 ap.add_argument('--xc', default='b3lyp')
 ap.add_argument('--conv-tol', type=float, default=1e-9)
+ap.add_argument('--molecule', default='water', choices=['water', 'taxol'])
+ap.add_argument('--level-shift', type=float, default=0.0)
+ap.add_argument('--max-cycle', type=int, default=50)
 a = ap.parse_args()
-mol = gto.M(atom=clusters.water_cluster(a.nwater), basis=a.basis, verbose=4)
+mol = gto.M(atom=clusters.taxol() if a.molecule == 'taxol' else clusters.water_cluster(a.nwater), basis=a.basis, verbose=4)
 mf = (dft.RKS(mol, xc=a.xc) if a.xc else scf.RHF(mol)).density_fit()
 mf.conv_tol = a.conv_tol
+mf.level_shift = a.level_shift
+mf.max_cycle = a.max_cycle
 t0 = time.perf_counter()
 e = mf.kernel()
 print('converged=%s cycles=%d E=%.10f wall=%.1f s (nao=%d naux=%d)' %
