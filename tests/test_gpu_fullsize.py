@@ -231,3 +231,63 @@ def test_water8_tz_converged_energy_vs_oracle_golden(xc):
     e = mf.kernel()
     assert mf.converged and (mol.nao, mf.with_df.get_naoaux()) == (g['nao'], g['naux'])
     assert abs(e - g[key]) < 1e-8, (e, g[key])
+
+
+def test_config4_taxol_tensor_columns_vs_oracle():
+    """BASELINE config 4 (taxol C47H51NO14 def2-TZVP, aux def2-tzvp-jkfit: nao 2228, naux 5598, nocc 226; geometry of
+    data/taxol.xyz) as it is meant to run - aux rows sharded over 8 ranks: rank 3's rows of the tensor against oracle
+    integrals on sampled AO shells (oracle (Q|pq), the oracle's own Cholesky factor of (P|Q) by trsm, rows [l0, l1)) to
+    1e-9, and one J/K build of the shard (square image, 128-orbital chunks: nocc_pad = 240) against a dense FP64 product
+    of the same rows."""
+    import scipy.linalg
+    import torch
+    from pyscf_amd import gto, df
+    from pyscf_amd.data import clusters
+    from pyscf_amd.df import df_jk
+    mol = gto.M(atom=clusters.taxol(), basis='def2-tzvp')
+    obj = df.DF(mol)
+    obj._shard_override = (3, 8)
+    obj.build()
+    nao, naux, nocc = mol.nao, obj.get_naoaux(), mol.nelectron // 2
+    assert (mol.natm, nao, naux, nocc) == (113, 2228, 5598, 226)
+    l0, l1 = obj.shard_range(naux, 3, 8)
+    cd = obj._cderi_dev
+    assert cd.shape == (l1 - l0, nao * (nao + 1) // 2) and l1 - l0 == 700
+    aux = obj.auxmol
+    low = scipy.linalg.cholesky(ref.int2c2e(aux), lower=True)
+    loc = ref.ao_loc(mol)
+    rng = np.random.RandomState(11)
+    shells = sorted(set(rng.randint(0, mol.nbas, size=5).tolist()) | {0, mol.nbas - 1})
+    worst, ncols = 0.0, 0
+    for ish in shells:
+        raw = ref.int3c2e_slab(mol, aux, ish, ish + 1)
+        want = scipy.linalg.solve_triangular(low, raw, lower=True, overwrite_b=True, check_finite=False)[l0:l1]
+        p0, p1 = int(loc[ish]), int(loc[ish + 1])
+        pq0, pq1 = p0 * (p0 + 1) // 2, p1 * (p1 + 1) // 2
+        worst = max(worst, float(np.abs(cd[:, pq0:pq1].cpu().numpy() - want).max()))
+        ncols += pq1 - pq0
+    assert ncols > 200 and worst < 1e-9, (ncols, worst)
+    # J/K of the shard vs a dense product of the same rows
+    dev = cd.device
+    c = np.linalg.qr(np.random.default_rng(1).standard_normal((nao, nocc)))[0] * np.sqrt(2.0)
+    dm = torch.from_numpy(c.dot(c.T)[None]).to(dev)
+    vj, vk = df_jk.get_jk_device(obj, dm, [df_jk.pad_orbitals(c, dev)])
+    assert obj._cderi_sq is not None
+    idx = torch.tril_indices(nao, nao, device=dev)
+    cdv = torch.from_numpy(c).to(dev)
+    vk_ref = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+    rho = torch.zeros(l1 - l0, dtype=torch.float64, device=dev)
+    dmt = (dm[0] + dm[0].T)[idx[0], idx[1]]
+    dmt[idx[0] == idx[1]] *= 0.5
+    for b0 in range(0, l1 - l0, 100):
+        full = torch.zeros((100, nao, nao), dtype=torch.float64, device=dev)
+        full[:, idx[0], idx[1]] = cd[b0:b0 + 100]
+        full = full + full.transpose(1, 2) - torch.diag_embed(torch.diagonal(full, dim1=1, dim2=2))
+        x = torch.matmul(full, cdv)
+        vk_ref += torch.einsum('Lpi,Lqi->pq', x, x)
+        rho[b0:b0 + 100] = cd[b0:b0 + 100] @ dmt
+    vj_ref = rho @ cd
+    assert float((vk[0] - vk_ref).abs().max()) < 1e-11 * float(vk_ref.abs().max())
+    assert float((vj[0] - vj_ref).abs().max()) < 1e-11 * float(vj_ref.abs().max())
+    obj.reset()
+    torch.cuda.empty_cache()

@@ -1,6 +1,7 @@
 """Build and contract ONE aux-row shard of a large configuration on a single GPU (emulates rank r of N
 without a process group): checks memory footprint, 64-bit indexing and timings at BASELINE config-5 scale.
-    python tools/shard_probe.py --nwater 128 --basis cc-pvdz --world 8 --rank 3"""
+    python tools/shard_probe.py --nwater 128 --basis cc-pvdz --world 8 --rank 3
+    python tools/shard_probe.py --molecule taxol --basis def2-tzvp --world 8 --rank 3        (config 4)"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,8 +14,10 @@ ap.add_argument('--nwater', type=int, default=128)
 ap.add_argument('--basis', default='cc-pvdz')
 ap.add_argument('--world', type=int, default=8)
 ap.add_argument('--rank', type=int, default=3)
+ap.add_argument('--molecule', default='water', choices=['water', 'taxol'])
+ap.add_argument('--repeat', type=int, default=3)
 a = ap.parse_args()
-mol = gto.M(atom=clusters.water_cluster(a.nwater), basis=a.basis)
+mol = gto.M(atom=clusters.taxol() if a.molecule == 'taxol' else clusters.water_cluster(a.nwater), basis=a.basis)
 nao, nocc = mol.nao, mol.nelectron // 2
 obj = df.DF(mol)
 obj._shard_override = (a.rank, a.world)
@@ -32,9 +35,10 @@ orb = [df_jk.pad_orbitals(c, dev)]
 vj, vk = df_jk.get_jk_device(obj, dm, orb)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-vj, vk = df_jk.get_jk_device(obj, dm, orb)
+for _ in range(a.repeat):
+    vj, vk = df_jk.get_jk_device(obj, dm, orb)
 torch.cuda.synchronize()
-tjk = time.perf_counter() - t0
+tjk = (time.perf_counter() - t0) / a.repeat
 # spot check against a dense fp64 reference on 8 rows of the shard
 sub = cd[:8]
 idx = torch.tril_indices(nao, nao, device=dev)
@@ -49,7 +53,8 @@ vk_ref = torch.einsum('Lpi,Lqi->pq', xx, xx)
 rho = torch.einsum('Lpq,pq->L', full, dm[0])
 vj_ref = torch.einsum('L,Lpq->pq', rho, full)
 vjf = torch.zeros((nao, nao), dtype=torch.float64, device=dev); vjf[idx[0], idx[1]] = vj2[0]
-print(json.dumps({'nao': nao, 'naux': naux, 'nocc': nocc, 'shard_rows': int(cd.shape[0]),
+print(json.dumps({'molecule': a.molecule if a.molecule != 'water' else '(H2O)_%d' % a.nwater, 'basis': a.basis, 'rank': a.rank,
+                  'world': a.world, 'square_image': getattr(obj, '_cderi_sq', None) is not None, 'nao': nao, 'naux': naux, 'nocc': nocc, 'shard_rows': int(cd.shape[0]),
                   'shard_GB': round(cd.numel() * 8e-9, 1), 'build_s': round(tb, 1), 'jk_ms_this_shard': round(tjk * 1e3, 1),
                   'mem_peak_GB': round(torch.cuda.max_memory_allocated() * 1e-9, 1),
                   'err_vk': float((vk2[0] - vk_ref).abs().max() / vk_ref.abs().max()),
