@@ -215,20 +215,21 @@ int PAMD_rho_from_mo_pair(const double *d_ca, const double *d_cb, long comp_stri
                           double coef, double *d_rho, long ldg, void *stream);
 int PAMD_rho_from_dm(const double *d_ao, const double *d_c0t, int nao, int ldao, long ldg_rows, long ldc,
                      int ncomp, long ng, double *d_rho, long ldg, void *stream);
-/* fac7: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C}.  wv[4][ldg] = w (vrho/2, 2 vsigma grad rho);
+/* fac[PAMD_XC_NFAC = 9]: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C, ITYH = short-range B88 (libxc gga_x_ityh)},
+ * then the omega of ITYH.  wv[4][ldg] = w (vrho/2, 2 vsigma grad rho);
  * d_acc[0] += sum w rho, d_acc[1] += sum w e_xc; d_exc nullable */
-int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double *d_weights, long ng,
+int PAMD_eval_xc(const double *fac, int gga, const double *d_rho, const double *d_weights, long ng,
                  long ldg, double *d_wv, double *d_exc, double *d_acc, void *stream);
 /* closed-shell response kernel, numint.nr_rks_fxc (dft/numint.py:1418-1530, weights of _rks_gga_wv1 :1560-1576):
  * wv1[4][ldg] = w (d vrho / 2, 2 [d vsigma grad rho0 + vsigma grad rho1]) along the first-order density d_rho1[4][ldg] */
-int PAMD_eval_fxc(const double *fac7, int gga, const double *d_rho0, const double *d_rho1, const double *d_weights,
+int PAMD_eval_fxc(const double *fac, int gga, const double *d_rho0, const double *d_rho1, const double *d_weights,
                   long ng, long ldg, double *d_wv1, void *stream);
 /* spin-polarised response kernel, numint.nr_uks_fxc (dft/numint.py:1690-1832, weights of _uks_gga_wv1 :1834-1915) */
-int PAMD_eval_fxc_pol(const double *fac7, int gga, const double *d_rho0_a, const double *d_rho0_b, const double *d_rho1_a,
+int PAMD_eval_fxc_pol(const double *fac, int gga, const double *d_rho0_a, const double *d_rho0_b, const double *d_rho1_a,
                       const double *d_rho1_b, const double *d_weights, long ng, long ldg, double *d_wv1_a,
                       double *d_wv1_b, void *stream);
 /* spin-polarised variant for nr_uks (dft/numint.py:1192-1324): d_acc3 = {nelec_a, nelec_b, exc} */
-int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
+int PAMD_eval_xc_pol(const double *fac, int gga, const double *d_rho_a, const double *d_rho_b,
                      const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,
                      double *d_evol /* nullable: energy density per volume */, void *stream);
 /* XC nuclear gradient of one grid block (pyscf/grad/rks.py:197-255 get_vxc/_gga_grad_sum_/_make_dR_dao_w contracted with

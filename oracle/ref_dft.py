@@ -297,17 +297,52 @@ def _build_functionals():
     Aa = betap / gamma / (sp.exp(-ec / gamma) - 1)
     H = gamma * sp.log(1 + betap / gamma * t2 * (1 + Aa * t2) / (1 + Aa * t2 + Aa ** 2 * t2 ** 2))
     out['pbec'] = rho * (ec + H)
+    # short-range B88 exchange of the ITYH scheme (Iikura, Tsuneda, Yanai, Hirao, JCP 115, 3540 (2001)) as libxc's
+    # gga_x_ityh defines it: e_s = -cx rho_s^(4/3) F(x) att(a), a = omega / (2 k), k = sqrt(9 pi / (2 cx F)) rho_s^(1/3)
+    om = sp.Symbol('omega', positive=True)
+    out['ityh'] = 2 * _ityh_spin(sp, rs_, sigma / 4, om)
     fns = {}
+    mods = [{'erf': _erf}, 'numpy']
     for k, e in out.items():
-        fns[k] = (sp.lambdify((rho, sigma), e, 'numpy'), sp.lambdify((rho, sigma), sp.diff(e, rho), 'numpy'),
-                  sp.lambdify((rho, sigma), sp.diff(e, sigma), 'numpy'),
-                  sp.lambdify((rho, sigma), sp.diff(e, rho, 2), 'numpy'),
-                  sp.lambdify((rho, sigma), sp.diff(e, rho, sigma), 'numpy'),
-                  sp.lambdify((rho, sigma), sp.diff(e, sigma, 2), 'numpy'))
+        v = (rho, sigma, om) if k == 'ityh' else (rho, sigma)
+        fns[k] = (sp.lambdify(v, e, mods), sp.lambdify(v, sp.diff(e, rho), mods),
+                  sp.lambdify(v, sp.diff(e, sigma), mods),
+                  sp.lambdify(v, sp.diff(e, rho, 2), mods),
+                  sp.lambdify(v, sp.diff(e, rho, sigma), mods),
+                  sp.lambdify(v, sp.diff(e, sigma, 2), mods))
     return fns
 
 
-_ORDER = ['slater', 'vwn5', 'vwnrpa', 'b88', 'lyp', 'pbex', 'pbec']
+def _erf(x):
+    from scipy.special import erf
+    return erf(x)
+
+
+def _ityh_spin(sp, r, s, om):
+    """Attenuated B88 exchange energy (per volume) of one spin channel with density r and |grad r|^2 = s.  att(a) = 1 - 8/3 a
+    (sqrt(pi) erf(1/(2a)) + 2a (b - c)), b = exp(-1/(4a^2)) - 1, c = 2a^2 b + 1/2; for a > 2 its expansion in 1/a^2 (the
+    closed form loses digits by cancellation there: 5e-13 relative at a = 2 in float64)."""
+    pi = sp.pi
+    beta = sp.Float('0.0042', 20)
+    cx = sp.Rational(3, 2) * (3 / (4 * pi)) ** sp.Rational(1, 3)
+    x = sp.sqrt(s) / r ** sp.Rational(4, 3)
+    F = 1 + beta / cx * x * x / (1 + 6 * beta * x * sp.asinh(x))
+    k = sp.sqrt(9 * pi / (2 * cx * F)) * r ** sp.Rational(1, 3)
+    a = om / (2 * k)
+    b = sp.exp(-1 / (4 * a * a)) - 1
+    c = 2 * a * a * b + sp.Rational(1, 2)
+    closed = 1 - sp.Rational(8, 3) * a * (sp.sqrt(pi) * sp.erf(1 / (2 * a)) + 2 * a * (b - c))
+    coef = [36, -960, 26880, -829440, 28385280, -1073479680, 44590694400, -2021444812800]
+    series = sum(sp.Integer(1) / (sp.Integer(cf) * a ** (2 * n + 2)) for n, cf in enumerate(coef))
+    att = sp.Piecewise((series, a > 2), (closed, True))
+    return -cx * r ** sp.Rational(4, 3) * F * att
+
+
+_ORDER = ['slater', 'vwn5', 'vwnrpa', 'b88', 'lyp', 'pbex', 'pbec', 'ityh']      # fac[8] = omega of 'ityh'
+
+
+def _args(fac, name, *v):
+    return v + (float(fac[8]),) if name == 'ityh' else v
 
 
 def eval_xc(fac, rho, sigma):
@@ -325,9 +360,10 @@ def eval_xc(fac, rho, sigma):
         if w == 0:
             continue
         f, fr, fs = _FUNCS[name][:3]
-        e[ok] += w * f(r, s)
-        vr[ok] += w * fr(r, s)
-        vs[ok] += w * fs(r, s) * np.ones_like(r)
+        a = _args(fac, name, r, s)
+        e[ok] += w * f(*a)
+        vr[ok] += w * fr(*a)
+        vs[ok] += w * fs(*a) * np.ones_like(r)
     return e, vr, vs
 
 
@@ -344,7 +380,7 @@ def eval_fxc(fac, rho, sigma):
         if w == 0:
             continue
         for k in range(3):
-            out[k][ok] += w * _FUNCS[name][3 + k](r, s) * np.ones_like(r)
+            out[k][ok] += w * _FUNCS[name][3 + k](*_args(fac, name, r, s)) * np.ones_like(r)
     return out
 
 
@@ -590,10 +626,14 @@ def _build_functionals_pol():
     Aa = beta_c / gamma_c / (sp.exp(-ec / (gamma_c * phi ** 3)) - 1)
     H = gamma_c * phi ** 3 * sp.log(1 + beta_c / gamma_c * t2 * (1 + Aa * t2) / (1 + Aa * t2 + Aa ** 2 * t2 ** 2))
     out['pbec'] = rho * (ec + H)
+    om = sp.Symbol('omega', positive=True)
+    out['ityh'] = _ityh_spin(sp, ra, saa, om) + _ityh_spin(sp, rb, sbb, om)
     fns = {}
     v = (ra, rb, saa, sab, sbb)
+    mods = [{'erf': _erf}, 'numpy']
     for k, e in out.items():
-        fns[k] = [sp.lambdify(v, e, 'numpy')] + [sp.lambdify(v, sp.diff(e, x), 'numpy') for x in v]
+        vv = v + (om,) if k == 'ityh' else v
+        fns[k] = [sp.lambdify(vv, e, mods)] + [sp.lambdify(vv, sp.diff(e, x), mods) for x in v]
     return fns
 
 
@@ -613,9 +653,10 @@ def eval_xc_pol(fac, ra, rb, saa, sab, sbb):
         if w == 0:
             continue
         f = _FUNCS_POL[name]
-        e[ok] += w * f[0](*args)
+        aa = _args(fac, name, *args)
+        e[ok] += w * f[0](*aa)
         for k in range(5):
-            dv[k][ok] += w * f[1 + k](*args) * np.ones(ok.sum())
+            dv[k][ok] += w * f[1 + k](*aa) * np.ones(ok.sum())
     return e, dv
 
 

@@ -47,6 +47,10 @@ __device__ inline Eps s_log(Eps a) { return {log(a.v), a.e / a.v}; }
 __device__ inline Eps s_exp(Eps a) { double f = exp(a.v); return {f, f * a.e}; }
 __device__ inline Eps s_atan(Eps a) { return {atan(a.v), a.e / (1.0 + a.v * a.v)}; }
 __device__ inline Eps s_asinh(Eps a) { return {asinh(a.v), a.e / sqrt(1.0 + a.v * a.v)}; }
+__device__ inline double s_erf(double a) { return erf(a); }
+__device__ inline Eps s_erf(Eps a) { return {erf(a.v), 1.1283791670955126 * exp(-a.v * a.v) * a.e}; }
+__device__ inline double s_val(double a) { return a; }
+__device__ inline double s_val(Eps a) { return a.v; }
 template <class S> __device__ inline S lift(double v);
 template <> __device__ inline double lift<double>(double v) { return v; }
 template <> __device__ inline Eps lift<Eps>(double v) { return Eps{v, 0.0}; }
@@ -176,10 +180,14 @@ template <class S> __device__ inline DualT<S> pbe_c(DualT<S> rho, DualT<S> sigma
 
 using Dual = DualT<double>;
 
-enum { F_SLATER = 0, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC, F_NUM };
+// attenuated (short-range) B88 exchange of one spin channel, defined with the spin-polarised functionals below
+template <class T> __device__ inline T ityh_spin(T r, T s, double omega);
+
+enum { F_SLATER = 0, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC, F_ITYH, F_NUM };
 
 struct XCSpec {
     double fac[F_NUM];
+    double omega;              // range-separation parameter of the attenuated exchange (F_ITYH)
 };
 
 // rho[4][ldg] (rho, dx, dy, dz; only row 0 used for LDA), weights[ng]
@@ -211,6 +219,7 @@ __global__ __launch_bounds__(256) void eval_xc_kernel(XCSpec spec, int gga, cons
             if (spec.fac[F_LYP] != 0) tot = tot + spec.fac[F_LYP] * lyp_c(dr, ds);
             if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * pbe_x(dr, ds);
             if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c(dr, ds);
+            if (spec.fac[F_ITYH] != 0) tot = tot + spec.fac[F_ITYH] * (2.0 * ityh_spin(0.5 * dr, 0.25 * ds, spec.omega));
             e = tot.v; vr = tot.r; vs = tot.s;
         }
         nel = w * r;
@@ -264,6 +273,7 @@ __global__ __launch_bounds__(256) void eval_fxc_kernel(XCSpec spec, int gga, con
         if (spec.fac[F_LYP] != 0) tot = tot + spec.fac[F_LYP] * lyp_c(dr, ds);
         if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * pbe_x(dr, ds);
         if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c(dr, ds);
+        if (spec.fac[F_ITYH] != 0) tot = tot + spec.fac[F_ITYH] * (2.0 * ityh_spin(0.5 * dr, 0.25 * ds, spec.omega));
         dvr = tot.r.e; vs = tot.s.v; dvs = tot.s.e;
     }
     wv[g] = 0.5 * w * dvr;
@@ -359,6 +369,49 @@ template <class S> __device__ inline D5T<S> b88_spin(D5T<S> r, D5T<S> s)
     D5T<S> r43 = pow5(r, 4.0 / 3.0);
     D5T<S> x = sqrt5(s + 1e-300) / r43;
     return -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * asinh5(x));
+}
+// ---- one spelling of the elementary functions for both AD types (DualT: closed shell, D5T: spin-polarised)
+template <class S> __device__ inline DualT<S> ad_pow(DualT<S> a, double p) { return dpow(a, p); }
+template <class S> __device__ inline D5T<S> ad_pow(D5T<S> a, double p) { return pow5(a, p); }
+template <class S> __device__ inline DualT<S> ad_sqrt(DualT<S> a) { return dsqrt(a); }
+template <class S> __device__ inline D5T<S> ad_sqrt(D5T<S> a) { return sqrt5(a); }
+template <class S> __device__ inline DualT<S> ad_exp(DualT<S> a) { return dexp(a); }
+template <class S> __device__ inline D5T<S> ad_exp(D5T<S> a) { return exp5(a); }
+template <class S> __device__ inline DualT<S> ad_asinh(DualT<S> a) { return dasinh(a); }
+template <class S> __device__ inline D5T<S> ad_asinh(D5T<S> a) { return asinh5(a); }
+template <class S> __device__ inline DualT<S> ad_erf(DualT<S> a) { return chain(a, s_erf(a.v), 1.1283791670955126 * s_exp(-(a.v * a.v))); }
+template <class S> __device__ inline D5T<S> ad_erf(D5T<S> a) { return chain5(a, s_erf(a.v), 1.1283791670955126 * s_exp(-(a.v * a.v))); }
+template <class S> __device__ inline double ad_val(DualT<S> a) { return s_val(a.v); }
+template <class S> __device__ inline double ad_val(D5T<S> a) { return s_val(a.v); }
+
+// Attenuation function of the erf-screened exchange hole (Iikura, Tsuneda, Yanai, Hirao, JCP 115, 3540 (2001), eq. 12; libxc
+// attenuation_erf):  att(a) = 1 - 8/3 a [sqrt(pi) erf(1/(2a)) + 2a (b - c)],  b = exp(-1/(4a^2)) - 1,  c = 2a^2 b + 1/2.
+// The closed form cancels to ~1/(36 a^2) for large a (5e-13 relative error at a = 2 in FP64), so from a = 1.4 on its
+// expansion in 1/a^2 is used (8 terms: 6e-16 at a = 1.5).
+template <class T> __device__ inline T att_erf(T a)
+{
+    if (ad_val(a) > 1.4) {
+        T i2 = 1.0 / (a * a);
+        return i2 * (1.0 / 36.0 + i2 * (-1.0 / 960.0 + i2 * (1.0 / 26880.0 + i2 * (-1.0 / 829440.0 + i2 * (1.0 / 28385280.0 +
+               i2 * (-1.0 / 1073479680.0 + i2 * (1.0 / 44590694400.0 + i2 * (-1.0 / 2021444812800.0))))))));
+    }
+    T b = ad_exp(-1.0 / (4.0 * a * a)) - 1.0;
+    T c = 2.0 * a * a * b + 0.5;
+    return 1.0 - (8.0 / 3.0) * a * (1.7724538509055159 * ad_erf(1.0 / (2.0 * a)) + 2.0 * a * (b - c));
+}
+
+// Short-range B88 exchange of one spin channel (density r, |grad r|^2 = s), ITYH scheme as libxc's gga_x_ityh:
+//   e = -cx r^(4/3) F(x) att(a),  F = B88 enhancement,  a = omega / (2 k),  k = sqrt(9 pi / (2 cx F)) r^(1/3)
+// (the long-range part of the exchange is the exact one, K_LR(omega); CAM-B3LYP = 0.35 B88 + 0.46 ITYH(0.33) + ...)
+template <class T> __device__ inline T ityh_spin(T r, T s, double omega)
+{
+    const double beta = 0.0042, cx = 1.5 * 0.62035049089940001;
+    T r43 = ad_pow(r, 4.0 / 3.0);
+    T x = ad_sqrt(s + 1e-300) / r43;
+    T F = 1.0 + (beta / cx) * x * x / (1.0 + 6.0 * beta * x * ad_asinh(x));
+    T k = ad_sqrt((9.0 * PI / (2.0 * cx)) / F) * ad_pow(r, 1.0 / 3.0);
+    T a = omega / (2.0 * k);
+    return -cx * r43 * F * att_erf(a);
 }
 template <class S> __device__ inline D5T<S> lyp_pol(D5T<S> ra, D5T<S> rb, D5T<S> saa, D5T<S> sab, D5T<S> sbb)
 {
@@ -464,6 +517,7 @@ __global__ __launch_bounds__(256) void eval_xc_pol_kernel(XCSpec spec, int gga, 
             if (spec.fac[F_LYP] != 0) tot = tot + spec.fac[F_LYP] * lyp_pol(Ra, Rb, Saa, Sab, Sbb);
             if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * (pbe_x_spin(Ra, Saa) + pbe_x_spin(Rb, Sbb));
             if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c_pol(rho, zeta, Saa + 2.0 * Sab + Sbb);
+            if (spec.fac[F_ITYH] != 0) tot = tot + spec.fac[F_ITYH] * (ityh_spin(Ra, Saa, spec.omega) + ityh_spin(Rb, Sbb, spec.omega));
             exc = w * tot.v;
             for (int k = 0; k < 5; k++) dv[k] = tot.d[k];
         }
@@ -535,6 +589,7 @@ __global__ __launch_bounds__(256) void eval_fxc_pol_kernel(XCSpec spec, int gga,
         if (spec.fac[F_LYP] != 0) tot = tot + spec.fac[F_LYP] * lyp_pol(X[0], X[1], X[2], X[3], X[4]);
         if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * (pbe_x_spin(X[0], X[2]) + pbe_x_spin(X[1], X[4]));
         if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c_pol(rho, zeta, X[2] + 2.0 * X[3] + X[4]);
+        if (spec.fac[F_ITYH] != 0) tot = tot + spec.fac[F_ITYH] * (ityh_spin(X[0], X[2], spec.omega) + ityh_spin(X[1], X[4], spec.omega));
         for (int k = 0; k < 5; k++) { v[k] = tot.d[k].v; dv[k] = tot.d[k].e; }
     }
     wv_a[g] = 0.5 * w * dv[0];
@@ -803,14 +858,15 @@ __global__ void reduce_sym_kernel(const double *__restrict__ part, int nsplit, i
 
 extern "C" {
 
-// spec: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C}; gga = 1 if any GGA term.
+// fac[9]: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C, ITYH (short-range B88)}, then omega of ITYH; gga = 1 if any GGA term.
 // d_acc[0] += sum w rho (nelec), d_acc[1] += sum w e_xc.  d_exc (nullable): e_xc per particle.
-int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double *d_weights, long ng, long ldg,
+int PAMD_eval_xc(const double *fac, int gga, const double *d_rho, const double *d_weights, long ng, long ldg,
                  double *d_wv, double *d_exc, double *d_acc, void *stream)
 {
     if (ng == 0) return 0;
     XCSpec spec;
-    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
+    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac[i];
+    spec.omega = fac[F_NUM];
     eval_xc_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho, d_weights, ng, ldg, d_wv,
                                                                        d_exc, d_acc);
     PAMD_CHECK_LAUNCH();
@@ -818,13 +874,14 @@ int PAMD_eval_xc(const double *fac7, int gga, const double *d_rho, const double 
 }
 
 // Response kernel: d_wv1[4][ldg] from the zeroth- and first-order densities d_rho0 / d_rho1 [4][ldg] (rho, grad rho)
-// of grid points [0, ng); same fac7 / gga as PAMD_eval_xc.  numint.nr_rks_fxc (dft/numint.py:1418-1530).
-int PAMD_eval_fxc(const double *fac7, int gga, const double *d_rho0, const double *d_rho1, const double *d_weights,
+// of grid points [0, ng); same fac / gga as PAMD_eval_xc.  numint.nr_rks_fxc (dft/numint.py:1418-1530).
+int PAMD_eval_fxc(const double *fac, int gga, const double *d_rho0, const double *d_rho1, const double *d_weights,
                   long ng, long ldg, double *d_wv1, void *stream)
 {
     if (ng == 0) return 0;
     XCSpec spec;
-    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
+    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac[i];
+    spec.omega = fac[F_NUM];
     eval_fxc_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho0, d_rho1, d_weights, ng, ldg,
                                                                         d_wv1);
     PAMD_CHECK_LAUNCH();
@@ -833,13 +890,14 @@ int PAMD_eval_fxc(const double *fac7, int gga, const double *d_rho0, const doubl
 
 // Spin-polarised response kernel: first-order weights d_wv1_a / d_wv1_b [4][ldg] from the zeroth-order (d_rho0_a/b) and
 // first-order (d_rho1_a/b) spin densities [4][ldg].  numint.nr_uks_fxc (dft/numint.py:1690-1915).
-int PAMD_eval_fxc_pol(const double *fac7, int gga, const double *d_rho0_a, const double *d_rho0_b, const double *d_rho1_a,
+int PAMD_eval_fxc_pol(const double *fac, int gga, const double *d_rho0_a, const double *d_rho0_b, const double *d_rho1_a,
                       const double *d_rho1_b, const double *d_weights, long ng, long ldg, double *d_wv1_a,
                       double *d_wv1_b, void *stream)
 {
     if (ng == 0) return 0;
     XCSpec spec;
-    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
+    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac[i];
+    spec.omega = fac[F_NUM];
     eval_fxc_pol_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho0_a, d_rho0_b, d_rho1_a,
                                                                             d_rho1_b, d_weights, ng, ldg, d_wv1_a, d_wv1_b);
     PAMD_CHECK_LAUNCH();
@@ -848,13 +906,14 @@ int PAMD_eval_fxc_pol(const double *fac7, int gga, const double *d_rho0_a, const
 
 // spin-polarised variant (numint.nr_uks)
 // d_evol (nullable) [ng]: XC energy density per unit volume (for the grid-response term of the gradient)
-int PAMD_eval_xc_pol(const double *fac7, int gga, const double *d_rho_a, const double *d_rho_b,
+int PAMD_eval_xc_pol(const double *fac, int gga, const double *d_rho_a, const double *d_rho_b,
                      const double *d_weights, long ng, long ldg, double *d_wv_a, double *d_wv_b, double *d_acc3,
                      double *d_evol, void *stream)
 {
     if (ng == 0) return 0;
     XCSpec spec;
-    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac7[i];
+    for (int i = 0; i < F_NUM; i++) spec.fac[i] = fac[i];
+    spec.omega = fac[F_NUM];
     eval_xc_pol_kernel<<<ceil_div(ng, 256), 256, 0, (hipStream_t)stream>>>(spec, gga, d_rho_a, d_rho_b, d_weights,
                                                                            ng, ldg, d_wv_a, d_wv_b, d_acc3, d_evol);
     PAMD_CHECK_LAUNCH();

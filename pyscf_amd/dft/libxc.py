@@ -2,17 +2,22 @@
 ``parse_xc`` :496-720, ``XC_CODES`` :60-210, ``hybrid_coeff``/``rsh_coeff``/``xc_type``).
 
 A functional is reduced to the weights of the building blocks implemented by the device kernel
-``PAMD_eval_xc`` (order: Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C) plus the exact-exchange
-fraction.  Names follow PySCF: 'LDA' / 'SLATER' = Slater exchange, 'VWN' = 'VWN5' (libxc id 7),
+``PAMD_eval_xc`` (order: Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C, ITYH = short-range B88 of the
+Iikura-Tsuneda-Yanai-Hirao scheme, libxc gga_x_ityh; slot 8 of the array is its omega) plus the exact-exchange
+fractions.  Names follow PySCF: 'LDA' / 'SLATER' = Slater exchange, 'VWN' = 'VWN5' (libxc id 7),
 'VWN_RPA' = 'VWNRPA' = 'VWN3' (id 8, libxc.py:168-169), 'B3LYP' = 'B3LYPG' = id 402 (VWN_RPA,
 libxc.py:175), 'B3LYP5' = VWN5 flavour (:177)."""
+import re
+
 import numpy as np
 
-F_SLATER, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC = range(7)
-_GGA = {F_B88, F_LYP, F_PBEX, F_PBEC}
+F_SLATER, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC, F_ITYH = range(8)
+F_OMEGA = 8                  # fac[F_OMEGA]: range-separation parameter of the attenuated exchange (F_ITYH)
+NFAC = 9
+_GGA = {F_B88, F_LYP, F_PBEX, F_PBEC, F_ITYH}
 
 _X = {'LDA': {F_SLATER: 1.}, 'SLATER': {F_SLATER: 1.}, 'LDA_X': {F_SLATER: 1.}, 'S': {F_SLATER: 1.},
-      'B88': {F_B88: 1.}, 'B': {F_B88: 1.}, 'PBE': {F_PBEX: 1.}, 'HF': {}}
+      'B88': {F_B88: 1.}, 'B': {F_B88: 1.}, 'PBE': {F_PBEX: 1.}, 'HF': {}, 'ITYH': {F_ITYH: 1.}}
 _C = {'VWN': {F_VWN5: 1.}, 'VWN5': {F_VWN5: 1.}, 'VWN_RPA': {F_VWNRPA: 1.}, 'VWNRPA': {F_VWNRPA: 1.},
       'VWN3': {F_VWNRPA: 1.}, 'LYP': {F_LYP: 1.}, 'PBE': {F_PBEC: 1.}}
 # compound names: (hyb, {component: weight})
@@ -26,22 +31,27 @@ _XC = {
     'LDA': (0.0, {F_SLATER: 1.}), 'SVWN': (0.0, {F_SLATER: 1., F_VWN5: 1.}),
     'LSDA': (0.0, {F_SLATER: 1., F_VWN5: 1.}),
     'HF': (1.0, {}),
+    # hyb_gga_xc_cam_b3lyp (Yanai, Tew, Handy, CPL 393, 51): (1 - 0.65) B88 + 0.46 ITYH(0.33) + 0.19 VWN5 + 0.81 LYP,
+    # exact exchange 0.19 short range / 0.65 long range.  4-tuples: (short-range HF, components, long-range HF, omega)
+    'CAMB3LYP': (0.19, {F_B88: 0.35, F_ITYH: 0.46, F_VWN5: 0.19, F_LYP: 0.81}, 0.65, 0.33),
 }
 
 
 def parse_xc(description):
-    """-> (hyb, fac[7]); see parse_xc_rsh for the range-separated exact-exchange terms."""
+    """-> (hyb, fac[9]); see parse_xc_rsh for the range-separated exact-exchange terms."""
     hyb, alpha, omega, fac = parse_xc_rsh(description)
     return hyb, fac
 
 
 def parse_xc_rsh(description):
-    """-> (hyb, alpha, omega, fac[7]).  Grammar subset of libxc.parse_xc (:496-720): 'X,C' with '+'-separated,
+    """-> (hyb, alpha, omega, fac[9]).  'RSH(omega,alpha,beta)' (libxc.py:640-660) sets omega and adds alpha to the long-range and
+    alpha + beta to the short-range exact exchange.  Grammar subset of libxc.parse_xc (:496-720): 'X,C' with '+'-separated,
     optionally 'w*name'-weighted terms, or a single compound name; exact exchange as 'HF' (full range: counts for
     hyb and alpha), 'SR_HF(omega)' (hyb only) and 'LR_HF(omega)' (alpha only), so that
     K = hyb K_full + (alpha - hyb) K_LR(omega)   (pyscf/dft/rks.py:110-127)."""
-    name = description.upper().replace(' ', '')
-    fac = np.zeros(7)
+    name = re.sub(r'(?<=[A-Z0-9])-(?=[A-Z])', '', description.upper().replace(' ', ''))     # 'CAM-B3LYP' = 'CAMB3LYP'
+    name = _protect_rsh(name)
+    fac = np.zeros(NFAC)
     hyb = 0.0
     alpha = 0.0
     omega = 0.0
@@ -61,6 +71,14 @@ def parse_xc_rsh(description):
             hyb += w
             alpha += w
             return
+        if token.startswith('RSH('):
+            om, a_, b_ = [float(v) for v in token[4:-1].split(';')]
+            if omega not in (0.0, om):
+                raise ValueError('different values of omega in one functional')
+            omega = om
+            alpha += w * a_
+            hyb += w * (a_ + b_)
+            return
         if token.startswith(('SR_HF', 'LR_HF')):
             if '(' in token:
                 om = float(token[token.index('(') + 1:token.index(')')])
@@ -73,12 +91,20 @@ def parse_xc_rsh(description):
                 alpha += w
             return
         if allow_compound and token in _XC and token not in table:
-            h, comps = _XC[token]
+            h, comps = _XC[token][:2]
             hyb += w * h
-            alpha += w * h
+            if len(_XC[token]) == 4:
+                alpha += w * _XC[token][2]
+                if omega not in (0.0, _XC[token][3]):
+                    raise ValueError('different values of omega in one functional')
+                omega = _XC[token][3]
+            else:
+                alpha += w * h
             for k, v in comps.items():
                 fac[k] += w * v
             return
+        if token not in table and table is _X and token in _C:
+            table = _C                   # an unambiguous correlation name in the exchange part (libxc.parse_xc accepts it)
         if token not in table:
             raise NotImplementedError('XC component %s is not implemented on the device' % token)
         for k, v in table[token].items():
@@ -98,14 +124,27 @@ def parse_xc_rsh(description):
                 add(_X, t, True)
     if omega == 0.0:
         alpha = hyb                      # no range separation: one full-range coefficient
+    if fac[F_ITYH] != 0 and omega == 0.0:
+        raise ValueError('ITYH (attenuated B88) needs a range-separation parameter: RSH(omega,alpha,beta)')
+    fac[F_OMEGA] = omega
     return hyb, alpha, omega, fac
+
+
+def _protect_rsh(name):
+    """The commas inside RSH(omega,alpha,beta) would be taken for the exchange,correlation separator."""
+    out, depth = [], 0
+    for ch in name:
+        depth += ch == '('
+        depth -= ch == ')'
+        out.append(';' if ch == ',' and depth else ch)
+    return ''.join(out)
 
 
 def xc_type(description):
     _, fac = parse_xc(description)
     if any(fac[k] != 0 for k in _GGA):
         return 'GGA'
-    return 'LDA' if np.any(fac != 0) else 'HF'
+    return 'LDA' if np.any(fac[:F_OMEGA] != 0) else 'HF'
 
 
 def hybrid_coeff(description, spin=0):

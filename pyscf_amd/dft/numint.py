@@ -94,11 +94,25 @@ class NumInt:
         return ()
 
     def rsh_coeff(self, xc_code):
-        return _xc.rsh_coeff(xc_code)
+        omega, alpha, beta = _xc.rsh_coeff(xc_code)
+        if self.omega is not None and omega != 0:
+            omega = float(self.omega)
+        return omega, alpha, beta
 
     def rsh_and_hybrid_coeff(self, xc_code, spin=0):
         omega, alpha, beta = self.rsh_coeff(xc_code)
         return omega, alpha, self.hybrid_coeff(xc_code, spin)
+
+    omega = None          # overrides the functional's range-separation parameter (KohnShamDFT.omega -> numint.omega,
+                          # pyscf/dft/rks.py:445-455, numint.py:2737-2760)
+
+    def _parse(self, xc_code):
+        """(hyb, fac[NFAC]) of libxc.parse_xc with the omega override applied to the attenuated exchange."""
+        hyb, fac = _xc.parse_xc(xc_code)
+        if self.omega is not None and fac[_xc.F_OMEGA] != 0:
+            fac = fac.copy()
+            fac[_xc.F_OMEGA] = abs(float(self.omega))
+        return hyb, fac
 
     # -- device plumbing ----------------------------------------------------------------------
     def _dev(self):
@@ -287,7 +301,7 @@ class NumInt:
         f64 = torch.float64
         nset = len(orbsets)
         ldg = plan.max_chunk_points
-        fac_c = (ctypes.c_double * 7)(*fac)
+        fac_c = (ctypes.c_double * _xc.NFAC)(*fac)
         M = torch.zeros((nset, nao, nao), dtype=f64, device=dev)
         acc = torch.zeros(3 if spin else 2, dtype=f64, device=dev)
         rho = torch.zeros((nset, 4, max(ldg, 1)), dtype=f64, device=dev)
@@ -380,7 +394,7 @@ class NumInt:
         nspin = 2 if spin else 1
         nvec = len(terms)
         ldg = max(plan.max_chunk_points, 1)
-        fac_c = (ctypes.c_double * 7)(*fac)
+        fac_c = (ctypes.c_double * _xc.NFAC)(*fac)
         M = torch.zeros((nspin, nvec, nao, nao), dtype=f64, device=dev)
         rho0 = torch.zeros((nspin, 4, ldg), dtype=f64, device=dev)
         rho1 = torch.zeros((nspin, 4, ldg), dtype=f64, device=dev)
@@ -470,7 +484,7 @@ class NumInt:
         dev = self._dev()
         if grids.coords is None:
             grids.build()
-        hyb, fac = _xc.parse_xc(xc_code)
+        hyb, fac = self._parse(xc_code)
         xctype = _xc.xc_type(xc_code)
         dms_arr = np.asarray(dms)
         nao = dms_arr.shape[-1]
@@ -512,7 +526,7 @@ class NumInt:
         nsplit = self.vmat_nsplit or pick_nsplit(((nao + 127) // 128) ** 2)
         nsplit_w = self.vmat_nsplit or pick_nsplit(((nao + 159) // 160) * ((nao + 127) // 128))
         nsplit_max = max(nsplit, nsplit_w)
-        fac_c = (ctypes.c_double * 7)(*fac)
+        fac_c = (ctypes.c_double * _xc.NFAC)(*fac)
         for iset in range(nset):
             use_mo = mo_coeff is not None and np.ndim(mo_occ) == 1 and nset == 1
             if use_mo:
@@ -603,7 +617,7 @@ class NumInt:
         dev = self._dev()
         if grids.coords is None:
             grids.build()
-        hyb, fac = _xc.parse_xc(xc_code)
+        hyb, fac = self._parse(xc_code)
         xctype = _xc.xc_type(xc_code)
         dms_arr = np.asarray(dms)
         if np.iscomplexobj(dms_arr):
@@ -637,7 +651,7 @@ class NumInt:
         wv = torch.empty((4, blk), dtype=f64, device=dev)
         c0t = torch.empty((nao, blk), dtype=f64, device=dev)
         nsplit = self.vmat_nsplit or pick_nsplit(((nao + 159) // 160) * ((nao + 127) // 128))
-        fac_c = (ctypes.c_double * 7)(*fac)
+        fac_c = (ctypes.c_double * _xc.NFAC)(*fac)
         ldd = _round_up(nao, 128)
 
         def padded(d):
@@ -690,7 +704,7 @@ class NumInt:
         dev = self._dev()
         if grids.coords is None:
             grids.build()
-        hyb, fac = _xc.parse_xc(xc_code)
+        hyb, fac = self._parse(xc_code)
         xctype = _xc.xc_type(xc_code)
         dma, dmb = np.asarray(dms[0], dtype=np.float64), np.asarray(dms[1], dtype=np.float64)
         nao = dma.shape[-1]
@@ -731,7 +745,7 @@ class NumInt:
             wv = torch.empty((2, 4, blk), dtype=f64, device=dev)
             c0t = torch.empty((nao, blk), dtype=f64, device=dev)
             nsplit = self.vmat_nsplit or pick_nsplit(((nao + 159) // 160) * ((nao + 127) // 128))
-            fac_c = (ctypes.c_double * 7)(*fac)
+            fac_c = (ctypes.c_double * _xc.NFAC)(*fac)
             ldd = _round_up(nao, 128)
 
             def padded(d):
@@ -813,7 +827,7 @@ class NumInt:
         dev = self._dev()
         if grids.coords is None:
             grids.build()
-        hyb, fac = _xc.parse_xc(xc_code)
+        hyb, fac = self._parse(xc_code)
         xctype = _xc.xc_type(xc_code)
         natm = mol.natm
         if xctype == 'HF':
@@ -838,7 +852,7 @@ class NumInt:
         d_h = np.zeros((nao, ldao))
         d_h[:, :nao] = (np.asarray(dm) + np.asarray(dm).T) * .5
         dsym = torch.from_numpy(d_h).to(dev)
-        fac_c = (ctypes.c_double * 7)(*fac)
+        fac_c = (ctypes.c_double * _xc.NFAC)(*fac)
         for ib, g0 in enumerate(range(0, ngrids, blk)):
             if ib % world != rank:
                 continue
@@ -929,7 +943,7 @@ class NumInt:
         dev = self._dev()
         if grids.coords is None:
             grids.build()
-        hyb, fac = _xc.parse_xc(xc_code)
+        hyb, fac = self._parse(xc_code)
         xctype = _xc.xc_type(xc_code)
         natm = mol.natm
         if xctype == 'HF':
@@ -957,7 +971,7 @@ class NumInt:
             d_h = np.zeros((nao, ldao))
             d_h[:, :nao] = (np.asarray(dms[s]) + np.asarray(dms[s]).T) * .5
             dsym.append(torch.from_numpy(d_h).to(dev))
-        fac_c = (ctypes.c_double * 7)(*fac)
+        fac_c = (ctypes.c_double * _xc.NFAC)(*fac)
         for ib, g0 in enumerate(range(0, ngrids, blk)):
             if ib % world != rank:
                 continue
@@ -1002,7 +1016,7 @@ class NumInt:
         dev = self._dev()
         if grids.coords is None:
             grids.build()
-        hyb, fac = _xc.parse_xc(xc_code)
+        hyb, fac = self._parse(xc_code)
         xctype = _xc.xc_type(xc_code)
         dms_arr = np.asarray(dms)
         assert dms_arr.ndim == 3 and dms_arr.shape[0] == 2, 'nr_uks expects (dm_alpha, dm_beta)'
@@ -1035,7 +1049,7 @@ class NumInt:
         nsplit = self.vmat_nsplit or pick_nsplit(((nao + 127) // 128) ** 2)
         nsplit_w = self.vmat_nsplit or pick_nsplit(((nao + 159) // 160) * ((nao + 127) // 128))
         nsplit_max = max(nsplit, nsplit_w)
-        fac_c = (ctypes.c_double * 7)(*fac)
+        fac_c = (ctypes.c_double * _xc.NFAC)(*fac)
         ops = []
         for s in range(2):
             if use_mo:

@@ -71,6 +71,15 @@ class RKS(hf.RHF):
         self.grids = gen_grid.Grids(mol)
         self._numint = numint.NumInt()
 
+    @property
+    def omega(self):
+        """Range-separation parameter override (KohnShamDFT.omega, pyscf/dft/rks.py:445-455): lives on the NumInt object."""
+        return self._numint.omega
+
+    @omega.setter
+    def omega(self, value):
+        self._numint.omega = value
+
     def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
         return get_veff(self, mol, dm, dm_last, vhf_last, hermi)
 

@@ -16,6 +16,15 @@ class UKS(uhf.UHF):
         self.grids = gen_grid.Grids(mol)
         self._numint = numint.NumInt()
 
+    @property
+    def omega(self):
+        """Range-separation parameter override (KohnShamDFT.omega, pyscf/dft/rks.py:445-455): lives on the NumInt object."""
+        return self._numint.omega
+
+    @omega.setter
+    def omega(self, value):
+        self._numint.omega = value
+
     def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
         if mol is None: mol = self.mol
         if dm is None: dm = self.make_rdm1()

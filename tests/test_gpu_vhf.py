@@ -103,3 +103,33 @@ def test_only_dfj():
     e_df = scf.RHF(mol).density_fit().run(conv_tol=1e-10).e_tot
     e_exact = scf.RHF(mol).run(conv_tol=1e-10).e_tot
     assert abs(e - e_df) > 1e-7 and abs(e - e_exact) > 1e-7          # a third, distinct approximation
+
+
+def test_camb3lyp_goldens():
+    """CAM-B3LYP = 0.35 B88 + 0.46 ITYH(omega 0.33) + 0.19 VWN5 + 0.81 LYP with 0.19 short-range / 0.65 long-range exact
+    exchange, exact (4-centre) J, K and K_LR: He / cc-pVDZ -2.89299475730048 for RKS and UKS (pyscf/dft/test/test_he.py:87-90),
+    H2O / 6-31g (50, 194) grids -76.35549300028714, with omega = 0.15 -76.36649222362115, also through the spelled-out
+    functional string (pyscf/dft/test/test_h2o.py:564-577)."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import radi
+    he = gto.M(atom='He 0 0 0', basis='cc-pvdz')
+    assert abs(dft.RKS(he, xc='camb3lyp').run(conv_tol=1e-11).e_tot - -2.89299475730048) < 1e-9
+    assert abs(dft.UKS(he, xc='camb3lyp').run(conv_tol=1e-11).e_tot - -2.89299475730048) < 1e-9
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
+    try:
+        mol = gto.M(atom=H2O, basis='6-31g')
+        es = []
+        for xc, omega in (('camb3lyp', None), ('camb3lyp', 0.15),
+                          ('RSH(.15,0.65,-0.46) + 0.46*ITYH + .35*B88 + VWN5*0.19, LYP*0.81', None)):
+            mf = dft.RKS(mol, xc=xc)
+            mf.grids.atom_grid = {'H': (50, 194), 'O': (50, 194)}
+            mf.conv_tol = 1e-10
+            if omega is not None:
+                mf.omega = omega
+            es.append(mf.kernel())
+            assert mf.converged
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    assert abs(es[0] - -76.35549300028714) < 2e-8, es
+    assert abs(es[1] - -76.36649222362115) < 2e-8 and abs(es[2] - -76.36649222362115) < 2e-8, es

@@ -40,6 +40,36 @@ def test_rks_energies_exact_jk(setup, xc, e_ref):
     assert conv and abs(e - e_ref) < 2e-8, (xc, e, e_ref)
 
 
+def test_camb3lyp_exact_jk_goldens(setup):
+    """Pins the attenuated (ITYH) B88 exchange of the oracle: CAM-B3LYP with exact J, K and long-range K - He / cc-pVDZ
+    -2.89299475730048 (pyscf/dft/test/test_he.py:87-90) and H2O / 6-31g -76.35549300028714, omega = 0.15:
+    -76.36649222362115 (pyscf/dft/test/test_h2o.py:564-577)."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import libxc
+    mol, coords, weights, eri = setup
+    he = gto.M(atom='He 0 0 0', basis='cc-pvdz')
+    hc, hw = ref_dft.build_grids(he)
+    from pyscf_amd.dft import radi
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
+    try:
+        c194, w194 = ref_dft.build_grids(mol, ATOM_GRID)                  # default (NWChem) pruning
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    for m, c, w, xc, e_ref in ((he, hc, hw, 'camb3lyp', -2.89299475730048), (mol, c194, w194, 'camb3lyp', -76.35549300028714),
+                               (mol, c194, w194, 'RSH(.15,0.65,-0.46) + 0.46*ITYH + .35*B88 + VWN5*0.19, LYP*0.81',
+                                -76.36649222362115)):
+        hyb, alpha, omega, fac = libxc.parse_xc_rsh(xc)
+        e4 = eri if m is mol else ref.int2e(m)
+        e4_lr = ref.int2e(m, omega)
+
+        def get_jk(dm, cc, occ, with_k):
+            vj, vk = ref.get_jk_exact(e4, dm)
+            return vj, hyb * vk + (alpha - hyb) * ref.get_jk_exact(e4_lr, dm)[1]
+        conv, e = ref_dft.rks_energy(m, fac, 1.0, True, c, w, get_jk)[:2]
+        assert conv and abs(e - e_ref) < 2e-9, (xc, e, e_ref)
+
+
 def test_df_rks_b88vwn(setup):
     """DF-RKS B88,VWN with the 'weigend' fitting basis: -76.690346887915879 (test_h2o.py:236-240)."""
     from pyscf_amd import df

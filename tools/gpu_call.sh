@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -x -k "config4" --durations=3 > gpurun_out/pytest_c4.log 2>&1
-tail -8 gpurun_out/pytest_c4.log
+timeout 1200 python -m pytest tests/test_gpu_dft.py tests/test_gpu_vhf.py tests/test_gpu_grad.py tests/test_gpu_response.py tests/test_gpu_xc_sparse.py -m gpu -q -x --durations=6 > gpurun_out/pytest_cam.log 2>&1
+tail -30 gpurun_out/pytest_cam.log
