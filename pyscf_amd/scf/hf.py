@@ -362,17 +362,20 @@ class SCF:
         return vj, vk
 
     only_dfj = False
-    _eri = None                # {omega: (nao, nao, nao, nao) device tensor}, built on first use like mf._eri (hf.py:2506-2507)
+    _eri = None                # {(mol tables, omega): (nao, nao, nao, nao) device tensor}, built on first use like mf._eri (hf.py:2506-2507)
 
     def _get_jk_incore(self, dm, hermi, with_j, with_k, omega):
         from . import _vhf
-        key = float(omega or 0.0)
+        from ..gto.moleintor import mol_fingerprint
+        om = float(omega or 0.0)
+        key = (mol_fingerprint(self.mol), om)        # content key: an in-place mol.build(atom=...) must not reuse the tensor
         if self._eri is None:
             self._eri = {}
         if key not in self._eri:
+            self._eri = {k: v for k, v in self._eri.items() if k[0] == key[0]}
             t0 = time.perf_counter()
-            self._eri[key] = _vhf.int2e_gpu(self.mol, None, key)
-            self._log('int2e (in-core, omega %g): %.4f s', key, time.perf_counter() - t0)
+            self._eri[key] = _vhf.int2e_gpu(self.mol, None, om)
+            self._log('int2e (in-core, omega %g): %.4f s', om, time.perf_counter() - t0)
         return _vhf.dot_eri_dm(self._eri[key], dm, hermi, with_j, with_k)
 
     def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
