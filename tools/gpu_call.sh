@@ -1,5 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_dft.py tests/test_gpu_vhf.py tests/test_gpu_grad.py tests/test_gpu_response.py tests/test_gpu_xc_sparse.py -m gpu -q -x --durations=6 > gpurun_out/pytest_cam.log 2>&1
-tail -30 gpurun_out/pytest_cam.log
+for t in "syrksk=1" "syrksk=0" "syrksk=1" "syrksk=0"; do
+timeout 300 python tools/kbench.py --steps 4 --tune $t --tag "$t-Konly" --no-j 2>/dev/null | tail -1 | cut -c1-330
+done

@@ -20,6 +20,7 @@ ap.add_argument('--no-split', action='store_true')
 ap.add_argument('--no-square', action='store_true')
 ap.add_argument('--no-fuse', action='store_true')
 ap.add_argument('--ksplit', type=int, default=0)
+ap.add_argument('--no-j', action='store_true', help='K only (as the K_LR / response calls do)')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 npair = a.nao * (a.nao + 1) // 2
@@ -45,16 +46,16 @@ c = np.linalg.qr(rng.standard_normal((a.nao, a.nocc)))[0] * np.sqrt(2.0)
 dm = c.dot(c.T)
 dms = torch.from_numpy(dm[None]).to(dev)
 orb = [df_jk.pad_orbitals(c, dev)]
-df_jk.get_jk_device(obj, dms, orb)
+df_jk.get_jk_device(obj, dms, orb, not a.no_j, True)
 torch.cuda.synchronize()
 import time
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
-    vj, vk = df_jk.get_jk_device(obj, dms, orb)
+    vj, vk = df_jk.get_jk_device(obj, dms, orb, not a.no_j, True)
 torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / a.steps * 1e3
 obj.kernel_timer = df_jk.KernelTimer()
 for _ in range(a.steps):
-    vj, vk = df_jk.get_jk_device(obj, dms, orb)
+    vj, vk = df_jk.get_jk_device(obj, dms, orb, not a.no_j, True)
 s = obj.kernel_timer.summary()
 fl = 2.0 * a.naux * a.nao * a.nao * a.nocc
 by = 8.0 * a.naux * npair
