@@ -281,3 +281,22 @@ def test_lindep_metric_eig_fallback_reference_case():
         out.append(obj.get_eri())
     assert out[0].shape == out[1].shape
     assert np.abs(out[0] - out[1]).max() < 1e-9
+
+
+def test_df_accepts_a_foreign_mole_object():
+    """`pyscf_amd.df.DF(mol)` installed as `mf.with_df` of a stock PySCF mean-field object reads only the
+    integral tables and a few plain attributes of the molecule - here a stand-in that has exactly those (the attribute list
+    a real `pyscf.gto.Mole` also provides) and none of pyscf_amd.gto.Mole's methods."""
+    import types
+    from pyscf_amd import gto, df
+    from tests.conftest import H2O
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    foreign = types.SimpleNamespace(_atm=mol._atm.copy(), _bas=mol._bas.copy(), _env=mol._env.copy(), _atom=list(mol._atom),
+                                    atom=mol.atom, basis=mol.basis, charge=0, spin=0, max_memory=4000, stdout=None, verbose=0)
+    obj = df.DF(foreign)
+    rng = np.random.default_rng(2)
+    dms = rng.standard_normal((2, mol.nao, mol.nao))
+    vj, vk = obj.get_jk(dms, hermi=0)                              # builds on first use, like the reference (df_jk.py:282-287)
+    cderi = ref.cholesky_eri(mol, df.make_auxmol(mol))
+    vj0, vk0 = ref.get_jk(cderi, dms, 0)
+    assert obj.get_naoaux() == 116 and np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9
