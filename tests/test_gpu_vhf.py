@@ -133,3 +133,40 @@ def test_camb3lyp_goldens():
         radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
     assert abs(es[0] - -76.35549300028714) < 2e-8, es
     assert abs(es[1] - -76.36649222362115) < 2e-8 and abs(es[2] - -76.36649222362115) < 2e-8, es
+
+
+def test_reference_h2o_631g_scf_goldens():
+    """pyscf/scf/test/test_h2o.py:52-107 through the product, exact (in-core 4-centre) and density-fitted ('weigend'): RHF and
+    UHF -75.98394849812, ROHF cation -75.578396379589748; DF-RHF / DF-UHF -75.983210886950, DF-ROHF cation
+    -75.5775921401438 (all to 1e-9 Eh, conv_tol 1e-11)."""
+    from pyscf_amd import gto, scf
+    mol = gto.M(atom=H2O, basis='6-31g')
+    cat = gto.M(atom=H2O, basis='6-31g', charge=1, spin=1)
+    for make, e_ref in ((lambda: scf.RHF(mol), -75.98394849812), (lambda: scf.UHF(mol), -75.98394849812),
+                        (lambda: scf.ROHF(cat), -75.578396379589748),
+                        (lambda: scf.RHF(mol).density_fit(auxbasis='weigend'), -75.983210886950),
+                        (lambda: scf.UHF(mol).density_fit(auxbasis='weigend'), -75.983210886950),
+                        (lambda: scf.ROHF(cat).density_fit(auxbasis='weigend'), -75.5775921401438)):
+        mf = make()
+        mf.conv_tol = 1e-11
+        e = mf.kernel()
+        assert mf.converged and abs(e - e_ref) < 1e-9, (type(mf).__name__, mf.with_df is not None, e, e_ref)
+
+
+@pytest.mark.parametrize('xc,e_ref', [('lda,vwn', -75.350995324984709), ('b3lypg', -75.927304010489976)])
+def test_reference_uks_cation_goldens(xc, e_ref):
+    """pyscf/dft/test/test_h2o.py:131-142: UKS of H2O+ / 6-31g with exact J/K, (50, 194) grids, Treutler pruning."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import radi
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
+    try:
+        cat = gto.M(atom=H2O, basis='6-31g', charge=1, spin=1)
+        mf = dft.UKS(cat, xc=xc)
+        mf.grids.atom_grid = {'H': (50, 194), 'O': (50, 194)}
+        mf.grids.prune = dft.gen_grid.treutler_prune
+        mf.conv_tol = 1e-10
+        e = mf.kernel()
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    assert mf.converged and abs(e - e_ref) < 2e-8, (xc, e, e_ref)
