@@ -92,3 +92,45 @@ def test_tddft_b3lyp_and_solvers():
     assert np.abs(ed - e[:3]).max() < 1e-6 and np.abs(eda - et[:3]).max() < 1e-6
     e = tdscf.TDA(_ks('b3lypg')).kernel(nstates=5)[0] * EV
     assert abs(ref.fp(e) - -41.385520327568869) < 3 * TOL, ref.fp(e)
+
+
+def test_excitation_energies_with_exact_integrals():
+    """The same reference values with the SAME integrals as the reference used (in-core 4-centre J/K, scf/_vhf.py - no
+    density fitting): TDA / TDHF singlets and triplets of HF / 6-31G (pyscf/tdscf/test/test_tdrhf.py:41-74), TDDFT and TDA with
+    LDA and B3LYP (test_tdrks.py:88-196) to 3e-5 eV - what is left is the eV conversion constant (27.2114 here)."""
+    from pyscf_amd import gto, scf, dft, tdscf
+    from pyscf_amd.dft import radi
+    tol = 3e-5
+    mol = gto.M(atom=HF, basis='631g')
+    mf = scf.RHF(mol).run(conv_tol=1e-11)
+    assert mf.with_df is None
+    for cls, singlet, want in ((tdscf.TDA, True, [11.90276464, 11.90276464, 16.86036434]),
+                               (tdscf.TDA, False, [11.01747918, 11.01747918, 13.16955056]),
+                               (tdscf.TDHF, True, [11.83487199, 11.83487199, 16.66309285]),
+                               (tdscf.TDHF, False, [10.8919234, 10.8919234, 12.63440705])):
+        td = cls(mf)
+        td.singlet = singlet
+        e = td.kernel(nstates=5)[0] * EV
+        assert np.abs(e[:3] - want).max() < tol, (cls.__name__, singlet, e[:3])
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
+    try:
+        ks = {}
+        for xc in ('lda, vwn', 'b3lyp5'):
+            ks[xc] = dft.RKS(mol, xc=xc)
+            ks[xc].grids.prune = None
+            ks[xc].run(conv_tol=1e-11)
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    e = tdscf.TDDFT(ks['lda, vwn']).kernel(nstates=5)[0] * EV
+    assert np.abs(e - [9.67249402, 9.67249402, 14.79447862, 30.32465371, 30.32465371]).max() < tol, e
+    td = tdscf.TDA(ks['lda, vwn'])
+    td.singlet = False
+    e = td.kernel(nstates=6)[0] * EV
+    assert np.abs(e - [9.0139312, 9.0139312, 12.42444659, 29.38040677, 29.63058493, 29.63058493]).max() < tol, e
+    e = tdscf.TDDFT(ks['b3lyp5']).kernel(nstates=5)[0] * EV
+    assert abs(ref.fp(e) - -41.29609453661341) < 3 * tol, ref.fp(e)
+    td = tdscf.TDA(ks['b3lyp5'])
+    td.singlet = False
+    e = td.kernel(nstates=5)[0] * EV
+    assert abs(ref.fp(e) - -40.020204585289648) < 3 * tol, ref.fp(e)
