@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_tdscf.py -m gpu -q -x -k exact > gpurun_out/pytest_td.log 2>&1
-tail -15 gpurun_out/pytest_td.log
+for t in "syrkprobe=0" "syrkprobe=1" "syrkprobe=2"; do
+timeout 300 python tools/kbench.py --steps 4 --tune $t --tag "$t" --no-j 2>/dev/null | tail -1 | cut -c1-260
+done
