@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for t in "syrkprobe=0" "syrkprobe=1" "syrkprobe=2"; do
-timeout 300 python tools/kbench.py --steps 4 --tune $t --tag "$t" --no-j 2>/dev/null | tail -1 | cut -c1-260
-done
+mkdir -p gpurun_out
+timeout 900 python tools/shard_probe.py --nwater 128 --basis cc-pvdz --world 8 --rank 3 > gpurun_out/shard_h2o128.json 2> gpurun_out/shard_h2o128.err
+tail -2 gpurun_out/shard_h2o128.err; cat gpurun_out/shard_h2o128.json
