@@ -8,8 +8,8 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'lib', 'libpyscf_amd.so')
 SOURCES = ['capi.hip', 'df_jk.hip', 'int3c2e.hip', 'int2e.hip', 'int1e.hip', 'grid.hip', 'xc.hip', 'xc_sparse.hip']
 # (source, extra flags, object tag): the int3c2e family is compiled once per aux angular momentum
-VARIANTS = [('int3c2e_lk.hip', ['-DPAMD_LK=%d' % lk], 'lk%d' % lk) for lk in range(6)] + \
-           [('int3c2e_grad_lk.hip', ['-DPAMD_LK=%d' % lk], 'lk%d' % lk) for lk in range(6)]
+VARIANTS = [('int3c2e_lk.hip', ['-DPAMD_LK=%d' % lk], 'lk%d' % lk) for lk in range(7)] + \
+           [('int3c2e_grad_lk.hip', ['-DPAMD_LK=%d' % lk], 'lk%d' % lk) for lk in range(7)]
 
 
 def _newest(paths):

@@ -18,12 +18,14 @@ int launch_int3c2e_lk2(int, int, const Int3c2eArgs &, hipStream_t);
 int launch_int3c2e_lk3(int, int, const Int3c2eArgs &, hipStream_t);
 int launch_int3c2e_lk4(int, int, const Int3c2eArgs &, hipStream_t);
 int launch_int3c2e_lk5(int, int, const Int3c2eArgs &, hipStream_t);
+int launch_int3c2e_lk6(int, int, const Int3c2eArgs &, hipStream_t);
 int launch_int3c2e_grad_lk0(int, int, const Int3c2eGradArgs &, hipStream_t);
 int launch_int3c2e_grad_lk1(int, int, const Int3c2eGradArgs &, hipStream_t);
 int launch_int3c2e_grad_lk2(int, int, const Int3c2eGradArgs &, hipStream_t);
 int launch_int3c2e_grad_lk3(int, int, const Int3c2eGradArgs &, hipStream_t);
 int launch_int3c2e_grad_lk4(int, int, const Int3c2eGradArgs &, hipStream_t);
 int launch_int3c2e_grad_lk5(int, int, const Int3c2eGradArgs &, hipStream_t);
+int launch_int3c2e_grad_lk6(int, int, const Int3c2eGradArgs &, hipStream_t);
 }
 
 using namespace pamd;
@@ -198,7 +200,8 @@ int PAMD_int3c2e_class(int li, int lj, int lk, const PAMD_int3c2e_args *args, vo
     case 3: return launch_int3c2e_lk3(li, lj, a, st);
     case 4: return launch_int3c2e_lk4(li, lj, a, st);
     case 5: return launch_int3c2e_lk5(li, lj, a, st);
-    default: return set_error(-2, "int3c2e: aux angular momentum > 5 unsupported", __FILE__, __LINE__);
+    case 6: return launch_int3c2e_lk6(li, lj, a, st);
+    default: return set_error(-2, "int3c2e: aux angular momentum > 6 unsupported", __FILE__, __LINE__);
     }
 }
 
@@ -218,7 +221,8 @@ int PAMD_int3c2e_grad_class(int li, int lj, int lk, const PAMD_int3c2e_grad_args
     case 3: return launch_int3c2e_grad_lk3(li, lj, a, st);
     case 4: return launch_int3c2e_grad_lk4(li, lj, a, st);
     case 5: return launch_int3c2e_grad_lk5(li, lj, a, st);
-    default: return set_error(-2, "int3c2e_grad: aux angular momentum > 5 unsupported", __FILE__, __LINE__);
+    case 6: return launch_int3c2e_grad_lk6(li, lj, a, st);
+    default: return set_error(-2, "int3c2e_grad: aux angular momentum > 6 unsupported", __FILE__, __LINE__);
     }
 }
 

@@ -1,5 +1,5 @@
 // Instantiates the gradient-contraction kernel family for one aux angular momentum (compile with
-// -DPAMD_LK=<0..5>); see int3c2e_grad_kernel.h.
+// -DPAMD_LK=<0..6>); see int3c2e_grad_kernel.h.
 #include "int3c2e_grad_kernel.h"
 
 #ifndef PAMD_LK
@@ -26,13 +26,16 @@ int PAMD_CAT(launch_int3c2e_grad_lk, PAMD_LK)(int li, int lj, const Int3c2eGradA
     case 3 * 8 + 2: return launch_grad_class<3, 2, LK>(a, st);
     case 3 * 8 + 3: return launch_grad_class<3, 3, LK>(a, st);
     case 4 * 8 + 0: return launch_grad_class<4, 0, LK>(a, st);   // also the 2-centre d(P|Q) with l_P = 4
+#if PAMD_LK <= 5              // g AO shells go with fitting shells up to h (quadruple-zeta sets); i fitting shells (def2 3d metals) with AO l <= 3
     case 4 * 8 + 1: return launch_grad_class<4, 1, LK>(a, st);
     case 4 * 8 + 2: return launch_grad_class<4, 2, LK>(a, st);
     case 4 * 8 + 3: return launch_grad_class<4, 3, LK>(a, st);
     case 4 * 8 + 4: return launch_grad_class<4, 4, LK>(a, st);
+#endif
     case 5 * 8 + 0: return launch_grad_class<5, 0, LK>(a, st);   // 2-centre d(P|Q) with l_P = 5
+    case 6 * 8 + 0: return launch_grad_class<6, 0, LK>(a, st);   // 2-centre d(P|Q) with l_P = 6
     default:
-        return set_error(-2, "int3c2e_grad: unsupported (l_i, l_j) class (AO l <= 4, aux l <= 5 supported)", __FILE__, __LINE__);
+        return set_error(-2, "int3c2e_grad: unsupported (l_i, l_j) class (AO l <= 4 with aux l <= 5, AO l <= 3 with aux l = 6)", __FILE__, __LINE__);
     }
 }
 

@@ -20,10 +20,13 @@ def predefined_auxbasis(mol, basis, xc='HF'):
     return DEFAULT_AUXBASIS.get(_mole._format_basis_name(basis))
 
 
-# electrons per l of the ground-state atom, H-Ar (pyscf/data/elements.py:457-468 CONFIGURATION)
+# electrons per l of the ground-state atom, H-Kr (pyscf/data/elements.py:457-468 CONFIGURATION)
 _CONFIGURATION = [[0, 0, 0, 0], [1, 0, 0, 0], [2, 0, 0, 0], [3, 0, 0, 0], [4, 0, 0, 0], [4, 1, 0, 0],
                   [4, 2, 0, 0], [4, 3, 0, 0], [4, 4, 0, 0], [4, 5, 0, 0], [4, 6, 0, 0],
-                  [5, 6, 0, 0], [6, 6, 0, 0], [6, 7, 0, 0], [6, 8, 0, 0], [6, 9, 0, 0], [6, 10, 0, 0], [6, 11, 0, 0], [6, 12, 0, 0]]
+                  [5, 6, 0, 0], [6, 6, 0, 0], [6, 7, 0, 0], [6, 8, 0, 0], [6, 9, 0, 0], [6, 10, 0, 0], [6, 11, 0, 0], [6, 12, 0, 0],
+                  [7, 12, 0, 0], [8, 12, 0, 0], [8, 12, 1, 0], [8, 12, 2, 0], [8, 12, 3, 0], [7, 12, 5, 0], [8, 12, 5, 0], [8, 12, 6, 0],
+                  [8, 12, 7, 0], [8, 12, 8, 0], [7, 12, 10, 0], [8, 12, 10, 0], [8, 13, 10, 0], [8, 14, 10, 0], [8, 15, 10, 0],
+                  [8, 16, 10, 0], [8, 17, 10, 0], [8, 18, 10, 0]]
 ETB_BETA = 2.0          # pyscf/df/addons.py:33
 
 

@@ -119,7 +119,7 @@ def load_basis(name, symb):
     key = _ALIAS.get(_format_basis_name(name))
     el = std_symbol_without_ghost(symb)
     if key is None or el not in _BASIS_DATA[key]:
-        raise KeyError('Basis %s not found for %s (packaged table covers H-Ar for: %s)'
+        raise KeyError('Basis %s not found for %s (packaged table covers H-Kr for: %s)'
                        % (name, symb, ', '.join(sorted(set(_ALIAS)))))
     return [[sh[0]] + [list(ec) for ec in sh[1:]] for sh in _BASIS_DATA[key][el]]
 

@@ -20,7 +20,7 @@ from . import mole as _mole
 
 EXPCUTOFF = 60.0          # primitive-pair screening: drop exp(-mu R^2) < e^-60 (libcint default)
 LMAX_AO = 4
-LMAX_AUX = 5
+LMAX_AUX = 6          # i fitting shells (def2-universal-jkfit of the 3d metals) with AO shells up to f
 
 
 # --------------------------------------------------------------------------- cart -> sph
@@ -234,6 +234,8 @@ class IntEngine:
             raise NotImplementedError('AO angular momentum > %d' % LMAX_AO)
         if self.aux is not None and self.aux.l.max() > LMAX_AUX:
             raise NotImplementedError('aux angular momentum > %d' % LMAX_AUX)
+        if self.aux is not None and self.aux.l.max() > 5 and self.ao.l.max() > 3:
+            raise NotImplementedError('i fitting shells are instantiated with AO shells up to f only')
         n = self.lib.PAMD_rys_table_len()
         self.rys = torch.empty(n, dtype=torch.float64, device=device)
         if torch.device(device).type == 'cuda':

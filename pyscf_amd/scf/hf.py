@@ -468,7 +468,10 @@ class RHF(SCF):
 # pyscf/data/elements.py:582-596 (electrons per l of the spherically averaged ROHF atom)
 NRSRHF_CONFIGURATION = [[0, 0, 0, 0], [1, 0, 0, 0], [2, 0, 0, 0], [3, 0, 0, 0], [4, 0, 0, 0], [4, 1, 0, 0],
                         [4, 2, 0, 0], [4, 3, 0, 0], [4, 4, 0, 0], [4, 5, 0, 0], [4, 6, 0, 0],
-                        [5, 6, 0, 0], [6, 6, 0, 0], [6, 7, 0, 0], [6, 8, 0, 0], [6, 9, 0, 0], [6, 10, 0, 0], [6, 11, 0, 0], [6, 12, 0, 0]]
+                        [5, 6, 0, 0], [6, 6, 0, 0], [6, 7, 0, 0], [6, 8, 0, 0], [6, 9, 0, 0], [6, 10, 0, 0], [6, 11, 0, 0], [6, 12, 0, 0],
+                        [7, 12, 0, 0], [8, 12, 0, 0], [8, 13, 0, 0], [8, 12, 2, 0], [8, 12, 3, 0], [8, 12, 4, 0], [6, 12, 7, 0], [6, 12, 8, 0],
+                        [6, 12, 9, 0], [6, 12, 10, 0], [7, 12, 10, 0], [8, 12, 10, 0], [8, 13, 10, 0], [8, 14, 10, 0], [8, 15, 10, 0],
+                        [8, 16, 10, 0], [8, 17, 10, 0], [8, 18, 10, 0]]
 
 
 def _has_device():
@@ -530,7 +533,7 @@ def init_guess_by_minao(mol, s1e=None, device=None):
             continue
         nuc = _mole.charge(symb)              # 0 for ghost atoms: basis functions but no atomic density (hf.py:430-436)
         if nuc >= len(NRSRHF_CONFIGURATION):
-            raise NotImplementedError('minao guess: element table covers H-Ar')
+            raise NotImplementedError('minao guess: element table covers H-Kr')
         ano = _mole.load_basis('ano', symb)
         by_l = {}
         for b in ano:

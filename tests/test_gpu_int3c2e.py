@@ -61,6 +61,22 @@ def test_all_classes_low_symmetry(basis, auxbasis):
     assert err < 1e-11 * max(1.0, np.abs(want).max()), err
 
 
+def test_fourth_period_classes_with_i_fitting_shells():
+    """3d metal with the def2 sets: AO shells up to f, fitting shells up to i (l = 6; def2-universal-jkfit of Sc-Zn), no symmetry:
+    the (l_i l_j | 6) kernels, the (6, 0 | l) metric classes, and the tensor they build."""
+    from pyscf_amd import gto, df
+    from pyscf_amd.df import incore
+    atom = 'Zn 0.1 -0.2 0.05; O 0.25 0.4 1.85; H 0.95 -0.3 2.35'
+    mol = gto.M(atom=atom, basis='def2-tzvp', spin=1)
+    aux = df.make_auxmol(mol)
+    assert mol._bas[:, 1].max() == 3 and aux._bas[:, 1].max() == 6
+    got = incore.aux_e2_gpu(mol, aux, _dev()).cpu().numpy()
+    want = ref.pack_tril(ref.int3c2e(mol, aux))
+    assert np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max())
+    cderi = incore.cholesky_eri_gpu(mol, aux, _dev()).cpu().numpy()
+    assert np.abs(cderi - ref.cholesky_eri(mol, aux)).max() < 1e-9
+
+
 def test_long_range_integrals_and_rsh_get_jk(h2o_dz):
     """omega > 0: erf(omega r12)/r12 integrals vs the oracle (tight), and DF.get_jk(dm, omega=1.1) vs the
     reference fingerprints (3 places, pyscf/df/test/test_df.py:101-117)."""

@@ -103,6 +103,44 @@ def test_second_row_rhf_and_b3lyp_vs_oracle():
     assert ks.converged and conv and abs(e - e0) < 1e-8, (e, e0)
 
 
+def test_fourth_period_rhf_b3lyp_and_gradient_vs_oracle():
+    """K-Kr: basis tables, MINAO occupations of the 4th period (pyscf/data/elements.py:582-620), radii and period-dependent
+    grids; i fitting shells.  KCl and ZnH2 / def2-SVP: DF-RHF and DF-RKS B3LYP energies against the oracle (own integrals,
+    own grids), the ZnH2 DF-RHF gradient against finite differences of the oracle energy."""
+    from oracle import ref_dft, ref_grad
+    from pyscf_amd import gto, scf, dft, df
+    from pyscf_amd.dft import libxc
+    B = 0.52917721092
+    for atoms in ([('K', (0., 0., 0.)), ('Cl', (0., 0., 2.67))], [('Zn', (0., 0.02, 0.)), ('H', (0., 0.1, 1.55)), ('H', (0.1, 0., -1.5))]):
+        mol = gto.M(atom=atoms, basis='def2-svp')
+        cderi = ref.cholesky_eri(mol, df.make_auxmol(mol))
+        mf = scf.RHF(mol).density_fit()
+        mf.conv_tol = 1e-10
+        e = mf.kernel()
+
+        def veff(dm, c, occ):
+            vj, vk = ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
+            return vj - .5 * vk
+        conv, e0 = ref.rhf_kernel(mol, veff, conv_tol=1e-10)[:2]
+        assert mf.converged and conv and abs(e - e0) < 1e-8, (atoms[0][0], e, e0)
+        if atoms[0][0] == 'Zn':
+            g = mf.nuc_grad_method().kernel()
+            assert abs(g.sum(axis=0)).max() < 1e-8
+            comps = [(0, 2), (1, 1)]
+            gfd = ref_grad.fd_gradient([(s, tuple(np.array(x) / B)) for s, x in atoms], 'def2-svp', None, components=comps)
+            for a, x in comps:
+                assert abs(g[a, x] - gfd[a, x]) < 1e-6, (a, x, g[a, x], gfd[a, x])
+        ks = dft.RKS(mol, xc='b3lyp').density_fit()
+        ks.conv_tol = 1e-10
+        e = ks.kernel()
+        coords, weights = ref_dft.build_grids(mol)
+        assert ks.grids.size == len(weights)
+        hyb, fac = libxc.parse_xc('b3lyp')
+        conv, e0 = ref_dft.rks_energy(mol, fac, hyb, True, coords, weights,
+                                      lambda dm, c, occ, with_k: ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ))[:2]
+        assert ks.converged and conv and abs(e - e0) < 1e-8, (atoms[0][0], e, e0)
+
+
 def test_golden_minao_guess():
     """Docstring example of init_guess_by_minao (pyscf/scf/hf.py:363-368): H2 / sto-3g."""
     from pyscf_amd import gto

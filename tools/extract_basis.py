@@ -3,7 +3,7 @@ ship with the reference (pyscf/gto/basis/*.dat, public Basis-Set-Exchange data).
 
 Run in the authoring container only (needs /root/reference):
     python tools/extract_basis.py
-Only numeric exponent/coefficient tables of H-Ar are kept: the basis sets the hot path's
+Only numeric exponent/coefficient tables of H-Kr (all-electron sets) are kept: the basis sets the hot path's
 configurations need (sto-3g, 6-31g, cc-pvdz, cc-pvtz, def2-svp, def2-tzvp and their J/JK
 fitting sets) plus a few common neighbours (cc-pvqz, aug-cc-pvdz/tz, Pople polarised sets).
 """
@@ -32,7 +32,8 @@ FILES = {
     'ccpvqzri': 'cc-pvqz-ri.dat', 'def2qzvp': 'def2-qzvp.dat', 'def2qzvpp': 'def2-qzvpp.dat', 'def2tzvpp': 'def2-tzvpp.dat',
     'def2svpd': 'def2-svpd.dat', 'def2tzvpd': 'def2-tzvpd.dat',
 }
-ELEMENTS = ['H', 'He', 'Li', 'Be', 'B', 'C', 'N', 'O', 'F', 'Ne', 'Na', 'Mg', 'Al', 'Si', 'P', 'S', 'Cl', 'Ar']
+ELEMENTS = ['H', 'He', 'Li', 'Be', 'B', 'C', 'N', 'O', 'F', 'Ne', 'Na', 'Mg', 'Al', 'Si', 'P', 'S', 'Cl', 'Ar',
+            'K', 'Ca', 'Sc', 'Ti', 'V', 'Cr', 'Mn', 'Fe', 'Co', 'Ni', 'Cu', 'Zn', 'Ga', 'Ge', 'As', 'Se', 'Br', 'Kr']
 
 out = {}
 for name, fn in FILES.items():

@@ -1,8 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for t in "syrk3=0 --ksplit 4" "syrk3=1 --ksplit 4" "syrk3=1 --ksplit 6" "syrk3=1 --ksplit 3"; do
-timeout 300 python tools/kbench.py --steps 4 --no-j --tag "$t" --tune $t 2>/dev/null | tail -1 | cut -c1-250
-done
-for t in "syrk3=0 --ksplit 4" "syrk3=1 --ksplit 6"; do
-timeout 300 python tools/kbench.py --steps 4 --tag "JK $t" --tune $t 2>/dev/null | tail -1 | cut -c1-300
-done
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_int3c2e.py tests/test_gpu_scf.py -m gpu -q -x --durations=5 > gpurun_out/pytest_tm.log 2>&1
+tail -25 gpurun_out/pytest_tm.log
