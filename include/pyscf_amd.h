@@ -215,8 +215,8 @@ int PAMD_rho_from_mo_pair(const double *d_ca, const double *d_cb, long comp_stri
                           double coef, double *d_rho, long ldg, void *stream);
 int PAMD_rho_from_dm(const double *d_ao, const double *d_c0t, int nao, int ldao, long ldg_rows, long ldc,
                      int ncomp, long ng, double *d_rho, long ldg, void *stream);
-/* fac[PAMD_XC_NFAC = 9]: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C, ITYH = short-range B88 (libxc gga_x_ityh)},
- * then the omega of ITYH.  wv[4][ldg] = w (vrho/2, 2 vsigma grad rho);
+/* fac[PAMD_XC_NFAC = 10]: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C, ITYH = short-range B88 (libxc gga_x_ityh),
+ * WB97 = the omega-B97 exchange-correlation functional}, then the omega of ITYH / WB97.  wv[4][ldg] = w (vrho/2, 2 vsigma grad rho);
  * d_acc[0] += sum w rho, d_acc[1] += sum w e_xc; d_exc nullable */
 int PAMD_eval_xc(const double *fac, int gga, const double *d_rho, const double *d_weights, long ng,
                  long ldg, double *d_wv, double *d_exc, double *d_acc, void *stream);

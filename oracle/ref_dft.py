@@ -301,20 +301,105 @@ def _build_functionals():
     # gga_x_ityh defines it: e_s = -cx rho_s^(4/3) F(x) att(a), a = omega / (2 k), k = sqrt(9 pi / (2 cx F)) rho_s^(1/3)
     om = sp.Symbol('omega', positive=True)
     out['ityh'] = 2 * _ityh_spin(sp, rs_, sigma / 4, om)
+    out['wb97'] = _wb97(sp, rho / 2, rho / 2, sigma / 4, sigma / 4, om)
     fns = {}
     mods = [{'erf': _erf}, 'numpy']
     for k, e in out.items():
-        v = (rho, sigma, om) if k == 'ityh' else (rho, sigma)
-        fns[k] = (sp.lambdify(v, e, mods), sp.lambdify(v, sp.diff(e, rho), mods),
-                  sp.lambdify(v, sp.diff(e, sigma), mods),
-                  sp.lambdify(v, sp.diff(e, rho, 2), mods),
-                  sp.lambdify(v, sp.diff(e, rho, sigma), mods),
-                  sp.lambdify(v, sp.diff(e, sigma, 2), mods))
+        v = (rho, sigma, om) if k in _WITH_OMEGA else (rho, sigma)
+        # lambdas (and the symbolic derivatives behind them) are made when first asked for
+        fns[k] = _LazySeq([lambda e=e, v=v: sp.lambdify(v, e, mods),
+                           lambda e=e, v=v: sp.lambdify(v, sp.diff(e, rho), mods),
+                           lambda e=e, v=v: sp.lambdify(v, sp.diff(e, sigma), mods),
+                           lambda e=e, v=v: sp.lambdify(v, sp.diff(e, rho, 2), mods),
+                           lambda e=e, v=v: sp.lambdify(v, sp.diff(e, rho, sigma), mods),
+                           lambda e=e, v=v: sp.lambdify(v, sp.diff(e, sigma, 2), mods)])
     return fns
+
+
+_WITH_OMEGA = ('ityh', 'wb97')
+
+
+class _LazySeq:
+    """Sequence of callables built on first access (int index or slice)."""
+
+    def __init__(self, makers):
+        self._makers = makers
+        self._made = {}
+
+    def _get(self, i):
+        if i not in self._made:
+            self._made[i] = self._makers[i]()
+        return self._made[i]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._get(j) for j in range(*i.indices(len(self._makers)))]
+        return self._get(i if i >= 0 else len(self._makers) + i)
+
+
+def _wb97(sp, ra, rb, saa, sbb, om):
+    """omega-B97 exchange-correlation energy per volume (Chai, Head-Gordon, JCP 128, 084106 (2008), Table I; libxc
+    hyb_gga_xc_wb97): short-range LSDA exchange (the erf attenuation of _ityh_spin with k_F of the spin density) times the B97
+    series in u = g s^2 / (1 + g s^2), g = 0.004; B97 correlation on the Stoll partition of the ORIGINAL PW92 parametrisation
+    (not the extra-digit 'pw_mod' one PBE uses), same-spin g = 0.2, opposite-spin g = 0.006 on the mean of the two s^2.  The
+    long-range exchange is the exact one (alpha = 1 at omega = 0.4).  Pinned by He / cc-pVDZ -2.89430888240579
+    (pyscf/dft/test/test_he.py:92-95)."""
+    pi = sp.pi
+    F = lambda v: sp.Float(v, 20)
+    cx = [F(v) for v in ('1.00000', '1.13116', '-2.74915', '12.0900', '-5.71642')]
+    css = [F(v) for v in ('1.00000', '-2.55352', '11.8926', '-26.9452', '17.0927')]
+    cos = [F(v) for v in ('1.00000', '3.99051', '-17.0066', '1.07292', '8.88211')]
+
+    def series(c, g, s, r83):
+        u = g * s / (r83 + g * s)                              # = g s^2 / (1 + g s^2) without forming s^2 = s / r^(8/3)
+        return sum(ci * u ** i for i, ci in enumerate(c))
+
+    def att(a):
+        b = sp.exp(-1 / (4 * a * a)) - 1
+        c = 2 * a * a * b + sp.Rational(1, 2)
+        closed = 1 - sp.Rational(8, 3) * a * (sp.sqrt(pi) * sp.erf(1 / (2 * a)) + 2 * a * (b - c))
+        coef = [36, -960, 26880, -829440, 28385280, -1073479680, 44590694400, -2021444812800]
+        ser = sum(sp.Integer(1) / (sp.Integer(cf) * a ** (2 * n + 2)) for n, cf in enumerate(coef))
+        return sp.Piecewise((ser, a > 2), (closed, True))
+
+    def ex_spin(r, s):
+        clda = sp.Rational(3, 2) * (3 / (4 * pi)) ** sp.Rational(1, 3)
+        kf = (6 * pi ** 2 * r) ** sp.Rational(1, 3)
+        return -clda * r ** sp.Rational(4, 3) * att(om / (2 * kf)) * series(cx, F('0.004'), s, r ** sp.Rational(8, 3))
+
+    def pw_g(rs, A, a1, b1, b2, b3, b4):
+        q = 2 * A * (b1 * sp.sqrt(rs) + b2 * rs + b3 * rs ** sp.Rational(3, 2) + b4 * rs ** 2)
+        return -2 * A * (1 + a1 * rs) * sp.log(1 + 1 / q)
+    para = [F(x) for x in ('0.031091', '0.21370', '7.5957', '3.5876', '1.6382', '0.49294')]
+    ferro = [F(x) for x in ('0.015545', '0.20548', '14.1189', '6.1977', '3.3662', '0.62517')]
+    stiff = [F(x) for x in ('0.016887', '0.11125', '10.357', '3.6231', '0.88026', '0.49671')]
+
+    def ec_pw(na, nb):
+        n = na + nb
+        zeta = (na - nb) / n
+        rs = (3 / (4 * pi * n)) ** sp.Rational(1, 3)
+        fz = ((1 + zeta) ** sp.Rational(4, 3) + (1 - zeta) ** sp.Rational(4, 3) - 2) / (2 ** sp.Rational(4, 3) - 2)
+        e0, e1, mac = pw_g(rs, *para), pw_g(rs, *ferro), pw_g(rs, *stiff)
+        return n * (e0 - mac * fz / F('1.709921') * (1 - zeta ** 4) + (e1 - e0) * fz * zeta ** 4)
+
+    def ec_ferro(n):
+        return n * pw_g((3 / (4 * pi * n)) ** sp.Rational(1, 3), *ferro)
+    ra83, rb83 = ra ** sp.Rational(8, 3), rb ** sp.Rational(8, 3)
+    eaa, ebb = ec_ferro(ra), ec_ferro(rb)
+    eab = ec_pw(ra, rb) - eaa - ebb
+    # opposite spin: u of the mean s^2 = (saa / ra^(8/3) + sbb / rb^(8/3)) / 2
+    g_os = F('0.006')
+    s_av = (saa * rb83 + sbb * ra83) / 2
+    u_os = g_os * s_av / (ra83 * rb83 + g_os * s_av)
+    return (ex_spin(ra, saa) + ex_spin(rb, sbb) + eaa * series(css, F('0.2'), saa, ra83) + ebb * series(css, F('0.2'), sbb, rb83) +
+            eab * sum(ci * u_os ** i for i, ci in enumerate(cos)))
 
 
 def _erf(x):
     from scipy.special import erf
+    x = np.asarray(x)
+    if x.dtype == np.longdouble:                       # scipy has no 80-bit erf; its argument 1/(2a) is harmless in float64
+        return erf(x.astype(np.float64)).astype(np.longdouble)
     return erf(x)
 
 
@@ -338,11 +423,15 @@ def _ityh_spin(sp, r, s, om):
     return -cx * r ** sp.Rational(4, 3) * F * att
 
 
-_ORDER = ['slater', 'vwn5', 'vwnrpa', 'b88', 'lyp', 'pbex', 'pbec', 'ityh']      # fac[8] = omega of 'ityh'
+_ORDER = ['slater', 'vwn5', 'vwnrpa', 'b88', 'lyp', 'pbex', 'pbec', 'ityh', 'wb97']      # fac[9] = omega of 'ityh' / 'wb97'
 
 
 def _args(fac, name, *v):
-    return v + (float(fac[8]),) if name == 'ityh' else v
+    if name == 'wb97':
+        # the expanded derivatives of the B97 series hold powers like rho^(-40/3) sigma^4: evaluated in 80-bit floats so that
+        # they neither overflow nor underflow on the low-density tail (results are cast back by the callers' += into float64)
+        v = tuple(np.asarray(x, dtype=np.longdouble) for x in v)
+    return v + (float(fac[9]),) if name in _WITH_OMEGA else v
 
 
 def eval_xc(fac, rho, sigma):
@@ -628,12 +717,14 @@ def _build_functionals_pol():
     out['pbec'] = rho * (ec + H)
     om = sp.Symbol('omega', positive=True)
     out['ityh'] = _ityh_spin(sp, ra, saa, om) + _ityh_spin(sp, rb, sbb, om)
+    out['wb97'] = _wb97(sp, ra, rb, saa, sbb, om)
     fns = {}
     v = (ra, rb, saa, sab, sbb)
     mods = [{'erf': _erf}, 'numpy']
     for k, e in out.items():
-        vv = v + (om,) if k == 'ityh' else v
-        fns[k] = [sp.lambdify(vv, e, mods)] + [sp.lambdify(vv, sp.diff(e, x), mods) for x in v]
+        vv = v + (om,) if k in _WITH_OMEGA else v
+        fns[k] = _LazySeq([lambda e=e, vv=vv: sp.lambdify(vv, e, mods)] +
+                          [lambda e=e, vv=vv, x=x: sp.lambdify(vv, sp.diff(e, x), mods) for x in v])
     return fns
 
 

@@ -182,8 +182,9 @@ using Dual = DualT<double>;
 
 // attenuated (short-range) B88 exchange of one spin channel, defined with the spin-polarised functionals below
 template <class T> __device__ inline T ityh_spin(T r, T s, double omega);
+template <class T> __device__ inline T wb97_xc(T ra, T rb, T saa, T sbb, double omega);
 
-enum { F_SLATER = 0, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC, F_ITYH, F_NUM };
+enum { F_SLATER = 0, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC, F_ITYH, F_WB97, F_NUM };
 
 struct XCSpec {
     double fac[F_NUM];
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void eval_xc_kernel(XCSpec spec, int gga, cons
             if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * pbe_x(dr, ds);
             if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c(dr, ds);
             if (spec.fac[F_ITYH] != 0) tot = tot + spec.fac[F_ITYH] * (2.0 * ityh_spin(0.5 * dr, 0.25 * ds, spec.omega));
+            if (spec.fac[F_WB97] != 0) tot = tot + spec.fac[F_WB97] * wb97_xc(0.5 * dr, 0.5 * dr, 0.25 * ds, 0.25 * ds, spec.omega);
             e = tot.v; vr = tot.r; vs = tot.s;
         }
         nel = w * r;
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(256) void eval_fxc_kernel(XCSpec spec, int gga, con
         if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * pbe_x(dr, ds);
         if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c(dr, ds);
         if (spec.fac[F_ITYH] != 0) tot = tot + spec.fac[F_ITYH] * (2.0 * ityh_spin(0.5 * dr, 0.25 * ds, spec.omega));
+        if (spec.fac[F_WB97] != 0) tot = tot + spec.fac[F_WB97] * wb97_xc(0.5 * dr, 0.5 * dr, 0.25 * ds, 0.25 * ds, spec.omega);
         dvr = tot.r.e; vs = tot.s.v; dvs = tot.s.e;
     }
     wv[g] = 0.5 * w * dvr;
@@ -381,6 +384,8 @@ template <class S> __device__ inline DualT<S> ad_asinh(DualT<S> a) { return dasi
 template <class S> __device__ inline D5T<S> ad_asinh(D5T<S> a) { return asinh5(a); }
 template <class S> __device__ inline DualT<S> ad_erf(DualT<S> a) { return chain(a, s_erf(a.v), 1.1283791670955126 * s_exp(-(a.v * a.v))); }
 template <class S> __device__ inline D5T<S> ad_erf(D5T<S> a) { return chain5(a, s_erf(a.v), 1.1283791670955126 * s_exp(-(a.v * a.v))); }
+template <class S> __device__ inline DualT<S> ad_log(DualT<S> a) { return dlog(a); }
+template <class S> __device__ inline D5T<S> ad_log(D5T<S> a) { return log5(a); }
 template <class S> __device__ inline double ad_val(DualT<S> a) { return s_val(a.v); }
 template <class S> __device__ inline double ad_val(D5T<S> a) { return s_val(a.v); }
 
@@ -412,6 +417,57 @@ template <class T> __device__ inline T ityh_spin(T r, T s, double omega)
     T k = ad_sqrt((9.0 * PI / (2.0 * cx)) / F) * ad_pow(r, 1.0 / 3.0);
     T a = omega / (2.0 * k);
     return -cx * r43 * F * att_erf(a);
+}
+// ---- omega-B97 (Chai, Head-Gordon, JCP 128, 084106 (2008), Table I; libxc hyb_gga_xc_wb97), one template for both AD types.
+// B97 series  g(u) = sum_i c_i u^i,  u = gamma s^2 / (1 + gamma s^2)  with  s^2 = sigma / r^(8/3)  written as
+// gamma sigma / (r^(8/3) + gamma sigma)  so that a vanishing spin density cannot overflow.
+template <class T> __device__ inline T b97_series(const double *c, T u)
+{
+    return c[0] + u * (c[1] + u * (c[2] + u * (c[3] + u * c[4])));
+}
+// Perdew-Wang 1992 G function with the ORIGINAL published digits (B97-type functionals; PBE uses the "pw_mod" digits above)
+template <class T> __device__ inline T pw92_g_orig(T rs, double A, double a1, double b1, double b2, double b3, double b4)
+{
+    T srs = ad_sqrt(rs);
+    T q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
+    return -2.0 * A * (1.0 + a1 * rs) * ad_log(1.0 + 1.0 / q);
+}
+// e_xc per volume from the spin densities ra, rb and |grad ra|^2 = saa, |grad rb|^2 = sbb:
+//   exchange      sum_s  e_x^LSDA(r_s) att(omega / (2 k_F,s)) g_x(u_s),          gamma_x  = 0.004, k_F,s = (6 pi^2 r_s)^(1/3)
+//   correlation   sum_s  e_c^PW92(r_s, 0) g_ss(u_s)  +  [e_c^PW92(ra, rb) - same-spin parts] g_os(u_av)   (Stoll partition),
+//                 gamma_ss = 0.2, gamma_os = 0.006 on the mean of the two s^2
+// The long-range exchange is exact (alpha = 1, omega = 0.4): K_LR on the host side.
+template <class T> __device__ inline T wb97_xc(T ra, T rb, T saa, T sbb, double omega)
+{
+    const double cx[5] = {1.00000, 1.13116, -2.74915, 12.0900, -5.71642};
+    const double css[5] = {1.00000, -2.55352, 11.8926, -26.9452, 17.0927};
+    const double cos_[5] = {1.00000, 3.99051, -17.0066, 1.07292, 8.88211};
+    const double clda = 1.5 * 0.62035049089940001;
+    T ra83 = ad_pow(ra, 8.0 / 3.0), rb83 = ad_pow(rb, 8.0 / 3.0);
+    T ua = 0.004 * saa / (ra83 + 0.004 * saa + 1e-300), ub = 0.004 * sbb / (rb83 + 0.004 * sbb + 1e-300);
+    T kfa = ad_pow(6.0 * PI * PI * ra, 1.0 / 3.0), kfb = ad_pow(6.0 * PI * PI * rb, 1.0 / 3.0);
+    T ex = -clda * (ad_pow(ra, 4.0 / 3.0) * att_erf(omega / (2.0 * kfa)) * b97_series(cx, ua) +
+                    ad_pow(rb, 4.0 / 3.0) * att_erf(omega / (2.0 * kfb)) * b97_series(cx, ub));
+    // PW92 (original digits): paramagnetic, ferromagnetic, spin stiffness
+    T n = ra + rb;
+    T zeta = (ra - rb) / n;
+    T rs = ad_pow(3.0 / (4.0 * PI) / n, 1.0 / 3.0);
+    T e0 = pw92_g_orig(rs, 0.031091, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+    T e1 = pw92_g_orig(rs, 0.015545, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+    T mac = pw92_g_orig(rs, 0.016887, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);
+    T p = 1.0 + zeta, m = 1.0 - zeta;
+    floor_at(p.v, 1e-14);
+    floor_at(m.v, 1e-14);
+    T fz = (ad_pow(p, 4.0 / 3.0) + ad_pow(m, 4.0 / 3.0) - 2.0) / (2.5198420997897464 - 2.0);
+    T z4 = zeta * zeta * zeta * zeta;
+    T ec = n * (e0 - mac * fz / 1.709921 * (1.0 - z4) + (e1 - e0) * fz * z4);
+    T rsa = ad_pow(3.0 / (4.0 * PI) / ra, 1.0 / 3.0), rsb = ad_pow(3.0 / (4.0 * PI) / rb, 1.0 / 3.0);
+    T eaa = ra * pw92_g_orig(rsa, 0.015545, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+    T ebb = rb * pw92_g_orig(rsb, 0.015545, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+    T uss_a = 0.2 * saa / (ra83 + 0.2 * saa + 1e-300), uss_b = 0.2 * sbb / (rb83 + 0.2 * sbb + 1e-300);
+    T s_av = 0.5 * (saa * rb83 + sbb * ra83);
+    T uos = 0.006 * s_av / (ra83 * rb83 + 0.006 * s_av + 1e-300);
+    return ex + eaa * b97_series(css, uss_a) + ebb * b97_series(css, uss_b) + (ec - eaa - ebb) * b97_series(cos_, uos);
 }
 template <class S> __device__ inline D5T<S> lyp_pol(D5T<S> ra, D5T<S> rb, D5T<S> saa, D5T<S> sab, D5T<S> sbb)
 {
@@ -518,6 +574,7 @@ __global__ __launch_bounds__(256) void eval_xc_pol_kernel(XCSpec spec, int gga, 
             if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * (pbe_x_spin(Ra, Saa) + pbe_x_spin(Rb, Sbb));
             if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c_pol(rho, zeta, Saa + 2.0 * Sab + Sbb);
             if (spec.fac[F_ITYH] != 0) tot = tot + spec.fac[F_ITYH] * (ityh_spin(Ra, Saa, spec.omega) + ityh_spin(Rb, Sbb, spec.omega));
+            if (spec.fac[F_WB97] != 0) tot = tot + spec.fac[F_WB97] * wb97_xc(Ra, Rb, Saa, Sbb, spec.omega);
             exc = w * tot.v;
             for (int k = 0; k < 5; k++) dv[k] = tot.d[k];
         }
@@ -590,6 +647,7 @@ __global__ __launch_bounds__(256) void eval_fxc_pol_kernel(XCSpec spec, int gga,
         if (spec.fac[F_PBEX] != 0) tot = tot + spec.fac[F_PBEX] * (pbe_x_spin(X[0], X[2]) + pbe_x_spin(X[1], X[4]));
         if (spec.fac[F_PBEC] != 0) tot = tot + spec.fac[F_PBEC] * pbe_c_pol(rho, zeta, X[2] + 2.0 * X[3] + X[4]);
         if (spec.fac[F_ITYH] != 0) tot = tot + spec.fac[F_ITYH] * (ityh_spin(X[0], X[2], spec.omega) + ityh_spin(X[1], X[4], spec.omega));
+        if (spec.fac[F_WB97] != 0) tot = tot + spec.fac[F_WB97] * wb97_xc(X[0], X[1], X[2], X[4], spec.omega);
         for (int k = 0; k < 5; k++) { v[k] = tot.d[k].v; dv[k] = tot.d[k].e; }
     }
     wv_a[g] = 0.5 * w * dv[0];
@@ -858,7 +916,7 @@ __global__ void reduce_sym_kernel(const double *__restrict__ part, int nsplit, i
 
 extern "C" {
 
-// fac[9]: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C, ITYH (short-range B88)}, then omega of ITYH; gga = 1 if any GGA term.
+// fac[10]: weights of {Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C, ITYH (short-range B88), WB97 (whole xc)}, then omega of ITYH / WB97; gga = 1 if any GGA term.
 // d_acc[0] += sum w rho (nelec), d_acc[1] += sum w e_xc.  d_exc (nullable): e_xc per particle.
 int PAMD_eval_xc(const double *fac, int gga, const double *d_rho, const double *d_weights, long ng, long ldg,
                  double *d_wv, double *d_exc, double *d_acc, void *stream)

@@ -3,18 +3,18 @@
 
 A functional is reduced to the weights of the building blocks implemented by the device kernel
 ``PAMD_eval_xc`` (order: Slater, VWN5, VWN_RPA, B88, LYP, PBE_X, PBE_C, ITYH = short-range B88 of the
-Iikura-Tsuneda-Yanai-Hirao scheme, libxc gga_x_ityh; slot 8 of the array is its omega) plus the exact-exchange
-fractions.  Names follow PySCF: 'LDA' / 'SLATER' = Slater exchange, 'VWN' = 'VWN5' (libxc id 7),
+Iikura-Tsuneda-Yanai-Hirao scheme, libxc gga_x_ityh; WB97 = the whole omega-B97 exchange-correlation functional; the last
+slot of the array is the omega of the attenuated exchange) plus the exact-exchange fractions.  Names follow PySCF: 'LDA' / 'SLATER' = Slater exchange, 'VWN' = 'VWN5' (libxc id 7),
 'VWN_RPA' = 'VWNRPA' = 'VWN3' (id 8, libxc.py:168-169), 'B3LYP' = 'B3LYPG' = id 402 (VWN_RPA,
 libxc.py:175), 'B3LYP5' = VWN5 flavour (:177)."""
 import re
 
 import numpy as np
 
-F_SLATER, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC, F_ITYH = range(8)
-F_OMEGA = 8                  # fac[F_OMEGA]: range-separation parameter of the attenuated exchange (F_ITYH)
-NFAC = 9
-_GGA = {F_B88, F_LYP, F_PBEX, F_PBEC, F_ITYH}
+F_SLATER, F_VWN5, F_VWNRPA, F_B88, F_LYP, F_PBEX, F_PBEC, F_ITYH, F_WB97 = range(9)
+F_OMEGA = 9                  # fac[F_OMEGA]: range-separation parameter of the attenuated exchange (F_ITYH, F_WB97)
+NFAC = 10
+_GGA = {F_B88, F_LYP, F_PBEX, F_PBEC, F_ITYH, F_WB97}
 
 _X = {'LDA': {F_SLATER: 1.}, 'SLATER': {F_SLATER: 1.}, 'LDA_X': {F_SLATER: 1.}, 'S': {F_SLATER: 1.},
       'B88': {F_B88: 1.}, 'B': {F_B88: 1.}, 'PBE': {F_PBEX: 1.}, 'HF': {}, 'ITYH': {F_ITYH: 1.}}
@@ -34,17 +34,20 @@ _XC = {
     # hyb_gga_xc_cam_b3lyp (Yanai, Tew, Handy, CPL 393, 51): (1 - 0.65) B88 + 0.46 ITYH(0.33) + 0.19 VWN5 + 0.81 LYP,
     # exact exchange 0.19 short range / 0.65 long range.  4-tuples: (short-range HF, components, long-range HF, omega)
     'CAMB3LYP': (0.19, {F_B88: 0.35, F_ITYH: 0.46, F_VWN5: 0.19, F_LYP: 0.81}, 0.65, 0.33),
+    # hyb_gga_xc_wb97 (Chai, Head-Gordon, JCP 128, 084106): attenuated-LSDA B97 exchange + B97 correlation, no short-range and
+    # full long-range exact exchange at omega = 0.4
+    'WB97': (0.0, {F_WB97: 1.0}, 1.0, 0.4),
 }
 
 
 def parse_xc(description):
-    """-> (hyb, fac[9]); see parse_xc_rsh for the range-separated exact-exchange terms."""
+    """-> (hyb, fac[NFAC]); see parse_xc_rsh for the range-separated exact-exchange terms."""
     hyb, alpha, omega, fac = parse_xc_rsh(description)
     return hyb, fac
 
 
 def parse_xc_rsh(description):
-    """-> (hyb, alpha, omega, fac[9]).  'RSH(omega,alpha,beta)' (libxc.py:640-660) sets omega and adds alpha to the long-range and
+    """-> (hyb, alpha, omega, fac[NFAC]).  'RSH(omega,alpha,beta)' (libxc.py:640-660) sets omega and adds alpha to the long-range and
     alpha + beta to the short-range exact exchange.  Grammar subset of libxc.parse_xc (:496-720): 'X,C' with '+'-separated,
     optionally 'w*name'-weighted terms, or a single compound name; exact exchange as 'HF' (full range: counts for
     hyb and alpha), 'SR_HF(omega)' (hyb only) and 'LR_HF(omega)' (alpha only), so that
@@ -124,8 +127,8 @@ def parse_xc_rsh(description):
                 add(_X, t, True)
     if omega == 0.0:
         alpha = hyb                      # no range separation: one full-range coefficient
-    if fac[F_ITYH] != 0 and omega == 0.0:
-        raise ValueError('ITYH (attenuated B88) needs a range-separation parameter: RSH(omega,alpha,beta)')
+    if (fac[F_ITYH] != 0 or fac[F_WB97] != 0) and omega == 0.0:
+        raise ValueError('the attenuated exchange (ITYH, WB97) needs a range-separation parameter: RSH(omega,alpha,beta)')
     fac[F_OMEGA] = omega
     return hyb, alpha, omega, fac
 

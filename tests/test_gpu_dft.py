@@ -49,7 +49,7 @@ def test_eval_ao_vs_oracle(basis):
     assert np.abs(ao0 - want[0]).max() < 1e-12 * max(1, np.abs(want).max())
 
 
-@pytest.mark.parametrize('xc', ['lda,vwn', 'lda,vwn_rpa', 'b88,vwn', 'b88,lyp', 'b3lyp', 'pbe,pbe', 'camb3lyp'])
+@pytest.mark.parametrize('xc', ['lda,vwn', 'lda,vwn_rpa', 'b88,vwn', 'b88,lyp', 'b3lyp', 'pbe,pbe', 'camb3lyp', 'wb97'])
 def test_nr_rks_vs_oracle(xc):
     from pyscf_amd import gto, dft, lib
     from pyscf_amd.dft import libxc
@@ -116,7 +116,7 @@ def test_df_rks_b3lyp_vs_oracle():
     assert conv and abs(e - e0) < 1e-8, (e, e0)
 
 
-@pytest.mark.parametrize('xc', ['lda,vwn', 'lda,vwn_rpa', 'b88,lyp', 'b3lyp', 'pbe,pbe', 'pbe0', 'camb3lyp'])
+@pytest.mark.parametrize('xc', ['lda,vwn', 'lda,vwn_rpa', 'b88,lyp', 'b3lyp', 'pbe,pbe', 'pbe0', 'camb3lyp', 'wb97'])
 def test_nr_uks_vs_oracle(xc):
     """Spin-polarised nr_uks (both branches) vs the oracle whose functionals are pinned by the UKS goldens."""
     from pyscf_amd import gto, dft, lib
@@ -289,7 +289,7 @@ def test_partition_schemes_vs_oracle(scheme):
     assert abs((g.weights * np.exp(-1.3 * r2)).sum() * (1.3 / np.pi) ** 1.5 - 1) < 1e-5
 
 
-@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe', 'camb3lyp'])
+@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe', 'camb3lyp', 'wb97'])
 def test_nr_rks_fxc_vs_oracle_and_finite_differences(xc):
     """NumInt.nr_rks_fxc (numint.py:1418-1530): the XC kernel contracted with first-order density matrices, from
     PAMD_eval_fxc (forward-over-forward AD), against (i) the numpy restatement with sympy second derivatives and (ii)
@@ -331,7 +331,7 @@ def test_nr_rks_fxc_vs_oracle_and_finite_differences(xc):
     assert np.abs(ni.nr_fxc(mol, grids, 'HF', dm0, d_oo)).max() == 0
 
 
-@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe', 'camb3lyp'])
+@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe', 'camb3lyp', 'wb97'])
 def test_nr_uks_fxc_and_singlet_triplet(xc):
     """NumInt.nr_uks_fxc / nr_rks_fxc_st (numint.py:1532-1549,1690-1915) from PAMD_eval_fxc_pol (the spin-polarised
     functionals on nested dual numbers): (i) on a closed-shell reference the singlet kernel equals the closed-shell one,

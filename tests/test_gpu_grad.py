@@ -80,7 +80,7 @@ def test_eval_ao_deriv2_vs_oracle():
         assert np.abs(ao[comp] - hess[x, y]).max() < 2e-8 * scale, comp
 
 
-@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe', 'camb3lyp'])
+@pytest.mark.parametrize('xc', ['lda,vwn', 'b3lyp', 'pbe,pbe', 'camb3lyp', 'wb97'])
 def test_nr_rks_grad_vs_oracle(xc):
     """XC gradient contraction (PAMD_eval_ao deriv 1/2, PAMD_dgemm_nt, PAMD_eval_xc, PAMD_xc_grad) against the
     numpy restatement of pyscf/grad/rks.py:get_vxc on the same grid and density."""

@@ -115,6 +115,10 @@ def test_camb3lyp_goldens():
     he = gto.M(atom='He 0 0 0', basis='cc-pvdz')
     assert abs(dft.RKS(he, xc='camb3lyp').run(conv_tol=1e-11).e_tot - -2.89299475730048) < 1e-9
     assert abs(dft.UKS(he, xc='camb3lyp').run(conv_tol=1e-11).e_tot - -2.89299475730048) < 1e-9
+    # omega-B97 (attenuated-LSDA B97 exchange, B97 correlation on the original PW92, full long-range exact exchange at 0.4)
+    assert abs(dft.RKS(he, xc='wb97').run(conv_tol=1e-11).e_tot - -2.89430888240579) < 1e-9
+    assert abs(dft.UKS(he, xc='wb97').run(conv_tol=1e-11).e_tot - -2.89430888240579) < 1e-9
+    assert abs(dft.RKS(he, xc='wb97 + 1e-9*HF').run(conv_tol=1e-11).e_tot - -2.89430888240579) < 1e-8
     old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
     radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
     try:

@@ -41,8 +41,8 @@ def test_rks_energies_exact_jk(setup, xc, e_ref):
 
 
 def test_camb3lyp_exact_jk_goldens(setup):
-    """Pins the attenuated (ITYH) B88 exchange of the oracle: CAM-B3LYP with exact J, K and long-range K - He / cc-pVDZ
-    -2.89299475730048 (pyscf/dft/test/test_he.py:87-90) and H2O / 6-31g -76.35549300028714, omega = 0.15:
+    """Pins the attenuated (ITYH) B88 exchange and the omega-B97 functional of the oracle: CAM-B3LYP and wB97 with exact J, K and
+    long-range K - He / cc-pVDZ -2.89299475730048 and -2.89430888240579 (pyscf/dft/test/test_he.py:87-95) and H2O / 6-31g -76.35549300028714, omega = 0.15:
     -76.36649222362115 (pyscf/dft/test/test_h2o.py:564-577)."""
     from pyscf_amd import gto
     from pyscf_amd.dft import libxc
@@ -56,7 +56,8 @@ def test_camb3lyp_exact_jk_goldens(setup):
         c194, w194 = ref_dft.build_grids(mol, ATOM_GRID)                  # default (NWChem) pruning
     finally:
         radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
-    for m, c, w, xc, e_ref in ((he, hc, hw, 'camb3lyp', -2.89299475730048), (mol, c194, w194, 'camb3lyp', -76.35549300028714),
+    for m, c, w, xc, e_ref in ((he, hc, hw, 'camb3lyp', -2.89299475730048), (he, hc, hw, 'wb97', -2.89430888240579),
+                               (mol, c194, w194, 'camb3lyp', -76.35549300028714),
                                (mol, c194, w194, 'RSH(.15,0.65,-0.46) + 0.46*ITYH + .35*B88 + VWN5*0.19, LYP*0.81',
                                 -76.36649222362115)):
         hyb, alpha, omega, fac = libxc.parse_xc_rsh(xc)

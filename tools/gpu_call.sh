@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_int3c2e.py tests/test_gpu_scf.py -m gpu -q -x --durations=5 > gpurun_out/pytest_tm.log 2>&1
-tail -25 gpurun_out/pytest_tm.log
+timeout 1200 python -m pytest tests/test_gpu_dft.py tests/test_gpu_vhf.py tests/test_gpu_grad.py tests/test_gpu_response.py tests/test_gpu_xc_sparse.py -m gpu -q -x --durations=4 > gpurun_out/pytest_wb97.log 2>&1
+tail -30 gpurun_out/pytest_wb97.log
