@@ -1,5 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_dft.py tests/test_gpu_vhf.py tests/test_gpu_grad.py tests/test_gpu_response.py tests/test_gpu_xc_sparse.py -m gpu -q -x --durations=4 > gpurun_out/pytest_wb97.log 2>&1
-tail -30 gpurun_out/pytest_wb97.log
+rm -f gpurun_out/shard_h2o32.jsonl
+for w in 1 2 4 8; do
+timeout 300 python tools/shard_probe.py --nwater 32 --basis cc-pvtz --world $w --rank $((w/2)) --repeat 5 2>/dev/null | tail -1 >> gpurun_out/shard_h2o32.jsonl
+done
+cat gpurun_out/shard_h2o32.jsonl
