@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for t in "" "--j2-defer" "" "--j2-defer"; do
-timeout 300 python tools/kbench.py --steps 5 --tag "defer:$t" $t 2>/dev/null | tail -1 | cut -c1-330
-done
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_bench_launch.py -m gpu -q -x > gpurun_out/pytest_2rank.log 2>&1
+tail -6 gpurun_out/pytest_2rank.log
