@@ -89,6 +89,14 @@ def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_TH
     mt = np.zeros((naux, lda))
     mt[:, :nL] = M[l0:l1].T
     mt_dev = torch.from_numpy(mt).to(device)
+    if torch.device(device).type == 'cuda':
+        free = (torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+        need = nL * npair * 8 + min(slab_bytes, npair * naux * 8)
+        if need > free:
+            raise MemoryError('DF tensor shard of %d x %d doubles (%.1f GB + %.1f GB of slab workspace) does not fit the %.1f GB '
+                              'free on %s: shard the auxiliary index over more ranks (one process per GPU), the out-of-core '
+                              'contraction of pyscf/df/outcore.py is not restated'
+                              % (nL, npair, nL * npair * 8e-9, min(slab_bytes, npair * naux * 8) * 1e-9, free * 1e-9, device))
     cderi = torch.empty((nL, npair), dtype=torch.float64, device=device)
     # AO row-shell slabs bounded by slab_bytes of T = [rows][naux]
     nsh = eng.ao.n
