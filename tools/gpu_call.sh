@@ -1,5 +1,5 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_bench_launch.py -m gpu -q -x > gpurun_out/pytest_2rank.log 2>&1
-tail -6 gpurun_out/pytest_2rank.log
+# Scratch wrapper for one `gpurun` call (overwritten per experiment).  The canonical commands are:
+#   python -m pytest tests -m gpu -q          python bench.py          bash tools/profile_round.sh r02
+cd ${GRAFT_REPO_ROOT:-.}
+python -m pytest tests -m gpu -q -x
