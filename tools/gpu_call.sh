@@ -1,5 +1,5 @@
 #!/bin/bash
-# Scratch wrapper for one `gpurun` call (overwritten per experiment).  The canonical commands are:
-#   python -m pytest tests -m gpu -q          python bench.py          bash tools/profile_round.sh r02
 cd ${GRAFT_REPO_ROOT:-.}
-python -m pytest tests -m gpu -q -x
+for t in "gemmwide=1" "gemmwide=0"; do
+timeout 400 python tools/response_bench.py --skip-general --tune $t 2>/dev/null | tail -1 | cut -c1-420
+done

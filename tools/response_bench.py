@@ -15,7 +15,12 @@ ap.add_argument('--basis', default='cc-pvtz')
 ap.add_argument('--xc', default='b3lyp')
 ap.add_argument('--nvec', type=int, default=4)
 ap.add_argument('--skip-general', action='store_true')
+ap.add_argument('--tune', default='', help='comma list key=value for PAMD_set_tuning')
 a = ap.parse_args()
+from pyscf_amd import lib as _L
+for kv in filter(None, a.tune.split(',')):
+    k, v = kv.split('=')
+    _L.check(_L.load_library().PAMD_set_tuning(k.encode(), int(v)))
 mol = gto.M(atom=clusters.water_cluster(a.nwater), basis=a.basis)
 mf = (dft.RKS(mol, xc=a.xc) if a.xc else scf.RHF(mol)).density_fit()
 t0 = time.perf_counter()
