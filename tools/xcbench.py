@@ -18,7 +18,12 @@ ap.add_argument('--nsplit', type=int, default=0)
 ap.add_argument('--dense', action='store_true')
 ap.add_argument('--tile', type=int, default=0)
 ap.add_argument('--cutoff', type=float, default=0)
+ap.add_argument('--tune-xc', default='', help='comma list key=value for PAMD_set_tuning_xc')
 a = ap.parse_args()
+import ctypes
+for kv in filter(None, a.tune_xc.split(',')):
+    k, v = kv.split('=')
+    lib.check(lib.load_library().PAMD_set_tuning_xc(k.encode(), int(v)))
 dev = torch.device('cuda', 0)
 mol = gto.M(atom=clusters.water_cluster(a.nwater), basis=a.basis)
 nao, nocc = mol.nao, mol.nelectron // 2
