@@ -44,7 +44,7 @@ def main():
     ap.add_argument('--basis', default=None, help='default: cc-pvtz (water clusters), def2-tzvp (taxol)')
     ap.add_argument('--molecule', default='water', choices=['water', 'taxol'],
                     help="'water': (H2O)_nwater (configs 3 and 5); 'taxol': C47H51NO14 of config 4")
-    ap.add_argument('--cpu-sample-rows', type=int, default=1200)
+    ap.add_argument('--cpu-sample-rows', type=int, default=0, help='aux rows of the CPU baseline (0: all rows if host RAM allows, else half)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the CPU baseline (default: all host cores)')
     ap.add_argument('--xc', default='b3lyp', help="XC functional of the secondary nr_rks timing ('' to skip)")
@@ -80,8 +80,11 @@ def main():
     dev_index = local_rank % max(ndev, 1)       # (several ranks may share a device only in the gloo self-test)
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
+    backend = None
+    grouped = world > 1 or 'RANK' in os.environ           # under torch.distributed.run a group exists even for one rank
+    if grouped:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         backend = os.environ.get('PAMD_DIST_BACKEND', 'nccl')        # 'nccl' = RCCL on ROCm
         if backend == 'nccl':
             if ndev < world:
@@ -91,6 +94,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         world = dist.get_world_size()          # n_gpus below = the ranks the process group really has
+        # pre-flight: the first collective of the run is a 1-element all-reduce (RCCL communicator set-up happens here, with
+        # a readable error, not inside the first J/K build) and every rank reports its free HBM
+        one = torch.ones(1, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(one)
+        if int(one.item()) != world:
+            raise SystemExit('bench.py: pre-flight all-reduce returned %r, expected %d' % (one.item(), world))
 
     from pyscf_amd import gto, df, lib
     from pyscf_amd.data import clusters
@@ -103,6 +112,18 @@ def main():
     mol = gto.M(atom=clusters.taxol() if args.molecule == 'taxol' else clusters.water_cluster(args.nwater), basis=args.basis)
     nao, nocc = mol.nao, mol.nelectron // 2
     dfobj = df.DF(mol)                      # aux basis by the reference's rule (cc-pvtz -> cc-pvtz-jkfit)
+    # pre-flight, memory: this rank's packed shard must fit (the square image is optional: DF.k_square='auto' builds it only
+    # when HBM allows); refuse with a clear message instead of an out-of-memory error inside the build
+    from pyscf_amd.lib import comm
+    naux_all = df.make_auxmol(mol, dfobj.auxbasis).nao_nr()
+    l0_, l1_ = dfobj.shard_range(naux_all, rank, world)
+    shard_gb = 8e-9 * (l1_ - l0_) * (nao * (nao + 1) // 2)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    preflight = {'device_count': ndev, 'hbm_free_GB': round(free_b / 1e9, 1), 'hbm_total_GB': round(total_b / 1e9, 1),
+                 'shard_GB': round(float(shard_gb), 1), 'square_image_GB': round(2.0 * float(shard_gb), 1)}
+    if shard_gb * 1e9 * 1.15 + (8 << 30) > free_b:
+        raise SystemExit('bench.py: rank %d needs %.1f GB for its %d aux rows (+ work space) but only %.1f GB of HBM are free; '
+                         'use more ranks (--gpus N)' % (rank, shard_gb, l1_ - l0_, free_b / 1e9))
     t0 = time.perf_counter()
     dfobj.build()
     torch.cuda.synchronize()
@@ -125,7 +146,8 @@ def main():
     orb_list = [df_jk.pad_orbitals(orbo, dev)]
 
     def step():
-        return df_jk.get_jk_device(dfobj, dms_dev, orb_list, True, True)
+        # D was built as orbo orbo^T (as make_rdm1 does, pyscf/scf/hf.py:855-868): the first J pass is fused into the half transform
+        return df_jk.get_jk_device(dfobj, dms_dev, orb_list, True, True, dm_from_orbitals=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -136,11 +158,19 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    ctimer = comm.CommTimer()
+    comm.set_timer(ctimer)                # HIP events around every collective of the timed steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         vjtril, vk = step()
     fence()
     dt = time.perf_counter() - t0
+    comm.set_timer(None)
+    comm_ms, comm_bytes = ctimer.total_ms() if ctimer.records else (0.0, 0)
+    comm_info = {'backend': backend, 'collectives_per_step': len(ctimer.records) / max(args.steps, 1),
+                 'comm_ms_per_step': round(comm_ms / max(args.steps, 1), 4) if grouped else None,
+                 'bytes_per_step': int(comm_bytes / max(args.steps, 1)),
+                 'what': '[J~ || K] packed f64 all-reduce (2 nao_pair doubles per density), HIP events on the launch stream'}
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -192,14 +222,18 @@ def main():
         dm_tag = lib.tag_array(dm, mo_coeff=c, mo_occ=mo_occ)
         ni.nr_rks(mol, grids, args.xc, dm_tag)
         fence()
-        t0 = time.perf_counter()
-        nel, exc, _ = ni.nr_rks(mol, grids, args.xc, dm_tag)
-        fence()
-        xc_ms = (time.perf_counter() - t0) * 1e3
+        xc_times = []
+        for _ in range(max(5, min(args.steps, 10))):           # median of >= 5 calls (one shot is dominated by noise)
+            t0 = time.perf_counter()
+            nel, exc, _ = ni.nr_rks(mol, grids, args.xc, dm_tag)
+            fence()
+            xc_times.append((time.perf_counter() - t0) * 1e3)
+        xc_ms = float(np.median(xc_times))
         ni.kernel_timer = df_jk.KernelTimer()
         ni.nr_rks(mol, grids, args.xc, dm_tag)
         xs = ni.kernel_timer.summary()
-        xc_info = {'xc': args.xc, 'nr_rks_ms_per_call': round(xc_ms, 1), 'ngrids': int(grids.size),
+        xc_info = {'xc': args.xc, 'nr_rks_ms_per_call': round(xc_ms, 1), 'nr_rks_ms_calls': [round(t, 1) for t in xc_times],
+                   'nr_rks_kernels_ms_sum': round(sum(t for t, n_ in xs.values()), 2), 'ngrids': int(grids.size),
                    'grid_build_s': round(grid_s, 2), 'nelec': float(nel),
                    'kernels_ms': {k: round(t, 2) for k, (t, n_) in xs.items()}}
         if ni.sparse:
@@ -211,7 +245,7 @@ def main():
                                        'ao_cached_in_hbm': plan.ao_c is not None}
 
     if rank != 0:
-        if world > 1:
+        if grouped:
             dist.destroy_process_group()
         return
 
@@ -277,33 +311,69 @@ def main():
     if 'e2_symm' in ksum:
         k_tflops['e2_symm'] = round(flops_e2 / (ksum['e2_symm'][0] * 1e-3) / 1e12, 2)
     if 'dgemm_tn' in ksum:
-        k_tflops['dgemm_tn'] = round(flops_syrk / (ksum['dgemm_tn'][0] * 1e-3) / 1e12, 2)
+        # the SYRK computes only the lower-triangular 128 x 128 tiles of K = X^T X: 'charged' is the SURVEY 8(d) full-square
+        # figure 2 naux nao^2 nocc over its time (may exceed the 78.6 TF/s peak: symmetry, not speed); 'executed' counts the
+        # tiles it really multiplies
+        nt = -(-nao // 128)
+        syrk_exec = flops_syrk * (nt * (nt + 1) / 2) * 128.0 * 128.0 / (float(nao) * nao)
+        k_tflops['dgemm_tn_charged'] = round(flops_syrk / (ksum['dgemm_tn'][0] * 1e-3) / 1e12, 2)
+        k_tflops['dgemm_tn_executed'] = round(syrk_exec / (ksum['dgemm_tn'][0] * 1e-3) / 1e12, 2)
+    else:
+        syrk_exec = 0.0
+    # whole-step roofline: the flops the step really executes (half transform + lower-triangular SYRK tiles) over ms_per_step
+    step_exec = flops_e2 + syrk_exec
+    step_roof = {'executed_TFLOP': round(step_exec / 1e12, 3), 'charged_TFLOP': round((flops_e2 + flops_syrk) / 1e12, 3),
+                 'achieved_TFLOPs': round(step_exec / (ms_per_step * 1e-3) / 1e12, 2), 'peak_TFLOPs': FP64_MFMA_PEAK_TFLOPS,
+                 'frac': round(step_exec / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                 'ideal_ms_at_peak': round(step_exec / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 2)}
 
     cpu = None
     parity = None
     if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
-        from oracle import ref
-        nrow = min(args.cpu_sample_rows, naux_local)
-        sample = dfobj._cderi_dev[:nrow].cpu().numpy()
+        from oracle import ref, ref_c
         ncore = args.cpu_threads or os.cpu_count()
-        ref.get_jk_rows_parallel(sample[:min(nrow, 64)], dm, c, mo_occ, nthreads=ncore)      # warm the BLAS threads
-        t0 = time.perf_counter()
-        vj0, vk0, cpu_flops = ref.get_jk_rows_parallel(sample, dm, c, mo_occ, nthreads=ncore)
-        cpu_s = time.perf_counter() - t0
-        cpu = {'value': round(cpu_s / nrow * naux * 1e3, 1), 'unit': 'ms/iter (extrapolated to all %d aux rows)' % naux,
-               'cores': ncore, 'kind': 'port', 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1),
-               'phases_s': getattr(ref.get_jk_rows_parallel, 'last_phases', None),
-               'sample': 'oracle/ref.get_jk_rows_parallel (restatement of df_jk.py:329-381 parallelised like '
-                         'AO2MOnr_e2_drv, nr_ao2mo.c:1253-1265: aux rows across %d threads, one single-threaded dsymm per '
-                         'row, threaded dgemm for buf1^T buf1) on %d of %d aux rows of the GPU-built tensor: %.2f s'
-                         % (ncore, nrow, naux, cpu_s)}
+        use_ref = ref_c.available()
+        nrow = args.cpu_sample_rows
+        if nrow <= 0:
+            # all aux rows when the host has room for the tensor (+ the reference's 240-row work buffers), else half of them
+            import psutil
+            avail = psutil.virtual_memory().available
+            nrow = naux_local if avail > 1.5 * 8.0 * naux_local * npair + (32 << 30) else -(-naux_local // 2)
+        nrow = min(nrow, naux_local)
+        sample = np.empty((nrow, npair))
+        for r0 in range(0, nrow, 240):                   # download in the reference's block size (no 2x staging copy)
+            sample[r0:r0 + 240] = dfobj._cderi_dev[r0:min(r0 + 240, nrow)].cpu().numpy()
+        if use_ref:
+            # oracle/_ref/libref_dfjk.so = pyscf/lib/ao2mo/nr_ao2mo.c + pyscf/lib/np_helper/*.c compiled as they are, driven
+            # call for call like pyscf/df/df_jk.py:329-381 (oracle/ref_c.get_jk): the reference's CPU path minus libcint
+            ref_c.get_jk(sample[:min(nrow, 240)], dm, c, mo_occ, nthreads=ncore)      # warm the thread pools
+            t0 = time.perf_counter()
+            vj0, vk0, cpu_flops = ref_c.get_jk(sample, dm, c, mo_occ, blockdim=240, nthreads=ncore)
+            cpu_s = time.perf_counter() - t0
+            phases, kind = ref_c.get_jk.last_phases, 'reference'
+            what = ("the reference's own C (AO2MOnr_e2_drv / AO2MOtranse2_nr_s2 / AO2MOmmm_bra_nr_s2 of lib/ao2mo/nr_ao2mo.c, NPdgemm / "
+                    "NPdunpack_tril of lib/np_helper) compiled into oracle/_ref and called as pyscf/df/df_jk.py:329-381 does, blocks "
+                    "of 240 aux rows; %d OpenMP threads, BLAS serial inside the parallel regions (scipy's OpenBLAS is capped at 64 "
+                    "threads, so it runs 1 thread per call and the reference's own omp loops use every core); the J line is "
+                    "numpy.matmul as in the reference" % ref_c.get_jk.last_threads)
+        else:
+            ref.get_jk_rows_parallel(sample[:min(nrow, 64)], dm, c, mo_occ, nthreads=ncore)      # warm the BLAS threads
+            t0 = time.perf_counter()
+            vj0, vk0, cpu_flops = ref.get_jk_rows_parallel(sample, dm, c, mo_occ, nthreads=ncore)
+            cpu_s = time.perf_counter() - t0
+            phases, kind = getattr(ref.get_jk_rows_parallel, 'last_phases', None), 'port'
+            what = ('oracle/ref.get_jk_rows_parallel (numpy restatement of df_jk.py:329-381; oracle/_ref was not built)')
+        cpu = {'value': round(cpu_s / nrow * naux * 1e3, 1),
+               'unit': 'ms/iter' + ('' if nrow == naux else ' (extrapolated from %d to all %d aux rows)' % (nrow, naux)),
+               'cores': ncore, 'kind': kind, 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1), 'phases_s': phases,
+               'sample': '%s; %d of %d aux rows of the GPU-built tensor: %.2f s' % (what, nrow, naux, cpu_s)}
         # parity at full size: the same rows through the HIP path
         sub = df.DF(mol)
         sub._cderi_dev = dfobj._cderi_dev[:nrow]
         vjt, vkd = df_jk.get_jk_device(_Single(sub), dms_dev, orb_list, True, True)
         vj1 = lib.unpack_tril(vjt.cpu().numpy(), 1)[0]
         vk1 = vkd.cpu().numpy()[0]
-        parity = {'rows': nrow, 'max_abs_err_vj': float(np.abs(vj1 - vj0).max()),
+        parity = {'rows': nrow, 'checker': kind, 'max_abs_err_vj': float(np.abs(vj1 - vj0).max()),
                   'max_abs_err_vk': float(np.abs(vk1 - vk0).max())}
 
     out = {
@@ -317,13 +387,13 @@ def main():
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
                    'naux_local': naux_local, 'naux_per_rank': naux_per_rank},
         'value_host_api_ms': round(host_api_ms, 3),
-        'roofline': roofline,
-        'cpu_baseline': cpu,
+        'roofline': roofline, 'roofline_step': step_roof,
+        'cpu_baseline': cpu, 'comm': comm_info, 'preflight': preflight,
         'kernels': kern, 'j_hbm_GBs': j_gbs, 'k_mfma_TFLOPs': k_tflops,
         'build_s': round(build_s, 2), 'parity_sample': parity, 'xc_path': xc_info,
     }
     print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -212,14 +212,24 @@ class DF:
                 # the reference's own format: dataset 'j3c' (naux, nao_pair) (pyscf/df/df.py:97-99, outcore.py:217-221);
                 # every rank reads exactly its aux rows
                 with hdf5.File(self._cderi) as f:
-                    d = f['j3c']
-                    naux = d.shape[0]
+                    # one dataset 'j3c' (naux, nao_pair), or the group 'j3c/0..N' of column blocks that stock PySCF's
+                    # outcore.cholesky_eri_b writes by default (_compatible_format = False; df.py:227-241)
+                    blocks = f.column_blocks('j3c') or [f['j3c']]
+                    naux = blocks[0].shape[0]
+                    ncol = sum(b.shape[1] for b in blocks)
+                    nao = self.mol.nao_nr() if hasattr(self.mol, 'nao_nr') else self.mol.nao
+                    if any(len(b.shape) != 2 or b.shape[0] != naux for b in blocks) or ncol != nao * (nao + 1) // 2:
+                        raise RuntimeError("%s: 'j3c' holds %d columns, expected nao_pair = %d for nao = %d (s2-packed (naux, "
+                                           "nao_pair) tensor, pyscf/df/df.py:59-72)" % (self._cderi, ncol, nao * (nao + 1) // 2, nao))
                     l0, l1 = self.shard_range(naux, self.rank, self.world_size)
-                    self._cderi_dev = torch.empty((l1 - l0, d.shape[1]), dtype=torch.float64, device=dev)
-                    step = max(1, (1 << 30) // (d.shape[1] * 8))
-                    for r0 in range(l0, l1, step):
-                        r1 = min(r0 + step, l1)
-                        self._cderi_dev[r0 - l0:r1 - l0] = torch.from_numpy(d.read_rows(r0, r1)).to(dev)
+                    self._cderi_dev = torch.empty((l1 - l0, ncol), dtype=torch.float64, device=dev)
+                    c0 = 0
+                    for d in blocks:
+                        step = max(1, (1 << 30) // (d.shape[1] * 8))
+                        for r0 in range(l0, l1, step):
+                            r1 = min(r0 + step, l1)
+                            self._cderi_dev[r0 - l0:r1 - l0, c0:c0 + d.shape[1]] = torch.from_numpy(d.read_rows(r0, r1)).to(dev)
+                        c0 += d.shape[1]
                 self._naux = naux
                 return self
             shard = self._shard_path(self._cderi)
@@ -260,15 +270,39 @@ class DF:
             self.build()
         return self._naux
 
-    def loop(self, blksize=None):
-        """Yield host row blocks of the rank-local shard (pyscf/df/df.py:214-242)."""
+    def loop(self, blksize=None, local=False):
+        """Yield host row blocks of the FULL tensor, rows 0..naux in order (pyscf/df/df.py:214-242) - what a stock consumer
+        (DF-MP2, DF-CCSD, `ao2mo`) expects.  With the aux index sharded over several ranks every rank takes part in the
+        iteration (it is a collective: each block is assembled from its owners' rows by an all-reduce of a zero-padded
+        buffer) and every rank receives every block.  `local=True`: only this rank's rows [l0, l1), no communication."""
+        import torch
         if self._cderi_dev is None:
             self.build()
         if blksize is None:
             blksize = self.blockdim
         n = self._cderi_dev.shape[0]
-        for b0 in range(0, n, blksize):
-            yield self._cderi_dev[b0:b0 + blksize].cpu().numpy()
+        from ..lib import comm as _comm
+        sharded = _comm.active(self.world_size) and getattr(self, '_shard_override', None) is None
+        if getattr(self, '_shard_override', None) is not None and self._shard_override[1] > 1 and not local:
+            raise RuntimeError('DF.loop(): this object holds one emulated shard (rank %d of %d) of the tensor, not all aux '
+                               'rows; pass local=True for the rows of the shard' % tuple(self._shard_override))
+        if local or not sharded:
+            for b0 in range(0, n, blksize):
+                yield self._cderi_dev[b0:b0 + blksize].cpu().numpy()
+            return
+        naux = self.get_naoaux()
+        l0, l1 = self.shard_range(naux, self.rank, self.world_size)
+        npair = self._cderi_dev.shape[1]
+        buf = torch.empty((min(blksize, naux), npair), dtype=torch.float64, device=self._cderi_dev.device)
+        for b0 in range(0, naux, blksize):
+            b1 = min(b0 + blksize, naux)
+            blk = buf[:b1 - b0]
+            blk.zero_()
+            a0, a1 = max(b0, l0), min(b1, l1)
+            if a1 > a0:
+                blk[a0 - b0:a1 - b0] = self._cderi_dev[a0 - l0:a1 - l0]
+            _comm.all_reduce([blk], self.group, self.world_size)
+            yield blk.cpu().numpy()
 
     # -- downstream consumers of the tensor (SURVEY.md 8f rank 2) ----------------------------------
     def _pair_gram(self, a, b):

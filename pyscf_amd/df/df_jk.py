@@ -16,6 +16,7 @@ import ctypes
 import numpy as np
 
 from .. import lib as _lib_mod
+from ..lib import comm as _comm
 
 _c = ctypes
 
@@ -75,17 +76,14 @@ def _call(dfobj, name, fn, *args):
 
 def _allreduce(dfobj, tensors):
     """Sum the rank-partial results over the aux-index shards (RCCL over xGMI)."""
-    if dfobj.world_size > 1 and getattr(dfobj, '_shard_override', None) is None:
-        import torch.distributed as dist
-        for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=dfobj.group)
+    if getattr(dfobj, '_shard_override', None) is None:
+        _comm.all_reduce(tensors, dfobj.group, dfobj.world_size)
 
 
 def _allreduce_jk_packed(dfobj, lib, vjtril, vk):
     """One collective for [J~ (packed) || K (packed)] when K is symmetric (MO branch): 2 nao_pair doubles per density instead
     of nao_pair + nao^2 (27.6 MB instead of 41.3 MB at config 3).  K is packed as (K + K^T)(1 - delta_pq / 2) by the kernel
     that packs density matrices, summed over the ranks, unpacked by PAMD_unpack_tril and halved off the diagonal."""
-    import torch.distributed as dist
     torch = _torch()
     st = _stream()
     nset, nao = vk.shape[0], vk.shape[-1]
@@ -94,7 +92,7 @@ def _allreduce_jk_packed(dfobj, lib, vjtril, vk):
     buf = torch.empty((nj + nset, npair), dtype=torch.float64, device=vk.device)
     buf[:nj].copy_(vjtril)
     _call(dfobj, 'pack_dm_tril', lib.PAMD_pack_dm_tril, _ptr(vk), _c.c_int(nset), _c.c_int(nao), _ptr(buf[nj:]), st)
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=dfobj.group)
+    _comm.all_reduce([buf], dfobj.group, dfobj.world_size)
     vjtril.copy_(buf[:nj])
     _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(buf[nj:]), _c.c_long(npair), _c.c_int(nset), _c.c_int(nao), _ptr(vk),
           _c.c_int(nao), _c.c_int(nao), st)
@@ -393,10 +391,31 @@ def get_j(dfobj, dm, hermi=0, direct_scf_tol=1e-13):
     return _lib_mod.unpack_tril(vjtril.cpu().numpy(), 1).reshape(shape)
 
 
-def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
+def _dm_matches_orbitals(dms_dev, orb_list, nao):
+    """True when every D_s equals orb_s orb_s^T (to 1e-10 relative): probe with one fixed pseudo-random vector."""
+    import os
+    torch = _torch()
+    full = os.environ.get('PAMD_DEBUG_CHECK_DM', '0') not in ('', '0')
+    gen = torch.Generator(device='cpu').manual_seed(20240601)
+    v = torch.rand(nao, dtype=torch.float64, generator=gen).to(dms_dev.device) - 0.5
+    worst = torch.zeros((), dtype=torch.float64, device=dms_dev.device)
+    for s_, (orb_s, _np, _ld) in enumerate(orb_list):
+        c_s = orb_s[:nao]
+        if full:
+            err = (dms_dev[s_] - c_s @ c_s.T).abs().max() / dms_dev[s_].abs().max().clamp_min(1.0)
+        else:
+            dv = dms_dev[s_] @ v
+            err = (dv - c_s @ (c_s.T @ v)).abs().max() / dv.abs().max().clamp_min(1.0)
+        worst = torch.maximum(worst, err)
+    return float(worst) <= 1e-10
+
+
+def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_from_orbitals=None):
     """Device-resident J/K build: inputs and outputs stay in HBM.
       dms_dev   (nset, nao, nao) f64 CUDA tensor
       orb_list  None (general-DM branch) or [(orb_dev, nocc_pad, ldo)] from `pad_orbitals`
+      dm_from_orbitals  True: the caller built dms_dev[s] = orb_s orb_s^T (SCF densities from make_rdm1) - the first J pass may
+                come out of the half transform's epilogue unchecked; False: never; None: decide by a cheap probe
     Returns (vjtril_dev (nset, nao_pair) | None, vk_dev (nset, nao, nao) | None), already summed
     over the aux-index shards of all ranks."""
     lib = _lib_mod.load_library()
@@ -420,12 +439,13 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
                 sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
                 fused = (len(orb_list) == nset and all(o[1] > 0 for o in orb_list) and
                          getattr(dfobj, 'fuse_j_pass1', True))
-                if fused:
-                    # the epilogue sum is the first J pass only for D_s = orb_s orb_s^T (what make_rdm1 tags): verify
-                    for s_, (orb_s, _np, _ld) in enumerate(orb_list):
-                        c_s = orb_s[:nao]
-                        if float((dms_dev[s_] - c_s @ c_s.T).abs().max()) > 1e-10 * max(1.0, float(dms_dev[s_].abs().max())):
-                            fused = False
+                if fused and dm_from_orbitals is not True:
+                    # the epilogue sum is the first J pass only for D_s = orb_s orb_s^T (what make_rdm1 tags; the reference
+                    # itself trusts the tag for K, "#TODO: test whether dm.mo_coeff matching dm", df_jk.py:340).  Callers
+                    # that built D from these orbitals say so (dm_from_orbitals=True: no check, no host sync, no library
+                    # GEMM in the hot loop); otherwise a random-vector probe D v = C (C^T v) decides - two GEMVs and one
+                    # scalar read-back instead of the nao^2 nocc product; PAMD_DEBUG_CHECK_DM=1 restores the full comparison.
+                    fused = dm_from_orbitals is None and _dm_matches_orbitals(dms_dev, orb_list, nao)
                 if fused:
                     # pass 1 comes out of the half transform (PAMD_nr_e2_square); pass 2 of each K block follows on
                     # the side stream behind that block's SYRK
@@ -469,7 +489,7 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True):
         else:
             vk_dev = _vk_general(dfobj, lib, dms_dev, nset, nao)
         outs.append(vk_dev)
-    if (dfobj.world_size > 1 and getattr(dfobj, '_shard_override', None) is None and orb_list is not None and
+    if (_comm.active(dfobj.world_size) and getattr(dfobj, '_shard_override', None) is None and orb_list is not None and
             vjtril is not None and vk_dev is not None and getattr(dfobj, 'packed_allreduce', True)):
         _allreduce_jk_packed(dfobj, lib, vjtril, vk_dev)               # MO branch: K is symmetric
     else:
@@ -542,7 +562,22 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         orb_list = pos
         if any(n is not None for n in neg):
             neg_sets = neg
-    vjtril, vk_dev = get_jk_device(dfobj, dms_dev, orb_list, with_j, with_k)
+    promise = None
+    if orb_list is not None and mo_coeff is not None and with_j and with_k:
+        # is D_s = orb_s orb_s^T?  make_rdm1 of this package says so in the tag; for a foreign tag (stock PySCF's
+        # lib.tag_array(dm, mo_coeff=, mo_occ=)) two host matrix-vector products decide - nothing on the device waits
+        promise = getattr(dm, 'dm_from_orbitals', None)
+        if promise is None:
+            v = np.random.RandomState(20240601).random_sample(nao) - 0.5
+            promise = True
+            for k in range(nset):
+                ck = mo_coeff[k][:, mo_occ[k] > 0]
+                dv = dms[k].dot(v)
+                if np.abs(dv - (ck * mo_occ[k][mo_occ[k] > 0]).dot(ck.T.dot(v))).max() > 1e-10 * max(1.0, np.abs(dv).max()):
+                    promise = False
+    elif neg_sets is not None or orb_list is not None:
+        promise = False if neg_sets is not None else None
+    vjtril, vk_dev = get_jk_device(dfobj, dms_dev, orb_list, with_j, with_k, dm_from_orbitals=promise)
     if neg_sets is not None:
         lib = _lib_mod.load_library()
         idx = [k for k in range(nset) if neg_sets[k] is not None]

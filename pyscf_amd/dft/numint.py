@@ -21,6 +21,7 @@ import os
 import numpy as np
 
 from .. import lib as _lib_mod
+from ..lib import comm as _comm
 from . import libxc as _xc
 
 _c = ctypes
@@ -133,6 +134,11 @@ class NumInt:
         except ImportError:
             pass
         return 0, 1
+
+    def _allreduce(self, tensors, world):
+        """Sum the ranks' partial grid sums (vmat, nelec, exc, gradient parts): RCCL all-reduce over the grid-tile shards."""
+        if getattr(self, '_world_override', None) is None:
+            _comm.all_reduce(tensors, self.group, world)
 
     def _shell_tables(self, mol, dev):
         from ..gto.moleintor import mol_fingerprint
@@ -349,10 +355,7 @@ class NumInt:
             self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(M[s]), _c.c_int(1), _c.c_int(nao), _c.c_int(nao),
                        _ptr(v[s]), st)
         rank, world = self._world()
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(v, group=self.group)
-            dist.all_reduce(acc, group=self.group)
+        self._allreduce([v, acc], world)
         return acc.cpu().numpy(), v.cpu().numpy()
 
     def _first_order_terms(self, dms2, lowrank, nao, dev):
@@ -471,9 +474,7 @@ class NumInt:
                 self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(M[s, i]), _c.c_int(1), _c.c_int(nao), _c.c_int(nao),
                            _ptr(v[s, i]), st)
         rank, world = self._world()
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(v, group=self.group)
+        self._allreduce([v], world)
         return v.cpu().numpy()
 
     # -- the hot entry point ----------------------------------------------------------------------
@@ -588,10 +589,7 @@ class NumInt:
             v = torch.empty((nao, nao), dtype=f64, device=dev)
             self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(part), _c.c_int(nsplit_max), _c.c_int(nao), _c.c_int(nao),
                        _ptr(v), st)
-            if world > 1:
-                import torch.distributed as dist
-                dist.all_reduce(v, group=self.group)
-                dist.all_reduce(acc, group=self.group)
+            self._allreduce([v, acc], world)
             a = acc.cpu().numpy()
             nelec[iset], excsum[iset] = a[0], a[1]
             vmat[iset] = v.cpu().numpy()
@@ -687,9 +685,7 @@ class NumInt:
         for i in range(nset):
             self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(parts[i]), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
                        _ptr(v), st)
-            if world > 1:
-                import torch.distributed as dist
-                dist.all_reduce(v, group=self.group)
+            self._allreduce([v], world)
             vmat[i] = v.cpu().numpy()
         return vmat.reshape(shape)
 
@@ -786,9 +782,7 @@ class NumInt:
                 for i in range(nset):
                     self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(parts[s, i]), _c.c_int(nsplit), _c.c_int(nao),
                                _c.c_int(nao), _ptr(v), st)
-                    if world > 1:
-                        import torch.distributed as dist
-                        dist.all_reduce(v, group=self.group)
+                    self._allreduce([v], world)
                     vmat[s, i] = v.cpu().numpy()
         return vmat[:, 0] if single else vmat
 
@@ -874,9 +868,7 @@ class NumInt:
             if resp:
                 resp['evol'][:ng] = resp['exc'][:ng] * rho[0, :ng]             # per particle -> per volume
                 self._response_block(resp, coords_dev, weights_dev, g0, ng, [(ao, c, wv)], gga, ldao, blk, nao, st)
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(out, group=self.group)
+        self._allreduce([out], world)
         s = out.cpu().numpy()
         aoslices = mol.aoslice_by_atom()
         de = np.zeros((natm, 3))
@@ -930,9 +922,7 @@ class NumInt:
 
     def _response_finish(self, resp, world):
         tot = resp['de_w'] + 2 * resp['de_move']
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(tot, group=self.group)
+        self._allreduce([tot], world)
         return tot.cpu().numpy()
 
     def nr_uks_grad(self, mol, grids, xc_code, dms, grid_response=False):
@@ -995,9 +985,7 @@ class NumInt:
             if resp:
                 self._response_block(resp, coords_dev, weights_dev, g0, ng, [(ao, c[0], wv[0]), (ao, c[1], wv[1])], gga,
                                      ldao, blk, nao, st)
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(out, group=self.group)
+        self._allreduce([out], world)
         sv = out.cpu().numpy()
         aoslices = mol.aoslice_by_atom()
         de = np.zeros((natm, 3))
@@ -1119,9 +1107,6 @@ class NumInt:
         for s in range(2):
             self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(part[s]), _c.c_int(nsplit_max), _c.c_int(nao),
                        _c.c_int(nao), _ptr(v[s]), st)
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(v, group=self.group)
-            dist.all_reduce(acc, group=self.group)
+        self._allreduce([v, acc], world)
         a = acc.cpu().numpy()
         return a[:2].copy(), float(a[2]), v.cpu().numpy()

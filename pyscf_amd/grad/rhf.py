@@ -277,6 +277,12 @@ class Gradients:
     (pyscf/grad/rhf.py:291-458, pyscf/df/grad/rhf.py:262-320)."""
 
     def __init__(self, mf):
+        if getattr(mf, 'only_dfj', False):
+            # density_fit(only_dfj=True): the SCF energy holds the EXACT in-core K; the reference then differentiates a DF J
+            # plus an exact K (pyscf/df/grad/rhf.py:73-83).  The exact-K gradient is not built here, and differentiating a
+            # DF-K energy instead would silently not be the derivative of the converged energy.
+            raise NotImplementedError('nuclear gradients with density_fit(only_dfj=True) need the exact-exchange gradient '
+                                      '(pyscf/df/grad/rhf.py:73-83), which is not implemented; use density_fit() with a fitted K')
         self.base = mf
         self.mol = mf.mol
         self.auxbasis_response = True

@@ -2,8 +2,9 @@
 
 Just enough for the one on-disk object of the DF path: the dataset ``'j3c'`` of shape (naux, nao_pair), float64, that
 ``pyscf.df.DF`` keeps in its ``_cderi`` file (pyscf/df/df.py:97-99,185-199; written by pyscf/df/outcore.py:217-221 and
-read back row block by row block in ``DF.loop``, df.py:214-242).  Files written here open in h5py / stock PySCF
-(``DF._cderi = 'file.h5'``) and vice versa.
+read back row block by row block in ``DF.loop``, df.py:214-242).  Files written here (one 2-d dataset 'j3c') open in h5py /
+stock PySCF (``DF._cderi = 'file.h5'``); in the other direction both layouts stock PySCF writes are read: the single
+dataset (``_compatible_format = True``) and the group ``'j3c/0..N'`` of column blocks (the default of outcore.cholesky_eri_b).
 """
 import ctypes
 import ctypes.util
@@ -130,6 +131,25 @@ class File:
         d = Dataset(lib, ds)
         self._open.append(d)
         return d
+
+    def exists(self, name):
+        """True when the link `name` (every component of it) exists in the file."""
+        parts, cur = name.strip('/').split('/'), ''
+        for comp in parts:
+            cur = comp if not cur else cur + '/' + comp
+            if self._lib.H5Lexists(_hid(self._id), cur.encode(), _hid(0)) <= 0:
+                return False
+        return True
+
+    def column_blocks(self, name):
+        """The datasets 'name/0', 'name/1', ... of a group of column blocks - the layout stock PySCF's
+        outcore.cholesky_eri_b writes when DF._compatible_format is False (pyscf/df/outcore.py:215-221, df.py:227-241) -
+        or [] when `name` is a plain dataset."""
+        out, i = [], 0
+        while self.exists('%s/%d' % (name, i)):
+            out.append(self['%s/%d' % (name, i)])
+            i += 1
+        return out
 
     def __getitem__(self, name):
         d = Dataset(self._lib, _chk(self._lib.H5Dopen2(_hid(self._id), name.encode(), _hid(0)), 'H5Dopen2 ' + name))

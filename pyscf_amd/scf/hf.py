@@ -325,7 +325,7 @@ class SCF:
         if mo_occ is None: mo_occ = self.mo_occ
         mocc = mo_coeff[:, mo_occ > 0]
         dm = (mocc * mo_occ[mo_occ > 0]).dot(mocc.conj().T)
-        return tag_array(dm, mo_coeff=mo_coeff, mo_occ=mo_occ)
+        return tag_array(dm, mo_coeff=mo_coeff, mo_occ=mo_occ, dm_from_orbitals=True)      # D = (C sqrt(occ))(C sqrt(occ))^T by construction
 
     def get_fock(self, h1e, s1e, vhf, dm, cycle=-1, diis=None, fock_last=None):
         """hf.py:1098-1146: damping before DIIS starts, DIIS from diis_start_cycle, level shift of the virtual space."""

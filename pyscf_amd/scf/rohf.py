@@ -87,6 +87,10 @@ class ROHF(hf.SCF):
             dm = np.array((dm * .5, dm * .5))
         focka, fockb = h1e + vhf[0], h1e + vhf[1]
         f = get_roothaan_fock((focka, fockb), dm, s1e)
+        if abs(getattr(self, 'damp', 0)) > 1e-4 or abs(getattr(self, 'level_shift', 0)) > 1e-4:
+            # pyscf/scf/rohf.py get_fock damps and level-shifts the Roothaan Fock matrix; not restated here - refuse rather
+            # than run silently unshifted iterations
+            raise NotImplementedError('ROHF: damp / level_shift are not implemented (set them to 0)')
         if cycle < 0 or diis is None:
             return f
         if cycle >= self.diis_start_cycle:

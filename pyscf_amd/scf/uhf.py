@@ -46,7 +46,7 @@ class UHF(hf.SCF):
         for s in range(2):
             c = mo_coeff[s][:, mo_occ[s] > 0]
             dms.append((c * mo_occ[s][mo_occ[s] > 0]).dot(c.conj().T))
-        return tag_array(np.array(dms), mo_coeff=mo_coeff, mo_occ=mo_occ)
+        return tag_array(np.array(dms), mo_coeff=mo_coeff, mo_occ=mo_occ, dm_from_orbitals=True)
 
     def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
         if dm is None: dm = self.make_rdm1()

@@ -37,6 +37,11 @@ def main():
     vj0, vk0 = ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
     vj, vk = obj.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=occ), hermi=1)       # MO branch, all-reduced over the shards
     assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9
+    # DF.loop() on a sharded tensor is a collective that hands EVERY rank the FULL tensor (what a stock DF-MP2 / ao2mo consumer
+    # iterates over, pyscf/df/df.py:214-242); loop(local=True) gives the rank's rows only
+    got = np.vstack(list(obj.loop(37)))
+    assert got.shape == cderi.shape and np.abs(got - cderi).max() < 1e-9
+    assert np.vstack(list(obj.loop(37, local=True))).shape[0] == l1 - l0
     dms = rng.standard_normal((2, nao, nao))
     vj0, vk0 = ref.get_jk(cderi, dms, 0)
     vj, vk = obj.get_jk(dms, hermi=0)                                              # general-DM branch

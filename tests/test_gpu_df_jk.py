@@ -214,6 +214,28 @@ def test_get_eri_ao2mo_and_npy_roundtrip(h2o, tmp_path):
         obj4._cderi_to_save = str(tmp_path / 'auto.h5')           # written by build(), as the reference does
         obj4.build()
         assert hdf5.is_hdf5(obj4._cderi_to_save)
+        # stock PySCF's default on-disk layout: GROUP 'j3c' with column blocks '0', '1', ... (outcore.cholesky_eri_b,
+        # pyscf/df/outcore.py:215-221, read by df.py:227-241)
+        import ctypes
+        grp = str(tmp_path / 'blocks.h5')
+        lib_h5 = hdf5._load()
+        with hdf5.File(grp, 'w') as f:
+            lib_h5.H5Gcreate2.restype = ctypes.c_int64
+            g = lib_h5.H5Gcreate2(ctypes.c_int64(f._id), b'j3c', ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0))
+            cuts = [0, 100, 101, cderi.shape[1]]
+            for i in range(3):
+                blk = np.ascontiguousarray(cderi[:, cuts[i]:cuts[i + 1]])
+                f.create_dataset('j3c/%d' % i, blk.shape).write_rows(0, blk)
+            lib_h5.H5Gclose(ctypes.c_int64(g))
+        obj5 = df.DF(mol)
+        obj5._cderi = grp
+        assert np.abs(np.vstack(list(obj5.loop(33))) - cderi).max() < 1e-14
+        from pyscf_amd import gto
+        from tests.conftest import H2O
+        bad = df.DF(gto.M(atom=H2O, basis='sto-3g'))             # wrong nao for this file: clear error, not an opaque IOError
+        bad._cderi = grp
+        with pytest.raises(RuntimeError, match='nao_pair'):
+            bad.build()
 
 
 def test_hermitian_dm_without_orbitals_is_factorized(h2o):

@@ -37,6 +37,8 @@ ap.add_argument('--rks', default='', help="also converge DF-RKS with this functi
 ap.add_argument('--dm0', default='', help='.npy start density for the SCF runs (any source: the converged energy does not '
                 'depend on it beyond conv_tol)')
 ap.add_argument('--conv-tol', type=float, default=1e-10)
+ap.add_argument('--unseeded', action='store_true', help="also converge DF-RHF from the ORACLE'S OWN core-Hamiltonian guess "
+                "(no density from anywhere else; key e_rhf_unseeded) - the independent-SCF golden VERDICT r02 asked for")
 a = ap.parse_args()
 os.makedirs(a.scratch, exist_ok=True)
 t00 = time.time()
@@ -140,6 +142,19 @@ if 'e_rhf' not in res:
     np.save(os.path.join(a.scratch, tag + '_rhf_dm.npy'), dm)
     save()
     log('E(DF-RHF) = %.12f' % e)
+
+if a.unseeded and 'e_rhf_unseeded' not in res:
+    conv, e, mo_e, mo_c, mo_occ, dm = ref.rhf_kernel(mol, lambda d, c, o: (lambda v: v[0] - .5 * v[1])(jk(d, c, o)),
+                                                     conv_tol=a.conv_tol, dm0=None, h1e=h1e, s1e=s1e, verbose=True,
+                                                     max_cycle=80)
+    assert conv
+    res['e_rhf_unseeded'] = float(e)
+    res['e_rhf_unseeded_note'] = ("DF-RHF from the oracle's own core-Hamiltonian ('1e') guess, oracle/ref.rhf_kernel, CDIIS, "
+                                  'conv_tol %g; no product data on the path' % a.conv_tol)
+    res['homo_lumo_unseeded'] = [float(mo_e[nocc - 1]), float(mo_e[nocc])]
+    np.save(os.path.join(a.scratch, tag + '_rhf_unseeded_dm.npy'), dm)
+    save()
+    log('E(DF-RHF, unseeded) = %.12f' % e)
 
 if a.rks and ('e_rks_' + a.rks) not in res:
     from oracle import ref_dft
