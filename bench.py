@@ -351,11 +351,13 @@ def main():
             vj0, vk0, cpu_flops = ref_c.get_jk(sample, dm, c, mo_occ, blockdim=240, nthreads=ncore)
             cpu_s = time.perf_counter() - t0
             phases, kind = ref_c.get_jk.last_phases, 'reference'
+            ncore = ref_c.get_jk.last_threads            # the threads really used (capped at 64: scipy's OpenBLAS)
             what = ("the reference's own C (AO2MOnr_e2_drv / AO2MOtranse2_nr_s2 / AO2MOmmm_bra_nr_s2 of lib/ao2mo/nr_ao2mo.c, NPdgemm / "
                     "NPdunpack_tril of lib/np_helper) compiled into oracle/_ref and called as pyscf/df/df_jk.py:329-381 does, blocks "
                     "of 240 aux rows; %d OpenMP threads, BLAS serial inside the parallel regions (scipy's OpenBLAS is capped at 64 "
-                    "threads, so it runs 1 thread per call and the reference's own omp loops use every core); the J line is "
-                    "numpy.matmul as in the reference" % ref_c.get_jk.last_threads)
+                    "concurrent callers, so the reference's omp loops run on min(host cores, 64) threads with one BLAS thread each - "
+                    "`cores` is that number, the host has %d); the J line is numpy.matmul as in the reference"
+                    % (ref_c.get_jk.last_threads, os.cpu_count()))
         else:
             ref.get_jk_rows_parallel(sample[:min(nrow, 64)], dm, c, mo_occ, nthreads=ncore)      # warm the BLAS threads
             t0 = time.perf_counter()

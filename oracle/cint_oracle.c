@@ -472,6 +472,42 @@ void oracle_int3c2e_slab(double *out, long ld, const int *atm, int natm, const i
     free(loc);
 }
 
+/* Rectangular (s1) block of the same integrals: AO shells i in [ish0, ish1) x AO shells j in [jsh0, jsh1), every aux function.
+ * out[k][(p - p0) * nj + (q - q0)] with p0 / q0 the first functions of shells ish0 / jsh0 and nj the functions of the j range.
+ * Used by tools/gen_golden_shard_local.py (pairs (p, q in a local support) of a tensor too large to generate whole). */
+void oracle_int3c2e_block(double *out, const int *atm, int natm, const int *bas, int nbas_ao,
+                          int nbas_aux, const double *env, int ish0, int ish1, int jsh0, int jsh1)
+{
+    int nbas = nbas_ao + nbas_aux;
+    int *loc = malloc(sizeof(int) * (nbas + 1));
+    make_ao_loc(bas, nbas, loc);
+    int nao = loc[nbas_ao];
+    long p0 = loc[ish0], q0 = loc[jsh0];
+    long ni = loc[ish1] - p0, nj = loc[jsh1] - q0;
+#pragma omp parallel for schedule(dynamic) collapse(2)
+    for (int ks = 0; ks < nbas_aux; ks++)
+    for (int is = ish0; is < ish1; is++) {
+        Shell K = get_shell(atm, bas, env, nbas_ao + ks);
+        Shell Kd = dummy_shell(K.r);
+        Shell I = get_shell(atm, bas, env, is);
+        int dk = nsph(&K), di = nsph(&I);
+        int k0 = loc[nbas_ao + ks] - nao, i0 = loc[is];
+        for (int js = jsh0; js < jsh1; js++) {
+            Shell J = get_shell(atm, bas, env, js);
+            int dj = nsph(&J), j0 = loc[js];
+            double *buf = malloc(sizeof(double) * di * dj * dk);
+            eri_sph(&I, &J, &K, &Kd, buf);   /* buf[k][j][i] */
+            for (int k = 0; k < dk; k++)
+                for (int j = 0; j < dj; j++)
+                    for (int i = 0; i < di; i++)
+                        out[(size_t)(k0 + k) * ni * nj + (size_t)(i0 + i - p0) * nj + (j0 + j - q0)] =
+                            buf[((size_t)k * dj + j) * di + i];
+            free(buf);
+        }
+    }
+    free(loc);
+}
+
 /* (i|k) over the shells [sh0, sh1) of a bas table: out[i][k] symmetric, n x n */
 void oracle_int2c2e(double *out, const int *atm, int natm, const int *bas, int sh0, int sh1,
                     const double *env)

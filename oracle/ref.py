@@ -147,6 +147,24 @@ def int3c2e_slab(mol, auxmol, ish0, ish1, omega=0.0, out=None):
     return out
 
 
+def int3c2e_block(mol, auxmol, ish0, ish1, jsh0, jsh1, omega=0.0):
+    """Raw integrals (Q|pq) for p in AO shells [ish0, ish1), q in AO shells [jsh0, jsh1), all aux Q: (naux, np, nq), no
+    symmetry packing (the rectangular counterpart of int3c2e_slab)."""
+    from pyscf_amd.gto import conc_env
+    atm, bas, env = conc_env(mol._atm, mol._bas, mol._env, auxmol._atm, auxmol._bas, auxmol._env)
+    atm = np.ascontiguousarray(atm, np.int32)
+    bas = np.ascontiguousarray(bas, np.int32)
+    env = np.ascontiguousarray(env)
+    loc = ao_loc(mol)
+    out = np.zeros((auxmol.nao_nr(), int(loc[ish1] - loc[ish0]), int(loc[jsh1] - loc[jsh0])))
+    lib().oracle_set_omega(ctypes.c_double(omega))
+    lib().oracle_int3c2e_block(_p(out), _p(atm), ctypes.c_int(len(atm)), _p(bas), ctypes.c_int(mol.nbas),
+                               ctypes.c_int(auxmol.nbas), _p(env), ctypes.c_int(ish0), ctypes.c_int(ish1), ctypes.c_int(jsh0),
+                               ctypes.c_int(jsh1))
+    lib().oracle_set_omega(ctypes.c_double(0.0))
+    return out
+
+
 def int2e(mol, omega=0.0):
     atm, bas, env = _tables(mol)
     n = mol.nao_nr()

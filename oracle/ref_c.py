@@ -13,8 +13,9 @@ DF J/K hot path (built by `make -C oracle ref` from the sources where they lie u
   * ``vj = lib.unpack_tril(vj, 1)``                                      (:410)      -> NPdunpack_tril_2d (pack_tril.c:214)
 
 Threading as in a stock PySCF build (OpenMP-threaded C, BLAS serial inside the parallel regions): the OpenBLAS that ships in
-scipy's wheel is pthread-based and capped at 64 threads, so it is pinned to ONE thread per call and every core is driven by the
-reference's own `#pragma omp` loops; `numpy.matmul` of the J line keeps numpy's own BLAS threading.
+scipy's wheel is pthread-based and compiled for at most 64 concurrent callers, so it is pinned to ONE thread per call and the
+reference's own `#pragma omp` loops run on min(host cores, 64) threads (more callers crashed it on the 256-core GPU host);
+`numpy.matmul` of the J line keeps numpy's own BLAS threading.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
 import ctypes
@@ -55,12 +56,17 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+MAX_BLAS_CALLERS = 64      # scipy's OpenBLAS is compiled for 64 threads: more CONCURRENT callers corrupt its buffer table
+                           # ("precompiled NUM_THREADS exceeded ... double free or corruption" on a 256-core host, r03)
+
+
 def set_threads(n):
-    """OpenMP threads of the reference's C (lib.num_threads(), pyscf/lib/misc.py:195-224); BLAS stays at one thread per call."""
+    """OpenMP threads of the reference's C (lib.num_threads(), pyscf/lib/misc.py:195-224), capped at MAX_BLAS_CALLERS; BLAS
+    stays at one thread per call.  Returns the thread count really used (bench.py reports it as `cores`)."""
     l = lib()
     l.scipy_openblas_set_num_threads(1)
-    if n:
-        l.omp_set_num_threads(ctypes.c_int(int(n)))
+    n = min(int(n or os.cpu_count() or 1), MAX_BLAS_CALLERS)
+    l.omp_set_num_threads(ctypes.c_int(n))
     return l.omp_get_max_threads()
 
 

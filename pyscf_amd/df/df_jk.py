@@ -610,22 +610,4 @@ def _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k):
 
 def _download(dfobj, tensors):
     """Device tensors -> fresh numpy arrays through a persistent pinned buffer (one async copy per tensor, one sync)."""
-    torch = _torch()
-    n = sum(t.numel() for t in tensors)
-    pin = getattr(dfobj, '_pinned', None)
-    if pin is None or pin.numel() < n:
-        pin = torch.empty(n, dtype=torch.float64, pin_memory=True)
-        dfobj._pinned = pin
-    off, views = 0, []
-    for t in tensors:
-        v = pin[off:off + t.numel()].view(t.shape)
-        v.copy_(t, non_blocking=True)
-        views.append(v)
-        off += t.numel()
-    torch.cuda.current_stream().synchronize()
-    outs = []
-    for v in views:                      # staging buffer -> caller-owned arrays (torch's copy is multi-threaded for large tensors)
-        o = np.empty(tuple(v.shape))
-        torch.from_numpy(o).copy_(v)
-        outs.append(o)
-    return outs
+    return _lib_mod.download(dfobj, tensors)

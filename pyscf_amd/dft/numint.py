@@ -294,7 +294,7 @@ class NumInt:
         orb_h[:nao, :nocc] = orbo
         return torch.from_numpy(orb_h).to(dev), nocc, nocc_pad, ldo, sign
 
-    def _sparse_xc(self, mol, grids, fac, gga, orbsets, spin):
+    def _sparse_xc(self, mol, grids, fac, gga, orbsets, spin, device_out=False):
         """nelec / exc / vmat of nr_rks (spin = 0, one orbital set) or nr_uks (spin = 1, two sets) on the compact AO
         subsets: per chunk of tiles  c = ao_c . C (sub_orb_dot) -> rho -> eval_xc -> aow_c (sub_scale) ->
         M[idx, idx] += ao_c^T aow_c (sub_vmat); finally V = M + M^T (numint.py:1157)."""
@@ -356,7 +356,31 @@ class NumInt:
                        _ptr(v[s]), st)
         rank, world = self._world()
         self._allreduce([v, acc], world)
-        return acc.cpu().numpy(), v.cpu().numpy()
+        if device_out:
+            return acc, v
+        a_h, v_h = _lib_mod.download(self, [acc, v])
+        return a_h, v_h
+
+    def nr_rks_device(self, mol, grids, xc_code, orbo):
+        """nr_rks for a closed-shell density given by its scaled occupied orbitals `orbo` = C_occ sqrt(occ), a (nao, nocc)
+        DEVICE tensor; returns DEVICE tensors (acc = [nelec, exc], vmat (nao, nao)) - nothing crosses PCIe (the SCF loop of
+        scf/device_scf.py).  Same arithmetic as nr_rks (numint.py:1074-1190) on the block-sparse pipeline."""
+        import torch
+        dev = self._dev()
+        if grids.coords is None:
+            grids.build()
+        hyb, fac = self._parse(xc_code)
+        xctype = _xc.xc_type(xc_code)
+        nao, nocc = orbo.shape
+        if xctype == 'HF':
+            return torch.zeros(2, dtype=torch.float64, device=dev), torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+        gga = 1 if xctype == 'GGA' else 0
+        nocc_pad = _round_up(max(nocc, 1), 16)
+        ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
+        orb = torch.zeros((_round_up(nao + 1, 16), ldo), dtype=torch.float64, device=dev)
+        orb[:nao, :nocc] = orbo
+        acc, v = self._sparse_xc(mol, grids, fac, gga, [(orb, nocc, nocc_pad, ldo, None)], 0, device_out=True)
+        return acc, v[0]
 
     def _first_order_terms(self, dms2, lowrank, nao, dev):
         """Per first-order density: ('pair', opA, opB, coef) when the caller tagged its factors (D = L R^T [+ h.c.], see

@@ -1,0 +1,362 @@
+"""The SCF cycle with everything resident in HBM.
+
+``hf.kernel`` mirrors ``pyscf/scf/hf.py:49-241`` statement by statement on numpy arrays: F, D, the DIIS vectors and the Fock
+extrapolation live on the host and cross PCIe every cycle, and the Fock matrix is diagonalised by a full ``eigh`` (98 ms at
+nao = 1856: rocSOLVER's tridiagonal reduction is launch-bound).  With J/K at 0.11 s that driver-side work was 2/3 of a cycle.
+
+``kernel_device`` runs the same iteration - same Fock / DIIS / energy / convergence definitions (hf.py:49-241, 244-319,
+1098-1146, 1193-1210; CDIIS scf/diis.py:40-96 + lib/diis.py:225-290) - on device tensors:
+
+  * J/K through ``df_jk.get_jk_device`` (device in, device out, D = C~ C~^T promised: no check, no sync), XC through
+    ``NumInt.nr_rks_device``; only scalars (energies, norms, DIIS overlaps) and the orbital energies reach the host,
+  * the occupied space of the orthogonalised Fock matrix F' = X^T F X comes, from cycle ``purify_from_cycle`` on, from
+    trace-correcting purification (SP2, Niklasson 2002: X <- X^2 or 2X - X^2, whichever moves Tr X towards nocc) - ~30 GEMMs
+    of nao^3 instead of an eigendecomposition; P is the projector on the nocc lowest eigenvectors, exactly what get_occ's
+    aufbau filling (hf.py:1148-1190) of the eigenvectors gives.  An orthonormal orbital basis of range(P) (the MO branch of K
+    and the orbital-based rho need a factor of D) is P applied to the previous occupied orbitals + Cholesky-QR.  The first
+    cycles, any case where the purification does not converge to an idempotent matrix of trace nocc (vanishing gap), and
+    the final / conv_check diagonalisation use the full eigh, so mo_energy / mo_coeff come out as in the reference,
+  * |g| = 2 |Q F' P|_F (Q = 1 - P) is the norm of hf.py:1193-1210's C_vir^T F C_occ * 2 without virtual orbitals.
+
+Stock callers still get numpy at the API edge (mf.mo_coeff, mf.mo_energy, mf.mo_occ, e_tot); ``mf.device_scf = False``
+(or a callback, damping, level shift, range-separated hybrids, open shells) selects the host loop.
+"""
+import ctypes as _c
+import time
+
+import numpy as np
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def eligible(mf, callback=None):
+    from . import hf
+    from ..df import DF
+    if not getattr(mf, 'device_scf', True) or callback is not None or not hf._has_device():
+        return False
+    if type(mf).__name__ not in ('RHF', 'RKS') or getattr(mf, 'only_dfj', False):
+        return False
+    if not isinstance(getattr(mf, 'with_df', None), DF) or mf.with_df.omega != 0:
+        return False
+    if abs(mf.damp) > 1e-4 or abs(mf.level_shift) > 1e-4 or mf.max_cycle <= 0:
+        return False
+    if mf.mol.nelectron % 2 or getattr(mf.mol, 'spin', 0):
+        return False
+    if mf.mol.nao < getattr(mf, 'device_scf_min_nao', 512):
+        return False
+    if type(mf).__name__ == 'RKS':
+        ni = mf._numint
+        if not getattr(ni, 'sparse', False):
+            return False
+        omega, alpha, hyb = ni.rsh_and_hybrid_coeff(mf.xc, spin=0)
+        if omega != 0 and alpha != 0:
+            return False                      # range-separated exchange: several tensors, host loop
+        from ..dft import libxc
+        if libxc.xc_type(mf.xc) not in ('LDA', 'GGA', 'HF'):
+            return False
+    return True
+
+
+class DeviceDIIS:
+    """CDIIS (pyscf/scf/diis.py:40-96, lib/diis.py:225-290) with the Fock and error vectors in HBM; the (n+1)^2 system is
+    solved on the host from the n new overlaps that each cycle downloads."""
+
+    def __init__(self, space, xorth):
+        self.space = space
+        self.x = xorth
+        self._f, self._e = [], []
+        self._h = np.zeros((0, 0))
+
+    def update(self, s, d, f):
+        torch = _torch()
+        sdf = s @ d @ f
+        err = self.x.T @ (sdf.T - sdf) @ self.x
+        ev = err.reshape(-1)
+        row = torch.stack([torch.dot(e, ev) for e in self._e] + [torch.dot(ev, ev)]).cpu().numpy()
+        self._f.append(f.clone())
+        self._e.append(ev)
+        nold = len(self._e) - 1
+        hnew = np.zeros((nold + 1, nold + 1))
+        if nold:
+            hnew[:nold, :nold] = self._h
+        hnew[nold, :] = hnew[:, nold] = row
+        self._h = hnew
+        if len(self._f) > self.space:
+            self._f.pop(0)
+            self._e.pop(0)
+            self._h = self._h[1:, 1:]
+        n = len(self._f)
+        h = np.zeros((n + 1, n + 1))
+        h[0, 1:] = h[1:, 0] = 1
+        h[1:, 1:] = self._h
+        g = np.zeros(n + 1)
+        g[0] = 1
+        import scipy.linalg
+        w, v = scipy.linalg.eigh(h)
+        if np.any(abs(w) < 1e-14):
+            idx = abs(w) > 1e-14
+            c = np.dot(v[:, idx] * (1. / w[idx]), np.dot(v[:, idx].T.conj(), g))
+        else:
+            try:
+                c = np.linalg.solve(h, g)
+            except np.linalg.LinAlgError:
+                idx = abs(w) > 1e-14
+                c = np.dot(v[:, idx] * (1. / w[idx]), np.dot(v[:, idx].T.conj(), g))
+        out = torch.zeros_like(f)
+        for ci, fi in zip(c[1:], self._f):
+            out.add_(fi, alpha=float(ci))
+        return out
+
+
+def purify_sp2(fp, nocc, max_iter=120, tol=1e-11):
+    """Projector on the nocc lowest eigenvectors of the symmetric matrix `fp` by SP2 trace-correcting purification.
+    Returns (P, iterations) or (None, iterations) when no idempotent matrix of trace nocc was reached."""
+    torch = _torch()
+    n = fp.shape[0]
+    # Gershgorin bounds of the spectrum
+    diag = torch.diagonal(fp)
+    rad = fp.abs().sum(dim=1) - diag.abs()
+    emin, emax = float((diag - rad).min()), float((diag + rad).max())
+    if not emax > emin:
+        return None, 0
+    x = (torch.eye(n, dtype=fp.dtype, device=fp.device) * emax - fp) / (emax - emin)
+    last = None
+    for it in range(1, max_iter + 1):
+        x2 = x @ x
+        tr, tr2, idem = (float(v) for v in torch.stack([torch.trace(x), torch.trace(x2), (x2 - x).norm()]).cpu())
+        if idem < tol * max(1.0, np.sqrt(nocc)) and abs(tr - nocc) < 1e-6:
+            return (x + x.T) * 0.5, it
+        if last is not None and it > 20 and idem > 0.5 * last and idem < 1e-8 and abs(tr - nocc) < 1e-6:
+            return (x + x.T) * 0.5, it           # at the rounding floor
+        last = idem
+        if abs(tr2 - nocc) < abs(2 * tr - tr2 - nocc):
+            x = x2
+        else:
+            x = 2 * x - x2
+    return None, max_iter
+
+
+def _adjust_phase(c):
+    """hf.py:1393-1403: the largest component of every orbital positive."""
+    torch = _torch()
+    idx = torch.argmax(c.abs(), dim=0)
+    sign = torch.where(c[idx, torch.arange(c.shape[1], device=c.device)] < 0, -1.0, 1.0).to(c.dtype)
+    return c * sign
+
+
+def _pad_orbitals_dev(orbo, nao):
+    """Device version of df_jk.pad_orbitals: (orb[rows][ldo], nocc_pad, ldo) of the scaled occupied orbitals."""
+    torch = _torch()
+    from ..df.df_jk import _round_up
+    nocc = orbo.shape[1]
+    nocc_pad = _round_up(max(nocc, 1), 16)
+    ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
+    mt = nocc_pad // 16
+    nchunk = -(-mt // 10)
+    ldo = max(ldo, nchunk * (-(-(-(-mt // nchunk)) // 2)) * 32)
+    ldo = max(ldo, min(_round_up(nocc_pad, 160), _round_up(nocc_pad, 128)))
+    buf = torch.zeros((_round_up(nao, 16), ldo), dtype=torch.float64, device=orbo.device)    # rows = the k extent of the kernels
+    buf[:nao, :nocc] = orbo
+    return buf, (nocc_pad if nocc else 0), ldo
+
+
+class _Veff:
+    """J/K (+ XC) of one density on the device: `build(dm, orbo)` -> (vhf, e2) with e2 the two-electron energy, i.e.
+    1/2 Tr(D vhf) for RHF (hf.py:244-297) and ecoul + exc for RKS (dft/rks.py:228-258)."""
+
+    def __init__(self, mf):
+        from ..df import df_jk
+        from .. import lib as _lib
+        self.mf = mf
+        self.df_jk = df_jk
+        self.lib = _lib.load_library()
+        self.is_ks = type(mf).__name__ == 'RKS'
+        self.hyb = 1.0
+        self.with_k = True
+        if self.is_ks:
+            ni = mf._numint
+            omega, alpha, hyb = ni.rsh_and_hybrid_coeff(mf.xc, spin=0)
+            self.hyb = hyb
+            self.with_k = hyb != 0
+            if mf.grids.coords is None:
+                t0 = time.perf_counter()
+                mf.grids.build()
+                mf._log('setting up grids: %d points, %.2f s', mf.grids.size, time.perf_counter() - t0)
+        self.t_jk = self.t_xc = 0.0
+
+    def build(self, dm, orbo):
+        torch = _torch()
+        mf, df_jk = self.mf, self.df_jk
+        dfobj = mf.with_df
+        nao = dm.shape[0]
+        t0 = time.perf_counter()
+        exc = None
+        vxc = None
+        if self.is_ks:
+            acc, vxc = mf._numint.nr_rks_device(mf.mol, mf.grids, mf.xc, orbo)
+            self.nelec_exc = acc
+        t1 = time.perf_counter()
+        orb = _pad_orbitals_dev(orbo, nao)
+        if self.with_k:
+            vjtril, vk = df_jk.get_jk_device(dfobj, dm[None], [orb], True, True, dm_from_orbitals=True)
+        else:
+            vjtril, vk = df_jk.get_jk_device(dfobj, dm[None], None, True, False)
+        vj = torch.empty((nao, nao), dtype=torch.float64, device=dm.device)
+        df_jk._call(dfobj, 'unpack_tril', self.lib.PAMD_unpack_tril, df_jk._ptr(vjtril), _c.c_long(vjtril.shape[1]), _c.c_int(1),
+                    _c.c_int(nao), df_jk._ptr(vj), _c.c_int(nao), _c.c_int(nao), df_jk._stream())
+        if not self.is_ks:
+            vhf = vj - 0.5 * vk[0]
+            e2 = 0.5 * torch.sum(vhf * dm)
+        else:
+            ecoul = 0.5 * torch.sum(vj * dm)
+            exc = self.nelec_exc[1]
+            if self.with_k:
+                vkh = vk[0] * self.hyb
+                vhf = vxc + vj - 0.5 * vkh
+                exc = exc - 0.25 * torch.sum(vkh * dm)
+            else:
+                vhf = vxc + vj
+            e2 = ecoul + exc
+        self.t_xc += t1 - t0
+        self.t_jk += time.perf_counter() - t1
+        return vhf, e2
+
+
+def kernel_device(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, conv_check=True):
+    """Same contract as hf.kernel: -> (converged, e_tot, mo_energy, mo_coeff, mo_occ), numpy at the edge."""
+    torch = _torch()
+    from . import hf
+    if conv_tol_grad is None:
+        conv_tol_grad = np.sqrt(conv_tol)
+    mol = mf.mol
+    dev = mf.with_df._device()
+    f64 = torch.float64
+    s1e_h = mf.get_ovlp(mol)
+    h1e_h = mf.get_hcore(mol)
+    dm_h = mf.get_init_guess(mol, mf.init_guess, s1e=s1e_h) if dm0 is None else dm0
+    # the first Fock build goes through the public host API: the start density may be anything (untagged, any rank)
+    vhf_h = mf.get_veff(mol, dm_h)
+    e_tot = mf.energy_tot(dm_h, h1e_h, vhf_h)
+    mf._log('init E= %.15g', e_tot)
+    enuc = mf.energy_nuc()
+    s = torch.from_numpy(np.ascontiguousarray(s1e_h)).to(dev)
+    h = torch.from_numpy(np.ascontiguousarray(h1e_h)).to(dev)
+    dm = torch.from_numpy(np.ascontiguousarray(np.asarray(dm_h), dtype=np.float64)).to(dev)
+    vhf = torch.from_numpy(np.ascontiguousarray(np.asarray(vhf_h), dtype=np.float64)).to(dev)
+    # canonical orthogonalisation (hf.py:1363-1379)
+    se, sv = torch.linalg.eigh(s)
+    keep = se > hf.OVERLAP_ZERO_EIGENVALUE_THRESHOLD
+    x = (sv[:, keep] / se[keep].sqrt()).contiguous()
+    nmo = x.shape[1]
+    nocc = mol.nelectron // 2
+    diis = DeviceDIIS(mf.diis_space, x) if mf.diis else None
+    veff = _Veff(mf)
+    purify_from = getattr(mf, 'purify_from_cycle', 3)
+    eye = torch.eye(nmo, dtype=f64, device=dev)
+
+    def full_eig(fock):
+        e, c = torch.linalg.eigh(x.T @ fock @ x)
+        c = _adjust_phase(x @ c)
+        e_h = e.cpu().numpy()
+        occ_h = mf.get_occ(e_h, None)
+        return e_h, c, occ_h
+
+    def occupied(fock, cycle, c_occ_prev):
+        """-> (orbo = C_occ sqrt(2), P' (orthonormal basis) | None, mo_energy_h | None, c_full | None, mo_occ_h | None)"""
+        if cycle >= purify_from and c_occ_prev is not None and getattr(mf, 'purify', True):
+            fp = x.T @ fock @ x
+            p, nit = purify_sp2(fp, nocc)
+            if p is not None:
+                # orthonormal basis of range(P): P applied to the previous occupied orbitals (orthonormal-basis
+                # coordinates x^T S C), Cholesky-QR
+                y = p @ c_occ_prev
+                m = y.T @ y
+                try:
+                    l = torch.linalg.cholesky(m)
+                    cq = torch.linalg.solve_triangular(l, y.T, upper=False).T.contiguous()
+                    # one re-orthonormalisation pass (CholQR2) keeps C^T C = 1 to rounding
+                    m2 = cq.T @ cq
+                    l2 = torch.linalg.cholesky(m2)
+                    cq = torch.linalg.solve_triangular(l2, cq.T, upper=False).T.contiguous()
+                    mf._purify_iters = nit
+                    return cq, p, fp
+                except Exception:
+                    pass
+        return None, None, None
+
+    scf_conv = False
+    mo_energy_h = mo_occ_h = None
+    c_full = None
+    c_occ_orth = None            # occupied orbitals in the orthonormal basis (coordinates w.r.t. the columns of x)
+    fock = None
+    cycle = -1
+    xs = x.T @ s                 # orthonormal-basis coordinates of an AO-basis orbital set: x^T S C
+    sqrt2 = float(np.sqrt(2.0))
+    t_eig = t_misc = 0.0
+    for cycle in range(mf.max_cycle):
+        t0 = time.perf_counter()
+        dm_last = dm
+        last_hf_e = e_tot
+        fock = h + vhf
+        if diis is not None and cycle >= mf.diis_start_cycle:
+            fock = diis.update(s, dm, fock)
+        te = time.perf_counter()
+        cq, p, fp = occupied(fock, cycle, c_occ_orth)
+        if cq is None:
+            mo_energy_h, c_full, mo_occ_h = full_eig(fock)
+            occ_mask = torch.from_numpy(mo_occ_h > 0).to(dev)
+            c_occ = c_full[:, occ_mask].contiguous()
+            c_occ_orth = xs @ c_occ
+            p = None
+        else:
+            c_occ_orth = cq
+            c_occ = x @ cq
+            c_full = None
+        torch.cuda.current_stream().synchronize()
+        t_eig += time.perf_counter() - te
+        orbo = c_occ * sqrt2
+        dm = orbo @ orbo.T
+        vhf, e2 = veff.build(dm, orbo)
+        e1 = torch.sum(h * dm)
+        fock_new = h + vhf
+        # |g| = |C_vir^T F C_occ| * 2 = 2 |Q F' P| in the orthonormal basis (hf.py:1193-1210)
+        fpn = x.T @ fock_new @ x
+        fo = fpn @ c_occ_orth                          # F' C_occ
+        g = fo - c_occ_orth @ (c_occ_orth.T @ fo)      # (1 - P) F' C_occ
+        scal = torch.stack([e1 + e2, g.norm() * 2.0, (dm - dm_last).norm()]).cpu().numpy()
+        e_tot = float(scal[0]) + enuc
+        norm_gorb, norm_ddm = float(scal[1]), float(scal[2])
+        fock = fock_new
+        mf._log('cycle= %d E= %.15g  delta_E= %4.3g  |g|= %4.3g  |ddm|= %4.3g  (%.3f s)%s',
+                cycle + 1, e_tot, e_tot - last_hf_e, norm_gorb, norm_ddm, time.perf_counter() - t0,
+                '' if p is None else '  [SP2 %d]' % getattr(mf, '_purify_iters', 0))
+        if abs(e_tot - last_hf_e) < conv_tol and norm_gorb < conv_tol_grad:
+            scf_conv = True
+            break
+    mf.cycles = cycle + 1
+    # the reference's extra cycle (hf.py:213-235): diagonalise the final Fock matrix, one more Fock build
+    mo_energy_h, c_full, mo_occ_h = full_eig(fock)
+    if scf_conv and conv_check:
+        occ_mask = torch.from_numpy(mo_occ_h > 0).to(dev)
+        c_occ = c_full[:, occ_mask].contiguous()
+        c_occ_orth = xs @ c_occ
+        orbo = c_occ * sqrt2
+        dm_last, dm = dm, orbo @ orbo.T
+        vhf, e2 = veff.build(dm, orbo)
+        fock = h + vhf
+        fpn = x.T @ fock @ x
+        fo = fpn @ c_occ_orth
+        g = fo - c_occ_orth @ (c_occ_orth.T @ fo)
+        scal = torch.stack([torch.sum(h * dm) + e2, g.norm() * 2.0]).cpu().numpy()
+        e_tot, last_hf_e = float(scal[0]) + enuc, e_tot
+        norm_gorb = float(scal[1])
+        scf_conv = abs(e_tot - last_hf_e) < conv_tol * 10 or norm_gorb < conv_tol_grad * 3
+        mf._log('Extra cycle  E= %.15g  delta_E= %4.3g  |g|= %4.3g', e_tot, e_tot - last_hf_e, norm_gorb)
+    mf._log('device SCF: occupied-space solves %.3f s, XC %.3f s, J/K %.3f s (host clocks incl. queueing)', t_eig, veff.t_xc,
+            veff.t_jk)
+    mf.scf_summary['nuc'] = enuc
+    mf._dm_dev = dm
+    return scf_conv, e_tot, mo_energy_h, c_full.cpu().numpy(), mo_occ_h

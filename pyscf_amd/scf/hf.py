@@ -146,6 +146,10 @@ class CDIIS:
 
 def kernel(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, callback=None, conv_check=True):
     """pyscf/scf/hf.py:49-241."""
+    from . import device_scf
+    if device_scf.eligible(mf, callback):
+        # closed-shell DF-RHF / DF-RKS from nao = 512: the same iteration with F, D and the DIIS vectors resident in HBM
+        return device_scf.kernel_device(mf, conv_tol, conv_tol_grad, dm0, conv_check)
     if conv_tol_grad is None:
         conv_tol_grad = np.sqrt(conv_tol)
     mol = mf.mol
@@ -227,6 +231,10 @@ class SCF:
     direct_scf_tol = 1e-13
     conv_check = True
     device_linalg = True
+    device_scf = True          # closed-shell DF-RHF / DF-RKS: the HBM-resident loop of scf/device_scf.py (from device_scf_min_nao)
+    device_scf_min_nao = 512
+    purify = True              # occupied space by SP2 purification instead of a full eigh from cycle `purify_from_cycle`
+    purify_from_cycle = 3
 
     def __init__(self, mol):
         self.mol = mol

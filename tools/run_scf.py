@@ -13,13 +13,22 @@ ap.add_argument('--conv-tol', type=float, default=1e-9)
 ap.add_argument('--molecule', default='water', choices=['water', 'taxol'])
 ap.add_argument('--level-shift', type=float, default=0.0)
 ap.add_argument('--max-cycle', type=int, default=50)
+ap.add_argument('--dump-orbitals', default='', help='.npz: orbo = C_occ sqrt(occ) and e_tot of the converged state (input of tools/gen_golden_streaming.py)')
+ap.add_argument('--host-loop', action='store_true', help='the numpy SCF loop instead of the HBM-resident one')
 a = ap.parse_args()
 mol = gto.M(atom=clusters.taxol() if a.molecule == 'taxol' else clusters.water_cluster(a.nwater), basis=a.basis, verbose=4)
 mf = (dft.RKS(mol, xc=a.xc) if a.xc else scf.RHF(mol)).density_fit()
 mf.conv_tol = a.conv_tol
 mf.level_shift = a.level_shift
 mf.max_cycle = a.max_cycle
+if a.host_loop:
+    mf.device_scf = False
 t0 = time.perf_counter()
 e = mf.kernel()
 print('converged=%s cycles=%d E=%.10f wall=%.1f s (nao=%d naux=%d)' %
       (mf.converged, mf.cycles, e, time.perf_counter() - t0, mol.nao, mf.with_df.get_naoaux()), flush=True)
+if a.dump_orbitals:
+    import numpy as np
+    occ = mf.mo_occ > 0
+    np.savez(a.dump_orbitals, orbo=mf.mo_coeff[:, occ] * np.sqrt(mf.mo_occ[occ]), e_tot=e, converged=mf.converged,
+             mo_energy=mf.mo_energy)
