@@ -188,6 +188,7 @@ def main():
         vj_h, vk_h = dfobj.get_jk(dm_tag, hermi=1)
     fence()
     host_api_ms = (time.perf_counter() - t0) / nh * 1e3
+    host_fused = getattr(dfobj, '_last_fused', None)       # was the first J pass fused for the foreign (unpromised) tag?
     if world > 1:
         tmax = torch.tensor([host_api_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -315,7 +316,7 @@ def main():
         # figure 2 naux nao^2 nocc over its time (may exceed the 78.6 TF/s peak: symmetry, not speed); 'executed' counts the
         # tiles it really multiplies
         nt = -(-nao // 128)
-        syrk_exec = flops_syrk * (nt * (nt + 1) / 2) * 128.0 * 128.0 / (float(nao) * nao)
+        syrk_exec = flops_syrk * (nt * (nt + 1) / 2) / (float(nt) * nt)     # useful share: lower-triangular tiles of the nt^2
         k_tflops['dgemm_tn_charged'] = round(flops_syrk / (ksum['dgemm_tn'][0] * 1e-3) / 1e12, 2)
         k_tflops['dgemm_tn_executed'] = round(syrk_exec / (ksum['dgemm_tn'][0] * 1e-3) / 1e12, 2)
     else:
@@ -388,7 +389,7 @@ def main():
                                   ' + unpacked image for the K half transform' if getattr(dfobj, '_cderi_sq', None) is not None else ''),
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
                    'naux_local': naux_local, 'naux_per_rank': naux_per_rank},
-        'value_host_api_ms': round(host_api_ms, 3),
+        'value_host_api_ms': round(host_api_ms, 3), 'host_api_fused_j': host_fused,
         'roofline': roofline, 'roofline_step': step_roof,
         'cpu_baseline': cpu, 'comm': comm_info, 'preflight': preflight,
         'kernels': kern, 'j_hbm_GBs': j_gbs, 'k_mfma_TFLOPs': k_tflops,

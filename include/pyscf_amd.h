@@ -274,6 +274,29 @@ int PAMD_sub_vmat(const double *d_ao_c, const long *d_ao_off, const double *d_ao
                   const long *d_idx_off, const int *d_ld, const int *d_idx, const int *d_work /* {tile, tm, tn} x nwork */,
                   int nwork, int G, int nao, double *d_vmat, long ldv, void *stream);  /* vmat[idx][idx] += ao_c[0]^T aow_c */
 
+/* ---- host-array, opaque-handle form of the DF J/K path (csrc/df_handle.hip) -------------------------------------------
+ * The reference's convention: plain C functions taking raw HOST pointers and ints, the caller owns every buffer
+ * (pyscf/df/df_jk.py:373-379 fdrv(..., buf1.ctypes.data_as(c_void_p), eri1..., orbo...), pyscf/gto/moleintor.py:590-596).
+ * These entry points need no device-side runtime in the caller (no torch): the handle owns all HBM (hipMalloc), calls
+ * return when the results are in the caller's arrays.  Return 0 or a negative code (PAMD_last_error() has the message).
+ *   PAMD_df_create        replaces DF.build (pyscf/df/df.py:147-199) -> incore.cholesky_eri (pyscf/df/incore.py:129-220):
+ *                         atm[natm][6], bas[nbas_ao + nbas_aux][8] (AO rows, then aux rows: gto.conc_env), env[nenv] in libcint's
+ *                         format (pyscf/gto/mole.py:58-88); lindep = LINEAR_DEP_THR of the eigen-decomposition fallback (:263-270)
+ *   PAMD_df_get_jk        replaces df_jk.get_jk (pyscf/df/df_jk.py:280-413): dm[nset][nao][nao]; orbo = NULL -> general-DM
+ *                         branch (:382-408); else the sqrt(occ)-scaled occupied orbitals of every density, (nao, nocc[s]) C order
+ *                         one after the other -> MO branch (:339-381).  flags bit 0: dm[s] == orbo_s orbo_s^T is guaranteed
+ *   PAMD_df_export_cderi  rows [l0, l1) of `_cderi` (naux, nao_pair) into out (DF.loop, pyscf/df/df.py:214-242)
+ *   PAMD_df_naux          rows of the tensor (get_naoaux, :248-257: fewer than the aux functions after an eigen-decomposition) */
+typedef struct PAMD_df PAMD_df;
+int PAMD_df_create(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
+                   double lindep, int device, PAMD_df **out);
+void PAMD_df_destroy(PAMD_df *h);
+int PAMD_df_naux(const PAMD_df *h, int *naux);
+int PAMD_df_nao(const PAMD_df *h, int *nao);
+int PAMD_df_export_cderi(PAMD_df *h, int l0, int l1, double *out);
+int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
+                   int with_k, int flags, double *vj, double *vk);
+
 #ifdef __cplusplus
 }
 #endif

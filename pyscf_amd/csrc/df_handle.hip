@@ -1,0 +1,815 @@
+// Host-array, opaque-handle entry points of the DF J/K path.
+//
+// The reference's C entry points take raw host pointers and ints; the CALLER OWNS ALL BUFFERS (numpy arrays allocated in
+// Python and passed by pointer, pyscf/df/df_jk.py:373-379, pyscf/gto/moleintor.py:590-596).  The PAMD_* kernel launchers of
+// this library take DEVICE pointers, which is right for a runtime that already lives on the GPU (pyscf_amd.df.DF keeps its
+// tensors in torch) but leaves a numpy-only caller without an allocator.  The functions below close that gap:
+//
+//   PAMD_df_create        libcint-format tables (atm, bas = AO rows then aux rows as gto.conc_env makes them, env) ->
+//                         handle owning the 3-index tensor in HBM: what DF.build does (pyscf/df/df.py:147-199 ->
+//                         df/incore.py:129-220 cholesky_eri: j2c, Cholesky, per AO-row slab L^-1 (Q|pq))
+//   PAMD_df_get_jk        host dm (+ optional occupied orbitals) -> host vj, vk: df_jk.get_jk (pyscf/df/df_jk.py:280-413),
+//                         MO branch :339-381 when orbitals are given, general-DM branch :382-408 otherwise
+//   PAMD_df_export_cderi  rows [l0, l1) of `_cderi` to a host array (DF.loop, pyscf/df/df.py:214-242)
+//   PAMD_df_naux / _nao / _destroy
+//
+// All device memory is hipMalloc'ed and owned by the handle; calls are synchronous with respect to the host on return; one
+// handle per thread at a time (not re-entrant).  Host work here is the one-time table preparation that
+// pyscf_amd/gto/moleintor.py does in numpy (segmented shells, primitive-pair records, cart->sph matrices); the numerical work
+// is the same kernel family (PAMD_int3c2e_class, PAMD_cderi_solve, PAMD_nr_e2_*, PAMD_dgemm_tn, PAMD_df_vj_pass*).
+// The metric factorisation uses rocSOLVER's potrf (and syevd for a linearly dependent metric, `lindep`, df/incore.py:263-270)
+// and rocBLAS dgemm for the block forward substitution of L^-1 - library calls for the one-time O(naux^3) step that the
+// reference hands to LAPACK (df/incore.py:154) - resolved with dlopen so that libpyscf_amd.so itself links nothing new.
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+#include "common.h"
+#include "../../include/pyscf_amd.h"
+
+using namespace pamd;
+
+namespace {
+
+constexpr int ATOM_OF = 0, ANG_OF = 1, NPRIM_OF = 2, NCTR_OF = 3, PTR_EXP = 5, PTR_COEFF = 6, BAS_SLOTS = 8;
+constexpr int PTR_COORD = 1, ATM_SLOTS = 6;
+constexpr double EXPCUTOFF = 60.0;          // primitive-pair screening (pyscf_amd/gto/moleintor.py)
+constexpr int LMAX_TAB = 6;
+
+inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------ cart -> sph
+double binom(int n, int k)
+{
+    if (k < 0 || k > n) return 0.0;
+    double r = 1;
+    for (int i = 1; i <= k; i++) r = r * (n - k + i) / i;
+    return r;
+}
+double fact(int n) { double r = 1; for (int i = 2; i <= n; i++) r *= i; return r; }
+
+// real solid harmonics in Cartesian monomials (Helgaker/Jorgensen/Olsen 6.4.47), ordering of pyscf/lib/parameters.py:69-77
+std::vector<double> c2s_matrix(int l)
+{
+    std::vector<int> cx, cy, cz;
+    for (int x = l; x >= 0; x--)
+        for (int y = l - x; y >= 0; y--) { cx.push_back(x); cy.push_back(y); cz.push_back(l - x - y); }
+    const int nc = (int)cx.size();
+    auto idx = [&](int lx, int ly, int lz) {
+        for (int i = 0; i < nc; i++) if (cx[i] == lx && cy[i] == ly && cz[i] == lz) return i;
+        return -1;
+    };
+    std::vector<double> out((2 * l + 1) * nc, 0.0);
+    for (int m = -l; m <= l; m++) {
+        const int am = std::abs(m);
+        double N = 1.0 / (std::pow(2.0, am) * fact(l)) * std::sqrt(2.0 * fact(l + am) * fact(l - am) / (m == 0 ? 2.0 : 1.0));
+        N *= std::sqrt((2 * l + 1) / (4 * M_PI));
+        int row = m + l;
+        if (l == 1) row = (m == 1) ? 0 : (m == -1 ? 1 : 2);
+        for (int t = 0; t <= (l - am) / 2; t++)
+            for (int u = 0; u <= t; u++) {
+                const int kmax = (m >= 0) ? am / 2 : (am - 1) / 2;
+                for (int k = 0; k <= kmax; k++) {
+                    const int twov = (m >= 0) ? 2 * k : 2 * k + 1;
+                    const double c = (((t + k) % 2) ? -1.0 : 1.0) * std::pow(0.25, t) * binom(l, t) * binom(l - t, am + t) *
+                                     binom(t, u) * binom(am, twov);
+                    const int ly = 2 * u + twov, lx = 2 * t + am - ly, lz = l - 2 * t - am;
+                    if (lx < 0 || lz < 0) continue;
+                    out[row * nc + idx(lx, ly, lz)] += N * c;
+                }
+            }
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ shell tables
+struct Shells {                         // segmented shells of a bas table (general contractions split, zero coefficients dropped)
+    std::vector<int> l, ao0, atom;
+    std::vector<double> xyz;            // [n][3]
+    std::vector<std::vector<double>> exps, coefs;
+    int nao = 0, n = 0;
+};
+
+Shells make_shells(const int *atm, const int *bas, int b0, int b1, const double *env)
+{
+    Shells s;
+    int off = 0;
+    for (int ib = b0; ib < b1; ib++) {
+        const int *b = bas + (long)ib * BAS_SLOTS;
+        const int ia = b[ATOM_OF], ll = b[ANG_OF], nprim = b[NPRIM_OF], nctr = b[NCTR_OF];
+        const double *r = env + atm[ia * ATM_SLOTS + PTR_COORD];
+        const double *e = env + b[PTR_EXP], *c = env + b[PTR_COEFF];
+        for (int k = 0; k < nctr; k++) {
+            std::vector<double> ee, cc;
+            for (int p = 0; p < nprim; p++)
+                if (c[k * nprim + p] != 0.0) { ee.push_back(e[p]); cc.push_back(c[k * nprim + p]); }
+            s.l.push_back(ll);
+            s.xyz.insert(s.xyz.end(), r, r + 3);
+            s.exps.push_back(ee);
+            s.coefs.push_back(cc);
+            s.ao0.push_back(off);
+            s.atom.push_back(ia);
+            off += 2 * ll + 1;
+        }
+    }
+    s.nao = off;
+    s.n = (int)s.l.size();
+    return s;
+}
+
+struct DevPool {                        // every device allocation of a handle, freed together
+    std::vector<void *> ptrs;
+    int alloc(void **p, size_t bytes)
+    {
+        *p = nullptr;
+        if (bytes == 0) bytes = 8;
+        PAMD_CHECK_HIP(hipMalloc(p, bytes));
+        ptrs.push_back(*p);
+        return 0;
+    }
+    void release(void *p)
+    {
+        auto it = std::find(ptrs.begin(), ptrs.end(), p);
+        if (it != ptrs.end()) { (void)hipFree(p); ptrs.erase(it); }
+    }
+    ~DevPool() { for (void *p : ptrs) (void)hipFree(p); }
+};
+
+template <class T>
+int upload(DevPool &pool, const std::vector<T> &h, T **d)
+{
+    int rc = pool.alloc((void **)d, h.size() * sizeof(T));
+    if (rc) return rc;
+    if (!h.empty()) PAMD_CHECK_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+struct PairClass {
+    int li = 0, lj = 0, n = 0;
+    std::vector<int> rowshell;
+    int *d_ish = nullptr, *d_jsh = nullptr, *d_pp0 = nullptr, *d_npp = nullptr;
+    double *d_pp = nullptr;
+    void subrange(int sh0, int sh1, int *i0, int *i1) const
+    {
+        *i0 = (int)(std::lower_bound(rowshell.begin(), rowshell.end(), sh0) - rowshell.begin());
+        *i1 = (int)(std::lower_bound(rowshell.begin(), rowshell.end(), sh1) - rowshell.begin());
+    }
+};
+
+struct AuxClass {
+    int l = 0, n = 0, npk = 0;
+    int *d_f0 = nullptr;
+    double *d_xyz = nullptr, *d_exp = nullptr, *d_coef = nullptr;
+};
+
+// all shell pairs (a, b) with l_a = li >= l_b = lj (a >= b when li == lj), primitive pairs screened by exp(-mu R^2) < e^-60,
+// sorted by the row shell so that an AO-row slab is a contiguous range (moleintor._PairClass)
+int make_pair_class(DevPool &pool, const Shells &s, int li, int lj, PairClass *pc)
+{
+    pc->li = li;
+    pc->lj = lj;
+    std::vector<int> ish, jsh, npp, pp0;
+    std::vector<double> pp;
+    for (int a = 0; a < s.n; a++) {
+        if (s.l[a] != li) continue;
+        for (int b = 0; b < s.n; b++) {
+            if (s.l[b] != lj || (li == lj && a < b)) continue;
+            const double *A = &s.xyz[3 * a], *B = &s.xyz[3 * b];
+            const double r2 = (A[0] - B[0]) * (A[0] - B[0]) + (A[1] - B[1]) * (A[1] - B[1]) + (A[2] - B[2]) * (A[2] - B[2]);
+            int cnt = 0;
+            const int first = (int)(pp.size() / 8);
+            for (size_t p = 0; p < s.exps[a].size(); p++)
+                for (size_t q = 0; q < s.exps[b].size(); q++) {
+                    const double ea = s.exps[a][p], eb = s.exps[b][q], z = ea + eb, arg = ea * eb / z * r2;
+                    if (!(arg < EXPCUTOFF)) continue;
+                    const double wa = ea / z;
+                    double P[3];
+                    for (int x = 0; x < 3; x++) P[x] = wa * A[x] + (1 - wa) * B[x];
+                    const double rec[8] = {z, P[0], P[1], P[2], std::exp(-arg) * s.coefs[a][p] * s.coefs[b][q],
+                                           P[0] - A[0], P[1] - A[1], P[2] - A[2]};
+                    pp.insert(pp.end(), rec, rec + 8);
+                    cnt++;
+                }
+            if (cnt) { ish.push_back(a); jsh.push_back(b); npp.push_back(cnt); pp0.push_back(first); }
+        }
+    }
+    const int n = (int)ish.size();
+    pc->n = n;
+    if (n == 0) return 0;
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int x, int y) { return std::max(ish[x], jsh[x]) < std::max(ish[y], jsh[y]); });
+    std::vector<int> o_ish(n), o_jsh(n), o_npp(n), o_pp0(n);
+    pc->rowshell.resize(n);
+    for (int i = 0; i < n; i++) {
+        const int k = order[i];
+        o_ish[i] = ish[k]; o_jsh[i] = jsh[k]; o_npp[i] = npp[k]; o_pp0[i] = pp0[k];
+        pc->rowshell[i] = std::max(ish[k], jsh[k]);
+    }
+    int rc;
+    if ((rc = upload(pool, o_ish, &pc->d_ish)) || (rc = upload(pool, o_jsh, &pc->d_jsh)) ||
+        (rc = upload(pool, o_pp0, &pc->d_pp0)) || (rc = upload(pool, o_npp, &pc->d_npp)) || (rc = upload(pool, pp, &pc->d_pp)))
+        return rc;
+    return 0;
+}
+
+// (P, unit s function on the same centre): the 2-centre family (moleintor._PairClass2c)
+int make_pair_class_2c(DevPool &pool, const Shells &s, int li, double s_factor, PairClass *pc)
+{
+    pc->li = li;
+    pc->lj = 0;
+    std::vector<int> ia, pp0, npp;
+    std::vector<double> pp;
+    for (int a = 0; a < s.n; a++) {
+        if (s.l[a] != li) continue;
+        ia.push_back(a);
+        pp0.push_back((int)(pp.size() / 8));
+        npp.push_back((int)s.exps[a].size());
+        for (size_t p = 0; p < s.exps[a].size(); p++) {
+            const double rec[8] = {s.exps[a][p], s.xyz[3 * a], s.xyz[3 * a + 1], s.xyz[3 * a + 2], s.coefs[a][p] * s_factor, 0, 0, 0};
+            pp.insert(pp.end(), rec, rec + 8);
+        }
+    }
+    pc->n = (int)ia.size();
+    if (pc->n == 0) return 0;
+    pc->rowshell = ia;
+    int rc;
+    if ((rc = upload(pool, ia, &pc->d_ish)) || (rc = upload(pool, ia, &pc->d_jsh)) || (rc = upload(pool, pp0, &pc->d_pp0)) ||
+        (rc = upload(pool, npp, &pc->d_npp)) || (rc = upload(pool, pp, &pc->d_pp)))
+        return rc;
+    return 0;
+}
+
+int make_aux_class(DevPool &pool, const Shells &s, int l, AuxClass *ac)
+{
+    std::vector<int> idx;
+    for (int i = 0; i < s.n; i++) if (s.l[i] == l) idx.push_back(i);
+    ac->l = l;
+    ac->n = (int)idx.size();
+    if (ac->n == 0) return 0;
+    size_t npk = 0;
+    for (int i : idx) npk = std::max(npk, s.exps[i].size());
+    ac->npk = (int)npk;
+    std::vector<int> f0(ac->n);
+    std::vector<double> xyz(3 * ac->n), ex(ac->n * npk, 1.0), co(ac->n * npk, 0.0);
+    for (int j = 0; j < ac->n; j++) {
+        const int i = idx[j];
+        f0[j] = s.ao0[i];
+        for (int x = 0; x < 3; x++) xyz[3 * j + x] = s.xyz[3 * i + x];
+        for (size_t k = 0; k < s.exps[i].size(); k++) { ex[j * npk + k] = s.exps[i][k]; co[j * npk + k] = s.coefs[i][k]; }
+    }
+    int rc;
+    if ((rc = upload(pool, f0, &ac->d_f0)) || (rc = upload(pool, xyz, &ac->d_xyz)) || (rc = upload(pool, ex, &ac->d_exp)) ||
+        (rc = upload(pool, co, &ac->d_coef)))
+        return rc;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ rocSOLVER / rocBLAS (dlopen)
+struct RocLib {
+    void *hblas = nullptr, *hsolver = nullptr, *handle = nullptr;
+    int (*create)(void **) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    int (*set_stream)(void *, hipStream_t) = nullptr;
+    int (*dgemm)(void *, int, int, int, int, int, const double *, const double *, int, const double *, int, const double *,
+                 double *, int) = nullptr;
+    int (*dpotrf)(void *, int, int, double *, int, int *) = nullptr;
+    int (*dsyevd)(void *, int, int, int, double *, int, double *, double *, int *) = nullptr;
+    int open()
+    {
+        if (handle) return 0;
+        hblas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!hblas) hblas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        hsolver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!hsolver) hsolver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        PAMD_REQUIRE(hblas && hsolver, "librocblas.so / librocsolver.so not found (metric factorisation of PAMD_df_create)");
+        create = (decltype(create))dlsym(hblas, "rocblas_create_handle");
+        destroy = (decltype(destroy))dlsym(hblas, "rocblas_destroy_handle");
+        set_stream = (decltype(set_stream))dlsym(hblas, "rocblas_set_stream");
+        dgemm = (decltype(dgemm))dlsym(hblas, "rocblas_dgemm");
+        dpotrf = (decltype(dpotrf))dlsym(hsolver, "rocsolver_dpotrf");
+        dsyevd = (decltype(dsyevd))dlsym(hsolver, "rocsolver_dsyevd");
+        PAMD_REQUIRE(create && destroy && set_stream && dgemm && dpotrf && dsyevd, "rocBLAS / rocSOLVER symbols missing");
+        PAMD_REQUIRE(create(&handle) == 0, "rocblas_create_handle failed");
+        return 0;
+    }
+    ~RocLib() { if (handle && destroy) destroy(handle); }
+};
+constexpr int ROC_OP_N = 111, ROC_FILL_UPPER = 121, ROC_EVECT_ORIGINAL = 211;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ the handle
+struct PAMD_df {
+    int device = 0;
+    int nao = 0, naux = 0, nL = 0;          // nL = rows of the tensor held (naux, or fewer after an eigen-decomposed metric)
+    long npair = 0;
+    DevPool pool;
+    hipStream_t st = nullptr, side = nullptr;
+    hipEvent_t ev = nullptr;
+    double *d_cderi = nullptr, *d_sq = nullptr;
+    int rows = 0;                           // round_up(nao, 16)
+    std::map<std::string, std::pair<double *, size_t>> ws;
+    double *workspace(const std::string &name, size_t ndoubles, int *rc)
+    {
+        auto it = ws.find(name);
+        *rc = 0;
+        if (it != ws.end() && it->second.second >= ndoubles) return it->second.first;
+        if (it != ws.end()) pool.release(it->second.first);
+        double *p = nullptr;
+        *rc = pool.alloc((void **)&p, (ndoubles + 256) * 8);       // +256: the LDS-DMA kernels read whole 128-column panel rows
+        if (*rc) return nullptr;
+        (void)hipMemsetAsync(p, 0, (ndoubles + 256) * 8, st);
+        ws[name] = {p, ndoubles};
+        return p;
+    }
+    ~PAMD_df()
+    {
+        if (ev) (void)hipEventDestroy(ev);
+        if (side) (void)hipStreamDestroy(side);
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+
+namespace {
+
+struct Engine {                            // device tables of one (AO basis, aux basis) pair, alive during PAMD_df_create
+    Shells ao, aux;
+    std::vector<PairClass> pcs, pcs2c;
+    std::vector<AuxClass> acs;
+    double *d_rys = nullptr, *d_c2s = nullptr, *d_ao_xyz = nullptr, *d_aux_xyz = nullptr;
+    int *d_c2s_off = nullptr, *d_ao_ao0 = nullptr, *d_aux_ao0 = nullptr;
+};
+
+int launch_class(const Engine &e, const PairClass &pc, int i0, int i1, const AuxClass &ac, double *T, long ldT, long row_offset,
+                 int tril, const double *shell_xyz, const int *shell_ao0, hipStream_t st)
+{
+    if (i1 <= i0) return 0;
+    PAMD_int3c2e_args a;
+    memset(&a, 0, sizeof(a));
+    a.pair_ish = pc.d_ish + i0;
+    a.pair_jsh = pc.d_jsh + i0;
+    a.pair_pp0 = pc.d_pp0 + i0;
+    a.pair_npp = pc.d_npp + i0;
+    a.pp = pc.d_pp;
+    a.shell_xyz = shell_xyz;
+    a.shell_ao0 = shell_ao0;
+    a.aux_f0 = ac.d_f0;
+    a.aux_xyz = ac.d_xyz;
+    a.aux_exp = ac.d_exp;
+    a.aux_coef = ac.d_coef;
+    a.naux_cls = ac.n;
+    a.npk = ac.npk;
+    a.rys_table = e.d_rys;
+    a.c2s = e.d_c2s;
+    a.c2s_off = e.d_c2s_off;
+    a.T = T;
+    a.ldT = ldT;
+    a.row_offset = row_offset;
+    a.tril = tril;
+    a.npairs = i1 - i0;
+    a.omega = 0.0;
+    return PAMD_int3c2e_class(pc.li, pc.lj, ac.l, &a, st);
+}
+
+void slab_rows(const Shells &ao, int sh0, int sh1, long *r0, long *r1)
+{
+    const long p0 = ao.ao0[sh0], p1 = sh1 < ao.n ? ao.ao0[sh1] : ao.nao;
+    *r0 = p0 * (p0 + 1) / 2;
+    *r1 = p1 * (p1 + 1) / 2;
+}
+
+// M with cderi = M (Q|pq): rows of L^-1 (Cholesky) or (V / sqrt(w))^T over the eigenvalues > lindep (df/incore.py:153-158,
+// 263-270).  Returns M^T as mt[naux][lda] on the host (lda = round_up(nrow, 16), zero padded) and the triangular flag.
+int decompose_metric(PAMD_df *h, RocLib &roc, double *d_j2c, int naux, double lindep, std::vector<double> *mt, int *nrow, int *lda,
+                     int *tri)
+{
+    int rc;
+    if ((rc = roc.open())) return rc;
+    roc.set_stream(roc.handle, h->st);
+    const size_t n2 = (size_t)naux * naux;
+    double *d_a = nullptr;
+    int *d_info = nullptr;
+    if ((rc = h->pool.alloc((void **)&d_a, n2 * 8)) || (rc = h->pool.alloc((void **)&d_info, 64))) return rc;
+    PAMD_CHECK_HIP(hipMemcpyAsync(d_a, d_j2c, n2 * 8, hipMemcpyDeviceToDevice, h->st));
+    // column-major 'upper' Cholesky of the symmetric matrix = row-major lower factor L (A = L L^T) in the same memory
+    PAMD_REQUIRE(roc.dpotrf(roc.handle, ROC_FILL_UPPER, naux, d_a, naux, d_info) == 0, "rocsolver_dpotrf failed");
+    int info = 0;
+    PAMD_CHECK_HIP(hipMemcpyAsync(&info, d_info, 4, hipMemcpyDeviceToHost, h->st));
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+    if (info == 0) {
+        // L^-1 by block forward substitution (the scheme of pyscf_amd/df/incore.py:_tri_inverse_dev): diagonal blocks on the
+        // host, Linv[i, :i] = -Dinv (L[i, :i] Linv[:i, :i]) as two device GEMMs per block row (row-major via swapped operands)
+        const int blk = 512;
+        double *d_inv = nullptr, *d_tmp = nullptr, *d_dinv = nullptr;
+        if ((rc = h->pool.alloc((void **)&d_inv, n2 * 8)) || (rc = h->pool.alloc((void **)&d_tmp, (size_t)blk * naux * 8)) ||
+            (rc = h->pool.alloc((void **)&d_dinv, (size_t)blk * blk * 8)))
+            return rc;
+        PAMD_CHECK_HIP(hipMemsetAsync(d_inv, 0, n2 * 8, h->st));
+        std::vector<double> dblk((size_t)blk * blk), dinv((size_t)blk * blk);
+        const double one = 1.0, zero = 0.0, mone = -1.0;
+        for (int i0 = 0; i0 < naux; i0 += blk) {
+            const int bi = std::min(blk, naux - i0);
+            PAMD_CHECK_HIP(hipMemcpy2DAsync(dblk.data(), (size_t)bi * 8, d_a + (size_t)i0 * naux + i0, (size_t)naux * 8,
+                                            (size_t)bi * 8, bi, hipMemcpyDeviceToHost, h->st));
+            PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+            std::fill(dinv.begin(), dinv.end(), 0.0);
+            for (int c = 0; c < bi; c++) {                       // forward substitution, column c of the inverse
+                dinv[(size_t)c * bi + c] = 1.0 / dblk[(size_t)c * bi + c];
+                for (int r = c + 1; r < bi; r++) {
+                    double s = 0;
+                    for (int k = c; k < r; k++) s += dblk[(size_t)r * bi + k] * dinv[(size_t)k * bi + c];
+                    dinv[(size_t)r * bi + c] = -s / dblk[(size_t)r * bi + r];
+                }
+            }
+            PAMD_CHECK_HIP(hipMemcpyAsync(d_dinv, dinv.data(), (size_t)bi * bi * 8, hipMemcpyHostToDevice, h->st));
+            PAMD_CHECK_HIP(hipMemcpy2DAsync(d_inv + (size_t)i0 * naux + i0, (size_t)naux * 8, d_dinv, (size_t)bi * 8, (size_t)bi * 8,
+                                            bi, hipMemcpyDeviceToDevice, h->st));
+            if (i0) {
+                // tmp (bi x i0) = L[i0:i1, :i0] (bi x i0) * Linv[:i0, :i0]   -> column-major: tmp^T = Linv^T L^T
+                PAMD_REQUIRE(roc.dgemm(roc.handle, ROC_OP_N, ROC_OP_N, i0, bi, i0, &one, d_inv, naux, d_a + (size_t)i0 * naux, naux,
+                                       &zero, d_tmp, i0) == 0, "rocblas_dgemm failed");
+                // Linv[i0:i1, :i0] = -Dinv (bi x bi) * tmp (bi x i0)
+                PAMD_REQUIRE(roc.dgemm(roc.handle, ROC_OP_N, ROC_OP_N, i0, bi, bi, &mone, d_tmp, i0, d_dinv, bi, &zero,
+                                       d_inv + (size_t)i0 * naux, naux) == 0, "rocblas_dgemm failed");
+            }
+            PAMD_CHECK_HIP(hipStreamSynchronize(h->st));         // dinv (host) is reused by the next block
+        }
+        std::vector<double> linv(n2);
+        PAMD_CHECK_HIP(hipMemcpy(linv.data(), d_inv, n2 * 8, hipMemcpyDeviceToHost));
+        *nrow = naux;
+        *lda = (int)std::max<long>(round_up(naux, 16), 16);
+        mt->assign((size_t)naux * *lda, 0.0);
+        for (int m = 0; m < naux; m++)
+            for (int q = 0; q <= m; q++) (*mt)[(size_t)q * *lda + m] = linv[(size_t)m * naux + q];
+        *tri = 1;
+        h->pool.release(d_inv); h->pool.release(d_tmp); h->pool.release(d_dinv);
+    } else {
+        // metric not positive definite: eigen-decomposition, keep w > lindep (pyscf/df/incore.py:263-270)
+        double *d_w = nullptr, *d_e = nullptr;
+        if ((rc = h->pool.alloc((void **)&d_w, (size_t)naux * 8)) || (rc = h->pool.alloc((void **)&d_e, (size_t)naux * 8))) return rc;
+        PAMD_CHECK_HIP(hipMemcpyAsync(d_a, d_j2c, n2 * 8, hipMemcpyDeviceToDevice, h->st));
+        PAMD_REQUIRE(roc.dsyevd(roc.handle, ROC_EVECT_ORIGINAL, ROC_FILL_UPPER, naux, d_a, naux, d_w, d_e, d_info) == 0,
+                     "rocsolver_dsyevd failed");
+        PAMD_CHECK_HIP(hipMemcpyAsync(&info, d_info, 4, hipMemcpyDeviceToHost, h->st));
+        PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+        PAMD_REQUIRE(info == 0, "rocsolver_dsyevd did not converge");
+        std::vector<double> w(naux), v(n2);                       // column-major eigenvectors: row m of the buffer = vector m
+        PAMD_CHECK_HIP(hipMemcpy(w.data(), d_w, (size_t)naux * 8, hipMemcpyDeviceToHost));
+        PAMD_CHECK_HIP(hipMemcpy(v.data(), d_a, n2 * 8, hipMemcpyDeviceToHost));
+        std::vector<int> keep;
+        for (int m = 0; m < naux; m++) if (w[m] > lindep) keep.push_back(m);
+        *nrow = (int)keep.size();
+        *lda = (int)std::max<long>(round_up(*nrow, 16), 16);
+        mt->assign((size_t)naux * *lda, 0.0);
+        for (int j = 0; j < *nrow; j++) {
+            const int m = keep[j];
+            const double f = 1.0 / std::sqrt(w[m]);
+            for (int q = 0; q < naux; q++) (*mt)[(size_t)q * *lda + j] = v[(size_t)m * naux + q] * f;
+        }
+        *tri = 0;
+        h->pool.release(d_w); h->pool.release(d_e);
+    }
+    h->pool.release(d_a);
+    h->pool.release(d_info);
+    return 0;
+}
+
+int build_square_image(PAMD_df *h)
+{
+    // K path on the unpacked image when HBM allows (DF.k_square = 'auto': 48 GB must stay free afterwards)
+    size_t free_b = 0, total_b = 0;
+    PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = ((size_t)h->nL * h->rows * h->rows + 256) * 8;
+    if (h->nL == 0 || need + (48ul << 30) > free_b) return 0;
+    int rc = h->pool.alloc((void **)&h->d_sq, need);
+    if (rc) { h->d_sq = nullptr; return 0; }
+    PAMD_CHECK_HIP(hipMemsetAsync(h->d_sq, 0, need, h->st));
+    return PAMD_unpack_tril(h->d_cderi, h->npair, h->nL, h->nao, h->d_sq, h->rows, h->rows, h->st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int PAMD_df_create(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
+                   double lindep, int device, PAMD_df **out)
+{
+    PAMD_REQUIRE(atm && bas && env && out && natm > 0 && nbas_ao > 0 && nbas_aux > 0 && nenv > 0, "PAMD_df_create: bad arguments");
+    *out = nullptr;
+    PAMD_CHECK_HIP(hipSetDevice(device));
+    PAMD_df *h = new PAMD_df;
+    h->device = device;
+    struct Guard { PAMD_df *p; ~Guard() { delete p; } } guard{h};
+    PAMD_CHECK_HIP(hipStreamCreate(&h->st));
+    PAMD_CHECK_HIP(hipStreamCreate(&h->side));
+    PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+    int rc;
+    Engine e;
+    DevPool tmp;                           // tables and scratch that die with this call
+    e.ao = make_shells(atm, bas, 0, nbas_ao, env);
+    e.aux = make_shells(atm, bas, nbas_ao, nbas_ao + nbas_aux, env);
+    int lmax_ao = 0, lmax_aux = 0;
+    for (int l : e.ao.l) lmax_ao = std::max(lmax_ao, l);
+    for (int l : e.aux.l) lmax_aux = std::max(lmax_aux, l);
+    PAMD_REQUIRE(lmax_ao <= 4 && lmax_aux <= LMAX_TAB && !(lmax_aux > 5 && lmax_ao > 3), "angular momentum beyond the instantiated kernels");
+    h->nao = e.ao.nao;
+    h->naux = e.aux.nao;
+    h->npair = (long)h->nao * (h->nao + 1) / 2;
+    h->rows = (int)round_up(h->nao, 16);
+    const int naux = h->naux;
+    // Rys table, cart->sph matrices, shell coordinates
+    if ((rc = tmp.alloc((void **)&e.d_rys, (size_t)PAMD_rys_table_len() * 8))) return rc;
+    if ((rc = PAMD_rys_table_upload(e.d_rys, h->st))) return rc;
+    std::vector<double> c2s;
+    std::vector<int> c2s_off;
+    for (int l = 0; l <= LMAX_TAB; l++) {
+        c2s_off.push_back((int)c2s.size());
+        std::vector<double> m = c2s_matrix(l);
+        c2s.insert(c2s.end(), m.begin(), m.end());
+    }
+    if ((rc = upload(tmp, c2s, &e.d_c2s)) || (rc = upload(tmp, c2s_off, &e.d_c2s_off)) || (rc = upload(tmp, e.ao.xyz, &e.d_ao_xyz)) ||
+        (rc = upload(tmp, e.ao.ao0, &e.d_ao_ao0)) || (rc = upload(tmp, e.aux.xyz, &e.d_aux_xyz)) ||
+        (rc = upload(tmp, e.aux.ao0, &e.d_aux_ao0)))
+        return rc;
+    for (int li = 0; li <= lmax_ao; li++)
+        for (int lj = 0; lj <= li; lj++) {
+            PairClass pc;
+            if ((rc = make_pair_class(tmp, e.ao, li, lj, &pc))) return rc;
+            if (pc.n) e.pcs.push_back(pc);
+        }
+    for (int l = 0; l <= lmax_aux; l++) {
+        AuxClass ac;
+        if ((rc = make_aux_class(tmp, e.aux, l, &ac))) return rc;
+        if (ac.n) e.acs.push_back(ac);
+        PairClass pc;
+        if ((rc = make_pair_class_2c(tmp, e.aux, l, 1.0 / c2s[c2s_off[0]], &pc))) return rc;
+        if (pc.n) e.pcs2c.push_back(pc);
+    }
+    // metric (P|Q)
+    double *d_j2c = nullptr;
+    if ((rc = tmp.alloc((void **)&d_j2c, (size_t)naux * naux * 8))) return rc;
+    PAMD_CHECK_HIP(hipMemsetAsync(d_j2c, 0, (size_t)naux * naux * 8, h->st));
+    for (const PairClass &pc : e.pcs2c)
+        for (const AuxClass &ac : e.acs)
+            if ((rc = launch_class(e, pc, 0, pc.n, ac, d_j2c, naux, 0, 0, e.d_aux_xyz, e.d_aux_ao0, h->st))) return rc;
+    {
+        // symmetrise on the host: (j2c + j2c^T) / 2 as pyscf_amd/df/incore.py does before the factorisation
+        std::vector<double> j((size_t)naux * naux);
+        PAMD_CHECK_HIP(hipMemcpyAsync(j.data(), d_j2c, j.size() * 8, hipMemcpyDeviceToHost, h->st));
+        PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+        for (int a = 0; a < naux; a++)
+            for (int b = 0; b < a; b++) {
+                const double v = 0.5 * (j[(size_t)a * naux + b] + j[(size_t)b * naux + a]);
+                j[(size_t)a * naux + b] = j[(size_t)b * naux + a] = v;
+            }
+        PAMD_CHECK_HIP(hipMemcpy(d_j2c, j.data(), j.size() * 8, hipMemcpyHostToDevice));
+    }
+    std::vector<double> mt;
+    int nrow = 0, lda = 0, tri = 0;
+    {
+        RocLib roc;
+        if ((rc = decompose_metric(h, roc, d_j2c, naux, lindep, &mt, &nrow, &lda, &tri))) return rc;
+    }
+    tmp.release(d_j2c);
+    h->nL = nrow;
+    double *d_mt = nullptr;
+    if ((rc = upload(tmp, mt, &d_mt))) return rc;
+    mt.clear();
+    mt.shrink_to_fit();
+    // the tensor, AO-row slab by slab (df/incore.py:189-217)
+    size_t free_b = 0, total_b = 0;
+    PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t tensor_b = (size_t)h->nL * h->npair * 8;
+    size_t slab_bytes = std::min<size_t>(24ul << 30, (size_t)h->npair * naux * 8);
+    if (tensor_b + slab_bytes + (1ul << 30) > free_b) {
+        snprintf(g_errmsg, sizeof(g_errmsg), "PAMD_df_create: the tensor (%.1f GB) + slab work space (%.1f GB) do not fit the %.1f GB "
+                 "of free HBM", tensor_b * 1e-9, slab_bytes * 1e-9, free_b * 1e-9);
+        return -2;
+    }
+    if ((rc = h->pool.alloc((void **)&h->d_cderi, tensor_b))) return rc;
+    const long max_rows = std::max<long>((long)(slab_bytes / ((size_t)naux * 8)), 1);
+    std::vector<std::pair<int, int>> slabs;
+    long bufrows = 0;
+    for (int sh0 = 0; sh0 < e.ao.n;) {
+        int sh1 = sh0 + 1;
+        long r0, r1;
+        while (sh1 < e.ao.n) {
+            slab_rows(e.ao, sh0, sh1 + 1, &r0, &r1);
+            if (r1 - r0 > max_rows) break;
+            sh1++;
+        }
+        slab_rows(e.ao, sh0, sh1, &r0, &r1);
+        bufrows = std::max(bufrows, r1 - r0);
+        slabs.push_back({sh0, sh1});
+        sh0 = sh1;
+    }
+    double *d_T = nullptr;
+    if ((rc = tmp.alloc((void **)&d_T, (size_t)bufrows * naux * 8))) return rc;
+    for (auto &sl : slabs) {
+        long r0, r1;
+        slab_rows(e.ao, sl.first, sl.second, &r0, &r1);
+        PAMD_CHECK_HIP(hipMemsetAsync(d_T, 0, (size_t)(r1 - r0) * naux * 8, h->st));
+        for (const PairClass &pc : e.pcs) {
+            int i0, i1;
+            pc.subrange(sl.first, sl.second, &i0, &i1);
+            for (const AuxClass &ac : e.acs)
+                if ((rc = launch_class(e, pc, i0, i1, ac, d_T, naux, r0, 1, e.d_ao_xyz, e.d_ao_ao0, h->st))) return rc;
+        }
+        if ((rc = PAMD_cderi_solve(d_mt, lda, d_T, naux, h->d_cderi + r0, h->npair, h->nL, r1 - r0, naux, 0, tri, h->st))) return rc;
+    }
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+    tmp.release(d_T);
+    tmp.release(d_mt);
+    if ((rc = build_square_image(h))) return rc;
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+    guard.p = nullptr;
+    *out = h;
+    return 0;
+}
+
+void PAMD_df_destroy(PAMD_df *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    delete h;
+}
+
+int PAMD_df_naux(const PAMD_df *h, int *naux)
+{
+    PAMD_REQUIRE(h && naux, "null handle");
+    *naux = h->nL;
+    return 0;
+}
+
+int PAMD_df_nao(const PAMD_df *h, int *nao)
+{
+    PAMD_REQUIRE(h && nao, "null handle");
+    *nao = h->nao;
+    return 0;
+}
+
+int PAMD_df_export_cderi(PAMD_df *h, int l0, int l1, double *out)
+{
+    PAMD_REQUIRE(h && out && 0 <= l0 && l0 <= l1 && l1 <= h->nL, "PAMD_df_export_cderi: bad row range");
+    PAMD_CHECK_HIP(hipSetDevice(h->device));
+    PAMD_CHECK_HIP(hipMemcpy(out, h->d_cderi + (size_t)l0 * h->npair, (size_t)(l1 - l0) * h->npair * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// dm   [nset][nao][nao] host, f64, C order.
+// orbo nullable.  Not NULL: the occupied orbitals scaled by sqrt(occ), set after set, each (nao, nocc[s]) C order (row = AO) -
+//      K comes from the MO branch (df_jk.py:339-381).  NULL: general-DM branch (df_jk.py:382-408), hermi is then ignored for K.
+// flags bit 0: the caller guarantees dm[s] = orbo_s orbo_s^T (what make_rdm1 builds) - the first J pass then comes out of the
+//      half transform's epilogue instead of a pass over the tensor.
+// vj, vk caller-owned [nset][nao][nao] (NULL with with_j / with_k = 0).
+int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
+                   int with_k, int flags, double *vj, double *vk)
+{
+    (void)hermi;
+    PAMD_REQUIRE(h && dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
+    PAMD_REQUIRE((!with_j || vj) && (!with_k || vk) && (with_j || with_k), "PAMD_df_get_jk: output pointers");
+    PAMD_REQUIRE(!orbo || nocc, "PAMD_df_get_jk: orbo needs nocc[nset]");
+    PAMD_CHECK_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->st;
+    int rc;
+    const long npair = h->npair;
+    const int nL = h->nL, ldx = h->rows, rows = h->rows;
+    const size_t n2 = (size_t)nao * nao;
+    double *d_dm = h->workspace("dm", (size_t)nset * n2, &rc);
+    if (rc) return rc;
+    PAMD_CHECK_HIP(hipMemcpyAsync(d_dm, dm, (size_t)nset * n2 * 8, hipMemcpyHostToDevice, st));
+    double *d_vjt = nullptr, *d_vk = nullptr, *d_rho = nullptr;
+    if (with_j) {
+        d_vjt = h->workspace("vjtril", (size_t)nset * npair, &rc);
+        if (rc) return rc;
+        PAMD_CHECK_HIP(hipMemsetAsync(d_vjt, 0, (size_t)nset * npair * 8, st));
+        d_rho = h->workspace("rho", (size_t)nset * std::max(nL, 1), &rc);
+        if (rc) return rc;
+        PAMD_CHECK_HIP(hipMemsetAsync(d_rho, 0, (size_t)nset * std::max(nL, 1) * 8, st));
+    }
+    const bool fused = with_j && with_k && orbo && (flags & 1) && nL > 0;
+    if (with_j && !fused && nL > 0) {
+        for (int s0 = 0; s0 < nset; s0 += 4) {
+            const int ns = std::min(4, nset - s0);
+            double *d_dt = h->workspace("dmtril", (size_t)4 * npair, &rc);
+            if (rc) return rc;
+            if ((rc = PAMD_pack_dm_tril(d_dm + (size_t)s0 * n2, ns, nao, d_dt, st))) return rc;
+            const long wlen = PAMD_df_vj_pass1_worksize(npair, nL, ns);
+            double *d_w = h->workspace("vj1work", (size_t)std::max<long>(wlen, 1), &rc);
+            if (rc) return rc;
+            if ((rc = PAMD_df_vj_pass1(h->d_cderi, npair, nL, d_dt, ns, d_rho + (size_t)s0 * nL, d_w, st))) return rc;
+            if ((rc = PAMD_df_vj_pass2(h->d_cderi, npair, nL, d_rho + (size_t)s0 * nL, ns, d_vjt + (size_t)s0 * npair, st))) return rc;
+        }
+    }
+    if (with_k) {
+        d_vk = h->workspace("vk", (size_t)nset * n2, &rc);
+        if (rc) return rc;
+        PAMD_CHECK_HIP(hipMemsetAsync(d_vk, 0, (size_t)nset * n2 * 8, st));
+        const int nsplit = 4;
+        const size_t budget = 8ul << 30;
+        const double *op = orbo;
+        for (int s = 0; s < nset && nL > 0; s++) {
+            double *d_part = h->workspace("kpart", (size_t)nsplit * n2, &rc);
+            if (rc) return rc;
+            PAMD_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nsplit * n2 * 8, st));
+            if (orbo) {
+                // ---- MO branch: X_L = B_L C~, K += X^T X (df_jk.py:353-380)
+                const int no = nocc[s];
+                const double *o_s = op;
+                op += (size_t)nao * no;
+                if (no == 0) continue;
+                const int nocc_pad = (int)round_up(no, 16);
+                long ldo = nocc_pad > 160 ? round_up(nocc_pad, 160) : nocc_pad;       // df_jk.pad_orbitals
+                const int mt = nocc_pad / 16, nchunk = (mt + 9) / 10;
+                ldo = std::max<long>(ldo, (long)nchunk * (((mt + nchunk - 1) / nchunk + 1) / 2) * 32);
+                ldo = std::max<long>(ldo, std::min(round_up(nocc_pad, 160), round_up(nocc_pad, 128)));
+                std::vector<double> oh((size_t)rows * ldo, 0.0);
+                for (int p = 0; p < nao; p++)
+                    for (int i = 0; i < no; i++) oh[(size_t)p * ldo + i] = o_s[(size_t)p * no + i];
+                double *d_orb = h->workspace("orb", (size_t)rows * ldo, &rc);
+                if (rc) return rc;
+                PAMD_CHECK_HIP(hipMemcpyAsync(d_orb, oh.data(), oh.size() * 8, hipMemcpyHostToDevice, st));
+                PAMD_CHECK_HIP(hipStreamSynchronize(st));                      // oh goes out of scope
+                long blk = std::max<long>(1, (long)(budget / ((size_t)nocc_pad * ldx * 8)));
+                blk = std::min<long>(blk, nL);
+                const long nblk = (nL + blk - 1) / blk;
+                blk = (nL + nblk - 1) / nblk;
+                double *d_X = h->workspace("X", (size_t)blk * nocc_pad * ldx, &rc);
+                if (rc) return rc;
+                double *d_rw = nullptr;
+                if (fused) {
+                    d_rw = h->workspace("rho_work", (size_t)std::max<long>(PAMD_nr_e2_rho_worksize((int)blk, ldx, nocc_pad), 1), &rc);
+                    if (rc) return rc;
+                }
+                for (long b0 = 0; b0 < nL; b0 += blk) {
+                    const int nb = (int)std::min<long>(blk, nL - b0);
+                    double *rho_b = fused ? d_rho + (size_t)s * nL + b0 : nullptr;
+                    if (h->d_sq)
+                        rc = PAMD_nr_e2_square(h->d_sq + (size_t)b0 * rows * rows, rows, rows, nb, nao, d_orb, (int)ldo, rows, nocc_pad,
+                                               d_X, ldx, rho_b, d_rw, st);
+                    else
+                        rc = PAMD_nr_e2_symm(h->d_cderi + (size_t)b0 * npair, npair, nb, nao, d_orb, (int)ldo, rows, nocc_pad, d_X, ldx,
+                                             rho_b, d_rw, st);
+                    if (rc) return rc;
+                    if (fused) {
+                        // second J pass of this block on the side stream, behind the block's SYRK (HBM-bound beside MFMA-bound)
+                        PAMD_CHECK_HIP(hipEventRecord(h->ev, st));
+                        PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev, 0));
+                        if ((rc = PAMD_df_vj_pass2(h->d_cderi + (size_t)b0 * npair, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side)))
+                            return rc;
+                    }
+                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, d_part, nao, nao, nao, (long)nb * nocc_pad, 1 | 2, nsplit, st))) return rc;
+                    if (fused) {
+                        // the next block's half transform overwrites nothing the side stream reads (rho_b, cderi): no wait here
+                    }
+                }
+                if ((rc = PAMD_reduce_splits(d_part, nsplit, nao, nao, d_vk + (size_t)s * n2, nao, 1, st))) return rc;
+            } else {
+                // ---- general-DM branch: T_L = B_L D, K = sum_L T_L^T B_L (df_jk.py:382-407)
+                const long ldo = rows > 160 ? round_up(rows, 160) : rows;
+                double *d_orb = h->workspace("orb_dm", (size_t)rows * ldo, &rc);
+                if (rc) return rc;
+                PAMD_CHECK_HIP(hipMemsetAsync(d_orb, 0, (size_t)rows * ldo * 8, st));
+                PAMD_CHECK_HIP(hipMemcpy2DAsync(d_orb, (size_t)ldo * 8, d_dm + (size_t)s * n2, (size_t)nao * 8, (size_t)nao * 8, nao,
+                                                hipMemcpyDeviceToDevice, st));
+                long blk = std::max<long>(1, (long)(budget / ((size_t)rows * ldx * 8)));
+                blk = std::min<long>(blk, nL);
+                long nblk = (nL + blk - 1) / blk;
+                blk = std::max<long>(1, ((nL + nblk - 1) / nblk) / 2);
+                double *d_X = h->workspace("X", (size_t)blk * rows * ldx, &rc);
+                if (rc) return rc;
+                double *d_full = h->workspace("full", (size_t)blk * rows * ldx, &rc);
+                if (rc) return rc;
+                PAMD_CHECK_HIP(hipMemsetAsync(d_full, 0, (size_t)blk * rows * ldx * 8, st));
+                for (long b0 = 0; b0 < nL; b0 += blk) {
+                    const int nb = (int)std::min<long>(blk, nL - b0);
+                    const double *sub = h->d_cderi + (size_t)b0 * npair;
+                    if ((rc = PAMD_nr_e2_symm(sub, npair, nb, nao, d_orb, (int)ldo, rows, rows, d_X, ldx, nullptr, nullptr, st))) return rc;
+                    if ((rc = PAMD_unpack_tril(sub, npair, nb, nao, d_full, ldx, rows, st))) return rc;
+                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_full, ldx, d_part, nao, nao, nao, (long)nb * rows, 0 | 2, nsplit, st))) return rc;
+                }
+                if ((rc = PAMD_reduce_splits(d_part, nsplit, nao, nao, d_vk + (size_t)s * n2, nao, 0, st))) return rc;
+            }
+        }
+    }
+    if (fused) {
+        PAMD_CHECK_HIP(hipEventRecord(h->ev, h->side));
+        PAMD_CHECK_HIP(hipStreamWaitEvent(st, h->ev, 0));
+    }
+    if (with_j) {
+        double *d_vj = h->workspace("vjfull", (size_t)nset * n2, &rc);
+        if (rc) return rc;
+        if ((rc = PAMD_unpack_tril(d_vjt, npair, nset, nao, d_vj, nao, nao, st))) return rc;
+        PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vj, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
+    }
+    if (with_k) PAMD_CHECK_HIP(hipMemcpyAsync(vk, d_vk, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
+    PAMD_CHECK_HIP(hipStreamSynchronize(st));
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->side));
+    return 0;
+}
+
+}  // extern "C"

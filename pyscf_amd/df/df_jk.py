@@ -446,6 +446,7 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                     # GEMM in the hot loop); otherwise a random-vector probe D v = C (C^T v) decides - two GEMVs and one
                     # scalar read-back instead of the nao^2 nocc product; PAMD_DEBUG_CHECK_DM=1 restores the full comparison.
                     fused = dm_from_orbitals is None and _dm_matches_orbitals(dms_dev, orb_list, nao)
+                dfobj._last_fused = bool(fused)
                 if fused:
                     # pass 1 comes out of the half transform (PAMD_nr_e2_square); pass 2 of each K block follows on
                     # the side stream behind that block's SYRK

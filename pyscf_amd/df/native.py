@@ -1,0 +1,160 @@
+"""numpy-only client of the host-array C ABI (include/pyscf_amd.h: PAMD_df_create / PAMD_df_get_jk / PAMD_df_export_cderi).
+
+This is the binding a PySCF maintainer would write: ctypes on raw numpy buffers, the caller owns every array, no torch, no
+device pointers in Python - the same convention as the reference's own C calls (pyscf/df/df_jk.py:373-379).  ``NativeDF``
+duck-types the part of ``pyscf.df.DF`` that ``_DFHF.get_jk`` uses (``get_jk``, ``get_naoaux``, ``loop``, ``build``, ``reset``,
+pyscf/df/df.py:147-267), so ``mf.with_df = NativeDF(mol)`` works with any object that has libcint-format ``_atm/_bas/_env``.
+
+(The torch-resident ``pyscf_amd.df.DF`` stays the production object: it shards over ranks, keeps results on the device for
+the HBM-resident SCF loop, and shares the stream with the XC path.  This one exists for callers without a device runtime.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_c = ctypes
+_lib = None
+
+
+def load():
+    """libpyscf_amd.so loaded WITHOUT importing torch (the HIP runtime is then the system one the library links by SONAME)."""
+    global _lib
+    if _lib is None:
+        here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        so = os.environ.get('PAMD_LIBRARY') or os.path.join(here, 'lib', 'libpyscf_amd.so')
+        if not os.path.exists(so):
+            raise ImportError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"`' % so)
+        lib = _c.CDLL(so)
+        lib.PAMD_last_error.restype = _c.c_char_p
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError('libpyscf_amd call failed (%d): %s' % (rc, load().PAMD_last_error().decode()))
+
+
+def _conc_env(atm1, bas1, env1, atm2, bas2, env2):
+    """gto.conc_env (pyscf/gto/mole.py:805-838): one atm / bas / env holding both molecules, pointers of the second shifted."""
+    off = len(env1)
+    natm_off = len(atm1)
+    atm2 = np.array(atm2, dtype=np.int32, copy=True)
+    bas2 = np.array(bas2, dtype=np.int32, copy=True)
+    atm2[:, 1] += off          # PTR_COORD
+    atm2[:, 3] += off          # PTR_ZETA
+    bas2[:, 0] += natm_off     # ATOM_OF
+    bas2[:, 5] += off          # PTR_EXP
+    bas2[:, 6] += off          # PTR_COEFF
+    return (np.ascontiguousarray(np.vstack((atm1, atm2)), dtype=np.int32), np.ascontiguousarray(np.vstack((bas1, bas2)), dtype=np.int32),
+            np.ascontiguousarray(np.hstack((env1, env2)), dtype=np.float64))
+
+
+class NativeDF:
+    blockdim = 240
+
+    def __init__(self, mol, auxbasis=None, auxmol=None, device=0, lindep=1e-7):
+        self.mol = mol
+        self.auxbasis = auxbasis
+        self.auxmol = auxmol
+        self.device = device
+        self.lindep = lindep
+        self._h = None
+        self._naux = None
+
+    def build(self):
+        if self._h is not None:
+            return self
+        if self.auxmol is None:
+            from . import addons                  # host-only: basis tables (any object with _atm/_bas/_env works as auxmol)
+            self.auxmol = addons.make_auxmol(self.mol, self.auxbasis)
+        mol, aux = self.mol, self.auxmol
+        atm, bas, env = _conc_env(np.asarray(mol._atm), np.asarray(mol._bas), np.asarray(mol._env),
+                                  np.asarray(aux._atm), np.asarray(aux._bas), np.asarray(aux._env))
+        h = _c.c_void_p()
+        _check(load().PAMD_df_create(atm.ctypes.data_as(_c.c_void_p), _c.c_int(len(atm)), bas.ctypes.data_as(_c.c_void_p),
+                                     _c.c_int(len(mol._bas)), _c.c_int(len(aux._bas)), env.ctypes.data_as(_c.c_void_p),
+                                     _c.c_int(len(env)), _c.c_double(self.lindep), _c.c_int(self.device), _c.byref(h)))
+        self._h = h
+        n = _c.c_int()
+        _check(load().PAMD_df_naux(h, _c.byref(n)))
+        self._naux = n.value
+        _check(load().PAMD_df_nao(h, _c.byref(n)))
+        self.nao = n.value
+        return self
+    kernel = build
+
+    def reset(self, mol=None):
+        if self._h is not None:
+            load().PAMD_df_destroy(self._h)
+        self._h = None
+        self._naux = None
+        if mol is not None:
+            self.mol = mol
+            self.auxmol = None
+        return self
+
+    def __del__(self):
+        try:
+            self.reset()
+        except Exception:
+            pass
+
+    def get_naoaux(self):
+        self.build()
+        return self._naux
+
+    def loop(self, blksize=None):
+        self.build()
+        blksize = blksize or self.blockdim
+        npair = self.nao * (self.nao + 1) // 2
+        for b0 in range(0, self._naux, blksize):
+            b1 = min(b0 + blksize, self._naux)
+            out = np.empty((b1 - b0, npair))
+            _check(load().PAMD_df_export_cderi(self._h, _c.c_int(b0), _c.c_int(b1), out.ctypes.data_as(_c.c_void_p)))
+            yield out
+
+    def get_jk(self, dm, hermi=1, with_j=True, with_k=True, direct_scf_tol=1e-13, omega=None):
+        if omega:
+            raise NotImplementedError('range-separated tensors: use pyscf_amd.df.DF')
+        self.build()
+        dms = np.asarray(dm)
+        if np.iscomplexobj(dms):
+            vjr, vkr = self.get_jk(dms.real, 0, with_j, with_k)
+            vji, vki = self.get_jk(dms.imag, 0, with_j, with_k)
+            return (vjr + 1j * vji if with_j else None), (vkr + 1j * vki if with_k else None)
+        shape = dms.shape
+        nao = shape[-1]
+        dms = np.ascontiguousarray(dms.reshape(-1, nao, nao), dtype=np.float64)
+        nset = len(dms)
+        orbo = nocc = None
+        flags = 0
+        mo_coeff = getattr(dm, 'mo_coeff', None)
+        if with_k and mo_coeff is not None:
+            mo_coeff = np.asarray(mo_coeff)
+            mo_occ = np.asarray(dm.mo_occ)
+            nmo = mo_occ.shape[-1]
+            mo_coeff = mo_coeff.reshape(-1, nao, nmo)
+            mo_occ = mo_occ.reshape(-1, nmo)
+            if mo_occ.shape[0] * 2 == nset:            # ROHF-style DM (df_jk.py:346-351)
+                mo_coeff = np.vstack((mo_coeff, mo_coeff))
+                mo_occ = np.vstack((np.array(mo_occ > 0, dtype=np.double), np.array(mo_occ == 2, dtype=np.double)))
+            blocks = [np.ascontiguousarray(mo_coeff[k][:, mo_occ[k] > 0] * np.sqrt(mo_occ[k][mo_occ[k] > 0])) for k in range(nset)]
+            nocc = np.array([b.shape[1] for b in blocks], dtype=np.int32)
+            orbo = np.concatenate([b.ravel() for b in blocks]) if nocc.sum() else np.zeros(1)
+            # dm == orbo orbo^T ?  (two matrix-vector products per density; the tag of this package's make_rdm1 promises it)
+            ok = getattr(dm, 'dm_from_orbitals', None)
+            if ok is None:
+                v = np.random.RandomState(20240601).random_sample(nao) - 0.5
+                ok = all(np.abs(dms[k].dot(v) - blocks[k].dot(blocks[k].T.dot(v))).max() <= 1e-10 * max(1.0, np.abs(dms[k].dot(v)).max())
+                         for k in range(nset))
+            flags = 1 if ok else 0
+        vj = np.empty_like(dms) if with_j else None
+        vk = np.empty_like(dms) if with_k else None
+        _check(load().PAMD_df_get_jk(
+            self._h, dms.ctypes.data_as(_c.c_void_p), orbo.ctypes.data_as(_c.c_void_p) if orbo is not None else None,
+            nocc.ctypes.data_as(_c.c_void_p) if nocc is not None else None, _c.c_int(nset), _c.c_int(nao), _c.c_int(hermi),
+            _c.c_int(int(with_j)), _c.c_int(int(with_k)), _c.c_int(flags),
+            vj.ctypes.data_as(_c.c_void_p) if with_j else None, vk.ctypes.data_as(_c.c_void_p) if with_k else None))
+        return (vj.reshape(shape) if with_j else None), (vk.reshape(shape) if with_k else None)

@@ -185,6 +185,8 @@ class _Veff:
                 t0 = time.perf_counter()
                 mf.grids.build()
                 mf._log('setting up grids: %d points, %.2f s', mf.grids.size, time.perf_counter() - t0)
+        if mf.with_df._cderi_dev is None:        # (a pure functional's first J may have gone the integral-direct way)
+            mf.with_df.build()
         self.t_jk = self.t_xc = 0.0
 
     def build(self, dm, orbo):
@@ -238,9 +240,10 @@ def kernel_device(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, conv_check=T
     h1e_h = mf.get_hcore(mol)
     dm_h = mf.get_init_guess(mol, mf.init_guess, s1e=s1e_h) if dm0 is None else dm0
     # the first Fock build goes through the public host API: the start density may be anything (untagged, any rank)
+    t_setup = time.perf_counter()
     vhf_h = mf.get_veff(mol, dm_h)
     e_tot = mf.energy_tot(dm_h, h1e_h, vhf_h)
-    mf._log('init E= %.15g', e_tot)
+    mf._log('init E= %.15g  (first Fock build incl. tensor / grid set-up: %.2f s)', e_tot, time.perf_counter() - t_setup)
     enuc = mf.energy_nuc()
     s = torch.from_numpy(np.ascontiguousarray(s1e_h)).to(dev)
     h = torch.from_numpy(np.ascontiguousarray(h1e_h)).to(dev)

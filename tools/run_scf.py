@@ -7,7 +7,7 @@ from pyscf_amd import gto, scf, dft
 from pyscf_amd.data import clusters
 ap = argparse.ArgumentParser()
 ap.add_argument('--nwater', type=int, default=32)
-ap.add_argument('--basis', default='cc-pvtz')
+ap.add_argument('--basis', default=None, help='default: cc-pvtz (water), def2-tzvp (taxol)')
 ap.add_argument('--xc', default='b3lyp')
 ap.add_argument('--conv-tol', type=float, default=1e-9)
 ap.add_argument('--molecule', default='water', choices=['water', 'taxol'])
@@ -16,6 +16,8 @@ ap.add_argument('--max-cycle', type=int, default=50)
 ap.add_argument('--dump-orbitals', default='', help='.npz: orbo = C_occ sqrt(occ) and e_tot of the converged state (input of tools/gen_golden_streaming.py)')
 ap.add_argument('--host-loop', action='store_true', help='the numpy SCF loop instead of the HBM-resident one')
 a = ap.parse_args()
+if a.basis is None:
+    a.basis = 'def2-tzvp' if a.molecule == 'taxol' else 'cc-pvtz'
 mol = gto.M(atom=clusters.taxol() if a.molecule == 'taxol' else clusters.water_cluster(a.nwater), basis=a.basis, verbose=4)
 mf = (dft.RKS(mol, xc=a.xc) if a.xc else scf.RHF(mol)).density_fit()
 mf.conv_tol = a.conv_tol
