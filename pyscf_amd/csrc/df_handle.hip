@@ -296,7 +296,7 @@ struct RocLib {
         PAMD_REQUIRE(create(&handle) == 0, "rocblas_create_handle failed");
         return 0;
     }
-    ~RocLib() { if (handle && destroy) destroy(handle); }
+    // (the process-wide instance is never destroyed: at exit the HIP runtime may already be gone)
 };
 constexpr int ROC_OP_N = 111, ROC_FILL_UPPER = 121, ROC_EVECT_ORIGINAL = 211;
 
@@ -571,7 +571,7 @@ int PAMD_df_create(const int *atm, int natm, const int *bas, int nbas_ao, int nb
     std::vector<double> mt;
     int nrow = 0, lda = 0, tri = 0;
     {
-        RocLib roc;
+        static RocLib roc;                 // one rocBLAS handle per process (creating one loads the library's kernels: seconds)
         if ((rc = decompose_metric(h, roc, d_j2c, naux, lindep, &mt, &nrow, &lda, &tri))) return rc;
     }
     tmp.release(d_j2c);
@@ -709,7 +709,10 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
         d_vk = h->workspace("vk", (size_t)nset * n2, &rc);
         if (rc) return rc;
         PAMD_CHECK_HIP(hipMemsetAsync(d_vk, 0, (size_t)nset * n2 * 8, st));
-        const int nsplit = 4;
+        // SYRK plan of df_jk.syrk_plan: balanced k split (flag 4) when the tiles leave workgroup slots free
+        const int ntl = ((nao + 127) / 128) * ((nao + 127) / 128 + 1) / 2, nfull = ntl < 32 ? 4 : std::min(4, std::max(1, 512 / ntl));
+        const bool bal = ntl >= 32 && ntl * nfull < 512;
+        const int nsplit = bal ? nfull + 1 : nfull, syrk_flags = bal ? (1 | 2 | 4) : (1 | 2);
         const size_t budget = 8ul << 30;
         const double *op = orbo;
         for (int s = 0; s < nset && nL > 0; s++) {
@@ -762,7 +765,7 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
                         if ((rc = PAMD_df_vj_pass2(h->d_cderi + (size_t)b0 * npair, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side)))
                             return rc;
                     }
-                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, d_part, nao, nao, nao, (long)nb * nocc_pad, 1 | 2, nsplit, st))) return rc;
+                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, d_part, nao, nao, nao, (long)nb * nocc_pad, syrk_flags, nsplit, st))) return rc;
                     if (fused) {
                         // the next block's half transform overwrites nothing the side stream reads (rho_b, cderi): no wait here
                     }

@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
 // 128 x 128 tile of C[split] += A^T B (all tiles, or the lower-triangular ones of the SYRK), v2 DMA scheme
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
-    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, int nsplit)
+    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, long kchunk)
 {
     const int bsplit = blockIdx.y, btile = blockIdx.x;
     constexpr int PA = KB * LDN;
@@ -828,9 +828,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
         tn = btile - tm * ntile_n;
     }
     const int p0 = tm * NT, q0 = tn * NT;
-    const long kchunk = ((kdim + nsplit - 1) / nsplit + KB - 1) / KB * KB;
-    const long kbeg = (long)bsplit * kchunk;
-    const long kend = (kbeg + kchunk < kdim) ? kbeg + kchunk : kdim;
+    // k range of this split: `kchunk` rows each, the LAST split takes what is left (uniform splits: about the same; balanced
+    // SYRK: a short remainder piece, see dgemm_tn_impl)
+    long kbeg = (long)bsplit * kchunk;
+    if (kbeg > kdim) kbeg = kdim;
+    const long kend = (kbeg + kchunk < kdim && bsplit + 1 < (int)gridDim.y) ? kbeg + kchunk : kdim;
     const int nk = (int)(kend - kbeg);                 // rows of this split: row offsets stay below 4 GiB (launcher)
     const __amdgpu_buffer_rsrc_t r_a = make_rsrc(A + kbeg * lda + p0);
     const __amdgpu_buffer_rsrc_t r_b = make_rsrc(B + kbeg * ldb + q0);
@@ -982,6 +984,8 @@ static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: 
 static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
 static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
+static int g_syrk_frac = 1;   // balanced SYRK: full pieces + one short remainder piece per tile (dgemm_tn_impl)
+static int g_num_cu = 256;    // MI355X
 static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
 
 extern "C" {
@@ -992,6 +996,8 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "glds") == 0) { g_use_glds = value; return 0; }
     if (strcmp(key, "gemmwide") == 0) { g_gemm_wide = value; return 0; }
     if (strcmp(key, "dmav2") == 0) { g_dma_v2 = value; return 0; }
+    if (strcmp(key, "syrkfrac") == 0) { g_syrk_frac = value; return 0; }
+    if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
     if (strcmp(key, "pairtail") == 0) { g_pair_tail = value; return 0; }
@@ -1254,7 +1260,7 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
     hipStream_t st = (hipStream_t)stream;
     // flags bit 1 (value 2): caller guarantees 160 readable doubles from every row start and
     // k ranges that are multiples of 16 -> LDS-DMA kernel
-    const long kchunk = ((k + nsplit - 1) / nsplit + KB - 1) / KB * KB;
+    long kchunk = ((k + nsplit - 1) / nsplit + KB - 1) / KB * KB;
     const bool aligned = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)d_A | (uintptr_t)d_B) % 16 == 0) &&
                          (k % KB == 0) && (kchunk % KB == 0);
     const bool glds = (lower_only & 2) && aligned && (g_use_glds || d_maskA);
@@ -1267,8 +1273,27 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
     dim3 grid(ntiles, nsplit);
     const bool v2 = glds && g_dma_v2 && !wide && d_maskA == nullptr &&
                     (kchunk + KB) * (long)((lda > ldb) ? lda : ldb) * 8 < (1L << 32);
-    if (v2)
-        gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, nsplit);
+    if (v2) {
+        // Balanced SYRK (flag 4, nsplit >= 2): the grid of U tiles x s uniform splits fills U s of the chip's 2 x 256 workgroup
+        // slots and every slot runs K / s rows - at nao = 1856: 120 x 4 = 480 of 512 slots, 32 idle for the whole launch.
+        // Instead: nsplit - 1 FULL pieces of kchunk rows per tile plus one SHORT remainder piece of <= kchunk / mfrac rows,
+        // dispatched last (blockIdx.y = nsplit - 1): the U short pieces run mfrac-deep one after the other in the
+        // 512 - U (nsplit - 1) slots the full pieces leave free, and the launch ends after kchunk = K mfrac / ((nsplit - 1)
+        // mfrac + 1) rows instead of K / (nsplit - 1): 4.25 instead of 4 effective splits at nao = 1856 (-6 %).  Every piece
+        // still walks its k range from the start, in step with the others of its split (L2 reuse of the X row panels).
+        if ((lower_only & 4) && g_syrk_frac && nsplit >= 2) {
+            const long slots = 2L * g_num_cu, full = (long)ntiles * (nsplit - 1);
+            long mfrac = 0;                      // smallest depth that fits = longest admissible short piece
+            for (long mm = 1; mm <= 64; mm++)
+                if (full + (ntiles + mm - 1) / mm <= slots) { mfrac = mm; break; }
+            if (mfrac >= 1) {
+                const long kt = (k + KB - 1) / KB;                                              // k-tiles
+                const long ct = (kt * mfrac + ((long)(nsplit - 1) * mfrac + 1) - 1) / ((long)(nsplit - 1) * mfrac + 1);
+                kchunk = ct * KB;
+            }
+        }
+        gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk);
+    }
     else if (glds)
     {
         if (wide)

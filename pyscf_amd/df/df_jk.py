@@ -156,10 +156,22 @@ def _rho_work(dfobj, lib, nb, ldx, nocc_pad):
 
 
 def syrk_plan(nao, nsplit=None):
-    """(flags, nsplit) of the K = X^T X product: 128 x 128 lower-triangular tiles, 4 k-splits (nao = 1856: 120 tiles x 4 = 480
-    of the chip's 512 workgroup slots, one round).  Measured alternatives that lost (profiles/r02): 17 splits in four full
-    rounds (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits = 510 slots (42.0 vs 41.6 ms)."""
-    return 1 | 2, nsplit or 4
+    """(flags, nsplit) of the K = X^T X product: 128 x 128 lower-triangular tiles (flag 1), LDS-DMA operands (flag 2) and the
+    balanced k split (flag 4, r03): nsplit - 1 full pieces + one short remainder piece per tile that runs in the workgroup
+    slots the full pieces leave free (csrc/df_jk.hip::dgemm_tn_impl) - at nao = 1856: 120 tiles x 4 full pieces = 480 of the
+    chip's 512 slots + 120 quarter-length pieces, 4.25 effective splits.  Measured alternatives that lost (profiles/r02):
+    17 uniform splits in four full rounds (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits = 510 slots (42.0 vs 41.6 ms),
+    stream-K (41.5 vs 39.6 ms)."""
+    if nsplit:
+        return 1 | 2, nsplit
+    nt = -(-nao // 128)
+    ntile = nt * (nt + 1) // 2
+    if ntile < 32:                                    # small matrices: 4 uniform splits (the slots are not the constraint)
+        return 1 | 2, 4
+    full = min(4, max(1, 512 // ntile))               # full pieces per tile that fit the chip's 2 x 256 workgroup slots
+    if ntile * full < 512:
+        return 1 | 2 | 4, full + 1
+    return 1 | 2, full
 
 
 def pad_orbitals(orbo, device):

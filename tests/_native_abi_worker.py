@@ -18,7 +18,10 @@ def main():
     assert 'torch' not in sys.modules
     h2o = 'O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587'
     mol = gto.M(atom=h2o, basis='cc-pvdz')
+    import time
+    t0 = time.perf_counter()
     obj = native.NativeDF(mol, auxbasis='weigend').build()
+    print('first PAMD_df_create (HIP + rocBLAS / rocSOLVER start-up included): %.2f s' % (time.perf_counter() - t0), flush=True)
     nao = mol.nao
     assert obj.get_naoaux() == 71
     assert native.NativeDF(mol).get_naoaux() == 116                        # default aux basis, test_df.py:53
@@ -40,7 +43,9 @@ def main():
     for basis, nw in (('cc-pvdz', 1), ('cc-pvtz', 2)):
         from pyscf_amd.data import clusters
         m2 = gto.M(atom=clusters.water_cluster(nw), basis=basis)
+        t0 = time.perf_counter()
         o2 = native.NativeDF(m2).build()
+        print('PAMD_df_create %s (H2O)_%d: %.2f s' % (basis, nw, time.perf_counter() - t0), flush=True)
         cd = ref.cholesky_eri(m2, addons.make_auxmol(m2))
         n, nocc = m2.nao, m2.nelectron // 2
         c = np.linalg.qr(np.random.RandomState(3).rand(n, n))[0]
