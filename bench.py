@@ -250,6 +250,34 @@ def main():
             dist.destroy_process_group()
         return
 
+    # what the FP64 matrix pipe of THIS chip sustains under its power limit (measured here, same run): the kernels' k-loop without
+    # its memory system on live operands (PAMD_mfma_f64_live) and a register-only stream on zero operands (the data-sheet case)
+    practical = None
+    try:
+        import ctypes as _ct
+        _so = lib.load_library()
+        _out = torch.zeros(4, dtype=torch.float64, device=dev)
+        _st = _ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def _timed(fn, flops):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return flops / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        it_live, it_reg = 90000, 110000
+        live = _timed(lambda: _so.PAMD_mfma_f64_live(_ct.c_void_p(_out.data_ptr()), 512, it_live, _st), 512 * 4 * it_live * 20 * 2048.0)
+        zero = _timed(lambda: _so.PAMD_mfma_f64_peak(_ct.c_void_p(_out.data_ptr()), 512, it_reg // 20, 20, _ct.c_double(0.0), _st),
+                      512 * 4 * (it_reg // 20) * 20 * 2048.0)
+        practical = {'mfma_live_operands_TFLOPs': round(live, 2), 'mfma_register_stream_zero_operands_TFLOPs': round(zero, 2),
+                     'what': 'PAMD_mfma_f64_live: 20 v_mfma_f64_16x16x4 per 9 fresh LDS fragment reads, no global memory, no '
+                             'barriers, 2 x 256 workgroups resident, ~0.1 s; the chip lowers its clock under live FP64 matrix load'}
+    except Exception as e:                       # never let a micro-benchmark break the metric line
+        practical = {'error': str(e)}
+
     nocc_pad = orb_list[0][1]
     # algorithmic work of this rank's shard
     flops_e2 = 2.0 * naux_local * nao * nao * nocc          # X_L = B_L C
@@ -267,10 +295,11 @@ def main():
         pmc_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, 'profiles'))
                           if os.path.exists(os.path.join(ROOT, 'profiles', d, 'pmc_summary.json')))
         traffic_src = 'profiles/%s/pmc_summary.json' % pmc_dirs[-1]
-        pm = json.load(open(os.path.join(ROOT, traffic_src)))['kernels']
+        pm_doc = json.load(open(os.path.join(ROOT, traffic_src)))
+        pm = pm_doc['kernels']
         square = getattr(dfobj, '_cderi_sq', None) is not None
         cands = {'e2_symm': ['e2_sq2_kernel', 'e2_sq_kernel'] if square else ['e2_pk_kernel', 'e2_symm_kernel', 'e2_symm'],
-                 'dgemm_tn': ['gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel'], 'vj_pass1': ['vj_pass1_rows_kernel'],
+                 'dgemm_tn': ['syrk_slots_kernel', 'gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel'], 'vj_pass1': ['vj_pass1_rows_kernel'],
                  'vj_pass2': ['vj_pass2_kernel']}[dom]
         pk = [k for k in cands if k in pm][0]
         # gfx950: FETCH_SIZE reports half the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM section).
@@ -284,8 +313,8 @@ def main():
         pass
     dtot, dcnt = ksum[dom]
     if traffic is not None and dom == 'e2_symm':
-        # the PMC pass ran at N = 1 (2224 aux rows per launch); a rank's launch moves bytes in proportion to its rows
-        traffic *= (naux_local / max(dcnt, 1)) / 2224.0
+        # the PMC pass ran at N = 1; a rank's launch moves bytes in proportion to its aux rows per launch (recorded with the pass)
+        traffic *= (naux_local / max(dcnt, 1)) / float(pm_doc.get('profiled_run', {}).get('rows_per_e2_launch', 2224.0))
     if dom in ('e2_symm', 'dgemm_tn'):
         fl = flops_e2 if dom == 'e2_symm' else flops_syrk
         ach = fl / (dtot * 1e-3) / 1e12
@@ -327,6 +356,9 @@ def main():
                  'achieved_TFLOPs': round(step_exec / (ms_per_step * 1e-3) / 1e12, 2), 'peak_TFLOPs': FP64_MFMA_PEAK_TFLOPS,
                  'frac': round(step_exec / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
                  'ideal_ms_at_peak': round(step_exec / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 2)}
+    if practical and 'mfma_live_operands_TFLOPs' in practical:
+        step_roof['frac_of_measured_mfma_ceiling'] = round(step_roof['achieved_TFLOPs'] / practical['mfma_live_operands_TFLOPs'], 4)
+    step_roof['measured_mfma_ceiling'] = practical
 
     cpu = None
     parity = None

@@ -48,6 +48,10 @@ int PAMD_version(void);
 int PAMD_device_count(void);                 /* 0 when no HIP device / driver is present */
 int PAMD_set_device(int dev);
 int PAMD_stream_synchronize(void *stream);
+/* micro-benchmarks of the FP64 matrix pipe (bench.py / tools/mfma_peak.py; not on the product path): a register-only MFMA stream,
+ * and the J/K kernels' k-loop without its memory system (fresh LDS operands every k-group, 20 MFMAs per 9 fragment reads) */
+int PAMD_mfma_f64_peak(double *d_out, int nblocks, int iters, int nacc, double scale, void *stream);
+int PAMD_mfma_f64_live(double *d_out, int nblocks, int iters, void *stream);
 
 /* ---- integral generation -------------------------------------------------------------------- */
 /* Argument block of one (l_i >= l_j | l_k) class launch.  All pointers are device pointers. */
@@ -126,6 +130,23 @@ typedef struct PAMD_int2e_args {
     double omega;               /* > 0: erf(omega r12)/r12; 0: 1/r12                             */
 } PAMD_int2e_args;
 int PAMD_int2e_class(const PAMD_int2e_args *args, void *stream);
+/* Integral-direct form of the same kernel family: no tensor, the integrals of every shell quartet are contracted with the
+ * densities as they are produced (pyscf/scf/_vhf.py:370-429 direct -> CVHFnr_direct_drv, lib/vhf/nr_direct.c:361-489, with
+ * CVHFdot_nrs8 :183-231 and the Schwarz prescreen CVHFnrs8_prescreen, lib/vhf/optimizer.c:90-117).  base.eri is ignored.
+ * q_out != NULL: Schwarz pass over the bra list (base.ket_* = base.bra_*), q_out[pair] = sqrt(max |(ij|ij)|). */
+typedef struct PAMD_int2e_direct_args {
+    PAMD_int2e_args base;
+    const double *dm;           /* [nset][nao][nao]                                            */
+    double *vj;                 /* [nset][nao][nao] accumulated (FP64 atomics); nullable       */
+    double *vk;                 /* [nset][nao][nao] accumulated; nullable                      */
+    int nset;
+    const double *q_bra;        /* [nbra] Schwarz factors (nullable: no screening)             */
+    const double *q_ket;        /* [nket]                                                      */
+    double cutoff;              /* skip a quartet when q_bra q_ket dm_max < cutoff             */
+    double dm_max;              /* max |dm|                                                    */
+    double *q_out;              /* [nbra]: Schwarz pass                                        */
+} PAMD_int2e_direct_args;
+int PAMD_int2e_direct_class(const PAMD_int2e_direct_args *args, void *stream);
 /* d_grad[natm][3] += Tr(Dt dT/dR) - Tr(Ws dS/dR): int1e_ipkin / int1e_ipovlp contractions of
  * pyscf/grad/rhf.py:62-75; Dt, Ws symmetric (nao, nao) */
 int PAMD_int1e_grad(const int *d_l, const int *d_ao0, const int *d_prim0, const int *d_nprim,

@@ -709,10 +709,7 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
         d_vk = h->workspace("vk", (size_t)nset * n2, &rc);
         if (rc) return rc;
         PAMD_CHECK_HIP(hipMemsetAsync(d_vk, 0, (size_t)nset * n2 * 8, st));
-        // SYRK plan of df_jk.syrk_plan: balanced k split (flag 4) when the tiles leave workgroup slots free
-        const int ntl = ((nao + 127) / 128) * ((nao + 127) / 128 + 1) / 2, nfull = ntl < 32 ? 4 : std::min(4, std::max(1, 512 / ntl));
-        const bool bal = ntl >= 32 && ntl * nfull < 512;
-        const int nsplit = bal ? nfull + 1 : nfull, syrk_flags = bal ? (1 | 2 | 4) : (1 | 2);
+        const int nsplit = 4, syrk_flags = 1 | 2;              // df_jk.syrk_plan: lower-triangular tiles, 4 uniform k splits
         const size_t budget = 8ul << 30;
         const double *op = orbo;
         for (int s = 0; s < nset && nL > 0; s++) {

@@ -14,7 +14,9 @@
 //              packed row directly: the symmetric unpack is fused into the LDS fill)
 //   gemm_tn    C[m][n]    += sum_k  A[k][m] * B[k][n]                 (FP64 MFMA; lower-tri
 //              tiles only for the K = X^T X  SYRK)
+#include <map>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "mfma_e2.h"
 
@@ -913,6 +915,112 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
         }
 }
 
+// SYRK C[split] += X^T X on a re-tiled lower triangle (r03).  The 2 x 2-wave tiling of gemm_tn_glds2 leaves dead 64 x 64
+// wave blocks wherever a 128 x 128 tile sticks out of the triangle: one per diagonal tile and, when the matrix has an odd
+// number nb of 64-column blocks, two per tile of the last tile row (three in the corner) - 45 of 480 at nao = 1856.  Here a
+// work item is FOUR 64 x 64 blocks that share at most four 64-column panels of X ("slots"): slots 0/1 arrive with the "A"
+// DMA (lanes 0-31 fetch slot 0, lanes 32-63 slot 1, per-lane source offsets in one loop-invariant VGPR), slots 2/3 with the
+// "B" DMA; wave w multiplies slot a[w] by slot b[w] into block (rb[w], cb[w]).  Items (host table, syrk_items()):
+//   * off-diagonal 128-tiles (I > J):  slots {2I, 2I+1, 2J, 2J+1}, the usual 2 x 2 arrangement
+//   * diagonal tile I + one block of the odd last block row r:  slots {2I, 2I+1, r}: (2I,2I), (2I+1,2I), (2I+1,2I+1), (r,2I)
+//   * the other blocks of row r three at a time: slots {r, c1, c2, c3}: (r,c1), (r,c2), (r,c3) [+ the corner (r,r)]
+// 110 items with 435 live blocks instead of 120 tiles at nao = 1856.  k loop, DMA scheme and epilogue as gemm_tn_glds2.
+__global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
+    const double *__restrict__ A, int lda, double *__restrict__ C, int ldc, int m, long kdim, const int *__restrict__ items,
+    long kchunk)
+{
+    const int bsplit = blockIdx.y;
+    constexpr int PA = KB * LDN;
+    __shared__ double sb0[2 * PA];
+    __shared__ double sb1[2 * PA];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int *it = items + (long)blockIdx.x * 16;
+    const int c0 = it[0], c1 = it[1], c2 = it[2], c3 = it[3];
+    const int wdesc = __builtin_amdgcn_readfirstlane(it[4 + wave * 3]);           // a | b << 8 | live << 16
+    const int rb = __builtin_amdgcn_readfirstlane(it[5 + wave * 3]), cb = __builtin_amdgcn_readfirstlane(it[6 + wave * 3]);
+    const int sa = wdesc & 0xff, sbt = (wdesc >> 8) & 0xff;
+    const bool live = (wdesc >> 16) & 1;
+    long kbeg = (long)bsplit * kchunk;
+    if (kbeg > kdim) kbeg = kdim;
+    const long kend = (kbeg + kchunk < kdim && bsplit + 1 < (int)gridDim.y) ? kbeg + kchunk : kdim;
+    const int nk = (int)(kend - kbeg);
+    const __amdgpu_buffer_rsrc_t r_a = make_rsrc(A + kbeg * lda);
+    const int lda8 = lda * 8;
+    const int voff_a = (lane & 31) * 16 + ((lane >> 5) ? c1 : c0) * 8;
+    const int voff_b = (lane & 31) * 16 + ((lane >> 5) ? c3 : c2) * 8;
+    const int fk = lane >> 4, fn = lane & 15;
+    const int offa = (sa >> 1) * PA + (sa & 1) * 64 + fk * LDN + fn;
+    const int offb = (sbt >> 1) * PA + (sbt & 1) * 64 + fk * LDN + fn;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    auto stage_row = [&](int k0, double *dst, int j) {
+        const int k = wave * 4 + j;
+        dma_row(r_a, dst + k * LDN, voff_a, (k0 + k) * lda8);
+        dma_row(r_a, dst + PA + k * LDN, voff_b, (k0 + k) * lda8);
+    };
+    auto step = [&](const double *cur, double *nxt, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kn = (k0 + KB < nk) ? k0 + KB : k0;
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = cur[offa + kk * LDN + a * 16];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = cur[offb + kk * LDN + b * 16];
+            stage_row(kn, nxt, kk >> 2);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+    };
+    auto step_idle = [&](double *nxt, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kn = (k0 + KB < nk) ? k0 + KB : k0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) stage_row(kn, nxt, j);
+    };
+    if (nk > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) stage_row(0, sb0, j);
+    }
+    if (live) {
+        for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
+            step(sb0, sb1, k0);
+            if (k0 + KB < nk) step(sb1, sb0, k0 + KB);
+        }
+    } else {
+        for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
+            step_idle(sb1, k0);
+            if (k0 + KB < nk) step_idle(sb0, k0 + KB);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    double *out = C + (long)bsplit * m * ldc;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int col = cb * 64 + b * 16 + fn;
+            if (col >= m) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rowi = rb * 64 + a * 16 + fk + 4 * r;
+                if (rowi < m) unsafeAtomicAdd(out + (long)rowi * ldc + col, acc[a][b][r]);
+            }
+        }
+}
+
 // flag[rt][ct] = max |src[16 rt .. 16 rt + 15][16 ct .. 16 ct + 15]| > thr   (rows >= nrows count as zero)
 __global__ __launch_bounds__(256) void tile_mask_kernel(const double *__restrict__ src, long ld, long nrows, double thr,
                                                         unsigned char *__restrict__ out, int nct)
@@ -984,6 +1092,7 @@ static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: 
 static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
 static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
+static int g_syrk_slots = 1;  // SYRK on the re-tiled triangle (syrk_slots_kernel) when the matrix has an odd number of 64-column blocks
 static int g_syrk_frac = 1;   // balanced SYRK: full pieces + one short remainder piece per tile (dgemm_tn_impl)
 static int g_num_cu = 256;    // MI355X
 static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
@@ -997,6 +1106,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "gemmwide") == 0) { g_gemm_wide = value; return 0; }
     if (strcmp(key, "dmav2") == 0) { g_dma_v2 = value; return 0; }
     if (strcmp(key, "syrkfrac") == 0) { g_syrk_frac = value; return 0; }
+    if (strcmp(key, "syrkslots") == 0) { g_syrk_slots = value; return 0; }
     if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
@@ -1250,6 +1360,62 @@ int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, lo
 
 // C[s][m][ldc] += A[k][m]^T B[k][n] over the s-th k range; s in [0,nsplit).  Device analogue of
 // lib.dot(buf1.T, buf1) (pyscf/df/df_jk.py:380; NPdgemm, pyscf/lib/np_helper/npdot.c:32).
+// Work items of syrk_slots_kernel for an m x m lower triangle with an ODD number nb of 64-column blocks (see the kernel's
+// comment); cached on the device per m.  16 ints per item: 4 slot column offsets, then per wave {a | b << 8 | live << 16, row
+// block, column block}.  nitems = 0: even nb (or a tiny matrix) - the caller keeps the 2 x 2 tiling.
+static int syrk_items(int m, const int **d_items, int *nitems)
+{
+    static std::map<int, std::pair<int *, int>> cache;
+    auto hit = cache.find(m);
+    if (hit != cache.end()) { *d_items = hit->second.first; *nitems = hit->second.second; return 0; }
+    const int nb = ceil_div(m, 64);
+    std::vector<int> tab;
+    if (nb % 2 == 1 && nb >= 5) {
+        const int nt = nb / 2, r = nb - 1;                   // full 128-tiles per side, the odd last block row
+        auto item = [&](int c0, int c1, int c2, int c3, const int w[4][4]) {    // w[wave] = {a, b, rb, cb} or rb < 0: dead
+            const int cc[4] = {c0 * 64, c1 * 64, c2 * 64, c3 * 64};
+            tab.insert(tab.end(), cc, cc + 4);
+            for (int q = 0; q < 4; q++) {
+                const bool lv = w[q][2] >= 0;
+                tab.push_back((lv ? (w[q][0] | (w[q][1] << 8) | (1 << 16)) : 0));
+                tab.push_back(lv ? w[q][2] : 0);
+                tab.push_back(lv ? w[q][3] : 0);
+            }
+        };
+        for (int I = 0; I < nt; I++)
+            for (int J = 0; J < I; J++) {
+                const int w[4][4] = {{0, 2, 2 * I, 2 * J}, {0, 3, 2 * I, 2 * J + 1}, {1, 2, 2 * I + 1, 2 * J}, {1, 3, 2 * I + 1, 2 * J + 1}};
+                item(2 * I, 2 * I + 1, 2 * J, 2 * J + 1, w);
+            }
+        for (int I = 0; I < nt; I++) {
+            const int w[4][4] = {{0, 0, 2 * I, 2 * I}, {1, 0, 2 * I + 1, 2 * I}, {1, 1, 2 * I + 1, 2 * I + 1}, {2, 0, r, 2 * I}};
+            item(2 * I, 2 * I + 1, r, r, w);
+        }
+        std::vector<int> rest;                               // (r, 2I+1) for every I, then the corner (r, r)
+        for (int I = 0; I < nt; I++) rest.push_back(2 * I + 1);
+        size_t pos = 0;
+        while (pos < rest.size()) {
+            int cs[3] = {-1, -1, -1};
+            for (int q = 0; q < 3 && pos < rest.size(); q++) cs[q] = rest[pos++];
+            const bool corner = pos >= rest.size();          // the last item also takes the corner block
+            const int w[4][4] = {{0, 1, cs[0] >= 0 ? r : -1, cs[0]}, {0, 2, cs[1] >= 0 ? r : -1, cs[1]},
+                                 {0, 3, cs[2] >= 0 ? r : -1, cs[2]}, {0, 0, corner ? r : -1, r}};
+            item(r, cs[0] >= 0 ? cs[0] : r, cs[1] >= 0 ? cs[1] : r, cs[2] >= 0 ? cs[2] : r, w);
+            if (corner) break;
+        }
+    }
+    int *d = nullptr;
+    const int n = (int)(tab.size() / 16);
+    if (n) {
+        PAMD_CHECK_HIP(hipMalloc((void **)&d, tab.size() * sizeof(int)));
+        PAMD_CHECK_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    cache[m] = {d, n};
+    *d_items = d;
+    *nitems = n;
+    return 0;
+}
+
 static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc,
                          int m, int n, long k, int lower_only, int nsplit, const unsigned char *d_maskA,
                          const unsigned char *d_maskB, void *stream)
@@ -1273,25 +1439,36 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
     dim3 grid(ntiles, nsplit);
     const bool v2 = glds && g_dma_v2 && !wide && d_maskA == nullptr &&
                     (kchunk + KB) * (long)((lda > ldb) ? lda : ldb) * 8 < (1L << 32);
-    if (v2) {
-        // Balanced SYRK (flag 4, nsplit >= 2): the grid of U tiles x s uniform splits fills U s of the chip's 2 x 256 workgroup
-        // slots and every slot runs K / s rows - at nao = 1856: 120 x 4 = 480 of 512 slots, 32 idle for the whole launch.
-        // Instead: nsplit - 1 FULL pieces of kchunk rows per tile plus one SHORT remainder piece of <= kchunk / mfrac rows,
-        // dispatched last (blockIdx.y = nsplit - 1): the U short pieces run mfrac-deep one after the other in the
-        // 512 - U (nsplit - 1) slots the full pieces leave free, and the launch ends after kchunk = K mfrac / ((nsplit - 1)
-        // mfrac + 1) rows instead of K / (nsplit - 1): 4.25 instead of 4 effective splits at nao = 1856 (-6 %).  Every piece
-        // still walks its k range from the start, in step with the others of its split (L2 reuse of the X row panels).
-        if ((lower_only & 4) && g_syrk_frac && nsplit >= 2) {
-            const long slots = 2L * g_num_cu, full = (long)ntiles * (nsplit - 1);
-            long mfrac = 0;                      // smallest depth that fits = longest admissible short piece
-            for (long mm = 1; mm <= 64; mm++)
-                if (full + (ntiles + mm - 1) / mm <= slots) { mfrac = mm; break; }
-            if (mfrac >= 1) {
-                const long kt = (k + KB - 1) / KB;                                              // k-tiles
-                const long ct = (kt * mfrac + ((long)(nsplit - 1) * mfrac + 1) - 1) / ((long)(nsplit - 1) * mfrac + 1);
-                kchunk = ct * KB;
-            }
+    // SYRK variants (flags on top of 1 = lower triangle, 2 = LDS-DMA operands), both measured in r03 (profiles/r03):
+    //   4  balanced k split: nsplit - 1 FULL pieces of kchunk rows per tile plus one SHORT remainder piece of <= kchunk / mfrac
+    //      rows, dispatched last (blockIdx.y = nsplit - 1), so that the U short pieces run mfrac-deep in the 2 x 256 - U (nsplit
+    //      - 1) workgroup slots the full pieces leave free: 4.25 instead of 4 effective splits at nao = 1856
+    //   8  re-tiled triangle (syrk_slots_kernel): no dead 64 x 64 wave blocks when the matrix has an odd number of 64-blocks
+    auto balanced_chunk = [&](long units) {
+        if (!(lower_only & 4) || !g_syrk_frac || nsplit < 2) return kchunk;
+        const long slots = 2L * g_num_cu, full = units * (nsplit - 1);
+        long mfrac = 0;                          // smallest depth that fits = longest admissible short piece
+        for (long mm = 1; mm <= 64; mm++)
+            if (full + (units + mm - 1) / mm <= slots) { mfrac = mm; break; }
+        if (mfrac < 1) return kchunk;
+        const long kt = (k + KB - 1) / KB;
+        const long ct = (kt * mfrac + ((long)(nsplit - 1) * mfrac + 1) - 1) / ((long)(nsplit - 1) * mfrac + 1);
+        return ct * KB;
+    };
+    if (v2 && (lower_only & 1) && (lower_only & 8) && g_syrk_slots && d_A == d_B && lda == ldb) {
+        const int *d_items = nullptr;
+        int nitems = 0;
+        int rc = syrk_items(m, &d_items, &nitems);
+        if (rc) return rc;
+        if (nitems > 0) {
+            dim3 g2(nitems, nsplit);
+            syrk_slots_kernel<<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems));
+            PAMD_CHECK_LAUNCH();
+            return 0;
         }
+    }
+    if (v2) {
+        if (lower_only & 1) kchunk = balanced_chunk(ntiles);
         gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk);
     }
     else if (glds)

@@ -78,11 +78,15 @@ __host__ __device__ inline Plan make_plan(int li, int lj, int lk, int ll)
     return p;
 }
 
-__global__ void int2e_kernel(Int2eArgs a)
+// MODE 0: write the 8 images into the dense tensor; 1: Schwarz pass (diagonal quartets only); 2: contract with densities
+template <int MODE>
+__global__ void int2e_kernel(Int2eDirectArgs xa)
 {
     extern __shared__ double smem[];
-    const int bra = blockIdx.x, ket = blockIdx.y;
-    if (a.same_class && ket > bra) return;
+    const Int2eArgs &a = xa.base;
+    const int bra = blockIdx.x, ket = MODE == 1 ? blockIdx.x : blockIdx.y;
+    if (MODE != 1 && a.same_class && ket > bra) return;
+    if (MODE == 2 && xa.q_bra && xa.q_bra[bra] * xa.q_ket[ket] * xa.dm_max < xa.cutoff) return;      // CVHFnrs8_prescreen
     const Plan p = make_plan(a.li, a.lj, a.lk, a.ll);
     const int tid = threadIdx.x, nth = blockDim.x;
     const int NR = p.nr;
@@ -246,25 +250,65 @@ __global__ void int2e_kernel(Int2eArgs a)
     {
         const long n = a.nao;
         const long p0 = a.shell_ao0[ish], q0 = a.shell_ao0[jsh], r0 = a.shell_ao0[ksh], s0 = a.shell_ao0[lsh];
+        double qmax = 0;
         for (int o = tid; o < p.nsi * p.nsj * p.nsk * p.nsl; o += nth) {
             const int ml = o % p.nsl, ijk = o / p.nsl;
             const int mk = ijk % p.nsk, mj = (ijk / p.nsk) % p.nsj, mi = ijk / (p.nsk * p.nsj);
-            // an element that is its own permutational image of another one of this block is written once (from the
-            // canonical member), so the tensor is exactly symmetric and independent of the write order
-            if ((ish == jsh && mj > mi) || (ksh == lsh && ml > mk) ||
-                (ish == ksh && jsh == lsh && mi * p.nsj + mj < mk * p.nsl + ml)) continue;
+            if (MODE == 1) {
+                if (mi != mk || mj != ml) continue;               // (ij|ij): the Schwarz diagonal
+            } else {
+                // an element that is its own permutational image of another one of this block is written once (from the
+                // canonical member), so the tensor is exactly symmetric and independent of the write order
+                if ((ish == jsh && mj > mi) || (ksh == lsh && ml > mk) ||
+                    (ish == ksh && jsh == lsh && mi * p.nsj + mj < mk * p.nsl + ml)) continue;
+            }
             double v = 0;
             for (int cl = 0; cl < p.ncl; cl++) v += c2s_l[ml * p.ncl + cl] * b3[ijk * p.ncl + cl];
             const long P = p0 + mi, Q = q0 + mj, R = r0 + mk, S = s0 + ml;
-            double *e = a.eri;
-            e[((P * n + Q) * n + R) * n + S] = v;
-            e[((Q * n + P) * n + R) * n + S] = v;
-            e[((P * n + Q) * n + S) * n + R] = v;
-            e[((Q * n + P) * n + S) * n + R] = v;
-            e[((R * n + S) * n + P) * n + Q] = v;
-            e[((S * n + R) * n + P) * n + Q] = v;
-            e[((R * n + S) * n + Q) * n + P] = v;
-            e[((S * n + R) * n + Q) * n + P] = v;
+            if (MODE == 1) {
+                qmax = fmax(qmax, fabs(v));
+            } else if (MODE == 0) {
+                double *e = a.eri;
+                e[((P * n + Q) * n + R) * n + S] = v;
+                e[((Q * n + P) * n + R) * n + S] = v;
+                e[((P * n + Q) * n + S) * n + R] = v;
+                e[((Q * n + P) * n + S) * n + R] = v;
+                e[((R * n + S) * n + P) * n + Q] = v;
+                e[((S * n + R) * n + P) * n + Q] = v;
+                e[((R * n + S) * n + Q) * n + P] = v;
+                e[((S * n + R) * n + Q) * n + P] = v;
+            } else {
+                // the distinct permutational images (a b | c d) of this canonical integral, each contracted once:
+                //   J[a][b] += v D[c][d],  K[a][c] += v D[b][d]     (vj_ij = sum_kl (ij|kl) D_lk, vk_il = sum_jk (ij|kl) D_jk with
+                //   symmetric handling as in CVHFdot_nrs8; for a non-symmetric D the images use D as stored: hermi = 0 safe
+                //   because every image (a b|c d) and its partner (a b|d c) are both visited)
+                const long im[8][4] = {{P, Q, R, S}, {Q, P, R, S}, {P, Q, S, R}, {Q, P, S, R},
+                                       {R, S, P, Q}, {S, R, P, Q}, {R, S, Q, P}, {S, R, Q, P}};
+                for (int t = 0; t < 8; t++) {
+                    bool dup = false;
+                    for (int u = 0; u < t; u++)
+                        dup = dup || (im[u][0] == im[t][0] && im[u][1] == im[t][1] && im[u][2] == im[t][2] && im[u][3] == im[t][3]);
+                    if (dup) continue;
+                    const long A_ = im[t][0], B_ = im[t][1], C_ = im[t][2], D_ = im[t][3];
+                    for (int sset = 0; sset < xa.nset; sset++) {
+                        const double *dm = xa.dm + (long)sset * n * n;
+                        if (xa.vj) unsafeAtomicAdd(xa.vj + (long)sset * n * n + A_ * n + B_, v * dm[D_ * n + C_]);
+                        if (xa.vk) unsafeAtomicAdd(xa.vk + (long)sset * n * n + A_ * n + D_, v * dm[B_ * n + C_]);
+                    }
+                }
+            }
+        }
+        if (MODE == 1) {
+            // block maximum -> q_out[bra] = sqrt(max |(ij|ij)|)
+            double *red = smem;                                   // everything else in LDS is dead now
+            __syncthreads();
+            red[tid] = qmax;
+            __syncthreads();
+            if (tid == 0) {
+                double mx = 0;
+                for (int t = 0; t < nth; t++) mx = fmax(mx, red[t]);
+                xa.q_out[bra] = sqrt(mx);
+            }
         }
     }
 }
@@ -272,12 +316,10 @@ __global__ void int2e_kernel(Int2eArgs a)
 }  // namespace
 }  // namespace pamd
 
-extern "C" {
-
-int PAMD_int2e_class(const PAMD_int2e_args *args, void *stream)
+static int launch_int2e(const pamd::Int2eDirectArgs &xa, int mode, void *stream)
 {
     using namespace pamd;
-    const Int2eArgs &a = *args;
+    const Int2eArgs &a = xa.base;
     PAMD_REQUIRE(a.li >= a.lj && a.lk >= a.ll && a.lj >= 0 && a.ll >= 0, "int2e class needs l_i >= l_j and l_k >= l_l");
     PAMD_REQUIRE(a.li <= 3 && a.lk <= 3, "int2e: AO angular momentum > 3 unsupported on the 4-centre path");
     const Plan p = make_plan(a.li, a.lj, a.lk, a.ll);
@@ -287,14 +329,36 @@ int PAMD_int2e_class(const PAMD_int2e_args *args, void *stream)
     if (a.nbra == 0 || a.nket == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        PAMD_CHECK_HIP(hipFuncSetAttribute((const void *)int2e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PAMD_CHECK_HIP(hipFuncSetAttribute((const void *)int2e_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PAMD_CHECK_HIP(hipFuncSetAttribute((const void *)int2e_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PAMD_CHECK_HIP(hipFuncSetAttribute((const void *)int2e_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int ncart4 = p.nci * p.ncj * p.nck * p.ncl;
     const int nth = ncart4 <= 64 ? 64 : ncart4 <= 1024 ? 128 : 256;
-    hipLaunchKernelGGL(int2e_kernel, dim3(a.nbra, a.nket), dim3(nth), lds, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(int2e_kernel<0>, dim3(a.nbra, a.nket), dim3(nth), lds, st, xa);
+    else if (mode == 1) hipLaunchKernelGGL(int2e_kernel<1>, dim3(a.nbra, 1), dim3(nth), lds, st, xa);
+    else hipLaunchKernelGGL(int2e_kernel<2>, dim3(a.nbra, a.nket), dim3(nth), lds, st, xa);
     PAMD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" {
+
+int PAMD_int2e_class(const PAMD_int2e_args *args, void *stream)
+{
+    pamd::Int2eDirectArgs xa;
+    memset(&xa, 0, sizeof(xa));
+    xa.base = *args;
+    return launch_int2e(xa, 0, stream);
+}
+
+// Integral-direct J/K (or, with q_out set, the Schwarz factors of the bra list; then base.ket_* must repeat base.bra_*)
+int PAMD_int2e_direct_class(const PAMD_int2e_direct_args *args, void *stream)
+{
+    PAMD_REQUIRE(args->q_out || ((args->vj || args->vk) && args->dm && args->nset > 0), "int2e direct: nothing to compute");
+    return launch_int2e(*args, args->q_out ? 1 : 2, stream);
 }
 
 }  // extern "C"

@@ -155,23 +155,26 @@ def _rho_work(dfobj, lib, nb, ldx, nocc_pad):
     return _ptr(dfobj._workspace('rho_work', (max(int(n), 1),)))
 
 
-def syrk_plan(nao, nsplit=None):
-    """(flags, nsplit) of the K = X^T X product: 128 x 128 lower-triangular tiles (flag 1), LDS-DMA operands (flag 2) and the
-    balanced k split (flag 4, r03): nsplit - 1 full pieces + one short remainder piece per tile that runs in the workgroup
-    slots the full pieces leave free (csrc/df_jk.hip::dgemm_tn_impl) - at nao = 1856: 120 tiles x 4 full pieces = 480 of the
-    chip's 512 slots + 120 quarter-length pieces, 4.25 effective splits.  Measured alternatives that lost (profiles/r02):
-    17 uniform splits in four full rounds (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits = 510 slots (42.0 vs 41.6 ms),
-    stream-K (41.5 vs 39.6 ms)."""
+def syrk_plan(nao, nsplit=None, flags=None):
+    """(flags, nsplit) of the K = X^T X product: 128 x 128 lower-triangular tiles (flag 1), LDS-DMA operands (flag 2), 4 uniform
+    k splits (nao = 1856: 120 tiles x 4 = 480 of the chip's 512 workgroup slots, one round).  Optional variants, both built and
+    measured in r03 and NOT faster (the FP64 matrix pipe runs at the chip's power-limited rate either way):
+    flag 4 = balanced k split (nsplit - 1 full pieces + short remainder pieces in the idle slots), flag 8 = re-tiled triangle
+    without dead wave blocks (csrc/df_jk.hip::syrk_slots_kernel).  Earlier measurements that lost (profiles/r02): 17 uniform
+    splits in four full rounds (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits (42.0 vs 41.6 ms), stream-K (41.5 vs 39.6 ms)."""
+    base = 1 | 2
+    if flags:
+        base |= flags
     if nsplit:
-        return 1 | 2, nsplit
-    nt = -(-nao // 128)
-    ntile = nt * (nt + 1) // 2
-    if ntile < 32:                                    # small matrices: 4 uniform splits (the slots are not the constraint)
-        return 1 | 2, 4
-    full = min(4, max(1, 512 // ntile))               # full pieces per tile that fit the chip's 2 x 256 workgroup slots
-    if ntile * full < 512:
-        return 1 | 2 | 4, full + 1
-    return 1 | 2, full
+        return base, nsplit
+    if flags and flags & 4:
+        nt = -(-nao // 128)
+        ntile = nt * (nt + 1) // 2
+        if ntile >= 32:
+            full = min(4, max(1, 512 // ntile))
+            if ntile * full < 512:
+                return base, full + 1
+    return base, 4
 
 
 def pad_orbitals(orbo, device):
@@ -201,7 +204,7 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
     dev = cderi.device
     st = _stream()
     ldx = _round_up(nao, 16)
-    syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit)
+    syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit, getattr(dfobj, 'k_syrk_flags', 0))
     vks = []
     for iset, (orb, nocc_pad, ldo) in enumerate(orb_list):
         vk = torch.zeros((nao, nao), dtype=torch.float64, device=dev)

@@ -372,7 +372,11 @@ class SCF:
     only_dfj = False
     _eri = None                # {(mol tables, omega): (nao, nao, nao, nao) device tensor}, built on first use like mf._eri (hf.py:2506-2507)
 
+    direct_jk = None           # None: in-core when the nao^4 tensor fits in HBM, integral-direct beyond; True / False force
+
     def _get_jk_incore(self, dm, hermi, with_j, with_k, omega):
+        """RHF.get_jk without density fitting (hf.py:2499-2511): the in-core tensor when it fits (`_is_mem_enough`), else
+        SCF.get_jk -> the integral-direct build (scf/_vhf.py:370-429)."""
         from . import _vhf
         from ..gto.moleintor import mol_fingerprint
         om = float(omega or 0.0)
@@ -380,6 +384,14 @@ class SCF:
         if self._eri is None:
             self._eri = {}
         if key not in self._eri:
+            use_direct = self.direct_jk
+            if use_direct is None:
+                use_direct = not _vhf.is_mem_enough(self.mol, None, 2.0 if om < 0 else 1.0)
+            if use_direct:
+                t0 = time.perf_counter()
+                out = _vhf.direct(self.mol, dm, hermi, with_j, with_k, om, None, self.direct_scf_tol)
+                self._log('direct vj and vk (4-centre, omega %g): %.4f s', om, time.perf_counter() - t0)
+                return out
             self._eri = {k: v for k, v in self._eri.items() if k[0] == key[0]}
             t0 = time.perf_counter()
             self._eri[key] = _vhf.int2e_gpu(self.mol, None, om)

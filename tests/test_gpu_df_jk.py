@@ -322,3 +322,31 @@ def test_df_accepts_a_foreign_mole_object():
     cderi = ref.cholesky_eri(mol, df.make_auxmol(mol))
     vj0, vk0 = ref.get_jk(cderi, dms, 0)
     assert obj.get_naoaux() == 116 and np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9
+
+
+@pytest.mark.parametrize('flags', [4, 8, 12])
+@pytest.mark.parametrize('nao,naux,nocc', [(300, 64, 40), (700, 48, 160), (257, 96, 161)])
+def test_syrk_variants_give_the_same_exchange(flags, nao, naux, nocc):
+    """The optional SYRK schedules of K = X^T X - balanced k split (flag 4: full pieces + a short remainder piece per tile) and
+    the re-tiled triangle without dead wave blocks (flag 8, csrc/df_jk.hip::syrk_slots_kernel; odd numbers of 64-column blocks:
+    nao 300 -> 5, 700 -> 11, 257 -> 5 with a ragged last block) - against the default schedule and a plain numpy product."""
+    from pyscf_amd import lib
+    rng = np.random.default_rng(nao + flags)
+    npair = nao * (nao + 1) // 2
+    cderi = rng.standard_normal((naux, npair)) / np.sqrt(nao)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao)
+    occ[:nocc] = 2
+    dm = lib.tag_array((c * occ).dot(c.T), mo_coeff=c, mo_occ=occ)
+    base = _dfobj(None, cderi)
+    vj0, vk0 = base.get_jk(dm, hermi=1)
+    obj = _dfobj(None, cderi)
+    obj.k_syrk_flags = flags
+    obj.k_block_bytes = 1 << 22                       # several K blocks: the partial buffers accumulate over launches
+    vj, vk = obj.get_jk(dm, hermi=1)
+    full = ref.unpack_tril(cderi)
+    x = np.einsum('Lpq,qi->Lip', full, c[:, :nocc] * np.sqrt(2.0))
+    vk_np = np.einsum('Lip,Liq->pq', x, x, optimize=True)
+    scale = max(1.0, np.abs(vk_np).max())
+    assert np.abs(vk - vk_np).max() < 1e-11 * scale and np.abs(vk - vk0).max() < 1e-11 * scale
+    assert np.abs(vk - vk.T).max() == 0 and np.abs(vj - vj0).max() < 1e-11 * max(1.0, np.abs(vj0).max())

@@ -174,3 +174,49 @@ def test_reference_uks_cation_goldens(xc, e_ref):
     finally:
         radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
     assert mf.converged and abs(e - e_ref) < 2e-8, (xc, e, e_ref)
+
+
+def test_integral_direct_jk_equals_incore_and_reference_goldens():
+    """The integral-direct branch of RHF.get_jk (pyscf/scf/_vhf.py:370-429 -> CVHFnr_direct_drv, lib/vhf/nr_direct.c:361-489,
+    Schwarz prescreen lib/vhf/optimizer.c:90-117): no nao^4 tensor, every shell quartet contracted as it is produced.
+      * the reference's exact-integral J/K fingerprints of pyscf/df/test/test_df_jk.py:158-165 (hermi = 0, two random densities),
+      * equal to the in-core contraction (and to the oracle's dense tensor) for symmetric and non-symmetric densities,
+      * the reference RHF energy of pyscf/scf/test/test_rhf.py:371-372 through an SCF that never builds the tensor,
+      * long-range and short-range operators (omega > 0 / < 0)."""
+    from pyscf_amd import gto, scf
+    from pyscf_amd.scf import _vhf
+    mol = gto.M(atom=H2O, basis='cc-pvdz')
+    nao = mol.nao
+    np.random.seed(1)
+    dms = np.random.random((2, nao, nao))
+    vj, vk = _vhf.direct(mol, dms, hermi=0)
+    assert abs(ref.fp(vj) - -194.08878302990749) < 1e-9 and abs(ref.fp(vk) - -46.530782983591152) < 1e-9
+    eri = _vhf.int2e_gpu(mol)
+    vj0, vk0 = _vhf.dot_eri_dm(eri, dms, hermi=0)
+    assert np.abs(vj - vj0).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11
+    sym = dms[0] + dms[0].T
+    vj, vk = _vhf.direct(mol, sym, hermi=1)
+    vj0, vk0 = _vhf.dot_eri_dm(eri, sym, hermi=1)
+    assert np.abs(vj - vj0).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11
+    vj1, none = _vhf.direct(mol, sym, with_k=False)
+    assert none is None and np.abs(vj1 - vj0).max() < 1e-11
+    # screening: a tight cut-off changes nothing beyond the cut-off itself, a crude one only a little
+    vj2, vk2 = _vhf.direct(mol, sym, direct_scf_tol=1e-6)
+    assert 0 < np.abs(vj2 - vj0).max() + np.abs(vk2 - vk0).max() < 1e-3 or np.abs(vj2 - vj0).max() < 1e-11
+    for omega in (0.3, -0.3):
+        e_w = _vhf.int2e_gpu(mol, None, omega)
+        a = _vhf.direct(mol, dms, hermi=0, omega=omega)
+        b = _vhf.dot_eri_dm(e_w, dms, hermi=0)
+        assert np.abs(a[0] - b[0]).max() < 1e-11 and np.abs(a[1] - b[1]).max() < 1e-11
+    mf = scf.RHF(mol)
+    mf.direct_jk = True
+    mf.conv_tol = 1e-11
+    e = mf.kernel()
+    assert mf.converged and not mf._eri                                  # no tensor was built
+    assert abs(e - -76.026765673119627) < 1e-9, e
+    # d and f shells through the direct kernel
+    mol3 = gto.M(atom=H2O, basis='cc-pvtz')
+    d3 = np.random.random((mol3.nao, mol3.nao))
+    a = _vhf.direct(mol3, d3, hermi=0)
+    b = _vhf.dot_eri_dm(_vhf.int2e_gpu(mol3), d3, hermi=0)
+    assert np.abs(a[0] - b[0]).max() < 1e-10 and np.abs(a[1] - b[1]).max() < 1e-10

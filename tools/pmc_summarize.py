@@ -20,7 +20,7 @@ for sub, name, dst in copies:
     f = find(sub, name)
     if f:
         shutil.copy(f, os.path.join(out, dst))
-SHORT = ['e2_sq2_kernel', 'e2_sq_kernel', 'e2_symm', 'gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel', 'gemm_tn_kernel',
+SHORT = ['syrk_slots_kernel', 'e2_sq2_kernel', 'e2_sq_kernel', 'e2_symm', 'gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel', 'gemm_tn_kernel',
          'vj_pass1_rows_kernel', 'vj_pass2_kernel', 'cderi_solve_kernel', 'eval_ao_kernel', 'int3c2e_kernel', 'scale_ao_kernel',
          'sub_orb_dot2_kernel', 'sub_orb_dot_kernel', 'sub_vmat_kernel', 'sub_scale_kernel', 'sub_gather_kernel']
 
@@ -79,5 +79,16 @@ doc = {'command': 'tools/profile_round.sh %s: rocprofv3 --pmc <counters> --kerne
                  'mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); one v_mfma_f64_16x16x4_f64 '
                  'counts 64 busy cycles.'],
        'kernels': summ}
+# rows of the half-transform launches of the profiled command (bench.py scales `roofline.traffic` by rows per launch)
+try:
+    blog = os.path.join(root, 'gpurun_out', 'prof_%s_bench.log' % tag)
+    line = [ln for ln in open(blog) if ln.startswith('{')][-1]
+    b = json.loads(line)
+    doc['profiled_run'] = {'naux_local': b['config']['naux_local'], 'e2_launches_per_step': b['kernels']['e2_symm']['launches'],
+                           'rows_per_e2_launch': b['config']['naux_local'] / b['kernels']['e2_symm']['launches'],
+                           'value_ms': b['value'], 'workload': b['config']['workload']}
+    shutil.copy(blog, os.path.join(out, 'bench_under_rocprofv3_stats.log'))
+except Exception as e:
+    print('no bench log:', e)
 json.dump(doc, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1)
 print(json.dumps(summ, indent=1)[:3000])
