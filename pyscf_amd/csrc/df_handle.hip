@@ -709,7 +709,20 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
         d_vk = h->workspace("vk", (size_t)nset * n2, &rc);
         if (rc) return rc;
         PAMD_CHECK_HIP(hipMemsetAsync(d_vk, 0, (size_t)nset * n2 * 8, st));
-        const int nsplit = 4, syrk_flags = 1 | 2;              // df_jk.syrk_plan: lower-triangular tiles, 4 uniform k splits
+        // df_jk.syrk_plan: re-tiled triangle + balanced k split when the matrix has an odd number of 64-column blocks
+        int nsplit = 4, syrk_flags = 1 | 2;
+        {
+            const int nb64 = (nao + 63) / 64;
+            if (nb64 % 2 == 1 && nb64 >= 5) {
+                const int ntl = nb64 / 2, units = ntl * (ntl - 1) / 2 + ntl + (ntl + 2) / 3;
+                double best = 0;
+                int bn = 0;
+                for (int n = 1; n < 8; n++)
+                    for (int m = 1; m < 9; m++)
+                        if (units * n + (units + m - 1) / m <= 512 && n + 1.0 / m > best) { best = n + 1.0 / m; bn = n; }
+                if (bn && units >= 32) { nsplit = bn + 1; syrk_flags = 1 | 2 | 4 | 8; }
+            }
+        }
         const size_t budget = 8ul << 30;
         const double *op = orbo;
         for (int s = 0; s < nset && nL > 0; s++) {

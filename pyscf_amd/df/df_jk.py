@@ -155,26 +155,43 @@ def _rho_work(dfobj, lib, nb, ldx, nocc_pad):
     return _ptr(dfobj._workspace('rho_work', (max(int(n), 1),)))
 
 
+def syrk_items(nao):
+    """Work items of the re-tiled SYRK triangle (csrc/df_jk.hip::syrk_items): 0 when the 2 x 2 tiling is kept (even number of
+    64-column blocks, small matrices)."""
+    nb = -(-nao // 64)
+    if nb % 2 == 0 or nb < 5:
+        return 0
+    nt = nb // 2
+    return nt * (nt - 1) // 2 + nt + -(-nt // 3)
+
+
 def syrk_plan(nao, nsplit=None, flags=None):
-    """(flags, nsplit) of the K = X^T X product: 128 x 128 lower-triangular tiles (flag 1), LDS-DMA operands (flag 2), 4 uniform
-    k splits (nao = 1856: 120 tiles x 4 = 480 of the chip's 512 workgroup slots, one round).  Optional variants, both built and
-    measured in r03 and NOT faster (the FP64 matrix pipe runs at the chip's power-limited rate either way):
-    flag 4 = balanced k split (nsplit - 1 full pieces + short remainder pieces in the idle slots), flag 8 = re-tiled triangle
-    without dead wave blocks (csrc/df_jk.hip::syrk_slots_kernel).  Earlier measurements that lost (profiles/r02): 17 uniform
-    splits in four full rounds (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits (42.0 vs 41.6 ms), stream-K (41.5 vs 39.6 ms)."""
+    """(flags, nsplit) of the K = X^T X product (flag 1: lower triangle, flag 2: LDS-DMA operands).
+
+    Default when the matrix has an odd number of 64-column blocks (nao = 1856: 29): the RE-TILED triangle (flag 8,
+    syrk_slots_kernel: work items of four live 64 x 64 wave blocks, 110 items instead of 120 tiles with 45 dead wave blocks)
+    with the BALANCED k split (flag 4): n full pieces of K m / (n m + 1) rows per item plus one 1/m-length remainder piece that
+    runs in the workgroup slots the full pieces leave free - n = 4, m = 2 at nao = 1856: 440 + 55 of the 512 slots, 4.5 effective
+    splits instead of 4.  Measured (profiles/r03/kbench_syrk_variants.log, K only): uniform 39.7 ms, balanced alone 41.2, re-tiled
+    alone 39.6, both 35.4.  Otherwise 128 x 128 tiles and 4 uniform splits (120 x 4 = 480 slots, one round).  Earlier variants
+    that lost (profiles/r02): 17 uniform splits (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits (42.0 vs 41.6), stream-K (41.5 vs 39.6)."""
     base = 1 | 2
-    if flags:
-        base |= flags
+    if flags is None:
+        flags = 12 if syrk_items(nao) else 0
+    base |= flags
     if nsplit:
         return base, nsplit
-    if flags and flags & 4:
+    if flags & 4:
         nt = -(-nao // 128)
-        ntile = nt * (nt + 1) // 2
-        if ntile >= 32:
-            full = min(4, max(1, 512 // ntile))
-            if ntile * full < 512:
-                return base, full + 1
-    return base, 4
+        units = syrk_items(nao) if (flags & 8) and syrk_items(nao) else nt * (nt + 1) // 2
+        best = None
+        for n in range(1, 8):
+            for m in range(1, 9):
+                if units * n + -(-units // m) <= 512 and (best is None or n + 1.0 / m > best[0]):
+                    best = (n + 1.0 / m, n)
+        if best is not None and units >= 32:
+            return base, best[1] + 1
+    return base & ~4, 4
 
 
 def pad_orbitals(orbo, device):
@@ -204,7 +221,7 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
     dev = cderi.device
     st = _stream()
     ldx = _round_up(nao, 16)
-    syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit, getattr(dfobj, 'k_syrk_flags', 0))
+    syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit, getattr(dfobj, 'k_syrk_flags', None))
     vks = []
     for iset, (orb, nocc_pad, ldo) in enumerate(orb_list):
         vk = torch.zeros((nao, nao), dtype=torch.float64, device=dev)

@@ -20,7 +20,7 @@ ap.add_argument('--no-split', action='store_true')
 ap.add_argument('--no-square', action='store_true')
 ap.add_argument('--no-fuse', action='store_true')
 ap.add_argument('--ksplit', type=int, default=0)
-ap.add_argument('--syrk-flags', type=int, default=0, help='4: balanced k split, 8: re-tiled triangle (df_jk.syrk_plan)')
+ap.add_argument('--syrk-flags', type=int, default=-1, help='4: balanced k split, 8: re-tiled triangle (df_jk.syrk_plan)')
 ap.add_argument('--no-j', action='store_true', help='K only (as the K_LR / response calls do)')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
@@ -37,7 +37,7 @@ obj.overlap_split = not a.no_split
 if a.no_square: obj.k_square = False
 if a.no_fuse: obj.fuse_j_pass1 = False
 if a.ksplit: obj.k_nsplit = a.ksplit
-obj.k_syrk_flags = a.syrk_flags
+obj.k_syrk_flags = None if a.syrk_flags < 0 else a.syrk_flags
 import ctypes
 from pyscf_amd import lib as _L
 for kv in filter(None, a.tune.split(',')):
