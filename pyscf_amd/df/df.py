@@ -122,7 +122,10 @@ class DF:
         return buf[:rows * naux].view(rows, naux)
 
     def square_image(self):
-        """sq[L][q][p] (rows and ld rounded up to 16, zero padded) of this rank's cderi rows, or None."""
+        """sq[L][q][p] (rows and ld rounded up to 16, zero padded) of the first `sq.shape[0]` of this rank's cderi rows, or None.
+        k_square = 'auto': all rows when HBM allows (k_square_reserve stays free); else as many rows as fit (r03: taxol on one
+        GPU - 111 GB packed, the 222 GB image does not fit beside it, the image of 60 % of the rows does; their half transform
+        runs on the LDS-DMA square kernel at 73 TF/s instead of 54 on the packed-operand one); fewer than 1/4 of the rows: none."""
         import torch
         import ctypes as _c
         from .. import lib as _lib
@@ -131,25 +134,31 @@ class DF:
         naux, npair = self._cderi_dev.shape
         nao = int((np.sqrt(8.0 * npair + 1) - 1) / 2 + .5)
         rows = (nao + 15) // 16 * 16
-        need = (naux * rows * rows + 256) * 8
         if naux == 0 or nao * (nao + 1) // 2 != npair:
             return None
+        nsq = naux
         if self.k_square == 'auto':
             free = torch.cuda.mem_get_info(self._cderi_dev.device)[0] + torch.cuda.memory_reserved(self._cderi_dev.device) \
                 - torch.cuda.memory_allocated(self._cderi_dev.device)
-            if need + self.k_square_reserve > free:
+            room = free - self.k_square_reserve - 256 * 8
+            nsq = min(naux, int(room // (rows * rows * 8))) if room > 0 else 0
+            if getattr(self, 'k_square_max_rows', None) is not None:       # cap (tests, tuning)
+                nsq = min(nsq, int(self.k_square_max_rows))
+            if nsq < naux:
+                nsq = nsq // 64 * 64                       # whole K blocks are cut at multiples of 64 rows (df_jk._vk_mo)
+            if nsq < max(naux // 4, 1) or not getattr(self, 'k_square_partial', True) and nsq < naux:
                 self.k_square = False
                 return None
         so = _lib.load_library()
         # unpack_tril writes every [p < nao][q < rows] entry; only the pad rows p >= nao (and the slack) need zeroing
-        buf = torch.empty(naux * rows * rows + 256, dtype=torch.float64, device=self._cderi_dev.device)
-        buf[naux * rows * rows:].zero_()
+        buf = torch.empty(nsq * rows * rows + 256, dtype=torch.float64, device=self._cderi_dev.device)
+        buf[nsq * rows * rows:].zero_()
         if rows > nao:
-            buf[:naux * rows * rows].view(naux, rows, rows)[:, nao:, :].zero_()
+            buf[:nsq * rows * rows].view(nsq, rows, rows)[:, nao:, :].zero_()
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(so.PAMD_unpack_tril(_c.c_void_p(self._cderi_dev.data_ptr()), _c.c_long(npair), _c.c_int(naux),
+        _lib.check(so.PAMD_unpack_tril(_c.c_void_p(self._cderi_dev.data_ptr()), _c.c_long(npair), _c.c_int(nsq),
                                        _c.c_int(nao), _c.c_void_p(buf.data_ptr()), _c.c_int(rows), _c.c_int(rows), st))
-        self._cderi_sq = buf[:naux * rows * rows].view(naux, rows, rows)
+        self._cderi_sq = buf[:nsq * rows * rows].view(nsq, rows, rows)
         return self._cderi_sq
 
     def drop_square_image(self):

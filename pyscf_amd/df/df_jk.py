@@ -221,7 +221,13 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
     dev = cderi.device
     st = _stream()
     ldx = _round_up(nao, 16)
-    syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit, getattr(dfobj, 'k_syrk_flags', None))
+    kflags = getattr(dfobj, 'k_syrk_flags', None)
+    if kflags is None and after_e2 is not None:
+        # the second J pass runs beside this SYRK on the side stream: it hides in the 32 workgroup slots the plain 120 x 4 grid
+        # leaves idle (J/K 108.8 ms) but not beside the balanced schedule that fills them (110.0 ms; K alone: 35.6 vs 39.7 ms) -
+        # the chip is at its FP64-matrix power limit either way, so keep the plain grid when J co-runs
+        kflags = 0
+    syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit, kflags)
     vks = []
     for iset, (orb, nocc_pad, ldo) in enumerate(orb_list):
         vk = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
@@ -233,9 +239,14 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
         part = dfobj._workspace('kpart', (nsplit, nao, nao))
         part.zero_()
         sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
-        for b0 in range(0, naux, blk):
-            nb = min(blk, naux - b0)
-            if sq is not None:
+        nsq = sq.shape[0] if sq is not None else 0
+        bounds = list(range(0, naux, blk)) + [naux]
+        if 0 < nsq < naux:
+            # partial image (rows [0, nsq)): cut the K blocks at its end
+            bounds = sorted(set(list(range(0, nsq, blk)) + [nsq] + list(range(nsq, naux, blk)) + [naux]))
+        for b0, b1 in zip(bounds[:-1], bounds[1:]):
+            nb = b1 - b0
+            if b1 <= nsq:
                 # fuse_j[set] = rho (naux) zeroed: the first J pass of the density orb orb^T comes out of the epilogue
                 rho_j = fuse_j[iset] if fuse_j is not None else None
                 _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[b0:b0 + nb]), _c.c_long(sq.shape[2]),
@@ -301,7 +312,7 @@ def _half_transform(dfobj, lib, b0, nb, orb, nocc_pad, ldo, nao, out, ldx, st):
     """out[L][i][p] = sum_q B_L[p,q] orb[q,i] for aux rows [b0, b0 + nb): square-image kernel when the image exists."""
     cderi = dfobj._cderi_dev
     sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
-    if sq is not None:
+    if sq is not None and b0 + nb <= sq.shape[0]:
         _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[b0:b0 + nb]), _c.c_long(sq.shape[2]), _c.c_int(sq.shape[1]),
               _c.c_int(nb), _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(out),
               _c.c_int(ldx), _c.c_void_p(0), _c.c_void_p(0), st)
@@ -421,6 +432,20 @@ def get_j(dfobj, dm, hermi=0, direct_scf_tol=1e-13):
                   _c.c_int(naux), _ptr(rho[s]), _ptr(vjtril[s, r0:r1]), st)
     _allreduce(dfobj, [vjtril])
     return _lib_mod.unpack_tril(vjtril.cpu().numpy(), 1).reshape(shape)
+
+
+def _dm_orbital_mismatch(dms_dev, orb_list, nao):
+    """0-dim device tensor max_s |D_s v - orb_s (orb_s^T v)| / max(1, |D_s v|) for one fixed pseudo-random vector: asynchronous
+    (no host sync here); ~0 when every D_s equals orb_s orb_s^T."""
+    torch = _torch()
+    gen = torch.Generator(device='cpu').manual_seed(20240601)
+    v = torch.rand(nao, dtype=torch.float64, generator=gen).to(dms_dev.device) - 0.5
+    worst = torch.zeros((), dtype=torch.float64, device=dms_dev.device)
+    for s_, (orb_s, _np, _ld) in enumerate(orb_list):
+        c_s = orb_s[:nao]
+        dv = dms_dev[s_] @ v
+        worst = torch.maximum(worst, (dv - c_s @ (c_s.T @ v)).abs().max() / dv.abs().max().clamp_min(1.0))
+    return worst
 
 
 def _dm_matches_orbitals(dms_dev, orb_list, nao):
@@ -596,18 +621,16 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         if any(n is not None for n in neg):
             neg_sets = neg
     promise = None
+    check = None
     if orb_list is not None and mo_coeff is not None and with_j and with_k:
-        # is D_s = orb_s orb_s^T?  make_rdm1 of this package says so in the tag; for a foreign tag (stock PySCF's
-        # lib.tag_array(dm, mo_coeff=, mo_occ=)) two host matrix-vector products decide - nothing on the device waits
+        # is D_s = orb_s orb_s^T?  make_rdm1 of this package says so in the tag.  For a foreign tag (stock PySCF's
+        # lib.tag_array(dm, mo_coeff=, mo_occ=); the reference itself trusts it for K, df_jk.py:340) the fused first J pass runs
+        # OPTIMISTICALLY and a device-side probe  max |D v - C (C^T v)|  travels back with the results: nothing waits for it, and
+        # in the rare case of a tag that does not match its matrix J is redone from the matrix by the two-pass kernels below.
         promise = getattr(dm, 'dm_from_orbitals', None)
         if promise is None:
-            v = np.random.RandomState(20240601).random_sample(nao) - 0.5
             promise = True
-            for k in range(nset):
-                ck = mo_coeff[k][:, mo_occ[k] > 0]
-                dv = dms[k].dot(v)
-                if np.abs(dv - (ck * mo_occ[k][mo_occ[k] > 0]).dot(ck.T.dot(v))).max() > 1e-10 * max(1.0, np.abs(dv).max()):
-                    promise = False
+            check = _dm_orbital_mismatch(dms_dev, orb_list, nao)
     elif neg_sets is not None or orb_list is not None:
         promise = False if neg_sets is not None else None
     vjtril, vk_dev = get_jk_device(dfobj, dms_dev, orb_list, with_j, with_k, dm_from_orbitals=promise)
@@ -618,7 +641,14 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         _allreduce(dfobj, [vk_neg])
         for j, k in enumerate(idx):
             vk_dev[k] -= vk_neg[j]
-    return _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k)
+    vj, vk = _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k)
+    if check is not None and float(check) > 1e-10:
+        # the tag did not describe the matrix: J from the matrix itself (the K of the MO branch follows the tag, as in the reference)
+        lib = _lib_mod.load_library()
+        vjtril = _vj(dfobj, lib, dms_dev, nset, nao)
+        _allreduce(dfobj, [vjtril])
+        vj = _to_host(dfobj, vjtril, None, nset, nao, dm_shape, True, False)[0]
+    return vj, vk
 
 
 def _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k):

@@ -350,3 +350,47 @@ def test_syrk_variants_give_the_same_exchange(flags, nao, naux, nocc):
     scale = max(1.0, np.abs(vk_np).max())
     assert np.abs(vk - vk_np).max() < 1e-11 * scale and np.abs(vk - vk0).max() < 1e-11 * scale
     assert np.abs(vk - vk.T).max() == 0 and np.abs(vj - vj0).max() < 1e-11 * max(1.0, np.abs(vj0).max())
+
+
+def test_partial_square_image():
+    """k_square = 'auto' with room for only some rows (taxol on one GPU): the rows that have an unpacked image go through the
+    square kernel, the rest through the packed-operand one, K blocks cut at the boundary; same J/K as without any image."""
+    from pyscf_amd import lib
+    nao, naux, nocc = 257, 301, 161
+    rng = np.random.default_rng(5)
+    cderi = rng.standard_normal((naux, nao * (nao + 1) // 2)) / np.sqrt(nao)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao)
+    occ[:nocc] = 2
+    dm = lib.tag_array((c * occ).dot(c.T), mo_coeff=c, mo_occ=occ)
+    ref_obj = _dfobj(None, cderi)
+    ref_obj.k_square = False
+    vj0, vk0 = ref_obj.get_jk(dm, hermi=1)
+    obj = _dfobj(None, cderi)
+    obj.k_square_max_rows = 150                    # -> 128 rows (multiple of 64) get an image
+    obj.k_block_bytes = 100 * 176 * 272 * 8        # ~100-row K blocks: 0-100, 100-128 | 128-228, 228-301
+    vj, vk = obj.get_jk(dm, hermi=1)
+    assert obj._cderi_sq is not None and obj._cderi_sq.shape[0] == 128
+    assert np.abs(vj - vj0).max() < 1e-11 * max(1.0, np.abs(vj0).max()) and np.abs(vk - vk0).max() < 1e-11 * max(1.0, np.abs(vk0).max())
+
+
+def test_foreign_tag_that_does_not_match_its_matrix(h2o):
+    """Stock PySCF tags a density with mo_coeff / mo_occ and trusts the tag for K only (df_jk.py:339-381: J from the matrix,
+    K from the orbitals, "#TODO: test whether dm.mo_coeff matching dm").  Here the first J pass is normally taken from the
+    orbitals (fused into the half transform); a device-side probe that travels back with the results catches a tag that does
+    not describe its matrix, and J is then redone from the matrix.  Consistent foreign tag: fused path, same numbers."""
+    from pyscf_amd import lib
+    mol, aux, cderi = h2o
+    obj = _dfobj(mol, cderi)
+    rng = np.random.default_rng(9)
+    c = np.linalg.qr(rng.standard_normal((mol.nao, mol.nao)))[0]
+    occ = np.zeros(mol.nao)
+    occ[:5] = 2
+    dm = (c * occ).dot(c.T)
+    vj0, vk0 = ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
+    vj, vk = obj.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=occ), hermi=1)           # foreign but consistent
+    assert obj._last_fused and np.abs(vj - vj0).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11
+    other = dm + 0.05 * np.eye(mol.nao)                                                # the tag no longer matches the matrix
+    vj1, _ = ref.get_jk(cderi, other, 1)
+    vj, vk = obj.get_jk(lib.tag_array(other, mo_coeff=c, mo_occ=occ), hermi=1)
+    assert np.abs(vj - vj1).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11
