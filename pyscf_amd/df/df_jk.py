@@ -224,8 +224,8 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
     kflags = getattr(dfobj, 'k_syrk_flags', None)
     if kflags is None and after_e2 is not None:
         # the second J pass runs beside this SYRK on the side stream: it hides in the 32 workgroup slots the plain 120 x 4 grid
-        # leaves idle (J/K 108.8 ms) but not beside the balanced schedule that fills them (110.0 ms; K alone: 35.6 vs 39.7 ms) -
-        # the chip is at its FP64-matrix power limit either way, so keep the plain grid when J co-runs
+        # leaves idle (J/K 108.8 ms) but not beside the balanced schedule that fills them (110.0 ms; K alone: 35.6 vs 39.7 ms): the
+        # SYRK's own L2 -> LDS panel traffic and the J stream share one path - plain grid when J co-runs
         kflags = 0
     syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit, kflags)
     vks = []
