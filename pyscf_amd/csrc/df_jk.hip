@@ -925,6 +925,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
 //   * diagonal tile I + one block of the odd last block row r:  slots {2I, 2I+1, r}: (2I,2I), (2I+1,2I), (2I+1,2I+1), (r,2I)
 //   * the other blocks of row r three at a time: slots {r, c1, c2, c3}: (r,c1), (r,c2), (r,c3) [+ the corner (r,r)]
 // 110 items with 435 live blocks instead of 120 tiles at nao = 1856.  k loop, DMA scheme and epilogue as gemm_tn_glds2.
+template <int PROBE>                  // PROBE = 1: benchmarking probe, skips the "B" DMA of every k-row (half the L2 -> LDS traffic, wrong results)
 __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
     const double *__restrict__ A, int lda, double *__restrict__ C, int ldc, int m, long kdim, const int *__restrict__ items,
     long kchunk)
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
     auto stage_row = [&](int k0, double *dst, int j) {
         const int k = wave * 4 + j;
         dma_row(r_a, dst + k * LDN, voff_a, (k0 + k) * lda8);
-        dma_row(r_a, dst + PA + k * LDN, voff_b, (k0 + k) * lda8);
+        if (PROBE == 0) dma_row(r_a, dst + PA + k * LDN, voff_b, (k0 + k) * lda8);
     };
     auto step = [&](const double *cur, double *nxt, int k0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1092,6 +1093,7 @@ static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: 
 static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
 static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
+static int g_syrk_probe = 0;  // benchmarking probe only: the re-tiled SYRK without its second panel DMA (results meaningless)
 static int g_syrk_slots = 1;  // SYRK on the re-tiled triangle (syrk_slots_kernel) when the matrix has an odd number of 64-column blocks
 static int g_syrk_frac = 1;   // balanced SYRK: full pieces + one short remainder piece per tile (dgemm_tn_impl)
 static int g_num_cu = 256;    // MI355X
@@ -1107,6 +1109,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "dmav2") == 0) { g_dma_v2 = value; return 0; }
     if (strcmp(key, "syrkfrac") == 0) { g_syrk_frac = value; return 0; }
     if (strcmp(key, "syrkslots") == 0) { g_syrk_slots = value; return 0; }
+    if (strcmp(key, "syrkprobe") == 0) { g_syrk_probe = value; return 0; }
     if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
@@ -1462,7 +1465,8 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
         if (rc) return rc;
         if (nitems > 0) {
             dim3 g2(nitems, nsplit);
-            syrk_slots_kernel<<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems));
+            if (g_syrk_probe) syrk_slots_kernel<1><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems));
+            else syrk_slots_kernel<0><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems));
             PAMD_CHECK_LAUNCH();
             return 0;
         }

@@ -348,9 +348,9 @@ def test_config5_h2o128_shard_jk_vs_oracle_golden():
     """BASELINE config 5 ((H2O)_128 cc-pVDZ, nao 3072, naux 14 848: a 560 GB tensor over 8 ranks) - rank 3's shard, 70 GB, built
     and contracted on one GPU by the production kernels (no collective: `_shard_override`) against the oracle:
       * sampled AO shells of the shard's tensor rows vs oracle integrals + the oracle's Cholesky factor, 1e-9,
-      * the shard's PARTIAL J/K of a seeded density supported on the first 8 molecules vs the golden that
-        tools/gen_golden_shard_local.py computed with the oracle alone (full nao x nao K_part, the nao x 192 rectangle of J_part,
-        rho_L of every row of the shard): every row of the shard enters, 1e-9 relative."""
+      * the shard's PARTIAL J/K of a seeded density supported on 8 molecules (the ones whose fitting functions open the shard's
+        row range) vs the golden that tools/gen_golden_shard_local.py computed with the oracle alone (full nao x nao K_part, the
+        nao x 192 rectangle of J_part): every row of the shard enters, 1e-9 relative."""
     import scipy.linalg
     import torch
     from oracle import golden_util
@@ -382,9 +382,10 @@ def test_config5_h2o128_shard_jk_vs_oracle_golden():
         worst = max(worst, float(np.abs(cd[:, pq0:pq1].cpu().numpy() - want).max()))
     assert worst < 1e-9, worst
     # partial J/K of the local seeded density
-    ns, nsyn = g['support_aos'], g['nsyn']
+    (a0, a1), nsyn = g['support_ao_range'], g['nsyn']
+    ns = a1 - a0
     c = np.zeros((nao, nsyn))
-    c[:ns] = golden_util.synthetic_orbitals(ns, nsyn) * np.sqrt(2.0)
+    c[a0:a1] = golden_util.synthetic_orbitals(ns, nsyn) * np.sqrt(2.0)
     dev = cd.device
     dm = torch.from_numpy(c.dot(c.T)[None]).to(dev)
     vjt, vk = df_jk.get_jk_device(obj, dm, [df_jk.pad_orbitals(c, dev)])
@@ -395,7 +396,7 @@ def test_config5_h2o128_shard_jk_vs_oracle_golden():
     assert abs(np.linalg.norm(vk) - g['vk_norm']) < 1e-9 * g['vk_norm']
     assert abs(golden_util.fp(vk) - g['vk_fp']) < 1e-8 * g['vk_norm']
     _check_samples(vk[ri, ci], g['vk_sample'], g['vk_absmax'])
-    rect = vj[:, :ns]
+    rect = vj[:, a0:a1]
     assert abs(np.linalg.norm(rect) - g['vj_rect_norm']) < 1e-9 * g['vj_rect_norm']
     assert abs(golden_util.fp(rect) - g['vj_rect_fp']) < 1e-8 * g['vj_rect_norm']
     _check_samples(rect[ri, ci % ns], g['vj_rect_sample'], g['vj_rect_absmax'])
