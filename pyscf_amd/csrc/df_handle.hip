@@ -17,9 +17,10 @@
 // handle per thread at a time (not re-entrant).  Host work here is the one-time table preparation that
 // pyscf_amd/gto/moleintor.py does in numpy (segmented shells, primitive-pair records, cart->sph matrices); the numerical work
 // is the same kernel family (PAMD_int3c2e_class, PAMD_cderi_solve, PAMD_nr_e2_*, PAMD_dgemm_tn, PAMD_df_vj_pass*).
-// The metric factorisation uses rocSOLVER's potrf (and syevd for a linearly dependent metric, `lindep`, df/incore.py:263-270)
-// and rocBLAS dgemm for the block forward substitution of L^-1 - library calls for the one-time O(naux^3) step that the
-// reference hands to LAPACK (df/incore.py:154) - resolved with dlopen so that libpyscf_amd.so itself links nothing new.
+// The metric factorisation (the reference hands it to LAPACK, df/incore.py:154) is a right-looking blocked Cholesky + block
+// forward substitution for L^-1 on this library's own FP64-MFMA GEMMs (PAMD_dgemm_nt / _tn), 256 x 256 diagonal blocks on the
+// host; only a linearly dependent metric (`lindep`, df/incore.py:263-270) needs rocSOLVER's syevd, resolved with dlopen on that
+// rare path, so that libpyscf_amd.so itself links nothing new and a cold start does not pay for loading rocBLAS / rocSOLVER.
 #include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
@@ -292,7 +293,7 @@ struct RocLib {
         dgemm = (decltype(dgemm))dlsym(hblas, "rocblas_dgemm");
         dpotrf = (decltype(dpotrf))dlsym(hsolver, "rocsolver_dpotrf");
         dsyevd = (decltype(dsyevd))dlsym(hsolver, "rocsolver_dsyevd");
-        PAMD_REQUIRE(create && destroy && set_stream && dgemm && dpotrf && dsyevd, "rocBLAS / rocSOLVER symbols missing");
+        PAMD_REQUIRE(create && destroy && set_stream && dsyevd, "rocBLAS / rocSOLVER symbols missing");
         PAMD_REQUIRE(create(&handle) == 0, "rocblas_create_handle failed");
         return 0;
     }
@@ -382,75 +383,144 @@ void slab_rows(const Shells &ao, int sh0, int sh1, long *r0, long *r1)
     *r1 = p1 * (p1 + 1) / 2;
 }
 
+__global__ void negate_copy_kernel(const double *__restrict__ src, long lds, double *__restrict__ dst, long ldd, long rows, int cols)
+{
+    const long r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x)
+        if (r < rows) dst[r * ldd + c] = -src[r * lds + c];
+}
+
+// Lower Cholesky factor of the symmetric row-major matrix d_a (n x n), in place, right-looking blocked: the diagonal block is
+// factorised and inverted on the host (nbk^3, negligible), the panel solve and the trailing update are FP64-MFMA GEMMs of this
+// library (PAMD_dgemm_nt).  *info = 0 on success, else the 1-based column of the first non-positive pivot (the matrix is then
+// left half-factorised: the caller falls back to the eigen-decomposition from a fresh copy).  The strict upper triangle is junk.
+int chol_blocked(PAMD_df *h, double *d_a, int n, int *info)
+{
+    const int nbk = 256;
+    int rc;
+    *info = 0;
+    double *d_p = nullptr, *d_n = nullptr, *d_dinv = nullptr;
+    if ((rc = h->pool.alloc((void **)&d_p, (size_t)n * nbk * 8)) || (rc = h->pool.alloc((void **)&d_n, (size_t)n * nbk * 8)) ||
+        (rc = h->pool.alloc((void **)&d_dinv, (size_t)nbk * nbk * 8)))
+        return rc;
+    std::vector<double> d((size_t)nbk * nbk), dinv((size_t)nbk * nbk);
+    for (int j0 = 0; j0 < n && *info == 0; j0 += nbk) {
+        const int bj = std::min(nbk, n - j0), j1 = j0 + bj;
+        PAMD_CHECK_HIP(hipMemcpy2DAsync(d.data(), (size_t)bj * 8, d_a + (size_t)j0 * n + j0, (size_t)n * 8, (size_t)bj * 8, bj,
+                                        hipMemcpyDeviceToHost, h->st));
+        PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+        for (int c = 0; c < bj && *info == 0; c++) {                 // unblocked Cholesky of the diagonal block (lower, row-major)
+            double s = d[(size_t)c * bj + c];
+            for (int k = 0; k < c; k++) s -= d[(size_t)c * bj + k] * d[(size_t)c * bj + k];
+            if (!(s > 0.0)) { *info = j0 + c + 1; break; }
+            const double lcc = std::sqrt(s);
+            d[(size_t)c * bj + c] = lcc;
+            for (int r = c + 1; r < bj; r++) {
+                double t = d[(size_t)r * bj + c];
+                for (int k = 0; k < c; k++) t -= d[(size_t)r * bj + k] * d[(size_t)c * bj + k];
+                d[(size_t)r * bj + c] = t / lcc;
+            }
+            for (int k = c + 1; k < bj; k++) d[(size_t)c * bj + k] = 0.0;
+        }
+        if (*info) break;
+        std::fill(dinv.begin(), dinv.end(), 0.0);
+        for (int c = 0; c < bj; c++) {                               // inverse of the lower block by forward substitution
+            dinv[(size_t)c * bj + c] = 1.0 / d[(size_t)c * bj + c];
+            for (int r = c + 1; r < bj; r++) {
+                double t = 0;
+                for (int k = c; k < r; k++) t += d[(size_t)r * bj + k] * dinv[(size_t)k * bj + c];
+                dinv[(size_t)r * bj + c] = -t / d[(size_t)r * bj + r];
+            }
+        }
+        PAMD_CHECK_HIP(hipMemcpy2DAsync(d_a + (size_t)j0 * n + j0, (size_t)n * 8, d.data(), (size_t)bj * 8, (size_t)bj * 8, bj,
+                                        hipMemcpyHostToDevice, h->st));
+        if (j1 < n) {
+            const long mrem = n - j1;
+            PAMD_CHECK_HIP(hipMemcpyAsync(d_dinv, dinv.data(), (size_t)bj * bj * 8, hipMemcpyHostToDevice, h->st));
+            PAMD_CHECK_HIP(hipMemsetAsync(d_p, 0, (size_t)mrem * bj * 8, h->st));
+            // P = A21 L11^-T:  P[m][c] = sum_k A21[m][k] Dinv[c][k]
+            if ((rc = PAMD_dgemm_nt(d_a + (size_t)j1 * n + j0, n, d_dinv, bj, d_p, bj, (int)mrem, bj, bj, 1, h->st))) return rc;
+            PAMD_CHECK_HIP(hipMemcpy2DAsync(d_a + (size_t)j1 * n + j0, (size_t)n * 8, d_p, (size_t)bj * 8, (size_t)bj * 8, mrem,
+                                            hipMemcpyDeviceToDevice, h->st));
+            negate_copy_kernel<<<(unsigned)mrem, 256, 0, h->st>>>(d_p, bj, d_n, bj, mrem, bj);
+            PAMD_CHECK_LAUNCH();
+            // trailing update A22 -= P P^T (the full square: the upper half is junk anyway)
+            if ((rc = PAMD_dgemm_nt(d_n, bj, d_p, bj, d_a + (size_t)j1 * n + j1, n, (int)mrem, (int)mrem, bj, 1, h->st))) return rc;
+        }
+        PAMD_CHECK_HIP(hipStreamSynchronize(h->st));                 // d / dinv (host) are reused by the next block column
+    }
+    h->pool.release(d_p); h->pool.release(d_n); h->pool.release(d_dinv);
+    return 0;
+}
+
 // M with cderi = M (Q|pq): rows of L^-1 (Cholesky) or (V / sqrt(w))^T over the eigenvalues > lindep (df/incore.py:153-158,
 // 263-270).  Returns M^T as mt[naux][lda] on the host (lda = round_up(nrow, 16), zero padded) and the triangular flag.
-int decompose_metric(PAMD_df *h, RocLib &roc, double *d_j2c, int naux, double lindep, std::vector<double> *mt, int *nrow, int *lda,
-                     int *tri)
+int decompose_metric(PAMD_df *h, double *d_j2c, int naux, double lindep, std::vector<double> *mt, int *nrow, int *lda, int *tri)
 {
     int rc;
-    if ((rc = roc.open())) return rc;
-    roc.set_stream(roc.handle, h->st);
     const size_t n2 = (size_t)naux * naux;
     double *d_a = nullptr;
-    int *d_info = nullptr;
-    if ((rc = h->pool.alloc((void **)&d_a, n2 * 8)) || (rc = h->pool.alloc((void **)&d_info, 64))) return rc;
+    if ((rc = h->pool.alloc((void **)&d_a, n2 * 8))) return rc;
     PAMD_CHECK_HIP(hipMemcpyAsync(d_a, d_j2c, n2 * 8, hipMemcpyDeviceToDevice, h->st));
-    // column-major 'upper' Cholesky of the symmetric matrix = row-major lower factor L (A = L L^T) in the same memory
-    PAMD_REQUIRE(roc.dpotrf(roc.handle, ROC_FILL_UPPER, naux, d_a, naux, d_info) == 0, "rocsolver_dpotrf failed");
     int info = 0;
-    PAMD_CHECK_HIP(hipMemcpyAsync(&info, d_info, 4, hipMemcpyDeviceToHost, h->st));
-    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+    if ((rc = chol_blocked(h, d_a, naux, &info))) return rc;
     if (info == 0) {
-        // L^-1 by block forward substitution (the scheme of pyscf_amd/df/incore.py:_tri_inverse_dev): diagonal blocks on the
-        // host, Linv[i, :i] = -Dinv (L[i, :i] Linv[:i, :i]) as two device GEMMs per block row (row-major via swapped operands)
-        const int blk = 512;
-        double *d_inv = nullptr, *d_tmp = nullptr, *d_dinv = nullptr;
-        if ((rc = h->pool.alloc((void **)&d_inv, n2 * 8)) || (rc = h->pool.alloc((void **)&d_tmp, (size_t)blk * naux * 8)) ||
-            (rc = h->pool.alloc((void **)&d_dinv, (size_t)blk * blk * 8)))
+        // W = (L^-1)^T (upper triangular, row-major) by block forward substitution (the scheme of pyscf_amd/df/incore.py:
+        // _tri_inverse_dev): W[i, i] = Dinv_i^T on the host, W[:i0, i] = -(L[i, :i0] Linv[:i0, :i0])^T Dinv_i^T as two GEMMs of
+        // this library per block row:  T = L[i,:i0] W[:i0,:i0]^T (NT),  W[:i0, i] += T^T (-Dinv_i^T) (TN)
+        const int blk = 256;
+        double *d_w = nullptr, *d_t = nullptr, *d_dt = nullptr;
+        if ((rc = h->pool.alloc((void **)&d_w, n2 * 8)) || (rc = h->pool.alloc((void **)&d_t, (size_t)blk * naux * 8)) ||
+            (rc = h->pool.alloc((void **)&d_dt, (size_t)blk * blk * 8)))
             return rc;
-        PAMD_CHECK_HIP(hipMemsetAsync(d_inv, 0, n2 * 8, h->st));
-        std::vector<double> dblk((size_t)blk * blk), dinv((size_t)blk * blk);
-        const double one = 1.0, zero = 0.0, mone = -1.0;
+        PAMD_CHECK_HIP(hipMemsetAsync(d_w, 0, n2 * 8, h->st));
+        std::vector<double> dblk((size_t)blk * blk), dinv((size_t)blk * blk), dneg((size_t)blk * blk);
         for (int i0 = 0; i0 < naux; i0 += blk) {
             const int bi = std::min(blk, naux - i0);
             PAMD_CHECK_HIP(hipMemcpy2DAsync(dblk.data(), (size_t)bi * 8, d_a + (size_t)i0 * naux + i0, (size_t)naux * 8,
                                             (size_t)bi * 8, bi, hipMemcpyDeviceToHost, h->st));
             PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
             std::fill(dinv.begin(), dinv.end(), 0.0);
-            for (int c = 0; c < bi; c++) {                       // forward substitution, column c of the inverse
+            for (int c = 0; c < bi; c++) {
                 dinv[(size_t)c * bi + c] = 1.0 / dblk[(size_t)c * bi + c];
                 for (int r = c + 1; r < bi; r++) {
-                    double s = 0;
-                    for (int k = c; k < r; k++) s += dblk[(size_t)r * bi + k] * dinv[(size_t)k * bi + c];
-                    dinv[(size_t)r * bi + c] = -s / dblk[(size_t)r * bi + r];
+                    double t = 0;
+                    for (int k = c; k < r; k++) t += dblk[(size_t)r * bi + k] * dinv[(size_t)k * bi + c];
+                    dinv[(size_t)r * bi + c] = -t / dblk[(size_t)r * bi + r];
                 }
             }
-            PAMD_CHECK_HIP(hipMemcpyAsync(d_dinv, dinv.data(), (size_t)bi * bi * 8, hipMemcpyHostToDevice, h->st));
-            PAMD_CHECK_HIP(hipMemcpy2DAsync(d_inv + (size_t)i0 * naux + i0, (size_t)naux * 8, d_dinv, (size_t)bi * 8, (size_t)bi * 8,
-                                            bi, hipMemcpyDeviceToDevice, h->st));
+            // diagonal block of W: Dinv^T; operand of the second GEMM: B[k][n] = -Dinv[n][k]
+            for (int r = 0; r < bi; r++)
+                for (int c = 0; c < bi; c++) { dblk[(size_t)r * bi + c] = dinv[(size_t)c * bi + r]; dneg[(size_t)r * bi + c] = -dinv[(size_t)c * bi + r]; }
+            PAMD_CHECK_HIP(hipMemcpy2DAsync(d_w + (size_t)i0 * naux + i0, (size_t)naux * 8, dblk.data(), (size_t)bi * 8, (size_t)bi * 8,
+                                            bi, hipMemcpyHostToDevice, h->st));
             if (i0) {
-                // tmp (bi x i0) = L[i0:i1, :i0] (bi x i0) * Linv[:i0, :i0]   -> column-major: tmp^T = Linv^T L^T
-                PAMD_REQUIRE(roc.dgemm(roc.handle, ROC_OP_N, ROC_OP_N, i0, bi, i0, &one, d_inv, naux, d_a + (size_t)i0 * naux, naux,
-                                       &zero, d_tmp, i0) == 0, "rocblas_dgemm failed");
-                // Linv[i0:i1, :i0] = -Dinv (bi x bi) * tmp (bi x i0)
-                PAMD_REQUIRE(roc.dgemm(roc.handle, ROC_OP_N, ROC_OP_N, i0, bi, bi, &mone, d_tmp, i0, d_dinv, bi, &zero,
-                                       d_inv + (size_t)i0 * naux, naux) == 0, "rocblas_dgemm failed");
+                PAMD_CHECK_HIP(hipMemcpyAsync(d_dt, dneg.data(), (size_t)bi * bi * 8, hipMemcpyHostToDevice, h->st));
+                PAMD_CHECK_HIP(hipMemsetAsync(d_t, 0, (size_t)bi * i0 * 8, h->st));
+                // T[m][c] = sum_k L[i0 + m][k] Linv[k][c] = sum_k L[i0 + m][k] W[c][k]      (m < bi, c < i0, k < i0)
+                if ((rc = PAMD_dgemm_nt(d_a + (size_t)i0 * naux, naux, d_w, naux, d_t, i0, bi, i0, i0, 1, h->st))) return rc;
+                // W[c][i0 + n] += sum_k T[k][c] (-Dinv[n][k])                                   (c < i0, n < bi, k < bi)
+                if ((rc = PAMD_dgemm_tn(d_t, i0, d_dt, bi, d_w + i0, naux, i0, bi, bi, 0, 1, h->st))) return rc;
             }
-            PAMD_CHECK_HIP(hipStreamSynchronize(h->st));         // dinv (host) is reused by the next block
+            PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
         }
-        std::vector<double> linv(n2);
-        PAMD_CHECK_HIP(hipMemcpy(linv.data(), d_inv, n2 * 8, hipMemcpyDeviceToHost));
         *nrow = naux;
         *lda = (int)std::max<long>(round_up(naux, 16), 16);
         mt->assign((size_t)naux * *lda, 0.0);
-        for (int m = 0; m < naux; m++)
-            for (int q = 0; q <= m; q++) (*mt)[(size_t)q * *lda + m] = linv[(size_t)m * naux + q];
+        PAMD_CHECK_HIP(hipMemcpy2D(mt->data(), (size_t)*lda * 8, d_w, (size_t)naux * 8, (size_t)naux * 8, naux, hipMemcpyDeviceToHost));
         *tri = 1;
-        h->pool.release(d_inv); h->pool.release(d_tmp); h->pool.release(d_dinv);
+        h->pool.release(d_w); h->pool.release(d_t); h->pool.release(d_dt);
     } else {
-        // metric not positive definite: eigen-decomposition, keep w > lindep (pyscf/df/incore.py:263-270)
+        // metric not positive definite: eigen-decomposition, keep w > lindep (pyscf/df/incore.py:263-270) - rocSOLVER's syevd,
+        // resolved with dlopen only on this rare path
+        static RocLib roc;                 // one rocBLAS handle per process (creating one loads the library's kernels: seconds)
+        if ((rc = roc.open())) return rc;
+        roc.set_stream(roc.handle, h->st);
         double *d_w = nullptr, *d_e = nullptr;
-        if ((rc = h->pool.alloc((void **)&d_w, (size_t)naux * 8)) || (rc = h->pool.alloc((void **)&d_e, (size_t)naux * 8))) return rc;
+        int *d_info = nullptr;
+        if ((rc = h->pool.alloc((void **)&d_w, (size_t)naux * 8)) || (rc = h->pool.alloc((void **)&d_e, (size_t)naux * 8)) ||
+            (rc = h->pool.alloc((void **)&d_info, 64)))
+            return rc;
         PAMD_CHECK_HIP(hipMemcpyAsync(d_a, d_j2c, n2 * 8, hipMemcpyDeviceToDevice, h->st));
         PAMD_REQUIRE(roc.dsyevd(roc.handle, ROC_EVECT_ORIGINAL, ROC_FILL_UPPER, naux, d_a, naux, d_w, d_e, d_info) == 0,
                      "rocsolver_dsyevd failed");
@@ -471,10 +541,9 @@ int decompose_metric(PAMD_df *h, RocLib &roc, double *d_j2c, int naux, double li
             for (int q = 0; q < naux; q++) (*mt)[(size_t)q * *lda + j] = v[(size_t)m * naux + q] * f;
         }
         *tri = 0;
-        h->pool.release(d_w); h->pool.release(d_e);
+        h->pool.release(d_w); h->pool.release(d_e); h->pool.release(d_info);
     }
     h->pool.release(d_a);
-    h->pool.release(d_info);
     return 0;
 }
 
@@ -570,10 +639,7 @@ int PAMD_df_create(const int *atm, int natm, const int *bas, int nbas_ao, int nb
     }
     std::vector<double> mt;
     int nrow = 0, lda = 0, tri = 0;
-    {
-        static RocLib roc;                 // one rocBLAS handle per process (creating one loads the library's kernels: seconds)
-        if ((rc = decompose_metric(h, roc, d_j2c, naux, lindep, &mt, &nrow, &lda, &tri))) return rc;
-    }
+    if ((rc = decompose_metric(h, d_j2c, naux, lindep, &mt, &nrow, &lda, &tri))) return rc;
     tmp.release(d_j2c);
     h->nL = nrow;
     double *d_mt = nullptr;
