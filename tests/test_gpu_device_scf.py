@@ -80,3 +80,26 @@ def test_device_loop_vs_oracle_scf():
     assert conv
     md, ed = _run(mol, '', True)
     assert abs(ed - e0) < 1e-8, (ed, e0)
+
+
+@pytest.mark.gpu
+def test_device_loop_sp2_on_the_syrk_kernel():
+    """From 256 orbitals the purification squares its matrix on the product's own SYRK kernel (device_scf._SymSquare) instead of a
+    library GEMM: (H2O)_5 cc-pVTZ, 290 orbitals zero-padded to 304, device loop = host loop."""
+    from pyscf_amd import gto
+    from pyscf_amd.data import clusters
+    mol = gto.M(atom=clusters.water_cluster(5), basis='cc-pvtz')
+    assert mol.nao == 290
+    mh, eh = _run(mol, '', False)
+    md, ed = _run(mol, '', True)
+    assert mh.converged and md.converged and abs(eh - ed) < 2e-9, (eh, ed)
+    assert getattr(md, '_purify_iters', 0) > 0
+    # the squaring itself
+    import torch
+    from pyscf_amd.scf.device_scf import _SymSquare
+    a = torch.randn(290, 290, dtype=torch.float64, device='cuda')
+    a = (a + a.T) * 0.5
+    sq = _SymSquare(290, a.device)
+    x2 = sq.square(sq.pad(a, 0), 1)
+    assert float((x2[:290, :290] - a @ a).abs().max()) < 1e-11 * float((a @ a).abs().max())
+    assert float(x2[290:].abs().max()) == 0 and float((x2 - x2.T).abs().max()) == 0
