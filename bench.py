@@ -418,7 +418,9 @@ def main():
         'config': {'workload': '%s %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM%s'
                                % (label, args.basis, _aux_label(getattr(dfobj.auxmol, 'basis', 'auto')),
                                   nao, naux, nocc, 8e-9 * naux * npair,
-                                  ' + unpacked image for the K half transform' if getattr(dfobj, '_cderi_sq', None) is not None else ''),
+                                  '' if getattr(dfobj, '_cderi_sq', None) is None else
+                                  ' + unpacked image for the K half transform' + ('' if dfobj._cderi_sq.shape[0] == naux_local else
+                                  ' (of %d of the %d aux rows: what fits)' % (dfobj._cderi_sq.shape[0], naux_local))),
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
                    'naux_local': naux_local, 'naux_per_rank': naux_per_rank},
         'value_host_api_ms': round(host_api_ms, 3), 'host_api_fused_j': host_fused,
