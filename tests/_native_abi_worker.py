@@ -12,10 +12,16 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    import time as _t
+    _t0 = _t.perf_counter()
+
+    def stamp(what):
+        print('[%7.2f s] %s' % (_t.perf_counter() - _t0, what), flush=True)
     from oracle import ref
     from pyscf_amd import gto, lib
     from pyscf_amd.df import addons, native
     assert 'torch' not in sys.modules
+    stamp('imports done')
     h2o = 'O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587'
     mol = gto.M(atom=h2o, basis='cc-pvdz')
     import time
@@ -24,6 +30,7 @@ def main():
     print('first PAMD_df_create (HIP + rocBLAS / rocSOLVER start-up included): %.2f s' % (time.perf_counter() - t0), flush=True)
     nao = mol.nao
     assert obj.get_naoaux() == 71
+    stamp('first handle built')
     assert native.NativeDF(mol).get_naoaux() == 116                        # default aux basis, test_df.py:53
     # G4: general-DM branch, two densities
     np.random.seed(1)
@@ -34,6 +41,7 @@ def main():
     vj1, none = obj.get_jk(dms, hermi=0, with_k=False)
     none2, vk1 = obj.get_jk(dms, hermi=0, with_j=False)
     assert none is None and none2 is None and np.abs(vj1 - vj).max() < 1e-12 and np.abs(vk1 - vk).max() < 1e-12
+    stamp('G4 / G6 goldens done')
     # the tensor itself, row block by row block (DF.loop)
     aux = addons.make_auxmol(mol, 'weigend')
     cderi = ref.cholesky_eri(mol, aux)
@@ -69,6 +77,7 @@ def main():
         vj0, vk0 = ref.get_jk(cd, dms2, 1)
         assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9
         o2.reset()
+    stamp('MO branch cases done')
     # linearly dependent metric: two copies of the aux basis on the same atoms -> Cholesky fails, eigen-decomposition path
     dup = gto.M(atom=h2o, basis='sto-3g')
     aux1 = addons.make_auxmol(dup, 'weigend')
@@ -84,6 +93,7 @@ def main():
     got = np.vstack(list(o3.loop()))
     assert np.abs(got.T.dot(got) - cd1.T.dot(cd1)).max() < 1e-7                      # same fitted (pq|rs)
     assert 'torch' not in sys.modules
+    stamp('linearly dependent metric done')
     print('NATIVE_ABI_OK', flush=True)
 
 

@@ -14,6 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_host_array_abi_from_numpy_without_torch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_native_abi_worker.py')], capture_output=True, text=True,
                        timeout=900)
+    try:                                               # keep the worker's timing lines where a GPU-box run can be inspected
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'native_abi_worker.log'), 'w') as f:
+            f.write(p.stdout + p.stderr[-2000:])
+    except OSError:
+        pass
     assert p.returncode == 0 and 'NATIVE_ABI_OK' in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
