@@ -25,6 +25,9 @@ def test_config3_converged_energy_vs_oracle_golden(xc):
     e = mf.kernel()
     assert mf.converged
     assert abs(e - g[key]) < 1e-8, (e, g[key])
+    if key + '_unseeded' in g:                     # the oracle's independent run (its own start density, no product data)
+        assert 'no product data' in g[key + '_unseeded_note']
+        assert abs(e - g[key + '_unseeded']) < 1e-8, (e, g[key + '_unseeded'])
     mf.with_df.reset()
     del mf
     torch.cuda.empty_cache()

@@ -37,6 +37,9 @@ ap.add_argument('--rks', default='', help="also converge DF-RKS with this functi
 ap.add_argument('--dm0', default='', help='.npy start density for the SCF runs (any source: the converged energy does not '
                 'depend on it beyond conv_tol)')
 ap.add_argument('--conv-tol', type=float, default=1e-10)
+ap.add_argument('--rks-key-suffix', default='', help="store the DF-RKS energy under 'e_rks_<xc><suffix>' (e.g. _unseeded with "
+                "--dm0 <the oracle's own RHF density>)")
+ap.add_argument('--rks-conv-tol', type=float, default=0.0, help='conv_tol of the DF-RKS run (default: --conv-tol)')
 ap.add_argument('--unseeded', action='store_true', help="also converge DF-RHF from a start density made by the ORACLE ALONE "
                 "(superposition of the oracle's own converged monomer densities; no density from anywhere else; key "
                 "e_rhf_unseeded) - the independent-SCF golden VERDICT r02 asked for")
@@ -176,7 +179,7 @@ if a.unseeded and 'e_rhf_unseeded' not in res:
     save()
     log('E(DF-RHF, unseeded) = %.12f' % e)
 
-if a.rks and ('e_rks_' + a.rks) not in res:
+if a.rks and ('e_rks_' + a.rks + a.rks_key_suffix) not in res:
     from oracle import ref_dft
     from pyscf_amd.dft import libxc
     hyb, fac = libxc.parse_xc(a.rks)
@@ -201,9 +204,13 @@ if a.rks and ('e_rks_' + a.rks) not in res:
         return n, e, v
     ref_dft.nr_rks = lambda m, c_, w_, f_, g_, dm: nr_rks_blocked(dm)       # rks_energy calls nr_rks(mol, coords, ...)
     start = dm0 if dm0 is not None else np.load(os.path.join(a.scratch, tag + '_rhf_dm.npy'))
-    e = ref_dft.rks_energy(mol, fac, hyb, gga, coords, weights, lambda d, c, o, wk: jk(d, c, o), conv_tol=a.conv_tol,
-                           verbose=True, dm0=start, h1e=h1e, s1e=s1e)[1]
-    res['e_rks_' + a.rks] = float(e)
+    e = ref_dft.rks_energy(mol, fac, hyb, gga, coords, weights, lambda d, c, o, wk: jk(d, c, o),
+                           conv_tol=a.rks_conv_tol or a.conv_tol, verbose=True, dm0=start, h1e=h1e, s1e=s1e)[1]
+    res['e_rks_' + a.rks + a.rks_key_suffix] = float(e)
+    if a.rks_key_suffix:
+        res['e_rks_' + a.rks + a.rks_key_suffix + '_note'] = (
+            'DF-RKS %s converged by oracle/ref_dft.rks_energy (conv_tol %g) from %s; no product data on the path'
+            % (a.rks, a.rks_conv_tol or a.conv_tol, os.path.basename(a.dm0) if a.dm0 else "the oracle's DF-RHF density"))
     res['ngrids'] = int(len(weights))
     save()
     log('E(DF-RKS %s) = %.12f' % (a.rks, e))
