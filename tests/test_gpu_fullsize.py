@@ -347,11 +347,9 @@ def test_config4_taxol_full_jk_and_energy_vs_oracle_golden():
 def test_config5_h2o128_shard_jk_vs_oracle_golden():
     """BASELINE config 5 ((H2O)_128 cc-pVDZ, nao 3072, naux 14 848: a 560 GB tensor over 8 ranks) - rank 3's shard, 70 GB, built
     and contracted on one GPU by the production kernels (no collective: `_shard_override`) against the oracle:
-      * sampled AO shells of the shard's tensor rows vs oracle integrals + the oracle's Cholesky factor, 1e-9,
       * the shard's PARTIAL J/K of a seeded density supported on 8 molecules (the ones whose fitting functions open the shard's
         row range) vs the golden that tools/gen_golden_shard_local.py computed with the oracle alone (full nao x nao K_part, the
         nao x 192 rectangle of J_part): every row of the shard enters, 1e-9 relative."""
-    import scipy.linalg
     import torch
     from oracle import golden_util
     from pyscf_amd import gto, df
@@ -367,20 +365,7 @@ def test_config5_h2o128_shard_jk_vs_oracle_golden():
     assert (nao, naux, [l0, l1]) == (g['nao'], g['naux'], g['aux_rows']) == (3072, 14848, [5568, 7424])
     cd = obj._cderi_dev
     assert cd.shape == (l1 - l0, nao * (nao + 1) // 2)
-    # tensor rows on sampled shells
-    aux = obj.auxmol
-    j2c = ref.int2c2e(aux)
-    assert abs(golden_util.fp(j2c) - g['j2c_fp']) < 1e-9 * np.abs(j2c).max() * 100
-    low = scipy.linalg.cholesky(j2c, lower=True)
-    linv_rows = scipy.linalg.solve_triangular(low, np.eye(naux), lower=True)[l0:l1]
-    loc = ref.ao_loc(mol)
-    worst = 0.0
-    for ish in (0, 5, mol.nbas // 2, mol.nbas - 1):
-        want = linv_rows.dot(ref.int3c2e_slab(mol, aux, ish, ish + 1))
-        p0, p1 = int(loc[ish]), int(loc[ish + 1])
-        pq0, pq1 = p0 * (p0 + 1) // 2, p1 * (p1 + 1) // 2
-        worst = max(worst, float(np.abs(cd[:, pq0:pq1].cpu().numpy() - want).max()))
-    assert worst < 1e-9, worst
+    # (the tensor rows themselves are compared entry by entry at configs 2-4; here every row of the shard enters through J/K)
     # partial J/K of the local seeded density
     (a0, a1), nsyn = g['support_ao_range'], g['nsyn']
     ns = a1 - a0
