@@ -383,6 +383,47 @@ void slab_rows(const Shells &ao, int sh0, int sh1, long *r0, long *r1)
     *r1 = p1 * (p1 + 1) / 2;
 }
 
+// Cyclic Jacobi eigen-solver for a small symmetric matrix (row-major a[n][n], destroyed): w[k] eigenvalues, v[k][n] the
+// eigenvector of w[k] (rows).  Used for linearly dependent metrics up to HOST_EIG_MAX functions; larger ones go to rocSOLVER.
+constexpr int HOST_EIG_MAX = 768;
+void jacobi_eig(int n, std::vector<double> &a, std::vector<double> &w, std::vector<double> &v)
+{
+    v.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++) v[(size_t)i * n + i] = 1.0;          // v holds V^T: row k = eigenvector k
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++) {
+            diag += a[(size_t)i * n + i] * a[(size_t)i * n + i];
+            for (int j = 0; j < i; j++) off += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+        }
+        if (off <= 1e-30 * (diag + off) || off == 0.0) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = a[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double app = a[(size_t)p * n + p], aqq = a[(size_t)q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; k++) {                        // columns p, q of A
+                    const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+                    a[(size_t)k * n + p] = c * akp - sn * akq;
+                    a[(size_t)k * n + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {                        // rows p, q of A and of V^T
+                    const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+                    a[(size_t)p * n + k] = c * apk - sn * aqk;
+                    a[(size_t)q * n + k] = sn * apk + c * aqk;
+                    const double vpk = v[(size_t)p * n + k], vqk = v[(size_t)q * n + k];
+                    v[(size_t)p * n + k] = c * vpk - sn * vqk;
+                    v[(size_t)q * n + k] = sn * vpk + c * vqk;
+                }
+            }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; i++) w[i] = a[(size_t)i * n + i];
+}
+
 __global__ void negate_copy_kernel(const double *__restrict__ src, long lds, double *__restrict__ dst, long ldd, long rows, int cols)
 {
     const long r = blockIdx.x;
@@ -511,25 +552,35 @@ int decompose_metric(PAMD_df *h, double *d_j2c, int naux, double lindep, std::ve
         *tri = 1;
         h->pool.release(d_w); h->pool.release(d_t); h->pool.release(d_dt);
     } else {
-        // metric not positive definite: eigen-decomposition, keep w > lindep (pyscf/df/incore.py:263-270) - rocSOLVER's syevd,
-        // resolved with dlopen only on this rare path
-        static RocLib roc;                 // one rocBLAS handle per process (creating one loads the library's kernels: seconds)
-        if ((rc = roc.open())) return rc;
-        roc.set_stream(roc.handle, h->st);
-        double *d_w = nullptr, *d_e = nullptr;
-        int *d_info = nullptr;
-        if ((rc = h->pool.alloc((void **)&d_w, (size_t)naux * 8)) || (rc = h->pool.alloc((void **)&d_e, (size_t)naux * 8)) ||
-            (rc = h->pool.alloc((void **)&d_info, 64)))
-            return rc;
-        PAMD_CHECK_HIP(hipMemcpyAsync(d_a, d_j2c, n2 * 8, hipMemcpyDeviceToDevice, h->st));
-        PAMD_REQUIRE(roc.dsyevd(roc.handle, ROC_EVECT_ORIGINAL, ROC_FILL_UPPER, naux, d_a, naux, d_w, d_e, d_info) == 0,
-                     "rocsolver_dsyevd failed");
-        PAMD_CHECK_HIP(hipMemcpyAsync(&info, d_info, 4, hipMemcpyDeviceToHost, h->st));
-        PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
-        PAMD_REQUIRE(info == 0, "rocsolver_dsyevd did not converge");
-        std::vector<double> w(naux), v(n2);                       // column-major eigenvectors: row m of the buffer = vector m
-        PAMD_CHECK_HIP(hipMemcpy(w.data(), d_w, (size_t)naux * 8, hipMemcpyDeviceToHost));
-        PAMD_CHECK_HIP(hipMemcpy(v.data(), d_a, n2 * 8, hipMemcpyDeviceToHost));
+        // metric not positive definite: eigen-decomposition, keep w > lindep (pyscf/df/incore.py:263-270).  Small metrics: a
+        // Jacobi solver on the host (no library start-up: the first use of the system rocSOLVER costs minutes on a cold box);
+        // larger ones: rocSOLVER's syevd, resolved with dlopen only here.
+        std::vector<double> w, v;                                 // row m of v = eigenvector m
+        if (naux <= HOST_EIG_MAX) {
+            std::vector<double> aj(n2);
+            PAMD_CHECK_HIP(hipMemcpy(aj.data(), d_j2c, n2 * 8, hipMemcpyDeviceToHost));
+            jacobi_eig(naux, aj, w, v);
+        } else {
+            static RocLib roc;             // one rocBLAS handle per process (creating one loads the library's kernels: seconds)
+            if ((rc = roc.open())) return rc;
+            roc.set_stream(roc.handle, h->st);
+            double *d_w = nullptr, *d_e = nullptr;
+            int *d_info = nullptr;
+            if ((rc = h->pool.alloc((void **)&d_w, (size_t)naux * 8)) || (rc = h->pool.alloc((void **)&d_e, (size_t)naux * 8)) ||
+                (rc = h->pool.alloc((void **)&d_info, 64)))
+                return rc;
+            PAMD_CHECK_HIP(hipMemcpyAsync(d_a, d_j2c, n2 * 8, hipMemcpyDeviceToDevice, h->st));
+            PAMD_REQUIRE(roc.dsyevd(roc.handle, ROC_EVECT_ORIGINAL, ROC_FILL_UPPER, naux, d_a, naux, d_w, d_e, d_info) == 0,
+                         "rocsolver_dsyevd failed");
+            PAMD_CHECK_HIP(hipMemcpyAsync(&info, d_info, 4, hipMemcpyDeviceToHost, h->st));
+            PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+            PAMD_REQUIRE(info == 0, "rocsolver_dsyevd did not converge");
+            w.resize(naux);
+            v.resize(n2);                                         // column-major eigenvectors: row m of the buffer = vector m
+            PAMD_CHECK_HIP(hipMemcpy(w.data(), d_w, (size_t)naux * 8, hipMemcpyDeviceToHost));
+            PAMD_CHECK_HIP(hipMemcpy(v.data(), d_a, n2 * 8, hipMemcpyDeviceToHost));
+            h->pool.release(d_w); h->pool.release(d_e); h->pool.release(d_info);
+        }
         std::vector<int> keep;
         for (int m = 0; m < naux; m++) if (w[m] > lindep) keep.push_back(m);
         *nrow = (int)keep.size();
@@ -541,7 +592,6 @@ int decompose_metric(PAMD_df *h, double *d_j2c, int naux, double lindep, std::ve
             for (int q = 0; q < naux; q++) (*mt)[(size_t)q * *lda + j] = v[(size_t)m * naux + q] * f;
         }
         *tri = 0;
-        h->pool.release(d_w); h->pool.release(d_e); h->pool.release(d_info);
     }
     h->pool.release(d_a);
     return 0;
