@@ -50,6 +50,8 @@ def main():
     ap.add_argument('--xc', default='b3lyp', help="XC functional of the secondary nr_rks timing ('' to skip)")
     ap.add_argument('--backend', default=None, help="torch.distributed backend ('nccl' = RCCL; 'gloo' for the "
                     "single-device self-test where several ranks share one GPU)")
+    ap.add_argument('--tune', default='', help='comma list key=value for PAMD_set_tuning (A/B runs)')
+    ap.add_argument('--syrk-flags', type=int, default=-1, help='override DF.k_syrk_flags (A/B runs): 0 plain, 12 re-tiled + balanced')
     args = ap.parse_args()
     if args.backend:
         os.environ['PAMD_DIST_BACKEND'] = args.backend
@@ -112,6 +114,11 @@ def main():
     mol = gto.M(atom=clusters.taxol() if args.molecule == 'taxol' else clusters.water_cluster(args.nwater), basis=args.basis)
     nao, nocc = mol.nao, mol.nelectron // 2
     dfobj = df.DF(mol)                      # aux basis by the reference's rule (cc-pvtz -> cc-pvtz-jkfit)
+    if args.syrk_flags >= 0:
+        dfobj.k_syrk_flags = args.syrk_flags
+    for kv in filter(None, args.tune.split(',')):
+        k_, v_ = kv.split('=')
+        lib.check(lib.load_library().PAMD_set_tuning(k_.encode(), int(v_)))
     # pre-flight, memory: this rank's packed shard must fit (the square image is optional: DF.k_square='auto' builds it only
     # when HBM allows); refuse with a clear message instead of an out-of-memory error inside the build
     from pyscf_amd.lib import comm

@@ -124,6 +124,51 @@ __global__ __launch_bounds__(256) void vj_pass2_kernel(
     }
 }
 
+// The same pass with 16-byte loads: every lane owns TWO adjacent packed columns (npair even, 16-byte aligned rows), so a wave
+// moves 1 KiB per load instruction and issues half as many loads and half as many scalar rho reads per byte - fewer issue slots
+// taken from the MFMA kernel it runs beside (r03; tuning key "j2wide").
+template <int NSET>
+__global__ __launch_bounds__(256) void vj_pass2_wide_kernel(
+    const double *__restrict__ cderi, long npair, int naux, const double *__restrict__ rho,
+    double *__restrict__ vj)
+{
+    const long npair2 = npair >> 1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npair2; i += (long)gridDim.x * 256) {
+        double2_t acc[NSET];
+#pragma unroll
+        for (int s = 0; s < NSET; s++) acc[s] = double2_t{0, 0};
+        const double2_t *col = reinterpret_cast<const double2_t *>(cderi) + i;
+        int L = 0;
+        for (; L + 8 <= naux; L += 8) {
+            double2_t b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) b[u] = __builtin_nontemporal_load(col + (long)(L + u) * npair2);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int s = 0; s < NSET; s++) {
+                    const double r = rho[s * naux + L + u];
+                    acc[s][0] += r * b[u][0];
+                    acc[s][1] += r * b[u][1];
+                }
+        }
+        for (; L < naux; L++) {
+            const double2_t b = col[(long)L * npair2];
+#pragma unroll
+            for (int s = 0; s < NSET; s++) {
+                const double r = rho[s * naux + L];
+                acc[s][0] += r * b[0];
+                acc[s][1] += r * b[1];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NSET; s++) {
+            vj[(long)s * npair + 2 * i] += acc[s][0];
+            vj[(long)s * npair + 2 * i + 1] += acc[s][1];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ K
 // X[L][i][p] = sum_q Bsym_L[q][p] * orb[q][i]: grid x = p tile (128 cols), y = L, z = chunk of MT*16 orbitals
 // (body and operand conventions: mfma_e2.h)
@@ -512,9 +557,10 @@ template <int NA, bool RHO, bool PAIR>
 __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
     double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int ncol, int ptile0, int nslot,
-    int nL)
+    int nL, int prio)
 {
     static_assert(NA == 4 || NA == 5, "128- or 160-orbital tile");
+    if (prio) __builtin_amdgcn_s_setprio(3);             // ahead of the tail of a co-running second J pass (tuning "e2prio")
     constexpr int M = NA * 32;                           // NA = 4: no remainder block
     __shared__ double sa0[KB * LDN + (NA == 5 ? KB * 32 : 0)];
     __shared__ double sa1[KB * LDN + (NA == 5 ? KB * 32 : 0)];
@@ -810,8 +856,9 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
 // 128 x 128 tile of C[split] += A^T B (all tiles, or the lower-triangular ones of the SYRK), v2 DMA scheme
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
-    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, long kchunk)
+    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, long kchunk, int prio)
 {
+    if (prio) __builtin_amdgcn_s_setprio(3);        // MFMA waves ahead of a co-resident HBM-bound kernel's waves (tuning "mfmaprio")
     const int bsplit = blockIdx.y, btile = blockIdx.x;
     constexpr int PA = KB * LDN;
     __shared__ double sb0[2 * PA];
@@ -928,8 +975,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
 template <int PROBE>                  // PROBE = 1: benchmarking probe, skips the "B" DMA of every k-row (half the L2 -> LDS traffic, wrong results)
 __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
     const double *__restrict__ A, int lda, double *__restrict__ C, int ldc, int m, long kdim, const int *__restrict__ items,
-    long kchunk)
+    long kchunk, int prio)
 {
+    if (prio) __builtin_amdgcn_s_setprio(3);
     const int bsplit = blockIdx.y;
     constexpr int PA = KB * LDN;
     __shared__ double sb0[2 * PA];
@@ -1089,6 +1137,9 @@ __global__ void pack_dm_kernel(const double *__restrict__ dm, int nao, double *_
 static int g_use_glds = 1;
 static int g_gemm_wide = 1;
 static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper bound
+static int g_e2_prio = 0;     // s_setprio 3 in the half transform (A/B switch)
+static int g_mfma_prio = 0;   // s_setprio 3 in the SYRK kernels (A/B switch)
+static int g_j2_wide = 0;     // second J pass with 16-byte loads (two packed columns per lane); A/B switch, default set after measurement
 static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: one per 256 columns)
 static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
@@ -1115,6 +1166,9 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
     if (strcmp(key, "pairtail") == 0) { g_pair_tail = value; return 0; }
     if (strcmp(key, "j2wg") == 0 && value >= 0) { g_j2_maxwg = value; return 0; }
+    if (strcmp(key, "j2wide") == 0) { g_j2_wide = value; return 0; }
+    if (strcmp(key, "mfmaprio") == 0) { g_mfma_prio = value; return 0; }
+    if (strcmp(key, "e2prio") == 0) { g_e2_prio = value; return 0; }
     if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
 }
@@ -1151,6 +1205,18 @@ int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *
     PAMD_REQUIRE(nset >= 1 && nset <= MAX_NSET, "nset must be 1..4 per call");
     if (naux == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (g_j2_wide && npair % 2 == 0 && ((uintptr_t)d_cderi % 16 == 0)) {
+        int grid = ceil_div(npair / 2, 256);
+        if (g_j2_maxwg > 0 && grid > g_j2_maxwg) grid = g_j2_maxwg;
+        switch (nset) {
+        case 1: vj_pass2_wide_kernel<1><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
+        case 2: vj_pass2_wide_kernel<2><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
+        case 3: vj_pass2_wide_kernel<3><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
+        default: vj_pass2_wide_kernel<4><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
+        }
+        PAMD_CHECK_LAUNCH();
+        return 0;
+    }
     int grid = ceil_div(npair, 256);
     if (g_j2_maxwg > 0 && grid > g_j2_maxwg) grid = g_j2_maxwg;
     switch (nset) {
@@ -1292,10 +1358,10 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
 #define LAUNCH_V2(NAV, RHOF)                                                                                        \
         do {                                                                                                         \
             e2_sq2_kernel<NAV, RHOF, false><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
-                                                                   nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL);    \
+                                                                   nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL, g_e2_prio);    \
             if (pair)                                                                                                \
                 e2_sq2_kernel<NAV, RHOF, true><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
-                                                                      nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL); \
+                                                                      nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio); \
         } while (0)
         if (na2 == 5) { if (d_rho) LAUNCH_V2(5, true); else LAUNCH_V2(5, false); }
         else          { if (d_rho) LAUNCH_V2(4, true); else LAUNCH_V2(4, false); }
@@ -1465,15 +1531,15 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
         if (rc) return rc;
         if (nitems > 0) {
             dim3 g2(nitems, nsplit);
-            if (g_syrk_probe) syrk_slots_kernel<1><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems));
-            else syrk_slots_kernel<0><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems));
+            if (g_syrk_probe) syrk_slots_kernel<1><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems), g_mfma_prio);
+            else syrk_slots_kernel<0><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems), g_mfma_prio);
             PAMD_CHECK_LAUNCH();
             return 0;
         }
     }
     if (v2) {
         if (lower_only & 1) kchunk = balanced_chunk(ntiles);
-        gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk);
+        gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio);
     }
     else if (glds)
     {
