@@ -193,6 +193,13 @@ def arg_group_grids(mol, coords, box_size=GROUP_BOX_SIZE):
     return rev_idx.ravel().argsort(kind='stable')
 
 
+def make_mask(mol, coords, relativity=0, shls_slice=None, cutoff=1e-15, verbose=None):
+    """pyscf/dft/gen_grid.py:422-447: the shell mask of the reference (uint8 screen index per block of 56 grid points and shell;
+    0 = ignorable).  Not used by the product's own XC path, which screens on AO values (dft/sparse_grid.py)."""
+    from ..gto.eval_gto import make_screen_index
+    return make_screen_index(mol, coords, shls_slice, cutoff)
+
+
 class Grids:
     """pyscf/dft/gen_grid.py:487-744 (defaults :565-576)."""
 
@@ -273,6 +280,10 @@ class Grids:
                 self.weights = np.hstack([self.weights, np.zeros(pad)])
                 self.atm_idx = np.hstack([self.atm_idx, np.full(pad, -1, np.int32)])
                 self.quadrature_weights = np.hstack([self.quadrature_weights, np.zeros(pad)])
+        if with_non0tab:                            # gen_grid.py:615-620: screen_index = non0tab = make_mask(...)
+            self.non0tab = self.screen_index = make_mask(mol, self.coords, cutoff=getattr(self, 'cutoff', 1e-15))
+        else:
+            self.non0tab = self.screen_index = None
         return self
 
     kernel = build

@@ -373,3 +373,24 @@ def test_nr_uks_fxc_and_singlet_triplet(xc):
     assert np.abs(v - want).max() < 2e-6 * max(1.0, np.abs(want).max()), np.abs(v - want).max()
     vs = ni.nr_fxc(mol, grids, xc, (da, db), (np.array([d1, d2]), np.array([d1b, d1b])), spin=1)
     assert vs.shape == (2, 2, mol.nao, mol.nao) and np.abs(vs[:, 0] - v).max() < 1e-12
+
+
+def test_grids_build_with_non0tab_golden():
+    """pyscf/dft/test/test_grids.py:132-140 through the PRODUCT's grid builder: `Grids.build()` on the device, then the
+    reference's shell mask on the scaled coordinates - 123 non-zero entries, lib.fp = -83.54934301013405; `with_non0tab=True`
+    attaches the mask as the reference does (gen_grid.py:615-620)."""
+    from pyscf_amd import gto, dft
+    from pyscf_amd.dft import gen_grid, radi
+    h2o = gto.M(atom=[["O", (0., 0., 0.)], [1, (0., -0.757, 0.587)], [1, (0., 0.757, 0.587)]], basis={"H": '6-31g', "O": '6-31g'})
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
+    try:
+        grid = dft.Grids(h2o)
+        grid.atom_grid = {"H": (10, 110), "O": (10, 110)}
+        grid.cutoff = 1e-15
+        grid.build(with_non0tab=True)
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    non0 = gen_grid.make_mask(h2o, grid.coords * 10.)
+    assert (non0 > 0).sum() == 123 and abs(ref.fp(non0) - -83.54934301013405) < 1e-9
+    assert grid.non0tab is not None and grid.non0tab.shape == non0.shape and grid.screen_index is grid.non0tab

@@ -338,3 +338,26 @@ def test_oracle_uks_fxc_reduces_to_closed_shell_kernel():
         vr = ref_dft.nr_rks_fxc(mol, coords, weights, fac, gga, dm0, 2 * d1)
         assert np.abs(vu[0] - vr).max() < 2e-6 * max(1.0, np.abs(vr).max()), (xc, np.abs(vu[0] - vr).max())
         assert np.abs(vu[1] - vr).max() < 2e-6 * max(1.0, np.abs(vr).max())
+
+
+def test_make_mask_screen_index_golden():
+    """pyscf/dft/test/test_grids.py:132-140 (G9): `gen_grid.make_mask` = `make_screen_index` -> GTO_screen_index
+    (pyscf/lib/gto/grid_ao_drv.c:32-123) on the (10, 110) grid of H2O / 6-31G scaled by 10: 123 non-zero entries,
+    lib.fp(non0tab) = -83.54934301013405.  The host restatement (pyscf_amd/gto/eval_gto.py) on the oracle's grid."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import gen_grid, radi
+    h2o = gto.M(atom=[["O", (0., 0., 0.)], [1, (0., -0.757, 0.587)], [1, (0., 0.757, 0.587)]], basis={"H": '6-31g', "O": '6-31g'})
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False                       # test_grids.py:46-49 (setUpModule)
+    try:
+        coords = ref_dft.build_grids(h2o, atom_grid={"H": (10, 110), "O": (10, 110)})[0]
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    non0 = gen_grid.make_mask(h2o, coords * 10.)
+    assert non0.dtype == np.uint8 and non0.shape == ((len(coords) + 55) // 56, h2o.nbas)
+    assert (non0 > 0).sum() == 123
+    assert abs(ref.fp(non0) - -83.54934301013405) < 1e-9
+    # shell slices and the cutoff argument
+    part = gen_grid.make_mask(h2o, coords * 10., shls_slice=(2, 5))
+    assert np.array_equal(part, non0[:, 2:5])
+    assert (gen_grid.make_mask(h2o, coords * 10., cutoff=1e-5) > 0).sum() <= 123
