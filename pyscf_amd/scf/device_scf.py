@@ -308,7 +308,7 @@ def kernel_device(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, conv_check=T
     nocc = mol.nelectron // 2
     diis = DeviceDIIS(mf.diis_space, x) if mf.diis else None
     veff = _Veff(mf)
-    purify_from = getattr(mf, 'purify_from_cycle', 3)
+    purify_from = getattr(mf, 'purify_from_cycle', 1)
     sym_sq = _SymSquare(nmo, dev) if nmo >= 256 and getattr(mf, 'purify', True) else None
 
     def full_eig(fock):

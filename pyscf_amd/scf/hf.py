@@ -234,7 +234,7 @@ class SCF:
     device_scf = True          # closed-shell DF-RHF / DF-RKS: the HBM-resident loop of scf/device_scf.py (from device_scf_min_nao)
     device_scf_min_nao = 512
     purify = True              # occupied space by SP2 purification instead of a full eigh from cycle `purify_from_cycle`
-    purify_from_cycle = 3
+    purify_from_cycle = 1
 
     def __init__(self, mol):
         self.mol = mol
