@@ -181,6 +181,16 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
                     int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work,
                     void *stream);
 long PAMD_nr_e2_rho_worksize(int nL, int ldx, int nocc_pad);             /* doubles of d_rho_work */
+/* packed-operand transform with the diagonal-block side image d_diag[nL][ceil(ldx/128)][128][128] of the same aux rows
+ * (both triangles of the 128 x 128 blocks on the diagonal of every B_L, 0 beyond nao; 14 % of the packed size at nao 1856):
+ * the k-tiles that cross the diagonal are then read once, unmasked - what AO2MOtranse2_nr_s2's per-row NPdunpack_tril
+ * (nr_ao2mo.c:1026-1031) does for the whole matrix, done for the blocks where the packed layout changes direction.
+ * d_diag NULL = PAMD_nr_e2_symm.  Build the image once per tensor with PAMD_e2_diag_blocks (PAMD_e2_diag_size doubles). */
+int PAMD_nr_e2_symm_diag(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
+                         int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work,
+                         const double *d_diag, void *stream);
+long PAMD_e2_diag_size(int nL, int ldx);
+int PAMD_e2_diag_blocks(const double *d_cderi, long npair, int nL, int nao, int ldx, double *d_diag, void *stream);
 /* the same contraction on the unpacked image sq[nL][rows][ld] (PAMD_unpack_tril into a zeroed buffer, rows = ld =
  * round_up(nao,16)): both operands stream by LDS-DMA; spends 2x the packed size of HBM to take the symmetric unpack out
  * of the hot loop.  d_orb as for PAMD_nr_e2_symm with ldo >= chunks * 32 * wa (pyscf_amd/df/df_jk.py:pad_orbitals) */

@@ -690,10 +690,15 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
 // matrix pipe's shadow; gain: the tensor is read once (30.7 GB per build instead of 61.3) and 2 x its size of HBM is free.
 // Reads beyond a packed row (pad rows q >= nao, pad columns p >= nao of the last tile) stay inside the buffer resource
 // (num_records = bytes to the end of the block, out-of-range -> 0) and only meet zero orbital rows or never-stored columns.
-template <int NA, bool RHO>
+// DIAG = true (r03): the 128 x 128 blocks on the diagonal of every B_L come from a small side image diag[L][P][128][128]
+// (full symmetric blocks, zero padded; 14 % of the packed size at nao = 1856, PAMD_e2_diag_blocks) in the ROW layout: the
+// crossing k-tiles are then visited once, without keep-masks, by the same body as the tiles below the diagonal - two loop
+// phases instead of three, 116 instead of 124 k-tiles at nao = 1856.
+template <int NA, bool RHO, bool DIAG>
 __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     const double *__restrict__ cderi, long npair, int nL, int kdim, const double *__restrict__ orb, int ldo,
-    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int nao)
+    double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int nao,
+    const double *__restrict__ diag, int ntile_p)
 {
     static_assert(NA == 4 || NA == 5, "128- or 160-orbital tile");
     constexpr int M = NA * 32;
@@ -752,8 +757,9 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     // body into several scheduling regions (and did: hipcc turns the obvious ternaries into s_cbranch)
     const int nA = p0 / KB;
     const int ncross = (kdim - p0) / KB < 8 ? (kdim - p0) / KB : 8;
-    const int nvirt = kdim / KB + ncross;
+    const int nvirt = DIAG ? kdim / KB : kdim / KB + ncross;
     auto tile_q0 = [&](int v) {
+        if (DIAG) return v * KB;                           // every k-tile once
         int adj = (v - nA + 1) >> 1;                       // tiles visited twice so far
         adj = adj < 0 ? 0 : adj;
         adj = adj > ncross ? ncross : adj;
@@ -761,8 +767,14 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     };
     auto tile_tr = [&](int v) {
         const int u = v - nA;
+        if (DIAG) return (u >> 31) & 1;                    // transposed layout above the diagonal block only
         return (int)(u < 0) | ((int)(u < 2 * ncross) & (u & 1) & (int)(u >= 0));
     };
+    // DIAG: base address and size of the two sources as integers - the buffer resource of a DMA is rebuilt from them with
+    // scalar arithmetic (a select between two resource descriptors would be a branch)
+    const long pk_base = (long)(cderi + L * npair);
+    const long dg_base = DIAG ? (long)(diag + ((long)L * ntile_p + p0 / NT) * (NT * NT)) : 0;
+    const unsigned pk_num = bytes_left > 0xffffffffL ? 0xffffffffu : (unsigned)bytes_left;
     int dvo[4];                                            // (transposed - row) difference of the DMA lane offsets
 #pragma unroll
     for (int j = 0; j < 4; j++) dvo[j] = voff_tr[j] - voff;
@@ -774,8 +786,18 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
         dma_row(r_orb, da + k * LDN, voff, (q0 + k) * ldo8);
         const int q = q0 + k;
         const int soff_row = (q * (q + 1) / 2 + p0) * 8;
-        const int soff = soff_row + tr * (q0 * 8 - soff_row);
-        dma_row(r_pk, db + k * (LDN - tr * (LDN - 128)), voff + tr * dvo[j], soff);
+        if constexpr (DIAG) {
+            const int u = v - nA;
+            const int is_dg = (~(u >> 31)) & ((u - ncross) >> 31) & 1;           // 0 <= u < ncross: the diagonal block
+            const int soff = soff_row + tr * (q0 * 8 - soff_row) + is_dg * ((q - p0) * (NT * 8) - soff_row);
+            const long base = pk_base + ((dg_base - pk_base) & -(long)is_dg);
+            const unsigned num = pk_num + (unsigned)is_dg * ((unsigned)(NT * NT * 8) - pk_num);
+            const __amdgpu_buffer_rsrc_t r_src = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, num, 0x00020000);
+            dma_row(r_src, db + k * (LDN - tr * (LDN - 128)), voff + tr * dvo[j], soff);
+        } else {
+            const int soff = soff_row + tr * (q0 * 8 - soff_row);
+            dma_row(r_pk, db + k * (LDN - tr * (LDN - 128)), voff + tr * dvo[j], soff);
+        }
         if (NA == 5 && j == 0) dma_row(r_orb, da + RB + wave * 128, voff_rem, (q0 + wave * 4) * ldo8);
     };
     // One k-tile body per (layout, masked?) pair, each a single basic block: measured with a layout-generic body, ~100 VALU
@@ -821,9 +843,11 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
         step(T_{}, F_{}, sa0, sq0, sa1, sq1, v);
         step(T_{}, F_{}, sa1, sq1, sa0, sq0, v + 1);
     }
-    for (; v < nA + 2 * ncross; v += 2) {                            // crossing tiles: row half, then transposed half
-        step(F_{}, T_{}, sa0, sq0, sa1, sq1, v);
-        step(T_{}, T_{}, sa1, sq1, sa0, sq0, v + 1);
+    if constexpr (!DIAG) {
+        for (; v < nA + 2 * ncross; v += 2) {                        // crossing tiles: row half, then transposed half
+            step(F_{}, T_{}, sa0, sq0, sa1, sq1, v);
+            step(T_{}, T_{}, sa1, sq1, sa0, sq0, v + 1);
+        }
     }
     for (; v < nvirt; v += 2) {                                      // below: row layout
         step(F_{}, F_{}, sa0, sq0, sa1, sq1, v);
@@ -1143,6 +1167,7 @@ static int g_j2_wide = 0;     // second J pass with 16-byte loads (two packed co
 static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: one per 256 columns)
 static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
+static int g_pk_diag = 1;     // e2_pk reads the diagonal 128 x 128 blocks from the side image when the caller passes one ("pkdiag")
 static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
 static int g_syrk_probe = 0;  // benchmarking probe only: the re-tiled SYRK without its second panel DMA (results meaningless)
 static int g_syrk_slots = 1;  // SYRK on the re-tiled triangle (syrk_slots_kernel) when the matrix has an odd number of 64-column blocks
@@ -1163,6 +1188,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "syrkprobe") == 0) { g_syrk_probe = value; return 0; }
     if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
+    if (strcmp(key, "pkdiag") == 0) { g_pk_diag = value; return 0; }
     if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
     if (strcmp(key, "pairtail") == 0) { g_pair_tail = value; return 0; }
     if (strcmp(key, "j2wg") == 0 && value >= 0) { g_j2_maxwg = value; return 0; }
@@ -1261,8 +1287,9 @@ static int reduce_rho_partials(const double *d_work, double *d_rho, int nL, int 
     return 0;
 }
 
-int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
-                    int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream)
+static int nr_e2_symm_impl(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
+                           int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream,
+                           const double *d_diag)
 {
     PAMD_REQUIRE(d_rho == nullptr || d_rho_work != nullptr, "d_rho needs d_rho_work (PAMD_nr_e2_rho_worksize doubles)");
     PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
@@ -1281,9 +1308,15 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
             ((uintptr_t)d_orb % 16 == 0) && ((uintptr_t)d_cderi % 8 == 0)) {
             dim3 gpk(ceil_div(ldx, NT) * nch, nL);
             double *rw = d_rho ? d_rho_work : nullptr;
-#define LAUNCH_PK(NAV, RHOF) e2_pk_kernel<NAV, RHOF><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, rw, nch, nao)
-            if (na == 5) { if (d_rho) LAUNCH_PK(5, true); else LAUNCH_PK(5, false); }
-            else         { if (d_rho) LAUNCH_PK(4, true); else LAUNCH_PK(4, false); }
+            const int ntile_p = ceil_div(ldx, NT);
+#define LAUNCH_PK(NAV, RHOF, DG) e2_pk_kernel<NAV, RHOF, DG><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, rw, nch, nao, d_diag, ntile_p)
+            if (d_diag && g_pk_diag) {
+                if (na == 5) { if (d_rho) LAUNCH_PK(5, true, true); else LAUNCH_PK(5, false, true); }
+                else         { if (d_rho) LAUNCH_PK(4, true, true); else LAUNCH_PK(4, false, true); }
+            } else {
+                if (na == 5) { if (d_rho) LAUNCH_PK(5, true, false); else LAUNCH_PK(5, false, false); }
+                else         { if (d_rho) LAUNCH_PK(4, true, false); else LAUNCH_PK(4, false, false); }
+            }
 #undef LAUNCH_PK
             PAMD_CHECK_LAUNCH();
             if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, (int)(gpk.x * 4), st);
@@ -1314,6 +1347,58 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
     PAMD_CHECK_LAUNCH();
     // the partial layout needs the MT actually launched to cover the chunk count used by the worksize query
     if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, (int)(grid.x * grid.z * 4), st);
+    return 0;
+}
+
+int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
+                    int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream)
+{
+    return nr_e2_symm_impl(d_cderi, npair, nL, nao, d_orb, ldo, orb_rows, nocc_pad, d_out, ldx, d_rho, d_rho_work, stream, nullptr);
+}
+
+// Same, with the diagonal-block side image of the same aux rows (PAMD_e2_diag_blocks): d_diag[nL][ceil(ldx/128)][128][128].
+// ldx must be the value the image was built for (its block count is part of the layout).
+int PAMD_nr_e2_symm_diag(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
+                         int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work,
+                         const double *d_diag, void *stream)
+{
+    PAMD_REQUIRE(d_diag == nullptr || (uintptr_t)d_diag % 16 == 0, "d_diag must be 16-byte aligned");
+    return nr_e2_symm_impl(d_cderi, npair, nL, nao, d_orb, ldo, orb_rows, nocc_pad, d_out, ldx, d_rho, d_rho_work, stream, d_diag);
+}
+
+// diag[L][P][r][c] = B_L[128 P + r][128 P + c] (both triangles; 0 where an index is >= nao): one workgroup per (P, L),
+// reads the 128 packed row pieces once (coalesced along c <= r) and writes both images through LDS
+__global__ __launch_bounds__(256) void e2_diag_blocks_kernel(const double *__restrict__ cderi, long npair, int nao,
+                                                             double *__restrict__ diag)
+{
+    __shared__ double t[NT][NT + 1];
+    const int P = blockIdx.x;
+    const long L = blockIdx.y;
+    const double *src = cderi + L * npair;
+    const int p0 = P * NT;
+    for (int e = threadIdx.x; e < NT * NT; e += 256) {
+        const int r = e >> 7, c = e & 127;
+        const long pr = p0 + r, pc = p0 + c;
+        double v = 0.0;
+        if (c <= r && pr < nao) v = src[pr * (pr + 1) / 2 + pc];
+        t[r][c] = v;
+    }
+    __syncthreads();
+    double *dst = diag + (L * gridDim.x + P) * (long)(NT * NT);
+    for (int e = threadIdx.x; e < NT * NT; e += 256) {
+        const int r = e >> 7, c = e & 127;
+        dst[e] = c <= r ? t[r][c] : t[c][r];
+    }
+}
+
+long PAMD_e2_diag_size(int nL, int ldx) { return (long)nL * ceil_div(ldx, NT) * NT * NT; }
+
+int PAMD_e2_diag_blocks(const double *d_cderi, long npair, int nL, int nao, int ldx, double *d_diag, void *stream)
+{
+    PAMD_REQUIRE(ldx >= nao, "ldx < nao");
+    if (nL == 0) return 0;
+    e2_diag_blocks_kernel<<<dim3(ceil_div(ldx, NT), nL), 256, 0, (hipStream_t)stream>>>(d_cderi, npair, nao, d_diag);
+    PAMD_CHECK_LAUNCH();
     return 0;
 }
 

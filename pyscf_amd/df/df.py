@@ -46,6 +46,9 @@ class DF:
         self.k_square = 'auto'
         self.k_square_reserve = 48 << 30     # HBM left free after the copy (X block, partial K, XC blocks, ...)
         self._cderi_sq = None
+        self.k_diag = True                  # packed-operand rows: keep the diagonal 128 x 128 blocks unpacked (diag_image)
+        self._cderi_diag = None
+        self._diag_row0 = 0
         self.fuse_j_pass1 = True            # MO branch: first J pass from the half transform's epilogue
         self.overlap_split = True           # two-pass J: pass 1 / pass 2 behind the first / second SYRK block
         self.factorize_hermitian_dm = True  # hermi=1 DMs without orbitals: eigen-factorise, use the MO kernels
@@ -161,10 +164,47 @@ class DF:
         self._cderi_sq = buf[:nsq * rows * rows].view(nsq, rows, rows)
         return self._cderi_sq
 
+    def diag_image(self):
+        """(dg, row0): dg[L - row0][P][128][128] = both triangles of the 128 x 128 blocks on the diagonal of B_L for the cderi
+        rows L >= row0 that the square image does NOT cover (all rows when there is none), or (None, 0).  14 % of the packed
+        size at nao 1856 (8.7 GB at BASELINE config 3); with it the packed-operand half transform reads the k-tiles that cross
+        the diagonal once and unmasked (PAMD_nr_e2_symm_diag, r03).  k_diag = False switches it off."""
+        import torch
+        import ctypes as _c
+        from .. import lib as _lib
+        if self._cderi_diag is not None or not getattr(self, 'k_diag', True) or self._cderi_dev is None:
+            return self._cderi_diag, self._diag_row0
+        naux, npair = self._cderi_dev.shape
+        nao = int((np.sqrt(8.0 * npair + 1) - 1) / 2 + .5)
+        if naux == 0 or nao * (nao + 1) // 2 != npair or nao < 128:
+            return None, 0
+        sq = self.square_image()
+        row0 = sq.shape[0] if sq is not None else 0
+        if row0 >= naux:
+            return None, 0
+        ldx = (nao + 15) // 16 * 16
+        so = _lib.load_library()
+        so.PAMD_e2_diag_size.restype = _c.c_long
+        n = so.PAMD_e2_diag_size(_c.c_int(naux - row0), _c.c_int(ldx))
+        dev = self._cderi_dev.device
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        if free - getattr(self, 'k_square_reserve', 0) < n * 8:
+            self.k_diag = False
+            return None, 0
+        buf = torch.empty(n, dtype=torch.float64, device=dev)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(so.PAMD_e2_diag_blocks(_c.c_void_p(self._cderi_dev[row0:].data_ptr()), _c.c_long(npair),
+                                          _c.c_int(naux - row0), _c.c_int(nao), _c.c_int(ldx), _c.c_void_p(buf.data_ptr()), st))
+        self._cderi_diag = buf.view(naux - row0, -1)
+        self._diag_row0 = row0
+        return self._cderi_diag, row0
+
     def drop_square_image(self):
         """Give the HBM of the square copy back (the gradient path needs it for W and Z)."""
         import torch
         self._cderi_sq = None
+        self._cderi_diag = None
+        self._diag_row0 = 0
         torch.cuda.empty_cache()
 
     def _workspace(self, name, shape):
@@ -196,6 +236,8 @@ class DF:
         self._cderi = None
         self._cderi_dev = None
         self._cderi_sq = None
+        self._cderi_diag = None
+        self._diag_row0 = 0
         self._naux = None
         self._ws = {}
         self._eng = None

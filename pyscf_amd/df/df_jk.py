@@ -255,10 +255,9 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
                       _ptr(rho_j[b0:]) if rho_j is not None else _c.c_void_p(0),
                       _rho_work(dfobj, lib, nb, ldx, nocc_pad) if rho_j is not None else _c.c_void_p(0), st)
             else:
-                _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(npair), _c.c_int(nb),
-                      _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X),
-                      _c.c_int(ldx), _ptr(fuse_j[iset][b0:]) if fuse_j is not None else _c.c_void_p(0),
-                      _rho_work(dfobj, lib, nb, ldx, nocc_pad) if fuse_j is not None else _c.c_void_p(0), st)
+                _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, nocc_pad, X, ldx,
+                           _ptr(fuse_j[iset][b0:]) if fuse_j is not None else None,
+                           _rho_work(dfobj, lib, nb, ldx, nocc_pad) if fuse_j is not None else None, st)
             if after_e2 is not None:
                 after_e2(b0, nb, iset)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
@@ -268,6 +267,22 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
               _c.c_int(nao), _ptr(vk), _c.c_int(nao), _c.c_int(1), st)
         vks.append(vk)
     return torch.stack(vks)
+
+
+def _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, nocc_pad, out, ldx, rho, rho_work, st):
+    """Half transform of the packed rows [b0, b0 + nb) (PAMD_nr_e2_symm), with the diagonal-block side image when the tensor
+    object keeps one for these rows (DF.diag_image, ldx = round_up(nao, 16))."""
+    cderi = dfobj._cderi_dev
+    dg, row0 = dfobj.diag_image() if hasattr(dfobj, 'diag_image') and ldx == _round_up(nao, 16) else (None, 0)
+    null = _c.c_void_p(0)
+    if dg is not None and b0 >= row0:
+        _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm_diag, _ptr(cderi[b0:b0 + nb]), _c.c_long(cderi.shape[1]), _c.c_int(nb),
+              _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(out), _c.c_int(ldx),
+              rho if rho is not None else null, rho_work if rho is not None else null, _ptr(dg[b0 - row0:]), st)
+    else:
+        _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(cderi.shape[1]), _c.c_int(nb),
+              _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(out), _c.c_int(ldx),
+              rho if rho is not None else null, rho_work if rho is not None else null, st)
 
 
 def _vk_general(dfobj, lib, dms_dev, nset, nao):
@@ -295,9 +310,7 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
         for b0 in range(0, naux, blk):
             nb = min(blk, naux - b0)
             sub = cderi[b0:b0 + nb]
-            _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
-                  _ptr(orb), _c.c_int(ldo), _c.c_int(rows), _c.c_int(rows), _ptr(X), _c.c_int(ldx), _c.c_void_p(0),
-                  _c.c_void_p(0), st)
+            _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, rows, X, ldx, None, None, st)
             _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
                                                 _ptr(full), _c.c_int(ldx), _c.c_int(rows), st)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(full), _c.c_int(ldx), _ptr(part),
@@ -317,9 +330,7 @@ def _half_transform(dfobj, lib, b0, nb, orb, nocc_pad, ldo, nao, out, ldx, st):
               _c.c_int(nb), _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(out),
               _c.c_int(ldx), _c.c_void_p(0), _c.c_void_p(0), st)
     else:
-        _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_symm, _ptr(cderi[b0:b0 + nb]), _c.c_long(cderi.shape[1]), _c.c_int(nb),
-              _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(out), _c.c_int(ldx),
-              _c.c_void_p(0), _c.c_void_p(0), st)
+        _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, nocc_pad, out, ldx, None, None, st)
 
 
 def _vk_lowrank(dfobj, lib, lefts, rights, sym, nao):

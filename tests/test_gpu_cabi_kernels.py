@@ -236,3 +236,21 @@ def test_nr_e2_symm_packed_dma_kernel(nao, naux, nocc):
         outs[flag] = got
     lib.check(so.PAMD_set_tuning(b'pkdma', 1))
     assert np.abs(outs[0] - outs[1]).max() < 1e-11 * np.abs(want).max()
+    # r03: the same with the diagonal-block side image (crossing k-tiles read once, no keep-masks)
+    so.PAMD_e2_diag_size.restype = C.c_long
+    ntile = (ldx + 127) // 128
+    assert so.PAMD_e2_diag_size(naux, ldx) == naux * ntile * 128 * 128
+    dg = torch.full((naux, ntile, 128, 128), 3.0, dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_e2_diag_blocks(_p(t_tril), C.c_long(npair), naux, nao, ldx, _p(dg), st))
+    dg_want = np.zeros((naux, ntile * 128, ntile * 128))
+    dg_want[:, :nao, :nao] = full
+    for t in range(ntile):
+        assert np.array_equal(dg[:, t].cpu().numpy(), dg_want[:, t * 128:(t + 1) * 128, t * 128:(t + 1) * 128]), t
+    x = torch.full((naux, nocc_pad, ldx), 7.0, dtype=torch.float64, device=dev)
+    rho = torch.zeros(naux, dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_nr_e2_symm_diag(_p(t_tril), C.c_long(npair), naux, nao, _p(orb), ldo, orb.shape[0], nocc_pad, _p(x), ldx,
+                                      _p(rho), _p(work), _p(dg), st))
+    got = x[:, :nocc, :nao].cpu().numpy()
+    assert np.abs(got - want).max() < 1e-11 * np.abs(want).max()
+    assert np.abs(got - outs[1]).max() < 1e-11 * np.abs(want).max()
+    assert np.abs(rho.cpu().numpy() - rho_want).max() < 1e-10 * np.abs(rho_want).max()

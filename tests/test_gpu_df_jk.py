@@ -371,6 +371,15 @@ def test_partial_square_image():
     obj.k_block_bytes = 100 * 176 * 272 * 8        # ~100-row K blocks: 0-100, 100-128 | 128-228, 228-301
     vj, vk = obj.get_jk(dm, hermi=1)
     assert obj._cderi_sq is not None and obj._cderi_sq.shape[0] == 128
+    # the packed rows beyond the image keep their diagonal blocks unpacked (DF.diag_image, r03); the reference object above ran
+    # the same kernel on all rows, and once more without the side image
+    assert obj._cderi_diag is not None and obj._diag_row0 == 128 and obj._cderi_diag.shape[0] == naux - 128
+    assert ref_obj._cderi_diag is not None and ref_obj._diag_row0 == 0 and ref_obj._cderi_diag.shape[0] == naux
+    plain = _dfobj(None, cderi)
+    plain.k_square = plain.k_diag = False
+    vj2, vk2 = plain.get_jk(dm, hermi=1)
+    assert plain._cderi_diag is None
+    assert np.abs(vj2 - vj0).max() < 1e-11 * max(1.0, np.abs(vj0).max()) and np.abs(vk2 - vk0).max() < 1e-11 * max(1.0, np.abs(vk0).max())
     assert np.abs(vj - vj0).max() < 1e-11 * max(1.0, np.abs(vj0).max()) and np.abs(vk - vk0).max() < 1e-11 * max(1.0, np.abs(vk0).max())
 
 

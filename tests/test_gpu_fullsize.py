@@ -206,9 +206,13 @@ def test_config3_full_jk_vs_oracle_golden(h2o32):
     sq, ksq = obj._cderi_sq, obj.k_square
     obj._cderi_sq, obj.k_square = None, False                 # packed-operand half transform (ranks without the HBM)
     try:
+        check(*df_jk.get_jk_device(obj, dms, orbs), 'packed operand + diagonal-block image')
+        assert obj._cderi_diag is not None and obj._cderi_diag.shape[0] == obj.get_naoaux()
+        obj._cderi_diag, obj.k_diag = None, False
         check(*df_jk.get_jk_device(obj, dms, orbs), 'packed operand')
     finally:
         obj._cderi_sq, obj.k_square = sq, ksq
+        obj._cderi_diag, obj.k_diag = None, True
     # the reference-style host API (numpy in / out, tagged DM) on the same tensor
     vj_h, vk_h = obj.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=np.full(nocc, 2.0)), hermi=1)
     assert np.abs(vj_h[ri, ci] - vj_s).max() < 1e-9 * g['vj_absmax']
