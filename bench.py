@@ -51,6 +51,9 @@ def main():
     ap.add_argument('--backend', default=None, help="torch.distributed backend ('nccl' = RCCL; 'gloo' for the "
                     "single-device self-test where several ranks share one GPU)")
     ap.add_argument('--tune', default='', help='comma list key=value for PAMD_set_tuning (A/B runs)')
+    ap.add_argument('--k-square', default='auto', choices=['auto', 'off'], help="'off': no unpacked image - the K half transform "
+                    "reads the packed rows (+ the diagonal-block side image, 14 %% of the tensor): what a rank without 2x the "
+                    "tensor size of spare HBM runs")
     ap.add_argument('--syrk-flags', type=int, default=-1, help='override DF.k_syrk_flags (A/B runs): 0 plain, 12 re-tiled + balanced')
     args = ap.parse_args()
     if args.backend:
@@ -116,6 +119,8 @@ def main():
     dfobj = df.DF(mol)                      # aux basis by the reference's rule (cc-pvtz -> cc-pvtz-jkfit)
     if args.syrk_flags >= 0:
         dfobj.k_syrk_flags = args.syrk_flags
+    if args.k_square == 'off':
+        dfobj.k_square = False
     for kv in filter(None, args.tune.split(',')):
         k_, v_ = kv.split('=')
         lib.check(lib.load_library().PAMD_set_tuning(k_.encode(), int(v_)))
@@ -425,9 +430,12 @@ def main():
         'config': {'workload': '%s %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM%s'
                                % (label, args.basis, _aux_label(getattr(dfobj.auxmol, 'basis', 'auto')),
                                   nao, naux, nocc, 8e-9 * naux * npair,
-                                  '' if getattr(dfobj, '_cderi_sq', None) is None else
-                                  ' + unpacked image for the K half transform' + ('' if dfobj._cderi_sq.shape[0] == naux_local else
-                                  ' (of %d of the %d aux rows: what fits)' % (dfobj._cderi_sq.shape[0], naux_local))),
+                                  ('' if getattr(dfobj, '_cderi_sq', None) is None else
+                                   ' + unpacked image for the K half transform' + ('' if dfobj._cderi_sq.shape[0] == naux_local else
+                                   ' (of %d of the %d aux rows: what fits)' % (dfobj._cderi_sq.shape[0], naux_local))) +
+                                  ('' if getattr(dfobj, '_cderi_diag', None) is None else
+                                   ' + diagonal-block image of %d packed rows (%.1f GB)' % (dfobj._cderi_diag.shape[0],
+                                                                                            8e-9 * dfobj._cderi_diag.numel()))),
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
                    'naux_local': naux_local, 'naux_per_rank': naux_per_rank},
         'value_host_api_ms': round(host_api_ms, 3), 'host_api_fused_j': host_fused,
