@@ -31,6 +31,9 @@ def test_bench_gpus2_launches_two_ranks():
     assert len(rows) == 2 and sum(rows) == one['config']['naux_per_rank'][0] and abs(rows[0] - rows[1]) <= 1
     assert two['config']['naux_local'] == rows[0]
     assert two['value'] > 0 and two['value_host_api_ms'] > 0
+    # the roofline durations are those of the timed steps (live HIP events), the serial pass is reported beside them
+    assert one['roofline']['launches_per_step'] >= 1 and one['kernels_serial_pass'] and 'e2_symm' in one['kernels']
+    assert one['kernels']['e2_symm']['ms_total'] < one['ms_per_step']
 
 
 def test_bench_refuses_a_world_size_mismatch():
