@@ -33,6 +33,7 @@ class DF:
         self.group = group
         # HBM budget for the half-transformed block X (MI355X: 288 GB per GPU)
         self.k_block_bytes = 8 << 30
+        self.k_e2_pipeline = 1     # sub-blocks of a K block whose half transforms are queued back to back (df_jk._vk_mo)
         self.k_nsplit = None       # k-splits of the K = X^T X product; None: df_jk.syrk_plan picks tile shape and splits
         self.lindep = 1e-7         # pyscf/df/incore.py:33
         self.decompose_j2c = 'CD'  # 'ED': eigen-decompose the metric even when it is positive definite (df/grad/rhf.py:45)
@@ -480,6 +481,7 @@ class DF:
             obj.omega = float(omega)
             obj.auxmol = self.auxmol
             obj.k_block_bytes, obj.k_nsplit, obj.lindep = self.k_block_bytes, self.k_nsplit, self.lindep
+            obj.k_e2_pipeline = self.k_e2_pipeline
             obj.decompose_j2c = self.decompose_j2c
             self._rsh_df[key] = obj
         return self._rsh_df[key]

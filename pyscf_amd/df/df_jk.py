@@ -244,22 +244,30 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
         if 0 < nsq < naux:
             # partial image (rows [0, nsq)): cut the K blocks at its end
             bounds = sorted(set(list(range(0, nsq, blk)) + [nsq] + list(range(nsq, naux, blk)) + [naux]))
+        # e2-first order inside a block (r03): the half transforms of its `nsub` sub-blocks are queued back to back and the second
+        # J pass of sub-block s (side stream) runs beside the half transform of sub-block s + 1 - a pure HBM stream hides ~80 %
+        # behind that kernel (its operands arrive by DMA one tile ahead) but only ~25 % behind the SYRK, whose L2 -> LDS panel
+        # traffic shares the path with it; only the last sub-block's pass is left for the SYRK.  One SYRK per block as before.
+        nsub = max(1, int(getattr(dfobj, 'k_e2_pipeline', 1) or 1)) if after_e2 is not None else 1
         for b0, b1 in zip(bounds[:-1], bounds[1:]):
             nb = b1 - b0
-            if b1 <= nsq:
-                # fuse_j[set] = rho (naux) zeroed: the first J pass of the density orb orb^T comes out of the epilogue
-                rho_j = fuse_j[iset] if fuse_j is not None else None
-                _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[b0:b0 + nb]), _c.c_long(sq.shape[2]),
-                      _c.c_int(sq.shape[1]), _c.c_int(nb), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
-                      _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(X), _c.c_int(ldx),
-                      _ptr(rho_j[b0:]) if rho_j is not None else _c.c_void_p(0),
-                      _rho_work(dfobj, lib, nb, ldx, nocc_pad) if rho_j is not None else _c.c_void_p(0), st)
-            else:
-                _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, nocc_pad, X, ldx,
-                           _ptr(fuse_j[iset][b0:]) if fuse_j is not None else None,
-                           _rho_work(dfobj, lib, nb, ldx, nocc_pad) if fuse_j is not None else None, st)
-            if after_e2 is not None:
-                after_e2(b0, nb, iset)
+            cuts = sorted(set(b0 + (nb * s_) // nsub for s_ in range(nsub + 1)))
+            for s0, s1 in zip(cuts[:-1], cuts[1:]):
+                ns, xs = s1 - s0, X[s0 - b0:]
+                if b1 <= nsq:
+                    # fuse_j[set] = rho (naux) zeroed: the first J pass of the density orb orb^T comes out of the epilogue
+                    rho_j = fuse_j[iset] if fuse_j is not None else None
+                    _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[s0:s0 + ns]), _c.c_long(sq.shape[2]),
+                          _c.c_int(sq.shape[1]), _c.c_int(ns), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
+                          _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(xs), _c.c_int(ldx),
+                          _ptr(rho_j[s0:]) if rho_j is not None else _c.c_void_p(0),
+                          _rho_work(dfobj, lib, ns, ldx, nocc_pad) if rho_j is not None else _c.c_void_p(0), st)
+                else:
+                    _e2_packed(dfobj, lib, s0, ns, nao, orb, ldo, nocc_pad, xs, ldx,
+                               _ptr(fuse_j[iset][s0:]) if fuse_j is not None else None,
+                               _rho_work(dfobj, lib, ns, ldx, nocc_pad) if fuse_j is not None else None, st)
+                if after_e2 is not None:
+                    after_e2(s0, ns, iset)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
                   _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(syrk_flags),
                   _c.c_int(nsplit), st)

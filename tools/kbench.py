@@ -18,6 +18,8 @@ ap.add_argument('--tune', default='', help='comma list key=value for PAMD_set_tu
 ap.add_argument('--no-overlap', action='store_true')
 ap.add_argument('--no-split', action='store_true')
 ap.add_argument('--no-square', action='store_true')
+ap.add_argument('--e2-pipeline', type=int, default=0)
+ap.add_argument('--block-gb', type=float, default=0)
 ap.add_argument('--no-fuse', action='store_true')
 ap.add_argument('--ksplit', type=int, default=0)
 ap.add_argument('--syrk-flags', type=int, default=-1, help='4: balanced k split, 8: re-tiled triangle (df_jk.syrk_plan)')
@@ -35,6 +37,8 @@ obj._naux = a.naux
 obj.overlap_jk = not a.no_overlap
 obj.overlap_split = not a.no_split
 if a.no_square: obj.k_square = False
+if a.e2_pipeline: obj.k_e2_pipeline = a.e2_pipeline
+if a.block_gb: obj.k_block_bytes = int(a.block_gb * (1 << 30))
 if a.no_fuse: obj.fuse_j_pass1 = False
 if a.ksplit: obj.k_nsplit = a.ksplit
 obj.k_syrk_flags = None if a.syrk_flags < 0 else a.syrk_flags
