@@ -56,6 +56,8 @@ def main():
     ap.add_argument('--k-square', default='auto', choices=['auto', 'off'], help="'off': no unpacked image - the K half transform "
                     "reads the packed rows (+ the diagonal-block side image, 14 %% of the tensor): what a rank without 2x the "
                     "tensor size of spare HBM runs")
+    ap.add_argument('--j2-policy', default='auto', choices=['auto', 'overlap', 'serial'], help='second J pass beside the SYRK on a '
+                    'side stream, or in line before a re-tiled SYRK; auto: both timed once in the first (warm-up) build')
     ap.add_argument('--syrk-flags', type=int, default=-1, help='override DF.k_syrk_flags (A/B runs): 0 plain, 12 re-tiled + balanced')
     args = ap.parse_args()
     if args.backend:
@@ -123,6 +125,7 @@ def main():
         dfobj.k_syrk_flags = args.syrk_flags
     if args.k_square == 'off':
         dfobj.k_square = False
+    dfobj.j2_policy = args.j2_policy
     for kv in filter(None, args.tune.split(',')):
         k_, v_ = kv.split('=')
         lib.check(lib.load_library().PAMD_set_tuning(k_.encode(), int(v_)))
@@ -169,6 +172,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step()           # set-up, not a warm-up step: builds the lazy images of the tensor and lets DF.j2_policy = 'auto' time its two schedules
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -452,6 +457,7 @@ def main():
         'value_host_api_ms': round(host_api_ms, 3), 'host_api_fused_j': host_fused,
         'roofline': roofline, 'roofline_step': step_roof,
         'cpu_baseline': cpu, 'comm': comm_info, 'preflight': preflight,
+        'jk_schedule': getattr(dfobj, '_j2_policy_times', {'chosen': dfobj.j2_policy}),
         'kernels': kern, 'kernels_what': 'HIP events around every launch of the %d timed steps, per step (ms_total) and per launch '
                                          '(ms_avg); J runs overlapped with K there' % args.steps,
         'kernels_serial_pass': kern_serial, 'j_hbm_GBs': j_gbs, 'k_mfma_TFLOPs': k_tflops,

@@ -28,6 +28,7 @@
 #include <string>
 #include <vector>
 #include "common.h"
+#include <cstdlib>
 #include "../../include/pyscf_amd.h"
 
 using namespace pamd;
@@ -311,7 +312,7 @@ struct PAMD_df {
     DevPool pool;
     hipStream_t st = nullptr, side = nullptr;
     hipEvent_t ev = nullptr;
-    double *d_cderi = nullptr, *d_sq = nullptr;
+    double *d_cderi = nullptr, *d_sq = nullptr, *d_diag = nullptr;
     int rows = 0;                           // round_up(nao, 16)
     std::map<std::string, std::pair<double *, size_t>> ws;
     double *workspace(const std::string &name, size_t ndoubles, int *rc)
@@ -599,7 +600,10 @@ int decompose_metric(PAMD_df *h, double *d_j2c, int naux, double lindep, std::ve
 
 int build_square_image(PAMD_df *h)
 {
-    // K path on the unpacked image when HBM allows (DF.k_square = 'auto': 48 GB must stay free afterwards)
+    // K path on the unpacked image when HBM allows (DF.k_square = 'auto': 48 GB must stay free afterwards);
+    // PAMD_DF_SQUARE=0 in the environment = DF.k_square = False (tests, memory-constrained callers)
+    const char *env = getenv("PAMD_DF_SQUARE");
+    if (env && env[0] == '0') return 0;
     size_t free_b = 0, total_b = 0;
     PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t need = ((size_t)h->nL * h->rows * h->rows + 256) * 8;
@@ -608,6 +612,20 @@ int build_square_image(PAMD_df *h)
     if (rc) { h->d_sq = nullptr; return 0; }
     PAMD_CHECK_HIP(hipMemsetAsync(h->d_sq, 0, need, h->st));
     return PAMD_unpack_tril(h->d_cderi, h->npair, h->nL, h->nao, h->d_sq, h->rows, h->rows, h->st);
+}
+
+// no room for the square image: keep at least the 128 x 128 diagonal blocks unpacked (14 % of the packed size at nao 1856), so
+// that the packed-operand half transform reads the k-tiles crossing the diagonal once and unmasked (DF.diag_image)
+int build_diag_image(PAMD_df *h)
+{
+    if (h->d_sq || h->nL == 0 || h->nao < 128) return 0;
+    size_t free_b = 0, total_b = 0;
+    PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = (size_t)PAMD_e2_diag_size(h->nL, h->rows) * 8;
+    if (need + (48ul << 30) > free_b) return 0;
+    int rc = h->pool.alloc((void **)&h->d_diag, need);
+    if (rc) { h->d_diag = nullptr; return 0; }
+    return PAMD_e2_diag_blocks(h->d_cderi, h->npair, h->nL, h->nao, h->rows, h->d_diag, h->st);
 }
 
 }  // namespace
@@ -741,6 +759,7 @@ int PAMD_df_create(const int *atm, int natm, const int *bas, int nbas_ao, int nb
     tmp.release(d_T);
     tmp.release(d_mt);
     if ((rc = build_square_image(h))) return rc;
+    if ((rc = build_diag_image(h))) return rc;
     PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
     guard.p = nullptr;
     *out = h;
@@ -881,8 +900,8 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
                         rc = PAMD_nr_e2_square(h->d_sq + (size_t)b0 * rows * rows, rows, rows, nb, nao, d_orb, (int)ldo, rows, nocc_pad,
                                                d_X, ldx, rho_b, d_rw, st);
                     else
-                        rc = PAMD_nr_e2_symm(h->d_cderi + (size_t)b0 * npair, npair, nb, nao, d_orb, (int)ldo, rows, nocc_pad, d_X, ldx,
-                                             rho_b, d_rw, st);
+                        rc = PAMD_nr_e2_symm_diag(h->d_cderi + (size_t)b0 * npair, npair, nb, nao, d_orb, (int)ldo, rows, nocc_pad, d_X, ldx,
+                                                  rho_b, d_rw, h->d_diag ? h->d_diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st);
                     if (rc) return rc;
                     if (fused) {
                         // second J pass of this block on the side stream, behind the block's SYRK (HBM-bound beside MFMA-bound)
@@ -917,7 +936,8 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
                 for (long b0 = 0; b0 < nL; b0 += blk) {
                     const int nb = (int)std::min<long>(blk, nL - b0);
                     const double *sub = h->d_cderi + (size_t)b0 * npair;
-                    if ((rc = PAMD_nr_e2_symm(sub, npair, nb, nao, d_orb, (int)ldo, rows, rows, d_X, ldx, nullptr, nullptr, st))) return rc;
+                    if ((rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, d_orb, (int)ldo, rows, rows, d_X, ldx, nullptr, nullptr,
+                                                   h->d_diag ? h->d_diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st))) return rc;
                     if ((rc = PAMD_unpack_tril(sub, npair, nb, nao, d_full, ldx, rows, st))) return rc;
                     if ((rc = PAMD_dgemm_tn(d_X, ldx, d_full, ldx, d_part, nao, nao, nao, (long)nb * rows, 0 | 2, nsplit, st))) return rc;
                 }

@@ -33,6 +33,9 @@ class DF:
         self.group = group
         # HBM budget for the half-transformed block X (MI355X: 288 GB per GPU)
         self.k_block_bytes = 8 << 30
+        self.j2_policy = 'auto'    # second J pass 'overlap' (side stream, beside a plain SYRK) | 'serial' (in line, re-tiled SYRK) |
+                                   # 'auto': both timed once per shape (df_jk.get_jk_device)
+        self.j2_tune_min_bytes = 4 << 30
         self.k_e2_pipeline = 1     # sub-blocks of a K block whose half transforms are queued back to back (df_jk._vk_mo)
         self.k_nsplit = None       # k-splits of the K = X^T X product; None: df_jk.syrk_plan picks tile shape and splits
         self.lindep = 1e-7         # pyscf/df/incore.py:33
@@ -189,7 +192,7 @@ class DF:
         n = so.PAMD_e2_diag_size(_c.c_int(naux - row0), _c.c_int(ldx))
         dev = self._cderi_dev.device
         free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-        if free - getattr(self, 'k_square_reserve', 0) < n * 8:
+        if free - (4 << 30) < n * 8:       # (the square image has left k_square_reserve free; the work buffers live in there)
             self.k_diag = False
             return None, 0
         buf = torch.empty(n, dtype=torch.float64, device=dev)
@@ -481,7 +484,7 @@ class DF:
             obj.omega = float(omega)
             obj.auxmol = self.auxmol
             obj.k_block_bytes, obj.k_nsplit, obj.lindep = self.k_block_bytes, self.k_nsplit, self.lindep
-            obj.k_e2_pipeline = self.k_e2_pipeline
+            obj.k_e2_pipeline, obj.j2_policy = self.k_e2_pipeline, self.j2_policy
             obj.decompose_j2c = self.decompose_j2c
             self._rsh_df[key] = obj
         return self._rsh_df[key]

@@ -212,7 +212,7 @@ def pad_orbitals(orbo, device):
     return torch.from_numpy(orb_h).to(device), (nocc_pad if nocc else 0), ldo
 
 
-def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
+def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True):
     """K_pq = sum_{L,i} X[L,i,p] X[L,i,q],  X[L,i,p] = sum_q B_L[p,q] orbo[q,i]
     (df_jk.py:353-380; nr_ao2mo.c:399-419,1240-1266).  orb_list: [(orb_dev, nocc_pad, ldo)]."""
     torch = _torch()
@@ -222,7 +222,7 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None):
     st = _stream()
     ldx = _round_up(nao, 16)
     kflags = getattr(dfobj, 'k_syrk_flags', None)
-    if kflags is None and after_e2 is not None:
+    if kflags is None and after_e2 is not None and j_corun:
         # the second J pass runs beside this SYRK on the side stream: it hides in the 32 workgroup slots the plain 120 x 4 grid
         # leaves idle (J/K 108.8 ms) but not beside the balanced schedule that fills them (110.0 ms; K alone: 35.6 vs 39.7 ms): the
         # SYRK's own L2 -> LDS panel traffic and the J stream share one path - plain grid when J co-runs
@@ -524,22 +524,57 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                     fused = dm_from_orbitals is None and _dm_matches_orbitals(dms_dev, orb_list, nao)
                 dfobj._last_fused = bool(fused)
                 if fused:
-                    # pass 1 comes out of the half transform (PAMD_nr_e2_square); pass 2 of each K block follows on
-                    # the side stream behind that block's SYRK
+                    # pass 1 comes out of the half transform (PAMD_nr_e2_square); pass 2 of each K block follows either on the
+                    # side stream behind that block's SYRK (plain SYRK grid) or in line before it (re-tiled + balanced SYRK):
+                    # which one is faster depends on the shape (config 3: overlapped 109.5 vs 111.7 ms; taxol on one GPU:
+                    # 351 vs 332 ms) - `DF.j2_policy = 'auto'` times both once per shape on tensors of 4 GB and more
                     naux_l, npair_l = dfobj._cderi_dev.shape
-                    rho_f = torch.zeros((nset, naux_l), dtype=torch.float64, device=dms_dev.device)
-                    vj_f = torch.zeros((nset, npair_l), dtype=torch.float64, device=dms_dev.device)
 
-                    def pass2_block(b0, nb, iset):
-                        ev = torch.cuda.Event()
-                        ev.record()
-                        side.wait_event(ev)
-                        with torch.cuda.stream(side):
-                            _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(dfobj._cderi_dev[b0:b0 + nb]),
-                                  _c.c_long(npair_l), _c.c_int(nb), _ptr(rho_f[iset, b0:]), _c.c_int(1),
-                                  _ptr(vj_f[iset]), _c.c_void_p(side.cuda_stream))
-                    vk_dev = _vk_mo(dfobj, lib, orb_list, nao, after_e2=pass2_block, fuse_j=rho_f)
-                    holder['vj'] = vj_f
+                    def run_fused(serial):
+                        rho_f = torch.zeros((nset, naux_l), dtype=torch.float64, device=dms_dev.device)
+                        vj_f = torch.zeros((nset, npair_l), dtype=torch.float64, device=dms_dev.device)
+
+                        def pass2_block(b0, nb, iset):
+                            if serial:
+                                _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(dfobj._cderi_dev[b0:b0 + nb]),
+                                      _c.c_long(npair_l), _c.c_int(nb), _ptr(rho_f[iset, b0:]), _c.c_int(1),
+                                      _ptr(vj_f[iset]), _stream())
+                                return
+                            ev = torch.cuda.Event()
+                            ev.record()
+                            side.wait_event(ev)
+                            with torch.cuda.stream(side):
+                                _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(dfobj._cderi_dev[b0:b0 + nb]),
+                                      _c.c_long(npair_l), _c.c_int(nb), _ptr(rho_f[iset, b0:]), _c.c_int(1),
+                                      _ptr(vj_f[iset]), _c.c_void_p(side.cuda_stream))
+                        vk = _vk_mo(dfobj, lib, orb_list, nao, after_e2=pass2_block, fuse_j=rho_f, j_corun=not serial)
+                        return vj_f, vk
+
+                    policy = getattr(dfobj, 'j2_policy', 'auto')
+                    if policy == 'auto':
+                        key = (nset, nao, tuple(o[1] for o in orb_list), naux_l,
+                               0 if sq is None else sq.shape[0])
+                        cache = dfobj.__dict__.setdefault('_j2_policy_cache', {})
+                        policy = cache.get(key)
+                        if policy is None and naux_l * npair_l * 8 < getattr(dfobj, 'j2_tune_min_bytes', 4 << 30):
+                            policy = cache[key] = 'overlap'
+                        if policy is None:
+                            timer, dfobj.kernel_timer = getattr(dfobj, 'kernel_timer', None), None
+                            run_fused(False)                                     # priming: lazy images, workspaces
+                            times = {}
+                            for name in ('overlap', 'serial'):
+                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                torch.cuda.current_stream().wait_stream(side)
+                                e0.record()
+                                run_fused(name == 'serial')
+                                torch.cuda.current_stream().wait_stream(side)
+                                e1.record()
+                                e1.synchronize()
+                                times[name] = e0.elapsed_time(e1)
+                            policy = cache[key] = 'serial' if times['serial'] < 0.99 * times['overlap'] else 'overlap'
+                            dfobj._j2_policy_times = dict(times, chosen=policy)
+                            dfobj.kernel_timer = timer
+                    holder['vj'], vk_dev = run_fused(policy == 'serial')
 
                 def launch_j(*_a):
                     if 'vj' in holder:

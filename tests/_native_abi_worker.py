@@ -78,6 +78,30 @@ def main():
         assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9
         o2.reset()
     stamp('MO branch cases done')
+    # no square image (PAMD_DF_SQUARE=0 = DF.k_square False): packed-operand half transform with the diagonal-block side image
+    # (PAMD_nr_e2_symm_diag) in both K branches - 120 fractionally occupied orbitals so that the 128-orbital chunk shape applies
+    os.environ['PAMD_DF_SQUARE'] = '0'
+    try:
+        m4 = gto.M(atom=clusters.water_cluster(4), basis='cc-pvtz')
+        o4 = native.NativeDF(m4).build()
+        cd = ref.cholesky_eri(m4, addons.make_auxmol(m4))
+        n = m4.nao
+        assert n >= 197
+        c = np.linalg.qr(np.random.RandomState(5).rand(n, n))[0]
+        occ = np.zeros(n)
+        occ[:120] = np.linspace(2.0, 0.5, 120)
+        dm = (c * occ).dot(c.T)
+        vj0, vk0 = ref.get_jk(cd, dm, 1, mo_coeff=c, mo_occ=occ)
+        vj, vk = o4.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=occ), hermi=1)
+        assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9, (np.abs(vj - vj0).max(), np.abs(vk - vk0).max())
+        dmg = dm + 0.05 * np.random.RandomState(6).rand(n, n)                 # no tag, not symmetric: general branch
+        vj0, vk0 = ref.get_jk(cd, dmg, 0)
+        vj, vk = o4.get_jk(dmg, hermi=0)
+        assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9, (np.abs(vj - vj0).max(), np.abs(vk - vk0).max())
+        o4.reset()
+    finally:
+        del os.environ['PAMD_DF_SQUARE']
+    stamp('packed + diagonal-block image cases done')
     # linearly dependent metric: two copies of the aux basis on the same atoms -> Cholesky fails, eigen-decomposition path
     dup = gto.M(atom=h2o, basis='sto-3g')
     aux1 = addons.make_auxmol(dup, 'weigend')

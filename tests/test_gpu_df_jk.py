@@ -403,3 +403,30 @@ def test_foreign_tag_that_does_not_match_its_matrix(h2o):
     vj1, _ = ref.get_jk(cderi, other, 1)
     vj, vk = obj.get_jk(lib.tag_array(other, mo_coeff=c, mo_occ=occ), hermi=1)
     assert np.abs(vj - vj1).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11
+
+
+def test_second_j_pass_schedules(h2o):
+    """DF.j2_policy: the second J pass on the side stream beside a plain SYRK ('overlap'), in line before the re-tiled SYRK
+    ('serial'), or whichever a one-off timing of both finds faster ('auto', tensors above j2_tune_min_bytes): same J and K."""
+    from pyscf_amd import lib
+    nao, naux, nocc = 200, 96, 37
+    rng = np.random.default_rng(11)
+    cderi = rng.standard_normal((naux, nao * (nao + 1) // 2)) / np.sqrt(nao)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao)
+    occ[:nocc] = 2
+    dm = lib.tag_array((c * occ).dot(c.T), mo_coeff=c, mo_occ=occ)
+    vj0, vk0 = ref.get_jk(cderi, np.asarray(dm), 1, mo_coeff=c, mo_occ=occ)
+    for policy in ('overlap', 'serial', 'auto'):
+        obj = _dfobj(None, cderi)
+        obj.j2_policy = policy
+        obj.j2_tune_min_bytes = 0                       # 'auto': time both schedules even on this small tensor
+        obj.k_block_bytes = 40 * 48 * 208 * 8           # several K blocks
+        for _ in range(2):
+            vj, vk = obj.get_jk(dm, hermi=1)
+            assert obj._last_fused
+            assert np.abs(vj - vj0).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11, policy
+        if policy == 'auto':
+            t = obj._j2_policy_times
+            assert t['chosen'] in ('overlap', 'serial') and t['overlap'] > 0 and t['serial'] > 0
+            assert list(obj._j2_policy_cache.values()) == [t['chosen']]

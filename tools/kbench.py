@@ -19,6 +19,7 @@ ap.add_argument('--no-overlap', action='store_true')
 ap.add_argument('--no-split', action='store_true')
 ap.add_argument('--no-square', action='store_true')
 ap.add_argument('--e2-pipeline', type=int, default=0)
+ap.add_argument('--j2-policy', default='overlap', choices=['auto', 'overlap', 'serial'])
 ap.add_argument('--block-gb', type=float, default=0)
 ap.add_argument('--no-fuse', action='store_true')
 ap.add_argument('--ksplit', type=int, default=0)
@@ -38,6 +39,7 @@ obj.overlap_jk = not a.no_overlap
 obj.overlap_split = not a.no_split
 if a.no_square: obj.k_square = False
 if a.e2_pipeline: obj.k_e2_pipeline = a.e2_pipeline
+obj.j2_policy = a.j2_policy
 if a.block_gb: obj.k_block_bytes = int(a.block_gb * (1 << 30))
 if a.no_fuse: obj.fuse_j_pass1 = False
 if a.ksplit: obj.k_nsplit = a.ksplit
