@@ -539,6 +539,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const double *p)
     return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 0xffffffff, 0x00020000);
 }
 
+// reads through this pointer type stay single ds_read_b64 instructions (volatile: hipcc never merges them into ds_read2_b64)
+typedef const volatile __attribute__((address_space(3))) double *lds_b64_ptr;
+
 __device__ __forceinline__ void dma_row(__amdgpu_buffer_rsrc_t r, double *lds_dst, int voff_bytes, int soff_bytes)
 {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
@@ -817,7 +820,11 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
             if constexpr (NA == 5) af[4] = ca[offr + kk * 32];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                const double val = TR ? cb[atr[kk >> 2] + b * 256] : cb[offb_row + kk * LDN + b * 16];
+                // transposed tiles: single ds_read_b64 (32-lane groups, 64-dword bank modulus - what the swizzle is made for).
+                // Merged into ds_read2_b64 (16-lane groups, 32-dword modulus) the 16 fn-lanes all read the same half of their
+                // 16-byte chunks: an inherent 2-way conflict (PMC, r03: SQ_LDS_BANK_CONFLICT 4.8e9 -> 0, LDS cycles 2.71e10 ->
+                // 1.93e10, kernel -1.2 %; every OTHER fragment read is faster merged - profiles/r03/kbench_frag_reads.log)
+                const double val = TR ? ((lds_b64_ptr)cb)[atr[kk >> 2] + b * 256] : cb[offb_row + kk * LDN + b * 16];
                 if (MK) {
                     const bool below = (d + tb[b] + kk) >= 0;      // q >= p
                     bf[b] = (below != TR) ? val : 0.0;
