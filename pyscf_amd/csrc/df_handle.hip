@@ -918,7 +918,7 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
                 if ((rc = PAMD_reduce_splits(d_part, nsplit, nao, nao, d_vk + (size_t)s * n2, nao, 1, st))) return rc;
             } else {
                 // ---- general-DM branch: T_L = B_L D, K = sum_L T_L^T B_L (df_jk.py:382-407)
-                const long ldo = rows > 160 ? round_up(rows, 160) : rows;
+                const long ldo = rows > 160 ? round_up(rows, 160) : round_up(rows, 32);    // whole 32-column wave tiles
                 double *d_orb = h->workspace("orb_dm", (size_t)rows * ldo, &rc);
                 if (rc) return rc;
                 PAMD_CHECK_HIP(hipMemsetAsync(d_orb, 0, (size_t)rows * ldo * 8, st));
@@ -930,16 +930,27 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
                 blk = std::max<long>(1, ((nL + nblk - 1) / nblk) / 2);
                 double *d_X = h->workspace("X", (size_t)blk * rows * ldx, &rc);
                 if (rc) return rc;
-                double *d_full = h->workspace("full", (size_t)blk * rows * ldx, &rc);
-                if (rc) return rc;
-                PAMD_CHECK_HIP(hipMemsetAsync(d_full, 0, (size_t)blk * rows * ldx * 8, st));
+                // rows with an unpacked image: it IS the second operand (no per-block unpack) and feeds the square-image kernel
+                double *d_full = nullptr;
+                if (!h->d_sq) {
+                    d_full = h->workspace("full", (size_t)blk * rows * ldx, &rc);
+                    if (rc) return rc;
+                    PAMD_CHECK_HIP(hipMemsetAsync(d_full, 0, (size_t)blk * rows * ldx * 8, st));
+                }
                 for (long b0 = 0; b0 < nL; b0 += blk) {
                     const int nb = (int)std::min<long>(blk, nL - b0);
                     const double *sub = h->d_cderi + (size_t)b0 * npair;
-                    if ((rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, d_orb, (int)ldo, rows, rows, d_X, ldx, nullptr, nullptr,
-                                                   h->d_diag ? h->d_diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st))) return rc;
-                    if ((rc = PAMD_unpack_tril(sub, npair, nb, nao, d_full, ldx, rows, st))) return rc;
-                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_full, ldx, d_part, nao, nao, nao, (long)nb * rows, 0 | 2, nsplit, st))) return rc;
+                    const double *second = d_full;
+                    if (h->d_sq) {
+                        second = h->d_sq + (size_t)b0 * rows * rows;
+                        if ((rc = PAMD_nr_e2_square(second, rows, rows, nb, nao, d_orb, (int)ldo, rows, rows, d_X, ldx, nullptr, nullptr, st)))
+                            return rc;
+                    } else {
+                        if ((rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, d_orb, (int)ldo, rows, rows, d_X, ldx, nullptr, nullptr,
+                                                       h->d_diag ? h->d_diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st))) return rc;
+                        if ((rc = PAMD_unpack_tril(sub, npair, nb, nao, d_full, ldx, rows, st))) return rc;
+                    }
+                    if ((rc = PAMD_dgemm_tn(d_X, ldx, second, ldx, d_part, nao, nao, nao, (long)nb * rows, 0 | 2, nsplit, st))) return rc;
                 }
                 if ((rc = PAMD_reduce_splits(d_part, nsplit, nao, nao, d_vk + (size_t)s * n2, nao, 0, st))) return rc;
             }

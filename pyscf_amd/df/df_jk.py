@@ -302,30 +302,41 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
     st = _stream()
     ldx = _round_up(nao, 16)
     rows = _round_up(nao, 16)
-    ldo = _round_up(rows, 160) if rows > 160 else rows
+    ldo = _round_up(rows, 160) if rows > 160 else _round_up(rows, 32)     # whole 32-column wave tiles (square-image kernel)
     nsplit = dfobj.k_nsplit or 4
     blk = max(1, _k_blocksize(dfobj, naux, rows, ldx) // 2)
     vk = torch.zeros((nset, nao, nao), dtype=torch.float64, device=dev)
     if naux == 0:
         return vk
     X = dfobj._workspace('X', (blk, rows, ldx))
-    full = dfobj._workspace('full', (blk, rows, ldx))
-    full.zero_()
+    # rows with an unpacked image: it IS the second operand (no per-block unpack) and feeds the square-image half transform
+    sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
+    nsq = sq.shape[0] if sq is not None and sq.shape[1] == rows and sq.shape[2] == ldx else 0
+    bounds = sorted(set(list(range(0, nsq, blk)) + [nsq] + list(range(nsq, naux, blk)) + [naux]))
+    full = None
+    if nsq < naux:
+        full = dfobj._workspace('full', (blk, rows, ldx))
+        full.zero_()
     for k in range(nset):
         orb = torch.zeros((rows, ldo), dtype=torch.float64, device=dev)
         orb[:nao, :nao] = dms_dev[k]
         part = torch.zeros((nsplit, nao, nao), dtype=torch.float64, device=dev)
-        for b0 in range(0, naux, blk):
-            nb = min(blk, naux - b0)
-            sub = cderi[b0:b0 + nb]
-            _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, rows, X, ldx, None, None, st)
-            _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(sub), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
-                                                _ptr(full), _c.c_int(ldx), _c.c_int(rows), st)
-            _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(full), _c.c_int(ldx), _ptr(part),
-                                             _c.c_int(nao), _c.c_int(nao), _c.c_int(nao),
-                                             _c.c_long(nb * rows), _c.c_int(0 | 2), _c.c_int(nsplit), st)
+        for b0, b1 in zip(bounds[:-1], bounds[1:]):
+            nb = b1 - b0
+            if nb == 0:
+                continue
+            if b1 <= nsq:
+                _half_transform(dfobj, lib, b0, nb, orb, rows, ldo, nao, X, ldx, st)
+                second = sq[b0:b1]
+            else:
+                _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, rows, X, ldx, None, None, st)
+                _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(cderi[b0:b1]), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
+                      _ptr(full), _c.c_int(ldx), _c.c_int(rows), st)
+                second = full
+            _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(second), _c.c_int(ldx), _ptr(part),
+                  _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * rows), _c.c_int(0 | 2), _c.c_int(nsplit), st)
         _call(dfobj, 'reduce_splits', lib.PAMD_reduce_splits, _ptr(part), _c.c_int(nsplit), _c.c_int(nao), _c.c_int(nao),
-                                              _ptr(vk[k]), _c.c_int(nao), _c.c_int(0), st)
+              _ptr(vk[k]), _c.c_int(nao), _c.c_int(0), st)
     return vk
 
 

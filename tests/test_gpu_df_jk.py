@@ -375,6 +375,11 @@ def test_partial_square_image():
     # the same kernel on all rows, and once more without the side image
     assert obj._cderi_diag is not None and obj._diag_row0 == 128 and obj._cderi_diag.shape[0] == naux - 128
     assert ref_obj._cderi_diag is not None and ref_obj._diag_row0 == 0 and ref_obj._cderi_diag.shape[0] == naux
+    # general-DM branch (hermi = 0) across the boundary: image rows are the second operand as they are, packed rows are unpacked
+    dmg = rng.standard_normal((nao, nao))
+    vjg, vkg = obj.get_jk(dmg, hermi=0)
+    vjg0, vkg0 = ref.get_jk(cderi, dmg, 0)
+    assert np.abs(vjg - vjg0).max() < 1e-11 * np.abs(vjg0).max() and np.abs(vkg - vkg0).max() < 1e-11 * np.abs(vkg0).max()
     plain = _dfobj(None, cderi)
     plain.k_square = plain.k_diag = False
     vj2, vk2 = plain.get_jk(dm, hermi=1)
