@@ -782,14 +782,20 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
 #pragma unroll
     for (int j = 0; j < 4; j++) dvo[j] = voff_tr[j] - voff;
 
-    auto stage_row = [&](int v, double *da, double *db, int j) {
+    // NTR: layout of the tile being staged when the caller knows it at compile time (0 row, 1 transposed; 2 = ask tile_tr):
+    // inside the DIAG kernel's two phases it does, and the lane offset / LDS stride / source offset selects (4 v_cndmask per
+    // k-tile - ~0.45 % of the kernel each - and a third of the SALU work) fold away
+    auto stage_row = [&](auto NTRc, int v, double *da, double *db, int j) {
+        constexpr int NTR = decltype(NTRc)::value;
         const int q0 = tile_q0(v);
-        const int tr = tile_tr(v);
+        const int tr = NTR == 2 ? tile_tr(v) : NTR;
         const int k = wave * 4 + j;
         dma_row(r_orb, da + k * LDN, voff, (q0 + k) * ldo8);
         const int q = q0 + k;
         const int soff_row = (q * (q + 1) / 2 + p0) * 8;
-        if constexpr (DIAG) {
+        if constexpr (DIAG && NTR == 1) {
+            dma_row(r_pk, db + k * 128, voff_tr[j], q0 * 8);                     // above the diagonal block: never from the side image
+        } else if constexpr (DIAG) {
             const int u = v - nA;
             const int is_dg = (~(u >> 31)) & ((u - ncross) >> 31) & 1;           // 0 <= u < ncross: the diagonal block
             const int soff = soff_row + tr * (q0 * 8 - soff_row) + is_dg * ((q - p0) * (NT * 8) - soff_row);
@@ -806,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     // One k-tile body per (layout, masked?) pair, each a single basic block: measured with a layout-generic body, ~100 VALU
     // selects per tile in a layout-generic body cost 12 % - a VALU between two FP64 MFMAs is not free (~6 cycles each) - so
     // the fragment addresses of a body are immediates again and the keep-masks exist only in the (<= 16) crossing tiles.
-    auto step = [&](auto TRc, auto MKc, const double *ca, const double *cb, double *na, double *nb, int v) {
+    auto step = [&](auto TRc, auto MKc, auto NTRc, const double *ca, const double *cb, double *na, double *nb, int v) {
         constexpr bool TR = decltype(TRc)::value, MK = decltype(MKc)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
                     bf[b] = val;
                 }
             }
-            stage_row(vn, na, nb, kk >> 2);
+            stage_row(NTRc, vn, na, nb, kk >> 2);
 #pragma unroll
             for (int a = 0; a < NA; a++)
 #pragma unroll
@@ -841,24 +847,41 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     };
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
+    using N0 = std::integral_constant<int, 0>;
+    using N1 = std::integral_constant<int, 1>;
+    using N2 = std::integral_constant<int, 2>;
 #pragma unroll
-    for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
-    // the three phases start on even tiles (nA is a multiple of 8, the crossing tiles come in pairs), so the buffer of
+    for (int j = 0; j < 4; j++) stage_row(N2{}, 0, sa0, sq0, j);
+    // the phases start on even tiles (nA is a multiple of 8, the crossing tiles come in pairs), so the buffer of
     // every call is a compile-time constant: with run-time buffer pointers hipcc needs waterfall loops for m0
     int v = 0;
-    for (; v < nA; v += 2) {                                         // above the diagonal: transposed layout
-        step(T_{}, F_{}, sa0, sq0, sa1, sq1, v);
-        step(T_{}, F_{}, sa1, sq1, sa0, sq0, v + 1);
-    }
-    if constexpr (!DIAG) {
-        for (; v < nA + 2 * ncross; v += 2) {                        // crossing tiles: row half, then transposed half
-            step(F_{}, T_{}, sa0, sq0, sa1, sq1, v);
-            step(T_{}, T_{}, sa1, sq1, sa0, sq0, v + 1);
+    if constexpr (DIAG) {
+        for (; v < nA - 2; v += 2) {                                     // above the diagonal: transposed layout, and so is the next tile
+            step(T_{}, F_{}, N1{}, sa0, sq0, sa1, sq1, v);
+            step(T_{}, F_{}, N1{}, sa1, sq1, sa0, sq0, v + 1);
         }
-    }
-    for (; v < nvirt; v += 2) {                                      // below: row layout
-        step(F_{}, F_{}, sa0, sq0, sa1, sq1, v);
-        if (v + 1 < nvirt) step(F_{}, F_{}, sa1, sq1, sa0, sq0, v + 1);
+        if (v < nA) {                                                    // its last pair: the tile after it is the diagonal block (row layout)
+            step(T_{}, F_{}, N1{}, sa0, sq0, sa1, sq1, v);
+            step(T_{}, F_{}, N0{}, sa1, sq1, sa0, sq0, v + 1);
+            v += 2;
+        }
+        for (; v < nvirt; v += 2) {                                      // diagonal block (side image) and below: row layout
+            step(F_{}, F_{}, N0{}, sa0, sq0, sa1, sq1, v);
+            if (v + 1 < nvirt) step(F_{}, F_{}, N0{}, sa1, sq1, sa0, sq0, v + 1);
+        }
+    } else {
+        for (; v < nA; v += 2) {                                         // above the diagonal: transposed layout
+            step(T_{}, F_{}, N2{}, sa0, sq0, sa1, sq1, v);
+            step(T_{}, F_{}, N2{}, sa1, sq1, sa0, sq0, v + 1);
+        }
+        for (; v < nA + 2 * ncross; v += 2) {                            // crossing tiles: row half, then transposed half
+            step(F_{}, T_{}, N2{}, sa0, sq0, sa1, sq1, v);
+            step(T_{}, T_{}, N2{}, sa1, sq1, sa0, sq0, v + 1);
+        }
+        for (; v < nvirt; v += 2) {                                      // below: row layout
+            step(F_{}, F_{}, N2{}, sa0, sq0, sa1, sq1, v);
+            if (v + 1 < nvirt) step(F_{}, F_{}, N2{}, sa1, sq1, sa0, sq0, v + 1);
+        }
     }
     double *out = X + L * nocc_pad * ldx;
     double rho_acc = 0;
