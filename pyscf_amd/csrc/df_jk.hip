@@ -556,7 +556,11 @@ __device__ __forceinline__ void dma_row(__amdgpu_buffer_rsrc_t r, double *lds_ds
 // g+1 under the MFMAs of group g.  Wave (wr, wc) owns orbital tiles {64 wr + 16 a, a < 4} and {128 + 16 wr}.
 // A wave whose 64 AO columns all lie beyond `ncol` (the 128-column tile overhangs the matrix) only stages its DMA rows:
 // its matrix-pipe time goes to the co-resident workgroup.
-template <int NA, bool RHO, bool PAIR>
+// PAIRM: 0 = every workgroup takes one aux row and 128 columns; 1 = every workgroup takes the 64 valid columns of the last
+// column tile for TWO aux rows (separate launch, tuning "e2merge" = 0); 2 (default, r03) = one launch for both: the rows
+// blockIdx.y >= nL of the grid carry the pair workgroups - no second kernel boundary, and their ~2 rounds of workgroups fill up
+// the last round of the main ones (2 x 0.5 ms of a 110 ms step).
+template <int NA, bool RHO, int PAIRM>
 __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
     double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int ncol, int ptile0, int nslot,
@@ -572,9 +576,23 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     constexpr int RB = KB * LDN;                         // start of the remainder block inside sa*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p0 = (ptile0 + blockIdx.x / nchunk) * NT;
-    const long L = PAIR ? 2 * (long)blockIdx.y : blockIdx.y;
-    const int m0 = (blockIdx.x % nchunk) * M;
+    bool PAIR = PAIRM == 1;
+    int ptile = ptile0 + blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    long L = PAIRM == 1 ? 2 * (long)blockIdx.y : blockIdx.y;
+    if constexpr (PAIRM == 2) {
+        if ((long)blockIdx.y >= nL) {                  // ptile0 = the pair tile; main tiles are 0 .. gridDim.x / nchunk - 1
+            const long idx = ((long)blockIdx.y - nL) * gridDim.x + blockIdx.x;
+            if (idx >= (long)nchunk * ((nL + 1) / 2)) return;
+            PAIR = true;
+            ptile = ptile0;
+            chunk = (int)(idx % nchunk);
+            L = 2 * (idx / nchunk);
+        } else {
+            ptile = blockIdx.x / nchunk;
+        }
+    }
+    const int p0 = ptile * NT;
+    const int m0 = chunk * M;
     const __amdgpu_buffer_rsrc_t r_sq = make_rsrc(sq + L * lstride + p0);
     const __amdgpu_buffer_rsrc_t r_orb = make_rsrc(orb + m0);
     const int ldb8 = (int)ld * 8, ldo8 = ldo * 8;
@@ -668,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) rho_acc += __shfl_xor(rho_acc, off, 64);
         if (lane == 0) {
-            const long slot = (long)ptile0 * nchunk + blockIdx.x;
+            const long slot = (long)ptile * nchunk + chunk;
             if (row_ok) rho[(Lw * nslot + slot) * 4 + wave] = rho_acc;
             if (PAIR) {                                            // this wave has nothing for the other row of the pair
                 const long Lo = L + (1 - wc);
@@ -1197,6 +1215,7 @@ static int g_j2_wide = 0;     // second J pass with 16-byte loads (two packed co
 static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: one per 256 columns)
 static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
+static int g_e2_merge = 1;    // e2_sq2: pair-tail workgroups inside the main launch ("e2merge")
 static int g_pk_diag = 1;     // e2_pk reads the diagonal 128 x 128 blocks from the side image when the caller passes one ("pkdiag")
 static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
 static int g_syrk_probe = 0;  // benchmarking probe only: the re-tiled SYRK without its second panel DMA (results meaningless)
@@ -1219,6 +1238,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "pkdiag") == 0) { g_pk_diag = value; return 0; }
+    if (strcmp(key, "e2merge") == 0) { g_e2_merge = value; return 0; }
     if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
     if (strcmp(key, "pairtail") == 0) { g_pair_tail = value; return 0; }
     if (strcmp(key, "j2wg") == 0 && value >= 0) { g_j2_maxwg = value; return 0; }
@@ -1469,13 +1489,20 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
         const bool pair = g_pair_tail && ptiles > 1 && last_valid <= 64 && nL >= 2;
         const int pmain = pair ? ptiles - 1 : ptiles;
         dim3 gmain(pmain * nchunk, nL), gpair(nchunk, ceil_div(nL, 2));
+        const bool merged = pair && g_e2_merge;
+        dim3 gboth(pmain * nchunk, nL + ceil_div(nchunk * ceil_div(nL, 2), pmain * nchunk));
         double *rw = d_rho ? d_rho_work : nullptr;
 #define LAUNCH_V2(NAV, RHOF)                                                                                        \
         do {                                                                                                         \
-            e2_sq2_kernel<NAV, RHOF, false><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+            if (merged) {                                                                                            \
+                e2_sq2_kernel<NAV, RHOF, 2><<<gboth, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                                                                   nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio); \
+                break;                                                                                               \
+            }                                                                                                        \
+            e2_sq2_kernel<NAV, RHOF, 0><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out,   \
                                                                    nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL, g_e2_prio);    \
             if (pair)                                                                                                \
-                e2_sq2_kernel<NAV, RHOF, true><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                e2_sq2_kernel<NAV, RHOF, 1><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
                                                                       nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio); \
         } while (0)
         if (na2 == 5) { if (d_rho) LAUNCH_V2(5, true); else LAUNCH_V2(5, false); }
