@@ -858,7 +858,7 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
                 if (bn && units >= 32) { nsplit = bn + 1; syrk_flags = 1 | 2 | 4 | 8; }
             }
         }
-        const size_t budget = 8ul << 30;
+        const size_t budget = 12ul << 30;               // DF.k_block_bytes
         const double *op = orbo;
         for (int s = 0; s < nset && nL > 0; s++) {
             double *d_part = h->workspace("kpart", (size_t)nsplit * n2, &rc);

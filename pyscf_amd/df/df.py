@@ -32,7 +32,7 @@ class DF:
         self.device = device
         self.group = group
         # HBM budget for the half-transformed block X (MI355X: 288 GB per GPU)
-        self.k_block_bytes = 8 << 30
+        self.k_block_bytes = 12 << 30      # X block: config 3 in ONE block (10.6 GB; one kernel boundary less per step, -0.5 %)
         self.j2_policy = 'auto'    # second J pass 'overlap' (side stream, beside a plain SYRK) | 'serial' (in line, re-tiled SYRK) |
                                    # 'auto': both timed once per shape (df_jk.get_jk_device)
         self.j2_tune_min_bytes = 4 << 30

@@ -235,6 +235,8 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True):
             vks.append(vk)
             continue
         blk = _k_blocksize(dfobj, naux, nocc_pad, ldx)
+        if after_e2 is not None and fuse_j is None and naux >= 2:
+            blk = min(blk, -(-naux // 2))      # two-pass J beside K: pass 1 behind the first block's SYRK, pass 2 behind the second's
         X = dfobj._workspace('X', (blk, nocc_pad, ldx))
         part = dfobj._workspace('kpart', (nsplit, nao, nao))
         part.zero_()
