@@ -29,6 +29,7 @@
 #include <vector>
 #include "common.h"
 #include <cstdlib>
+#include <chrono>
 #include "../../include/pyscf_amd.h"
 
 using namespace pamd;
@@ -313,6 +314,7 @@ struct PAMD_df {
     hipStream_t st = nullptr, side = nullptr;
     hipEvent_t ev = nullptr;
     double *d_cderi = nullptr, *d_sq = nullptr, *d_diag = nullptr;
+    std::map<long, int> j2_policy;         // (nset, occupied counts) -> 0 overlap / 1 serial second J pass (PAMD_df_get_jk)
     int rows = 0;                           // round_up(nao, 16)
     std::map<std::string, std::pair<double *, size_t>> ws;
     double *workspace(const std::string &name, size_t ndoubles, int *rc)
@@ -801,8 +803,9 @@ int PAMD_df_export_cderi(PAMD_df *h, int l0, int l1, double *out)
 // flags bit 0: the caller guarantees dm[s] = orbo_s orbo_s^T (what make_rdm1 builds) - the first J pass then comes out of the
 //      half transform's epilogue instead of a pass over the tensor.
 // vj, vk caller-owned [nset][nao][nao] (NULL with with_j / with_k = 0).
-int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
-                   int with_k, int flags, double *vj, double *vk)
+// serial_j2: the second J pass of the fused path in line before a re-tiled SYRK (1) or on the side stream beside a plain one (0)
+static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
+                          int with_k, int flags, double *vj, double *vk, int serial_j2)
 {
     (void)hermi;
     PAMD_REQUIRE(h && dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
@@ -858,6 +861,7 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
                 if (bn && units >= 32) { nsplit = bn + 1; syrk_flags = 1 | 2 | 4 | 8; }
             }
         }
+        if (fused && !serial_j2) { nsplit = 4; syrk_flags = 1 | 2; }      // df_jk._vk_mo: plain grid beside the co-running J pass
         const size_t budget = 12ul << 30;               // DF.k_block_bytes
         const double *op = orbo;
         for (int s = 0; s < nset && nL > 0; s++) {
@@ -905,10 +909,15 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
                     if (rc) return rc;
                     if (fused) {
                         // second J pass of this block on the side stream, behind the block's SYRK (HBM-bound beside MFMA-bound)
-                        PAMD_CHECK_HIP(hipEventRecord(h->ev, st));
-                        PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev, 0));
-                        if ((rc = PAMD_df_vj_pass2(h->d_cderi + (size_t)b0 * npair, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side)))
-                            return rc;
+                        if (serial_j2) {
+                            if ((rc = PAMD_df_vj_pass2(h->d_cderi + (size_t)b0 * npair, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, st)))
+                                return rc;
+                        } else {
+                            PAMD_CHECK_HIP(hipEventRecord(h->ev, st));
+                            PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev, 0));
+                            if ((rc = PAMD_df_vj_pass2(h->d_cderi + (size_t)b0 * npair, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side)))
+                                return rc;
+                        }
                     }
                     if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, d_part, nao, nao, nao, (long)nb * nocc_pad, syrk_flags, nsplit, st))) return rc;
                     if (fused) {
@@ -970,6 +979,39 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
     PAMD_CHECK_HIP(hipStreamSynchronize(st));
     PAMD_CHECK_HIP(hipStreamSynchronize(h->side));
     return 0;
+}
+
+// Schedule of the second J pass on the fused path (DF.j2_policy of the Python layer): which of the two is faster depends on the
+// shape (config 3: overlapped, taxol on one GPU: in line), so a tensor of 4 GB and more gets both timed once per (nset, occupied
+// count) - two extra builds at the first call - and the choice is kept in the handle.  PAMD_DF_J2 = overlap | serial overrides.
+int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
+                   int with_k, int flags, double *vj, double *vk)
+{
+    PAMD_REQUIRE(h, "PAMD_df_get_jk: null handle");
+    const bool fused = with_j && with_k && orbo && (flags & 1) && h->nL > 0;
+    int serial = 0;
+    if (fused) {
+        const char *env = getenv("PAMD_DF_J2");
+        if (env && (env[0] == 's' || env[0] == 'o')) {
+            serial = env[0] == 's';
+        } else if ((size_t)h->nL * (size_t)h->npair * 8 >= (4ul << 30) && nocc) {
+            long key = nset;
+            for (int s = 0; s < nset; s++) key = key * 4099 + nocc[s];
+            auto it = h->j2_policy.find(key);
+            if (it == h->j2_policy.end()) {
+                double ms[2] = {0, 0};
+                for (int trial = 0; trial < 3; trial++) {             // overlap (priming, untimed), overlap, serial
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const int rc = df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, trial == 2);
+                    if (rc) return rc;
+                    if (trial) ms[trial - 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                }
+                it = h->j2_policy.emplace(key, ms[1] < 0.99 * ms[0] ? 1 : 0).first;
+            }
+            serial = it->second;
+        }
+    }
+    return df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, serial);
 }
 
 }  // extern "C"

@@ -94,6 +94,11 @@ def main():
         vj0, vk0 = ref.get_jk(cd, dm, 1, mo_coeff=c, mo_occ=occ)
         vj, vk = o4.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=occ), hermi=1)
         assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9, (np.abs(vj - vj0).max(), np.abs(vk - vk0).max())
+        for sched in ('serial', 'overlap'):                                   # both schedules of the fused path's second J pass
+            os.environ['PAMD_DF_J2'] = sched
+            vj, vk = o4.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=occ), hermi=1)
+            assert np.abs(vj - vj0).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9, sched
+        del os.environ['PAMD_DF_J2']
         dmg = dm + 0.05 * np.random.RandomState(6).rand(n, n)                 # no tag, not symmetric: general branch
         vj0, vk0 = ref.get_jk(cd, dmg, 0)
         vj, vk = o4.get_jk(dmg, hermi=0)
