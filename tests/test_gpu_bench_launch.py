@@ -31,6 +31,15 @@ def test_bench_gpus2_launches_two_ranks():
     assert len(rows) == 2 and sum(rows) == one['config']['naux_per_rank'][0] and abs(rows[0] - rows[1]) <= 1
     assert two['config']['naux_local'] == rows[0]
     assert two['value'] > 0 and two['value_host_api_ms'] > 0
+    # the driver's contract for the JSON line
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in one, key
+    assert one['steps'] == 2 and one['warmup'] == 1 and one['higher_is_better'] is False and one['dtype'] == 'f64'
+    assert one['unit'] == 'ms' and abs(one['value'] - one['ms_per_step']) < 1e-9 and 'workload' in one['config']
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(one['roofline'])
+    assert abs(one['roofline']['frac'] - one['roofline']['achieved'] / one['roofline']['peak']) < 1e-3
+    assert one['jk_schedule']['chosen'] in ('overlap', 'serial', 'auto')
     # the roofline durations are those of the timed steps (live HIP events), the serial pass is reported beside them
     assert one['roofline']['launches_per_step'] >= 1 and one['kernels_serial_pass'] and 'e2_symm' in one['kernels']
     assert one['kernels']['e2_symm']['ms_total'] < one['ms_per_step']
