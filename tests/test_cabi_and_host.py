@@ -23,6 +23,22 @@ def test_header_symbols_exported():
     assert so.PAMD_rys_table_len() == 38976
 
 
+def test_host_side_size_functions():
+    """Pure host arithmetic of the C ABI (no device call): workspace sizes a caller allocates before the launches."""
+    from pyscf_amd import lib
+    so = lib.load_library()
+    so.PAMD_e2_diag_size.restype = ctypes.c_long
+    # diag[nL][ceil(ldx / 128)][128][128] doubles: BASELINE config 3 (ldx = 1856 -> 15 blocks) is 8.7 GB, 14 % of the packed tensor
+    assert so.PAMD_e2_diag_size(4448, 1856) == 4448 * 15 * 128 * 128
+    assert abs(so.PAMD_e2_diag_size(4448, 1856) / (4448 * (1856 * 1857 // 2)) - 0.1426) < 1e-3
+    assert so.PAMD_e2_diag_size(3, 129) == 3 * 2 * 128 * 128 and so.PAMD_e2_diag_size(0, 500) == 0
+    # one partial per wave of every (aux row, column tile, orbital chunk) workgroup; monotone in every argument
+    w = so.PAMD_nr_e2_rho_worksize
+    assert w(4448, 1856, 160) >= 4448 * 15 * 1 * 4 and w(10, 1856, 160) <= w(11, 1856, 160) <= w(11, 1857, 160) <= w(11, 1857, 336)
+    so.PAMD_df_vj_pass1_worksize.restype = ctypes.c_long
+    assert so.PAMD_df_vj_pass1_worksize(ctypes.c_long(1856 * 1857 // 2), 4448, 1) > 0
+
+
 def test_args_struct_matches_header():
     from pyscf_amd.gto import moleintor
     hdr = open(os.path.join(ROOT, 'include', 'pyscf_amd.h')).read()
