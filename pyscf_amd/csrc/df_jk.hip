@@ -15,6 +15,7 @@
 //   gemm_tn    C[m][n]    += sum_k  A[k][m] * B[k][n]                 (FP64 MFMA; lower-tri
 //              tiles only for the K = X^T X  SYRK)
 #include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 #include "common.h"
@@ -1576,8 +1577,14 @@ int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, lo
 // block, column block}.  nitems = 0: even nb (or a tiny matrix) - the caller keeps the 2 x 2 tiling.
 static int syrk_items(int m, const int **d_items, int *nitems)
 {
-    static std::map<int, std::pair<int *, int>> cache;
-    auto hit = cache.find(m);
+    // one table per (device, m): a process may hold handles on several GPUs and call from one host thread per device
+    static std::map<std::pair<int, int>, std::pair<int *, int>> cache;
+    static std::mutex cache_mutex;
+    int dev = 0;
+    PAMD_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> guard(cache_mutex);
+    const std::pair<int, int> key(dev, m);
+    auto hit = cache.find(key);
     if (hit != cache.end()) { *d_items = hit->second.first; *nitems = hit->second.second; return 0; }
     const int nb = ceil_div(m, 64);
     std::vector<int> tab;
@@ -1621,7 +1628,7 @@ static int syrk_items(int m, const int **d_items, int *nitems)
         PAMD_CHECK_HIP(hipMalloc((void **)&d, tab.size() * sizeof(int)));
         PAMD_CHECK_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    cache[m] = {d, n};
+    cache[key] = {d, n};
     *d_items = d;
     *nitems = n;
     return 0;
@@ -1664,6 +1671,9 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
         if (mfrac < 1) return kchunk;
         const long kt = (k + KB - 1) / KB;
         const long ct = (kt * mfrac + ((long)(nsplit - 1) * mfrac + 1) - 1) / ((long)(nsplit - 1) * mfrac + 1);
+        // the FULL pieces of the balanced split are longer than the uniform ones the v2 test above was made with: the kernels'
+        // 32-bit row offsets (k0 + k) * ld * 8 must stay inside the 4 GiB buffer window for them as well, else uniform pieces
+        if ((ct * KB + KB) * (long)((lda > ldb) ? lda : ldb) * 8 >= (1L << 32)) return kchunk;
         return ct * KB;
     };
     if (v2 && (lower_only & 1) && (lower_only & 8) && g_syrk_slots && d_A == d_B && lda == ldb) {

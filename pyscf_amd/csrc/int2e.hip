@@ -327,7 +327,10 @@ static int launch_int2e(const pamd::Int2eDirectArgs &xa, int mode, void *stream)
     const size_t lds = (size_t)p.total * sizeof(double);
     PAMD_REQUIRE(lds <= 160 * 1024, "int2e: LDS budget exceeded");
     if (a.nbra == 0 || a.nket == 0) return 0;
-    static bool attr_set = false;
+    static bool attr_done[64] = {false};        // per device (the attribute lives in the device's code object); setting it twice is harmless
+    int dev = 0;
+    PAMD_CHECK_HIP(hipGetDevice(&dev));
+    bool &attr_set = attr_done[dev & 63];
     if (!attr_set) {
         PAMD_CHECK_HIP(hipFuncSetAttribute((const void *)int2e_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PAMD_CHECK_HIP(hipFuncSetAttribute((const void *)int2e_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -694,10 +694,10 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         # lib.tag_array(dm, mo_coeff=, mo_occ=); the reference itself trusts it for K, df_jk.py:340) the fused first J pass runs
         # OPTIMISTICALLY and a device-side probe  max |D v - C (C^T v)|  travels back with the results: nothing waits for it, and
         # in the rare case of a tag that does not match its matrix J is redone from the matrix by the two-pass kernels below.
-        promise = getattr(dm, 'dm_from_orbitals', None)
-        if promise is None:
-            promise = True
-            check = _dm_orbital_mismatch(dms_dev, orb_list, nao)
+        # r04 (ADVICE): the package's own tag is probed as well - a tagged array edited in place (dm *= .5, dm[...] += x) keeps its
+        # attributes; only the internal device loop (get_jk_device, densities it built itself) runs unchecked
+        promise = True
+        check = _dm_orbital_mismatch(dms_dev, orb_list, nao)
     elif neg_sets is not None or orb_list is not None:
         promise = False if neg_sets is not None else None
     vjtril, vk_dev = get_jk_device(dfobj, dms_dev, orb_list, with_j, with_k, dm_from_orbitals=promise)

@@ -32,6 +32,10 @@ def _torch():
     return torch
 
 
+_RESTATED = ('get_occ', 'get_fock', 'get_veff', 'eig', '_eigh', 'make_rdm1', 'get_grad', 'energy_tot', 'energy_elec',
+             'get_hcore', 'get_ovlp', 'get_jk', 'get_j', 'get_k')
+
+
 def eligible(mf, callback=None):
     from . import hf
     from ..df import DF
@@ -39,6 +43,16 @@ def eligible(mf, callback=None):
         return False
     if type(mf).__name__ not in ('RHF', 'RKS') or getattr(mf, 'only_dfj', False):
         return False
+    # the device loop restates get_fock / get_occ / eig / make_rdm1 / get_veff / get_grad / energy_tot of the STOCK classes: a
+    # subclass or an instance that overrides one of them (mf.get_occ = mom_occ, fractional occupations, a patched get_veff ...)
+    # keeps the host loop, which calls the methods themselves
+    from ..dft import rks as _rks
+    stock = _rks.RKS if type(mf).__name__ == 'RKS' else hf.RHF
+    for name in _RESTATED:
+        if name in getattr(mf, '__dict__', {}):
+            return False
+        if getattr(type(mf), name, None) is not getattr(stock, name, None):
+            return False
     if not isinstance(getattr(mf, 'with_df', None), DF) or mf.with_df.omega != 0:
         return False
     if abs(mf.damp) > 1e-4 or abs(mf.level_shift) > 1e-4 or mf.max_cycle <= 0:
@@ -358,6 +372,7 @@ def kernel_device(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, conv_check=T
         if diis is not None and cycle >= mf.diis_start_cycle:
             fock = diis.update(s, dm, fock)
         te = time.perf_counter()
+        fock_used = fock             # the (DIIS) Fock matrix whose occupied space makes this cycle's density
         cq, p, fp = occupied(fock, cycle, c_occ_orth)
         if cq is None:
             mo_energy_h, c_full, mo_occ_h = full_eig(fock)
@@ -391,9 +406,14 @@ def kernel_device(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, conv_check=T
             scf_conv = True
             break
     mf.cycles = cycle + 1
-    # the reference's extra cycle (hf.py:213-235): diagonalise the final Fock matrix, one more Fock build
-    mo_energy_h, c_full, mo_occ_h = full_eig(fock)
-    if scf_conv and conv_check:
+    if not (scf_conv and conv_check):
+        # not converged, or no conv_check: the reference returns the orbitals of the LAST cycle, the ones e_tot and dm were made
+        # from (hf.py:176-211) - eigenpairs of that cycle's Fock matrix; a purification cycle has none yet, so diagonalise it now
+        if c_full is None:
+            mo_energy_h, c_full, mo_occ_h = full_eig(fock_used)
+    else:
+        # the reference's extra cycle (hf.py:213-235): diagonalise the final Fock matrix, one more Fock build
+        mo_energy_h, c_full, mo_occ_h = full_eig(fock)
         occ_mask = torch.from_numpy(mo_occ_h > 0).to(dev)
         c_occ = c_full[:, occ_mask].contiguous()
         c_occ_orth = xs @ c_occ

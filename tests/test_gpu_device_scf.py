@@ -103,3 +103,52 @@ def test_device_loop_sp2_on_the_syrk_kernel():
     x2 = sq.square(sq.pad(a, 0), 1)
     assert float((x2[:290, :290] - a @ a).abs().max()) < 1e-11 * float((a @ a).abs().max())
     assert float(x2[290:].abs().max()) == 0 and float((x2 - x2.T).abs().max()) == 0
+
+
+@pytest.mark.gpu
+def test_unconverged_device_loop_returns_the_orbitals_of_its_density():
+    """stopped at max_cycle (or with conv_check = False) the loop returns, like hf.py:176-241, the orbitals e_tot and
+    dm were made from - not the eigenvectors of the next Fock matrix.  Same numbers as the host loop cycle for cycle."""
+    from pyscf_amd import gto
+    from pyscf_amd.data import clusters
+    mol = gto.M(atom=clusters.water_cluster(3), basis='cc-pvdz')
+    for kw in (dict(max_cycle=4), dict(conv_check=False)):
+        mh, eh = _run(mol, '', False, **kw)
+        md, ed = _run(mol, '', True, **kw)
+        assert md.converged == mh.converged
+        assert abs(eh - ed) < 1e-8, (kw, eh, ed)
+        dm = md.make_rdm1()
+        assert abs(md.energy_tot(dm) - ed) < 1e-9, kw                   # the returned orbitals reproduce the returned energy
+        assert np.abs(md.mo_energy - mh.mo_energy).max() < 1e-6, kw
+        assert np.abs(np.asarray(dm) - np.asarray(mh.make_rdm1())).max() < 1e-6, kw
+
+
+@pytest.mark.gpu
+def test_overridden_methods_keep_the_host_loop():
+    """an instance- or class-level override of a method the device loop restates (the PySCF idiom mf.get_occ = ...)
+    must not be bypassed."""
+    from pyscf_amd import gto, scf
+    from pyscf_amd.data import clusters
+    from pyscf_amd.scf import device_scf
+    mol = gto.M(atom=clusters.water_cluster(2), basis='cc-pvdz')
+    mf = scf.RHF(mol).density_fit()
+    mf.device_scf_min_nao = 0
+    assert device_scf.eligible(mf)
+    calls = []
+    stock = mf.get_occ
+
+    def get_occ(mo_energy=None, mo_coeff=None):
+        calls.append(1)
+        return stock(mo_energy, mo_coeff)
+    mf.get_occ = get_occ
+    assert not device_scf.eligible(mf)
+    mf.kernel()
+    assert mf.converged and len(calls) >= mf.cycles
+
+    class MyRHF(scf.RHF):
+        def get_fock(self, *a, **k):
+            return scf.RHF.get_fock(self, *a, **k)
+    MyRHF.__name__ = 'RHF'
+    m2 = MyRHF(mol).density_fit()
+    m2.device_scf_min_nao = 0
+    assert not device_scf.eligible(m2)
