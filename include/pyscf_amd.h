@@ -319,6 +319,33 @@ int PAMD_sub_vmat(const double *d_ao_c, const long *d_ao_off, const double *d_ao
  *   PAMD_df_export_cderi  rows [l0, l1) of `_cderi` (naux, nao_pair) into out (DF.loop, pyscf/df/df.py:214-242)
  *   PAMD_df_naux          rows of the tensor (get_naoaux, :248-257: fewer than the aux functions after an eigen-decomposition) */
 typedef struct PAMD_df PAMD_df;
+/* r04 - the same handle over SEVERAL devices of the node, in ONE process (SURVEY.md 8(b) `mi_ctx_create(const int *devices, int ndev, ...)`;
+ * the caller is the single Python thread of hf.kernel, pyscf/df/df_jk.py:175-176): the auxiliary index L is cut into ndev contiguous,
+ * row-balanced shards (the serial loop over L blocks this replaces: pyscf/df/df_jk.py:362-381), part p lives on devices[p] (a device
+ * may be listed more than once), PAMD_df_get_jk runs one host thread per part and sums the partial [J~ | K] on devices[0] (direct
+ * peer copies over xGMI where hipDeviceCanAccessPeer allows, through the host otherwise; K of the MO branch travels packed).
+ *   PAMD_df_create_multi  = PAMD_df_create with a device list
+ *   PAMD_df_create_ex     every option:  omega != 0 -> the tensor of erf(omega r12)/r12 (omega > 0) or erfc(|omega| r12)/r12 (omega < 0),
+ *                         what DF.range_coulomb(omega) holds (pyscf/df/df.py:298-333);  max_device_bytes > 0 caps the HBM one part
+ *                         may take - rows that do not fit (with or without a cap) stay in page-locked HOST memory and are streamed
+ *                         through two staging buffers under the kernels in every PAMD_df_get_jk: the out-of-core twin of the
+ *                         reference (pyscf/df/outcore.py:109-232, pyscf/df/df.py:167,214-242), PCIe-bound for those rows.
+ *                         flags bit 0: keep the sharded code path even for a one-entry device list
+ *   PAMD_df_layout        layout[5] = {parts, rows resident in HBM, rows in host memory, rows with a square image, peer copies 0 / 1},
+ *                         part_rows[parts] (nullable) = rows per part */
+typedef struct PAMD_df_options {
+    double lindep;              /* LINEAR_DEP_THR of the eigen-decomposition fallback (pyscf/df/incore.py:263-270) */
+    double omega;               /* range-separation parameter, 0 = Coulomb */
+    const int *devices;         /* [ndev] HIP device indices (NULL with ndev <= 0: device 0) */
+    int ndev;
+    int flags;
+    long long max_device_bytes; /* 0: whatever the device has free */
+} PAMD_df_options;
+int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
+                      const PAMD_df_options *opt, PAMD_df **out);
+int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
+                         double lindep, const int *devices, int ndev, PAMD_df **out);
+int PAMD_df_layout(const PAMD_df *h, long *layout, int *part_rows);
 int PAMD_df_create(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                    double lindep, int device, PAMD_df **out);
 void PAMD_df_destroy(PAMD_df *h);

@@ -25,7 +25,9 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "common.h"
 #include <cstdlib>
@@ -306,16 +308,30 @@ constexpr int ROC_OP_N = 111, ROC_FILL_UPPER = 121, ROC_EVECT_ORIGINAL = 211;
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ the handle
+// One PAMD_df is either a SHARD (rows [l0, l0 + nL) of the tensor on one device: what PAMD_df_create makes, with l0 = 0 and all
+// rows) or, when `parts` is not empty, a multi-device handle whose parts are shards on the listed devices.
+// A shard keeps its rows in HBM as far as they fit (`n_res` rows, d_cderi) and the rest in page-locked host memory (h_cderi),
+// streamed through two staging buffers during every J/K build (the out-of-core twin of the reference, pyscf/df/outcore.py:109-232,
+// pyscf/df/df.py:167,214-242: there blocks of the HDF5 file, here blocks of pinned RAM under double-buffered H2D copies).
 struct PAMD_df {
     int device = 0;
-    int nao = 0, naux = 0, nL = 0;          // nL = rows of the tensor held (naux, or fewer after an eigen-decomposed metric)
+    int nao = 0, naux = 0;                  // AO functions, auxiliary functions
+    int nL = 0;                             // tensor rows this handle answers for (a shard: its rows; multi: all rows)
+    int l0 = 0, nL_total = 0;               // first global row of a shard, rows of the whole tensor
     long npair = 0;
-    DevPool pool;
-    hipStream_t st = nullptr, side = nullptr;
-    hipEvent_t ev = nullptr;
-    double *d_cderi = nullptr, *d_sq = nullptr, *d_diag = nullptr;
-    std::map<long, int> j2_policy;         // (nset, occupied counts) -> 0 overlap / 1 serial second J pass (PAMD_df_get_jk)
     int rows = 0;                           // round_up(nao, 16)
+    double omega = 0.0;                     // 0 Coulomb, > 0 erf(omega r12)/r12, < 0 erfc(|omega| r12)/r12
+    DevPool pool;
+    hipStream_t st = nullptr, side = nullptr, copy = nullptr;
+    hipEvent_t ev = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    double *d_cderi = nullptr, *d_sq = nullptr, *d_diag = nullptr;
+    int n_res = 0;                          // rows [0, n_res) resident in HBM, rows [n_res, nL) in h_cderi
+    double *h_cderi = nullptr;              // pinned host memory, (nL - n_res) x npair
+    double *d_stage[2] = {nullptr, nullptr};
+    int stage_rows = 0;
+    std::map<long, int> j2_policy;          // (nset, occupied counts) -> 0 overlap / 1 serial second J pass (PAMD_df_get_jk)
+    std::vector<PAMD_df *> parts;           // multi-device handle: the shards (owned)
+    int peer_ok = 0;                        // multi: partial results reach part 0 by direct peer copies
     std::map<std::string, std::pair<double *, size_t>> ws;
     double *workspace(const std::string &name, size_t ndoubles, int *rc)
     {
@@ -332,7 +348,18 @@ struct PAMD_df {
     }
     ~PAMD_df()
     {
+        for (PAMD_df *p : parts) {
+            (void)hipSetDevice(p->device);
+            delete p;
+        }
+        if (!parts.empty()) (void)hipSetDevice(device);
+        if (h_cderi) (void)hipHostFree(h_cderi);
+        for (int k = 0; k < 2; k++) {
+            if (ev_ready[k]) (void)hipEventDestroy(ev_ready[k]);
+            if (ev_free[k]) (void)hipEventDestroy(ev_free[k]);
+        }
         if (ev) (void)hipEventDestroy(ev);
+        if (copy) (void)hipStreamDestroy(copy);
         if (side) (void)hipStreamDestroy(side);
         if (st) (void)hipStreamDestroy(st);
     }
@@ -340,16 +367,30 @@ struct PAMD_df {
 
 namespace {
 
-struct Engine {                            // device tables of one (AO basis, aux basis) pair, alive during PAMD_df_create
+struct Tables {                            // host-side tables of one (AO basis, aux basis) pair, shared by all parts
     Shells ao, aux;
+    int lmax_ao = 0, lmax_aux = 0;
+    std::vector<double> c2s;
+    std::vector<int> c2s_off;
+};
+
+struct Metric {                            // M^T with cderi = M (Q|pq), host copy shared by all parts (decompose_metric)
+    std::vector<double> mt;
+    int nrow = 0, lda = 0, tri = 0;
+};
+
+struct Engine {                            // device tables of one part, alive during the build
+    const Tables *t = nullptr;
     std::vector<PairClass> pcs, pcs2c;
     std::vector<AuxClass> acs;
     double *d_rys = nullptr, *d_c2s = nullptr, *d_ao_xyz = nullptr, *d_aux_xyz = nullptr;
     int *d_c2s_off = nullptr, *d_ao_ao0 = nullptr, *d_aux_ao0 = nullptr;
 };
 
+std::mutex g_dev_mutex[64];                // builds on the same device are serialised (a devices list may repeat a device)
+
 int launch_class(const Engine &e, const PairClass &pc, int i0, int i1, const AuxClass &ac, double *T, long ldT, long row_offset,
-                 int tril, const double *shell_xyz, const int *shell_ao0, hipStream_t st)
+                 int tril, const double *shell_xyz, const int *shell_ao0, double omega, hipStream_t st)
 {
     if (i1 <= i0) return 0;
     PAMD_int3c2e_args a;
@@ -375,7 +416,7 @@ int launch_class(const Engine &e, const PairClass &pc, int i0, int i1, const Aux
     a.row_offset = row_offset;
     a.tril = tril;
     a.npairs = i1 - i0;
-    a.omega = 0.0;
+    a.omega = omega;
     return PAMD_int3c2e_class(pc.li, pc.lj, ac.l, &a, st);
 }
 
@@ -384,6 +425,11 @@ void slab_rows(const Shells &ao, int sh0, int sh1, long *r0, long *r1)
     const long p0 = ao.ao0[sh0], p1 = sh1 < ao.n ? ao.ao0[sh1] : ao.nao;
     *r0 = p0 * (p0 + 1) / 2;
     *r1 = p1 * (p1 + 1) / 2;
+}
+
+__global__ void sub_inplace_kernel(double *__restrict__ a, const double *__restrict__ b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] -= b[i];
 }
 
 // Cyclic Jacobi eigen-solver for a small symmetric matrix (row-major a[n][n], destroyed): w[k] eigenvalues, v[k][n] the
@@ -600,7 +646,130 @@ int decompose_metric(PAMD_df *h, double *d_j2c, int naux, double lindep, std::ve
     return 0;
 }
 
-int build_square_image(PAMD_df *h)
+
+// ------------------------------------------------------------------------------------------------ build
+int make_tables(const int *atm, const int *bas, int nbas_ao, int nbas_aux, const double *env, Tables *t)
+{
+    t->ao = make_shells(atm, bas, 0, nbas_ao, env);
+    t->aux = make_shells(atm, bas, nbas_ao, nbas_ao + nbas_aux, env);
+    for (int l : t->ao.l) t->lmax_ao = std::max(t->lmax_ao, l);
+    for (int l : t->aux.l) t->lmax_aux = std::max(t->lmax_aux, l);
+    PAMD_REQUIRE(t->lmax_ao <= 4 && t->lmax_aux <= LMAX_TAB && !(t->lmax_aux > 5 && t->lmax_ao > 3),
+                 "angular momentum beyond the instantiated kernels");
+    for (int l = 0; l <= LMAX_TAB; l++) {
+        t->c2s_off.push_back((int)t->c2s.size());
+        std::vector<double> m = c2s_matrix(l);
+        t->c2s.insert(t->c2s.end(), m.begin(), m.end());
+    }
+    return 0;
+}
+
+int init_shard(PAMD_df *h, const Tables &t, int device, double omega)
+{
+    h->device = device;
+    h->omega = omega;
+    h->nao = t.ao.nao;
+    h->naux = t.aux.nao;
+    h->npair = (long)h->nao * (h->nao + 1) / 2;
+    h->rows = (int)round_up(h->nao, 16);
+    PAMD_CHECK_HIP(hipStreamCreate(&h->st));
+    PAMD_CHECK_HIP(hipStreamCreate(&h->side));
+    PAMD_CHECK_HIP(hipStreamCreate(&h->copy));
+    PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) {
+        PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev_ready[k], hipEventDisableTiming));
+        PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev_free[k], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// Rys table, cart->sph matrices, shell coordinates, shell-pair and aux-class tables on the handle's device
+int prepare_engine(PAMD_df *h, const Tables &t, Engine &e, DevPool &tmp)
+{
+    int rc;
+    e.t = &t;
+    if ((rc = tmp.alloc((void **)&e.d_rys, (size_t)PAMD_rys_table_len() * 8))) return rc;
+    if ((rc = PAMD_rys_table_upload(e.d_rys, h->st))) return rc;
+    if ((rc = upload(tmp, t.c2s, &e.d_c2s)) || (rc = upload(tmp, t.c2s_off, &e.d_c2s_off)) || (rc = upload(tmp, t.ao.xyz, &e.d_ao_xyz)) ||
+        (rc = upload(tmp, t.ao.ao0, &e.d_ao_ao0)) || (rc = upload(tmp, t.aux.xyz, &e.d_aux_xyz)) ||
+        (rc = upload(tmp, t.aux.ao0, &e.d_aux_ao0)))
+        return rc;
+    for (int li = 0; li <= t.lmax_ao; li++)
+        for (int lj = 0; lj <= li; lj++) {
+            PairClass pc;
+            if ((rc = make_pair_class(tmp, t.ao, li, lj, &pc))) return rc;
+            if (pc.n) e.pcs.push_back(pc);
+        }
+    for (int l = 0; l <= t.lmax_aux; l++) {
+        AuxClass ac;
+        if ((rc = make_aux_class(tmp, t.aux, l, &ac))) return rc;
+        if (ac.n) e.acs.push_back(ac);
+    }
+    return 0;
+}
+
+// d_dst = integrals of the operator selected by h->omega; fill(omega') runs all class launches of one pass into its argument.
+// omega < 0 (short range, erfc): Coulomb pass minus the long-range pass at |omega| (pyscf_amd/gto/moleintor.py:_short_range)
+template <class Fill>
+int fill_operator(PAMD_df *h, double *d_dst, double *d_scratch, size_t n, Fill fill)
+{
+    int rc;
+    PAMD_CHECK_HIP(hipMemsetAsync(d_dst, 0, n * 8, h->st));
+    if ((rc = fill(d_dst, h->omega < 0 ? 0.0 : h->omega))) return rc;
+    if (h->omega < 0) {
+        PAMD_REQUIRE(d_scratch, "short-range pass needs a scratch buffer");
+        PAMD_CHECK_HIP(hipMemsetAsync(d_scratch, 0, n * 8, h->st));
+        if ((rc = fill(d_scratch, -h->omega))) return rc;
+        sub_inplace_kernel<<<2048, 256, 0, h->st>>>(d_dst, d_scratch, n);
+        PAMD_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// metric (P|Q) -> Metric (host): df/incore.py:150-158 (+ :263-270)
+int compute_metric(PAMD_df *h, const Engine &e, DevPool &tmp, double lindep, Metric *m)
+{
+    int rc;
+    const Tables &t = *e.t;
+    const int naux = h->naux;
+    std::vector<PairClass> pcs2c;
+    for (int l = 0; l <= t.lmax_aux; l++) {
+        PairClass pc;
+        if ((rc = make_pair_class_2c(tmp, t.aux, l, 1.0 / t.c2s[t.c2s_off[0]], &pc))) return rc;
+        if (pc.n) pcs2c.push_back(pc);
+    }
+    const size_t n2 = (size_t)naux * naux;
+    double *d_j2c = nullptr, *d_scr = nullptr;
+    if ((rc = tmp.alloc((void **)&d_j2c, n2 * 8))) return rc;
+    if (h->omega < 0 && (rc = tmp.alloc((void **)&d_scr, n2 * 8))) return rc;
+    rc = fill_operator(h, d_j2c, d_scr, n2, [&](double *dst, double om) {
+        for (const PairClass &pc : pcs2c)
+            for (const AuxClass &ac : e.acs) {
+                const int r = launch_class(e, pc, 0, pc.n, ac, dst, naux, 0, 0, e.d_aux_xyz, e.d_aux_ao0, om, h->st);
+                if (r) return r;
+            }
+        return 0;
+    });
+    if (rc) return rc;
+    {
+        // symmetrise on the host: (j2c + j2c^T) / 2 as pyscf_amd/df/incore.py does before the factorisation
+        std::vector<double> j(n2);
+        PAMD_CHECK_HIP(hipMemcpyAsync(j.data(), d_j2c, n2 * 8, hipMemcpyDeviceToHost, h->st));
+        PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+        for (int a = 0; a < naux; a++)
+            for (int b = 0; b < a; b++) {
+                const double v = 0.5 * (j[(size_t)a * naux + b] + j[(size_t)b * naux + a]);
+                j[(size_t)a * naux + b] = j[(size_t)b * naux + a] = v;
+            }
+        PAMD_CHECK_HIP(hipMemcpy(d_j2c, j.data(), n2 * 8, hipMemcpyHostToDevice));
+    }
+    if ((rc = decompose_metric(h, d_j2c, naux, lindep, &m->mt, &m->nrow, &m->lda, &m->tri))) return rc;
+    tmp.release(d_j2c);
+    if (d_scr) tmp.release(d_scr);
+    return 0;
+}
+
+int build_square_image(PAMD_df *h, size_t cap_left)
 {
     // K path on the unpacked image when HBM allows (DF.k_square = 'auto': 48 GB must stay free afterwards);
     // PAMD_DF_SQUARE=0 in the environment = DF.k_square = False (tests, memory-constrained callers)
@@ -609,7 +778,7 @@ int build_square_image(PAMD_df *h)
     size_t free_b = 0, total_b = 0;
     PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t need = ((size_t)h->nL * h->rows * h->rows + 256) * 8;
-    if (h->nL == 0 || need + (48ul << 30) > free_b) return 0;
+    if (h->nL == 0 || h->n_res < h->nL || need + (48ul << 30) > free_b || need > cap_left) return 0;
     int rc = h->pool.alloc((void **)&h->d_sq, need);
     if (rc) { h->d_sq = nullptr; return 0; }
     PAMD_CHECK_HIP(hipMemsetAsync(h->d_sq, 0, need, h->st));
@@ -618,154 +787,665 @@ int build_square_image(PAMD_df *h)
 
 // no room for the square image: keep at least the 128 x 128 diagonal blocks unpacked (14 % of the packed size at nao 1856), so
 // that the packed-operand half transform reads the k-tiles crossing the diagonal once and unmasked (DF.diag_image)
-int build_diag_image(PAMD_df *h)
+int build_diag_image(PAMD_df *h, size_t cap_left)
 {
-    if (h->d_sq || h->nL == 0 || h->nao < 128) return 0;
+    if (h->d_sq || h->nL == 0 || h->n_res < h->nL || h->nao < 128) return 0;
     size_t free_b = 0, total_b = 0;
     PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t need = (size_t)PAMD_e2_diag_size(h->nL, h->rows) * 8;
-    if (need + (48ul << 30) > free_b) return 0;
+    if (need + (48ul << 30) > free_b || need > cap_left) return 0;
     int rc = h->pool.alloc((void **)&h->d_diag, need);
     if (rc) { h->d_diag = nullptr; return 0; }
     return PAMD_e2_diag_blocks(h->d_cderi, h->npair, h->nL, h->nao, h->rows, h->d_diag, h->st);
+}
+
+// Rows [h->l0, h->l0 + h->nL) of the tensor, AO-row slab by slab (df/incore.py:189-217): into HBM as far as `max_device_bytes`
+// (0: the device's free memory) allows, the remaining rows into page-locked host memory through a staging buffer.
+int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_t max_device_bytes)
+{
+    int rc;
+    const Tables &t = *e.t;
+    const int naux = h->naux, nL = h->nL;
+    const long npair = h->npair;
+    double *d_mt = nullptr;
+    if ((rc = upload(tmp, m.mt, &d_mt))) return rc;
+    size_t free_b = 0, total_b = 0;
+    PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const char *envcap = getenv("PAMD_DF_DEVICE_BYTES");            // tests / memory-constrained callers
+    if (envcap && atof(envcap) > 0) max_device_bytes = (size_t)atof(envcap);
+    const size_t cap = max_device_bytes ? std::min(free_b, max_device_bytes) : free_b;
+    const size_t row_b = (size_t)npair * 8, tensor_b = (size_t)nL * row_b;
+    const int npass = h->omega < 0 ? 2 : 1;
+    size_t slab_bytes = std::min<size_t>(24ul << 30, (size_t)npair * naux * 8);
+    const size_t margin = std::min<size_t>(1ul << 30, cap / 16);
+    size_t stage_b = 0;
+    if (tensor_b + npass * slab_bytes + margin <= cap) {
+        h->n_res = nL;
+    } else {
+        // out of core: a share of the cap each for the slab work space, the two staging buffers and the J/K work space
+        slab_bytes = std::min<size_t>(slab_bytes, std::min<size_t>(6ul << 30, cap / (4 * npass)));
+        stage_b = std::min<size_t>(4ul << 30, cap / 8);
+        const size_t work_b = std::min<size_t>(20ul << 30, cap / 4);
+        const size_t used = npass * slab_bytes + 2 * stage_b + work_b + margin;
+        h->stage_rows = (int)std::min<size_t>(stage_b / row_b, (size_t)nL);
+        if (h->stage_rows < 1) {
+            snprintf(g_errmsg, sizeof(g_errmsg), "PAMD_df_create: %.3f GB of device memory cannot stage one tensor row (%.3f GB)",
+                     cap * 1e-9, row_b * 1e-9);
+            return -2;
+        }
+        h->n_res = cap > used ? (int)std::min<size_t>((cap - used) / row_b, (size_t)nL) : 0;
+        const size_t host_b = (size_t)(nL - h->n_res) * row_b;
+        if (hipHostMalloc((void **)&h->h_cderi, std::max<size_t>(host_b, 8), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h->h_cderi = nullptr;
+            snprintf(g_errmsg, sizeof(g_errmsg), "PAMD_df_create: %.1f GB of the tensor do not fit the device and %.1f GB of page-locked "
+                     "host memory could not be allocated", tensor_b * 1e-9, host_b * 1e-9);
+            return -2;
+        }
+        for (int k = 0; k < 2; k++)
+            if ((rc = h->pool.alloc((void **)&h->d_stage[k], (size_t)h->stage_rows * row_b + 256 * 8))) return rc;
+    }
+    if (h->n_res && (rc = h->pool.alloc((void **)&h->d_cderi, (size_t)h->n_res * row_b + 256 * 8))) return rc;
+    const long max_rows = std::max<long>((long)(slab_bytes / ((size_t)naux * 8)), 1);
+    std::vector<std::pair<int, int>> slabs;
+    long bufrows = 0;
+    for (int sh0 = 0; sh0 < t.ao.n;) {
+        int sh1 = sh0 + 1;
+        long r0, r1;
+        while (sh1 < t.ao.n) {
+            slab_rows(t.ao, sh0, sh1 + 1, &r0, &r1);
+            if (r1 - r0 > max_rows) break;
+            sh1++;
+        }
+        slab_rows(t.ao, sh0, sh1, &r0, &r1);
+        bufrows = std::max(bufrows, r1 - r0);
+        slabs.push_back({sh0, sh1});
+        sh0 = sh1;
+    }
+    double *d_T = nullptr, *d_T2 = nullptr;
+    if ((rc = tmp.alloc((void **)&d_T, (size_t)bufrows * naux * 8))) return rc;
+    if (npass == 2 && (rc = tmp.alloc((void **)&d_T2, (size_t)bufrows * naux * 8))) return rc;
+    for (auto &sl : slabs) {
+        long r0, r1;
+        slab_rows(t.ao, sl.first, sl.second, &r0, &r1);
+        const long ncol = r1 - r0;
+        rc = fill_operator(h, d_T, d_T2, (size_t)ncol * naux, [&](double *dst, double om) {
+            for (const PairClass &pc : e.pcs) {
+                int i0, i1;
+                pc.subrange(sl.first, sl.second, &i0, &i1);
+                for (const AuxClass &ac : e.acs) {
+                    const int r = launch_class(e, pc, i0, i1, ac, dst, naux, r0, 1, e.d_ao_xyz, e.d_ao_ao0, om, h->st);
+                    if (r) return r;
+                }
+            }
+            return 0;
+        });
+        if (rc) return rc;
+        if (h->n_res &&
+            (rc = PAMD_cderi_solve(d_mt + h->l0, m.lda, d_T, naux, h->d_cderi + r0, npair, h->n_res, ncol, naux, h->l0, m.tri, h->st)))
+            return rc;
+        for (int rb0 = h->n_res; rb0 < nL; rb0 += h->stage_rows) {
+            // host rows of this column slab: solve into the staging buffer ([rows][ncol]), strided copy into the pinned tensor
+            const int nb = std::min(h->stage_rows, nL - rb0);
+            if ((rc = PAMD_cderi_solve(d_mt + h->l0 + rb0, m.lda, d_T, naux, h->d_stage[0], ncol, nb, ncol, naux, h->l0 + rb0, m.tri, h->st)))
+                return rc;
+            PAMD_CHECK_HIP(hipMemcpy2DAsync(h->h_cderi + (size_t)(rb0 - h->n_res) * npair + r0, row_b, h->d_stage[0], (size_t)ncol * 8,
+                                            (size_t)ncol * 8, nb, hipMemcpyDeviceToHost, h->st));
+        }
+    }
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+    tmp.release(d_T);
+    if (d_T2) tmp.release(d_T2);
+    tmp.release(d_mt);
+    const size_t held = (size_t)h->n_res * row_b + 2 * stage_b;
+    const size_t cap_left = max_device_bytes ? (cap > held ? cap - held : 0) : ~(size_t)0;
+    if ((rc = build_square_image(h, cap_left))) return rc;
+    if ((rc = build_diag_image(h, cap_left))) return rc;
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+// one shard, start to finish, on the calling thread: `metric` is computed here (and returned) when m->nrow == 0 on entry
+int create_shard(const Tables &t, int device, double omega, double lindep, size_t max_device_bytes, Metric *m, int part, int nparts,
+                 PAMD_df **out)
+{
+    *out = nullptr;
+    PAMD_CHECK_HIP(hipSetDevice(device));
+    std::lock_guard<std::mutex> lock(g_dev_mutex[device & 63]);
+    PAMD_df *h = new PAMD_df;
+    struct Guard { PAMD_df *p; ~Guard() { delete p; } } guard{h};
+    int rc;
+    if ((rc = init_shard(h, t, device, omega))) return rc;
+    Engine e;
+    DevPool tmp;                           // tables and scratch that die with this call
+    if ((rc = prepare_engine(h, t, e, tmp))) return rc;
+    if (m->nrow == 0 && m->mt.empty() && (rc = compute_metric(h, e, tmp, lindep, m))) return rc;
+    // contiguous, row-balanced shards (DF.shard_range)
+    const int base = m->nrow / nparts, rem = m->nrow % nparts;
+    h->nL_total = m->nrow;
+    h->l0 = part * base + std::min(part, rem);
+    h->nL = base + (part < rem ? 1 : 0);
+    if ((rc = build_rows(h, e, tmp, *m, max_device_bytes))) return rc;
+    guard.p = nullptr;
+    *out = h;
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ J/K of one shard
+struct Seg {                               // a run of tensor rows as the kernels see it
+    const double *rows;                    // packed rows on the device
+    int n, row0;                           // count, first (shard-local) row
+    const double *sq, *diag;               // unpacked image / diagonal-block image of these rows (nullable)
+    int stage;                             // -1: resident; 0 / 1: arrives in that staging buffer
+};
+
+struct OrbSet {                            // one density's occupied orbitals on the device (df_jk.pad_orbitals)
+    double *d_orb = nullptr;
+    int no = 0, nocc_pad = 0;
+    long ldo = 0;
+};
+
+// dm   [nset][nao][nao] host, f64, C order.
+// orbo nullable.  Not NULL: the occupied orbitals scaled by sqrt(occ), set after set, each (nao, nocc[s]) C order (row = AO) -
+//      K comes from the MO branch (df_jk.py:339-381).  NULL: general-DM branch (df_jk.py:382-408), hermi is then ignored for K.
+// flags bit 0: the caller guarantees dm[s] = orbo_s orbo_s^T (what make_rdm1 builds) - the first J pass then comes out of the
+//      half transform's epilogue instead of a pass over the tensor.
+// vj, vk caller-owned [nset][nao][nao] (NULL with with_j / with_k = 0).
+// serial_j2: the second J pass of the fused path in line before a re-tiled SYRK (1) or on the side stream beside a plain one (0)
+// download = 0: the results stay on the device (work spaces "vjtril": packed J~ [nset][npair], "vk": [nset][nao][nao]) for the
+//      multi-device reduction; the stream is synchronised either way.
+// Rows in host memory (out-of-core shard) arrive block by block in two staging buffers, the copy of block b + 1 under the kernels
+// of block b; every contraction is a sum over aux rows, so each block is contracted completely (both J passes, half transform,
+// SYRK into the split-K partials) while it is on the device - one sweep over the host rows per build.
+static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
+                          int with_k, int flags, double *vj, double *vk, int serial_j2, int download)
+{
+    (void)hermi;
+    PAMD_REQUIRE(h && dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
+    PAMD_REQUIRE(!download || ((!with_j || vj) && (!with_k || vk)), "PAMD_df_get_jk: output pointers");
+    PAMD_REQUIRE(with_j || with_k, "PAMD_df_get_jk: nothing to do");
+    PAMD_REQUIRE(!orbo || nocc, "PAMD_df_get_jk: orbo needs nocc[nset]");
+    PAMD_CHECK_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->st;
+    int rc;
+    const long npair = h->npair;
+    const int nL = h->nL, ldx = h->rows, rows = h->rows;
+    const size_t n2 = (size_t)nao * nao;
+    const bool streamed = h->n_res < nL;
+    if (streamed) serial_j2 = 1;           // the staged rows are released when the main stream is done with them
+    double *d_dm = h->workspace("dm", (size_t)nset * n2, &rc);
+    if (rc) return rc;
+    PAMD_CHECK_HIP(hipMemcpyAsync(d_dm, dm, (size_t)nset * n2 * 8, hipMemcpyHostToDevice, st));
+    double *d_vjt = nullptr, *d_vk = nullptr, *d_rho = nullptr, *d_dt = nullptr, *d_w1 = nullptr, *d_part = nullptr;
+    const bool fused = with_j && with_k && orbo && (flags & 1) && nL > 0;
+    if (with_j) {
+        d_vjt = h->workspace("vjtril", (size_t)nset * npair, &rc);
+        if (rc) return rc;
+        PAMD_CHECK_HIP(hipMemsetAsync(d_vjt, 0, (size_t)nset * npair * 8, st));
+        d_rho = h->workspace("rho", (size_t)nset * std::max(nL, 1), &rc);
+        if (rc) return rc;
+        PAMD_CHECK_HIP(hipMemsetAsync(d_rho, 0, (size_t)nset * std::max(nL, 1) * 8, st));
+        if (!fused && nL > 0) {
+            d_dt = h->workspace("dmtril", (size_t)nset * npair, &rc);
+            if (rc) return rc;
+            if ((rc = PAMD_pack_dm_tril(d_dm, nset, nao, d_dt, st))) return rc;
+        }
+    }
+    // ---- rows as the kernels will see them
+    std::vector<Seg> segs;
+    if (h->n_res > 0) segs.push_back({h->d_cderi, h->n_res, 0, h->d_sq, h->d_diag, -1});
+    for (int b0 = h->n_res, k = 0; b0 < nL; b0 += h->stage_rows, k ^= 1)
+        segs.push_back({h->d_stage[k], std::min(h->stage_rows, nL - b0), b0, nullptr, nullptr, k});
+    int max_seg = 0;
+    for (const Seg &sg : segs) max_seg = std::max(max_seg, sg.n);
+    if (with_j && !fused && nL > 0) {
+        d_w1 = h->workspace("vj1work", (size_t)std::max<long>(PAMD_df_vj_pass1_worksize(npair, max_seg, std::min(nset, 4)), 1), &rc);
+        if (rc) return rc;
+    }
+    // ---- K set-up: SYRK plan, orbitals of every set, split-K partials of every set
+    int nsplit = 4, syrk_flags = 1 | 2;
+    std::vector<OrbSet> orbs(nset);
+    size_t budget = 12ul << 30;                                 // DF.k_block_bytes
+    if (streamed) {
+        size_t free_b = 0, total_b = 0;
+        PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+        budget = std::min(budget, std::max<size_t>(free_b / 3, 1ul << 20));
+    }
+    if (with_k) {
+        d_vk = h->workspace("vk", (size_t)nset * n2, &rc);
+        if (rc) return rc;
+        PAMD_CHECK_HIP(hipMemsetAsync(d_vk, 0, (size_t)nset * n2 * 8, st));
+        // df_jk.syrk_plan: re-tiled triangle + balanced k split when the matrix has an odd number of 64-column blocks
+        const int nb64 = (nao + 63) / 64;
+        if (orbo && nb64 % 2 == 1 && nb64 >= 5) {
+            const int ntl = nb64 / 2, units = ntl * (ntl - 1) / 2 + ntl + (ntl + 2) / 3;
+            double best = 0;
+            int bn = 0;
+            for (int n = 1; n < 8; n++)
+                for (int m = 1; m < 9; m++)
+                    if (units * n + (units + m - 1) / m <= 512 && n + 1.0 / m > best) { best = n + 1.0 / m; bn = n; }
+            if (bn && units >= 32) { nsplit = bn + 1; syrk_flags = 1 | 2 | 4 | 8; }
+        }
+        if (fused && !serial_j2) { nsplit = 4; syrk_flags = 1 | 2; }      // df_jk._vk_mo: plain grid beside the co-running J pass
+        d_part = h->workspace("kpart", (size_t)nset * nsplit * n2, &rc);
+        if (rc) return rc;
+        PAMD_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nset * nsplit * n2 * 8, st));
+        const double *op = orbo;
+        for (int s = 0; s < nset && orbo; s++) {
+            OrbSet &o = orbs[s];
+            o.no = nocc[s];
+            const double *o_s = op;
+            op += (size_t)nao * o.no;
+            if (o.no == 0) continue;
+            o.nocc_pad = (int)round_up(o.no, 16);
+            long ldo = o.nocc_pad > 160 ? round_up(o.nocc_pad, 160) : o.nocc_pad;       // df_jk.pad_orbitals
+            const int mt = o.nocc_pad / 16, nchunk = (mt + 9) / 10;
+            ldo = std::max<long>(ldo, (long)nchunk * (((mt + nchunk - 1) / nchunk + 1) / 2) * 32);
+            ldo = std::max<long>(ldo, std::min(round_up(o.nocc_pad, 160), round_up(o.nocc_pad, 128)));
+            o.ldo = ldo;
+            std::vector<double> oh((size_t)rows * ldo, 0.0);
+            for (int p = 0; p < nao; p++)
+                for (int i = 0; i < o.no; i++) oh[(size_t)p * ldo + i] = o_s[(size_t)p * o.no + i];
+            char name[32];
+            snprintf(name, sizeof(name), "orb%d", s);
+            o.d_orb = h->workspace(name, (size_t)rows * ldo, &rc);
+            if (rc) return rc;
+            PAMD_CHECK_HIP(hipMemcpyAsync(o.d_orb, oh.data(), oh.size() * 8, hipMemcpyHostToDevice, st));
+            PAMD_CHECK_HIP(hipStreamSynchronize(st));                      // oh goes out of scope
+        }
+    }
+    // general-DM branch: the density itself is the "orbital" operand
+    double *d_orb_dm = nullptr;
+    const long ldo_dm = rows > 160 ? round_up(rows, 160) : round_up(rows, 32);    // whole 32-column wave tiles
+    if (with_k && !orbo && nL > 0) {
+        d_orb_dm = h->workspace("orb_dm", (size_t)rows * ldo_dm, &rc);
+        if (rc) return rc;
+    }
+    // ---- staging pipeline of the host rows
+    for (int k = 0; k < 2 && streamed; k++) PAMD_CHECK_HIP(hipEventRecord(h->ev_free[k], st));
+    auto issue_copy = [&](size_t i) -> int {
+        if (i >= segs.size() || segs[i].stage < 0) return 0;
+        const Seg &sg = segs[i];
+        PAMD_CHECK_HIP(hipStreamWaitEvent(h->copy, h->ev_free[sg.stage], 0));
+        PAMD_CHECK_HIP(hipMemcpyAsync(h->d_stage[sg.stage], h->h_cderi + (size_t)(sg.row0 - h->n_res) * npair, (size_t)sg.n * npair * 8,
+                                      hipMemcpyHostToDevice, h->copy));
+        PAMD_CHECK_HIP(hipEventRecord(h->ev_ready[sg.stage], h->copy));
+        return 0;
+    };
+    for (size_t i = 0; i < segs.size(); i++)
+        if (segs[i].stage >= 0) { if ((rc = issue_copy(i))) return rc; break; }     // prime the first staged block
+    for (size_t si = 0; si < segs.size(); si++) {
+        const Seg &sg = segs[si];
+        if (sg.stage >= 0) {
+            if ((rc = issue_copy(si + 1))) return rc;                  // the next block travels while this one is contracted
+            PAMD_CHECK_HIP(hipStreamWaitEvent(st, h->ev_ready[sg.stage], 0));
+        }
+        if (with_j && !fused) {
+            for (int s0 = 0; s0 < nset; s0 += 4) {
+                const int ns = std::min(4, nset - s0);
+                // rho of 4 sets at a time: [ns][n] contiguous for the kernels, then scattered into rho[s][row0 ..]
+                double *d_rs = h->workspace("rho_seg", (size_t)4 * std::max(max_seg, 1), &rc);
+                if (rc) return rc;
+                if ((rc = PAMD_df_vj_pass1(sg.rows, npair, sg.n, d_dt + (size_t)s0 * npair, ns, d_rs, d_w1, st))) return rc;
+                if ((rc = PAMD_df_vj_pass2(sg.rows, npair, sg.n, d_rs, ns, d_vjt + (size_t)s0 * npair, st))) return rc;
+            }
+        }
+        for (int s = 0; s < nset && with_k; s++) {
+            double *part_s = d_part + (size_t)s * nsplit * n2;
+            if (orbo) {
+                // ---- MO branch: X_L = B_L C~, K += X^T X (df_jk.py:353-380)
+                const OrbSet &o = orbs[s];
+                if (o.no == 0) continue;
+                long blk = std::max<long>(1, (long)(budget / ((size_t)o.nocc_pad * ldx * 8)));
+                blk = std::min<long>(blk, sg.n);
+                const long nblk = (sg.n + blk - 1) / blk;
+                blk = (sg.n + nblk - 1) / nblk;
+                double *d_X = h->workspace("X", (size_t)blk * o.nocc_pad * ldx, &rc);
+                if (rc) return rc;
+                double *d_rw = nullptr;
+                if (fused) {
+                    d_rw = h->workspace("rho_work", (size_t)std::max<long>(PAMD_nr_e2_rho_worksize((int)blk, ldx, o.nocc_pad), 1), &rc);
+                    if (rc) return rc;
+                }
+                for (long b0 = 0; b0 < sg.n; b0 += blk) {
+                    const int nb = (int)std::min<long>(blk, sg.n - b0);
+                    const double *sub = sg.rows + (size_t)b0 * npair;
+                    double *rho_b = fused ? d_rho + (size_t)s * nL + sg.row0 + b0 : nullptr;
+                    if (sg.sq)
+                        rc = PAMD_nr_e2_square(sg.sq + (size_t)b0 * rows * rows, rows, rows, nb, nao, o.d_orb, (int)o.ldo, rows, o.nocc_pad,
+                                               d_X, ldx, rho_b, d_rw, st);
+                    else
+                        rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, o.d_orb, (int)o.ldo, rows, o.nocc_pad, d_X, ldx, rho_b, d_rw,
+                                                  sg.diag ? sg.diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st);
+                    if (rc) return rc;
+                    if (fused) {
+                        // second J pass of this block: in line, or on the side stream beside the block's SYRK (HBM- beside MFMA-bound)
+                        if (serial_j2) {
+                            if ((rc = PAMD_df_vj_pass2(sub, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, st))) return rc;
+                        } else {
+                            PAMD_CHECK_HIP(hipEventRecord(h->ev, st));
+                            PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev, 0));
+                            if ((rc = PAMD_df_vj_pass2(sub, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side))) return rc;
+                        }
+                    }
+                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, part_s, nao, nao, nao, (long)nb * o.nocc_pad, syrk_flags, nsplit, st))) return rc;
+                }
+            } else {
+                // ---- general-DM branch: T_L = B_L D, K = sum_L T_L^T B_L (df_jk.py:382-407)
+                PAMD_CHECK_HIP(hipMemsetAsync(d_orb_dm, 0, (size_t)rows * ldo_dm * 8, st));
+                PAMD_CHECK_HIP(hipMemcpy2DAsync(d_orb_dm, (size_t)ldo_dm * 8, d_dm + (size_t)s * n2, (size_t)nao * 8, (size_t)nao * 8, nao,
+                                                hipMemcpyDeviceToDevice, st));
+                long blk = std::max<long>(1, (long)(budget / ((size_t)rows * ldx * 8)));
+                blk = std::min<long>(blk, sg.n);
+                const long nblk = (sg.n + blk - 1) / blk;
+                blk = std::max<long>(1, ((sg.n + nblk - 1) / nblk) / 2);
+                double *d_X = h->workspace("X", (size_t)blk * rows * ldx, &rc);
+                if (rc) return rc;
+                // rows with an unpacked image: it IS the second operand (no per-block unpack) and feeds the square-image kernel
+                double *d_full = nullptr;
+                if (!sg.sq) {
+                    d_full = h->workspace("full", (size_t)blk * rows * ldx, &rc);
+                    if (rc) return rc;
+                    PAMD_CHECK_HIP(hipMemsetAsync(d_full, 0, (size_t)blk * rows * ldx * 8, st));
+                }
+                for (long b0 = 0; b0 < sg.n; b0 += blk) {
+                    const int nb = (int)std::min<long>(blk, sg.n - b0);
+                    const double *sub = sg.rows + (size_t)b0 * npair;
+                    const double *second = d_full;
+                    if (sg.sq) {
+                        second = sg.sq + (size_t)b0 * rows * rows;
+                        if ((rc = PAMD_nr_e2_square(second, rows, rows, nb, nao, d_orb_dm, (int)ldo_dm, rows, rows, d_X, ldx, nullptr, nullptr, st)))
+                            return rc;
+                    } else {
+                        if ((rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, d_orb_dm, (int)ldo_dm, rows, rows, d_X, ldx, nullptr, nullptr,
+                                                       sg.diag ? sg.diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st))) return rc;
+                        if ((rc = PAMD_unpack_tril(sub, npair, nb, nao, d_full, ldx, rows, st))) return rc;
+                    }
+                    if ((rc = PAMD_dgemm_tn(d_X, ldx, second, ldx, part_s, nao, nao, nao, (long)nb * rows, 0 | 2, nsplit, st))) return rc;
+                }
+            }
+        }
+        if (sg.stage >= 0) PAMD_CHECK_HIP(hipEventRecord(h->ev_free[sg.stage], st));
+    }
+    for (int s = 0; s < nset && with_k && nL > 0; s++)
+        if (!orbo || orbs[s].no)
+            if ((rc = PAMD_reduce_splits(d_part + (size_t)s * nsplit * n2, nsplit, nao, nao, d_vk + (size_t)s * n2, nao, orbo ? 1 : 0, st)))
+                return rc;
+    if (fused && !serial_j2) {
+        PAMD_CHECK_HIP(hipEventRecord(h->ev, h->side));
+        PAMD_CHECK_HIP(hipStreamWaitEvent(st, h->ev, 0));
+    }
+    if (download) {
+        if (with_j) {
+            double *d_vj = h->workspace("vjfull", (size_t)nset * n2, &rc);
+            if (rc) return rc;
+            if ((rc = PAMD_unpack_tril(d_vjt, npair, nset, nao, d_vj, nao, nao, st))) return rc;
+            PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vj, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
+        }
+        if (with_k) PAMD_CHECK_HIP(hipMemcpyAsync(vk, d_vk, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
+    }
+    PAMD_CHECK_HIP(hipStreamSynchronize(st));
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->side));
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->copy));
+    return 0;
+}
+
+// Schedule of the second J pass on the fused path (DF.j2_policy of the Python layer): which of the two is faster depends on the
+// shape (config 3: overlapped, taxol on one GPU: in line), so a tensor of 4 GB and more gets both timed once per (nset, occupied
+// count) - two extra builds at the first call - and the choice is kept in the handle.  PAMD_DF_J2 = overlap | serial overrides.
+static int shard_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
+                        int with_k, int flags, double *vj, double *vk, int download)
+{
+    const bool fused = with_j && with_k && orbo && (flags & 1) && h->nL > 0;
+    int serial = 0;
+    if (fused && h->n_res == h->nL) {
+        const char *env = getenv("PAMD_DF_J2");
+        if (env && (env[0] == 's' || env[0] == 'o')) {
+            serial = env[0] == 's';
+        } else if ((size_t)h->nL * (size_t)h->npair * 8 >= (4ul << 30) && nocc) {
+            long key = nset;
+            for (int s = 0; s < nset; s++) key = key * 4099 + nocc[s];
+            auto it = h->j2_policy.find(key);
+            if (it == h->j2_policy.end()) {
+                double ms[2] = {0, 0};
+                for (int trial = 0; trial < 3; trial++) {             // overlap (priming, untimed), overlap, serial
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const int rc = df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, trial == 2, download);
+                    if (rc) return rc;
+                    if (trial) ms[trial - 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                }
+                it = h->j2_policy.emplace(key, ms[1] < 0.99 * ms[0] ? 1 : 0).first;
+            }
+            serial = it->second;
+        }
+    }
+    return df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, serial, download);
+}
+
+namespace {
+
+// out[i] = sum_p in[p * stride + i]  (fixed order: the multi-device sum is reproducible run to run)
+__global__ void sum_parts_kernel(const double *__restrict__ in, size_t stride, int nparts, double *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double a = 0;
+        for (int p = 0; p < nparts; p++) a += in[(size_t)p * stride + i];
+        out[i] = a;
+    }
+}
+
+// lower triangle of a symmetric (nao, nao) matrix <-> packed rows (the K of the MO branch travels packed like J~)
+__global__ void pack_lower_kernel(const double *__restrict__ full, int nao, double *__restrict__ tril)
+{
+    const int p = blockIdx.y;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q <= p; q += gridDim.x * blockDim.x)
+        tril[(size_t)p * (p + 1) / 2 + q] = full[(size_t)p * nao + q];
+}
+
+// every part contracts its shard on its own host thread; errors come back with their messages
+struct PartResult { int rc = 0; std::string msg; };
+
+template <class F>
+int run_parts(const std::vector<PAMD_df *> &parts, F f)
+{
+    std::vector<PartResult> res(parts.size());
+    std::vector<std::thread> th;
+    for (size_t p = 0; p < parts.size(); p++)
+        th.emplace_back([&, p]() {
+            res[p].rc = f((int)p, parts[p]);
+            if (res[p].rc) res[p].msg = g_errmsg;          // g_errmsg is thread local: carry it over to the caller's thread
+        });
+    for (auto &t : th) t.join();
+    for (size_t p = 0; p < parts.size(); p++)
+        if (res[p].rc) {
+            snprintf(g_errmsg, sizeof(g_errmsg), "device %d (part %d): %s", parts[p]->device, (int)p, res[p].msg.c_str());
+            return res[p].rc;
+        }
+    return 0;
+}
+
+// Partial [J~ | K] of the parts -> part 0 (peer copies over xGMI, or through the host when the devices cannot reach each
+// other), fixed-order sum there, one download.  K of the MO branch is symmetric and travels packed.
+int multi_reduce_download(PAMD_df *m, int nset, int nao, int with_j, int with_k, bool k_symmetric, double *vj, double *vk)
+{
+    PAMD_df *h0 = m->parts[0];
+    const int np = (int)m->parts.size();
+    const long npair = h0->npair;
+    const size_t n2 = (size_t)nao * nao;
+    const size_t nj = with_j ? (size_t)nset * npair : 0;
+    const size_t nk = with_k ? (size_t)nset * (k_symmetric ? (size_t)npair : n2) : 0;
+    const size_t len = nj + nk;
+    int rc;
+    // every part lays out its message [J~ | K (packed)] in its own work space
+    rc = run_parts(m->parts, [&](int, PAMD_df *h) -> int {
+        PAMD_CHECK_HIP(hipSetDevice(h->device));
+        int r;
+        double *msg = h->workspace("msg", len, &r);
+        if (r) return r;
+        if (with_j) PAMD_CHECK_HIP(hipMemcpyAsync(msg, h->ws["vjtril"].first, nj * 8, hipMemcpyDeviceToDevice, h->st));
+        if (with_k) {
+            const double *d_vk = h->ws["vk"].first;
+            if (k_symmetric) {
+                for (int s = 0; s < nset; s++) {
+                    pack_lower_kernel<<<dim3((nao + 255) / 256, nao), 256, 0, h->st>>>(d_vk + (size_t)s * n2, nao, msg + nj + (size_t)s * npair);
+                    PAMD_CHECK_LAUNCH();
+                }
+            } else {
+                PAMD_CHECK_HIP(hipMemcpyAsync(msg + nj, d_vk, nk * 8, hipMemcpyDeviceToDevice, h->st));
+            }
+        }
+        PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+        return 0;
+    });
+    if (rc) return rc;
+    PAMD_CHECK_HIP(hipSetDevice(h0->device));
+    double *gather = h0->workspace("gather", (size_t)np * len, &rc);
+    if (rc) return rc;
+    std::vector<double> bounce;
+    for (int p = 0; p < np; p++) {
+        PAMD_df *hp = m->parts[p];
+        const double *src = hp->ws["msg"].first;
+        double *dst = gather + (size_t)p * len;
+        if (hp->device == h0->device) {
+            PAMD_CHECK_HIP(hipMemcpyAsync(dst, src, len * 8, hipMemcpyDeviceToDevice, h0->st));
+        } else if (m->peer_ok) {
+            PAMD_CHECK_HIP(hipMemcpyPeerAsync(dst, h0->device, src, hp->device, len * 8, h0->st));
+        } else {
+            bounce.resize(len);
+            PAMD_CHECK_HIP(hipSetDevice(hp->device));
+            PAMD_CHECK_HIP(hipMemcpy(bounce.data(), src, len * 8, hipMemcpyDeviceToHost));
+            PAMD_CHECK_HIP(hipSetDevice(h0->device));
+            PAMD_CHECK_HIP(hipMemcpy(dst, bounce.data(), len * 8, hipMemcpyHostToDevice));
+        }
+    }
+    double *total = h0->workspace("total", len, &rc);
+    if (rc) return rc;
+    sum_parts_kernel<<<1024, 256, 0, h0->st>>>(gather, len, np, total, len);
+    PAMD_CHECK_LAUNCH();
+    if (with_j) {
+        double *d_vj = h0->workspace("vjfull", (size_t)nset * n2, &rc);
+        if (rc) return rc;
+        if ((rc = PAMD_unpack_tril(total, npair, nset, nao, d_vj, nao, nao, h0->st))) return rc;
+        PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vj, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h0->st));
+    }
+    if (with_k) {
+        if (k_symmetric) {
+            double *d_vkf = h0->workspace("vkfull", (size_t)nset * n2, &rc);
+            if (rc) return rc;
+            if ((rc = PAMD_unpack_tril(total + nj, npair, nset, nao, d_vkf, nao, nao, h0->st))) return rc;
+            PAMD_CHECK_HIP(hipMemcpyAsync(vk, d_vkf, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h0->st));
+        } else {
+            PAMD_CHECK_HIP(hipMemcpyAsync(vk, total + nj, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h0->st));
+        }
+    }
+    PAMD_CHECK_HIP(hipStreamSynchronize(h0->st));
+    return 0;
 }
 
 }  // namespace
 
 extern "C" {
 
+int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
+                      const PAMD_df_options *opt, PAMD_df **out)
+{
+    PAMD_REQUIRE(atm && bas && env && out && opt && natm > 0 && nbas_ao > 0 && nbas_aux > 0 && nenv > 0, "PAMD_df_create: bad arguments");
+    *out = nullptr;
+    const int ndev = opt->ndev > 0 ? opt->ndev : 1;
+    PAMD_REQUIRE(opt->ndev <= 0 || opt->devices, "PAMD_df_create: devices[ndev]");
+    PAMD_REQUIRE(ndev <= 64, "PAMD_df_create: at most 64 parts");
+    std::vector<int> devs(ndev, 0);
+    for (int i = 0; i < ndev && opt->devices; i++) devs[i] = opt->devices[i];
+    int ndevice = 0;
+    PAMD_CHECK_HIP(hipGetDeviceCount(&ndevice));
+    for (int d : devs) PAMD_REQUIRE(d >= 0 && d < ndevice, "PAMD_df_create: device index out of range");
+    Tables t;
+    int rc;
+    if ((rc = make_tables(atm, bas, nbas_ao, nbas_aux, env, &t))) return rc;
+    const size_t cap = opt->max_device_bytes > 0 ? (size_t)opt->max_device_bytes : 0;
+    Metric m;
+    if (opt->ndev <= 0 || (ndev == 1 && !(opt->flags & 1))) {
+        // the plain single-device handle
+        PAMD_df *h = nullptr;
+        if ((rc = create_shard(t, devs[0], opt->omega, opt->lindep, cap, &m, 0, 1, &h))) return rc;
+        *out = h;
+        return 0;
+    }
+    PAMD_df *mh = new PAMD_df;
+    struct Guard { PAMD_df *p; ~Guard() { delete p; } } guard{mh};
+    mh->device = devs[0];
+    mh->omega = opt->omega;
+    mh->parts.assign(ndev, nullptr);
+    // part 0 factorises the metric on its device; the host copy of M^T is then shared by all parts, which build their row
+    // ranges concurrently, one host thread per part (the raw (Q|pq) slabs are generated redundantly: ~0.1 s at config 3)
+    if ((rc = create_shard(t, devs[0], opt->omega, opt->lindep, cap, &m, 0, ndev, &mh->parts[0]))) return rc;
+    std::vector<PAMD_df *> rest(ndev - 1, nullptr);
+    {
+        std::vector<PartResult> res(ndev - 1);
+        std::vector<std::thread> th;
+        for (int p = 1; p < ndev; p++)
+            th.emplace_back([&, p]() {
+                res[p - 1].rc = create_shard(t, devs[p], opt->omega, opt->lindep, cap, &m, p, ndev, &rest[p - 1]);
+                if (res[p - 1].rc) res[p - 1].msg = g_errmsg;
+            });
+        for (auto &x : th) x.join();
+        for (int p = 1; p < ndev; p++) mh->parts[p] = rest[p - 1];
+        for (int p = 1; p < ndev; p++)
+            if (res[p - 1].rc) {
+                snprintf(g_errmsg, sizeof(g_errmsg), "device %d (part %d): %s", devs[p], p, res[p - 1].msg.c_str());
+                for (PAMD_df *&q : mh->parts) { if (q) { (void)hipSetDevice(q->device); delete q; q = nullptr; } }
+                mh->parts.clear();
+                return res[p - 1].rc;
+            }
+    }
+    PAMD_df *h0 = mh->parts[0];
+    mh->nao = h0->nao;
+    mh->naux = h0->naux;
+    mh->npair = h0->npair;
+    mh->rows = h0->rows;
+    mh->nL = mh->nL_total = h0->nL_total;
+    // direct peer copies into part 0 where the devices can reach each other (xGMI); PAMD_DF_PEER=0 forces the host bounce
+    mh->peer_ok = 1;
+    const char *envp = getenv("PAMD_DF_PEER");
+    if (envp && envp[0] == '0') mh->peer_ok = 0;
+    PAMD_CHECK_HIP(hipSetDevice(devs[0]));
+    for (int p = 1; p < ndev && mh->peer_ok; p++) {
+        if (devs[p] == devs[0]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devs[0], devs[p]) != hipSuccess || !can) { (void)hipGetLastError(); mh->peer_ok = 0; break; }
+        const hipError_t e = hipDeviceEnablePeerAccess(devs[p], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) mh->peer_ok = 0;
+        (void)hipGetLastError();
+    }
+    guard.p = nullptr;
+    *out = mh;
+    return 0;
+}
+
 int PAMD_df_create(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                    double lindep, int device, PAMD_df **out)
 {
-    PAMD_REQUIRE(atm && bas && env && out && natm > 0 && nbas_ao > 0 && nbas_aux > 0 && nenv > 0, "PAMD_df_create: bad arguments");
-    *out = nullptr;
-    PAMD_CHECK_HIP(hipSetDevice(device));
-    PAMD_df *h = new PAMD_df;
-    h->device = device;
-    struct Guard { PAMD_df *p; ~Guard() { delete p; } } guard{h};
-    PAMD_CHECK_HIP(hipStreamCreate(&h->st));
-    PAMD_CHECK_HIP(hipStreamCreate(&h->side));
-    PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
-    int rc;
-    Engine e;
-    DevPool tmp;                           // tables and scratch that die with this call
-    e.ao = make_shells(atm, bas, 0, nbas_ao, env);
-    e.aux = make_shells(atm, bas, nbas_ao, nbas_ao + nbas_aux, env);
-    int lmax_ao = 0, lmax_aux = 0;
-    for (int l : e.ao.l) lmax_ao = std::max(lmax_ao, l);
-    for (int l : e.aux.l) lmax_aux = std::max(lmax_aux, l);
-    PAMD_REQUIRE(lmax_ao <= 4 && lmax_aux <= LMAX_TAB && !(lmax_aux > 5 && lmax_ao > 3), "angular momentum beyond the instantiated kernels");
-    h->nao = e.ao.nao;
-    h->naux = e.aux.nao;
-    h->npair = (long)h->nao * (h->nao + 1) / 2;
-    h->rows = (int)round_up(h->nao, 16);
-    const int naux = h->naux;
-    // Rys table, cart->sph matrices, shell coordinates
-    if ((rc = tmp.alloc((void **)&e.d_rys, (size_t)PAMD_rys_table_len() * 8))) return rc;
-    if ((rc = PAMD_rys_table_upload(e.d_rys, h->st))) return rc;
-    std::vector<double> c2s;
-    std::vector<int> c2s_off;
-    for (int l = 0; l <= LMAX_TAB; l++) {
-        c2s_off.push_back((int)c2s.size());
-        std::vector<double> m = c2s_matrix(l);
-        c2s.insert(c2s.end(), m.begin(), m.end());
-    }
-    if ((rc = upload(tmp, c2s, &e.d_c2s)) || (rc = upload(tmp, c2s_off, &e.d_c2s_off)) || (rc = upload(tmp, e.ao.xyz, &e.d_ao_xyz)) ||
-        (rc = upload(tmp, e.ao.ao0, &e.d_ao_ao0)) || (rc = upload(tmp, e.aux.xyz, &e.d_aux_xyz)) ||
-        (rc = upload(tmp, e.aux.ao0, &e.d_aux_ao0)))
-        return rc;
-    for (int li = 0; li <= lmax_ao; li++)
-        for (int lj = 0; lj <= li; lj++) {
-            PairClass pc;
-            if ((rc = make_pair_class(tmp, e.ao, li, lj, &pc))) return rc;
-            if (pc.n) e.pcs.push_back(pc);
-        }
-    for (int l = 0; l <= lmax_aux; l++) {
-        AuxClass ac;
-        if ((rc = make_aux_class(tmp, e.aux, l, &ac))) return rc;
-        if (ac.n) e.acs.push_back(ac);
-        PairClass pc;
-        if ((rc = make_pair_class_2c(tmp, e.aux, l, 1.0 / c2s[c2s_off[0]], &pc))) return rc;
-        if (pc.n) e.pcs2c.push_back(pc);
-    }
-    // metric (P|Q)
-    double *d_j2c = nullptr;
-    if ((rc = tmp.alloc((void **)&d_j2c, (size_t)naux * naux * 8))) return rc;
-    PAMD_CHECK_HIP(hipMemsetAsync(d_j2c, 0, (size_t)naux * naux * 8, h->st));
-    for (const PairClass &pc : e.pcs2c)
-        for (const AuxClass &ac : e.acs)
-            if ((rc = launch_class(e, pc, 0, pc.n, ac, d_j2c, naux, 0, 0, e.d_aux_xyz, e.d_aux_ao0, h->st))) return rc;
-    {
-        // symmetrise on the host: (j2c + j2c^T) / 2 as pyscf_amd/df/incore.py does before the factorisation
-        std::vector<double> j((size_t)naux * naux);
-        PAMD_CHECK_HIP(hipMemcpyAsync(j.data(), d_j2c, j.size() * 8, hipMemcpyDeviceToHost, h->st));
-        PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
-        for (int a = 0; a < naux; a++)
-            for (int b = 0; b < a; b++) {
-                const double v = 0.5 * (j[(size_t)a * naux + b] + j[(size_t)b * naux + a]);
-                j[(size_t)a * naux + b] = j[(size_t)b * naux + a] = v;
-            }
-        PAMD_CHECK_HIP(hipMemcpy(d_j2c, j.data(), j.size() * 8, hipMemcpyHostToDevice));
-    }
-    std::vector<double> mt;
-    int nrow = 0, lda = 0, tri = 0;
-    if ((rc = decompose_metric(h, d_j2c, naux, lindep, &mt, &nrow, &lda, &tri))) return rc;
-    tmp.release(d_j2c);
-    h->nL = nrow;
-    double *d_mt = nullptr;
-    if ((rc = upload(tmp, mt, &d_mt))) return rc;
-    mt.clear();
-    mt.shrink_to_fit();
-    // the tensor, AO-row slab by slab (df/incore.py:189-217)
-    size_t free_b = 0, total_b = 0;
-    PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
-    const size_t tensor_b = (size_t)h->nL * h->npair * 8;
-    size_t slab_bytes = std::min<size_t>(24ul << 30, (size_t)h->npair * naux * 8);
-    if (tensor_b + slab_bytes + (1ul << 30) > free_b) {
-        snprintf(g_errmsg, sizeof(g_errmsg), "PAMD_df_create: the tensor (%.1f GB) + slab work space (%.1f GB) do not fit the %.1f GB "
-                 "of free HBM", tensor_b * 1e-9, slab_bytes * 1e-9, free_b * 1e-9);
-        return -2;
-    }
-    if ((rc = h->pool.alloc((void **)&h->d_cderi, tensor_b))) return rc;
-    const long max_rows = std::max<long>((long)(slab_bytes / ((size_t)naux * 8)), 1);
-    std::vector<std::pair<int, int>> slabs;
-    long bufrows = 0;
-    for (int sh0 = 0; sh0 < e.ao.n;) {
-        int sh1 = sh0 + 1;
-        long r0, r1;
-        while (sh1 < e.ao.n) {
-            slab_rows(e.ao, sh0, sh1 + 1, &r0, &r1);
-            if (r1 - r0 > max_rows) break;
-            sh1++;
-        }
-        slab_rows(e.ao, sh0, sh1, &r0, &r1);
-        bufrows = std::max(bufrows, r1 - r0);
-        slabs.push_back({sh0, sh1});
-        sh0 = sh1;
-    }
-    double *d_T = nullptr;
-    if ((rc = tmp.alloc((void **)&d_T, (size_t)bufrows * naux * 8))) return rc;
-    for (auto &sl : slabs) {
-        long r0, r1;
-        slab_rows(e.ao, sl.first, sl.second, &r0, &r1);
-        PAMD_CHECK_HIP(hipMemsetAsync(d_T, 0, (size_t)(r1 - r0) * naux * 8, h->st));
-        for (const PairClass &pc : e.pcs) {
-            int i0, i1;
-            pc.subrange(sl.first, sl.second, &i0, &i1);
-            for (const AuxClass &ac : e.acs)
-                if ((rc = launch_class(e, pc, i0, i1, ac, d_T, naux, r0, 1, e.d_ao_xyz, e.d_ao_ao0, h->st))) return rc;
-        }
-        if ((rc = PAMD_cderi_solve(d_mt, lda, d_T, naux, h->d_cderi + r0, h->npair, h->nL, r1 - r0, naux, 0, tri, h->st))) return rc;
-    }
-    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
-    tmp.release(d_T);
-    tmp.release(d_mt);
-    if ((rc = build_square_image(h))) return rc;
-    if ((rc = build_diag_image(h))) return rc;
-    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
-    guard.p = nullptr;
-    *out = h;
-    return 0;
+    PAMD_df_options opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.lindep = lindep;
+    opt.devices = &device;
+    opt.ndev = 1;
+    return PAMD_df_create_ex(atm, natm, bas, nbas_ao, nbas_aux, env, nenv, &opt, out);
+}
+
+int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
+                         double lindep, const int *devices, int ndev, PAMD_df **out)
+{
+    PAMD_REQUIRE(devices && ndev > 0, "PAMD_df_create_multi: devices[ndev]");
+    PAMD_df_options opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.lindep = lindep;
+    opt.devices = devices;
+    opt.ndev = ndev;
+    opt.flags = 1;                          // a one-entry list still goes through the sharded code path
+    return PAMD_df_create_ex(atm, natm, bas, nbas_ao, nbas_aux, env, nenv, &opt, out);
 }
 
 void PAMD_df_destroy(PAMD_df *h)
@@ -789,229 +1469,66 @@ int PAMD_df_nao(const PAMD_df *h, int *nao)
     return 0;
 }
 
+// layout[0] parts, [1] rows resident in HBM (all parts), [2] rows in page-locked host memory, [3] rows with a square image,
+// [4] direct peer copies between the parts (0 / 1); part_rows (nullable) [nparts] rows per part
+int PAMD_df_layout(const PAMD_df *h, long *layout, int *part_rows)
+{
+    PAMD_REQUIRE(h && layout, "null handle");
+    std::vector<const PAMD_df *> ps;
+    if (h->parts.empty()) ps.push_back(h);
+    for (const PAMD_df *p : h->parts) ps.push_back(p);
+    layout[0] = (long)ps.size();
+    layout[1] = layout[2] = layout[3] = 0;
+    layout[4] = h->parts.empty() ? 0 : h->peer_ok;
+    for (size_t i = 0; i < ps.size(); i++) {
+        layout[1] += ps[i]->n_res;
+        layout[2] += ps[i]->nL - ps[i]->n_res;
+        layout[3] += ps[i]->d_sq ? ps[i]->nL : 0;
+        if (part_rows) part_rows[i] = ps[i]->nL;
+    }
+    return 0;
+}
+
+static int shard_export(PAMD_df *h, int l0, int l1, double *out)      // shard-local rows
+{
+    PAMD_CHECK_HIP(hipSetDevice(h->device));
+    const int r1 = std::min(l1, h->n_res);
+    if (l0 < r1)
+        PAMD_CHECK_HIP(hipMemcpy(out, h->d_cderi + (size_t)l0 * h->npair, (size_t)(r1 - l0) * h->npair * 8, hipMemcpyDeviceToHost));
+    const int a = std::max(l0, h->n_res);
+    if (a < l1)
+        memcpy(out + (size_t)(a - l0) * h->npair, h->h_cderi + (size_t)(a - h->n_res) * h->npair, (size_t)(l1 - a) * h->npair * 8);
+    return 0;
+}
+
 int PAMD_df_export_cderi(PAMD_df *h, int l0, int l1, double *out)
 {
     PAMD_REQUIRE(h && out && 0 <= l0 && l0 <= l1 && l1 <= h->nL, "PAMD_df_export_cderi: bad row range");
-    PAMD_CHECK_HIP(hipSetDevice(h->device));
-    PAMD_CHECK_HIP(hipMemcpy(out, h->d_cderi + (size_t)l0 * h->npair, (size_t)(l1 - l0) * h->npair * 8, hipMemcpyDeviceToHost));
+    if (h->parts.empty()) return shard_export(h, l0, l1, out);
+    for (PAMD_df *p : h->parts) {
+        const int a = std::max(l0, p->l0), b = std::min(l1, p->l0 + p->nL);
+        if (a < b) {
+            const int rc = shard_export(p, a - p->l0, b - p->l0, out + (size_t)(a - l0) * h->npair);
+            if (rc) return rc;
+        }
+    }
     return 0;
 }
 
-// dm   [nset][nao][nao] host, f64, C order.
-// orbo nullable.  Not NULL: the occupied orbitals scaled by sqrt(occ), set after set, each (nao, nocc[s]) C order (row = AO) -
-//      K comes from the MO branch (df_jk.py:339-381).  NULL: general-DM branch (df_jk.py:382-408), hermi is then ignored for K.
-// flags bit 0: the caller guarantees dm[s] = orbo_s orbo_s^T (what make_rdm1 builds) - the first J pass then comes out of the
-//      half transform's epilogue instead of a pass over the tensor.
-// vj, vk caller-owned [nset][nao][nao] (NULL with with_j / with_k = 0).
-// serial_j2: the second J pass of the fused path in line before a re-tiled SYRK (1) or on the side stream beside a plain one (0)
-static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
-                          int with_k, int flags, double *vj, double *vk, int serial_j2)
-{
-    (void)hermi;
-    PAMD_REQUIRE(h && dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
-    PAMD_REQUIRE((!with_j || vj) && (!with_k || vk) && (with_j || with_k), "PAMD_df_get_jk: output pointers");
-    PAMD_REQUIRE(!orbo || nocc, "PAMD_df_get_jk: orbo needs nocc[nset]");
-    PAMD_CHECK_HIP(hipSetDevice(h->device));
-    hipStream_t st = h->st;
-    int rc;
-    const long npair = h->npair;
-    const int nL = h->nL, ldx = h->rows, rows = h->rows;
-    const size_t n2 = (size_t)nao * nao;
-    double *d_dm = h->workspace("dm", (size_t)nset * n2, &rc);
-    if (rc) return rc;
-    PAMD_CHECK_HIP(hipMemcpyAsync(d_dm, dm, (size_t)nset * n2 * 8, hipMemcpyHostToDevice, st));
-    double *d_vjt = nullptr, *d_vk = nullptr, *d_rho = nullptr;
-    if (with_j) {
-        d_vjt = h->workspace("vjtril", (size_t)nset * npair, &rc);
-        if (rc) return rc;
-        PAMD_CHECK_HIP(hipMemsetAsync(d_vjt, 0, (size_t)nset * npair * 8, st));
-        d_rho = h->workspace("rho", (size_t)nset * std::max(nL, 1), &rc);
-        if (rc) return rc;
-        PAMD_CHECK_HIP(hipMemsetAsync(d_rho, 0, (size_t)nset * std::max(nL, 1) * 8, st));
-    }
-    const bool fused = with_j && with_k && orbo && (flags & 1) && nL > 0;
-    if (with_j && !fused && nL > 0) {
-        for (int s0 = 0; s0 < nset; s0 += 4) {
-            const int ns = std::min(4, nset - s0);
-            double *d_dt = h->workspace("dmtril", (size_t)4 * npair, &rc);
-            if (rc) return rc;
-            if ((rc = PAMD_pack_dm_tril(d_dm + (size_t)s0 * n2, ns, nao, d_dt, st))) return rc;
-            const long wlen = PAMD_df_vj_pass1_worksize(npair, nL, ns);
-            double *d_w = h->workspace("vj1work", (size_t)std::max<long>(wlen, 1), &rc);
-            if (rc) return rc;
-            if ((rc = PAMD_df_vj_pass1(h->d_cderi, npair, nL, d_dt, ns, d_rho + (size_t)s0 * nL, d_w, st))) return rc;
-            if ((rc = PAMD_df_vj_pass2(h->d_cderi, npair, nL, d_rho + (size_t)s0 * nL, ns, d_vjt + (size_t)s0 * npair, st))) return rc;
-        }
-    }
-    if (with_k) {
-        d_vk = h->workspace("vk", (size_t)nset * n2, &rc);
-        if (rc) return rc;
-        PAMD_CHECK_HIP(hipMemsetAsync(d_vk, 0, (size_t)nset * n2 * 8, st));
-        // df_jk.syrk_plan: re-tiled triangle + balanced k split when the matrix has an odd number of 64-column blocks
-        int nsplit = 4, syrk_flags = 1 | 2;
-        {
-            const int nb64 = (nao + 63) / 64;
-            if (nb64 % 2 == 1 && nb64 >= 5) {
-                const int ntl = nb64 / 2, units = ntl * (ntl - 1) / 2 + ntl + (ntl + 2) / 3;
-                double best = 0;
-                int bn = 0;
-                for (int n = 1; n < 8; n++)
-                    for (int m = 1; m < 9; m++)
-                        if (units * n + (units + m - 1) / m <= 512 && n + 1.0 / m > best) { best = n + 1.0 / m; bn = n; }
-                if (bn && units >= 32) { nsplit = bn + 1; syrk_flags = 1 | 2 | 4 | 8; }
-            }
-        }
-        if (fused && !serial_j2) { nsplit = 4; syrk_flags = 1 | 2; }      // df_jk._vk_mo: plain grid beside the co-running J pass
-        const size_t budget = 12ul << 30;               // DF.k_block_bytes
-        const double *op = orbo;
-        for (int s = 0; s < nset && nL > 0; s++) {
-            double *d_part = h->workspace("kpart", (size_t)nsplit * n2, &rc);
-            if (rc) return rc;
-            PAMD_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nsplit * n2 * 8, st));
-            if (orbo) {
-                // ---- MO branch: X_L = B_L C~, K += X^T X (df_jk.py:353-380)
-                const int no = nocc[s];
-                const double *o_s = op;
-                op += (size_t)nao * no;
-                if (no == 0) continue;
-                const int nocc_pad = (int)round_up(no, 16);
-                long ldo = nocc_pad > 160 ? round_up(nocc_pad, 160) : nocc_pad;       // df_jk.pad_orbitals
-                const int mt = nocc_pad / 16, nchunk = (mt + 9) / 10;
-                ldo = std::max<long>(ldo, (long)nchunk * (((mt + nchunk - 1) / nchunk + 1) / 2) * 32);
-                ldo = std::max<long>(ldo, std::min(round_up(nocc_pad, 160), round_up(nocc_pad, 128)));
-                std::vector<double> oh((size_t)rows * ldo, 0.0);
-                for (int p = 0; p < nao; p++)
-                    for (int i = 0; i < no; i++) oh[(size_t)p * ldo + i] = o_s[(size_t)p * no + i];
-                double *d_orb = h->workspace("orb", (size_t)rows * ldo, &rc);
-                if (rc) return rc;
-                PAMD_CHECK_HIP(hipMemcpyAsync(d_orb, oh.data(), oh.size() * 8, hipMemcpyHostToDevice, st));
-                PAMD_CHECK_HIP(hipStreamSynchronize(st));                      // oh goes out of scope
-                long blk = std::max<long>(1, (long)(budget / ((size_t)nocc_pad * ldx * 8)));
-                blk = std::min<long>(blk, nL);
-                const long nblk = (nL + blk - 1) / blk;
-                blk = (nL + nblk - 1) / nblk;
-                double *d_X = h->workspace("X", (size_t)blk * nocc_pad * ldx, &rc);
-                if (rc) return rc;
-                double *d_rw = nullptr;
-                if (fused) {
-                    d_rw = h->workspace("rho_work", (size_t)std::max<long>(PAMD_nr_e2_rho_worksize((int)blk, ldx, nocc_pad), 1), &rc);
-                    if (rc) return rc;
-                }
-                for (long b0 = 0; b0 < nL; b0 += blk) {
-                    const int nb = (int)std::min<long>(blk, nL - b0);
-                    double *rho_b = fused ? d_rho + (size_t)s * nL + b0 : nullptr;
-                    if (h->d_sq)
-                        rc = PAMD_nr_e2_square(h->d_sq + (size_t)b0 * rows * rows, rows, rows, nb, nao, d_orb, (int)ldo, rows, nocc_pad,
-                                               d_X, ldx, rho_b, d_rw, st);
-                    else
-                        rc = PAMD_nr_e2_symm_diag(h->d_cderi + (size_t)b0 * npair, npair, nb, nao, d_orb, (int)ldo, rows, nocc_pad, d_X, ldx,
-                                                  rho_b, d_rw, h->d_diag ? h->d_diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st);
-                    if (rc) return rc;
-                    if (fused) {
-                        // second J pass of this block on the side stream, behind the block's SYRK (HBM-bound beside MFMA-bound)
-                        if (serial_j2) {
-                            if ((rc = PAMD_df_vj_pass2(h->d_cderi + (size_t)b0 * npair, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, st)))
-                                return rc;
-                        } else {
-                            PAMD_CHECK_HIP(hipEventRecord(h->ev, st));
-                            PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev, 0));
-                            if ((rc = PAMD_df_vj_pass2(h->d_cderi + (size_t)b0 * npair, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side)))
-                                return rc;
-                        }
-                    }
-                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, d_part, nao, nao, nao, (long)nb * nocc_pad, syrk_flags, nsplit, st))) return rc;
-                    if (fused) {
-                        // the next block's half transform overwrites nothing the side stream reads (rho_b, cderi): no wait here
-                    }
-                }
-                if ((rc = PAMD_reduce_splits(d_part, nsplit, nao, nao, d_vk + (size_t)s * n2, nao, 1, st))) return rc;
-            } else {
-                // ---- general-DM branch: T_L = B_L D, K = sum_L T_L^T B_L (df_jk.py:382-407)
-                const long ldo = rows > 160 ? round_up(rows, 160) : round_up(rows, 32);    // whole 32-column wave tiles
-                double *d_orb = h->workspace("orb_dm", (size_t)rows * ldo, &rc);
-                if (rc) return rc;
-                PAMD_CHECK_HIP(hipMemsetAsync(d_orb, 0, (size_t)rows * ldo * 8, st));
-                PAMD_CHECK_HIP(hipMemcpy2DAsync(d_orb, (size_t)ldo * 8, d_dm + (size_t)s * n2, (size_t)nao * 8, (size_t)nao * 8, nao,
-                                                hipMemcpyDeviceToDevice, st));
-                long blk = std::max<long>(1, (long)(budget / ((size_t)rows * ldx * 8)));
-                blk = std::min<long>(blk, nL);
-                long nblk = (nL + blk - 1) / blk;
-                blk = std::max<long>(1, ((nL + nblk - 1) / nblk) / 2);
-                double *d_X = h->workspace("X", (size_t)blk * rows * ldx, &rc);
-                if (rc) return rc;
-                // rows with an unpacked image: it IS the second operand (no per-block unpack) and feeds the square-image kernel
-                double *d_full = nullptr;
-                if (!h->d_sq) {
-                    d_full = h->workspace("full", (size_t)blk * rows * ldx, &rc);
-                    if (rc) return rc;
-                    PAMD_CHECK_HIP(hipMemsetAsync(d_full, 0, (size_t)blk * rows * ldx * 8, st));
-                }
-                for (long b0 = 0; b0 < nL; b0 += blk) {
-                    const int nb = (int)std::min<long>(blk, nL - b0);
-                    const double *sub = h->d_cderi + (size_t)b0 * npair;
-                    const double *second = d_full;
-                    if (h->d_sq) {
-                        second = h->d_sq + (size_t)b0 * rows * rows;
-                        if ((rc = PAMD_nr_e2_square(second, rows, rows, nb, nao, d_orb, (int)ldo, rows, rows, d_X, ldx, nullptr, nullptr, st)))
-                            return rc;
-                    } else {
-                        if ((rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, d_orb, (int)ldo, rows, rows, d_X, ldx, nullptr, nullptr,
-                                                       h->d_diag ? h->d_diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st))) return rc;
-                        if ((rc = PAMD_unpack_tril(sub, npair, nb, nao, d_full, ldx, rows, st))) return rc;
-                    }
-                    if ((rc = PAMD_dgemm_tn(d_X, ldx, second, ldx, d_part, nao, nao, nao, (long)nb * rows, 0 | 2, nsplit, st))) return rc;
-                }
-                if ((rc = PAMD_reduce_splits(d_part, nsplit, nao, nao, d_vk + (size_t)s * n2, nao, 0, st))) return rc;
-            }
-        }
-    }
-    if (fused) {
-        PAMD_CHECK_HIP(hipEventRecord(h->ev, h->side));
-        PAMD_CHECK_HIP(hipStreamWaitEvent(st, h->ev, 0));
-    }
-    if (with_j) {
-        double *d_vj = h->workspace("vjfull", (size_t)nset * n2, &rc);
-        if (rc) return rc;
-        if ((rc = PAMD_unpack_tril(d_vjt, npair, nset, nao, d_vj, nao, nao, st))) return rc;
-        PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vj, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
-    }
-    if (with_k) PAMD_CHECK_HIP(hipMemcpyAsync(vk, d_vk, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
-    PAMD_CHECK_HIP(hipStreamSynchronize(st));
-    PAMD_CHECK_HIP(hipStreamSynchronize(h->side));
-    return 0;
-}
-
-// Schedule of the second J pass on the fused path (DF.j2_policy of the Python layer): which of the two is faster depends on the
-// shape (config 3: overlapped, taxol on one GPU: in line), so a tensor of 4 GB and more gets both timed once per (nset, occupied
-// count) - two extra builds at the first call - and the choice is kept in the handle.  PAMD_DF_J2 = overlap | serial overrides.
 int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
                    int with_k, int flags, double *vj, double *vk)
 {
     PAMD_REQUIRE(h, "PAMD_df_get_jk: null handle");
-    const bool fused = with_j && with_k && orbo && (flags & 1) && h->nL > 0;
-    int serial = 0;
-    if (fused) {
-        const char *env = getenv("PAMD_DF_J2");
-        if (env && (env[0] == 's' || env[0] == 'o')) {
-            serial = env[0] == 's';
-        } else if ((size_t)h->nL * (size_t)h->npair * 8 >= (4ul << 30) && nocc) {
-            long key = nset;
-            for (int s = 0; s < nset; s++) key = key * 4099 + nocc[s];
-            auto it = h->j2_policy.find(key);
-            if (it == h->j2_policy.end()) {
-                double ms[2] = {0, 0};
-                for (int trial = 0; trial < 3; trial++) {             // overlap (priming, untimed), overlap, serial
-                    const auto t0 = std::chrono::steady_clock::now();
-                    const int rc = df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, trial == 2);
-                    if (rc) return rc;
-                    if (trial) ms[trial - 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                }
-                it = h->j2_policy.emplace(key, ms[1] < 0.99 * ms[0] ? 1 : 0).first;
-            }
-            serial = it->second;
-        }
-    }
-    return df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, serial);
+    PAMD_REQUIRE((!with_j || vj) && (!with_k || vk) && (with_j || with_k), "PAMD_df_get_jk: output pointers");
+    if (h->parts.empty()) return shard_get_jk(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, 1);
+    PAMD_REQUIRE(dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
+    // one host thread per device contracts that device's shard (the serial decomposition this replaces: df_jk.py:362-381);
+    // the partial [J~ | K] are summed on part 0's device and leave in one download
+    int rc = run_parts(h->parts, [&](int, PAMD_df *p) {
+        return shard_get_jk(p, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, nullptr, nullptr, 0);
+    });
+    if (rc) return rc;
+    return multi_reduce_download(h, nset, nao, with_j, with_k, orbo != nullptr, vj, vk);
 }
 
 }  // extern "C"

@@ -270,7 +270,10 @@ int launch_grad_class(const Int3c2eGradArgs &ga, hipStream_t st)
     static_assert(lds <= 160 * 1024, "LDS budget exceeded");
     if (ga.base.npairs == 0 || ga.base.naux_cls == 0) return 0;
     auto kern = int3c2e_grad_kernel<LI, LJ, LK, C::S, C::NTHREADS>;
-    static bool attr_set = false;
+    static bool attr_done[64] = {false};       // per device: the attribute belongs to the device's code object (multi-GPU handles)
+    int dev_id = 0;
+    if (lds > 64 * 1024) PAMD_CHECK_HIP(hipGetDevice(&dev_id));
+    bool &attr_set = attr_done[dev_id & 63];
     if (!attr_set && lds > 64 * 1024) {
         PAMD_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;

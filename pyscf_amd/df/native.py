@@ -51,17 +51,32 @@ def _conc_env(atm1, bas1, env1, atm2, bas2, env2):
             np.ascontiguousarray(np.hstack((env1, env2)), dtype=np.float64))
 
 
+class _Options(_c.Structure):
+    """PAMD_df_options of include/pyscf_amd.h"""
+    _fields_ = [('lindep', _c.c_double), ('omega', _c.c_double), ('devices', _c.POINTER(_c.c_int)), ('ndev', _c.c_int),
+                ('flags', _c.c_int), ('max_device_bytes', _c.c_longlong)]
+
+
 class NativeDF:
+    """``NativeDF(mol, auxbasis)``: one GPU.  ``NativeDF(mol, auxbasis, devices=range(8))``: the same object over several
+    devices of the node in THIS process - the aux index is sharded inside the C handle (PAMD_df_create_multi), a stock
+    single-process ``mf.with_df = NativeDF(mol, devices=range(8)); mf.kernel()`` uses all of them.  ``max_device_bytes``
+    caps the HBM a part may take: rows beyond it (or beyond the device's free memory) are kept in page-locked host memory
+    and streamed under the kernels in every build (out-of-core, PCIe-bound for those rows)."""
     blockdim = 240
 
-    def __init__(self, mol, auxbasis=None, auxmol=None, device=0, lindep=1e-7):
+    def __init__(self, mol, auxbasis=None, auxmol=None, device=0, lindep=1e-7, devices=None, omega=0.0, max_device_bytes=0):
         self.mol = mol
         self.auxbasis = auxbasis
         self.auxmol = auxmol
         self.device = device
+        self.devices = None if devices is None else [int(d) for d in devices]
         self.lindep = lindep
+        self.omega = float(omega)
+        self.max_device_bytes = int(max_device_bytes)
         self._h = None
         self._naux = None
+        self._rsh_df = {}                         # omega -> NativeDF of that operator (pyscf/df/df.py:298-333 range_coulomb)
 
     def build(self):
         if self._h is not None:
@@ -73,9 +88,12 @@ class NativeDF:
         atm, bas, env = _conc_env(np.asarray(mol._atm), np.asarray(mol._bas), np.asarray(mol._env),
                                   np.asarray(aux._atm), np.asarray(aux._bas), np.asarray(aux._env))
         h = _c.c_void_p()
-        _check(load().PAMD_df_create(atm.ctypes.data_as(_c.c_void_p), _c.c_int(len(atm)), bas.ctypes.data_as(_c.c_void_p),
-                                     _c.c_int(len(mol._bas)), _c.c_int(len(aux._bas)), env.ctypes.data_as(_c.c_void_p),
-                                     _c.c_int(len(env)), _c.c_double(self.lindep), _c.c_int(self.device), _c.byref(h)))
+        devs = self.devices if self.devices is not None else [int(self.device)]
+        arr = (_c.c_int * len(devs))(*devs)
+        opt = _Options(self.lindep, self.omega, arr, len(devs), 1 if self.devices is not None else 0, self.max_device_bytes)
+        _check(load().PAMD_df_create_ex(atm.ctypes.data_as(_c.c_void_p), _c.c_int(len(atm)), bas.ctypes.data_as(_c.c_void_p),
+                                        _c.c_int(len(mol._bas)), _c.c_int(len(aux._bas)), env.ctypes.data_as(_c.c_void_p),
+                                        _c.c_int(len(env)), _c.byref(opt), _c.byref(h)))
         self._h = h
         n = _c.c_int()
         _check(load().PAMD_df_naux(h, _c.byref(n)))
@@ -85,11 +103,33 @@ class NativeDF:
         return self
     kernel = build
 
+    def layout(self):
+        """{'parts', 'rows_resident', 'rows_host', 'rows_square', 'peer', 'part_rows'} of the built handle (PAMD_df_layout)."""
+        self.build()
+        lay = (_c.c_long * 5)()
+        rows = (_c.c_int * 64)()
+        _check(load().PAMD_df_layout(self._h, lay, rows))
+        return dict(parts=lay[0], rows_resident=lay[1], rows_host=lay[2], rows_square=lay[3], peer=lay[4],
+                    part_rows=[rows[i] for i in range(lay[0])])
+
+    def range_coulomb(self, omega):
+        """The handle of erf(omega r12)/r12 (omega > 0) or erfc(|omega| r12)/r12 (omega < 0), cached per omega."""
+        if not omega:
+            return self
+        key = '%.6f' % omega
+        if key not in self._rsh_df:
+            self._rsh_df[key] = NativeDF(self.mol, self.auxbasis, self.auxmol, self.device, self.lindep, self.devices, omega,
+                                         self.max_device_bytes)
+        return self._rsh_df[key]
+
     def reset(self, mol=None):
         if self._h is not None:
             load().PAMD_df_destroy(self._h)
         self._h = None
         self._naux = None
+        for o in getattr(self, '_rsh_df', {}).values():
+            o.reset()
+        self._rsh_df = {}
         if mol is not None:
             self.mol = mol
             self.auxmol = None
@@ -116,8 +156,8 @@ class NativeDF:
             yield out
 
     def get_jk(self, dm, hermi=1, with_j=True, with_k=True, direct_scf_tol=1e-13, omega=None):
-        if omega:
-            raise NotImplementedError('range-separated tensors: use pyscf_amd.df.DF')
+        if omega is not None and omega != 0 and omega != self.omega:
+            return self.range_coulomb(omega).get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
         self.build()
         dms = np.asarray(dm)
         if np.iscomplexobj(dms):
@@ -144,7 +184,8 @@ class NativeDF:
             nocc = np.array([b.shape[1] for b in blocks], dtype=np.int32)
             orbo = np.concatenate([b.ravel() for b in blocks]) if nocc.sum() else np.zeros(1)
             # dm == orbo orbo^T ?  (two matrix-vector products per density; the tag of this package's make_rdm1 promises it)
-            ok = getattr(dm, 'dm_from_orbitals', None)
+            # (the package's own tag is probed as well: a tagged array edited in place keeps its attributes)
+            ok = None
             if ok is None:
                 v = np.random.RandomState(20240601).random_sample(nao) - 0.5
                 ok = all(np.abs(dms[k].dot(v) - blocks[k].dot(blocks[k].T.dot(v))).max() <= 1e-10 * max(1.0, np.abs(dms[k].dot(v)).max())
