@@ -305,6 +305,14 @@ int PAMD_sub_vmat(const double *d_ao_c, const long *d_ao_off, const double *d_ao
                   const long *d_idx_off, const int *d_ld, const int *d_idx, const int *d_work /* {tile, tm, tn} x nwork */,
                   int nwork, int G, int nao, double *d_vmat, long ldv, void *stream);  /* vmat[idx][idx] += ao_c[0]^T aow_c */
 
+/* r04: the symmetrised product V = M + M^T on balanced blocks, lower triangle only (two products per block, half the atomics);
+ * d_work = {tile, p0, gp, q0, gq, diag} x nwork from PAMD_sub_vmat_work (host; work NULL -> count); PAMD_mirror_tril completes V */
+int PAMD_sub_vmat_sym(const double *d_ao_c, const long *d_ao_off, const double *d_aow_c, const long *d_aow_off,
+                      const long *d_idx_off, const int *d_ld, const int *d_idx, const int *d_work, int nwork, int G, int nao,
+                      double *d_vmat, long ldv, void *stream);
+long PAMD_sub_vmat_work(const int *ld, int ntile, int *work);
+int PAMD_mirror_tril(const double *d_part, int m, int ldc, double *d_out, void *stream);
+
 /* ---- host-array, opaque-handle form of the DF J/K path (csrc/df_handle.hip) -------------------------------------------
  * The reference's convention: plain C functions taking raw HOST pointers and ints, the caller owns every buffer
  * (pyscf/df/df_jk.py:373-379 fdrv(..., buf1.ctypes.data_as(c_void_p), eri1..., orbo...), pyscf/gto/moleintor.py:590-596).

@@ -14,13 +14,18 @@
 //   sub_vmat      M[idx[mu]][idx[nu]] += sum_{g in tile} ao_c[0][g][mu] aow_c[g][nu]  (LDS-DMA GEMM, scatter-add)
 //
 // idx[tile][ld_t] maps a compact column to its AO index (>= nao for padding columns).
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "mfma_e2.h"
 
 using namespace pamd;
 
 static int g_orb_dot_dma = 1;
+static int g_vmat_probe = 0;   // benchmarking probes of sub_vmat_sym ("vmatprobe", see the kernel)
+static int g_vmat_burst = 0;   // sub_vmat_sym: DMA rows of the next k-tile in one burst behind the first MFMA group ("vmatburst")
+static int g_vmat_xcd = 1;     // sub_vmat*: work items of one tile on ONE XCD (its L2 then serves the panel re-reads); A/B switch "vmatxcd"
 
 namespace {
 
@@ -31,6 +36,19 @@ struct SubTiles {
     const int *ld;          // [ntile] ld_t
     const int *idx;         // compact column -> AO index
 };
+
+
+// Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.  A work list ordered by tile
+// therefore spreads the blocks of one tile - which read the same two panels - over all eight L2s, and every one of them fetches
+// the panels from HBM again (r03 counters: 4 x the algorithmic bytes).  This maps block b to the list position that keeps
+// consecutive items on one XCD: XCD x works through its own contiguous stretch of the list (speed only - any dispatch order is
+// correct).
+__device__ __forceinline__ int xcd_contiguous(int b, int n, int enabled)
+{
+    if (!enabled || n < 16) return b;
+    const int q = n >> 3, r = n & 7, x = b & 7, slot = b >> 3;
+    return x < r ? x * (q + 1) + slot : r * (q + 1) + (x - r) * q + slot;
+}
 
 // grid: x = 128-point slice of the tile, y = component, z = tile * nchunk + orbital chunk
 template <int MT>
@@ -172,14 +190,15 @@ __global__ __launch_bounds__(256) void sub_scale_kernel(const double *__restrict
 // (one loop instance per live-group count).  Epilogue: FP64 no-return atomics into M[idx[mu]][idx[nu]].
 __global__ __launch_bounds__(256, 2) void sub_vmat_kernel(const double *__restrict__ ao_c, const double *__restrict__ aow_c,
                                                           SubTiles tl, const int *__restrict__ work, int G, int nao,
-                                                          double *__restrict__ vmat, long ldv)
+                                                          double *__restrict__ vmat, long ldv, int xcd)
 {
     __shared__ double sb0[2 * KB * LDN];
     __shared__ double sb1[2 * KB * LDN];
     constexpr int PA = KB * LDN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t = work[3 * blockIdx.x], tm = work[3 * blockIdx.x + 1], tn = work[3 * blockIdx.x + 2];
+    const int item = xcd_contiguous(blockIdx.x, gridDim.x, xcd);
+    const int t = work[3 * item], tm = work[3 * item + 1], tn = work[3 * item + 2];
     const int ld = tl.ld[t];
     const int p0 = tm * NT, q0 = tn * NT;
     // buffer-resource LDS-DMA as in gemm_tn_glds2 (df_jk.hip): scalar row offsets, no per-lane address arithmetic, the
@@ -279,6 +298,170 @@ __global__ __launch_bounds__(256, 2) void sub_vmat_kernel(const double *__restri
     }
 }
 
+// r04: the LOWER triangle of V = M + M^T (numint.py:1157), M = ao_c[0]^T aow_c, on BALANCED blocks.
+// The r03 kernel above cuts the ld_t x ld_t product of a tile into 128 x 128 blocks from the left: at the mean ld_t of config 3
+// (400 = 3 x 128 + 16) 7 of its 16 blocks are edge blocks with 1/8 of the MFMA work and the full 32-k-tile DMA / barrier pipeline
+// (matrix pipe busy 0.53).  Here the host cuts the 16-column groups of a tile into ceil(g / 8) pieces of nearly equal size
+// (400 -> 7 + 6 + 6 + 6 groups), a work item is one pair of pieces (i >= j) = {tile, p0, gp, q0, gq, diag}, its two wave rows /
+// columns split their piece evenly (ceil(gp / 2) | the rest), and the block accumulates BOTH products of the symmetrised matrix,
+//     V[i][j] = A_i^T W_j + W_i^T A_j        (A = ao_c[0], W = aow_c),
+// in one accumulator pass (two k-loops over the tile's G points: 2 x 32 k-tiles per prologue / epilogue instead of 32).  Only
+// blocks on and below the diagonal exist; a diagonal block computes M_ii once and folds M_ii + M_ii^T in its epilogue (entry
+// (r, c) is added at [max][min], twice when r == c): exactly the MFMA work of r03 and 5/8 of its FP64 atomics.
+// idx[] ascends inside a tile, so compact (mu >= nu) is AO (idx[mu] >= idx[nu]): vmat receives exactly its lower triangle;
+// PAMD_mirror_tril completes V.
+// PROBE (benchmarking only, results meaningless unless 0): 1 = no scatter-add, 2 = no DMA inside the k-loop (stale tiles), 3 = no MFMAs
+template <bool BURST, int PROBE>  // BURST: all DMA rows of k-tile t + 1 behind the FIRST MFMA group of tile t instead of one row per group
+__global__ __launch_bounds__(256, 2) void sub_vmat_sym_kernel(const double *__restrict__ ao_c, const double *__restrict__ aow_c,
+                                                              SubTiles tl, const int *__restrict__ work, int G, int nao,
+                                                              double *__restrict__ vmat, long ldv, int xcd)
+{
+    __shared__ double sb0[2 * KB * LDN];
+    __shared__ double sb1[2 * KB * LDN];
+    constexpr int PA = KB * LDN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    (void)xcd;
+    const int *w = work + 6 * (long)blockIdx.x;       // the list is in dispatch order (PAMD_sub_vmat_work)
+    const int t = w[0], p0 = w[1], gp = w[2], q0 = w[3], gq = w[4], diag = w[5];
+    if (gp == 0) return;                              // padding item of a shorter XCD queue (uniform for the workgroup)
+    const int ld = tl.ld[t];
+    const int voff = lane * 16, ld8 = ld * 8;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+    // even split of the piece between the two wave rows / columns
+    const int ga0 = (gp + 1) >> 1, gb0 = (gq + 1) >> 1;
+    const int na = wr == 0 ? ga0 : gp - ga0, nb = wc == 0 ? gb0 : gq - gb0;
+    const int ra = wr * ga0 * 16, cb = wc * gb0 * 16;
+    const int offa = fk * LDN + ra + fn, offb = PA + fk * LDN + cb + fn;
+    const double *A = ao_c + tl.ao_off[t], *W = aow_c + tl.aow_off[t];
+    // a diagonal block needs M_ii only: (M + M^T)_ii is folded in the epilogue (entry (r, c) goes to [max][min], twice on r == c)
+    const int nphase = diag ? 1 : 2;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    auto kloop = [&](auto NAc, auto NBc) {
+        constexpr int NA = decltype(NAc)::value, NB = decltype(NBc)::value;
+        for (int ph = 0; ph < nphase; ph++) {
+            // phase 0: rows of A (columns p0..) x rows of W (columns q0..); phase 1: W (p0..) x A (q0..)
+            const __amdgpu_buffer_rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc((void *)((ph ? W : A) + p0), 0, 0xffffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc((void *)((ph ? A : W) + q0), 0, 0xffffffff, 0x00020000);
+            auto stage_row = [&](int k0, double *dst, int j) {
+                const int k = wave * 4 + j;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(dst + k * LDN), 16, voff, (k0 + k) * ld8, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_b, (__attribute__((address_space(3))) void *)(dst + PA + k * LDN), 16, voff, (k0 + k) * ld8, 0, 0);
+            };
+            auto step = [&](const double *cur, double *nxt, int k0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int kn = (k0 + KB < G) ? k0 + KB : k0;
+#pragma unroll
+                for (int kk = 0; kk < KB; kk += 4) {
+                    double af[4], bf[4];
+#pragma unroll
+                    for (int a = 0; a < NA; a++) af[a] = cur[offa + kk * LDN + a * 16];
+#pragma unroll
+                    for (int b = 0; b < NB; b++) bf[b] = cur[offb + kk * LDN + b * 16];
+                    if (PROBE == 2) {
+                    } else if (BURST) {
+                        if (kk == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) stage_row(kn, nxt, j);
+                        }
+                    } else {
+                        stage_row(kn, nxt, kk >> 2);
+                    }
+                    if (PROBE == 3) {
+                        acc[0][0][0] += af[0] + bf[0];
+                        continue;
+                    }
+#pragma unroll
+                    for (int a = 0; a < NA; a++)
+#pragma unroll
+                        for (int b = 0; b < NB; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+                }
+            };
+            __syncthreads();                   // every wave is done reading the buffers of the previous phase
+#pragma unroll
+            for (int j = 0; j < 4; j++) stage_row(0, sb0, j);
+            for (int k0 = 0; k0 < G; k0 += 2 * KB) {
+                step(sb0, sb1, k0);
+                if (k0 + KB < G) step(sb1, sb0, k0 + KB);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tile re-loaded itself: let it land before the buffers are reused
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    auto pick_b = [&](auto NAc) {
+        switch (nb) {
+        case 1: kloop(NAc, I1{}); break;
+        case 2: kloop(NAc, I2{}); break;
+        case 3: kloop(NAc, I3{}); break;
+        default: kloop(NAc, I4{}); break;
+        }
+    };
+    if (na <= 0 || nb <= 0) {
+        kloop(I0{}, I0{});                 // nothing to compute: stage the DMA rows only (the barriers are the workgroup's)
+        return;
+    }
+    switch (na) {
+    case 1: pick_b(I1{}); break;
+    case 2: pick_b(I2{}); break;
+    case 3: pick_b(I3{}); break;
+    default: pick_b(I4{}); break;
+    }
+    if (PROBE == 1) {
+        double sum = 0;                                    // keeps every accumulator alive
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (sum == 1.2345e300) vmat[0] = 1;
+        return;
+    }
+    const int *idx = tl.idx + tl.idx_off[t];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        if (b >= nb) continue;
+        const int col = q0 + cb + b * 16 + fn;
+        if (col >= ld) continue;
+        const int aj = idx[col];
+        if (aj >= nao) continue;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            if (a >= na) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rowi = p0 + ra + a * 16 + fk + 4 * r;
+                if (rowi >= ld) continue;
+                const int ai = idx[rowi];
+                if (ai >= nao) continue;
+                if (!diag) unsafeAtomicAdd(vmat + (long)ai * ldv + aj, acc[a][b][r]);
+                else if (rowi > col) unsafeAtomicAdd(vmat + (long)ai * ldv + aj, acc[a][b][r]);
+                else if (rowi < col) unsafeAtomicAdd(vmat + (long)aj * ldv + ai, acc[a][b][r]);
+                else unsafeAtomicAdd(vmat + (long)ai * ldv + aj, 2.0 * acc[a][b][r]);
+            }
+        }
+    }
+}
+
+// out[i][j] = out[j][i] = part[max(i, j)][min(i, j)]: completes a matrix accumulated on its lower triangle
+__global__ void mirror_tril_kernel(const double *__restrict__ part, int m, int ldc, double *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= m) return;
+    out[(long)i * m + j] = i >= j ? part[(long)i * ldc + j] : part[(long)j * ldc + i];
+}
+
 // ao_c[tile][c][g][mu] = dense[c][g0 + g][idx[mu]] (0 for padding columns and for rows beyond the dense block):
 // fills the compact image from a dense PAMD_eval_ao block.  grid: x = column chunk, y = g, z = tile (of this call)
 __global__ __launch_bounds__(256) void sub_gather_kernel(const double *__restrict__ dense, long dense_rows, int ldao,
@@ -304,6 +487,9 @@ extern "C" {
 int PAMD_set_tuning_xc(const char *key, int value)
 {
     if (strcmp(key, "orbdotdma") == 0) { g_orb_dot_dma = value; return 0; }
+    if (strcmp(key, "vmatxcd") == 0) { g_vmat_xcd = value; return 0; }
+    if (strcmp(key, "vmatburst") == 0) { g_vmat_burst = value; return 0; }
+    if (strcmp(key, "vmatprobe") == 0) { g_vmat_probe = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
 }
 
@@ -378,7 +564,83 @@ int PAMD_sub_vmat(const double *d_ao_c, const long *d_ao_off, const double *d_ao
     PAMD_REQUIRE(((uintptr_t)d_ao_c | (uintptr_t)d_aow_c) % 16 == 0, "16-byte aligned operands");
     if (nwork == 0) return 0;
     SubTiles tl{d_ao_off, d_aow_off, d_idx_off, d_ld, d_idx};
-    sub_vmat_kernel<<<nwork, 256, 0, (hipStream_t)stream>>>(d_ao_c, d_aow_c, tl, d_work, G, nao, d_vmat, ldv);
+    sub_vmat_kernel<<<nwork, 256, 0, (hipStream_t)stream>>>(d_ao_c, d_aow_c, tl, d_work, G, nao, d_vmat, ldv, g_vmat_xcd);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// r04: vmat (lower triangle) += the lower triangle of  M + M^T,  M = sum_tiles scatter(ao_c[t][0]^T aow_c[t]),  for the nwork
+// work items {tile, p0, gp, q0, gq, diag} of d_work[6 nwork]: piece pairs (i >= j) of a balanced cut of the tile's 16-column
+// groups (p0 / q0 first compact column, gp / gq <= 8 groups, diag = 1 for i == j); PAMD_sub_vmat_work builds the list on the
+// host.  Complete the matrix with PAMD_mirror_tril.  Replaces PAMD_sub_vmat + PAMD_reduce_sym of r03.
+int PAMD_sub_vmat_sym(const double *d_ao_c, const long *d_ao_off, const double *d_aow_c, const long *d_aow_off,
+                      const long *d_idx_off, const int *d_ld, const int *d_idx, const int *d_work, int nwork, int G, int nao,
+                      double *d_vmat, long ldv, void *stream)
+{
+    PAMD_REQUIRE(G % KB == 0, "tile size must be a multiple of 16");
+    PAMD_REQUIRE(((uintptr_t)d_ao_c | (uintptr_t)d_aow_c) % 16 == 0, "16-byte aligned operands");
+    if (nwork == 0) return 0;
+    SubTiles tl{d_ao_off, d_aow_off, d_idx_off, d_ld, d_idx};
+    #define LAUNCH_VS(B, P) sub_vmat_sym_kernel<B, P><<<nwork, 256, 0, (hipStream_t)stream>>>(d_ao_c, d_aow_c, tl, d_work, G, nao, d_vmat, ldv, g_vmat_xcd)
+    if (g_vmat_probe == 1) LAUNCH_VS(false, 1);
+    else if (g_vmat_probe == 2) LAUNCH_VS(false, 2);
+    else if (g_vmat_probe == 3) LAUNCH_VS(false, 3);
+    else if (g_vmat_burst) LAUNCH_VS(true, 0);
+    else LAUNCH_VS(false, 0);
+#undef LAUNCH_VS
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// Host helper: the work list of PAMD_sub_vmat_sym for `ntile` tiles with leading dimensions ld[] (multiples of 16).
+// work == NULL: returns the number of items only.  Returns the item count (6 ints each).
+// The list is in DISPATCH order: workgroup b runs on XCD b % 8 (round-robin dispatch), so position b holds the next item of
+// that XCD's own queue.  Tiles are dealt to the eight queues largest first, each to the queue with the least MFMA work so far
+// (cost of an item = ceil(gp / 2) ceil(gq / 2) tile-MFMAs per k-step, twice that off the diagonal), and all items of a tile sit in ONE queue: the blocks
+// that read the same two panels run on one XCD at about the same time and share its L2 (r03: every XCD fetched the panels from
+// HBM again, 4 x the algorithmic bytes).  Shorter queues are padded with no-op items (gp = 0).  "vmatxcd" = 0: plain list.
+long PAMD_sub_vmat_work(const int *ld, int ntile, int *work)
+{
+    std::vector<int> order(ntile);
+    for (int i = 0; i < ntile; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ld[a] > ld[b]; });
+    const int nq = g_vmat_xcd ? 8 : 1;
+    std::vector<std::vector<int>> queue(nq);
+    std::vector<double> load(nq, 0.0);
+    for (int t : order) {
+        const int g = ld[t] / 16, np = (g + 7) / 8;
+        if (np == 0) continue;
+        const int base = g / np, rem = g % np;
+        std::vector<int> first(np + 1, 0);
+        for (int i = 0; i < np; i++) first[i + 1] = first[i] + base + (i < rem ? 1 : 0);
+        int qi = 0;
+        for (int k = 1; k < nq; k++) if (load[k] < load[qi]) qi = k;
+        for (int i = 0; i < np; i++)
+            for (int j = 0; j <= i; j++) {
+                const int gp = first[i + 1] - first[i], gq = first[j + 1] - first[j];
+                const int w[6] = {t, first[i] * 16, gp, first[j] * 16, gq, i == j};
+                queue[qi].insert(queue[qi].end(), w, w + 6);
+                load[qi] += ((gp + 1) / 2) * ((gq + 1) / 2) * (i == j ? 1 : 2);
+            }
+    }
+    size_t depth = 0;
+    for (auto &q : queue) depth = std::max(depth, q.size() / 6);
+    const long n = (long)depth * nq;
+    if (work) {
+        for (size_t d = 0; d < depth; d++)
+            for (int k = 0; k < nq; k++) {
+                int *w = work + 6 * (d * nq + k);
+                if (d * 6 < queue[k].size()) memcpy(w, &queue[k][d * 6], 6 * sizeof(int));
+                else { w[0] = 0; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 0; w[5] = 0; }
+            }
+    }
+    return n;
+}
+
+int PAMD_mirror_tril(const double *d_part, int m, int ldc, double *d_out, void *stream)
+{
+    dim3 grid(ceil_div(m, 256), m);
+    mirror_tril_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_part, m, ldc, d_out);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

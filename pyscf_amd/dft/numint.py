@@ -80,7 +80,9 @@ class NumInt:
         self.sparse = True              # False: the dense tile-masked pipeline below (kept for comparison / tests)
         self.sparse_tile = 512          # grid points per tile (multiple of 128; 512 measured best at (H2O)_32: 30.1 ms vs 32.0 / 35.1 for 1024 / 2048)
         self.sparse_cutoff = 1e-14      # a shell is active on a tile if some value / gradient component exceeds this
-        self.sparse_chunk_points = 131072   # grid points per launch group (bounds the c = ao . C workspace)
+        self.sparse_chunk_points = 1 << 21  # grid points per launch group (bounds the c = ao . C workspace: 5.5 GB at config 3); r04: one
+                                            # group for the whole grid - 9 launches per kernel cost 0.9 ms of tails in sub_vmat alone
+        self.vmat_sym = True            # r04: V = M + M^T on balanced blocks, lower triangle only (PAMD_sub_vmat_sym); False: the r03 kernel
         self.ao_cache = 'auto'          # keep the compact AO image in HBM across calls: True / False / 'auto' (if it fits)
         self.ao_cache_reserve = 40 << 30    # HBM left free after caching ('auto')
 
@@ -347,13 +349,21 @@ class NumInt:
             for s in range(nset):
                 self._call('scale_ao', lib.PAMD_sub_scale_ao, _ptr(aoc), tabs[0], tabs[1], tabs[3], _c.c_int(nt),
                            _c.c_int(G), _c.c_int(ncomp), _c.c_int(ch['ld_max']), _ptr(wv[s]), _c.c_long(ldg), _ptr(aow), st)
-                self._call('ao_dot_aow', lib.PAMD_sub_vmat, _ptr(aoc), tabs[0], _ptr(aow), tabs[1], tabs[2], tabs[3],
-                           _ptr(plan.idx), _ptr(ch['work']), _c.c_int(ch['nwork']), _c.c_int(G), _c.c_int(nao),
-                           _ptr(M[s]), _c.c_long(nao), st)
+                if self.vmat_sym:
+                    self._call('ao_dot_aow', lib.PAMD_sub_vmat_sym, _ptr(aoc), tabs[0], _ptr(aow), tabs[1], tabs[2], tabs[3],
+                               _ptr(plan.idx), _ptr(ch['work_sym']), _c.c_int(ch['nwork_sym']), _c.c_int(G), _c.c_int(nao),
+                               _ptr(M[s]), _c.c_long(nao), st)
+                else:
+                    self._call('ao_dot_aow', lib.PAMD_sub_vmat, _ptr(aoc), tabs[0], _ptr(aow), tabs[1], tabs[2], tabs[3],
+                               _ptr(plan.idx), _ptr(ch['work']), _c.c_int(ch['nwork']), _c.c_int(G), _c.c_int(nao),
+                               _ptr(M[s]), _c.c_long(nao), st)
         v = torch.empty((nset, nao, nao), dtype=f64, device=dev)
         for s in range(nset):
-            self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(M[s]), _c.c_int(1), _c.c_int(nao), _c.c_int(nao),
-                       _ptr(v[s]), st)
+            if self.vmat_sym:           # M holds the lower triangle of V = M + M^T (numint.py:1157) already
+                self._call('reduce_sym', lib.PAMD_mirror_tril, _ptr(M[s]), _c.c_int(nao), _c.c_int(nao), _ptr(v[s]), st)
+            else:
+                self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(M[s]), _c.c_int(1), _c.c_int(nao), _c.c_int(nao),
+                           _ptr(v[s]), st)
         rank, world = self._world()
         self._allreduce([v, acc], world)
         if device_out:
@@ -489,14 +499,22 @@ class NumInt:
                 for s in range(nspin):
                     self._call('scale_ao', lib.PAMD_sub_scale_ao, _ptr(aoc), tabs[0], tabs[1], tabs[3], _c.c_int(nt),
                                _c.c_int(G), _c.c_int(ncomp), _c.c_int(ch['ld_max']), _ptr(wv[s]), _c.c_long(ldg), _ptr(aow), st)
-                    self._call('ao_dot_aow', lib.PAMD_sub_vmat, _ptr(aoc), tabs[0], _ptr(aow), tabs[1], tabs[2], tabs[3],
-                               _ptr(plan.idx), _ptr(ch['work']), _c.c_int(ch['nwork']), _c.c_int(G), _c.c_int(nao),
-                               _ptr(M[s, i]), _c.c_long(nao), st)
+                    if self.vmat_sym:
+                        self._call('ao_dot_aow', lib.PAMD_sub_vmat_sym, _ptr(aoc), tabs[0], _ptr(aow), tabs[1], tabs[2], tabs[3],
+                                   _ptr(plan.idx), _ptr(ch['work_sym']), _c.c_int(ch['nwork_sym']), _c.c_int(G), _c.c_int(nao),
+                                   _ptr(M[s, i]), _c.c_long(nao), st)
+                    else:
+                        self._call('ao_dot_aow', lib.PAMD_sub_vmat, _ptr(aoc), tabs[0], _ptr(aow), tabs[1], tabs[2], tabs[3],
+                                   _ptr(plan.idx), _ptr(ch['work']), _c.c_int(ch['nwork']), _c.c_int(G), _c.c_int(nao),
+                                   _ptr(M[s, i]), _c.c_long(nao), st)
         v = torch.empty((nspin, nvec, nao, nao), dtype=f64, device=dev)
         for s in range(nspin):
             for i in range(nvec):
-                self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(M[s, i]), _c.c_int(1), _c.c_int(nao), _c.c_int(nao),
-                           _ptr(v[s, i]), st)
+                if self.vmat_sym:
+                    self._call('reduce_sym', lib.PAMD_mirror_tril, _ptr(M[s, i]), _c.c_int(nao), _c.c_int(nao), _ptr(v[s, i]), st)
+                else:
+                    self._call('reduce_sym', lib.PAMD_reduce_sym, _ptr(M[s, i]), _c.c_int(1), _c.c_int(nao), _c.c_int(nao),
+                               _ptr(v[s, i]), st)
         rank, world = self._world()
         self._allreduce([v], world)
         return v.cpu().numpy()

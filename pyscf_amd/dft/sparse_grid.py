@@ -65,7 +65,11 @@ class SparsePlan:
         self._runs = self._tile_runs(max(1, int(ni.block_bytes // (self.ncomp * self.ldao * 8 * G))))
         active = self._screen(sh)
         self._tables(sh, active)
-        self._chunks(ni.sparse_chunk_points)
+        # launch groups: as few as the orbital-product work space allows (ncomp x nocc_pad x points doubles per buffer, at most
+        # `chunk_buffer_bytes` each; the response kernels hold three of them)
+        nocc_hint = _round_up(max(getattr(mol, 'nelectron', 2) // 2, 1), 16)
+        cap = int(getattr(ni, 'chunk_buffer_bytes', 6 << 30) // (self.ncomp * 8 * nocc_hint))
+        self._chunks(max(G, min(int(ni.sparse_chunk_points), max(cap, 131072))))
         self.ao_c = None
         if self._cache_fits():
             self.ao_c = torch.empty(self.ao_total + 256, dtype=torch.float64, device=dev)
@@ -166,9 +170,17 @@ class SparsePlan:
                 for tm in range(nt):
                     for tn in range(nt):
                         work.append((t, tm, tn))
+            # r04: piece pairs (i >= j) of a balanced cut of every tile's 16-column groups (PAMD_sub_vmat_sym)
+            ld32 = np.ascontiguousarray(ldc, dtype=np.int32)
+            lib = _lib_mod.load_library()
+            lib.PAMD_sub_vmat_work.restype = _c.c_long
+            nsym = int(lib.PAMD_sub_vmat_work(ld32.ctypes.data_as(_c.c_void_p), _c.c_int(len(ld32)), _c.c_void_p(0)))
+            wsym = np.zeros(max(nsym, 1) * 6, np.int32)
+            lib.PAMD_sub_vmat_work(ld32.ctypes.data_as(_c.c_void_p), _c.c_int(len(ld32)), wsym.ctypes.data_as(_c.c_void_p))
             self.chunks.append(dict(t0=t0, t1=t1, ao_base=base, ao_size=int(ao_sz.sum()), aow_size=int(aow_sz.sum()),
                                     ld_max=int(ldc.max()), nwork=len(work),
-                                    work=torch.from_numpy(np.asarray(work, np.int32).reshape(-1)).to(self.dev)))
+                                    work=torch.from_numpy(np.asarray(work, np.int32).reshape(-1)).to(self.dev),
+                                    nwork_sym=nsym, work_sym=torch.from_numpy(wsym).to(self.dev)))
             base += int(ao_sz.sum())
         self.ao_total = base
         self.ao_off = torch.from_numpy(ao_off).to(self.dev)

@@ -106,6 +106,25 @@ def test_sub_kernels_vs_numpy(G, ncomp, nocc):
         assert np.abs(got_aow - aw).max() < 1e-12 * max(1.0, np.abs(aw).max())
         Mw[np.ix_(cols, cols)] += a[0].T.dot(aw)
     assert np.abs(M.cpu().numpy() - Mw).max() < 1e-11 * max(1.0, np.abs(Mw).max())
+    # r04: V = M + M^T accumulated on its lower triangle by balanced blocks (PAMD_sub_vmat_sym), completed by PAMD_mirror_tril
+    so.PAMD_sub_vmat_work.restype = C.c_long
+    ld32 = np.ascontiguousarray(ld, dtype=np.int32)
+    nw = so.PAMD_sub_vmat_work(ld32.ctypes.data_as(C.c_void_p), ntile, None)
+    wl = np.zeros(nw * 6, np.int32)
+    assert so.PAMD_sub_vmat_work(ld32.ctypes.data_as(C.c_void_p), ntile, wl.ctypes.data_as(C.c_void_p)) == nw
+    items = wl.reshape(-1, 6)
+    assert np.all(items[:, 2] <= 8) and np.all(items[:, 4] <= 8) and np.all(items[:, 1] >= items[:, 3])
+    for k in range(ntile):                                    # the pieces of a tile cover its groups exactly once
+        mine = items[(items[:, 0] == k) & (items[:, 5] == 1)]
+        assert mine[:, 2].sum() * 16 == ld[k] and np.array_equal(np.sort(mine[:, 1]), np.concatenate([[0], np.cumsum(mine[np.argsort(mine[:, 1]), 2])[:-1] * 16]))
+    L = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_sub_vmat_sym(_p(ao_c), _p(d_ao_off), _p(aow), _p(d_aow_off), _p(d_idx_off), _p(d_ld), _p(d_idx), _p(t(wl)),
+                                   int(nw), G, nao, _p(L), C.c_long(nao), st))
+    V = torch.empty((nao, nao), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_mirror_tril(_p(L), nao, nao, _p(V), st))
+    Vw = Mw + Mw.T
+    assert float(torch.triu(L, 1).abs().max()) == 0.0                       # nothing above the diagonal
+    assert np.abs(V.cpu().numpy() - Vw).max() < 1e-11 * max(1.0, np.abs(Vw).max())
 
 
 @pytest.fixture(scope='module')

@@ -23,6 +23,52 @@ taxol_dump) # converged DF-RKS B3LYP orbitals of config 4 (input of the oracle f
   timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/build_mfma -o b -- $B > $R/$O/build_mfma.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/build_write -o b -- $B > $R/$O/build_write.log 2>&1
   cd $R; tail -2 $O/build_valu.log; find $O -name "*.csv" | head; find $O -name "*.db" -delete ;;
+xcab)       # XC leg A/B: r03 sub_vmat vs r04 sub_vmat_sym, with / without the XCD-aware work order
+  : > $O/xcbench.log
+  for v in "--vmat-sym 1 --chunk 2000000" "--vmat-sym 1 --chunk 2000000 --tune-xc vmatprobe=1" "--vmat-sym 1 --chunk 2000000 --tile 1024" "--vmat-sym 1 --chunk 2000000 --tile 1024 --tune-xc vmatprobe=1" "--vmat-sym 1 --chunk 2000000 --tile 768"; do
+    echo "== $v" >> $O/xcbench.log
+    timeout 400 python tools/xcbench.py --steps 5 $v 2>/dev/null | tail -1 >> $O/xcbench.log
+  done
+  python - <<'PY'
+import json
+for l in open('gpurun_out/xcab/xcbench.log'):
+    if l.startswith('=='): print(l.strip()); continue
+    d=json.loads(l); print('   wall', d['wall_ms_per_call'], d['kernel_ms'], d['executed']['ao_dot_aow'])
+PY
+  ;;
+xcpmc)      # counters of the XC kernels for the sub_vmat variants: gpu_job.sh xcpmc
+  cd /tmp
+  for tag in "r03:--vmat-sym 0 --tune-xc vmatxcd=0" "r03x:--vmat-sym 0 --tune-xc vmatxcd=1" "sym:--vmat-sym 1 --tune-xc vmatxcd=0" "symx:--vmat-sym 1 --tune-xc vmatxcd=1"; do
+    T=${tag%%:*}; V=${tag#*:}
+    B="python $R/tools/xcbench.py --steps 2 $V"
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/${T}_fetch -o x -- $B > $R/$O/${T}_fetch.log 2>&1
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/${T}_write -o x -- $B > $R/$O/${T}_write.log 2>&1
+    timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/$O/${T}_sq -o x -- $B > $R/$O/${T}_sq.log 2>&1
+  done
+  cd $R
+  python tools/pmc_table.py $O > $O/summary.txt; cat $O/summary.txt
+  find $O -name "*.db" -delete; find $O -name "*_kernel_trace.csv" -delete ;;
+probe)      # one-off hardware probes
+  ./tools/probe/cu_mask_probe.bin 2>&1 | tee $O/cu_mask_probe.log ;;
+kab)        # kbench A/B of tuning keys on the config-3 shape: gpu_job.sh kab "<tune1>" "<tune2>" ...  (use - for none)
+  : > $O/kbench.log
+  for t in "$@"; do
+    [ "$t" = "-" ] && T="" || T="$t"
+    for rep in 1 2; do
+      echo "== tune=$T" >> $O/kbench.log
+      timeout 300 python tools/kbench.py --steps 5 $KBENCH_ARGS ${T:+--tune $T} 2>&1 | tail -1 >> $O/kbench.log
+    done
+  done
+  cut -c1-420 $O/kbench.log ;;
+kpol)       # kbench over J-pass-2 schedules: gpu_job.sh kpol "<kbench args 1>" "<kbench args 2>" ...
+  : > $O/kbench.log
+  for t in "$@"; do
+    for rep in 1 2; do
+      echo "== $t" >> $O/kbench.log
+      timeout 300 python tools/kbench.py --steps 5 $t 2>&1 | tail -1 >> $O/kbench.log
+    done
+  done
+  cut -c1-330 $O/kbench.log ;;
 run)        # arbitrary command line, logged: gpu_job.sh run <tag> <cmd...>
   T=$1; shift; timeout 1500 "$@" > $O/$T.log 2>&1; tail -30 $O/$T.log ;;
 *) echo "unknown job $JOB"; exit 2 ;;

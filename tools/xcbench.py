@@ -18,6 +18,8 @@ ap.add_argument('--nsplit', type=int, default=0)
 ap.add_argument('--dense', action='store_true')
 ap.add_argument('--tile', type=int, default=0)
 ap.add_argument('--cutoff', type=float, default=0)
+ap.add_argument('--vmat-sym', type=int, default=1, help='1: PAMD_sub_vmat_sym (r04), 0: the r03 kernel')
+ap.add_argument('--chunk', type=int, default=0, help='grid points per launch group')
 ap.add_argument('--tune-xc', default='', help='comma list key=value for PAMD_set_tuning_xc')
 a = ap.parse_args()
 import ctypes
@@ -42,6 +44,8 @@ if a.nsplit: ni.vmat_nsplit = a.nsplit
 if a.dense: ni.sparse = False
 if a.tile: ni.sparse_tile = a.tile
 if a.cutoff: ni.sparse_cutoff = a.cutoff
+ni.vmat_sym = bool(a.vmat_sym)
+if a.chunk: ni.sparse_chunk_points = a.chunk
 n, e, vm = ni.nr_rks(mol, grids, a.xc, dm)
 torch.cuda.synchronize()
 ni.kernel_timer = df_jk.KernelTimer()
@@ -63,4 +67,13 @@ if ni.sparse:
                    'compact_GB': plan.ao_total * 8e-9, 'cached': plan.ao_c is not None}
     out['TF']['ao_dot_mo'] = round(out['TF']['ao_dot_mo'] * plan.density, 1)
     out['TF']['ao_dot_aow'] = round(out['TF']['ao_dot_aow'] * plan.density2, 1)
+    # executed flops of the two MFMA products from the plan itself (16-column groups incl. padding): roofline of the XC leg
+    ldh = plan.ld_host.astype(np.float64)
+    npad = (nocc + 15) // 16 * 16
+    fl_mo = 2.0 * plan.ncomp * plan.G * float(ldh.sum()) * npad
+    fl_vm = 2.0 * plan.G * float((ldh ** 2).sum())
+    out['vmat_sym'] = bool(ni.vmat_sym)
+    out['executed'] = {k: {'TF': round(f * 1e-12, 4), 'ms': round(s[k][0] / a.steps, 2), 'TFs': round(f / (s[k][0] / a.steps) * 1e-9, 1),
+                           'frac_of_78.6': round(f / (s[k][0] / a.steps) * 1e-9 / 78.6, 3)}
+                       for k, f in (('ao_dot_mo', fl_mo), ('ao_dot_aow', fl_vm))}
 print(json.dumps(out))
