@@ -363,6 +363,38 @@ int PAMD_df_export_cderi(PAMD_df *h, int l0, int l1, double *out);
 int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
                    int with_k, int flags, double *vj, double *vk);
 
+/* ---- host-array, opaque-handle form of the XC quadrature (csrc/xc_handle.hip; SURVEY.md 8(b) mi_xc_build_grids / mi_nr_rks) ----
+ * Same convention as the PAMD_df_* handle: raw HOST pointers, the caller owns every array, no device runtime needed in the caller.
+ *   PAMD_grid_weights_host  replaces VXCgen_grid (pyscf/lib/dft/grid_basis.c:32-101) + the normalisation loop of
+ *                           gen_grid.get_partition (pyscf/dft/gen_grid.py:341-419) for the points of atom `ia`: coords[ngrids][3]
+ *                           (already shifted to the atom), vol[ngrids] the atomic quadrature weights, radii_table[natm][natm]
+ *                           (nullable: radii_adjust = None), scheme 0 Becke / 1 Stratmann / 2 LKO  ->  weights[ngrids]
+ *   PAMD_xc_create          atm / bas / env of the molecule (libcint format) + coords[ngrids][3], weights[ngrids] of a built Grids
+ *                           object (pyscf/dft/gen_grid.py:487-744) -> handle; the block-sparse plan (tiles of 512 points, active
+ *                           shells per tile, compact AO image cached in HBM) is built at the first call per functional type
+ *   PAMD_xc_nr_rks          replaces numint.nr_rks (pyscf/dft/numint.py:1074-1190).  fac[PAMD_XC_NFAC] = the component weights the
+ *                           host-side parser produces (libxc.parse_xc -> LIBXC_eval_xc(ids, facs), pyscf/dft/libxc.py:496-720,
+ *                           pyscf/lib/dft/libxc_itrf.c:968-1024); xctype 0 LDA / 1 GGA; every density s of the nset is given by
+ *                           orbital factors D_s = sum_i signs[i] c_i c_i^T: orbs = the (nao, nocc[s]) blocks one after the other
+ *                           (C order, row = AO; occupied orbitals scaled by sqrt(occ) as numint's _gen_rho_evaluator MO branch,
+ *                           :2930-2994), signs nullable (all +1) -> nelec[nset], exc[nset], vmat[nset][nao][nao]
+ *   PAMD_xc_nr_uks          replaces numint.nr_uks (:1192-1324): orbs = alpha block then beta block, nocc[2] -> nelec[2], exc[1],
+ *                           vmat[2][nao][nao]
+ *   PAMD_xc_plan_info       info[3] = {tiles, mean fraction of AO functions active per tile, GB of the cached compact image} */
+#define PAMD_XC_NFAC 10
+typedef struct PAMD_xc PAMD_xc;
+int PAMD_grid_weights_host(const double *coords, long ngrids, const double *atm_coords, int natm, const double *radii_table, int scheme,
+                           int ia, const double *vol, int device, double *weights);
+int PAMD_xc_create(const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, const double *coords,
+                   const double *weights, long ngrids, int device, PAMD_xc **out);
+void PAMD_xc_destroy(PAMD_xc *h);
+int PAMD_xc_nao(const PAMD_xc *h, int *nao);
+int PAMD_xc_plan_info(PAMD_xc *h, int xctype, double *info);
+int PAMD_xc_nr_rks(PAMD_xc *h, const double *fac, int xctype, int nset, const double *orbs, const int *nocc, const double *signs,
+                   double *nelec, double *exc, double *vmat);
+int PAMD_xc_nr_uks(PAMD_xc *h, const double *fac, int xctype, const double *orbs, const int *nocc, const double *signs, double *nelec,
+                   double *exc, double *vmat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'lib', 'libpyscf_amd.so')
-SOURCES = ['capi.hip', 'df_handle.hip', 'df_jk.hip', 'int3c2e.hip', 'int2e.hip', 'int1e.hip', 'grid.hip', 'xc.hip', 'xc_sparse.hip']
+SOURCES = ['capi.hip', 'df_handle.hip', 'df_jk.hip', 'int3c2e.hip', 'int2e.hip', 'int1e.hip', 'grid.hip', 'xc.hip', 'xc_sparse.hip', 'xc_handle.hip']
 # (source, extra flags, object tag): the int3c2e family is compiled once per aux angular momentum
 VARIANTS = [('int3c2e_lk.hip', ['-DPAMD_LK=%d' % lk], 'lk%d' % lk) for lk in range(7)] + \
            [('int3c2e_grad_lk.hip', ['-DPAMD_LK=%d' % lk], 'lk%d' % lk) for lk in range(7)]

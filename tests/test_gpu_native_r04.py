@@ -35,9 +35,17 @@ def test_config3_through_the_native_handle_vs_oracle_golden():
     _run('_native_cfg3_worker.py', 'NATIVE_CFG3_OK', 1500)
 
 
+@pytest.mark.gpu
+def test_xc_handle_grids_nr_rks_nr_uks_and_df_rks_golden_without_torch():
+    """PAMD_grid_weights_host / PAMD_xc_create / PAMD_xc_nr_rks / PAMD_xc_nr_uks from numpy, no torch in the
+    process; the reference's DF-RKS golden -76.690346887915879 (pyscf/dft/test/test_h2o.py:236-240) through NativeDF +
+    NativeNumInt + NativeGrids."""
+    _run('_native_xc_worker.py', 'NATIVE_XC_OK', 1200)
+
+
 def test_library_exports_the_r04_handle_api_without_torch():
     code = ("import sys; sys.path.insert(0, %r); from pyscf_amd.df import native; lib = native.load(); "
-            "[getattr(lib, n) for n in ('PAMD_df_create_ex', 'PAMD_df_create_multi', 'PAMD_df_layout')]; "
+            "[getattr(lib, n) for n in ('PAMD_df_create_ex', 'PAMD_df_create_multi', 'PAMD_df_layout', 'PAMD_grid_weights_host', 'PAMD_xc_create', 'PAMD_xc_nr_rks', 'PAMD_xc_nr_uks', 'PAMD_xc_plan_info', 'PAMD_xc_destroy')]; from pyscf_amd.dft import native as xn; "
             "assert 'torch' not in sys.modules; print('ok')" % ROOT)
     p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and 'ok' in p.stdout, p.stderr[-2000:]
