@@ -45,6 +45,8 @@ ap.add_argument('--local-waters', type=int, default=8)
 ap.add_argument('--first-water', type=int, default=-1, help='first molecule of the support (default: the molecule whose aux '
                 'functions open the rank\'s row range, so that the partial J/K are of order one, not a far tail)')
 ap.add_argument('--nsyn', type=int, default=32)
+ap.add_argument('--rows', type=int, nargs=2, default=None, help='explicit aux row range [l0, l1) instead of a rank (e.g. two adjacent shards at once)')
+ap.add_argument('--tag', default='')
 ap.add_argument('--rows-per-pass', type=int, default=0, help='AO shells per integral block (0: sized for ~4 GB)')
 ap.add_argument('--nsample', type=int, default=4096)
 ap.add_argument('--check-dense', action='store_true', help='small cases: compare with the dense oracle tensor')
@@ -62,6 +64,8 @@ nao, naux = mol.nao, auxmol.nao_nr()
 base, rem = divmod(naux, a.world)                      # DF.shard_range
 l0 = a.rank * base + min(a.rank, rem)
 l1 = l0 + base + (1 if a.rank < rem else 0)
+if a.rows:
+    l0, l1 = a.rows
 nl = l1 - l0
 loc = ref.ao_loc(mol)
 if a.first_water < 0:
@@ -128,9 +132,10 @@ if a.check_dense:
     vj0, vk0 = ref.get_jk(cd, dm, 1)
     print('check vs dense oracle: |dJ| %.2e |dK| %.2e' % (np.abs(vj0[:, a0:a1] - vj_rect).max(), np.abs(vk0 - vk).max()))
 
-tag = 'h2o%d_%s_rank%dof%d_local' % (a.nwater, a.basis.replace('-', ''), a.rank, a.world)
+tag = a.tag or ('h2o%d_%s_rows%d-%d_local' % (a.nwater, a.basis.replace('-', ''), l0, l1) if a.rows else
+                'h2o%d_%s_rank%dof%d_local' % (a.nwater, a.basis.replace('-', ''), a.rank, a.world))
 ri, ci = golden_util.sample_positions(nao, a.nsample)
-res = {'system': '(H2O)_%d %s, aux rows [%d, %d) of %d (rank %d of %d)' % (a.nwater, a.basis, l0, l1, naux, a.rank, a.world),
+res = {'system': '(H2O)_%d %s, aux rows [%d, %d) of %d (%s)' % (a.nwater, a.basis, l0, l1, naux, 'explicit row range' if a.rows else 'rank %d of %d' % (a.rank, a.world)),
        'nao': nao, 'naux': naux, 'aux_rows': [l0, l1], 'support_ao_range': [a0, a1], 'support_waters': [a.first_water,
                                                                                                  a.first_water + a.local_waters],
        'nsyn': a.nsyn,
