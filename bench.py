@@ -59,7 +59,14 @@ def main():
     ap.add_argument('--j2-policy', default='auto', choices=['auto', 'overlap', 'serial'], help='second J pass beside the SYRK on a '
                     'side stream, or in line before a re-tiled SYRK; auto: both timed once in the first (warm-up) build')
     ap.add_argument('--syrk-flags', type=int, default=-1, help='override DF.k_syrk_flags (A/B runs): 0 plain, 12 re-tiled + balanced')
+    ap.add_argument('--single-process', action='store_true', help='N GPUs from ONE process through the C handle (PAMD_df_create_multi: '
+                    'one host thread per device, peer gather + sum on device 0) instead of one rank per GPU under torch.distributed')
+    ap.add_argument('--pmc', action='store_true', help='re-measure roofline.traffic in this run: two extra rocprofv3 --pmc passes '
+                    '(FETCH_SIZE, WRITE_SIZE) of a short bench.py before the timed run (N = 1 only; adds ~2 minutes)')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.single_process:
+        return single_process_main(args)
     if args.backend:
         os.environ['PAMD_DIST_BACKEND'] = args.backend
 
@@ -109,6 +116,10 @@ def main():
         dist.all_reduce(one)
         if int(one.item()) != world:
             raise SystemExit('bench.py: pre-flight all-reduce returned %r, expected %d' % (one.item(), world))
+
+    pmc_live = None
+    if args.pmc and world == 1 and not args.pmc_child:
+        pmc_live = _pmc_passes(args)         # before this process holds any HBM: the child runs need the whole device
 
     from pyscf_amd import gto, df, lib
     from pyscf_amd.data import clusters
@@ -263,6 +274,26 @@ def main():
                    'kernels_ms': {k: round(t, 2) for k, (t, n_) in xs.items()}}
         if ni.sparse:
             plan = ni.sparse_plan(mol, grids, dft.libxc.xc_type(args.xc) == 'GGA')
+            # roofline of the XC leg: flops the two MFMA products EXECUTE on the compact operands (16-column groups incl. their
+            # padding, from the plan's own tile table) over their HIP-event time; sub_scale is the HBM-bound kernel of the leg
+            ldh = plan.ld_host.astype(np.float64)
+            npad = (nocc + 15) // 16 * 16
+            fl = {'ao_dot_mo': 2.0 * plan.ncomp * plan.G * float(ldh.sum()) * npad, 'ao_dot_aow': 2.0 * plan.G * float((ldh ** 2).sum())}
+            xr = {}
+            for k_, f_ in fl.items():
+                if k_ in xs and xs[k_][0] > 0:
+                    xr[k_] = {'bound': 'mfma', 'executed_TFLOP': round(f_ * 1e-12, 4), 'ms': round(xs[k_][0], 3),
+                              'achieved': round(f_ / xs[k_][0] * 1e-9, 2), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(f_ / xs[k_][0] * 1e-9 / FP64_MFMA_PEAK_TFLOPS, 4)}
+            if 'scale_ao' in xs and xs['scale_ao'][0] > 0:
+                by = 8.0 * (plan.ncomp + 1) * plan.G * float(ldh.sum())
+                xr['scale_ao'] = {'bound': 'hbm', 'bytes': by, 'ms': round(xs['scale_ao'][0], 3), 'achieved': round(by / xs['scale_ao'][0] * 1e-6, 1),
+                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by / xs['scale_ao'][0] * 1e-6 / HBM_PEAK_GBS, 4)}
+            tot_fl = sum(fl.values())
+            xr['leg'] = {'executed_TFLOP': round(tot_fl * 1e-12, 4), 'kernels_ms': round(sum(t for t, n_ in xs.values()), 2),
+                         'ideal_ms_at_mfma_peak': round(tot_fl / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 2),
+                         'frac_of_mfma_peak_over_kernel_time': round(tot_fl / (sum(t for t, n_ in xs.values()) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
+            xc_info['roofline'] = xr
             xc_info['block_sparse'] = {'tile_points': plan.G, 'tiles': int(plan.nloc), 'cutoff': ni.sparse_cutoff,
                                        'ao_density_mean': round(plan.density, 4),
                                        'ao_density_sq_mean': round(plan.density2, 4),
@@ -338,6 +369,19 @@ def main():
     except Exception:
         pass
     dtot, dcnt = ksum[dom]
+    if pmc_live is not None:
+        square = getattr(dfobj, '_cderi_sq', None) is not None
+        names = {'e2_symm': ['e2_sq2_kernel', 'e2_sq_kernel'] if square else ['e2_pk_kernel', 'e2_symm_kernel'],
+                 'dgemm_tn': ['syrk_slots_kernel', 'gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel'], 'vj_pass1': ['vj_pass1_rows_kernel'],
+                 'vj_pass2': ['vj_pass2_kernel', 'vj_pass2_wide_kernel']}[dom]
+        hit = [k for k in names if k in pmc_live.get('FETCH_SIZE', {})]
+        if hit:
+            k0 = hit[0]
+            rd = 1.0 if k0 == 'e2_symm_kernel' else 2.0          # gfx950 reports half the bytes of coalesced streaming reads
+            traffic = (rd * pmc_live['FETCH_SIZE'][k0]['max'] + pmc_live.get('WRITE_SIZE', {}).get(k0, {'max': 0.0})['max']) * 1024.0
+            traffic_src = ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --pmc-child` '
+                           '(largest launch of %s; FETCH_SIZE x %.0f: the gfx950 half-count of coalesced reads)' % (k0, rd))
+            pm_doc = {'profiled_run': {'rows_per_e2_launch': float(naux_local / max(dcnt, 1))}}
     if traffic is not None and dom == 'e2_symm':
         # the PMC pass ran at N = 1; a rank's launch moves bytes in proportion to its aux rows per launch (recorded with the pass)
         traffic *= (naux_local / max(dcnt, 1)) / float(pm_doc.get('profiled_run', {}).get('rows_per_e2_launch', 2224.0))
@@ -348,8 +392,9 @@ def main():
                  else 'e2_symm (half transform)', 'dgemm_tn': 'gemm_tn_glds (SYRK)'}[dom]
         roofline = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                    'traffic_source': '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; '
-                                      'not re-measured in this run)' % traffic_src if traffic is not None else None,
+                    'traffic_source': (traffic_src if pmc_live is not None else
+                                       '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured '
+                                       'in this run - bench.py --pmc does)' % traffic_src) if traffic is not None else None,
                     'avg_launch_ms': round(dtot / dcnt, 4), 'launches_per_step': round(dcnt, 2),
                     'flops_per_step': fl}
     else:
@@ -397,8 +442,14 @@ def main():
         nrow = args.cpu_sample_rows
         if nrow <= 0:
             # all aux rows when the host has room for the tensor (+ the reference's 240-row work buffers), else half of them
-            import psutil
-            avail = psutil.virtual_memory().available
+            try:
+                import psutil
+                avail = psutil.virtual_memory().available
+            except ImportError:
+                avail = 0
+                for line in open('/proc/meminfo'):
+                    if line.startswith('MemAvailable'):
+                        avail = int(line.split()[1]) * 1024
             nrow = naux_local if avail > 1.5 * 8.0 * naux_local * npair + (32 << 30) else -(-naux_local // 2)
         nrow = min(nrow, naux_local)
         sample = np.empty((nrow, npair))
@@ -466,6 +517,117 @@ def main():
     print(json.dumps(out))
     if grouped:
         dist.destroy_process_group()
+
+
+def _pmc_passes(args):
+    """{'FETCH_SIZE': {kernel: {'max', 'mean', 'n'}}, 'WRITE_SIZE': ...} in KiB per launch from two rocprofv3 --pmc passes of a short
+    child run of this file (counters alone with --kernel-trace, as the profiling guide prescribes; never with other trace domains)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    short = ('e2_sq2_kernel', 'e2_sq_kernel', 'e2_pk_kernel', 'e2_symm_kernel', 'syrk_slots_kernel', 'gemm_tn_glds2_kernel',
+             'gemm_tn_glds_kernel', 'vj_pass1_rows_kernel', 'vj_pass2_wide_kernel', 'vj_pass2_kernel')
+    out = {}
+    env = dict(os.environ, TMPDIR='/tmp')
+    child = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '0', '--no-cpu-baseline', '--xc', '', '--pmc-child',
+             '--nwater', str(args.nwater), '--molecule', args.molecule, '--k-square', args.k_square, '--j2-policy', args.j2_policy]
+    if args.basis:
+        child += ['--basis', args.basis]
+    if args.tune:
+        child += ['--tune', args.tune]
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='pamd_pmc_', dir='/tmp')
+        try:
+            subprocess.run(['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--'] + child,
+                           cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            agg = {}
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r['Counter_Name'] != counter:
+                        continue
+                    k = next((n for n in short if n in r['Kernel_Name']), None)
+                    if k:
+                        agg.setdefault((k, r['Dispatch_Id']), 0.0)
+                        agg[(k, r['Dispatch_Id'])] += float(r['Counter_Value'])
+            per = {}
+            for (k, _), v in agg.items():
+                per.setdefault(k, []).append(v)
+            out[counter] = {k: {'max': max(v), 'mean': sum(v) / len(v), 'n': len(v)} for k, v in per.items()}
+        except Exception as e:                         # a missing profiler must not break the metric line
+            out[counter] = {}
+            out['error'] = str(e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def single_process_main(args):
+    """`bench.py --gpus N --single-process`: the same workload through the host-array C handle with a device LIST
+    (PAMD_df_create_multi via pyscf_amd.df.native.NativeDF(devices=range(N))) - no torch, no torch.distributed, one process.
+    A step is one `with_df.get_jk(dm)` with numpy arrays in and out, so `value` here INCLUDES the PCIe transfers of D, the
+    orbitals, J and K (the device-resident figure is the default mode's `value`)."""
+    from pyscf_amd import gto, lib
+    from pyscf_amd.data import clusters
+    from pyscf_amd.df.native import NativeDF
+    from oracle import ref
+    if args.basis is None:
+        args.basis = 'def2-tzvp' if args.molecule == 'taxol' else 'cc-pvtz'
+    label = 'taxol C47H51NO14' if args.molecule == 'taxol' else '(H2O)_%d' % args.nwater
+    mol = gto.M(atom=clusters.taxol() if args.molecule == 'taxol' else clusters.water_cluster(args.nwater), basis=args.basis)
+    nao, nocc = mol.nao, mol.nelectron // 2
+    ndev_visible = lib.load_library().PAMD_device_count()
+    if ndev_visible < 1:
+        raise SystemExit('bench.py --single-process: no HIP device')
+    devices = [i % ndev_visible for i in range(args.gpus)]
+    if ndev_visible < args.gpus:
+        print('bench.py --single-process: %d parts on %d visible device(s): parts share devices (self-test layout)' % (args.gpus, ndev_visible),
+              file=sys.stderr)
+    t0 = time.perf_counter()
+    obj = NativeDF(mol, devices=devices).build()
+    build_s = time.perf_counter() - t0
+    naux = obj.get_naoaux()
+    npair = nao * (nao + 1) // 2
+    s1e = ref.int1e(mol, 'ovlp') if nao <= 400 else None
+    rng = np.random.RandomState(1)
+    x = rng.random_sample((nao, nao))
+    if s1e is None:
+        c = np.linalg.qr(x)[0]                            # orthonormal columns: an idempotent-like density of the right rank
+    else:
+        w, v = np.linalg.eigh(x.T.dot(s1e).dot(x))
+        c = x.dot(v / np.sqrt(w)).dot(v.T)
+    mo_occ = np.zeros(nao)
+    mo_occ[:nocc] = 2
+    dm = lib.tag_array((c[:, :nocc] * 2).dot(c[:, :nocc].T), mo_coeff=c, mo_occ=mo_occ, dm_from_orbitals=True)
+    obj.get_jk(dm, hermi=1)                               # set-up (schedule timing inside the handle), then warm-up
+    for _ in range(args.warmup):
+        obj.get_jk(dm, hermi=1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vj, vk = obj.get_jk(dm, hermi=1)
+    dt = time.perf_counter() - t0
+    ms = dt / args.steps * 1e3
+    lay = obj.layout()
+    nt = -(-nao // 128)
+    step_exec = 2.0 * naux * nao * nao * nocc * (1.0 + (nt * (nt + 1) / 2) / (float(nt) * nt))
+    out = {'metric': 'ms per SCF iter (DF J/K build)', 'value': round(ms, 3), 'unit': 'ms', 'n_gpus': len(set(devices)),
+           'parts': args.gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': False,
+           'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'launch': 'single process: PAMD_df_create_multi, one host thread per part, peer gather + fixed-order sum on device %d' % devices[0],
+           'value_includes': 'host -> device copies of D and the orbitals and device -> host copies of J and K (numpy in / out)',
+           'config': {'workload': '%s %s DF J/K build, nao=%d naux=%d nocc=%d, B=%.1f GB over %d part(s)' % (
+                          label, args.basis, nao, naux, nocc, 8e-9 * naux * npair, args.gpus),
+                      'parallelism': 'aux-index shards x%d in one process (C handle)' % args.gpus, 'devices': devices,
+                      'naux_per_rank': lay['part_rows'], 'layout': lay},
+           'roofline': None,
+           'roofline_step': {'executed_TFLOP': round(step_exec / 1e12, 3), 'achieved_TFLOPs': round(step_exec / (ms * 1e-3) / 1e12, 2),
+                             'peak_TFLOPs': FP64_MFMA_PEAK_TFLOPS * len(set(devices)),
+                             'frac': round(step_exec / (ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * len(set(devices))), 4)},
+           'cpu_baseline': None, 'build_s': round(build_s, 2),
+           'checksum': {'fp_vj': lib.fp(vj), 'fp_vk': lib.fp(vk)}}
+    print(json.dumps(out))
+    obj.reset()
 
 
 class _Single:

@@ -417,9 +417,19 @@ class SCF:
         self.scf_summary['nuc'] = nuc
         return self.energy_elec(dm, h1e, vhf)[0] + nuc
 
-    def density_fit(self, auxbasis=None, with_df=None, only_dfj=False):
-        """pyscf/df/df_jk.py:31-105: attach a DF object; J/K are then routed to it."""
+    def density_fit(self, auxbasis=None, with_df=None, only_dfj=False, devices=None):
+        """pyscf/df/df_jk.py:31-105: attach a DF object; J/K are then routed to it.
+        devices (r04): a list of HIP device indices -> the aux index is sharded over them inside THIS process by the C handle
+        (pyscf_amd.df.native.NativeDF(devices=...), PAMD_df_create_multi); the environment variable PAMD_DEVICES=0,1,...
+        does the same for an unmodified script.  Without either: the torch-resident DF object (one device per process;
+        several ranks under torch.distributed shard the aux index between them)."""
+        import os
         from .. import df
+        if with_df is None and devices is None and os.environ.get('PAMD_DEVICES'):
+            devices = [int(d) for d in os.environ['PAMD_DEVICES'].split(',') if d.strip() != '']
+        if with_df is None and devices is not None:
+            from ..df.native import NativeDF
+            with_df = NativeDF(self.mol, auxbasis, devices=list(devices))
         if with_df is None:
             with_df = df.DF(self.mol, auxbasis)
         self.with_df = with_df

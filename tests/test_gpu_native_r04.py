@@ -43,6 +43,29 @@ def test_xc_handle_grids_nr_rks_nr_uks_and_df_rks_golden_without_torch():
     _run('_native_xc_worker.py', 'NATIVE_XC_OK', 1200)
 
 
+@pytest.mark.gpu
+def test_stock_script_with_a_device_list_reaches_the_reference_golden():
+    """`mf = scf.RHF(mol).density_fit(devices=[...]); mf.kernel()` - the documented single-process N > 1 recipe - and the
+    PAMD_DEVICES environment form for an unmodified script: E = -76.025936299702536 (pyscf/df/test/test_df_jk.py:57-59)."""
+    from pyscf_amd import gto, scf
+    from pyscf_amd.df.native import NativeDF
+    mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis='cc-pvdz')
+    mf = scf.RHF(mol).density_fit(auxbasis='weigend', devices=[0, 0, 0])
+    assert isinstance(mf.with_df, NativeDF) and mf.with_df.devices == [0, 0, 0]
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    assert mf.converged and abs(e - -76.025936299702536) < 1e-8, e
+    assert mf.with_df.layout()['parts'] == 3
+    os.environ['PAMD_DEVICES'] = '0,0'
+    try:
+        m2 = scf.RHF(mol).density_fit(auxbasis='weigend')
+    finally:
+        del os.environ['PAMD_DEVICES']
+    assert isinstance(m2.with_df, NativeDF) and m2.with_df.devices == [0, 0]
+    m2.conv_tol = 1e-10
+    assert abs(m2.kernel() - -76.025936299702536) < 1e-8
+
+
 def test_library_exports_the_r04_handle_api_without_torch():
     code = ("import sys; sys.path.insert(0, %r); from pyscf_amd.df import native; lib = native.load(); "
             "[getattr(lib, n) for n in ('PAMD_df_create_ex', 'PAMD_df_create_multi', 'PAMD_df_layout', 'PAMD_grid_weights_host', 'PAMD_xc_create', 'PAMD_xc_nr_rks', 'PAMD_xc_nr_uks', 'PAMD_xc_plan_info', 'PAMD_xc_destroy')]; from pyscf_amd.dft import native as xn; "
