@@ -67,8 +67,9 @@ def _pack_tril_dev(m):
 
 
 def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale=1.0):
-    """Z_T[pq][Q] (nao_pair, naux) and Y[P][Q] (naux, naux) of the module docstring, on the device; the Coulomb part
-    scaled by jscale (0 for the exchange-only terms of range-separated hybrids).
+    """W[L][pq] (local aux rows x nao_pair), the local rows of M (cderi = M (Q|pq)) and Y[P][Q] (naux, naux) of the module
+    docstring, on the device - Z_T[pq][Q] = sum_L W[L][pq] M[L][Q] is formed slab by slab by the caller (z_slab); the Coulomb
+    part scaled by jscale (0 for the exchange-only terms of range-separated hybrids).
 
     occ_blocks: [(C (nao, nocc) with D_s = C C^T, weight)], e.g. RHF [(C_occ, 2)], UHF [(Ca, 1), (Cb, 1)].
     mh: (rows of cderi, naux) host matrix with cderi = mh (Q|pq), i.e. L^-1 of the metric's Cholesky factor or, for a
@@ -131,13 +132,16 @@ def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale=1.0):
         ytil += 0.5 * kscale * wgt * (ys @ gather_rows(ys).T)
     linv = torch.from_numpy(np.ascontiguousarray(mh)).to(dev)    # all rows: [naux_all][nq]
     linv_loc = linv[l0:l1]
-    nq = linv.shape[1]
-    z_t = torch.empty((npair, nq), dtype=f64, device=dev)        # Z_T[pq][Q] = sum_L W[L][pq] Linv[L][Q] over the local rows
-    step = max(1, int((2 << 30) // (nq * 8)))
-    for p0 in range(0, npair, step):
-        torch.matmul(W[:, p0:p0 + step].T, linv_loc, out=z_t[p0:p0 + step])
     y_pq = linv_loc.T @ (ytil @ linv)
-    return z_t, y_pq
+    # r04: Z_T[pq][Q] = sum_L W[L][pq] Linv[L][Q] is NOT formed here any more (it has the size of the whole tensor per rank):
+    # _grad_2e forms it AO-row slab by slab from (W, linv_loc) - see there
+    return W, linv_loc, y_pq
+
+
+def z_slab(W, linv_loc, r0, r1, out=None):
+    """Z_T[pq][Q] for the packed rows pq in [r0, r1), summed over the LOCAL aux rows: (r1 - r0, nq)."""
+    import torch
+    return torch.matmul(W[:, r0:r1].T, linv_loc, out=out)
 
 
 def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, grad):
@@ -153,13 +157,6 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     eng = get_engine(mol, dfobj.auxmol, dev, dfobj.omega)
     naux = eng.aux.nao
     if sharded:
-        # every rank holds the partial Z_T of its aux rows at FULL size (nao_pair x naux): fine up to BASELINE config 4 on
-        # 288 GB, not at config-5 size - there the W tensor has to be re-sharded by pq slabs first
-        need = eng.ao.nao * (eng.ao.nao + 1) // 2 * naux * 8
-        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-        if need + (16 << 30) > free:
-            raise NotImplementedError('aux-sharded gradient: the partial two-particle density (%.0f GB per rank) does not fit; '
-                                      'the pq-slab re-sharding of W is not built' % (need * 1e-9))
         grad_total, grad = grad, torch.zeros_like(grad)
     j2c = eng.int2c2e().cpu().numpy()
     mh = _decompose_j2c((j2c + j2c.T) * .5, dfobj.lindep, getattr(dfobj, 'decompose_j2c', 'CD'), dev)[0]     # as in the tensor build
@@ -168,31 +165,74 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     if l1 - l0 != nrow_local:
         raise RuntimeError('the tensor has %d rows here, the metric decomposes into %d (this rank: %d)'
                            % (nrow_local, mh.shape[0], l1 - l0))
-    z_t, y_pq = two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale)
+    W, linv_loc, y_pq = two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale)
     y_pq = y_pq.contiguous()
-    _dbg('Z,Y built')
+    _dbg('W,Y built')
+    nq = linv_loc.shape[1]
     ao_atom = _dev(eng.ao.atom, dev)
     aux_atom = _dev(eng.aux.atom, dev)
     aux_xyz, aux_ao0 = _dev(eng.aux.xyz, dev), _dev(eng.aux.ao0, dev)
+    # r04 - the scalable form (the reference streams the same contraction block by block,
+    # pyscf/df/grad/rhf.py:117-199).  Z_T[pq][Q] is formed and consumed AO-row slab by slab: a slab of packed rows [r0, r1) is
+    # one GEMM over the LOCAL aux rows, W[:, r0:r1]^T M_loc -> (r1 - r0, nq); on an aux-sharded tensor the ranks' partial slabs
+    # are summed onto the slab's OWNER (slabs dealt round-robin; RCCL reduce, all-reduce on gloo) and only the owner runs the
+    # slab's derivative-integral kernels (pair sub-ranges by row shell, Z addressed with a row offset - the addressing of the
+    # tensor build).  Per rank: its rows of W (the size of its cderi shard), one slab buffer, 1 / world of the GEMM AND of the
+    # derivative-integral work - nothing of the size of the whole tensor, so config-5 shapes no longer refuse.
+    slab_bytes = int(getattr(dfobj, 'grad_slab_bytes', 4 << 30))
+    max_rows = max(1, slab_bytes // (nq * 8))
+    slabs, sh0 = [], 0
+    nsh = eng.ao.n
+    while sh0 < nsh:
+        sh1 = sh0 + 1
+        while sh1 < nsh and eng.slab_rows(sh0, sh1 + 1)[1] - eng.slab_rows(sh0, sh1 + 1)[0] <= max_rows:
+            sh1 += 1
+        slabs.append((sh0, sh1))
+        sh0 = sh1
+    bufrows = max(eng.slab_rows(a, b)[1] - eng.slab_rows(a, b)[0] for a, b in slabs)
+    zbuf = torch.empty((bufrows, nq), dtype=torch.float64, device=dev)
+    dfobj._grad_slabs = len(slabs)
     passes = [None] if dfobj.omega >= 0 else [0.0, -dfobj.omega]
+    world, rank = (dfobj.world_size, dfobj.rank) if sharded else (1, 0)
     try:
-        for ip, om in enumerate(passes):
-            if om is not None:
-                eng._omega_override = om
-            if ip == 1:
-                z_t.neg_()
-                y_pq.neg_()
-            # (1) sum Z dA: 3-centre derivative blocks
-            for pc in eng.pair_classes():
-                for ac in eng.aux_classes():
-                    eng.grad_launch(pc, ac, z_t, naux, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, auxbasis_response)
-                    _dbg('3c class %d %d | %d' % (pc.li, pc.lj, ac.l))
-            # (2) sum Y dM: 2-centre metric
-            if auxbasis_response:
+        for islab, (sa, sb) in enumerate(slabs):
+            r0, r1 = eng.slab_rows(sa, sb)
+            z = z_slab(W, linv_loc, r0, r1, out=zbuf[:r1 - r0])
+            owner = islab % world
+            if sharded:
+                import torch.distributed as dist
+                from ..lib import comm as _comm
+                if _comm.backend_name(dfobj.group) == 'nccl':
+                    dist.reduce(z, dst=dist.get_global_rank(dfobj.group, owner) if dfobj.group is not None else owner, group=dfobj.group)
+                else:
+                    dist.all_reduce(z, group=dfobj.group)
+                if owner != rank:
+                    continue
+            for ip, om in enumerate(passes):
+                if om is not None:
+                    eng._omega_override = om
+                if ip == 1:
+                    z.neg_()
+                # (1) sum Z dA: 3-centre derivative blocks of this slab
+                for pc in eng.pair_classes():
+                    i0, i1 = pc.subrange(sa, sb)
+                    if i1 <= i0:
+                        continue
+                    for ac in eng.aux_classes():
+                        eng.grad_launch(pc, ac, z, nq, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, auxbasis_response, i0=i0, i1=i1,
+                                        row_offset=r0)
+        _dbg('3c slabs done')
+        # (2) sum Y dM: 2-centre metric (every rank its partial Y)
+        if auxbasis_response:
+            for ip, om in enumerate(passes):
+                if om is not None:
+                    eng._omega_override = om
+                if ip == 1:
+                    y_pq.neg_()
                 for pc in eng.pair_classes_2c():
                     for ac in eng.aux_classes():
                         eng.grad_launch(pc, ac, y_pq, naux, 0, aux_xyz, aux_ao0, aux_atom, grad, True)
-        torch.cuda.synchronize()         # z_t / y_pq are released on return
+        torch.cuda.synchronize()         # W / zbuf / y_pq are released on return
     finally:
         if hasattr(eng, '_omega_override'):
             del eng._omega_override

@@ -276,12 +276,15 @@ class IntEngine:
         _lib_mod.check(self.lib.PAMD_int3c2e_class(ctypes.c_int(pc.li), ctypes.c_int(pc.lj),
                                                    ctypes.c_int(ac.l), ctypes.byref(a), st))
 
-    def grad_launch(self, pc, ac, Z, ldZ, tril, shell_xyz, shell_ao0, shell_atom, grad, aux_response):
-        """grad[rep][atom][3] += sum Z[row(pq)][Q] d(pq|Q)/dR for one (pair class, aux class): PAMD_int3c2e_grad_class."""
-        if pc.n == 0 or ac.n == 0:
+    def grad_launch(self, pc, ac, Z, ldZ, tril, shell_xyz, shell_ao0, shell_atom, grad, aux_response, i0=0, i1=None, row_offset=0):
+        """grad[rep][atom][3] += sum Z[row(pq) - row_offset][Q] d(pq|Q)/dR for the pairs [i0, i1) of one (pair class, aux class):
+        PAMD_int3c2e_grad_class.  A slab of Z (packed rows from row_offset on) goes with the pair sub-range of its row shells."""
+        if i1 is None:
+            i1 = pc.n
+        if i1 <= i0 or ac.n == 0:
             return
         g = _GradArgs()
-        self._fill_args(g.base, pc, 0, pc.n, ac, Z, ldZ, 0, tril, shell_xyz, shell_ao0)
+        self._fill_args(g.base, pc, i0, i1, ac, Z, ldZ, row_offset, tril, shell_xyz, shell_ao0)
         g.pp_ab = pc.pp_ab.data_ptr()
         g.shell_atom = shell_atom.data_ptr()
         g.aux_atom = ac.atom.data_ptr()

@@ -78,3 +78,14 @@ def all_reduce(tensors, group=None, world=None, op=None):
         e1.record()
         t.records.append((e0, e1, sum(x.numel() * x.element_size() for x in tensors)))
     return True
+
+
+def backend_name(group=None):
+    """'nccl' (RCCL), 'gloo', ... of the group's process group; '' when none is initialised."""
+    if not initialized():
+        return ''
+    import torch.distributed as dist
+    try:
+        return str(dist.get_backend(group))
+    except Exception:
+        return ''

@@ -91,7 +91,9 @@ def main():
             mf.grids.level = 1
         mf.conv_tol = 1e-11
         mf.kernel()
+        obj.grad_slab_bytes = 1 << 17       # r04: many Z slabs -> owners alternate between the ranks, every slab is reduced
         g_shard = mf.nuc_grad_method().kernel()
+        assert obj._grad_slabs > 4, obj._grad_slabs
         full = df.DF(mol)
         full._shard_override = (0, 1)
         full.build()

@@ -30,6 +30,27 @@ def test_df_rhf_gradient_goldens_and_fd():
     assert np.abs(g - gfd).max() < 2e-7
 
 
+def test_gradient_slabwise_two_particle_density():
+    """r04: Z_T[pq][Q] is formed and contracted AO-row slab by slab (grad/rhf.py::_grad_2e; the reference streams the same
+    contraction, pyscf/df/grad/rhf.py:117-199): many small slabs = one slab, to rounding; the golden fingerprint with slabs."""
+    from pyscf_amd import gto, scf
+    mol = gto.M(atom=H2O, basis='6-31g')
+    mf = scf.RHF(mol).density_fit(auxbasis='ccpvdz-jkfit').run(conv_tol=1e-12)
+    g1 = mf.nuc_grad_method().kernel()
+    assert mf.with_df._grad_slabs == 1
+    mf.with_df.grad_slab_bytes = 1 << 14
+    g2 = mf.nuc_grad_method().kernel()
+    assert mf.with_df._grad_slabs > 3
+    assert np.abs(g1 - g2).max() < 1e-12 and abs(ref.fp(g2) - 0.005516638190173352) < 2e-7
+    from pyscf_amd.data import clusters
+    mol = gto.M(atom=clusters.water_cluster(3), basis='cc-pvtz')          # f shells, inter-molecular pairs
+    mf = scf.RHF(mol).density_fit().run(conv_tol=1e-11)
+    g1 = mf.nuc_grad_method().kernel()
+    mf.with_df.grad_slab_bytes = 1 << 20
+    g2 = mf.nuc_grad_method().kernel()
+    assert mf.with_df._grad_slabs > 5 and np.abs(g1 - g2).max() < 1e-11, (mf.with_df._grad_slabs, np.abs(g1 - g2).max())
+
+
 def test_df_uhf_gradient_goldens_and_fd():
     """test_df_grad.py:95-110: triplet H2O 6-31G (default aux cc-pvdz-jkfit), UHF."""
     from pyscf_amd import gto, scf

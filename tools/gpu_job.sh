@@ -69,6 +69,10 @@ kpol)       # kbench over J-pass-2 schedules: gpu_job.sh kpol "<kbench args 1>" 
     done
   done
   cut -c1-330 $O/kbench.log ;;
+r04a)       # new tests of the round + bench modes
+  timeout 1200 python -m pytest -q -x --durations=6 tests/test_gpu_native_r04.py::test_stock_script_with_a_device_list_reaches_the_reference_golden tests/test_gpu_fullsize_cfg45.py::test_config4_taxol_df_rks_xc_and_energy_vs_oracle_golden > $O/pytest.log 2>&1; tail -12 $O/pytest.log
+  timeout 600 python bench.py --gpus 2 --single-process --steps 3 > $O/bench_single_process_2parts.json 2> $O/bench_sp.err; cut -c1-700 $O/bench_single_process_2parts.json; tail -2 $O/bench_sp.err
+  timeout 1200 python bench.py --pmc --steps 10 --warmup 2 > $O/bench_pmc.json 2> $O/bench_pmc.err; tail -c 1500 $O/bench_pmc.json; tail -3 $O/bench_pmc.err ;;
 run)        # arbitrary command line, logged: gpu_job.sh run <tag> <cmd...>
   T=$1; shift; timeout 1500 "$@" > $O/$T.log 2>&1; tail -30 $O/$T.log ;;
 *) echo "unknown job $JOB"; exit 2 ;;
