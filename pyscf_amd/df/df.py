@@ -57,6 +57,9 @@ class DF:
         self.overlap_split = True           # two-pass J: pass 1 / pass 2 behind the first / second SYRK block
         self.factorize_hermitian_dm = True  # hermi=1 DMs without orbitals: eigen-factorise, use the MO kernels
         self.kernel_timer = None   # df_jk.KernelTimer() to collect per-kernel HIP-event timings
+        self.outcore = True        # a tensor that does not fit the device goes to the C handle (HBM + streamed host rows) in build()
+        self.outcore_device_bytes = 0   # > 0: cap on the device memory the tensor may take (tests, memory-constrained callers)
+        self._native = None
         self._ws = {}
 
     # -- distributed geometry ----------------------------------------------------------
@@ -243,6 +246,9 @@ class DF:
         self._cderi_diag = None
         self._diag_row0 = 0
         self._naux = None
+        if getattr(self, '_native', None) is not None:
+            self._native.reset()
+        self._native = None
         self._ws = {}
         self._eng = None
         self._rsh_df = {}          # pyscf/df/df.py:210: the range-separated children hold the old mol / auxmol
@@ -260,6 +266,8 @@ class DF:
 
     def build(self):
         import torch
+        if getattr(self, '_native', None) is not None:
+            return self
         dev = self._device()
         if isinstance(self._cderi, str):
             from ..lib import hdf5
@@ -312,9 +320,28 @@ class DF:
         from . import incore
         self._naux = self.auxmol.nao_nr()
         l0, l1 = self.shard_range(self._naux, self.rank, self.world_size)
-        self._cderi_dev = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1,
-                                                  lindep=self.lindep, omega=self.omega,
-                                                  decompose_j2c=self.decompose_j2c)
+        try:
+            if self.outcore_device_bytes and (l1 - l0) * (self.mol.nao * (self.mol.nao + 1) // 2) * 8 > self.outcore_device_bytes:
+                raise MemoryError('tensor shard above DF.outcore_device_bytes')
+            self._cderi_dev = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1,
+                                                      lindep=self.lindep, omega=self.omega,
+                                                      decompose_j2c=self.decompose_j2c)
+        except MemoryError:
+            # r04 - the out-of-core twin (pyscf/df/outcore.py:109-232, pyscf/df/df.py:167): the tensor does not fit this device.
+            # A single-process object hands the job to the C handle, which keeps what fits in HBM, the rest in page-locked host
+            # memory, and streams it under the kernels in every build (PCIe-bound for those rows: slower, not wrong).  J/K, loop
+            # and range_coulomb go through it; the HBM-resident SCF loop and the gradients need the in-core tensor.
+            if self.world_size > 1 or getattr(self, '_shard_override', None) is not None or not getattr(self, 'outcore', True) \
+                    or getattr(self, 'decompose_j2c', 'CD') != 'CD':
+                raise
+            from .native import NativeDF
+            import torch as _torch
+            idx = dev.index if dev.index is not None else _torch.cuda.current_device()
+            _torch.cuda.empty_cache()                       # give the handle's hipMalloc the memory torch had cached
+            self._native = NativeDF(self.mol, self.auxbasis, auxmol=self.auxmol, device=idx, lindep=self.lindep, omega=self.omega,
+                                    max_device_bytes=int(getattr(self, 'outcore_device_bytes', 0))).build()
+            self._naux = self._native.get_naoaux()
+            return self
         if isinstance(self._cderi_to_save, str):
             self.save(self._cderi_to_save)
         return self
@@ -324,6 +351,11 @@ class DF:
         if self._naux is None:
             self.build()
         return self._naux
+
+    def out_of_core(self):
+        """None, or the layout of the C handle that holds the tensor because it did not fit the device (NativeDF.layout())."""
+        nat = getattr(self, '_native', None)
+        return None if nat is None else nat.layout()
 
     def loop(self, blksize=None, local=False):
         """Yield host row blocks of the FULL tensor, rows 0..naux in order (pyscf/df/df.py:214-242) - what a stock consumer
@@ -335,6 +367,10 @@ class DF:
             self.build()
         if blksize is None:
             blksize = self.blockdim
+        if getattr(self, '_native', None) is not None:
+            for blk in self._native.loop(blksize):
+                yield blk
+            return
         n = self._cderi_dev.shape[0]
         from ..lib import comm as _comm
         sharded = _comm.active(self.world_size) and getattr(self, '_shard_override', None) is None
@@ -491,7 +527,9 @@ class DF:
 
     def get_jk(self, dm, hermi=1, with_j=True, with_k=True, direct_scf_tol=1e-13, omega=None):
         if omega is not None and omega != 0:
-            return df_jk.get_jk(self.range_coulomb(omega), dm, hermi, with_j, with_k, direct_scf_tol)
+            return self.range_coulomb(omega).get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
+        if getattr(self, '_native', None) is not None:          # out of core: the C handle holds the tensor (build())
+            return self._native.get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
         return df_jk.get_jk(self, dm, hermi, with_j, with_k, direct_scf_tol)
 
 

@@ -630,8 +630,11 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
             not getattr(dfobj, 'incore_anyway', False)):
         # 3-index tensor not initialised: integral-direct J (df_jk.py:282-285)
         return get_j(dfobj, dm, hermi, direct_scf_tol), None
-    if dfobj._cderi_dev is None:
+    if dfobj._cderi_dev is None and getattr(dfobj, '_native', None) is None:
         dfobj.build()
+    if getattr(dfobj, '_native', None) is not None:
+        # the tensor did not fit the device: the C handle holds it (HBM + page-locked host rows, DF.build) and answers
+        return dfobj._native.get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
     dms = np.asarray(dm)
     if np.iscomplexobj(dms):
         # real/imag split, as _DFHF.get_jk does for complex DMs (df_jk.py:160-171)

@@ -149,10 +149,13 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     tensor; returns the integral engine.  A long-range tensor (dfobj.omega > 0) differentiates the erf-attenuated
     integrals; a short-range one (omega < 0) the Coulomb integrals with (Z, Y) and the long-range ones with (-Z, -Y)."""
     import torch
-    if dfobj._cderi_dev is None:
+    if dfobj._cderi_dev is None and getattr(dfobj, '_native', None) is None:
         dfobj.build()
+    if getattr(dfobj, '_native', None) is not None:
+        raise NotImplementedError('analytic gradients need the in-core tensor; this DF object holds it out of core (C handle): '
+                                  'shard the auxiliary index over more ranks')
     dev = dfobj._cderi_dev.device
-    dfobj.drop_square_image()            # W and Z below each take the size of cderi
+    dfobj.drop_square_image()            # W below takes the size of cderi
     sharded = dfobj.world_size > 1 and getattr(dfobj, '_shard_override', None) is None
     eng = get_engine(mol, dfobj.auxmol, dev, dfobj.omega)
     naux = eng.aux.nao
@@ -251,8 +254,11 @@ def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_respo
     exact exchange of range-separated hybrids, pyscf/df/grad/rks.py:84-110)."""
     import torch
     so = _lib_mod.load_library()
-    if dfobj._cderi_dev is None:
+    if dfobj._cderi_dev is None and getattr(dfobj, '_native', None) is None:
         dfobj.build()
+    if getattr(dfobj, '_native', None) is not None:
+        raise NotImplementedError('analytic gradients need the in-core tensor; this DF object holds it out of core (C handle): '
+                                  'shard the auxiliary index over more ranks')
     dev = dfobj._cderi_dev.device
     natm = mol.natm
     grad = torch.zeros((NREP, natm, 3), dtype=torch.float64, device=dev)

@@ -71,6 +71,12 @@ def eligible(mf, callback=None):
         from ..dft import libxc
         if libxc.xc_type(mf.xc) not in ('LDA', 'GGA', 'HF'):
             return False
+    # the loop works on the in-core device tensor: build it now; an out-of-core tensor (DF.build handed it to the C handle) keeps
+    # the host loop
+    if mf.with_df._cderi_dev is None and getattr(mf.with_df, '_native', None) is None:
+        mf.with_df.build()
+    if getattr(mf.with_df, '_native', None) is not None:
+        return False
     return True
 
 

@@ -72,3 +72,47 @@ def test_library_exports_the_r04_handle_api_without_torch():
             "assert 'torch' not in sys.modules; print('ok')" % ROOT)
     p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and 'ok' in p.stdout, p.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_torch_resident_df_falls_back_to_the_streaming_handle_when_the_tensor_does_not_fit():
+    """The out-of-core twin behind the production object (pyscf/df/outcore.py:109-232, df/df.py:167): a DF whose tensor is above
+    its device-memory cap no longer raises MemoryError - build() hands it to the C handle (rows in HBM + page-locked host rows
+    streamed per build); J/K and the SCF energy are those of the in-core object, the device SCF loop steps aside."""
+    import numpy as np
+    from oracle import ref
+    from pyscf_amd import gto, scf, df, lib
+    from pyscf_amd.data import clusters
+    mol = gto.M(atom=clusters.water_cluster(2), basis='cc-pvtz')
+    nao = mol.nao
+    npair = nao * (nao + 1) // 2
+    obj = df.DF(mol)
+    obj.outcore_device_bytes = 40 * npair * 8 * 4            # ~40 resident rows of 278
+    obj.build()
+    lay = obj.out_of_core()
+    assert lay is not None and lay['rows_host'] > 0 and lay['rows_resident'] + lay['rows_host'] == obj.get_naoaux() == 278, lay
+    cd = ref.cholesky_eri(mol, df.make_auxmol(mol))
+    rng = np.random.RandomState(2)
+    dm = rng.rand(2, nao, nao)
+    vj0, vk0 = ref.get_jk(cd, dm, 0)
+    vj, vk = obj.get_jk(dm, hermi=0)
+    assert np.abs(vj - vj0).max() < 1e-10 and np.abs(vk - vk0).max() < 1e-10
+    assert np.abs(np.vstack(list(obj.loop(64))) - cd).max() < 1e-10
+    mf = scf.RHF(mol).density_fit(with_df=obj)
+    mf.device_scf_min_nao = 0                                # would take the HBM-resident loop; must fall back to the host loop
+    mf.conv_tol = 1e-10
+    e = mf.kernel()
+    m0 = scf.RHF(mol).density_fit()
+    m0.conv_tol = 1e-10
+    e0 = m0.kernel()
+    assert mf.converged and abs(e - e0) < 1e-9, (e, e0)
+    with pytest.raises(NotImplementedError):
+        mf.nuc_grad_method().kernel()
+    obj.reset()
+    assert obj.out_of_core() is None
+    # switched off: the old behaviour
+    obj2 = df.DF(mol)
+    obj2.outcore_device_bytes = 40 * npair * 8 * 4
+    obj2.outcore = False
+    with pytest.raises(MemoryError):
+        obj2.build()
