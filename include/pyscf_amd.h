@@ -354,6 +354,9 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
 int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                          double lindep, const int *devices, int ndev, PAMD_df **out);
 int PAMD_df_layout(const PAMD_df *h, long *layout, int *part_rows);
+/* the metric factorisation alone (df/incore.py:150-158, :263-270; decompose_j2c = 'ED' with force_ed): host j2c[naux][naux] ->
+ * host m[nrow][naux] (caller provides naux x naux doubles), cderi = m (Q|pq); *tri = 1: rows of L^-1 */
+int PAMD_metric_decompose(const double *j2c, int naux, double lindep, int force_ed, int device, double *m, int *nrow, int *tri);
 int PAMD_df_create(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                    double lindep, int device, PAMD_df **out);
 void PAMD_df_destroy(PAMD_df *h);

@@ -435,18 +435,19 @@ int chol_blocked(PAMD_df *h, double *d_a, int n, int *info)
 
 // M with cderi = M (Q|pq): rows of L^-1 (Cholesky) or (V / sqrt(w))^T over the eigenvalues > lindep (df/incore.py:153-158,
 // 263-270).  Returns M^T as mt[naux][lda] on the host (lda = round_up(nrow, 16), zero padded) and the triangular flag.
-int decompose_metric(PAMD_df *h, double *d_j2c, int naux, double lindep, std::vector<double> *mt, int *nrow, int *lda, int *tri)
+int decompose_metric(PAMD_df *h, double *d_j2c, int naux, double lindep, std::vector<double> *mt, int *nrow, int *lda, int *tri,
+                     bool force_ed = false)
 {
     int rc;
     const size_t n2 = (size_t)naux * naux;
     double *d_a = nullptr;
     if ((rc = h->pool.alloc((void **)&d_a, n2 * 8))) return rc;
     PAMD_CHECK_HIP(hipMemcpyAsync(d_a, d_j2c, n2 * 8, hipMemcpyDeviceToDevice, h->st));
-    int info = 0;
-    if ((rc = chol_blocked(h, d_a, naux, &info))) return rc;
+    int info = 1;
+    if (!force_ed && (rc = chol_blocked(h, d_a, naux, &info))) return rc;
     if (info == 0) {
         // W = (L^-1)^T (upper triangular, row-major) by block forward substitution (the scheme of pyscf_amd/df/incore.py:
-        // _tri_inverse_dev): W[i, i] = Dinv_i^T on the host, W[:i0, i] = -(L[i, :i0] Linv[:i0, :i0])^T Dinv_i^T as two GEMMs of
+        // _decompose_j2c of r02): W[i, i] = Dinv_i^T on the host, W[:i0, i] = -(L[i, :i0] Linv[:i0, :i0])^T Dinv_i^T as two GEMMs of
         // this library per block row:  T = L[i,:i0] W[:i0,:i0]^T (NT),  W[:i0, i] += T^T (-Dinv_i^T) (TN)
         const int blk = 256;
         double *d_w = nullptr, *d_t = nullptr, *d_dt = nullptr;
@@ -1311,6 +1312,30 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
     }
     guard.p = nullptr;
     *out = mh;
+    return 0;
+}
+
+// The metric factorisation of DF.build as a call of its own (df/incore.py:150-158, :263-270): j2c[naux][naux] (host, symmetric)
+// -> m[nrow][naux] (host; caller provides naux x naux doubles) with cderi = m (Q|pq): rows of L^-1 (*tri = 1) or, when the Cholesky
+// factorisation meets a non-positive pivot or force_ed is set (decompose_j2c = 'ED', df/grad/rhf.py:423-443), (V / sqrt(w))^T over
+// the eigenvalues > lindep (*tri = 0).  The same blocked Cholesky / block forward substitution on this library's FP64-MFMA GEMMs
+// that PAMD_df_create uses - pyscf_amd/df/incore.py calls it too, so there is ONE factorisation code path (r04).
+int PAMD_metric_decompose(const double *j2c, int naux, double lindep, int force_ed, int device, double *m, int *nrow, int *tri)
+{
+    PAMD_REQUIRE(j2c && m && nrow && tri && naux > 0, "PAMD_metric_decompose: bad arguments");
+    PAMD_CHECK_HIP(hipSetDevice(device));
+    PAMD_df h;
+    h.device = device;
+    PAMD_CHECK_HIP(hipStreamCreate(&h.st));
+    int rc;
+    double *d_j = nullptr;
+    if ((rc = h.pool.alloc((void **)&d_j, (size_t)naux * naux * 8))) return rc;
+    PAMD_CHECK_HIP(hipMemcpy(d_j, j2c, (size_t)naux * naux * 8, hipMemcpyHostToDevice));
+    std::vector<double> mt;
+    int lda = 0;
+    if ((rc = decompose_metric(&h, d_j, naux, lindep, &mt, nrow, &lda, tri, force_ed != 0))) return rc;
+    for (int r = 0; r < *nrow; r++)
+        for (int q = 0; q < naux; q++) m[(size_t)r * naux + q] = mt[(size_t)q * lda + r];
     return 0;
 }
 

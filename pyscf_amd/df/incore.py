@@ -24,47 +24,39 @@ DEVICE_FACTOR_MIN = 1024     # metric size from which the factorisation runs on 
 def _decompose_j2c(j2c, lindep, decompose='CD', device=None):
     """-> (M with cderi = M (Q|pq), triangular flag).  M = L^-1 or, when the Cholesky factorisation fails or 'ED' is
     asked for (the decompose_j2c switch of pyscf/df/grad/rhf.py:423-443), (V / sqrt(w))^T over the eigenvalues > lindep.
-    From naux = 1024 the Cholesky factor and its triangular inverse are computed on this rank's own GPU (hipSOLVER
-    potrf + trsm through torch): with one process per GPU the eight ranks of a node no longer run eight O(naux^3) LAPACK
+    From naux = 1024 the Cholesky factor and its triangular inverse are computed on this rank's own GPU (r04: by the library's
+    own blocked factorisation, PAMD_metric_decompose - the code PAMD_df_create runs; r02-r03 went through torch's potrf): with one
+    process per GPU the eight ranks of a node no longer run eight O(naux^3) LAPACK
     factorisations on the shared host cores at the same time (14 848^3 each at BASELINE config 5), and nothing has to be
     broadcast.  The reference does the same factorisation with scipy on the host (pyscf/df/incore.py:154)."""
+    if device is not None and len(j2c) >= DEVICE_FACTOR_MIN:
+        # r04: ONE factorisation code path - the library's own blocked Cholesky + block forward substitution on its FP64-MFMA
+        # GEMMs (csrc/df_handle.hip: what PAMD_df_create runs), eigen-decomposition inside when a pivot fails or 'ED' is asked for
+        import torch
+        naux = len(j2c)
+        idx = torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()
+        jh = np.ascontiguousarray(j2c, dtype=np.float64)
+        m = np.empty((naux, naux))
+        nrow, tri = ctypes.c_int(), ctypes.c_int()
+        lib = _lib_mod.load_library()
+        _lib_mod.check(lib.PAMD_metric_decompose(jh.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(naux), ctypes.c_double(lindep),
+                                                 ctypes.c_int(int(decompose.upper() != 'CD')), ctypes.c_int(idx),
+                                                 m.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nrow), ctypes.byref(tri)))
+        torch.cuda.set_device(idx)
+        return np.ascontiguousarray(m[:nrow.value]), bool(tri.value)
     if decompose.upper() == 'CD':
-        if device is not None and len(j2c) >= DEVICE_FACTOR_MIN:
-            import torch
-            jd = torch.from_numpy(np.ascontiguousarray(j2c)).to(device)
-            low, info = torch.linalg.cholesky_ex(jd)
-            if int(info) == 0:
-                return _tri_inverse_dev(low).cpu().numpy(), True
-        else:
-            try:
-                low = scipy.linalg.cholesky(j2c, lower=True)
-                linv = scipy.linalg.solve_triangular(low, np.eye(len(low)), lower=True, check_finite=False)
-                return linv, True
-            except scipy.linalg.LinAlgError:
-                pass
+        try:
+            low = scipy.linalg.cholesky(j2c, lower=True)
+            linv = scipy.linalg.solve_triangular(low, np.eye(len(low)), lower=True, check_finite=False)
+            return linv, True
+        except scipy.linalg.LinAlgError:
+            pass
     w, v = scipy.linalg.eigh(j2c)
     mask = w > lindep
     v = v[:, mask] / np.sqrt(w[mask])
     return v.T, False
-
-
-def _tri_inverse_dev(low, blk=512):
-    """Inverse of a lower-triangular device matrix by block forward substitution: the diagonal blocks are inverted on the
-    host (blk^3, negligible), every off-diagonal block row is one device GEMM chain
-    Linv[i, :i] = -Linv[i, i] (L[i, :i] Linv[:i, :i]).  (hipBLAS trsm cannot allocate its workspace for an identity
-    right-hand side of this size on the ROCm 7.2 image.)"""
-    import torch
-    n = low.shape[0]
-    out = torch.zeros_like(low)
-    for i0 in range(0, n, blk):
-        i1 = min(i0 + blk, n)
-        dinv = scipy.linalg.solve_triangular(low[i0:i1, i0:i1].cpu().numpy(), np.eye(i1 - i0), lower=True,
-                                             check_finite=False)
-        dinv = torch.from_numpy(dinv).to(low.device)
-        out[i0:i1, i0:i1] = dinv
-        if i0:
-            out[i0:i1, :i0] = -dinv @ (low[i0:i1, :i0] @ out[:i0, :i0])
-    return out
 
 
 def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_THR,

@@ -254,3 +254,48 @@ def test_nr_e2_symm_packed_dma_kernel(nao, naux, nocc):
     assert np.abs(got - want).max() < 1e-11 * np.abs(want).max()
     assert np.abs(got - outs[1]).max() < 1e-11 * np.abs(want).max()
     assert np.abs(rho.cpu().numpy() - rho_want).max() < 1e-10 * np.abs(rho_want).max()
+
+
+def test_metric_decompose_cholesky_and_eigen_paths():
+    """PAMD_metric_decompose (r04: the ONE factorisation code path of DF.build, Python object and C handle alike;
+    pyscf/df/incore.py:150-158, :263-270): M j2c M^T = 1 for the Cholesky form (M lower triangular), the forced
+    eigen-decomposition ('ED', df/grad/rhf.py:423-443) and a linearly dependent metric (rank-deficient: fewer rows)."""
+    from pyscf_amd import lib
+    from pyscf_amd.df import incore
+    so = lib.load_library()
+    rng = np.random.default_rng(3)
+    n = 1100                                                    # above DEVICE_FACTOR_MIN and HOST_EIG_MAX: blocked Cholesky, rocSOLVER syevd
+    a = rng.standard_normal((n, n + 50))
+    j2c = a.dot(a.T) / n + 0.05 * np.eye(n)
+    for force_ed in (0, 1):
+        m = np.empty((n, n))
+        nrow, tri = C.c_int(), C.c_int()
+        lib.check(so.PAMD_metric_decompose(j2c.ctypes.data_as(C.c_void_p), n, C.c_double(1e-7), force_ed, 0, m.ctypes.data_as(C.c_void_p),
+                                           C.byref(nrow), C.byref(tri)))
+        assert nrow.value == n and tri.value == (0 if force_ed else 1)
+        assert np.abs(m.dot(j2c).dot(m.T) - np.eye(n)).max() < 1e-9
+        if not force_ed:
+            assert np.abs(np.triu(m, 1)).max() == 0.0
+            low = np.linalg.cholesky(j2c)
+            assert np.abs(m.dot(low) - np.eye(n)).max() < 1e-10
+    # the Python layer goes through the same entry point from naux = 1024
+    import torch
+    mm, tri = incore._decompose_j2c(j2c, 1e-7, 'CD', torch.device('cuda', 0))
+    assert tri and np.abs(mm - m0_cd(j2c)).max() < 1e-9
+    # linearly dependent: the last 100 functions are copies of the first 100
+    j2 = j2c.copy()
+    j2[-100:] = j2[:100]
+    j2[:, -100:] = j2[:, :100]
+    m = np.empty((n, n))
+    nrow, tri = C.c_int(), C.c_int()
+    lib.check(so.PAMD_metric_decompose(j2.ctypes.data_as(C.c_void_p), n, C.c_double(1e-7), 0, 0, m.ctypes.data_as(C.c_void_p), C.byref(nrow),
+                                       C.byref(tri)))
+    assert nrow.value == n - 100 and tri.value == 0
+    mk = m[:nrow.value]
+    assert np.abs(mk.dot(j2).dot(mk.T) - np.eye(nrow.value)).max() < 1e-8
+
+
+def m0_cd(j2c):
+    import scipy.linalg
+    low = scipy.linalg.cholesky(j2c, lower=True)
+    return scipy.linalg.solve_triangular(low, np.eye(len(low)), lower=True)
