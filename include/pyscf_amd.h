@@ -390,6 +390,10 @@ int PAMD_grid_weights_host(const double *coords, long ngrids, const double *atm_
                            int ia, const double *vol, int device, double *weights);
 int PAMD_xc_create(const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, const double *coords,
                    const double *weights, long ngrids, int device, PAMD_xc **out);
+/* the same over a device list in one process: grid tiles (512 consecutive points) dealt round-robin over the parts, one host
+ * thread per part, nelec / exc summed on the host and vmat on devices[0] (peer copies or host bounce) */
+int PAMD_xc_create_multi(const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, const double *coords,
+                         const double *weights, long ngrids, const int *devices, int ndev, PAMD_xc **out);
 void PAMD_xc_destroy(PAMD_xc *h);
 int PAMD_xc_nao(const PAMD_xc *h, int *nao);
 int PAMD_xc_plan_info(PAMD_xc *h, int xctype, double *info);

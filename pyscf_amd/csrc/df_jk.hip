@@ -928,6 +928,9 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
 }
 
 // 128 x 128 tile of C[split] += A^T B (all tiles, or the lower-triangular ones of the SYRK), v2 DMA scheme
+// BURST: the DMA rows of k-tile t + 1 all behind the FIRST MFMA group of tile t (3/4 of a tile more lead for the late rows; A/B
+// switch "syrkburst": does the SYRK beside the co-running J pass wait on DMA latency?)
+template <bool BURST>
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
     double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, long kchunk, int prio, int xmap,
@@ -998,7 +1001,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
             for (int a = 0; a < 4; a++) af[a] = cur[offa + kk * LDN + a * 16];
 #pragma unroll
             for (int b = 0; b < 4; b++) bf[b] = cur[offb + kk * LDN + b * 16];
-            stage_row(kn, nxt, kk >> 2);
+            if (BURST) {
+                if (kk == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) stage_row(kn, nxt, j);
+                }
+            } else {
+                stage_row(kn, nxt, kk >> 2);
+            }
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -1235,6 +1245,7 @@ static int g_pk_diag = 1;     // e2_pk reads the diagonal 128 x 128 blocks from 
 static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
 static int g_syrk_probe = 0;  // benchmarking probe only: the re-tiled SYRK without its second panel DMA (results meaningless)
 static int g_syrk_slots = 1;  // SYRK on the re-tiled triangle (syrk_slots_kernel) when the matrix has an odd number of 64-column blocks
+static int g_syrk_burst = 0;  // plain-grid SYRK: next tile's DMA rows in one burst ("syrkburst")
 static int g_syrk_xmap = 0;   // plain-grid SYRK: one k split per group of XCDs ("syrkxmap"; A/B in profiles/r04)
 static int g_syrk_frac = 1;   // balanced SYRK: full pieces + one short remainder piece per tile (dgemm_tn_impl)
 static int g_num_cu = 256;    // MI355X
@@ -1252,6 +1263,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "syrkslots") == 0) { g_syrk_slots = value; return 0; }
     if (strcmp(key, "syrkprobe") == 0) { g_syrk_probe = value; return 0; }
     if (strcmp(key, "syrkxmap") == 0) { g_syrk_xmap = value; return 0; }
+    if (strcmp(key, "syrkburst") == 0) { g_syrk_burst = value; return 0; }
     if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "pkdiag") == 0) { g_pk_diag = value; return 0; }
@@ -1717,9 +1729,11 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
         if (xmap) {
             const int xp = 8 / nsplit;
             dim3 g1(8 * ceil_div(ntiles, xp));
-            gemm_tn_glds2_kernel<<<g1, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 1, ntiles, nsplit);
+            if (g_syrk_burst) gemm_tn_glds2_kernel<true><<<g1, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 1, ntiles, nsplit);
+            else gemm_tn_glds2_kernel<false><<<g1, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 1, ntiles, nsplit);
         } else {
-            gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 0, ntiles, nsplit);
+            if (g_syrk_burst) gemm_tn_glds2_kernel<true><<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 0, ntiles, nsplit);
+            else gemm_tn_glds2_kernel<false><<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 0, ntiles, nsplit);
         }
     }
     else if (glds)

@@ -22,7 +22,9 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "common.h"
 #include "host_tables.h"
@@ -104,6 +106,8 @@ struct PAMD_xc {
     double *d_xyz = nullptr, *d_exps = nullptr, *d_coefs = nullptr, *d_c2s = nullptr;
     double *d_coords = nullptr, *d_weights = nullptr;            // weights zero-padded to ntile * G
     XcPlan plan[2];                                              // LDA (1 component), GGA (4)
+    std::vector<PAMD_xc *> parts;                                // multi-device handle: grid tiles dealt round-robin (owned)
+    int peer_ok = 0;
     std::map<std::string, std::pair<double *, size_t>> ws;
     double *workspace(const std::string &name, size_t ndoubles, int *rc)
     {
@@ -118,7 +122,15 @@ struct PAMD_xc {
         ws[name] = {p, ndoubles};
         return p;
     }
-    ~PAMD_xc() { if (st) (void)hipStreamDestroy(st); }
+    ~PAMD_xc()
+    {
+        for (PAMD_xc *p : parts) {
+            (void)hipSetDevice(p->device);
+            delete p;
+        }
+        if (!parts.empty()) (void)hipSetDevice(device);
+        if (st) (void)hipStreamDestroy(st);
+    }
 };
 
 namespace {
@@ -264,6 +276,7 @@ int upload_orbitals(PAMD_xc *h, const char *tag, const double *orb, int nocc, co
 }
 
 // nelec / exc / vmat of one closed-shell density (spin = 0, ops[0]) or of a spin pair (spin = 1, ops[0], ops[1])
+// vmat == NULL: the matrices stay on the device (work space "V", [nset][nao][nao]) for the multi-device sum
 int xc_contract(PAMD_xc *h, const double *fac, int gga, int spin, OrbOp *ops, double *acc_h, double *vmat)
 {
     int rc;
@@ -326,8 +339,87 @@ int xc_contract(PAMD_xc *h, const double *fac, int gga, int spin, OrbOp *ops, do
     for (int s = 0; s < nset; s++)
         if ((rc = PAMD_mirror_tril(d_M + (size_t)s * n2, nao, nao, d_V + (size_t)s * n2, st))) return rc;
     PAMD_CHECK_HIP(hipMemcpyAsync(acc_h, d_acc, 4 * 8, hipMemcpyDeviceToHost, st));
-    PAMD_CHECK_HIP(hipMemcpyAsync(vmat, d_V, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
+    if (vmat) PAMD_CHECK_HIP(hipMemcpyAsync(vmat, d_V, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
     PAMD_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+__global__ void xc_sum_parts_kernel(const double *__restrict__ in, size_t stride, int nparts, double *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double a = 0;
+        for (int p = 0; p < nparts; p++) a += in[(size_t)p * stride + i];
+        out[i] = a;
+    }
+}
+
+std::mutex g_xc_dev_mutex[64];
+
+// one call on every part (one host thread per part), then nelec / exc summed on the host and the matrices on parts[0]'s device
+// (peer copies where the devices can reach each other, host bounce otherwise; fixed order)
+int xc_multi(PAMD_xc *m, const double *fac, int gga, int spin, const double *orbs, const int *nocc, const double *signs, double *acc_out,
+             double *vmat)
+{
+    const int np = (int)m->parts.size(), nset = spin ? 2 : 1, nao = m->nao;
+    const size_t n2 = (size_t)nao * nao, len = (size_t)nset * n2;
+    std::vector<int> rcs(np, 0);
+    std::vector<std::string> msgs(np);
+    std::vector<double> accs((size_t)np * 4, 0.0);
+    std::vector<std::thread> th;
+    for (int p = 0; p < np; p++)
+        th.emplace_back([&, p]() {
+            PAMD_xc *h = m->parts[p];
+            auto body = [&]() -> int {
+                PAMD_CHECK_HIP(hipSetDevice(h->device));
+                std::lock_guard<std::mutex> lock(g_xc_dev_mutex[h->device & 63]);     // parts that share a device take turns
+                OrbOp ops[2];
+                int rc;
+                if ((rc = upload_orbitals(h, "0", orbs, nocc[0], signs, &ops[0]))) return rc;
+                if (spin && (rc = upload_orbitals(h, "1", orbs + (size_t)nao * nocc[0], nocc[1], signs ? signs + nocc[0] : nullptr, &ops[1])))
+                    return rc;
+                return xc_contract(h, fac, gga, spin, ops, &accs[(size_t)p * 4], nullptr);
+            };
+            rcs[p] = body();
+            if (rcs[p]) msgs[p] = g_errmsg;
+        });
+    for (auto &t : th) t.join();
+    for (int p = 0; p < np; p++)
+        if (rcs[p]) {
+            snprintf(g_errmsg, sizeof(g_errmsg), "device %d (part %d): %s", m->parts[p]->device, p, msgs[p].c_str());
+            return rcs[p];
+        }
+    for (int k = 0; k < 4; k++) {
+        acc_out[k] = 0;
+        for (int p = 0; p < np; p++) acc_out[k] += accs[(size_t)p * 4 + k];
+    }
+    PAMD_xc *h0 = m->parts[0];
+    PAMD_CHECK_HIP(hipSetDevice(h0->device));
+    int rc;
+    double *gather = h0->workspace("gather", (size_t)np * len, &rc);
+    if (rc) return rc;
+    std::vector<double> bounce;
+    for (int p = 0; p < np; p++) {
+        PAMD_xc *hp = m->parts[p];
+        const double *src = hp->ws["V"].first;
+        double *dst = gather + (size_t)p * len;
+        if (hp->device == h0->device) {
+            PAMD_CHECK_HIP(hipMemcpyAsync(dst, src, len * 8, hipMemcpyDeviceToDevice, h0->st));
+        } else if (m->peer_ok) {
+            PAMD_CHECK_HIP(hipMemcpyPeerAsync(dst, h0->device, src, hp->device, len * 8, h0->st));
+        } else {
+            bounce.resize(len);
+            PAMD_CHECK_HIP(hipSetDevice(hp->device));
+            PAMD_CHECK_HIP(hipMemcpy(bounce.data(), src, len * 8, hipMemcpyDeviceToHost));
+            PAMD_CHECK_HIP(hipSetDevice(h0->device));
+            PAMD_CHECK_HIP(hipMemcpy(dst, bounce.data(), len * 8, hipMemcpyHostToDevice));
+        }
+    }
+    double *total = h0->workspace("total", len, &rc);
+    if (rc) return rc;
+    xc_sum_parts_kernel<<<1024, 256, 0, h0->st>>>(gather, len, np, total, len);
+    PAMD_CHECK_LAUNCH();
+    PAMD_CHECK_HIP(hipMemcpyAsync(vmat, total, len * 8, hipMemcpyDeviceToHost, h0->st));
+    PAMD_CHECK_HIP(hipStreamSynchronize(h0->st));
     return 0;
 }
 
@@ -359,6 +451,48 @@ int PAMD_grid_weights_host(const double *coords, long ngrids, const double *atm_
     becke_normalise_kernel<<<ceil_div(ngrids, 256), 256>>>(d_pb, natm, ngrids, ia, d_vol, d_w);
     PAMD_CHECK_LAUNCH();
     PAMD_CHECK_HIP(hipMemcpy(weights, d_w, (size_t)ngrids * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// devices[ndev]: the grid TILES (512 consecutive points of the caller's - box-sorted - order) are dealt round-robin over the
+// parts, as the torch path deals them over ranks (dft/sparse_grid.py); nelec, exc and vmat are sums over grid points, so every
+// part is an ordinary handle on its sub-grid.  A device may be listed more than once.
+int PAMD_xc_create_multi(const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, const double *coords,
+                         const double *weights, long ngrids, const int *devices, int ndev, PAMD_xc **out)
+{
+    PAMD_REQUIRE(devices && ndev > 0 && ndev <= 64 && out && coords && weights && ngrids > 0, "PAMD_xc_create_multi: bad arguments");
+    *out = nullptr;
+    PAMD_xc *m = new PAMD_xc;
+    struct Guard { PAMD_xc *p; ~Guard() { delete p; } } guard{m};
+    m->device = devices[0];
+    m->ngrids = ngrids;
+    const long ntile = (ngrids + XC_G - 1) / XC_G;
+    for (int p = 0; p < ndev; p++) {
+        std::vector<double> c, w;
+        for (long t = p; t < ntile; t += ndev) {             // (only the grid's last tile can be short, and it ends its part)
+            const long g0 = t * XC_G, g1 = std::min<long>(g0 + XC_G, ngrids);
+            c.insert(c.end(), coords + 3 * g0, coords + 3 * g1);
+            w.insert(w.end(), weights + g0, weights + g1);
+        }
+        if (w.empty()) { c.assign(coords, coords + 3); w.assign(1, 0.0); }      // more parts than tiles: a weightless point
+        PAMD_xc *part = nullptr;
+        int rc = PAMD_xc_create(atm, natm, bas, nbas, env, nenv, c.data(), w.data(), (long)w.size(), devices[p], &part);
+        if (rc) return rc;
+        m->parts.push_back(part);
+    }
+    m->nao = m->parts[0]->nao;
+    m->peer_ok = 1;
+    PAMD_CHECK_HIP(hipSetDevice(devices[0]));
+    for (int p = 1; p < ndev && m->peer_ok; p++) {
+        if (devices[p] == devices[0]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[0], devices[p]) != hipSuccess || !can) { (void)hipGetLastError(); m->peer_ok = 0; break; }
+        const hipError_t e = hipDeviceEnablePeerAccess(devices[p], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) m->peer_ok = 0;
+        (void)hipGetLastError();
+    }
+    guard.p = nullptr;
+    *out = m;
     return 0;
 }
 
@@ -431,6 +565,19 @@ int PAMD_xc_nao(const PAMD_xc *h, int *nao)
 int PAMD_xc_plan_info(PAMD_xc *h, int xctype, double *info)
 {
     PAMD_REQUIRE(h && info, "null handle");
+    if (!h->parts.empty()) {
+        info[0] = info[1] = info[2] = 0;
+        for (PAMD_xc *p : h->parts) {
+            double pi[3];
+            int rc = PAMD_xc_plan_info(p, xctype, pi);
+            if (rc) return rc;
+            info[0] += pi[0];
+            info[1] += pi[1] * pi[0];
+            info[2] += pi[2];
+        }
+        if (info[0] > 0) info[1] /= info[0];
+        return 0;
+    }
     PAMD_CHECK_HIP(hipSetDevice(h->device));
     int rc = build_plan(h, xctype);
     if (rc) return rc;
@@ -451,10 +598,14 @@ int PAMD_xc_nr_rks(PAMD_xc *h, const double *fac, int xctype, int nset, const do
     const double *o = orbs, *sg = signs;
     for (int s = 0; s < nset; s++) {
         OrbOp op;
-        int rc = upload_orbitals(h, "0", o, nocc[s], sg, &op);
-        if (rc) return rc;
+        int rc;
         double acc[4];
-        if ((rc = xc_contract(h, fac, xctype, 0, &op, acc, vmat + (size_t)s * n2))) return rc;
+        if (!h->parts.empty()) {
+            if ((rc = xc_multi(h, fac, xctype, 0, o, nocc + s, sg, acc, vmat + (size_t)s * n2))) return rc;
+        } else {
+            if ((rc = upload_orbitals(h, "0", o, nocc[s], sg, &op))) return rc;
+            if ((rc = xc_contract(h, fac, xctype, 0, &op, acc, vmat + (size_t)s * n2))) return rc;
+        }
         nelec[s] = acc[0];
         exc[s] = acc[1];
         o += (size_t)h->nao * nocc[s];
@@ -471,10 +622,14 @@ int PAMD_xc_nr_uks(PAMD_xc *h, const double *fac, int xctype, const double *orbs
     PAMD_CHECK_HIP(hipSetDevice(h->device));
     OrbOp ops[2];
     int rc;
-    if ((rc = upload_orbitals(h, "0", orbs, nocc[0], signs, &ops[0]))) return rc;
-    if ((rc = upload_orbitals(h, "1", orbs + (size_t)h->nao * nocc[0], nocc[1], signs ? signs + nocc[0] : nullptr, &ops[1]))) return rc;
     double acc[4];
-    if ((rc = xc_contract(h, fac, xctype, 1, ops, acc, vmat))) return rc;
+    if (!h->parts.empty()) {
+        if ((rc = xc_multi(h, fac, xctype, 1, orbs, nocc, signs, acc, vmat))) return rc;
+    } else {
+        if ((rc = upload_orbitals(h, "0", orbs, nocc[0], signs, &ops[0]))) return rc;
+        if ((rc = upload_orbitals(h, "1", orbs + (size_t)h->nao * nocc[0], nocc[1], signs ? signs + nocc[0] : nullptr, &ops[1]))) return rc;
+        if ((rc = xc_contract(h, fac, xctype, 1, ops, acc, vmat))) return rc;
+    }
     nelec[0] = acc[0];
     nelec[1] = acc[1];
     *exc = acc[2];

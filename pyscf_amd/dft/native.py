@@ -59,8 +59,9 @@ class NativeNumInt:
     libxc = _xc
     omega = None
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
         self.device = device
+        self.devices = None if devices is None else [int(d) for d in devices]     # several GPUs in this process: PAMD_xc_create_multi
         self._h = None
         self._key = None
 
@@ -117,9 +118,15 @@ class NativeNumInt:
             coords = np.ascontiguousarray(grids.coords, dtype=np.float64)
             weights = np.ascontiguousarray(grids.weights, dtype=np.float64)
             h = _c.c_void_p()
-            _native._check(_native.load().PAMD_xc_create(_ptr(atm), _c.c_int(len(atm)), _ptr(bas), _c.c_int(len(bas)), _ptr(env),
-                                                         _c.c_int(len(env)), _ptr(coords), _ptr(weights), _c.c_long(len(weights)),
-                                                         _c.c_int(int(self.device)), _c.byref(h)))
+            if self.devices is not None:
+                devs = (_c.c_int * len(self.devices))(*self.devices)
+                _native._check(_native.load().PAMD_xc_create_multi(_ptr(atm), _c.c_int(len(atm)), _ptr(bas), _c.c_int(len(bas)), _ptr(env),
+                                                                   _c.c_int(len(env)), _ptr(coords), _ptr(weights), _c.c_long(len(weights)),
+                                                                   devs, _c.c_int(len(self.devices)), _c.byref(h)))
+            else:
+                _native._check(_native.load().PAMD_xc_create(_ptr(atm), _c.c_int(len(atm)), _ptr(bas), _c.c_int(len(bas)), _ptr(env),
+                                                             _c.c_int(len(env)), _ptr(coords), _ptr(weights), _c.c_long(len(weights)),
+                                                             _c.c_int(int(self.device)), _c.byref(h)))
             self._h, self._key = h, key
         return self._h
 

@@ -86,14 +86,7 @@ class RKS(hf.RHF):
     def energy_elec(self, dm=None, h1e=None, vhf=None):
         return energy_elec(self, dm, h1e, vhf)
 
-    def density_fit(self, auxbasis=None, with_df=None, only_dfj=False):
-        from .. import df
-        if with_df is None:
-            if auxbasis is None and not numint._xc.is_hybrid_xc(self.xc):
-                # pure functionals fit J only: the reference picks a J-fit set (df/addons.py:326-330,
-                # 354-357) - packaged here as def2-universal-jfit ('weigend')
-                pass
-            with_df = df.DF(self.mol, auxbasis)
-        self.with_df = with_df
-        self.only_dfj = bool(only_dfj)
-        return self
+    def density_fit(self, auxbasis=None, with_df=None, only_dfj=False, devices=None):
+        # (pure functionals fit J only: the reference picks a J-fit set, df/addons.py:326-330, 354-357 - DF(mol, None) follows the
+        # same rule); `devices`: scf/hf.py::SCF.density_fit - J/K and the XC tiles over a device list in this process
+        return hf.SCF.density_fit(self, auxbasis, with_df, only_dfj, devices)

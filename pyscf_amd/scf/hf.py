@@ -430,6 +430,9 @@ class SCF:
         if with_df is None and devices is not None:
             from ..df.native import NativeDF
             with_df = NativeDF(self.mol, auxbasis, devices=list(devices))
+            if hasattr(self, '_numint'):                       # Kohn-Sham: the grid tiles go over the same device list
+                from ..dft.native import NativeNumInt
+                self._numint = NativeNumInt(devices=list(devices))
         if with_df is None:
             with_df = df.DF(self.mol, auxbasis)
         self.with_df = with_df

@@ -94,6 +94,22 @@ def main():
             assert np.abs(np.asarray(n1) - np.asarray(n0)).max() < 1e-9 and abs(e1 - e0) < 1e-9 * abs(e0), (xc, n1, n0, e1, e0)
             assert np.abs(v1 - v0).max() < 1e-8 * max(1.0, np.abs(v0).max()), (xc, np.abs(v1 - v0).max())
     ni.reset()
+    # the same over a device list (tiles dealt round-robin over the parts; the test box has one GPU: the list repeats it)
+    for devs in ([0, 0], [0, 0, 0, 0, 0]):
+        nm = NativeNumInt(devices=devs)
+        for xc in ('lda,vwn', 'b3lyp'):
+            hyb, fac = libxc.parse_xc(xc)
+            gga = libxc.xc_type(xc) == 'GGA'
+            n0, e0, v0 = ref_dft.nr_rks(mol, grids.coords, grids.weights, fac, gga, dm)
+            n1, e1, v1 = nm.nr_rks(mol, grids, xc, lib.tag_array(dm, mo_coeff=c, mo_occ=occ))
+            assert abs(n1 - n0) < 1e-10 * abs(n0) and abs(e1 - e0) < 1e-10 * abs(e0), (devs, xc)
+            assert np.abs(v1 - v0).max() < 1e-9 * max(1.0, np.abs(v0).max()), (devs, xc, np.abs(v1 - v0).max())
+        hyb, fac = libxc.parse_xc('b3lyp')
+        n0, e0, v0 = ref_dft.nr_uks(mol, grids.coords, grids.weights, fac, True, dma, dmb)
+        n1, e1, v1 = nm.nr_uks(mol, grids, 'b3lyp', np.array([dma, dmb]))
+        assert np.abs(np.asarray(n1) - np.asarray(n0)).max() < 1e-9 and abs(e1 - e0) < 1e-9 * abs(e0) and np.abs(v1 - v0).max() < 1e-8
+        assert nm.plan_info(mol, grids, 'b3lyp')['tiles'] >= -(-grids.size // 512)
+        nm.reset()
     stamp('nr_rks / nr_uks vs oracle')
 
     # ---- the reference's DF-RKS golden through the stock driver with the three native objects

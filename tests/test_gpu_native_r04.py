@@ -56,6 +56,24 @@ def test_stock_script_with_a_device_list_reaches_the_reference_golden():
     e = mf.kernel()
     assert mf.converged and abs(e - -76.025936299702536) < 1e-8, e
     assert mf.with_df.layout()['parts'] == 3
+    # Kohn-Sham: J/K and the XC tiles over the same device list (DF-RKS golden of pyscf/dft/test/test_h2o.py:236-240)
+    from pyscf_amd import dft
+    from pyscf_amd.dft import radi, gen_grid
+    from pyscf_amd.dft.native import NativeNumInt
+    old = radi.ATOM_SPECIFIC_TREUTLER_GRIDS
+    radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
+    try:
+        m631 = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis='6-31g')
+        ks = dft.RKS(m631).density_fit(auxbasis='weigend', devices=[0, 0])
+        assert isinstance(ks._numint, NativeNumInt) and ks._numint.devices == [0, 0]
+        ks.grids.prune = gen_grid.treutler_prune
+        ks.grids.atom_grid = {'H': (50, 194), 'O': (50, 194)}
+        ks.xc = 'b88, vwn'
+        ks.conv_tol = 1e-10
+        eks = ks.kernel()
+    finally:
+        radi.ATOM_SPECIFIC_TREUTLER_GRIDS = old
+    assert ks.converged and abs(eks - -76.690346887915879) < 1e-8, eks
     os.environ['PAMD_DEVICES'] = '0,0'
     try:
         m2 = scf.RHF(mol).density_fit(auxbasis='weigend')
