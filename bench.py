@@ -609,6 +609,26 @@ def single_process_main(args):
     dt = time.perf_counter() - t0
     ms = dt / args.steps * 1e3
     lay = obj.layout()
+    xc_info = None
+    if args.xc:
+        # the XC leg through the host-array handle over the same device list (grid tiles dealt round-robin over the parts)
+        from pyscf_amd.dft.native import NativeGrids, NativeNumInt
+        t0 = time.perf_counter()
+        grids = NativeGrids(mol, device=devices[0]).build()
+        grid_s = time.perf_counter() - t0
+        ni = NativeNumInt(devices=devices)
+        t0 = time.perf_counter()
+        ni.nr_rks(mol, grids, args.xc, dm)                # builds the block-sparse plans of all parts
+        plan_s = time.perf_counter() - t0
+        xt = []
+        for _ in range(max(5, min(args.steps, 10))):
+            t0 = time.perf_counter()
+            nel, exc, _v = ni.nr_rks(mol, grids, args.xc, dm)
+            xt.append((time.perf_counter() - t0) * 1e3)
+        xc_info = {'xc': args.xc, 'nr_rks_ms_per_call': round(float(np.median(xt)), 1), 'nr_rks_ms_calls': [round(t, 1) for t in xt],
+                   'ngrids': int(grids.size), 'grid_build_s': round(grid_s, 2), 'plan_build_s': round(plan_s, 2), 'nelec': float(nel),
+                   'plan': ni.plan_info(mol, grids, args.xc), 'what': 'NativeNumInt(devices=...).nr_rks with numpy in / out (PAMD_xc_nr_rks)'}
+        ni.reset()
     nt = -(-nao // 128)
     step_exec = 2.0 * naux * nao * nao * nocc * (1.0 + (nt * (nt + 1) / 2) / (float(nt) * nt))
     out = {'metric': 'ms per SCF iter (DF J/K build)', 'value': round(ms, 3), 'unit': 'ms', 'n_gpus': len(set(devices)),
@@ -624,7 +644,7 @@ def single_process_main(args):
            'roofline_step': {'executed_TFLOP': round(step_exec / 1e12, 3), 'achieved_TFLOPs': round(step_exec / (ms * 1e-3) / 1e12, 2),
                              'peak_TFLOPs': FP64_MFMA_PEAK_TFLOPS * len(set(devices)),
                              'frac': round(step_exec / (ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * len(set(devices))), 4)},
-           'cpu_baseline': None, 'build_s': round(build_s, 2),
+           'cpu_baseline': None, 'build_s': round(build_s, 2), 'xc_path': xc_info,
            'checksum': {'fp_vj': lib.fp(vj), 'fp_vk': lib.fp(vk)}}
     print(json.dumps(out))
     obj.reset()
