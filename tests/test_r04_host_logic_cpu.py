@@ -1,0 +1,111 @@
+"""Host-side logic added in r04 that needs no GPU: the work list of PAMD_sub_vmat_sym, the options struct of PAMD_df_create_ex as
+ctypes sees it, the device-list plumbing of density_fit (no handle is built), the XC golden generator's energy bookkeeping."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from pyscf_amd.df import native
+    return native.load()
+
+
+def test_sub_vmat_work_list_covers_every_block_pair_once_and_balances_the_xcd_queues():
+    so = _lib()
+    so.PAMD_sub_vmat_work.restype = C.c_long
+    rng = np.random.RandomState(4)
+    ld = np.ascontiguousarray(rng.randint(1, 60, size=257) * 16, dtype=np.int32)
+    ld[5] = 16
+    ld[9] = 8 * 16 * 3 + 16                       # 25 groups: pieces 7 + 6 + 6 + 6
+    n = so.PAMD_sub_vmat_work(ld.ctypes.data_as(C.c_void_p), len(ld), None)
+    w = np.zeros(n * 6, np.int32)
+    assert so.PAMD_sub_vmat_work(ld.ctypes.data_as(C.c_void_p), len(ld), w.ctypes.data_as(C.c_void_p)) == n
+    it = w.reshape(-1, 6)
+    live = it[it[:, 2] > 0]
+    assert n % 8 == 0 and np.all(live[:, 2] <= 8) and np.all(live[:, 4] <= 8) and np.all(live[:, 4] > 0)
+    for t in range(len(ld)):
+        mine = live[live[:, 0] == t]
+        g = ld[t] // 16
+        diag = mine[mine[:, 5] == 1]
+        pieces = sorted((int(p0), int(gp)) for p0, gp in diag[:, 1:3])
+        # the pieces tile [0, ld) without gaps, sizes differ by at most one group
+        pos = 0
+        for p0, gp in pieces:
+            assert p0 == pos
+            pos += gp * 16
+        assert pos == ld[t] and max(gp for _, gp in pieces) - min(gp for _, gp in pieces) <= 1
+        npc = len(pieces)
+        assert npc == -(-g // 8) and len(mine) == npc * (npc + 1) // 2
+        # every pair (i >= j) exactly once, none above the diagonal
+        pairs = {(int(r[1]), int(r[3])) for r in mine}
+        assert len(pairs) == len(mine) and all(a >= b for a, b in pairs)
+        # all items of a tile sit in ONE dispatch queue (position % 8)
+        where = np.nonzero((it[:, 0] == t) & (it[:, 2] > 0))[0]
+        assert len(set(where % 8)) == 1
+    cost = ((it[:, 2] + 1) // 2) * ((it[:, 4] + 1) // 2) * np.where(it[:, 5] == 1, 1, 2)
+    per = np.array([cost[k::8].sum() for k in range(8)], dtype=float)
+    assert per.max() - per.min() <= 0.02 * per.mean() + 32, per
+    # no tiles at all
+    assert so.PAMD_sub_vmat_work(ld.ctypes.data_as(C.c_void_p), 0, None) == 0
+
+
+def test_df_options_struct_matches_the_header():
+    from pyscf_amd.df import native
+    hdr = open(os.path.join(ROOT, 'include', 'pyscf_amd.h')).read()
+    body = re.search(r'typedef struct PAMD_df_options \{(.*?)\} PAMD_df_options;', hdr, re.S).group(1)
+    names = re.findall(r'(\w+);\s*(?:/\*.*?\*/)?\s*$', body, re.M)
+    assert names == [f[0] for f in native._Options._fields_], (names, native._Options._fields_)
+    assert C.sizeof(native._Options) == 8 + 8 + 8 + 4 + 4 + 8
+
+
+def test_density_fit_device_list_plumbing_without_a_device():
+    from pyscf_amd import gto, scf, dft
+    from pyscf_amd.df.native import NativeDF
+    from pyscf_amd.dft.native import NativeNumInt
+    mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis='sto-3g')
+    mf = scf.RHF(mol).density_fit(devices=range(4))
+    assert isinstance(mf.with_df, NativeDF) and mf.with_df.devices == [0, 1, 2, 3] and mf.with_df._h is None
+    ks = dft.RKS(mol, xc='b3lyp').density_fit(auxbasis='weigend', devices=[2, 3])
+    assert isinstance(ks.with_df, NativeDF) and isinstance(ks._numint, NativeNumInt) and ks._numint.devices == [2, 3]
+    assert ks._numint.rsh_and_hybrid_coeff('b3lyp')[2] == 0.2 and ks._numint._xc_type('b3lyp') == 'GGA'
+    os.environ['PAMD_DEVICES'] = '1, 0'
+    try:
+        m2 = scf.RHF(mol).density_fit()
+    finally:
+        del os.environ['PAMD_DEVICES']
+    assert isinstance(m2.with_df, NativeDF) and m2.with_df.devices == [1, 0]
+    m3 = scf.RHF(mol).density_fit()
+    assert not isinstance(m3.with_df, NativeDF)
+    # range_coulomb keeps one handle object per omega, reset drops them
+    a = mf.with_df.range_coulomb(0.3)
+    assert a is mf.with_df.range_coulomb(0.3) and a.omega == 0.3 and a.devices == [0, 1, 2, 3] and mf.with_df.range_coulomb(0) is mf.with_df
+    mf.with_df.reset()
+    assert mf.with_df._rsh_df == {}
+
+
+def test_xc_golden_generator_combines_the_oracle_energy_functional(tmp_path):
+    """tools/gen_golden_xc.py --combine-only: E_RKS[D] = E_RHF[D] + (1 - hyb)/4 Tr(D K) + E_xc from two oracle-only files."""
+    import shutil
+    g = {'conv_e_rhf_functional': -10.0, 'conv_tr_d_vk': 4.0, 'conv_e_tot_of_the_orbital_source': -11.5}
+    jk = tmp_path / 'jk.json'
+    jk.write_text(json.dumps(g))
+    tag = '_unit_test_combine'
+    out = os.path.join(ROOT, 'tests', 'golden', tag + '_oracle.json')
+    try:
+        with open(out, 'w') as f:
+            json.dump({'xc_x_exc': -2.0}, f)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_golden_xc.py'), '--molecule', 'water', '--nwater', '1', '--xc', 'b3lyp',
+                            '--orbitals', 'x', '--combine-only', '--jk-json', 'x=%s' % jk, '--tag', tag], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        r = json.load(open(out))
+        assert abs(r['xc_x_e_rks_functional'] - (-10.0 + 0.25 * 0.8 * 4.0 - 2.0)) < 1e-12
+    finally:
+        if os.path.exists(out):
+            os.remove(out)

@@ -73,6 +73,24 @@ r04a)       # new tests of the round + bench modes
   timeout 1200 python -m pytest -q -x --durations=6 tests/test_gpu_native_r04.py::test_stock_script_with_a_device_list_reaches_the_reference_golden tests/test_gpu_fullsize_cfg45.py::test_config4_taxol_df_rks_xc_and_energy_vs_oracle_golden > $O/pytest.log 2>&1; tail -12 $O/pytest.log
   timeout 600 python bench.py --gpus 2 --single-process --steps 3 > $O/bench_single_process_2parts.json 2> $O/bench_sp.err; cut -c1-700 $O/bench_single_process_2parts.json; tail -2 $O/bench_sp.err
   timeout 1200 python bench.py --pmc --steps 10 --warmup 2 > $O/bench_pmc.json 2> $O/bench_pmc.err; tail -c 1500 $O/bench_pmc.json; tail -3 $O/bench_pmc.err ;;
+evidence)   # the round's measured evidence (everything except the test suite): gpu_job.sh evidence <tag>
+  TAG=${1:-r04}
+  bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log
+  timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench_h2o32_1gpu_steps20.json 2> $O/bench20.err; cut -c1-260 $O/bench_h2o32_1gpu_steps20.json
+  timeout 900 python bench.py --pmc --no-cpu-baseline > $O/bench_h2o32_1gpu_pmc.json 2> $O/bench_pmc.err; cut -c1-200 $O/bench_h2o32_1gpu_pmc.json
+  timeout 600 python bench.py --k-square off --no-cpu-baseline --xc '' > $O/bench_h2o32_1gpu_ksquare_off.json 2> $O/bench_ksq.err; cut -c1-200 $O/bench_h2o32_1gpu_ksquare_off.json
+  timeout 900 python bench.py --molecule taxol --no-cpu-baseline > $O/bench_taxol_1gpu.json 2> $O/bench_taxol.err; cut -c1-200 $O/bench_taxol_1gpu.json
+  timeout 600 python bench.py --gpus 1 --single-process --steps 5 > $O/bench_single_process_1part.json 2> $O/bench_sp1.err; cut -c1-200 $O/bench_single_process_1part.json
+  timeout 600 python bench.py --gpus 2 --single-process --steps 5 > $O/bench_single_process_2parts_1gpu.json 2> $O/bench_sp2.err; cut -c1-200 $O/bench_single_process_2parts_1gpu.json
+  timeout 600 python tools/run_scf.py --nwater 32 --xc b3lyp --conv-tol 1e-10 > $O/scf_h2o32_b3lyp.log 2>&1; tail -2 $O/scf_h2o32_b3lyp.log
+  timeout 600 python tools/run_scf.py --nwater 32 --xc '' --conv-tol 1e-10 > $O/scf_h2o32_rhf.log 2>&1; tail -1 $O/scf_h2o32_rhf.log
+  timeout 600 python tools/run_scf.py --molecule taxol --xc b3lyp --conv-tol 1e-9 > $O/scf_taxol_b3lyp.log 2>&1; tail -1 $O/scf_taxol_b3lyp.log
+  timeout 600 python tools/grad_bench.py --nwater 32 > $O/grad_h2o32_rhf.json 2> $O/grad.err; cat $O/grad_h2o32_rhf.json | cut -c1-300
+  : > $O/shard_probe_h2o32_world1_2_4_8.jsonl
+  for w in 1 2 4 8; do timeout 300 python tools/shard_probe.py --nwater 32 --basis cc-pvtz --world $w --rank 0 2>/dev/null | tail -1 >> $O/shard_probe_h2o32_world1_2_4_8.jsonl; done
+  cut -c1-220 $O/shard_probe_h2o32_world1_2_4_8.jsonl
+  timeout 600 python tools/shard_probe.py --nwater 128 --basis cc-pvdz --world 8 --rank 3 2>/dev/null | tail -1 > $O/shard_probe_h2o128_rank3of8.json; cut -c1-300 $O/shard_probe_h2o128_rank3of8.json
+  find gpurun_out -name "*.db" -delete ;;
 run)        # arbitrary command line, logged: gpu_job.sh run <tag> <cmd...>
   T=$1; shift; timeout 1500 "$@" > $O/$T.log 2>&1; tail -30 $O/$T.log ;;
 *) echo "unknown job $JOB"; exit 2 ;;
