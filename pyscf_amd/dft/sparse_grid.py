@@ -71,6 +71,10 @@ class SparsePlan:
         cap = int(getattr(ni, 'chunk_buffer_bytes', 6 << 30) // (self.ncomp * 8 * nocc_hint))
         self._chunks(max(G, min(int(ni.sparse_chunk_points), max(cap, 131072))))
         self.ao_c = None
+        if not self._cache_fits() and self.max_chunk_points > 131072:
+            # the compact image is recomputed chunk by chunk in every call: small launch groups bound that buffer (one big group
+            # would need the whole image at once - 17.7 GiB at taxol size, found by the r04 taxol bench)
+            self._chunks(131072)
         if self._cache_fits():
             self.ao_c = torch.empty(self.ao_total + 256, dtype=torch.float64, device=dev)
             self.ao_c[self.ao_total:].zero_()
