@@ -128,12 +128,11 @@ __global__ __launch_bounds__(256) void vj_pass2_kernel(
 // The same pass with 16-byte loads: every lane owns TWO adjacent packed columns (npair even, 16-byte aligned rows), so a wave
 // moves 1 KiB per load instruction and issues half as many loads and half as many scalar rho reads per byte - fewer issue slots
 // taken from the MFMA kernel it runs beside (r03; tuning key "j2wide").
-template <int NSET, int U>
+template <int NSET>
 __global__ __launch_bounds__(256) void vj_pass2_wide_kernel(
     const double *__restrict__ cderi, long npair, int naux, const double *__restrict__ rho,
-    double *__restrict__ vj, int prio)
+    double *__restrict__ vj)
 {
-    if (prio) __builtin_amdgcn_s_setprio(3);       // the few waves this pass gets beside the SYRK issue their loads at once ("j2prio")
     const long npair2 = npair >> 1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npair2; i += (long)gridDim.x * 256) {
         double2_t acc[NSET];
@@ -141,12 +140,12 @@ __global__ __launch_bounds__(256) void vj_pass2_wide_kernel(
         for (int s = 0; s < NSET; s++) acc[s] = double2_t{0, 0};
         const double2_t *col = reinterpret_cast<const double2_t *>(cderi) + i;
         int L = 0;
-        for (; L + U <= naux; L += U) {
-            double2_t b[U];
+        for (; L + 8 <= naux; L += 8) {
+            double2_t b[8];
 #pragma unroll
-            for (int u = 0; u < U; u++) b[u] = __builtin_nontemporal_load(col + (long)(L + u) * npair2);
+            for (int u = 0; u < 8; u++) b[u] = __builtin_nontemporal_load(col + (long)(L + u) * npair2);
 #pragma unroll
-            for (int u = 0; u < U; u++)
+            for (int u = 0; u < 8; u++)
 #pragma unroll
                 for (int s = 0; s < NSET; s++) {
                     const double r = rho[s * naux + L + u];
@@ -928,26 +927,12 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
 }
 
 // 128 x 128 tile of C[split] += A^T B (all tiles, or the lower-triangular ones of the SYRK), v2 DMA scheme
-// BURST: the DMA rows of k-tile t + 1 all behind the FIRST MFMA group of tile t (3/4 of a tile more lead for the late rows; A/B
-// switch "syrkburst": does the SYRK beside the co-running J pass wait on DMA latency?)
-template <bool BURST>
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
-    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, long kchunk, int prio, int xmap,
-    int ntiles, int nsplit)
+    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, long kchunk, int prio)
 {
     if (prio) __builtin_amdgcn_s_setprio(3);        // MFMA waves ahead of a co-resident HBM-bound kernel's waves (tuning "mfmaprio")
-    int bsplit = blockIdx.y, btile = blockIdx.x;
-    if (xmap) {
-        // r04: 1-D launch, one k split per group of 8 / nsplit XCDs (workgroup b runs on XCD b % 8, each XCD has its own L2): an
-        // XCD's L2 then streams only ITS split's rows of X - 8 / nsplit copies of X leave HBM per SYRK instead of the ~11 the
-        // tile-major order costs (r03 counters: 123 GB for a 10.6 GB block), which is the room the co-running J pass needs
-        const int b = blockIdx.x, xcd = b & 7, j = b >> 3, xp = 8 / nsplit;
-        bsplit = xcd / xp;
-        btile = (xcd % xp) + xp * j;
-        if (btile >= ntiles) return;
-    }
-    const int nsplit_g = xmap ? nsplit : (int)gridDim.y;
+    const int bsplit = blockIdx.y, btile = blockIdx.x;
     constexpr int PA = KB * LDN;
     __shared__ double sb0[2 * PA];
     __shared__ double sb1[2 * PA];
@@ -969,7 +954,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     // SYRK: a short remainder piece, see dgemm_tn_impl)
     long kbeg = (long)bsplit * kchunk;
     if (kbeg > kdim) kbeg = kdim;
-    const long kend = (kbeg + kchunk < kdim && bsplit + 1 < nsplit_g) ? kbeg + kchunk : kdim;
+    const long kend = (kbeg + kchunk < kdim && bsplit + 1 < (int)gridDim.y) ? kbeg + kchunk : kdim;
     const int nk = (int)(kend - kbeg);                 // rows of this split: row offsets stay below 4 GiB (launcher)
     const __amdgpu_buffer_rsrc_t r_a = make_rsrc(A + kbeg * lda + p0);
     const __amdgpu_buffer_rsrc_t r_b = make_rsrc(B + kbeg * ldb + q0);
@@ -1001,14 +986,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
             for (int a = 0; a < 4; a++) af[a] = cur[offa + kk * LDN + a * 16];
 #pragma unroll
             for (int b = 0; b < 4; b++) bf[b] = cur[offb + kk * LDN + b * 16];
-            if (BURST) {
-                if (kk == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) stage_row(kn, nxt, j);
-                }
-            } else {
-                stage_row(kn, nxt, kk >> 2);
-            }
+            stage_row(kn, nxt, kk >> 2);
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -1235,8 +1213,6 @@ static int g_e2_mtmax = 10;   // orbital tiles (of 16) per workgroup, upper boun
 static int g_e2_prio = 0;     // s_setprio 3 in the half transform (A/B switch)
 static int g_mfma_prio = 0;   // s_setprio 3 in the SYRK kernels (A/B switch)
 static int g_j2_wide = 0;     // second J pass with 16-byte loads (two packed columns per lane); A/B switch, default set after measurement
-static int g_j2_prio = 0;     // s_setprio 3 in the wide second J pass ("j2prio")
-static int g_j2_unroll = 8;   // loads in flight per lane of the wide second J pass: 8 or 16 ("j2unroll")
 static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: one per 256 columns)
 static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
@@ -1245,8 +1221,6 @@ static int g_pk_diag = 1;     // e2_pk reads the diagonal 128 x 128 blocks from 
 static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
 static int g_syrk_probe = 0;  // benchmarking probe only: the re-tiled SYRK without its second panel DMA (results meaningless)
 static int g_syrk_slots = 1;  // SYRK on the re-tiled triangle (syrk_slots_kernel) when the matrix has an odd number of 64-column blocks
-static int g_syrk_burst = 0;  // plain-grid SYRK: next tile's DMA rows in one burst ("syrkburst")
-static int g_syrk_xmap = 0;   // plain-grid SYRK: one k split per group of XCDs ("syrkxmap"; A/B in profiles/r04)
 static int g_syrk_frac = 1;   // balanced SYRK: full pieces + one short remainder piece per tile (dgemm_tn_impl)
 static int g_num_cu = 256;    // MI355X
 static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
@@ -1262,8 +1236,6 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "syrkfrac") == 0) { g_syrk_frac = value; return 0; }
     if (strcmp(key, "syrkslots") == 0) { g_syrk_slots = value; return 0; }
     if (strcmp(key, "syrkprobe") == 0) { g_syrk_probe = value; return 0; }
-    if (strcmp(key, "syrkxmap") == 0) { g_syrk_xmap = value; return 0; }
-    if (strcmp(key, "syrkburst") == 0) { g_syrk_burst = value; return 0; }
     if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "pkdiag") == 0) { g_pk_diag = value; return 0; }
@@ -1272,8 +1244,6 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "pairtail") == 0) { g_pair_tail = value; return 0; }
     if (strcmp(key, "j2wg") == 0 && value >= 0) { g_j2_maxwg = value; return 0; }
     if (strcmp(key, "j2wide") == 0) { g_j2_wide = value; return 0; }
-    if (strcmp(key, "j2prio") == 0) { g_j2_prio = value; return 0; }
-    if (strcmp(key, "j2unroll") == 0) { g_j2_unroll = value; return 0; }
     if (strcmp(key, "mfmaprio") == 0) { g_mfma_prio = value; return 0; }
     if (strcmp(key, "e2prio") == 0) { g_e2_prio = value; return 0; }
     if (strcmp(key, "e2mt") == 0 && value >= 1 && value <= 10) { g_e2_mtmax = value; return 0; }
@@ -1315,16 +1285,12 @@ int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *
     if (g_j2_wide && npair % 2 == 0 && ((uintptr_t)d_cderi % 16 == 0)) {
         int grid = ceil_div(npair / 2, 256);
         if (g_j2_maxwg > 0 && grid > g_j2_maxwg) grid = g_j2_maxwg;
-#define LAUNCH_J2W(NS)                                                                                                           \
-        if (g_j2_unroll >= 16) vj_pass2_wide_kernel<NS, 16><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril, g_j2_prio); \
-        else vj_pass2_wide_kernel<NS, 8><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril, g_j2_prio)
         switch (nset) {
-        case 1: LAUNCH_J2W(1); break;
-        case 2: LAUNCH_J2W(2); break;
-        case 3: LAUNCH_J2W(3); break;
-        default: LAUNCH_J2W(4); break;
+        case 1: vj_pass2_wide_kernel<1><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
+        case 2: vj_pass2_wide_kernel<2><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
+        case 3: vj_pass2_wide_kernel<3><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
+        default: vj_pass2_wide_kernel<4><<<grid, 256, 0, st>>>(d_cderi, npair, naux, d_rho, d_vjtril); break;
         }
-#undef LAUNCH_J2W
         PAMD_CHECK_LAUNCH();
         return 0;
     }
@@ -1725,16 +1691,7 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
     }
     if (v2) {
         if (lower_only & 1) kchunk = balanced_chunk(ntiles);
-        const bool xmap = g_syrk_xmap && (lower_only & 1) && !(lower_only & 4) && (nsplit == 2 || nsplit == 4 || nsplit == 8) && ntiles >= 32;
-        if (xmap) {
-            const int xp = 8 / nsplit;
-            dim3 g1(8 * ceil_div(ntiles, xp));
-            if (g_syrk_burst) gemm_tn_glds2_kernel<true><<<g1, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 1, ntiles, nsplit);
-            else gemm_tn_glds2_kernel<false><<<g1, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 1, ntiles, nsplit);
-        } else {
-            if (g_syrk_burst) gemm_tn_glds2_kernel<true><<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 0, ntiles, nsplit);
-            else gemm_tn_glds2_kernel<false><<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, 0, ntiles, nsplit);
-        }
+        gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio);
     }
     else if (glds)
     {

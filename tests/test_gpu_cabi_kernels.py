@@ -299,3 +299,27 @@ def m0_cd(j2c):
     import scipy.linalg
     low = scipy.linalg.cholesky(j2c, lower=True)
     return scipy.linalg.solve_triangular(low, np.eye(len(low)), lower=True)
+
+
+def test_balanced_syrk_inside_the_4gib_row_offset_window():
+    """the balanced k split makes FULL pieces longer than the uniform ones; the kernels address rows with 32-bit offsets
+    inside a 4 GiB buffer window, and a shape like m = 2496 columns x 600 000 rows (uniform piece 200 000 rows = 3.99 GB, balanced
+    piece 240 000 rows = 4.8 GB) used to wrap.  The launcher now falls back to uniform pieces there: K = X^T X against torch."""
+    torch, so, dev, st, lib = _setup()
+    m, k = 2496, 600_000                               # 39 blocks of 64 columns (odd: re-tiled triangle), nsplit 3 by syrk_plan's rule
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    x = torch.empty((k, m), dtype=torch.float64, device=dev)
+    for r0 in range(0, k, 50_000):
+        x[r0:r0 + 50_000].normal_(generator=g)
+    x *= 1.0 / np.sqrt(k)
+    nsplit = 3
+    part = torch.zeros((nsplit, m, m), dtype=torch.float64, device=dev)
+    lib.check(so.PAMD_dgemm_tn(_p(x), m, _p(x), m, _p(part), m, m, m, C.c_long(k), 1 | 2 | 4 | 8, nsplit, st))
+    got = torch.tril(part.sum(dim=0))
+    want = torch.zeros((m, m), dtype=torch.float64, device=dev)
+    for r0 in range(0, k, 100_000):                    # reference in chunks (a full-size matmul workspace is not needed)
+        want += x[r0:r0 + 100_000].T @ x[r0:r0 + 100_000]
+    want = torch.tril(want)
+    err = float((got - want).abs().max())
+    assert err < 1e-11 * float(want.abs().max()), err
