@@ -10,6 +10,18 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _release_cached_hbm():
+    """The worker is a separate process that hipMallocs for itself: hand it what this process's torch allocator has cached."""
+    if 'torch' in sys.modules:
+        import gc
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    yield
+
+
 @pytest.mark.gpu
 def test_host_array_abi_from_numpy_without_torch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_native_abi_worker.py')], capture_output=True, text=True,

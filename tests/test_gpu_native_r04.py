@@ -11,6 +11,18 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _release_cached_hbm():
+    """The workers are separate processes that hipMalloc for themselves: hand them what this process's torch allocator has cached."""
+    if 'torch' in sys.modules:
+        import gc
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    yield
+
+
 def _run(script, marker, timeout, *args):
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', script)] + list(args), capture_output=True, text=True, timeout=timeout)
     try:
