@@ -1157,78 +1157,104 @@ int run_parts(const std::vector<PAMD_df *> &parts, F f)
     return 0;
 }
 
-// Partial [J~ | K] of the parts -> part 0 (peer copies over xGMI, or through the host when the devices cannot reach each
-// other), fixed-order sum there, one download.  K of the MO branch is symmetric and travels packed.
-int multi_reduce_download(PAMD_df *m, int nset, int nao, int with_j, int with_k, bool k_symmetric, double *vj, double *vk)
+// Partial [J~ | K] of the parts -> part 0, fixed-order sum there, one download.  K of the MO branch is symmetric and travels
+// packed.  Every part PUSHES its message into its slot of the gather buffer on parts[0]'s device from its own host thread and on
+// its own stream (multi_push): on a node with one xGMI link per pair of GPUs the ndev - 1 copies run concurrently, each on its own
+// link (a gather issued from part 0's single stream would serialise them: 7 x 0.55 ms against a ~14 ms shard at 8 GPUs).
+struct MultiMsg {
+    int nset = 0, nao = 0, with_j = 0, with_k = 0;
+    bool k_symmetric = false;
+    size_t nj = 0, nk = 0, len = 0;
+    double *gather = nullptr;                   // [nparts][len] on parts[0]'s device
+};
+
+int multi_prepare(PAMD_df *m, int nset, int nao, int with_j, int with_k, bool k_symmetric, MultiMsg *mm)
 {
     PAMD_df *h0 = m->parts[0];
-    const int np = (int)m->parts.size();
-    const long npair = h0->npair;
     const size_t n2 = (size_t)nao * nao;
-    const size_t nj = with_j ? (size_t)nset * npair : 0;
-    const size_t nk = with_k ? (size_t)nset * (k_symmetric ? (size_t)npair : n2) : 0;
-    const size_t len = nj + nk;
-    int rc;
-    // every part lays out its message [J~ | K (packed)] in its own work space
-    rc = run_parts(m->parts, [&](int, PAMD_df *h) -> int {
-        PAMD_CHECK_HIP(hipSetDevice(h->device));
-        int r;
-        double *msg = h->workspace("msg", len, &r);
-        if (r) return r;
-        if (with_j) PAMD_CHECK_HIP(hipMemcpyAsync(msg, h->ws["vjtril"].first, nj * 8, hipMemcpyDeviceToDevice, h->st));
-        if (with_k) {
-            const double *d_vk = h->ws["vk"].first;
-            if (k_symmetric) {
-                for (int s = 0; s < nset; s++) {
-                    pack_lower_kernel<<<dim3((nao + 255) / 256, nao), 256, 0, h->st>>>(d_vk + (size_t)s * n2, nao, msg + nj + (size_t)s * npair);
-                    PAMD_CHECK_LAUNCH();
-                }
-            } else {
-                PAMD_CHECK_HIP(hipMemcpyAsync(msg + nj, d_vk, nk * 8, hipMemcpyDeviceToDevice, h->st));
-            }
-        }
-        PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
-        return 0;
-    });
-    if (rc) return rc;
+    mm->nset = nset; mm->nao = nao; mm->with_j = with_j; mm->with_k = with_k; mm->k_symmetric = k_symmetric;
+    mm->nj = with_j ? (size_t)nset * h0->npair : 0;
+    mm->nk = with_k ? (size_t)nset * (k_symmetric ? (size_t)h0->npair : n2) : 0;
+    mm->len = mm->nj + mm->nk;
     PAMD_CHECK_HIP(hipSetDevice(h0->device));
-    double *gather = h0->workspace("gather", (size_t)np * len, &rc);
+    int rc;
+    mm->gather = h0->workspace("gather", m->parts.size() * mm->len, &rc);
     if (rc) return rc;
-    std::vector<double> bounce;
-    for (int p = 0; p < np; p++) {
-        PAMD_df *hp = m->parts[p];
-        const double *src = hp->ws["msg"].first;
-        double *dst = gather + (size_t)p * len;
-        if (hp->device == h0->device) {
-            PAMD_CHECK_HIP(hipMemcpyAsync(dst, src, len * 8, hipMemcpyDeviceToDevice, h0->st));
-        } else if (m->peer_ok) {
-            PAMD_CHECK_HIP(hipMemcpyPeerAsync(dst, h0->device, src, hp->device, len * 8, h0->st));
+    PAMD_CHECK_HIP(hipStreamSynchronize(h0->st));         // (a fresh work space is zeroed on h0's stream)
+    return 0;
+}
+
+// on the part's own thread, after its shard_get_jk: lay out [J~ | K (packed)] and copy it into the part's gather slot
+int multi_push(PAMD_df *m, int p, const MultiMsg &mm)
+{
+    PAMD_df *h = m->parts[p], *h0 = m->parts[0];
+    PAMD_CHECK_HIP(hipSetDevice(h->device));
+    const size_t n2 = (size_t)mm.nao * mm.nao;
+    const long npair = h->npair;
+    int rc;
+    double *dst = mm.gather + (size_t)p * mm.len;
+    const bool same = h->device == h0->device;
+    // same device: straight into the slot; else stage the message here and push it in one copy
+    double *msg = dst;
+    if (!same) {
+        msg = h->workspace("msg", mm.len, &rc);
+        if (rc) return rc;
+    }
+    if (mm.with_j) PAMD_CHECK_HIP(hipMemcpyAsync(msg, h->ws["vjtril"].first, mm.nj * 8, hipMemcpyDeviceToDevice, h->st));
+    if (mm.with_k) {
+        const double *d_vk = h->ws["vk"].first;
+        if (mm.k_symmetric) {
+            for (int s = 0; s < mm.nset; s++) {
+                pack_lower_kernel<<<dim3((mm.nao + 255) / 256, mm.nao), 256, 0, h->st>>>(d_vk + (size_t)s * n2, mm.nao,
+                                                                                      msg + mm.nj + (size_t)s * npair);
+                PAMD_CHECK_LAUNCH();
+            }
         } else {
-            bounce.resize(len);
-            PAMD_CHECK_HIP(hipSetDevice(hp->device));
-            PAMD_CHECK_HIP(hipMemcpy(bounce.data(), src, len * 8, hipMemcpyDeviceToHost));
-            PAMD_CHECK_HIP(hipSetDevice(h0->device));
-            PAMD_CHECK_HIP(hipMemcpy(dst, bounce.data(), len * 8, hipMemcpyHostToDevice));
+            PAMD_CHECK_HIP(hipMemcpyAsync(msg + mm.nj, d_vk, mm.nk * 8, hipMemcpyDeviceToDevice, h->st));
         }
     }
-    double *total = h0->workspace("total", len, &rc);
+    if (!same) {
+        if (m->peer_ok) {
+            PAMD_CHECK_HIP(hipMemcpyPeerAsync(dst, h0->device, msg, h->device, mm.len * 8, h->st));
+        } else {
+            std::vector<double> bounce(mm.len);
+            PAMD_CHECK_HIP(hipMemcpyAsync(bounce.data(), msg, mm.len * 8, hipMemcpyDeviceToHost, h->st));
+            PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+            PAMD_CHECK_HIP(hipSetDevice(h0->device));
+            PAMD_CHECK_HIP(hipMemcpy(dst, bounce.data(), mm.len * 8, hipMemcpyHostToDevice));
+            PAMD_CHECK_HIP(hipSetDevice(h->device));
+        }
+    }
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int multi_sum_download(PAMD_df *m, const MultiMsg &mm, double *vj, double *vk)
+{
+    PAMD_df *h0 = m->parts[0];
+    const int np = (int)m->parts.size(), nset = mm.nset, nao = mm.nao;
+    const long npair = h0->npair;
+    const size_t n2 = (size_t)nao * nao;
+    int rc;
+    PAMD_CHECK_HIP(hipSetDevice(h0->device));
+    double *total = h0->workspace("total", mm.len, &rc);
     if (rc) return rc;
-    sum_parts_kernel<<<1024, 256, 0, h0->st>>>(gather, len, np, total, len);
+    sum_parts_kernel<<<1024, 256, 0, h0->st>>>(mm.gather, mm.len, np, total, mm.len);
     PAMD_CHECK_LAUNCH();
-    if (with_j) {
+    if (mm.with_j) {
         double *d_vj = h0->workspace("vjfull", (size_t)nset * n2, &rc);
         if (rc) return rc;
         if ((rc = PAMD_unpack_tril(total, npair, nset, nao, d_vj, nao, nao, h0->st))) return rc;
         PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vj, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h0->st));
     }
-    if (with_k) {
-        if (k_symmetric) {
+    if (mm.with_k) {
+        if (mm.k_symmetric) {
             double *d_vkf = h0->workspace("vkfull", (size_t)nset * n2, &rc);
             if (rc) return rc;
-            if ((rc = PAMD_unpack_tril(total + nj, npair, nset, nao, d_vkf, nao, nao, h0->st))) return rc;
+            if ((rc = PAMD_unpack_tril(total + mm.nj, npair, nset, nao, d_vkf, nao, nao, h0->st))) return rc;
             PAMD_CHECK_HIP(hipMemcpyAsync(vk, d_vkf, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h0->st));
         } else {
-            PAMD_CHECK_HIP(hipMemcpyAsync(vk, total + nj, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h0->st));
+            PAMD_CHECK_HIP(hipMemcpyAsync(vk, total + mm.nj, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h0->st));
         }
     }
     PAMD_CHECK_HIP(hipStreamSynchronize(h0->st));
@@ -1306,9 +1332,17 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
         if (devs[p] == devs[0]) continue;
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, devs[0], devs[p]) != hipSuccess || !can) { (void)hipGetLastError(); mh->peer_ok = 0; break; }
-        const hipError_t e = hipDeviceEnablePeerAccess(devs[p], 0);
+        hipError_t e = hipDeviceEnablePeerAccess(devs[p], 0);
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) mh->peer_ok = 0;
         (void)hipGetLastError();
+        // ... and the other direction: the parts push into part 0's gather buffer from their own streams
+        int can2 = 0;
+        if (hipDeviceCanAccessPeer(&can2, devs[p], devs[0]) != hipSuccess || !can2) { (void)hipGetLastError(); mh->peer_ok = 0; break; }
+        PAMD_CHECK_HIP(hipSetDevice(devs[p]));
+        e = hipDeviceEnablePeerAccess(devs[0], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) mh->peer_ok = 0;
+        (void)hipGetLastError();
+        PAMD_CHECK_HIP(hipSetDevice(devs[0]));
     }
     guard.p = nullptr;
     *out = mh;
@@ -1439,11 +1473,15 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
     PAMD_REQUIRE(dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
     // one host thread per device contracts that device's shard (the serial decomposition this replaces: df_jk.py:362-381);
     // the partial [J~ | K] are summed on part 0's device and leave in one download
-    int rc = run_parts(h->parts, [&](int, PAMD_df *p) {
-        return shard_get_jk(p, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, nullptr, nullptr, 0);
+    MultiMsg mm;
+    int rc = multi_prepare(h, nset, nao, with_j, with_k, orbo != nullptr, &mm);
+    if (rc) return rc;
+    rc = run_parts(h->parts, [&](int ip, PAMD_df *p) -> int {
+        const int r = shard_get_jk(p, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, nullptr, nullptr, 0);
+        return r ? r : multi_push(h, ip, mm);
     });
     if (rc) return rc;
-    return multi_reduce_download(h, nset, nao, with_j, with_k, orbo != nullptr, vj, vk);
+    return multi_sum_download(h, mm, vj, vk);
 }
 
 }  // extern "C"

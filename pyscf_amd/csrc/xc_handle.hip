@@ -365,6 +365,12 @@ int xc_multi(PAMD_xc *m, const double *fac, int gga, int spin, const double *orb
     std::vector<int> rcs(np, 0);
     std::vector<std::string> msgs(np);
     std::vector<double> accs((size_t)np * 4, 0.0);
+    PAMD_xc *h0 = m->parts[0];
+    PAMD_CHECK_HIP(hipSetDevice(h0->device));
+    int rc0;
+    double *gather = h0->workspace("gather", (size_t)np * len, &rc0);
+    if (rc0) return rc0;
+    PAMD_CHECK_HIP(hipStreamSynchronize(h0->st));
     std::vector<std::thread> th;
     for (int p = 0; p < np; p++)
         th.emplace_back([&, p]() {
@@ -377,7 +383,24 @@ int xc_multi(PAMD_xc *m, const double *fac, int gga, int spin, const double *orb
                 if ((rc = upload_orbitals(h, "0", orbs, nocc[0], signs, &ops[0]))) return rc;
                 if (spin && (rc = upload_orbitals(h, "1", orbs + (size_t)nao * nocc[0], nocc[1], signs ? signs + nocc[0] : nullptr, &ops[1])))
                     return rc;
-                return xc_contract(h, fac, gga, spin, ops, &accs[(size_t)p * 4], nullptr);
+                if ((rc = xc_contract(h, fac, gga, spin, ops, &accs[(size_t)p * 4], nullptr))) return rc;
+                // push this part's matrices into its slot of the gather buffer on parts[0]'s device, from this thread and on this
+                // part's stream: the copies of different parts run concurrently (one xGMI link each)
+                const double *src = h->ws["V"].first;
+                double *dst = gather + (size_t)p * len;
+                if (h->device == h0->device) {
+                    PAMD_CHECK_HIP(hipMemcpyAsync(dst, src, len * 8, hipMemcpyDeviceToDevice, h->st));
+                } else if (m->peer_ok) {
+                    PAMD_CHECK_HIP(hipMemcpyPeerAsync(dst, h0->device, src, h->device, len * 8, h->st));
+                } else {
+                    std::vector<double> bounce(len);
+                    PAMD_CHECK_HIP(hipMemcpy(bounce.data(), src, len * 8, hipMemcpyDeviceToHost));
+                    PAMD_CHECK_HIP(hipSetDevice(h0->device));
+                    PAMD_CHECK_HIP(hipMemcpy(dst, bounce.data(), len * 8, hipMemcpyHostToDevice));
+                    PAMD_CHECK_HIP(hipSetDevice(h->device));
+                }
+                PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+                return 0;
             };
             rcs[p] = body();
             if (rcs[p]) msgs[p] = g_errmsg;
@@ -392,28 +415,8 @@ int xc_multi(PAMD_xc *m, const double *fac, int gga, int spin, const double *orb
         acc_out[k] = 0;
         for (int p = 0; p < np; p++) acc_out[k] += accs[(size_t)p * 4 + k];
     }
-    PAMD_xc *h0 = m->parts[0];
     PAMD_CHECK_HIP(hipSetDevice(h0->device));
     int rc;
-    double *gather = h0->workspace("gather", (size_t)np * len, &rc);
-    if (rc) return rc;
-    std::vector<double> bounce;
-    for (int p = 0; p < np; p++) {
-        PAMD_xc *hp = m->parts[p];
-        const double *src = hp->ws["V"].first;
-        double *dst = gather + (size_t)p * len;
-        if (hp->device == h0->device) {
-            PAMD_CHECK_HIP(hipMemcpyAsync(dst, src, len * 8, hipMemcpyDeviceToDevice, h0->st));
-        } else if (m->peer_ok) {
-            PAMD_CHECK_HIP(hipMemcpyPeerAsync(dst, h0->device, src, hp->device, len * 8, h0->st));
-        } else {
-            bounce.resize(len);
-            PAMD_CHECK_HIP(hipSetDevice(hp->device));
-            PAMD_CHECK_HIP(hipMemcpy(bounce.data(), src, len * 8, hipMemcpyDeviceToHost));
-            PAMD_CHECK_HIP(hipSetDevice(h0->device));
-            PAMD_CHECK_HIP(hipMemcpy(dst, bounce.data(), len * 8, hipMemcpyHostToDevice));
-        }
-    }
     double *total = h0->workspace("total", len, &rc);
     if (rc) return rc;
     xc_sum_parts_kernel<<<1024, 256, 0, h0->st>>>(gather, len, np, total, len);
