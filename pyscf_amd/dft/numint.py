@@ -316,7 +316,8 @@ class NumInt:
         wv = torch.empty((nset, 4, max(ldg, 1)), dtype=f64, device=dev)
         nocc_pad_max = max(o[2] for o in orbsets)
         cmo = torch.empty(ncomp * nocc_pad_max * max(ldg, 1), dtype=f64, device=dev)
-        aow = torch.zeros(plan.max_aow_chunk + 256, dtype=f64, device=dev)
+        aow = torch.empty(plan.max_aow_chunk + 256, dtype=f64, device=dev)       # sub_scale writes every element of a launch group;
+        aow[plan.max_aow_chunk:].zero_()                                         # only the 256-double read slack needs defined values
         aoc_buf = None
         if plan.ao_c is None:
             aoc_buf = torch.zeros(plan.max_ao_chunk + 256, dtype=f64, device=dev)
@@ -442,7 +443,8 @@ class NumInt:
                 all_ops += [tt[1]] if tt[0] == 'op' else [tt[1], tt[2]]
         pad_max = max(o[2] for o in all_ops)
         bufs = [torch.empty(ncomp * pad_max * ldg, dtype=f64, device=dev) for _ in range(3)]   # c0 / cached left / right
-        aow = torch.zeros(plan.max_aow_chunk + 256, dtype=f64, device=dev)
+        aow = torch.empty(plan.max_aow_chunk + 256, dtype=f64, device=dev)       # sub_scale writes every element of a launch group;
+        aow[plan.max_aow_chunk:].zero_()                                         # only the 256-double read slack needs defined values
         aoc_buf = torch.zeros(plan.max_ao_chunk + 256, dtype=f64, device=dev) if plan.ao_c is None else None
         for ch in plan.chunks:
             t0, nt = ch['t0'], ch['t1'] - ch['t0']

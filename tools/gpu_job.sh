@@ -10,7 +10,8 @@ case $JOB in
 suite)      # whole GPU suite, default bench line, smoke
   timeout 2400 python -m pytest tests -q -m gpu -x --durations=12 > $O/pytest_gpu.log 2>&1; tail -18 $O/pytest_gpu.log
   timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 800 $O/bench_default.json; tail -3 $O/bench_default.err
-  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  timeout 900 python bench.py --molecule taxol --no-cpu-baseline > $O/bench_taxol_1gpu.json 2> $O/bench_taxol.err; cut -c1-240 $O/bench_taxol_1gpu.json; tail -2 $O/bench_taxol.err ;;
 tests)      # selected tests: gpu_job.sh tests <pytest args>
   timeout 1800 python -m pytest -q -x --durations=8 "$@" > $O/pytest.log 2>&1; tail -25 $O/pytest.log ;;
 taxol_dump) # converged DF-RKS B3LYP orbitals of config 4 (input of the oracle functional golden) + VALU counters of the build
