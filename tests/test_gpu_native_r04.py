@@ -111,7 +111,7 @@ def test_torch_resident_df_falls_back_to_the_streaming_handle_when_the_tensor_do
     streamed per build); J/K and the SCF energy are those of the in-core object, the device SCF loop steps aside."""
     import numpy as np
     from oracle import ref
-    from pyscf_amd import gto, scf, df, lib
+    from pyscf_amd import gto, scf, df
     from pyscf_amd.data import clusters
     mol = gto.M(atom=clusters.water_cluster(2), basis='cc-pvtz')
     nao = mol.nao

@@ -92,7 +92,6 @@ def test_density_fit_device_list_plumbing_without_a_device():
 
 def test_xc_golden_generator_combines_the_oracle_energy_functional(tmp_path):
     """tools/gen_golden_xc.py --combine-only: E_RKS[D] = E_RHF[D] + (1 - hyb)/4 Tr(D K) + E_xc from two oracle-only files."""
-    import shutil
     g = {'conv_e_rhf_functional': -10.0, 'conv_tr_d_vk': 4.0, 'conv_e_tot_of_the_orbital_source': -11.5}
     jk = tmp_path / 'jk.json'
     jk.write_text(json.dumps(g))
