@@ -27,7 +27,7 @@ def _run(script, marker, timeout, *args):
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', script)] + list(args), capture_output=True, text=True, timeout=timeout)
     try:
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-        with open(os.path.join(ROOT, 'gpurun_out', script.replace('.py', '.log')), 'w') as f:
+        with open(os.path.join(ROOT, 'gpurun_out', script.replace('.py', '') + ('_' + args[0] if args else '') + '.log'), 'w') as f:
             f.write(p.stdout + p.stderr[-3000:])
     except OSError:
         pass
@@ -94,6 +94,23 @@ def test_stock_script_with_a_device_list_reaches_the_reference_golden():
     assert isinstance(m2.with_df, NativeDF) and m2.with_df.devices == [0, 0]
     m2.conv_tol = 1e-10
     assert abs(m2.kernel() - -76.025936299702536) < 1e-8
+
+
+@pytest.mark.gpu
+def test_config4_taxol_sharded_eight_ways_through_the_handle_vs_oracle_golden():
+    """BASELINE config 4 as it is meant to run - aux-L sharded 8 ways - through the real multi-part code path (eight parts on the
+    one test GPU: sharded build, eight host threads, gather, fixed-order sum) against the oracle-only taxol golden."""
+    _run('_native_cfg45_worker.py', 'NATIVE_CONFIG4_OK', 1500, 'config4')
+
+
+@pytest.mark.gpu
+def test_config5_whole_tensor_out_of_core_on_one_gpu_vs_oracle_goldens():
+    """BASELINE config 5, all 14 848 aux rows (560 GB) on ONE GPU: resident rows + ~330 GB streamed from page-locked host memory
+    per build; J / K of a seeded local density against the sum of two oracle-only goldens covering every row."""
+    for name in ('h2o128_ccpvdz_rows0-7424_local_oracle.json', 'h2o128_ccpvdz_rows7424-14848_local_oracle.json'):
+        if not os.path.exists(os.path.join(ROOT, 'tests', 'golden', name)):
+            pytest.skip('%s not generated (tools/gen_golden_shard_local.py --rows ...)' % name)
+    _run('_native_cfg45_worker.py', 'NATIVE_CONFIG5_OK', 2400, 'config5')
 
 
 def test_library_exports_the_r04_handle_api_without_torch():
