@@ -15,11 +15,22 @@ ap.add_argument('--level-shift', type=float, default=0.0)
 ap.add_argument('--max-cycle', type=int, default=50)
 ap.add_argument('--dump-orbitals', default='', help='.npz: orbo = C_occ sqrt(occ) and e_tot of the converged state (input of tools/gen_golden_streaming.py)')
 ap.add_argument('--host-loop', action='store_true', help='the numpy SCF loop instead of the HBM-resident one')
+ap.add_argument('--native', action='store_true', help='J/K through the host-array C handle (NativeDF): rows that do not fit HBM are streamed from '
+                'page-locked host memory - e.g. (H2O)_128 cc-pVDZ (560 GB tensor) on ONE GPU')
+ap.add_argument('--devices', default='', help='with --native: comma list of HIP devices for the handle')
 a = ap.parse_args()
 if a.basis is None:
     a.basis = 'def2-tzvp' if a.molecule == 'taxol' else 'cc-pvtz'
 mol = gto.M(atom=clusters.taxol() if a.molecule == 'taxol' else clusters.water_cluster(a.nwater), basis=a.basis, verbose=4)
-mf = (dft.RKS(mol, xc=a.xc) if a.xc else scf.RHF(mol)).density_fit()
+mf = (dft.RKS(mol, xc=a.xc) if a.xc else scf.RHF(mol))
+if a.native:
+    from pyscf_amd.df.native import NativeDF
+    devs = [int(d) for d in a.devices.split(',')] if a.devices else None
+    t0 = time.perf_counter()
+    mf = mf.density_fit(with_df=NativeDF(mol, devices=devs).build())
+    print('NativeDF built in %.1f s: layout %s' % (time.perf_counter() - t0, mf.with_df.layout()), flush=True)
+else:
+    mf = mf.density_fit()
 mf.conv_tol = a.conv_tol
 mf.level_shift = a.level_shift
 mf.max_cycle = a.max_cycle
