@@ -8,7 +8,7 @@
 //                           the normalisation of gen_grid.get_partition (pyscf/dft/gen_grid.py:341-419), host arrays in / out
 //   PAMD_xc_create          libcint-format tables of the molecule + the quadrature (coords, weights as a Grids object holds them,
 //                           pyscf/dft/gen_grid.py:487-744) -> handle owning the block-sparse plan of pyscf_amd/dft/sparse_grid.py:
-//                           grid tiles of 512 points, per tile the AO shells with a value above 1e-14 (the role of GTO_screen_index,
+//                           grid tiles of 512 points, per tile the AO shells with a value above 1e-13 (the role of GTO_screen_index,
 //                           lib/gto/grid_ao_drv.c:32-123, computed from the values), their AO values compacted and cached in HBM
 //   PAMD_xc_nr_rks          numint.nr_rks (numint.py:1074-1190) for densities given by orbital factors D = sum_i s_i c_i c_i^T
 //                           (occupied orbitals scaled by sqrt(occ), s = +1; or a signed eigen-factorisation made by the caller):
@@ -36,7 +36,7 @@ using namespace pamd::host;
 namespace {
 
 constexpr int XC_G = 512;                       // grid points per tile (NumInt.sparse_tile)
-constexpr double XC_CUTOFF = 1e-14;             // NumInt.sparse_cutoff
+constexpr double XC_CUTOFF = 1e-13;             // NumInt.sparse_cutoff (the reference's `cutoff = CUTOFF * 1e2`, numint.py:2845)
 constexpr size_t XC_BLOCK_BYTES = 6ul << 30;    // dense evaluation block / orbital-product work space
 
 struct XcChunk {                                // a launch group of consecutive tiles

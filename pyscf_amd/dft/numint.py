@@ -79,7 +79,10 @@ class NumInt:
         # block-sparse path (dft/sparse_grid.py, csrc/xc_sparse.hip): compact AO subsets per grid tile
         self.sparse = True              # False: the dense tile-masked pipeline below (kept for comparison / tests)
         self.sparse_tile = 512          # grid points per tile (multiple of 128; 512 measured best at (H2O)_32: 30.1 ms vs 32.0 / 35.1 for 1024 / 2048)
-        self.sparse_cutoff = 1e-14      # a shell is active on a tile if some value / gradient component exceeds this
+        self.sparse_cutoff = 1e-13      # a shell is active on a tile if some value / gradient component exceeds this.  r04: 1e-13, the
+                                        # reference's own threshold for the sparse contractions (numint.py:1120,2845 `cutoff = CUTOFF * 1e2`;
+                                        # its AO screen itself is the 1e-15 exponent estimate): nelec, exc and vxc of config 3 unchanged to
+                                        # 12 digits against 1e-14, 5 % fewer active functions (profiles/r04/xcbench_cutoff_sweep.log)
         self.sparse_chunk_points = 1 << 21  # grid points per launch group (bounds the c = ao . C workspace: 5.5 GB at config 3); r04: one
                                             # group for the whole grid - 9 launches per kernel cost 0.9 ms of tails in sub_vmat alone
         self.vmat_sym = True            # r04: V = M + M^T on balanced blocks, lower triangle only (PAMD_sub_vmat_sym); False: the r03 kernel

@@ -26,7 +26,7 @@ taxol_dump) # converged DF-RKS B3LYP orbitals of config 4 (input of the oracle f
   cd $R; tail -2 $O/build_valu.log; find $O -name "*.csv" | head; find $O -name "*.db" -delete ;;
 xcab)       # XC leg A/B: r03 sub_vmat vs r04 sub_vmat_sym, with / without the XCD-aware work order
   : > $O/xcbench.log
-  for v in "--vmat-sym 1 --chunk 2000000" "--vmat-sym 1 --chunk 2000000 --tune-xc vmatprobe=1" "--vmat-sym 1 --chunk 2000000 --tile 1024" "--vmat-sym 1 --chunk 2000000 --tile 1024 --tune-xc vmatprobe=1" "--vmat-sym 1 --chunk 2000000 --tile 768"; do
+  for v in "" "--cutoff 1e-13" "--cutoff 1e-12" "--cutoff 1e-11"; do
     echo "== $v" >> $O/xcbench.log
     timeout 400 python tools/xcbench.py --steps 5 $v 2>/dev/null | tail -1 >> $O/xcbench.log
   done
@@ -34,7 +34,7 @@ xcab)       # XC leg A/B: r03 sub_vmat vs r04 sub_vmat_sym, with / without the X
 import json
 for l in open('gpurun_out/xcab/xcbench.log'):
     if l.startswith('=='): print(l.strip()); continue
-    d=json.loads(l); print('   wall', d['wall_ms_per_call'], d['kernel_ms'], d['executed']['ao_dot_aow'])
+    d=json.loads(l); print('   wall', d['wall_ms_per_call'], 'nelec %.12f exc %.12f' % (d['nelec'], d['exc']), d['kernel_ms'], d['plan']['density'], d['plan']['density2'])
 PY
   ;;
 xcpmc)      # counters of the XC kernels for the sub_vmat variants: gpu_job.sh xcpmc
