@@ -299,6 +299,11 @@ int PAMD_sub_gather_ao(const double *d_dense, long dense_rows, int ldao, int nco
 int PAMD_sub_orb_dot(const double *d_ao_c, const long *d_ao_off, const long *d_idx_off, const int *d_ld, const int *d_idx,
                      int ntile, int G, int ncomp, const double *d_orb, int ldo, int nocc_pad, double *d_cmo,
                      long comp_stride, long ldc, void *stream);   /* cmo[c][i][t G + g] = sum_mu orb[idx[mu]][i] ao_c[t][c][g][mu] */
+/* r04: rho[4][ldg] (rho, grad rho) of sum_i sign_i c_i c_i^T on the GGA image in one kernel (= PAMD_sub_orb_dot + PAMD_rho_from_mo,
+ * numint.py:328-469); returns 1 without launching when the shape has no fused kernel (the caller then uses the two calls) */
+int PAMD_sub_orb_rho(const double *d_ao_c, const long *d_ao_off, const long *d_idx_off, const int *d_ld, const int *d_idx,
+                     int ntile, int G, const double *d_orb, int ldo, int nocc, int nocc_pad, const double *d_sign, double *d_rho,
+                     long ldg, void *stream);
 int PAMD_sub_scale_ao(const double *d_ao_c, const long *d_ao_off, const long *d_aow_off, const int *d_ld, int ntile, int G,
                       int ncomp, int ld_max, const double *d_wv, long ldg, double *d_aow_c, void *stream);
 int PAMD_sub_vmat(const double *d_ao_c, const long *d_ao_off, const double *d_aow_c, const long *d_aow_off,

@@ -299,8 +299,7 @@ int xc_contract(PAMD_xc *h, const double *fac, int gga, int spin, OrbOp *ops, do
     if (rc) return rc;
     double *d_wv = h->workspace("wv", (size_t)nset * 4 * ldg, &rc);
     if (rc) return rc;
-    double *d_cmo = h->workspace("cmo", (size_t)ncomp * nocc_pad_max * ldg, &rc);
-    if (rc) return rc;
+    double *d_cmo = nullptr;                  // only the unfused orbital product needs it (LDA, fewer than 128 orbitals per chunk)
     double *d_aow = h->workspace("aow", (size_t)pl.max_aow, &rc);
     if (rc) return rc;
     PAMD_CHECK_HIP(hipMemsetAsync(d_M, 0, (size_t)nset * n2 * 8, st));
@@ -318,6 +317,18 @@ int xc_contract(PAMD_xc *h, const double *fac, int gga, int spin, OrbOp *ops, do
                 continue;
             }
             const long cs = (long)ops[s].nocc_pad * npts;
+            if (gga) {
+                // rho / grad rho in the orbital product's epilogue (no c[comp][i][g] buffer); 1 = no fused kernel for this shape
+                if (ops[s].nocc_pad > 160) PAMD_CHECK_HIP(hipMemsetAsync(rho_s, 0, (size_t)4 * ldg * 8, st));
+                rc = PAMD_sub_orb_rho(pl.d_ao_c, ao_off, idx_off, ld, pl.d_idx, nt, G, ops[s].d_orb, (int)ops[s].ldo, ops[s].nocc,
+                                      ops[s].nocc_pad, ops[s].d_sign, rho_s, ldg, st);
+                if (rc < 0) return rc;
+                if (rc == 0) continue;
+            }
+            if (!d_cmo) {
+                d_cmo = h->workspace("cmo", (size_t)ncomp * nocc_pad_max * ldg, &rc);
+                if (rc) return rc;
+            }
             if ((rc = PAMD_sub_orb_dot(pl.d_ao_c, ao_off, idx_off, ld, pl.d_idx, nt, G, ncomp, ops[s].d_orb, (int)ops[s].ldo, ops[s].nocc_pad,
                                        d_cmo, cs, npts, st)))
                 return rc;

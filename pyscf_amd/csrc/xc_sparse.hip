@@ -23,6 +23,7 @@
 using namespace pamd;
 
 static int g_orb_dot_dma = 1;
+static int g_orb_rho_fused = 1;  // GGA: rho / grad rho in the orbital product's epilogue (PAMD_sub_orb_rho); A/B switch "orbrho"
 static int g_vmat_probe = 0;   // benchmarking probes of sub_vmat_sym ("vmatprobe", see the kernel)
 static int g_vmat_burst = 0;   // sub_vmat_sym: DMA rows of the next k-tile in one burst behind the first MFMA group ("vmatburst")
 static int g_vmat_xcd = 1;     // sub_vmat*: work items of one tile on ONE XCD (its L2 then serves the panel re-reads); A/B switch "vmatxcd"
@@ -165,6 +166,139 @@ __global__ __launch_bounds__(256, 2) void sub_orb_dot2_kernel(const double *__re
                 if (i < nocc_pad) out[(long)i * ldc + n] = acc[a][b][r];
             }
         }
+}
+
+// r04: the orbital product fused with the density evaluation (GGA): rho, grad rho straight from the accumulators, the
+// 5.5 GB c[comp][i][g] buffer of config 3 never exists (PAMD_sub_orb_dot + PAMD_rho_from_mo in one kernel; numint.py:328-469
+// eval_rho2 on the active shells).  Same k-loop, operands and LDS image as sub_orb_dot2_kernel; what changes is which rows of
+// the compact image make up the 128 B columns of a workgroup: 32 grid points x the FOUR components, laid out so that wave column
+// wc owns points [16 wc, 16 wc + 16) and its b-th MFMA column tile is component b.  Lane (fk, fn), register r of acc[a][b] then
+// holds c_b[i][g] for one orbital i = tile row and one point g = fn for ALL four b: rho += s_i c_0^2, grad rho_x += 2 s_i c_0 c_x
+// are lane-local products; the sums over the orbitals run over (a, r) in the lane, over fk by two wave shuffles, over the two
+// wave rows through 2 KB of LDS.  Orbital chunks beyond the first (nocc_pad > 160) add up by FP64 atomics into the zeroed rho.
+// grid: x = 32-point slice of the tile, z = tile * nchunk + chunk.
+__global__ __launch_bounds__(256, 2) void sub_orb_rho_kernel(const double *__restrict__ ao_c, SubTiles tl, int G, int nchunk,
+                                                             const double *__restrict__ orb, int ldo, int nocc,
+                                                             const double *__restrict__ sign, double *__restrict__ rho, long ldg)
+{
+    __shared__ double sa0[KB * LDN + KB * 32];
+    __shared__ double sa1[KB * LDN + KB * 32];
+    __shared__ double sq0[KB * LDN];
+    __shared__ double sq1[KB * LDN];
+    constexpr int RB = KB * LDN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = blockIdx.z / nchunk, chunk = blockIdx.z - t * nchunk;
+    const int ld = tl.ld[t];
+    const int g0 = blockIdx.x * 32, m0 = chunk * 160;
+    const int *idx = tl.idx + tl.idx_off[t];
+    const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc((void *)(ao_c + tl.ao_off[t] + (long)g0 * ld), 0, 0xffffffff,
+                                                                        0x00020000);
+    const __amdgpu_buffer_rsrc_t r_orb = __builtin_amdgcn_make_buffer_rsrc((void *)(orb + m0), 0, 0xffffffff, 0x00020000);
+    const int ldo8 = ldo * 8;
+    const int voff = lane * 16;
+    const int rrow = lane >> 4;
+    const int voff_remcol = (128 + ((((lane & 15) * 2) - 16 * (rrow & 1)) & 31)) * 8;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+    const int offa = fk * LDN + wr * 64 + fn;
+    const int offr = RB + fk * 32 + ((wr * 16 + fn + 16 * (fk & 1)) & 31);
+    const int pl = fn & 7, bodd = (fn >> 3) & 1;
+    const int offb_tr = (wc * 8 + (fn >> 3)) * 128 + (((pl ^ bodd) * 8) + ((fk >> 1) ^ (pl & 1))) * 2 + (fk & 1);
+    int atr[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) atr[g] = offb_tr + (((2 * g) ^ (pl & 6))) * 2;
+    int voff_tr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int blk = wave * 4 + j;
+        const int pl_s = (lane >> 3) ^ (blk & 1);
+        const int kp = (lane & 7) ^ pl_s;
+        const int n = blk * 8 + pl_s;                              // B column of the workgroup: wave column n >> 6, its tile (n >> 4) & 3
+        const int comp = (n >> 4) & 3, pt = ((n >> 6) << 4) | (n & 15);
+        voff_tr[j] = (int)((((long)comp * G + pt) * ld + 2 * kp) * 8);
+    }
+
+    double4_t acc[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    auto stage_row = [&](int k0, double *da, double *db, int j) {
+        const int k = wave * 4 + j;
+        const int row = idx[k0 + k];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_orb, (__attribute__((address_space(3))) void *)(da + k * LDN), 16, voff, row * ldo8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_b, (__attribute__((address_space(3))) void *)(db + k * 128), 16, voff_tr[j], k0 * 8, 0, 0);
+        if (j == 0) {
+            const int rowl = idx[k0 + wave * 4 + rrow];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_orb, (__attribute__((address_space(3))) void *)(da + RB + wave * 128), 16,
+                                                     rowl * ldo8 + voff_remcol, 0, 0, 0);
+        }
+    };
+    auto step = [&](const double *ca, const double *cb, double *na, double *nb, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kn = (k0 + KB < ld) ? k0 + KB : k0;
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[5], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
+            af[4] = ca[offr + kk * 32];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = cb[atr[kk >> 2] + b * 256];
+            stage_row(kn, na, nb, kk >> 2);
+#pragma unroll
+            for (int a = 0; a < 5; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
+    for (int k0 = 0; k0 < ld; k0 += 2 * KB) {
+        step(sa0, sq0, sa1, sq1, k0);
+        if (k0 + KB < ld) step(sa1, sq1, sa0, sq0, k0 + KB);
+    }
+    // ---- rho, grad rho of the wave's 16 points over its 80 orbitals
+    double p0 = 0, px = 0, py = 0, pz = 0;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = m0 + (a < 4 ? wr * 64 + a * 16 : 128 + wr * 16) + fk + 4 * r;
+            const double c0 = acc[a][0][r];
+            const double w = (sign != nullptr && i < nocc) ? sign[i] * c0 : c0;      // rows i >= nocc: zero orbital columns, c0 = 0
+            p0 += w * c0;
+            px += w * acc[a][1][r];
+            py += w * acc[a][2][r];
+            pz += w * acc[a][3][r];
+        }
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+        p0 += __shfl_xor(p0, off, 64);
+        px += __shfl_xor(px, off, 64);
+        py += __shfl_xor(py, off, 64);
+        pz += __shfl_xor(pz, off, 64);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the last k-tile re-loaded itself: let it land before the LDS is reused
+    __syncthreads();
+    double *part = sa0;                                      // [wave][4][16]
+    if (fk == 0) {
+        part[(wave * 4 + 0) * 16 + fn] = p0;
+        part[(wave * 4 + 1) * 16 + fn] = 2.0 * px;
+        part[(wave * 4 + 2) * 16 + fn] = 2.0 * py;
+        part[(wave * 4 + 3) * 16 + fn] = 2.0 * pz;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int c = tid >> 5, pt = tid & 31, wcol = pt >> 4, f = pt & 15;
+        const double v = part[((0 * 2 + wcol) * 4 + c) * 16 + f] + part[((1 * 2 + wcol) * 4 + c) * 16 + f];
+        double *dst = rho + (long)c * ldg + (long)t * G + g0 + pt;
+        if (nchunk == 1) *dst = v;
+        else unsafeAtomicAdd(dst, v);
+    }
 }
 
 // aow_c[tile][g][mu] = sum_c wv[c][tile*G + g] ao_c[tile][c][g][mu];  grid: x = column chunk, y = g, z = tile
@@ -487,6 +621,7 @@ extern "C" {
 int PAMD_set_tuning_xc(const char *key, int value)
 {
     if (strcmp(key, "orbdotdma") == 0) { g_orb_dot_dma = value; return 0; }
+    if (strcmp(key, "orbrho") == 0) { g_orb_rho_fused = value; return 0; }
     if (strcmp(key, "vmatxcd") == 0) { g_vmat_xcd = value; return 0; }
     if (strcmp(key, "vmatburst") == 0) { g_vmat_burst = value; return 0; }
     if (strcmp(key, "vmatprobe") == 0) { g_vmat_probe = value; return 0; }
@@ -536,6 +671,31 @@ int PAMD_sub_orb_dot(const double *d_ao_c, const long *d_ao_off, const long *d_i
     default: LAUNCH_S(10); break;
     }
 #undef LAUNCH_S
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// r04: rho[4][ldg] (rho, grad rho; entry t*G + g) of the density sum_i sign_i c_i c_i^T on the GGA compact image in ONE kernel
+// (PAMD_sub_orb_dot + PAMD_rho_from_mo without the c[comp][i][g] buffer; numint.py:328-469).  Returns 1 - nothing launched -
+// when the shape has no fused kernel (fewer than 128 orbitals per 160-chunk, unaligned operands): the caller then runs the two
+// separate calls.  d_sign nullable [nocc].  With more than one orbital chunk (nocc_pad > 160) d_rho must be zeroed by the
+// caller (the chunks add up by atomics); with one chunk every entry of the ntile * G points is written.
+int PAMD_sub_orb_rho(const double *d_ao_c, const long *d_ao_off, const long *d_idx_off, const int *d_ld, const int *d_idx,
+                     int ntile, int G, const double *d_orb, int ldo, int nocc, int nocc_pad, const double *d_sign, double *d_rho,
+                     long ldg, void *stream)
+{
+    PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
+    PAMD_REQUIRE(G % NT == 0, "tile size must be a multiple of 128");
+    if (ntile == 0 || nocc_pad == 0) return 0;
+    const int mt_total = nocc_pad / 16;
+    const int nchunk = ceil_div(mt_total, 10);
+    const int mt = ceil_div(mt_total, nchunk);
+    if (!(g_orb_rho_fused && g_orb_dot_dma && mt >= 8 && ldo >= nchunk * 160 && ldo % 2 == 0 && (uintptr_t)d_orb % 16 == 0 &&
+          (uintptr_t)d_ao_c % 16 == 0 && (long)ntile * nchunk < 65536))
+        return 1;
+    SubTiles tl{d_ao_off, nullptr, d_idx_off, d_ld, d_idx};
+    dim3 grid(G / 32, 1, ntile * nchunk);
+    sub_orb_rho_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_ao_c, tl, G, nchunk, d_orb, ldo, nocc, d_sign, d_rho, ldg);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

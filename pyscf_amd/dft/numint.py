@@ -85,6 +85,7 @@ class NumInt:
                                         # 12 digits against 1e-14, 5 % fewer active functions (profiles/r04/xcbench_cutoff_sweep.log)
         self.sparse_chunk_points = 1 << 21  # grid points per launch group (bounds the c = ao . C workspace: 5.5 GB at config 3); r04: one
                                             # group for the whole grid - 9 launches per kernel cost 0.9 ms of tails in sub_vmat alone
+        self.fuse_rho = True            # r04: GGA densities in the epilogue of the orbital product (PAMD_sub_orb_rho)
         self.vmat_sym = True            # r04: V = M + M^T on balanced blocks, lower triangle only (PAMD_sub_vmat_sym); False: the r03 kernel
         self.ao_cache = 'auto'          # keep the compact AO image in HBM across calls: True / False / 'auto' (if it fits)
         self.ao_cache_reserve = 40 << 30    # HBM left free after caching ('auto')
@@ -318,7 +319,7 @@ class NumInt:
         rho = torch.zeros((nset, 4, max(ldg, 1)), dtype=f64, device=dev)
         wv = torch.empty((nset, 4, max(ldg, 1)), dtype=f64, device=dev)
         nocc_pad_max = max(o[2] for o in orbsets)
-        cmo = torch.empty(ncomp * nocc_pad_max * max(ldg, 1), dtype=f64, device=dev)
+        cmo = None                                     # allocated when the unfused orbital product runs (LDA, small nocc)
         aow = torch.empty(plan.max_aow_chunk + 256, dtype=f64, device=dev)       # sub_scale writes every element of a launch group;
         aow[plan.max_aow_chunk:].zero_()                                         # only the 256-double read slack needs defined values
         aoc_buf = None
@@ -338,6 +339,22 @@ class NumInt:
                 if nocc == 0:
                     rho[s].zero_()
                     continue
+                if gga and self.fuse_rho:
+                    # r04: rho / grad rho in the orbital product's epilogue - the c[comp][i][g] buffer (5.5 GB at config 3) is
+                    # never written (PAMD_sub_orb_rho; returns 1 when the shape has no fused kernel)
+                    if nocc_pad > 160:
+                        rho[s].zero_()                     # several orbital chunks add up by atomics
+                    args = (_ptr(aoc), tabs[0], tabs[2], tabs[3], _ptr(plan.idx), _c.c_int(nt), _c.c_int(G), _ptr(orb),
+                            _c.c_int(ldo), _c.c_int(nocc), _c.c_int(nocc_pad), _ptr(sign) if sign is not None else _c.c_void_p(0),
+                            _ptr(rho[s]), _c.c_long(ldg), st)
+                    rc = (self.kernel_timer.call('ao_dot_mo', lib.PAMD_sub_orb_rho, *args) if self.kernel_timer is not None
+                          else lib.PAMD_sub_orb_rho(*args))
+                    if rc == 0:
+                        continue
+                    if rc < 0:
+                        _lib_mod.check(rc)
+                if cmo is None:
+                    cmo = torch.empty(ncomp * nocc_pad_max * max(ldg, 1), dtype=f64, device=dev)
                 self._call('ao_dot_mo', lib.PAMD_sub_orb_dot, _ptr(aoc), tabs[0], tabs[2], tabs[3], _ptr(plan.idx),
                            _c.c_int(nt), _c.c_int(G), _c.c_int(ncomp), _ptr(orb), _c.c_int(ldo), _c.c_int(nocc_pad),
                            _ptr(cmo), _c.c_long(nocc_pad * npts), _c.c_long(npts), st)

@@ -80,6 +80,26 @@ def test_sub_kernels_vs_numpy(G, ncomp, nocc):
         want_sub[:, :, k * G:(k + 1) * G] = np.einsum('cgm,mi->cig', dense[:, k * G:(k + 1) * G, cols], cmat[cols])
     got = cmo.view(ncomp, nocc_pad, npts)[:, :nocc].cpu().numpy()
     assert np.abs(got - want_sub).max() < 1e-11 * max(1.0, np.abs(want_sub).max())
+    if ncomp == 4:
+        # r04: the same product with rho / grad rho taken in its epilogue (PAMD_sub_orb_rho), signed "occupations"
+        sg = np.where(rng.random(nocc) < 0.3, -1.0, 1.0)
+        for sign in (None, sg):
+            w = want_sub if sign is None else want_sub * sign[None, :, None]
+            rho_want = np.stack([np.einsum('ig,ig->g', w[0], want_sub[0])] +
+                                [2 * np.einsum('ig,ig->g', w[0], want_sub[c]) for c in (1, 2, 3)])
+            ldg = npts + 64
+            rho = torch.full((4, ldg), 3.0 if nocc_pad <= 160 else 0.0, dtype=torch.float64, device=dev)     # several chunks add into zeros
+            d_sg = t(sign) if sign is not None else None
+            rc = so.PAMD_sub_orb_rho(_p(ao_c), _p(d_ao_off), _p(d_idx_off), _p(d_ld), _p(d_idx), ntile, G, _p(orb), ldo, nocc, nocc_pad,
+                                     _p(d_sg) if d_sg is not None else None, _p(rho), C.c_long(ldg), st)
+            mt_total = nocc_pad // 16
+            nchunk = -(-mt_total // 10)
+            if -(-mt_total // nchunk) < 8:                      # fewer than 128 orbitals per 160-chunk
+                assert rc == 1                                  # no fused kernel for this shape: the caller runs the two calls
+                continue
+            assert rc == 0, lib.load_library().PAMD_last_error()
+            got_rho = rho[:, :npts].cpu().numpy()
+            assert np.abs(got_rho - rho_want).max() < 1e-11 * max(1.0, np.abs(rho_want).max()), (nocc, sign is not None)
     # aow = sum_c wv_c ao_c ; M[idx, idx] += ao0^T aow
     wv = rng.standard_normal((4, npts))
     d_wv = t(wv)

@@ -26,7 +26,8 @@ taxol_dump) # converged DF-RKS B3LYP orbitals of config 4 (input of the oracle f
   cd $R; tail -2 $O/build_valu.log; find $O -name "*.csv" | head; find $O -name "*.db" -delete ;;
 xcab)       # XC leg A/B: r03 sub_vmat vs r04 sub_vmat_sym, with / without the XCD-aware work order
   : > $O/xcbench.log
-  for v in "" "--cutoff 1e-13" "--cutoff 1e-12" "--cutoff 1e-11"; do
+  timeout 600 python -m pytest -q -x tests/test_gpu_xc_sparse.py tests/test_gpu_dft.py -m gpu -k "not fxc" > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+  for v in "--tune-xc orbrho=0" "--tune-xc orbrho=1"; do
     echo "== $v" >> $O/xcbench.log
     timeout 400 python tools/xcbench.py --steps 5 $v 2>/dev/null | tail -1 >> $O/xcbench.log
   done
