@@ -181,6 +181,7 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
                     int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work,
                     void *stream);
 long PAMD_nr_e2_rho_worksize(int nL, int ldx, int nocc_pad);             /* doubles of d_rho_work */
+int  PAMD_e2_orb_ld(int nocc_pad);                                       /* ldo that lets every half-transform kernel tile nocc_pad columns */
 /* packed-operand transform with the diagonal-block side image d_diag[nL][ceil(ldx/128)][128][128] of the same aux rows
  * (both triangles of the 128 x 128 blocks on the diagonal of every B_L, 0 beyond nao; 14 % of the packed size at nao 1856):
  * the k-tiles that cross the diagonal are then read once, unmasked - what AO2MOtranse2_nr_s2's per-row NPdunpack_tril

@@ -935,6 +935,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
             const int mt = o.nocc_pad / 16, nchunk = (mt + 9) / 10;
             ldo = std::max<long>(ldo, (long)nchunk * (((mt + nchunk - 1) / nchunk + 1) / 2) * 32);
             ldo = std::max<long>(ldo, std::min(round_up(o.nocc_pad, 160), round_up(o.nocc_pad, 128)));
+            ldo = std::max<long>(ldo, PAMD_e2_orb_ld(o.nocc_pad));
             o.ldo = ldo;
             std::vector<double> oh((size_t)rows * ldo, 0.0);
             for (int p = 0; p < nao; p++)
@@ -949,7 +950,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
     }
     // general-DM branch: the density itself is the "orbital" operand
     double *d_orb_dm = nullptr;
-    const long ldo_dm = rows > 160 ? round_up(rows, 160) : round_up(rows, 32);    // whole 32-column wave tiles
+    const long ldo_dm = std::max<long>(rows > 160 ? round_up(rows, 160) : round_up(rows, 32), PAMD_e2_orb_ld(rows));   // whole wave tiles
     if (with_k && !orbo && nL > 0) {
         d_orb_dm = h->workspace("orb_dm", (size_t)rows * ldo_dm, &rc);
         if (rc) return rc;
@@ -993,7 +994,10 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                 blk = std::min<long>(blk, sg.n);
                 const long nblk = (sg.n + blk - 1) / blk;
                 blk = (sg.n + nblk - 1) / nblk;
-                double *d_X = h->workspace("X", (size_t)blk * o.nocc_pad * ldx, &rc);
+                // rows per aux index in X = the orbitals themselves (no padding to 16): the SYRK contracts nb * no rows, padded with
+                // zero rows to a whole k-tile at the END of the block only
+                const int xr = o.no;
+                double *d_X = h->workspace("X", ((size_t)blk * xr + 16) * ldx, &rc);
                 if (rc) return rc;
                 double *d_rw = nullptr;
                 if (fused) {
@@ -1005,10 +1009,10 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                     const double *sub = sg.rows + (size_t)b0 * npair;
                     double *rho_b = fused ? d_rho + (size_t)s * nL + sg.row0 + b0 : nullptr;
                     if (sg.sq)
-                        rc = PAMD_nr_e2_square(sg.sq + (size_t)b0 * rows * rows, rows, rows, nb, nao, o.d_orb, (int)o.ldo, rows, o.nocc_pad,
+                        rc = PAMD_nr_e2_square(sg.sq + (size_t)b0 * rows * rows, rows, rows, nb, nao, o.d_orb, (int)o.ldo, rows, xr,
                                                d_X, ldx, rho_b, d_rw, st);
                     else
-                        rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, o.d_orb, (int)o.ldo, rows, o.nocc_pad, d_X, ldx, rho_b, d_rw,
+                        rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, o.d_orb, (int)o.ldo, rows, xr, d_X, ldx, rho_b, d_rw,
                                                   sg.diag ? sg.diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st);
                     if (rc) return rc;
                     if (fused) {
@@ -1021,7 +1025,9 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                             if ((rc = PAMD_df_vj_pass2(sub, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side))) return rc;
                         }
                     }
-                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, part_s, nao, nao, nao, (long)nb * o.nocc_pad, syrk_flags, nsplit, st))) return rc;
+                    const long kx = (long)nb * xr, kx16 = round_up(kx, 16);
+                    if (kx16 > kx) { PAMD_CHECK_HIP(hipMemsetAsync(d_X + (size_t)kx * ldx, 0, (size_t)(kx16 - kx) * ldx * 8, st)); }
+                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, part_s, nao, nao, nao, kx16, syrk_flags, nsplit, st))) return rc;
                 }
             } else {
                 // ---- general-DM branch: T_L = B_L D, K = sum_L T_L^T B_L (df_jk.py:382-407)

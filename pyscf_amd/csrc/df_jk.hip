@@ -561,13 +561,33 @@ __device__ __forceinline__ void dma_row(__amdgpu_buffer_rsrc_t r, double *lds_ds
 // column tile for TWO aux rows (separate launch, tuning "e2merge" = 0); 2 (default, r03) = one launch for both: the rows
 // blockIdx.y >= nL of the grid carry the pair workgroups - no second kernel boundary, and their ~2 rounds of workgroups fill up
 // the last round of the main ones (2 x 0.5 ms of a 110 ms step).
-template <int NA, bool RHO, int PAIRM>
+// blockIdx.x -> (AO column tile, orbital chunk) of the two v2 half-transform kernels when there are several chunks (r04).
+// Workgroup b of a launch runs on XCD b % 8, so the plain  x = ptile * nchunk + chunk  puts chunk c of EVERY tile on the XCDs
+// of one parity (nchunk = 2): the two chunks of a tile - same tensor panel - never share an L2, and with chunks of different
+// cost (wide last chunk) half of the XCDs carry all the cheap ones.  Mapped: groups of 8 column tiles, inside a group
+// x = chunk * 8 + tile, so the chunks of one tile are 8 workgroups apart = the same XCD, a few dispatches apart, and every XCD
+// sees every chunk kind.  The last group holds what is left of the P tiles.
+__device__ __forceinline__ void e2_chunk_map(int x, int nchunk, int P, int xmap, int &ptile, int &chunk)
+{
+    if (!xmap || nchunk == 1) { ptile = x / nchunk; chunk = x - ptile * nchunk; return; }
+    const int gsz = 8 * nchunk, g = x / gsz, j = x - g * gsz;
+    int pg = P - 8 * g;
+    pg = pg > 8 ? 8 : pg;
+    chunk = j / pg;
+    ptile = 8 * g + j - chunk * pg;
+}
+
+// WM > 0 (r04, NA = 4 only): the LAST orbital chunk holds WM < 8 MFMA tiles and runs in a 1 x 4 wave arrangement - every wave
+// takes all WM orbital tiles x 32 AO columns (WM + 2 fragment reads per 2 WM MFMAs), so no wave of the workgroup multiplies
+// padding: nocc = 226 (taxol) costs 8 + 7 tiles instead of 2 x 8.  Same LDS image, same DMA schedule, same partial layout.
+template <int NA, bool RHO, int PAIRM, int WM = 0>
 __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     const double *__restrict__ sq, long ld, long lstride, int kdim, const double *__restrict__ orb, int ldo,
     double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int ncol, int ptile0, int nslot,
-    int nL, int prio)
+    int nL, int prio, int xmap)
 {
     static_assert(NA == 4 || NA == 5, "128- or 160-orbital tile");
+    static_assert(WM == 0 || (NA == 4 && WM >= 1 && WM < 8), "wide last chunk: 128-orbital panels");
     if (prio) __builtin_amdgcn_s_setprio(3);             // ahead of the tail of a co-running second J pass (tuning "e2prio")
     constexpr int M = NA * 32;                           // NA = 4: no remainder block
     __shared__ double sa0[KB * LDN + (NA == 5 ? KB * 32 : 0)];
@@ -578,7 +598,9 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     bool PAIR = PAIRM == 1;
-    int ptile = ptile0 + blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    int ptile, chunk;
+    if constexpr (PAIRM == 1) { ptile = ptile0 + blockIdx.x / nchunk; chunk = blockIdx.x % nchunk; }
+    else e2_chunk_map(blockIdx.x, nchunk, gridDim.x / nchunk, xmap, ptile, chunk);
     long L = PAIRM == 1 ? 2 * (long)blockIdx.y : blockIdx.y;
     if constexpr (PAIRM == 2) {
         if ((long)blockIdx.y >= nL) {                  // ptile0 = the pair tile; main tiles are 0 .. gridDim.x / nchunk - 1
@@ -588,8 +610,6 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
             ptile = ptile0;
             chunk = (int)(idx % nchunk);
             L = 2 * (idx / nchunk);
-        } else {
-            ptile = blockIdx.x / nchunk;
         }
     }
     const int p0 = ptile * NT;
@@ -649,6 +669,81 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
 #pragma unroll
         for (int j = 0; j < 4; j++) stage_row(kn, na, nb, j);
     };
+    if constexpr (WM > 0) {
+        if (chunk == nchunk - 1) {                       // workgroup-uniform
+            double4_t wacc[WM][2];
+#pragma unroll
+            for (int a = 0; a < WM; a++) wacc[a][0] = wacc[a][1] = double4_t{0, 0, 0, 0};
+            const int woffa = fk * LDN + fn;                                    // + kk * LDN + 16 a
+            const int woffb = fk * LDN + wave * 32 + fn;                        // + kk * LDN + 16 b
+            auto wstep = [&](const double *ca, const double *cb, double *na, double *nb, int k0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int kn = (k0 + KB < kdim) ? k0 + KB : k0;
+#pragma unroll
+                for (int kk = 0; kk < KB; kk += 4) {
+                    double af[WM], bf[2];
+#pragma unroll
+                    for (int a = 0; a < WM; a++) af[a] = ca[woffa + kk * LDN + a * 16];
+                    bf[0] = cb[woffb + kk * LDN];
+                    bf[1] = cb[woffb + kk * LDN + 16];
+                    stage_row(kn, na, nb, kk >> 2);
+#pragma unroll
+                    for (int a = 0; a < WM; a++) {
+                        wacc[a][0] = mfma_f64_16x16x4(af[a], bf[0], wacc[a][0]);
+                        wacc[a][1] = mfma_f64_16x16x4(af[a], bf[1], wacc[a][1]);
+                    }
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
+            if (PAIR || p0 + wave * 32 < ncol) {
+                for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
+                    wstep(sa0, sq0, sa1, sq1, k0);
+                    if (k0 + KB < kdim) wstep(sa1, sq1, sa0, sq0, k0 + KB);
+                }
+            } else {
+                for (int k0 = 0; k0 < kdim; k0 += 2 * KB) {
+                    step_idle(sa1, sq1, k0);
+                    if (k0 + KB < kdim) step_idle(sa0, sq0, k0 + KB);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const int wrow = wave >> 1;                                         // PAIR: waves 0, 1 -> row L, waves 2, 3 -> row L + 1
+            const long Lw = L + (PAIR ? wrow : 0);
+            const bool row_ok = Lw < nL;
+            double *out = X + Lw * nocc_pad * ldx;
+            double rho_acc = 0;
+#pragma unroll
+            for (int a = 0; a < WM; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const long p = p0 + (PAIR ? (wave & 1) * 32 : wave * 32) + b * 16 + fn;
+                    if (p >= ldx || !row_ok) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = m0 + a * 16 + fk + 4 * r;
+                        if (i < nocc_pad) {
+                            out[(long)i * ldx + p] = wacc[a][b][r];
+                            if (RHO) rho_acc += wacc[a][b][r] * orb[p * ldo + i];
+                        }
+                    }
+                }
+            if (RHO) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) rho_acc += __shfl_xor(rho_acc, off, 64);
+                if (lane == 0) {
+                    const long slot = (long)ptile * nchunk + chunk;
+                    if (row_ok) rho[(Lw * nslot + slot) * 4 + wave] = rho_acc;
+                    if (PAIR) {
+                        const long Lo = L + (1 - wrow);
+                        if (Lo < nL) rho[(Lo * nslot + slot) * 4 + wave] = 0.0;
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
     if (PAIR || p0 + wc * 64 < ncol) {
@@ -716,14 +811,17 @@ __global__ __launch_bounds__(256, 2) void e2_sq2_kernel(
 // (full symmetric blocks, zero padded; 14 % of the packed size at nao = 1856, PAMD_e2_diag_blocks) in the ROW layout: the
 // crossing k-tiles are then visited once, without keep-masks, by the same body as the tiles below the diagonal - two loop
 // phases instead of three, 116 instead of 124 k-tiles at nao = 1856.
-template <int NA, bool RHO, bool DIAG>
+// WM > 0 (r04, NA = 4): last orbital chunk of WM < 8 tiles in the 1 x 4 wave arrangement, as in e2_sq2_kernel.
+template <int NA, bool RHO, bool DIAG, int WM = 0>
 __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     const double *__restrict__ cderi, long npair, int nL, int kdim, const double *__restrict__ orb, int ldo,
     double *__restrict__ X, int nocc_pad, long ldx, double *__restrict__ rho, int nchunk, int nao,
-    const double *__restrict__ diag, int ntile_p)
+    const double *__restrict__ diag, int ntile_p, int xmap)
 {
     static_assert(NA == 4 || NA == 5, "128- or 160-orbital tile");
+    static_assert(WM == 0 || (NA == 4 && WM >= 1 && WM < 8), "wide last chunk: 128-orbital panels");
     constexpr int M = NA * 32;
+    constexpr int WMe = WM > 0 ? WM : 1;
     __shared__ double sa0[KB * LDN + (NA == 5 ? KB * 32 : 0)];
     __shared__ double sa1[KB * LDN + (NA == 5 ? KB * 32 : 0)];
     __shared__ double sq0[KB * LDN];
@@ -731,9 +829,11 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     constexpr int RB = KB * LDN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p0 = (blockIdx.x / nchunk) * NT;
+    int ptile, chunk;
+    e2_chunk_map(blockIdx.x, nchunk, ntile_p, xmap, ptile, chunk);
+    const int p0 = ptile * NT;
     const long L = blockIdx.y;
-    const int m0 = (blockIdx.x % nchunk) * M;
+    const int m0 = chunk * M;
     const long bytes_left = (long)(nL - L) * npair * 8;
     const __amdgpu_buffer_rsrc_t r_pk = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(cderi + L * npair), 0, bytes_left > 0xffffffffL ? 0xffffffff : (unsigned)bytes_left, 0x00020000);
@@ -769,11 +869,29 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
 #pragma unroll
     for (int b = 0; b < 4; b++) tb[b] = fk - fn - wc * 64 - b * 16;
 
+    // the same quantities for the 1 x 4 arrangement: wave w owns AO columns [32 w, 32 w + 32) = LDS blocks 4 w .. 4 w + 3
+    const int woffa = fk * LDN + fn;
+    const int woffb_row = fk * LDN + wave * 32 + fn;
+    const int woffb_tr = (wave * 4 + (fn >> 3)) * 128 + (((pl ^ bodd) * 8) + ((fk >> 1) ^ (pl & 1))) * 2 + (fk & 1);
+    int watr[4], wtb[2];
+#pragma unroll
+    for (int g = 0; g < 4; g++) watr[g] = woffb_tr + (((2 * g) ^ (pl & 6))) * 2;
+    wtb[0] = fk - fn - wave * 32;
+    wtb[1] = wtb[0] - 16;
+
+    bool wide = false;
+    if constexpr (WM > 0) wide = chunk == nchunk - 1;                    // workgroup-uniform
     double4_t acc[NA][4];
+    double4_t wacc[WMe][2];
+    if (!wide) {                                                         // (only one of the two sets is live on either path)
 #pragma unroll
-    for (int a = 0; a < NA; a++)
+        for (int a = 0; a < NA; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+            for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+    } else {
+#pragma unroll
+        for (int a = 0; a < WMe; a++) wacc[a][0] = wacc[a][1] = double4_t{0, 0, 0, 0};
+    }
 
     // virtual tile v -> (q0, transposed? as 0 / 1), by integer arithmetic only: any branch here would split the k-tile
     // body into several scheduling regions (and did: hipcc turns the obvious ternaries into s_cbranch)
@@ -831,14 +949,36 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     // One k-tile body per (layout, masked?) pair, each a single basic block: measured with a layout-generic body, ~100 VALU
     // selects per tile in a layout-generic body cost 12 % - a VALU between two FP64 MFMAs is not free (~6 cycles each) - so
     // the fragment addresses of a body are immediates again and the keep-masks exist only in the (<= 16) crossing tiles.
-    auto step = [&](auto TRc, auto MKc, auto NTRc, const double *ca, const double *cb, double *na, double *nb, int v) {
-        constexpr bool TR = decltype(TRc)::value, MK = decltype(MKc)::value;
+    auto step = [&](auto WDc, auto TRc, auto MKc, auto NTRc, const double *ca, const double *cb, double *na, double *nb, int v) {
+        constexpr bool WD = decltype(WDc)::value, TR = decltype(TRc)::value, MK = decltype(MKc)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int vn = (v + 1 < nvirt - 1) ? v + 1 : nvirt - 1;   // last tile: harmless reload into the idle buffer
         const int d = tile_q0(v) - p0;
 #pragma unroll
         for (int kk = 0; kk < KB; kk += 4) {
+            if constexpr (WD) {
+                double af[WMe], bf[2];
+#pragma unroll
+                for (int a = 0; a < WMe; a++) af[a] = ca[woffa + kk * LDN + a * 16];
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const double val = TR ? ((lds_b64_ptr)cb)[watr[kk >> 2] + b * 256] : cb[woffb_row + kk * LDN + b * 16];
+                    if (MK) {
+                        const bool below = (d + wtb[b] + kk) >= 0;
+                        bf[b] = (below != TR) ? val : 0.0;
+                    } else {
+                        bf[b] = val;
+                    }
+                }
+                stage_row(NTRc, vn, na, nb, kk >> 2);
+#pragma unroll
+                for (int a = 0; a < WMe; a++) {
+                    wacc[a][0] = mfma_f64_16x16x4(af[a], bf[0], wacc[a][0]);
+                    wacc[a][1] = mfma_f64_16x16x4(af[a], bf[1], wacc[a][1]);
+                }
+                continue;
+            }
             double af[NA], bf[4];
 #pragma unroll
             for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
@@ -873,37 +1013,60 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
     for (int j = 0; j < 4; j++) stage_row(N2{}, 0, sa0, sq0, j);
     // the phases start on even tiles (nA is a multiple of 8, the crossing tiles come in pairs), so the buffer of
     // every call is a compile-time constant: with run-time buffer pointers hipcc needs waterfall loops for m0
+    auto run = [&](auto WDc) {
     int v = 0;
     if constexpr (DIAG) {
         for (; v < nA - 2; v += 2) {                                     // above the diagonal: transposed layout, and so is the next tile
-            step(T_{}, F_{}, N1{}, sa0, sq0, sa1, sq1, v);
-            step(T_{}, F_{}, N1{}, sa1, sq1, sa0, sq0, v + 1);
+            step(WDc, T_{}, F_{}, N1{}, sa0, sq0, sa1, sq1, v);
+            step(WDc, T_{}, F_{}, N1{}, sa1, sq1, sa0, sq0, v + 1);
         }
         if (v < nA) {                                                    // its last pair: the tile after it is the diagonal block (row layout)
-            step(T_{}, F_{}, N1{}, sa0, sq0, sa1, sq1, v);
-            step(T_{}, F_{}, N0{}, sa1, sq1, sa0, sq0, v + 1);
+            step(WDc, T_{}, F_{}, N1{}, sa0, sq0, sa1, sq1, v);
+            step(WDc, T_{}, F_{}, N0{}, sa1, sq1, sa0, sq0, v + 1);
             v += 2;
         }
         for (; v < nvirt; v += 2) {                                      // diagonal block (side image) and below: row layout
-            step(F_{}, F_{}, N0{}, sa0, sq0, sa1, sq1, v);
-            if (v + 1 < nvirt) step(F_{}, F_{}, N0{}, sa1, sq1, sa0, sq0, v + 1);
+            step(WDc, F_{}, F_{}, N0{}, sa0, sq0, sa1, sq1, v);
+            if (v + 1 < nvirt) step(WDc, F_{}, F_{}, N0{}, sa1, sq1, sa0, sq0, v + 1);
         }
     } else {
         for (; v < nA; v += 2) {                                         // above the diagonal: transposed layout
-            step(T_{}, F_{}, N2{}, sa0, sq0, sa1, sq1, v);
-            step(T_{}, F_{}, N2{}, sa1, sq1, sa0, sq0, v + 1);
+            step(WDc, T_{}, F_{}, N2{}, sa0, sq0, sa1, sq1, v);
+            step(WDc, T_{}, F_{}, N2{}, sa1, sq1, sa0, sq0, v + 1);
         }
         for (; v < nA + 2 * ncross; v += 2) {                            // crossing tiles: row half, then transposed half
-            step(F_{}, T_{}, N2{}, sa0, sq0, sa1, sq1, v);
-            step(T_{}, T_{}, N2{}, sa1, sq1, sa0, sq0, v + 1);
+            step(WDc, F_{}, T_{}, N2{}, sa0, sq0, sa1, sq1, v);
+            step(WDc, T_{}, T_{}, N2{}, sa1, sq1, sa0, sq0, v + 1);
         }
         for (; v < nvirt; v += 2) {                                      // below: row layout
-            step(F_{}, F_{}, N2{}, sa0, sq0, sa1, sq1, v);
-            if (v + 1 < nvirt) step(F_{}, F_{}, N2{}, sa1, sq1, sa0, sq0, v + 1);
+            step(WDc, F_{}, F_{}, N2{}, sa0, sq0, sa1, sq1, v);
+            if (v + 1 < nvirt) step(WDc, F_{}, F_{}, N2{}, sa1, sq1, sa0, sq0, v + 1);
         }
     }
+    };
+    if constexpr (WM > 0) { if (wide) run(T_{}); else run(F_{}); } else run(F_{});
     double *out = X + L * nocc_pad * ldx;
     double rho_acc = 0;
+    if constexpr (WM > 0) {
+        if (wide) {
+#pragma unroll
+            for (int a = 0; a < WMe; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const long p = p0 + wave * 32 + b * 16 + fn;
+                    if (p >= ldx) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = m0 + a * 16 + fk + 4 * r;
+                        if (i < nocc_pad) {
+                            out[(long)i * ldx + p] = wacc[a][b][r];
+                            if (RHO && p < nao) rho_acc += wacc[a][b][r] * orb[p * ldo + i];
+                        }
+                    }
+                }
+        }
+    }
+    if (!wide)
 #pragma unroll
     for (int a = 0; a < NA; a++)
 #pragma unroll
@@ -1217,6 +1380,8 @@ static int g_j2_maxwg = 0;    // cap on the workgroups of the second J pass (0: 
 static int g_pair_tail = 1;   // half-empty last column tile of e2_sq2 as one workgroup per pair of aux rows
 static int g_sq_shift = 0;    // benchmarking probe only: read the square image from a base shifted by this many doubles
 static int g_e2_merge = 1;    // e2_sq2: pair-tail workgroups inside the main launch ("e2merge")
+static int g_e2_xmap = 1;     // e2_sq2 / e2_pk with several orbital chunks: the chunks of a column tile on one XCD ("e2xmap", r04)
+static int g_e2_wide = 1;     // e2_sq2 / e2_pk: last orbital chunk of < 8 tiles in the 1 x 4 wave arrangement ("e2wide", r04)
 static int g_pk_diag = 1;     // e2_pk reads the diagonal 128 x 128 blocks from the side image when the caller passes one ("pkdiag")
 static int g_pk_dma = 1;      // packed-operand half transform by LDS-DMA (e2_pk) when the chunk shape allows
 static int g_syrk_probe = 0;  // benchmarking probe only: the re-tiled SYRK without its second panel DMA (results meaningless)
@@ -1240,6 +1405,8 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "pkdiag") == 0) { g_pk_diag = value; return 0; }
     if (strcmp(key, "e2merge") == 0) { g_e2_merge = value; return 0; }
+    if (strcmp(key, "e2wide") == 0) { g_e2_wide = value; return 0; }
+    if (strcmp(key, "e2xmap") == 0) { g_e2_xmap = value; return 0; }
     if (strcmp(key, "sqshift") == 0) { g_sq_shift = value; return 0; }
     if (strcmp(key, "pairtail") == 0) { g_pair_tail = value; return 0; }
     if (strcmp(key, "j2wg") == 0 && value >= 0) { g_j2_maxwg = value; return 0; }
@@ -1308,9 +1475,10 @@ int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *
 
 // Device analogue of AO2MOnr_e2_drv(ftrans=AO2MOtranse2_nr_s2, fmmm=AO2MOmmm_bra_nr_s2)
 // (pyscf/lib/ao2mo/nr_ao2mo.c:1240-1266): out[L][i][p] = sum_q unpack(cderi[L])[p][q] orb[q][i].
-//   d_orb   [orb_rows][ldo] row-major, columns >= norb zero-padded up to nocc_pad (multiple of 16);
+//   d_orb   [orb_rows][ldo] row-major, columns >= norb zero up to ldo (PAMD_e2_orb_ld(nocc_pad) columns: whole kernel chunks);
 //           orb_rows >= nao allocated rows (rows >= nao zero) - round_up(nao,16) enables the LDS-DMA kernel
-//   d_out   [nL][nocc_pad][ldx]
+//   d_out   [nL][nocc_pad][ldx]: nocc_pad rows per aux index - any value >= norb (r04: no longer a multiple of 16, so that the
+//           K = X^T X that follows contracts nL * norb rows, not nL * round_up(norb, 16): 6 % of the SYRK at norb = 226)
 //   d_rho   (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] (first J pass of the density orb orb^T)
 // Doubles of workspace the fused first J pass needs (d_rho_work): one partial per wave of every workgroup of a row.
 // Orbital tiling of the v2 half-transform kernels: chunks of 160 (NA = 5) or 128 (NA = 4) orbitals, whichever pads
@@ -1321,8 +1489,37 @@ static void v2_tile(int nocc_pad, int *na, int *nchunk, double *waste)
     if (c128 < c160) { *na = 4; *nchunk = c128 / 128; *waste = (double)c128 / nocc_pad - 1.0; }
     else             { *na = 5; *nchunk = c160 / 160; *waste = (double)c160 / nocc_pad - 1.0; }
 }
+// r04: 128-orbital chunks with a LAST chunk of wm < 8 tiles in the 1 x 4 wave arrangement (e2_sq2 / e2_pk, WM > 0).  Returns
+// true when that costs fewer MFMA tiles than the best uniform tiling; a last chunk is never narrower than 4 tiles (below
+// that the panel DMA per MFMA doubles again and the exact-tile kernels are the better choice).
+static bool v2_wide(int nocc_pad, int *nchunk, int *wm, double *waste)
+{
+    const int T = ceil_div(nocc_pad, 16), nch = ceil_div(T, 8), r = T - 8 * (nch - 1);
+    if (!g_e2_wide || r == 8) return false;
+    const int w = r < 4 ? 4 : r, cost = 8 * (nch - 1) + w;
+    const int c160 = ceil_div(nocc_pad, 160) * 10, c128 = ceil_div(nocc_pad, 128) * 8;
+    if (cost >= (c128 < c160 ? c128 : c160)) return false;
+    *nchunk = nch; *wm = w; *waste = (double)cost * 16 / nocc_pad - 1.0;
+    return true;
+}
 // padded MFMA work a v2 kernel may spend before the exact-tile kernels (lower matrix-pipe efficiency) are the better choice
 static const double V2_WASTE_SQUARE = 0.13, V2_WASTE_PACKED = 0.30;
+
+// Leading dimension (columns, zero beyond the orbitals) the half-transform kernels want for nocc_pad orbital columns: whole
+// chunks of the exact-tile kernels, of the uniform v2 tilings and - r04 - of the 128-column chunks with a wide last chunk.
+int PAMD_e2_orb_ld(int nocc_pad)
+{
+    if (nocc_pad <= 0) return 0;
+    const int p16 = ceil_div(nocc_pad, 16) * 16;
+    int ldo = p16 > 160 ? ceil_div(p16, 160) * 160 : p16;
+    const int mt = p16 / 16, nchunk = ceil_div(mt, 10);
+    ldo = max(ldo, nchunk * ceil_div(ceil_div(mt, nchunk), 2) * 32);
+    ldo = max(ldo, min(ceil_div(p16, 160) * 160, ceil_div(p16, 128) * 128));
+    int nchw, wmw;
+    double wastew;
+    if (v2_wide(p16, &nchw, &wmw, &wastew) && wastew <= V2_WASTE_PACKED) ldo = max(ldo, nchw * 128);
+    return ldo;
+}
 
 long PAMD_nr_e2_rho_worksize(int nL, int ldx, int nocc_pad)
 {
@@ -1343,16 +1540,21 @@ static int nr_e2_symm_impl(const double *d_cderi, long npair, int nL, int nao, c
                            const double *d_diag)
 {
     PAMD_REQUIRE(d_rho == nullptr || d_rho_work != nullptr, "d_rho needs d_rho_work (PAMD_nr_e2_rho_worksize doubles)");
-    PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
+    PAMD_REQUIRE(nocc_pad >= 0 && nocc_pad <= ldo, "nocc_pad (rows of d_out per aux index) must be <= ldo");
     PAMD_REQUIRE(ldx >= nao, "ldx < nao");
     if (nL == 0 || nocc_pad == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    int mt_total = nocc_pad / 16;
+    int mt_total = ceil_div(nocc_pad, 16);
     {
         // all-DMA packed-operand kernel: 160- or 128-orbital chunks (as PAMD_nr_e2_square), q rows padded to a multiple of 16
-        int na, nch;
+        int na, nch, wm = 0;
         double waste;
         v2_tile(nocc_pad, &na, &nch, &waste);
+        {
+            int nchw, wmw;
+            double wastew;
+            if (v2_wide(nocc_pad, &nchw, &wmw, &wastew) && ldo >= nchw * 128) { na = 4; nch = nchw; wm = wmw; waste = wastew; }
+        }
         const int kdim = ceil_div(nao, KB) * KB;
         if (g_pk_dma && waste <= V2_WASTE_PACKED && ldo >= nch * na * 32 && orb_rows >= kdim && ldo % 2 == 0 && ldx <= kdim &&
             (long)kdim * (kdim + 1) / 2 * 8 + 4096 < (1L << 31) && (long)orb_rows * ldo * 8 < (1L << 32) &&
@@ -1360,7 +1562,21 @@ static int nr_e2_symm_impl(const double *d_cderi, long npair, int nL, int nao, c
             dim3 gpk(ceil_div(ldx, NT) * nch, nL);
             double *rw = d_rho ? d_rho_work : nullptr;
             const int ntile_p = ceil_div(ldx, NT);
-#define LAUNCH_PK(NAV, RHOF, DG) e2_pk_kernel<NAV, RHOF, DG><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, rw, nch, nao, d_diag, ntile_p)
+#define LAUNCH_PK(NAV, RHOF, DG) e2_pk_kernel<NAV, RHOF, DG><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, rw, nch, nao, d_diag, ntile_p, g_e2_xmap)
+#define LAUNCH_PKW(WMV, RHOF, DG) e2_pk_kernel<4, RHOF, DG, WMV><<<gpk, 256, 0, st>>>(d_cderi, npair, nL, kdim, d_orb, ldo, d_out, nocc_pad, ldx, rw, nch, nao, d_diag, ntile_p, g_e2_xmap)
+#define LAUNCH_PKW_ALL(WMV)                                                                                   \
+            do {                                                                                              \
+                if (d_diag && g_pk_diag) { if (d_rho) LAUNCH_PKW(WMV, true, true); else LAUNCH_PKW(WMV, false, true); }     \
+                else                     { if (d_rho) LAUNCH_PKW(WMV, true, false); else LAUNCH_PKW(WMV, false, false); }   \
+            } while (0)
+            if (wm) {
+                switch (wm) {
+                case 4: LAUNCH_PKW_ALL(4); break;
+                case 5: LAUNCH_PKW_ALL(5); break;
+                case 6: LAUNCH_PKW_ALL(6); break;
+                default: LAUNCH_PKW_ALL(7); break;
+                }
+            } else
             if (d_diag && g_pk_diag) {
                 if (na == 5) { if (d_rho) LAUNCH_PK(5, true, true); else LAUNCH_PK(5, false, true); }
                 else         { if (d_rho) LAUNCH_PK(4, true, true); else LAUNCH_PK(4, false, true); }
@@ -1369,6 +1585,8 @@ static int nr_e2_symm_impl(const double *d_cderi, long npair, int nL, int nao, c
                 else         { if (d_rho) LAUNCH_PK(4, true, false); else LAUNCH_PK(4, false, false); }
             }
 #undef LAUNCH_PK
+#undef LAUNCH_PKW
+#undef LAUNCH_PKW_ALL
             PAMD_CHECK_LAUNCH();
             if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, (int)(gpk.x * 4), st);
             return 0;
@@ -1464,22 +1682,27 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
                       int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream)
 {
     PAMD_REQUIRE(d_rho == nullptr || d_rho_work != nullptr, "d_rho needs d_rho_work (PAMD_nr_e2_rho_worksize doubles)");
-    PAMD_REQUIRE(nocc_pad % 16 == 0 && nocc_pad <= ldo, "nocc_pad must be a multiple of 16 and <= ldo");
+    PAMD_REQUIRE(nocc_pad >= 0 && nocc_pad <= ldo, "nocc_pad (rows of d_out per aux index) must be <= ldo");
     PAMD_REQUIRE(rows % KB == 0 && rows >= nao && orb_rows >= rows, "q rows must be padded to a multiple of 16");
     PAMD_REQUIRE(ld % 2 == 0 && ldo % 2 == 0 && ld >= nao && ldx >= nao, "leading dimensions");
     PAMD_REQUIRE(((uintptr_t)d_sq | (uintptr_t)d_orb) % 16 == 0, "16-byte aligned operands");
     if (nL == 0 || nocc_pad == 0) return 0;
     d_sq += g_sq_shift;            // (probe: misaligned DMA source; results are then meaningless)
     hipStream_t st = (hipStream_t)stream;
-    const int mt_total = nocc_pad / 16;                       // orbital MFMA tiles
+    const int mt_total = ceil_div(nocc_pad, 16);               // orbital MFMA tiles
     const int nchunk = ceil_div(mt_total, 10);
     const int wa = ceil_div(ceil_div(mt_total, nchunk), 2);   // MFMA tiles per wave row; workgroup covers 2 wa tiles
     PAMD_REQUIRE(ldo >= nchunk * wa * 32, "orbital leading dimension too small for tile padding");
     dim3 grid(ceil_div(ldx, NT) * nchunk, nL);
     PAMD_REQUIRE((long)rows * ld * 8 < (1L << 31) && (long)orb_rows * ldo * 8 < (1L << 32), "panel offsets exceed 32 bits");
-    int na2, nch2;
+    int na2, nch2, wm2 = 0;
     double waste2;
     v2_tile(nocc_pad, &na2, &nch2, &waste2);
+    {
+        int nchw, wmw;
+        double wastew;
+        if (v2_wide(nocc_pad, &nchw, &wmw, &wastew) && ldo >= nchw * 128) { na2 = 4; nch2 = nchw; wm2 = wmw; waste2 = wastew; }
+    }
     if (g_dma_v2 && waste2 <= V2_WASTE_SQUARE && ldo >= nch2 * na2 * 32) {
         // 160- or 128-orbital chunks: v2 kernel.  A last column tile that is at most half full runs as a second launch over
         // pairs of aux rows (PAIR instance); rho partials of both launches share one [nL][nslot][4] layout.
@@ -1497,17 +1720,35 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
         do {                                                                                                         \
             if (merged) {                                                                                            \
                 e2_sq2_kernel<NAV, RHOF, 2><<<gboth, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
-                                                                   nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio); \
+                                                                   nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio, g_e2_xmap); \
                 break;                                                                                               \
             }                                                                                                        \
             e2_sq2_kernel<NAV, RHOF, 0><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out,   \
-                                                                   nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL, g_e2_prio);    \
+                                                                   nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL, g_e2_prio, g_e2_xmap);    \
             if (pair)                                                                                                \
                 e2_sq2_kernel<NAV, RHOF, 1><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
-                                                                      nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio); \
+                                                                      nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio, g_e2_xmap); \
         } while (0)
-        if (na2 == 5) { if (d_rho) LAUNCH_V2(5, true); else LAUNCH_V2(5, false); }
+#define LAUNCH_W(WMV, RHOF)                                                                                          \
+        do {                                                                                                         \
+            if (merged)                                                                                              \
+                e2_sq2_kernel<4, RHOF, 2, WMV><<<gboth, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                                                                   nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio, g_e2_xmap); \
+            else                                                                                                     \
+                e2_sq2_kernel<4, RHOF, 0, WMV><<<dim3(ptiles * nchunk, nL), 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, \
+                                                                   d_out, nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL, g_e2_prio, g_e2_xmap); \
+        } while (0)
+        if (wm2) {                          // (without the merged pair rows every column tile, also a half-empty last one, is a main tile)
+            switch (wm2) {
+            case 4: if (d_rho) LAUNCH_W(4, true); else LAUNCH_W(4, false); break;
+            case 5: if (d_rho) LAUNCH_W(5, true); else LAUNCH_W(5, false); break;
+            case 6: if (d_rho) LAUNCH_W(6, true); else LAUNCH_W(6, false); break;
+            default: if (d_rho) LAUNCH_W(7, true); else LAUNCH_W(7, false); break;
+            }
+        }
+        else if (na2 == 5) { if (d_rho) LAUNCH_V2(5, true); else LAUNCH_V2(5, false); }
         else          { if (d_rho) LAUNCH_V2(4, true); else LAUNCH_V2(4, false); }
+#undef LAUNCH_W
 #undef LAUNCH_V2
         PAMD_CHECK_LAUNCH();
         if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, nslot * 4, st);

@@ -194,22 +194,26 @@ def syrk_plan(nao, nsplit=None, flags=None):
     return base & ~4, 4
 
 
+def orbital_ld(nocc_pad):
+    """Leading dimension of a zero-padded orbital operand with nocc_pad columns: whole chunks of every half-transform kernel
+    (the library's rule, PAMD_e2_orb_ld in df_jk.hip)."""
+    return int(_lib_mod.load_library().PAMD_e2_orb_ld(_c.c_int(int(nocc_pad))))
+
+
 def pad_orbitals(orbo, device):
     """Host (nao, nocc) occupied-orbital block C_occ*sqrt(occ) -> zero-padded device operand
     (orb[nao][ldo], nocc_pad) in the layout PAMD_nr_e2_symm expects."""
     torch = _torch()
     nao, nocc = orbo.shape
     nocc_pad = _round_up(max(nocc, 1), 16)
-    ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
-    # the square-image kernel tiles the orbitals in chunks of 32*wa columns (PAMD_nr_e2_square)
-    mt = nocc_pad // 16
-    nchunk = -(-mt // 10)
-    ldo = max(ldo, nchunk * (-(-(-(-mt // nchunk)) // 2)) * 32)
-    # the v2 DMA kernels tile the orbitals in chunks of 160 or 128 columns, whichever pads less (df_jk.hip::v2_tile)
-    ldo = max(ldo, min(_round_up(nocc_pad, 160), _round_up(nocc_pad, 128)))
+    # whole chunks of the exact-tile kernels (32 wa columns), of the v2 DMA kernels (160 or 128 columns, df_jk.hip::v2_tile) and of
+    # the 128-column chunks with a narrower last one (v2_wide)
+    ldo = orbital_ld(nocc_pad)
     orb_h = np.zeros((_round_up(nao, 16), ldo))          # zero rows up to a multiple of the k-tile
     orb_h[:nao, :nocc] = orbo
-    return torch.from_numpy(orb_h).to(device), (nocc_pad if nocc else 0), ldo
+    orb = torch.from_numpy(orb_h).to(device)
+    orb.norb = nocc                                      # the K branch keeps `norb` rows per aux index in X (r04), not nocc_pad
+    return orb, (nocc_pad if nocc else 0), ldo
 
 
 def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True):
@@ -237,7 +241,10 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True):
         blk = _k_blocksize(dfobj, naux, nocc_pad, ldx)
         if after_e2 is not None and fuse_j is None and naux >= 2:
             blk = min(blk, -(-naux // 2))      # two-pass J beside K: pass 1 behind the first block's SYRK, pass 2 behind the second's
-        X = dfobj._workspace('X', (blk, nocc_pad, ldx))
+        # rows per aux index in X: the orbitals themselves where the operand says how many there are (pad_orbitals), so that the
+        # SYRK contracts nb * norb rows - zero rows pad the END of a block to a whole k-tile, not every aux index (nocc = 226: 6 %)
+        xr = int(getattr(orb, 'norb', 0)) or nocc_pad
+        X = dfobj._workspace('X', (blk * nocc_pad + 16, ldx))
         part = dfobj._workspace('kpart', (nsplit, nao, nao))
         part.zero_()
         sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
@@ -255,23 +262,27 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True):
             nb = b1 - b0
             cuts = sorted(set(b0 + (nb * s_) // nsub for s_ in range(nsub + 1)))
             for s0, s1 in zip(cuts[:-1], cuts[1:]):
-                ns, xs = s1 - s0, X[s0 - b0:]
+                ns, xs = s1 - s0, X[(s0 - b0) * xr:]
                 if b1 <= nsq:
                     # fuse_j[set] = rho (naux) zeroed: the first J pass of the density orb orb^T comes out of the epilogue
                     rho_j = fuse_j[iset] if fuse_j is not None else None
                     _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[s0:s0 + ns]), _c.c_long(sq.shape[2]),
                           _c.c_int(sq.shape[1]), _c.c_int(ns), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
-                          _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(xs), _c.c_int(ldx),
+                          _c.c_int(orb.shape[0]), _c.c_int(xr), _ptr(xs), _c.c_int(ldx),
                           _ptr(rho_j[s0:]) if rho_j is not None else _c.c_void_p(0),
                           _rho_work(dfobj, lib, ns, ldx, nocc_pad) if rho_j is not None else _c.c_void_p(0), st)
                 else:
-                    _e2_packed(dfobj, lib, s0, ns, nao, orb, ldo, nocc_pad, xs, ldx,
+                    _e2_packed(dfobj, lib, s0, ns, nao, orb, ldo, xr, xs, ldx,
                                _ptr(fuse_j[iset][s0:]) if fuse_j is not None else None,
                                _rho_work(dfobj, lib, ns, ldx, nocc_pad) if fuse_j is not None else None, st)
                 if after_e2 is not None:
                     after_e2(s0, ns, iset)
+            kx = nb * xr
+            kx16 = _round_up(kx, 16)
+            if kx16 > kx:
+                X[kx:kx16].zero_()
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
-                  _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(nb * nocc_pad), _c.c_int(syrk_flags),
+                  _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(kx16), _c.c_int(syrk_flags),
                   _c.c_int(nsplit), st)
         _call(dfobj, 'reduce_splits', lib.PAMD_reduce_splits, _ptr(part), _c.c_int(nsplit), _c.c_int(nao),
               _c.c_int(nao), _ptr(vk), _c.c_int(nao), _c.c_int(1), st)
@@ -305,6 +316,7 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
     ldx = _round_up(nao, 16)
     rows = _round_up(nao, 16)
     ldo = _round_up(rows, 160) if rows > 160 else _round_up(rows, 32)     # whole 32-column wave tiles (square-image kernel)
+    ldo = max(ldo, orbital_ld(rows))
     nsplit = dfobj.k_nsplit or 4
     blk = max(1, _k_blocksize(dfobj, naux, rows, ldx) // 2)
     vk = torch.zeros((nset, nao, nao), dtype=torch.float64, device=dev)

@@ -221,16 +221,13 @@ def _adjust_phase(c):
 def _pad_orbitals_dev(orbo, nao):
     """Device version of df_jk.pad_orbitals: (orb[rows][ldo], nocc_pad, ldo) of the scaled occupied orbitals."""
     torch = _torch()
-    from ..df.df_jk import _round_up
+    from ..df.df_jk import _round_up, orbital_ld
     nocc = orbo.shape[1]
     nocc_pad = _round_up(max(nocc, 1), 16)
-    ldo = _round_up(nocc_pad, 160) if nocc_pad > 160 else nocc_pad
-    mt = nocc_pad // 16
-    nchunk = -(-mt // 10)
-    ldo = max(ldo, nchunk * (-(-(-(-mt // nchunk)) // 2)) * 32)
-    ldo = max(ldo, min(_round_up(nocc_pad, 160), _round_up(nocc_pad, 128)))
+    ldo = orbital_ld(nocc_pad)
     buf = torch.zeros((_round_up(nao, 16), ldo), dtype=torch.float64, device=orbo.device)    # rows = the k extent of the kernels
     buf[:nao, :nocc] = orbo
+    buf.norb = nocc
     return buf, (nocc_pad if nocc else 0), ldo
 
 

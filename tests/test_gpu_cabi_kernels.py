@@ -152,9 +152,12 @@ def test_dgemm_tn_masked_and_tile_mask(m, n, k, nsplit):
 
 
 @pytest.mark.parametrize('nao,naux,nocc', [(130, 37, 33), (257, 20, 161), (64, 5, 16), (200, 9, 150), (145, 4, 310),
-                                           (272, 3, 139), (200, 6, 240), (150, 7, 120), (145, 4, 500), (320, 3, 226)])
+                                           (272, 3, 139), (200, 6, 240), (150, 7, 120), (145, 4, 500), (320, 3, 226),
+                                           (145, 5, 200), (200, 4, 216), (272, 3, 360), (130, 2, 176)])
 def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
-    """(nocc 240, 120, 500, 226: the 128-orbital instance of the v2 kernel, one to four chunks, with the pair-tail launch.)
+    """(nocc 240, 120, 500, 226: the 128-orbital instance of the v2 kernel, one to four chunks, with the pair-tail launch;
+    r04: nocc 226 / 240 / 200 / 216 / 360 / 176 / 161 end in a last chunk of 7 / 7 / 5 / 6 / 7 / 4 / 4 tiles in the 1 x 4 wave
+    arrangement - bitwise the same X as the uniform tiling, tuning key e2wide = 0.)
     PAMD_unpack_tril -> PAMD_nr_e2_square (LDS-DMA half transform on the unpacked image) against numpy, including the
     first J pass taken from the epilogue: rho_L = sum_{i,p} X[L,i,p] C[p,i] = sum_pq B_L[pq] (C C^T)[pq]."""
     torch, so, dev, st, lib = _setup()
@@ -188,6 +191,25 @@ def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
     lib.check(so.PAMD_nr_e2_square(_p(sq), C.c_long(rows), rows, naux, nao, _p(orb), ldo, orb.shape[0], nocc_pad,
                                    _p(x2), ldx, C.c_void_p(0), C.c_void_p(0), st))
     assert torch.equal(x, x2)
+    lib.check(so.PAMD_set_tuning(b'e2wide', 0))
+    x3 = torch.zeros_like(x)
+    rho3 = torch.zeros(naux, dtype=torch.float64, device=dev)
+    try:
+        lib.check(so.PAMD_nr_e2_square(_p(sq), C.c_long(rows), rows, naux, nao, _p(orb), ldo, orb.shape[0], nocc_pad,
+                                       _p(x3), ldx, _p(rho3), _p(work), st))
+    finally:
+        lib.check(so.PAMD_set_tuning(b'e2wide', 1))
+    assert torch.equal(x, x3)                              # every element: the same k order in either wave arrangement
+    assert np.abs(rho3.cpu().numpy() - rho_want).max() < 1e-10 * np.abs(rho_want).max()
+    if nocc % 16:
+        # r04: nocc rows per aux index in the output (what the K branch uses: the SYRK then contracts naux * nocc rows)
+        x4 = torch.full((naux * nocc + 16, ldx), 7.0, dtype=torch.float64, device=dev)
+        rho4 = torch.zeros(naux, dtype=torch.float64, device=dev)
+        lib.check(so.PAMD_nr_e2_square(_p(sq), C.c_long(rows), rows, naux, nao, _p(orb), ldo, orb.shape[0], nocc,
+                                       _p(x4), ldx, _p(rho4), _p(work), st))
+        assert torch.equal(x4[:naux * nocc].view(naux, nocc, ldx), x[:, :nocc])
+        assert bool((x4[naux * nocc:] == 7.0).all())
+        assert np.abs(rho4.cpu().numpy() - rho_want).max() < 1e-10 * np.abs(rho_want).max()
     # the fused pass is deterministic (per-wave partials + fixed-order reduction, no FP atomics): bitwise repeatable,
     # also through the packed-operand kernel
     for fn, args in ((so.PAMD_nr_e2_square, (_p(sq), C.c_long(rows), rows, naux, nao)),
@@ -203,7 +225,7 @@ def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
 
 @pytest.mark.parametrize('nao,naux,nocc', [(200, 9, 150), (145, 4, 310), (272, 3, 139), (100, 3, 150), (1000, 2, 160),
                                            (129, 5, 160), (200, 9, 240), (150, 4, 120), (100, 3, 100), (145, 4, 500),
-                                           (320, 3, 226)])
+                                           (320, 3, 226), (145, 5, 200), (200, 4, 216), (272, 3, 360), (130, 2, 176)])
 def test_nr_e2_symm_packed_dma_kernel(nao, naux, nocc):
     """PAMD_nr_e2_symm on the shapes that take the all-DMA packed-operand kernel (160- or 128-orbital chunks, whichever pads
     the occupied block less): transposed tiles above
@@ -236,6 +258,13 @@ def test_nr_e2_symm_packed_dma_kernel(nao, naux, nocc):
         outs[flag] = got
     lib.check(so.PAMD_set_tuning(b'pkdma', 1))
     assert np.abs(outs[0] - outs[1]).max() < 1e-11 * np.abs(want).max()
+    if nocc % 16:
+        x4 = torch.full((naux * nocc + 16, ldx), 7.0, dtype=torch.float64, device=dev)     # r04: nocc rows per aux index
+        lib.check(so.PAMD_nr_e2_symm(_p(t_tril), C.c_long(npair), naux, nao, _p(orb), ldo, orb.shape[0], nocc, _p(x4), ldx,
+                                     C.c_void_p(0), C.c_void_p(0), st))
+        got4 = x4[:naux * nocc].view(naux, nocc, ldx)[:, :, :nao].cpu().numpy()
+        assert np.abs(got4 - want).max() < 1e-11 * np.abs(want).max()
+        assert bool((x4[naux * nocc:] == 7.0).all())
     # r03: the same with the diagonal-block side image (crossing k-tiles read once, no keep-masks)
     so.PAMD_e2_diag_size.restype = C.c_long
     ntile = (ldx + 127) // 128

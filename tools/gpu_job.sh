@@ -50,6 +50,15 @@ xcpmc)      # counters of the XC kernels for the sub_vmat variants: gpu_job.sh x
   cd $R
   python tools/pmc_table.py $O > $O/summary.txt; cat $O/summary.txt
   find $O -name "*.db" -delete; find $O -name "*_kernel_trace.csv" -delete ;;
+e2w)        # wide last orbital chunk of the half transform (taxol shape): kernel tests, then kbench with / without
+  timeout 900 python -m pytest -q -x tests/test_gpu_cabi_kernels.py tests/test_gpu_df_jk.py tests/test_gpu_native_abi.py tests/test_gpu_device_scf.py tests/test_gpu_fullsize_cfg45.py::test_config4_taxol_full_jk_and_energy_vs_oracle_golden -m gpu > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+  : > $O/kbench.log
+  for t in "$@"; do
+    [ "$t" = "-" ] && T="" || T="$t"
+    echo "== tune=$T" >> $O/kbench.log
+    timeout 400 python tools/kbench.py --steps 4 --nao 2228 --naux 5598 --nocc 226 --j2-policy serial ${T:+--tune $T} 2>&1 | tail -1 >> $O/kbench.log
+  done
+  cut -c1-600 $O/kbench.log ;;
 probe)      # one-off hardware probes
   ./tools/probe/cu_mask_probe.bin 2>&1 | tee $O/cu_mask_probe.log ;;
 kab)        # kbench A/B of tuning keys on the config-3 shape: gpu_job.sh kab "<tune1>" "<tune2>" ...  (use - for none)
