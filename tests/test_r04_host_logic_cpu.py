@@ -108,3 +108,24 @@ def test_xc_golden_generator_combines_the_oracle_energy_functional(tmp_path):
     finally:
         if os.path.exists(out):
             os.remove(out)
+
+
+def test_orbital_leading_dimension_covers_every_half_transform_tiling():
+    """PAMD_e2_orb_ld (host function): whole chunks of the exact-tile kernels (32 x wave-row tiles, <= 10 tiles per chunk), of the
+    uniform 160 / 128-orbital tilings and of the 128-orbital chunks with a narrower last chunk (r04, df_jk.hip::v2_wide)."""
+    so = _lib()
+    ld = lambda n: int(so.PAMD_e2_orb_ld(C.c_int(n)))
+    assert ld(0) == 0
+    for n in list(range(1, 700, 7)) + [16, 128, 160, 226, 240, 256, 1856, 2240]:
+        v, p16 = ld(n), -(-n // 16) * 16
+        assert v >= p16 and v % 16 == 0
+        assert v >= min(-(-p16 // 160) * 160, -(-p16 // 128) * 128)
+        t = p16 // 16
+        nch = -(-t // 8)
+        r = t - 8 * (nch - 1)
+        cost = 8 * (nch - 1) + max(r, 4)
+        uniform = min(-(-p16 // 160) * 10, -(-p16 // 128) * 8)
+        if r < 8 and cost < uniform and cost * 16 <= 1.30 * p16:
+            assert v >= nch * 128, n                     # room for the wide last chunk's 128-column panel
+    assert ld(160) == 160 and ld(16) == 128              # config 3 unchanged; tiny operands already took one 128-column chunk
+    assert ld(226) == ld(240) == 320 and ld(400) == 512
