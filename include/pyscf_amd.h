@@ -177,6 +177,10 @@ int PAMD_df_vj_pass1(const double *d_cderi, long npair, int naux, const double *
                      double *d_rho, double *d_work, void *stream);        /* rho[s][L] = B_L . dmtril_s */
 int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *d_rho, int nset,
                      double *d_vjtril, void *stream);                     /* vjtril[s] += rho_s^T B  */
+/* Half transform X[L][i][p] = sum_q B_L[p][q] orb[q][i] (AO2MOnr_e2_drv + AO2MOmmm_bra_nr_s2, nr_ao2mo.c:399-419,1240-1266):
+ * d_orb [orb_rows][ldo], columns beyond the orbitals zero up to ldo = PAMD_e2_orb_ld(nocc_pad); d_out [nL][nocc_pad][ldx].
+ * nocc_pad = rows of d_out per aux index: any value >= the number of orbitals (r04: no longer a multiple of 16 - with exactly
+ * norb rows the K = X^T X that follows contracts nL * norb rows; pad the END of the block with zero rows to a multiple of 16). */
 int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const double *d_orb, int ldo,
                     int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work,
                     void *stream);
@@ -194,7 +198,7 @@ long PAMD_e2_diag_size(int nL, int ldx);
 int PAMD_e2_diag_blocks(const double *d_cderi, long npair, int nL, int nao, int ldx, double *d_diag, void *stream);
 /* the same contraction on the unpacked image sq[nL][rows][ld] (PAMD_unpack_tril into a zeroed buffer, rows = ld =
  * round_up(nao,16)): both operands stream by LDS-DMA; spends 2x the packed size of HBM to take the symmetric unpack out
- * of the hot loop.  d_orb as for PAMD_nr_e2_symm with ldo >= chunks * 32 * wa (pyscf_amd/df/df_jk.py:pad_orbitals) */
+ * of the hot loop.  d_orb, nocc_pad as for PAMD_nr_e2_symm */
 int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, const double *d_orb, int ldo,
                       int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work,
                       void *stream);

@@ -560,20 +560,23 @@ class NumInt:
         mo_occ = getattr(dms, 'mo_occ', None)
         nelec = np.zeros(nset)
         excsum = np.zeros(nset)
-        vmat = np.zeros((nset, nao, nao))
         if xctype == 'HF':
+            vmat = np.zeros((nset, nao, nao))
             return (nelec[0], excsum[0], vmat[0]) if dms_arr.ndim == 2 else (nelec, excsum, vmat)
         gga = 1 if xctype == 'GGA' else 0
         ncomp = 4 if gga else 1
         if self.sparse:
             tagged = mo_coeff is not None and np.ndim(mo_occ) == 1 and nset == 1
+            vs = []
             for iset in range(nset):
                 ops = [self._orbital_operand(dms2[iset], mo_coeff if tagged else None, mo_occ, nao, dev)]
                 a, v = self._sparse_xc(mol, grids, fac, gga, ops, 0)
-                nelec[iset], excsum[iset], vmat[iset] = a[0], a[1], v[0]
+                nelec[iset], excsum[iset] = a[0], a[1]
+                vs.append(v[0])                 # the page-locked array lib.download handed out: no second 8 nao^2-byte host copy
             if dms_arr.ndim == 2:
-                return nelec[0], excsum[0], vmat[0]
-            return nelec, excsum, vmat.reshape(shape)
+                return nelec[0], excsum[0], vs[0]
+            return nelec, excsum, (vs[0][None] if nset == 1 else np.stack(vs)).reshape(shape)
+        vmat = np.zeros((nset, nao, nao))
         coords_dev, weights_dev = self._grid_tables(grids, dev)
         ngrids = grids.size
         ldao = _round_up(nao, 16)
