@@ -717,7 +717,9 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
         slab_bytes = std::min<size_t>(slab_bytes, std::min<size_t>(6ul << 30, cap / (4 * npass)));
         stage_b = std::min<size_t>(4ul << 30, cap / 8);
         const size_t work_b = std::min<size_t>(20ul << 30, cap / 4);
-        const size_t used = npass * slab_bytes + 2 * stage_b + work_b + margin;
+        // head room for the other clients of the device in this process (a torch context created AFTER the handle found no
+        // memory at config 5 - "no HIP device" in the SCF driver): 4 GB or 1/16 of the cap stay unclaimed
+        const size_t used = npass * slab_bytes + 2 * stage_b + work_b + margin + std::min<size_t>(4ul << 30, cap / 16);
         h->stage_rows = (int)std::min<size_t>(stage_b / row_b, (size_t)nL);
         if (h->stage_rows < 1) {
             snprintf(g_errmsg, sizeof(g_errmsg), "PAMD_df_create: %.3f GB of device memory cannot stage one tensor row (%.3f GB)",
