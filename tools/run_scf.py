@@ -26,7 +26,6 @@ mf = (dft.RKS(mol, xc=a.xc) if a.xc else scf.RHF(mol))
 if a.native:
     from pyscf_amd.df.native import NativeDF
     devs = [int(d) for d in a.devices.split(',')] if a.devices else None
-    mf.get_ovlp()                      # the SCF driver's own device context exists before the handle sizes itself to the free memory
     t0 = time.perf_counter()
     mf = mf.density_fit(with_df=NativeDF(mol, devices=devs).build())
     print('NativeDF built in %.1f s: layout %s' % (time.perf_counter() - t0, mf.with_df.layout()), flush=True)
