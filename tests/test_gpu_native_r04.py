@@ -110,8 +110,10 @@ def test_config5_whole_tensor_out_of_core_on_one_gpu_vs_oracle_goldens():
     for name in ('h2o128_ccpvdz_rows0-7424_local_oracle.json', 'h2o128_ccpvdz_rows7424-14848_local_oracle.json'):
         if not os.path.exists(os.path.join(ROOT, 'tests', 'golden', name)):
             pytest.skip('%s not generated (tools/gen_golden_shard_local.py --rows ...)' % name)
-    if os.environ.get('PAMD_SKIP_CONFIG5_FULL'):
-        pytest.skip('PAMD_SKIP_CONFIG5_FULL set')
+    if not os.environ.get('PAMD_RUN_CONFIG5_FULL'):
+        # opt-in: two minutes, 270 GB of HBM and 292 GB of page-locked host memory in one process; the passing run of this round is
+        # kept in profiles/r04/native_handle_config5_whole_tensor_one_gpu.log (tools/gpu_job.sh cfg5 runs it)
+        pytest.skip('set PAMD_RUN_CONFIG5_FULL=1 to run the 560 GB case')
     avail_gb = 0.0
     try:
         with open('/proc/meminfo') as f:

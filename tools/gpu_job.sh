@@ -59,6 +59,9 @@ e2w)        # wide last orbital chunk of the half transform (taxol shape): kerne
     timeout 400 python tools/kbench.py --steps 4 --nao 2228 --naux 5598 --nocc 226 --j2-policy serial ${T:+--tune $T} 2>&1 | tail -1 >> $O/kbench.log
   done
   cut -c1-600 $O/kbench.log ;;
+cfg5)       # BASELINE config 5 whole (560 GB) on one GPU through the out-of-core handle (opt-in test)
+  PAMD_RUN_CONFIG5_FULL=1 timeout 1500 python -m pytest -q -x tests/test_gpu_native_r04.py::test_config5_whole_tensor_out_of_core_on_one_gpu_vs_oracle_goldens -m gpu > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+  tail -4 gpurun_out/_native_cfg45_worker_config5.log ;;
 probe)      # one-off hardware probes
   ./tools/probe/cu_mask_probe.bin 2>&1 | tee $O/cu_mask_probe.log ;;
 kab)        # kbench A/B of tuning keys on the config-3 shape: gpu_job.sh kab "<tune1>" "<tune2>" ...  (use - for none)
