@@ -370,6 +370,10 @@ int PAMD_metric_decompose(const double *j2c, int naux, double lindep, int force_
 int PAMD_df_create(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                    double lindep, int device, PAMD_df **out);
 void PAMD_df_destroy(PAMD_df *h);
+/* page-locked (portable) host memory for result / input arrays of the host-array entry points: copies at the PCIe rate instead of
+ * the pageable ~10 GB/s.  Optional - every entry point takes any host pointer. */
+int PAMD_host_alloc(long long nbytes, void **out);
+int PAMD_host_free(void *p);
 int PAMD_df_naux(const PAMD_df *h, int *naux);
 int PAMD_df_nao(const PAMD_df *h, int *nao);
 int PAMD_df_export_cderi(PAMD_df *h, int l0, int l1, double *out);

@@ -868,11 +868,17 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
     const size_t n2 = (size_t)nao * nao;
     const bool streamed = h->n_res < nL;
     if (streamed) serial_j2 = 1;           // the staged rows are released when the main stream is done with them
-    double *d_dm = h->workspace("dm", (size_t)nset * n2, &rc);
-    if (rc) return rc;
-    PAMD_CHECK_HIP(hipMemcpyAsync(d_dm, dm, (size_t)nset * n2 * 8, hipMemcpyHostToDevice, st));
     double *d_vjt = nullptr, *d_vk = nullptr, *d_rho = nullptr, *d_dt = nullptr, *d_w1 = nullptr, *d_part = nullptr;
     const bool fused = with_j && with_k && orbo && (flags & 1) && nL > 0;
+    // the matrix itself is needed on the device for J from the matrix and for the general-DM K branch only: with J taken from the
+    // orbitals (fused) the 8 nao^2-byte upload of a pageable caller array per set (per part of a device list) is skipped
+    const bool need_dm = (with_j && !fused) || (with_k && !orbo);
+    double *d_dm = nullptr;
+    if (need_dm) {
+        d_dm = h->workspace("dm", (size_t)nset * n2, &rc);
+        if (rc) return rc;
+        PAMD_CHECK_HIP(hipMemcpyAsync(d_dm, dm, (size_t)nset * n2 * 8, hipMemcpyHostToDevice, st));
+    }
     if (with_j) {
         d_vjt = h->workspace("vjtril", (size_t)nset * npair, &rc);
         if (rc) return rc;
@@ -1403,6 +1409,24 @@ int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, 
     opt.ndev = ndev;
     opt.flags = 1;                          // a one-entry list still goes through the sharded code path
     return PAMD_df_create_ex(atm, natm, bas, nbas_ao, nbas_aux, env, nenv, &opt, out);
+}
+
+// Page-locked host memory for callers that want their result / input arrays copied at the PCIe rate (a pageable 8 nao^2-byte
+// array moves at ~10 GB/s and faults its pages in on first touch; page-locked memory at ~50 GB/s): NativeDF / NativeNumInt hand
+// out J, K and vxc in arrays made of it.  Portable: every device of the process sees it as pinned.
+int PAMD_host_alloc(long long nbytes, void **out)
+{
+    PAMD_REQUIRE(out, "PAMD_host_alloc: null output pointer");
+    *out = nullptr;
+    PAMD_REQUIRE(nbytes >= 0, "PAMD_host_alloc: negative size");
+    PAMD_CHECK_HIP(hipHostMalloc(out, nbytes > 8 ? (size_t)nbytes : 8, hipHostMallocPortable));
+    return 0;
+}
+
+int PAMD_host_free(void *p)
+{
+    if (p) PAMD_CHECK_HIP(hipHostFree(p));
+    return 0;
 }
 
 void PAMD_df_destroy(PAMD_df *h)

@@ -36,6 +36,51 @@ def _check(rc):
         raise RuntimeError('libpyscf_amd call failed (%d): %s' % (rc, load().PAMD_last_error().decode()))
 
 
+class _PinnedBlock:
+    """One PAMD_host_alloc block (page-locked, portable); freed with the last numpy view of it."""
+
+    def __init__(self, nbytes):
+        self.ptr = _c.c_void_p()
+        _check(load().PAMD_host_alloc(_c.c_longlong(int(nbytes)), _c.byref(self.ptr)))
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().PAMD_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+_pinned_pool = []        # [numpy float64 view of a whole block]: a block is handed out again once no result array refers to it
+
+
+def pinned_empty(shape):
+    """float64 array of `shape` in page-locked host memory (results of get_jk / nr_rks: the device -> host copy then runs at the
+    PCIe rate, ~50 GB/s, instead of the pageable ~10 GB/s plus first-touch page faults).  Blocks are recycled by reference count:
+    one is reused only when every array handed out from it is gone, so callers keep and modify results as long as they like.
+    Falls back to pageable numpy memory if the allocation is refused."""
+    import sys
+    n = int(np.prod(shape)) if len(shape) else 1
+    base = None
+    for arr in _pinned_pool:
+        if arr.size >= n and arr.size <= 4 * max(n, 1) and sys.getrefcount(arr) == 3:      # pool list + loop variable + argument
+            base = arr
+            break
+    if base is None:
+        if len(_pinned_pool) >= 8:
+            _pinned_pool[:] = [a for a in _pinned_pool if sys.getrefcount(a) > 3]
+        try:
+            blk = _PinnedBlock(max(n, 1) * 8)
+        except RuntimeError:
+            return np.empty(shape)
+        buf = (_c.c_double * max(n, 1)).from_address(blk.ptr.value)
+        buf._pamd_block = blk                                  # the block lives as long as the ctypes view (= the numpy base)
+        base = np.frombuffer(buf, dtype=np.float64)
+        _pinned_pool.append(base)
+    return base[:n].reshape(shape)
+
+
 def _conc_env(atm1, bas1, env1, atm2, bas2, env2):
     """gto.conc_env (pyscf/gto/mole.py:805-838): one atm / bas / env holding both molecules, pointers of the second shifted."""
     off = len(env1)
@@ -191,8 +236,8 @@ class NativeDF:
                 ok = all(np.abs(dms[k].dot(v) - blocks[k].dot(blocks[k].T.dot(v))).max() <= 1e-10 * max(1.0, np.abs(dms[k].dot(v)).max())
                          for k in range(nset))
             flags = 1 if ok else 0
-        vj = np.empty_like(dms) if with_j else None
-        vk = np.empty_like(dms) if with_k else None
+        vj = pinned_empty(dms.shape) if with_j else None
+        vk = pinned_empty(dms.shape) if with_k else None
         _check(load().PAMD_df_get_jk(
             self._h, dms.ctypes.data_as(_c.c_void_p), orbo.ctypes.data_as(_c.c_void_p) if orbo is not None else None,
             nocc.ctypes.data_as(_c.c_void_p) if nocc is not None else None, _c.c_int(nset), _c.c_int(nao), _c.c_int(hermi),

@@ -156,8 +156,10 @@ class NativeNumInt:
         shape = dms_arr.shape
         dms2 = dms_arr.reshape(-1, nao, nao)
         nset = len(dms2)
-        nelec, excsum, vmat = np.zeros(nset), np.zeros(nset), np.zeros((nset, nao, nao))
+        nelec, excsum = np.zeros(nset), np.zeros(nset)
         xctype = _xc.xc_type(xc_code)
+        # the library writes every element of vmat: page-locked memory (copied at the PCIe rate) instead of zero-filled pageable pages
+        vmat = np.zeros((nset, nao, nao)) if xctype == 'HF' else _native.pinned_empty((nset, nao, nao))
         if xctype != 'HF':
             if xctype not in ('LDA', 'GGA'):
                 raise NotImplementedError('xc type %s' % xctype)
@@ -182,8 +184,9 @@ class NativeNumInt:
         dms_arr = np.asarray(dms)
         nao = dms_arr.shape[-1]
         assert dms_arr.shape == (2, nao, nao), 'nr_uks: one (alpha, beta) pair'
-        nelec, exc, vmat = np.zeros(2), np.zeros(1), np.zeros((2, nao, nao))
+        nelec, exc = np.zeros(2), np.zeros(1)
         xctype = _xc.xc_type(xc_code)
+        vmat = np.zeros((2, nao, nao)) if xctype == 'HF' else _native.pinned_empty((2, nao, nao))
         if xctype != 'HF':
             if xctype not in ('LDA', 'GGA'):
                 raise NotImplementedError('xc type %s' % xctype)
