@@ -96,6 +96,15 @@ def _conc_env(atm1, bas1, env1, atm2, bas2, env2):
             np.ascontiguousarray(np.hstack((env1, env2)), dtype=np.float64))
 
 
+def _scaled_occupied(c, occ):
+    """C[:, occ > 0] * sqrt(occ) as a C-contiguous (nao, nocc) array; a contiguous occupied range (the usual case) is a slice, not
+    a boolean-mask gather over the whole coefficient matrix (2-4 ms at nao = 1856)."""
+    idx = np.flatnonzero(occ > 0)
+    if len(idx) and idx[-1] - idx[0] + 1 == len(idx):
+        return np.ascontiguousarray(c[:, idx[0]:idx[-1] + 1] * np.sqrt(occ[idx[0]:idx[-1] + 1]))
+    return np.ascontiguousarray(c[:, idx] * np.sqrt(occ[idx]))
+
+
 class _Options(_c.Structure):
     """PAMD_df_options of include/pyscf_amd.h"""
     _fields_ = [('lindep', _c.c_double), ('omega', _c.c_double), ('devices', _c.POINTER(_c.c_int)), ('ndev', _c.c_int),
@@ -225,7 +234,7 @@ class NativeDF:
             if mo_occ.shape[0] * 2 == nset:            # ROHF-style DM (df_jk.py:346-351)
                 mo_coeff = np.vstack((mo_coeff, mo_coeff))
                 mo_occ = np.vstack((np.array(mo_occ > 0, dtype=np.double), np.array(mo_occ == 2, dtype=np.double)))
-            blocks = [np.ascontiguousarray(mo_coeff[k][:, mo_occ[k] > 0] * np.sqrt(mo_occ[k][mo_occ[k] > 0])) for k in range(nset)]
+            blocks = [_scaled_occupied(mo_coeff[k], mo_occ[k]) for k in range(nset)]
             nocc = np.array([b.shape[1] for b in blocks], dtype=np.int32)
             orbo = np.concatenate([b.ravel() for b in blocks]) if nocc.sum() else np.zeros(1)
             # dm == orbo orbo^T ?  (two matrix-vector products per density; the tag of this package's make_rdm1 promises it)
