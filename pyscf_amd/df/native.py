@@ -229,7 +229,7 @@ class NativeDF:
             mo_coeff = np.asarray(mo_coeff)
             mo_occ = np.asarray(dm.mo_occ)
             nmo = mo_occ.shape[-1]
-            mo_coeff = mo_coeff.reshape(-1, nao, nmo)
+            mo_coeff = mo_coeff[None] if mo_coeff.ndim == 2 else mo_coeff.reshape(-1, nao, nmo)   # (no copy of an F-ordered eigh result)
             mo_occ = mo_occ.reshape(-1, nmo)
             if mo_occ.shape[0] * 2 == nset:            # ROHF-style DM (df_jk.py:346-351)
                 mo_coeff = np.vstack((mo_coeff, mo_coeff))

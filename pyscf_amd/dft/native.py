@@ -141,8 +141,7 @@ class NativeNumInt:
         """(orb (nao, r) C order, signs (r) | None): D = sum_i s_i c_i c_i^T - the tag's occupied orbitals scaled by sqrt(occ)
         (numint.py:2930-2994 MO branch), else the eigen-factorisation of the symmetric part (a density only sees that part)."""
         if mo_coeff is not None:
-            occ = np.asarray(mo_occ)
-            return np.ascontiguousarray(np.asarray(mo_coeff)[:, occ > 0] * np.sqrt(occ[occ > 0])), None
+            return _native._scaled_occupied(np.asarray(mo_coeff), np.asarray(mo_occ)), None
         w, v = np.linalg.eigh((dm + dm.T) * .5)
         keep = abs(w) > 1e-14 * max(abs(w).max(), 1e-300)
         sg = np.sign(w[keep])
