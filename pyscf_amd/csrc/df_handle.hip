@@ -852,6 +852,8 @@ struct OrbSet {                            // one density's occupied orbitals on
 // Rows in host memory (out-of-core shard) arrive block by block in two staging buffers, the copy of block b + 1 under the kernels
 // of block b; every contraction is a sum over aux rows, so each block is contracted completely (both J passes, half transform,
 // SYRK into the split-K partials) while it is on the device - one sweep over the host rows per build.
+static const int SYRK_RESERVE = 16;          // DF.k_syrk_reserve of the torch path
+
 static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
                           int with_k, int flags, double *vj, double *vk, int serial_j2, int download)
 {
@@ -918,16 +920,17 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
         PAMD_CHECK_HIP(hipMemsetAsync(d_vk, 0, (size_t)nset * n2 * 8, st));
         // df_jk.syrk_plan: re-tiled triangle + balanced k split when the matrix has an odd number of 64-column blocks
         const int nb64 = (nao + 63) / 64;
+        // beside a co-running J pass 2 the balanced schedule leaves SYRK_RESERVE of the 512 workgroup slots to the pass (df_jk._vk_mo)
+        const int reserve = (fused && !serial_j2) ? SYRK_RESERVE : 0;
         if (orbo && nb64 % 2 == 1 && nb64 >= 5) {
             const int ntl = nb64 / 2, units = ntl * (ntl - 1) / 2 + ntl + (ntl + 2) / 3;
             double best = 0;
             int bn = 0;
             for (int n = 1; n < 8; n++)
                 for (int m = 1; m < 9; m++)
-                    if (units * n + (units + m - 1) / m <= 512 && n + 1.0 / m > best) { best = n + 1.0 / m; bn = n; }
-            if (bn && units >= 32) { nsplit = bn + 1; syrk_flags = 1 | 2 | 4 | 8; }
+                    if (units * n + (units + m - 1) / m <= 512 - reserve && n + 1.0 / m > best) { best = n + 1.0 / m; bn = n; }
+            if (bn && units >= 32) { nsplit = bn + 1; syrk_flags = 1 | 2 | 4 | 8 | ((reserve / 4) << 8); }
         }
-        if (fused && !serial_j2) { nsplit = 4; syrk_flags = 1 | 2; }      // df_jk._vk_mo: plain grid beside the co-running J pass
         d_part = h->workspace("kpart", (size_t)nset * nsplit * n2, &rc);
         if (rc) return rc;
         PAMD_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nset * nsplit * n2 * 8, st));

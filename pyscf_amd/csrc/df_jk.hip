@@ -1388,6 +1388,7 @@ static int g_syrk_probe = 0;  // benchmarking probe only: the re-tiled SYRK with
 static int g_syrk_slots = 1;  // SYRK on the re-tiled triangle (syrk_slots_kernel) when the matrix has an odd number of 64-column blocks
 static int g_syrk_frac = 1;   // balanced SYRK: full pieces + one short remainder piece per tile (dgemm_tn_impl)
 static int g_num_cu = 256;    // MI355X
+static int g_syrk_reserve = 0; // balanced SYRK: workgroup slots (of 2 x 256) left free for a co-running J pass 2 ("syrkreserve")
 static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
 
 extern "C" {
@@ -1399,6 +1400,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "gemmwide") == 0) { g_gemm_wide = value; return 0; }
     if (strcmp(key, "dmav2") == 0) { g_dma_v2 = value; return 0; }
     if (strcmp(key, "syrkfrac") == 0) { g_syrk_frac = value; return 0; }
+    if (strcmp(key, "syrkreserve") == 0 && value >= 0 && value < 256) { g_syrk_reserve = value; return 0; }
     if (strcmp(key, "syrkslots") == 0) { g_syrk_slots = value; return 0; }
     if (strcmp(key, "syrkprobe") == 0) { g_syrk_probe = value; return 0; }
     if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
@@ -1905,7 +1907,9 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
     //   8  re-tiled triangle (syrk_slots_kernel): no dead 64 x 64 wave blocks when the matrix has an odd number of 64-blocks
     auto balanced_chunk = [&](long units) {
         if (!(lower_only & 4) || !g_syrk_frac || nsplit < 2) return kchunk;
-        const long slots = 2L * g_num_cu, full = units * (nsplit - 1);
+        // workgroup slots left free for a co-running kernel (J pass 2): bits 8-15 of the flags word in units of 4, else the tuning key
+        const int reserve = ((lower_only >> 8) & 0xff) ? ((lower_only >> 8) & 0xff) * 4 : g_syrk_reserve;
+        const long slots = 2L * g_num_cu - reserve, full = units * (nsplit - 1);
         long mfrac = 0;                          // smallest depth that fits = longest admissible short piece
         for (long mm = 1; mm <= 64; mm++)
             if (full + (units + mm - 1) / mm <= slots) { mfrac = mm; break; }

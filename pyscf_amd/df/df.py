@@ -38,6 +38,8 @@ class DF:
         self.j2_tune_min_bytes = 4 << 30
         self.k_e2_pipeline = 1     # sub-blocks of a K block whose half transforms are queued back to back (df_jk._vk_mo)
         self.k_nsplit = None       # k-splits of the K = X^T X product; None: df_jk.syrk_plan picks tile shape and splits
+        self.k_syrk_reserve = 16   # > 0: beside a co-running J pass 2 the balanced re-tiled SYRK, sized to leave that many of the
+                                   # 512 workgroup slots to the pass, instead of the plain grid (df_jk._vk_mo)
         self.lindep = 1e-7         # pyscf/df/incore.py:33
         self.decompose_j2c = 'CD'  # 'ED': eigen-decompose the metric even when it is positive definite (df/grad/rhf.py:45)
         self.omega = 0.0           # > 0: long-range, < 0: short-range tensor (set by range_coulomb)

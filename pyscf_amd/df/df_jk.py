@@ -165,7 +165,7 @@ def syrk_items(nao):
     return nt * (nt - 1) // 2 + nt + -(-nt // 3)
 
 
-def syrk_plan(nao, nsplit=None, flags=None):
+def syrk_plan(nao, nsplit=None, flags=None, reserve=0):
     """(flags, nsplit) of the K = X^T X product (flag 1: lower triangle, flag 2: LDS-DMA operands).
 
     Default when the matrix has an odd number of 64-column blocks (nao = 1856: 29): the RE-TILED triangle (flag 8,
@@ -187,7 +187,7 @@ def syrk_plan(nao, nsplit=None, flags=None):
         best = None
         for n in range(1, 8):
             for m in range(1, 9):
-                if units * n + -(-units // m) <= 512 and (best is None or n + 1.0 / m > best[0]):
+                if units * n + -(-units // m) <= 512 - reserve and (best is None or n + 1.0 / m > best[0]):
                     best = (n + 1.0 / m, n)
         if best is not None and units >= 32:
             return base, best[1] + 1
@@ -226,12 +226,18 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True):
     st = _stream()
     ldx = _round_up(nao, 16)
     kflags = getattr(dfobj, 'k_syrk_flags', None)
+    reserve = 0
     if kflags is None and after_e2 is not None and j_corun:
         # the second J pass runs beside this SYRK on the side stream: it hides in the 32 workgroup slots the plain 120 x 4 grid
         # leaves idle (J/K 108.8 ms) but not beside the balanced schedule that fills them (110.0 ms; K alone: 35.6 vs 39.7 ms): the
-        # SYRK's own L2 -> LDS panel traffic and the J stream share one path - plain grid when J co-runs
-        kflags = 0
-    syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit, kflags)
+        # SYRK's own L2 -> LDS panel traffic and the J stream share one path - plain grid when J co-runs,
+        # or (DF.k_syrk_reserve > 0, late r04) the balanced re-tiled schedule sized to leave that many slots to the pass
+        reserve = int(getattr(dfobj, 'k_syrk_reserve', 0) or 0)
+        if not reserve:
+            kflags = 0
+    syrk_flags, nsplit = syrk_plan(nao, dfobj.k_nsplit, kflags, reserve)
+    if reserve and (syrk_flags & 4):
+        syrk_flags |= (reserve // 4) << 8          # PAMD_dgemm_tn: bits 8-15 of the flags = slots the balanced split leaves free, / 4
     vks = []
     for iset, (orb, nocc_pad, ldo) in enumerate(orb_list):
         vk = torch.zeros((nao, nao), dtype=torch.float64, device=dev)

@@ -23,6 +23,7 @@ ap.add_argument('--j2-policy', default='overlap', choices=['auto', 'overlap', 's
 ap.add_argument('--block-gb', type=float, default=0)
 ap.add_argument('--no-fuse', action='store_true')
 ap.add_argument('--ksplit', type=int, default=0)
+ap.add_argument('--syrk-reserve', type=int, default=0, help='balanced re-tiled SYRK beside the co-running J pass, this many workgroup slots left free')
 ap.add_argument('--syrk-flags', type=int, default=-1, help='4: balanced k split, 8: re-tiled triangle (df_jk.syrk_plan)')
 ap.add_argument('--no-j', action='store_true', help='K only (as the K_LR / response calls do)')
 a = ap.parse_args()
@@ -43,6 +44,7 @@ obj.j2_policy = a.j2_policy
 if a.block_gb: obj.k_block_bytes = int(a.block_gb * (1 << 30))
 if a.no_fuse: obj.fuse_j_pass1 = False
 if a.ksplit: obj.k_nsplit = a.ksplit
+obj.k_syrk_reserve = a.syrk_reserve
 obj.k_syrk_flags = None if a.syrk_flags < 0 else a.syrk_flags
 import ctypes
 from pyscf_amd import lib as _L
