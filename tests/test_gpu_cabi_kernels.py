@@ -153,11 +153,12 @@ def test_dgemm_tn_masked_and_tile_mask(m, n, k, nsplit):
 
 @pytest.mark.parametrize('nao,naux,nocc', [(130, 37, 33), (257, 20, 161), (64, 5, 16), (200, 9, 150), (145, 4, 310),
                                            (272, 3, 139), (200, 6, 240), (150, 7, 120), (145, 4, 500), (320, 3, 226),
-                                           (145, 5, 200), (200, 4, 216), (272, 3, 360), (130, 2, 176)])
+                                           (145, 5, 200), (200, 4, 216), (272, 3, 360), (130, 2, 176), (145, 3, 100),
+                                           (200, 4, 88), (320, 5, 70)])
 def test_nr_e2_square_and_fused_rho(nao, naux, nocc):
     """(nocc 240, 120, 500, 226: the 128-orbital instance of the v2 kernel, one to four chunks, with the pair-tail launch;
     r04: nocc 226 / 240 / 200 / 216 / 360 / 176 / 161 end in a last chunk of 7 / 7 / 5 / 6 / 7 / 4 / 4 tiles in the 1 x 4 wave
-    arrangement - bitwise the same X as the uniform tiling, tuning key e2wide = 0.)
+    arrangement - bitwise the same X as the uniform tiling, tuning key e2wide = 0; nocc 100 / 88 / 70: ONE wide chunk of 7 / 6 / 5.)
     PAMD_unpack_tril -> PAMD_nr_e2_square (LDS-DMA half transform on the unpacked image) against numpy, including the
     first J pass taken from the epilogue: rho_L = sum_{i,p} X[L,i,p] C[p,i] = sum_pq B_L[pq] (C C^T)[pq]."""
     torch, so, dev, st, lib = _setup()
