@@ -349,6 +349,13 @@ typedef struct PAMD_df PAMD_df;
  *                         through two staging buffers under the kernels in every PAMD_df_get_jk: the out-of-core twin of the
  *                         reference (pyscf/df/outcore.py:109-232, pyscf/df/df.py:167,214-242), PCIe-bound for those rows.
  *                         flags bit 0: keep the sharded code path even for a one-entry device list
+ *                         flags bit 1 (r05): ONE RANK of a multi-process job - the handle holds only the rows of shard `part` of
+ *                         `nparts` (contiguous, row-balanced: DF.shard_range) on devices[0], out of core where they do not fit;
+ *                         PAMD_df_get_jk returns that shard's PARTIAL J/K, the caller sums over the ranks (the accumulation over
+ *                         `dfobj.loop()` blocks of pyscf/df/df_jk.py:362-381, spread over processes)
+ *   PAMD_df_shard_info    info[4] = {first global row, rows held, rows of the whole tensor, 1 = partial sums}
+ *   PAMD_df_last_timing   host-clock timings of the last PAMD_df_get_jk: out[3 + 3 parts] = {parts, ms of sum + download on part 0,
+ *                         peer copies used 0/1, then per part: ms contraction, ms push into the gather buffer, bytes pushed across devices}
  *   PAMD_df_layout        layout[5] = {parts, rows resident in HBM, rows in host memory, rows with a square image, peer copies 0 / 1},
  *                         part_rows[parts] (nullable) = rows per part */
 typedef struct PAMD_df_options {
@@ -358,12 +365,16 @@ typedef struct PAMD_df_options {
     int ndev;
     int flags;
     long long max_device_bytes; /* 0: whatever the device has free */
+    int part;                   /* flags bit 1 only: this handle holds shard `part` ... */
+    int nparts;                 /* ... of `nparts` contiguous row-balanced shards (one rank of a multi-process job) */
 } PAMD_df_options;
 int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                       const PAMD_df_options *opt, PAMD_df **out);
 int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                          double lindep, const int *devices, int ndev, PAMD_df **out);
 int PAMD_df_layout(const PAMD_df *h, long *layout, int *part_rows);
+int PAMD_df_shard_info(const PAMD_df *h, int *info);
+int PAMD_df_last_timing(const PAMD_df *h, double *out, int nout);
 /* the metric factorisation alone (df/incore.py:150-158, :263-270; decompose_j2c = 'ED' with force_ed): host j2c[naux][naux] ->
  * host m[nrow][naux] (caller provides naux x naux doubles), cderi = m (Q|pq); *tri = 1: rows of L^-1 */
 int PAMD_metric_decompose(const double *j2c, int naux, double lindep, int force_ed, int device, double *m, int *nrow, int *tri);

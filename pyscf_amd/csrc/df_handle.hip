@@ -25,6 +25,8 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -203,6 +205,40 @@ constexpr int ROC_OP_N = 111, ROC_FILL_UPPER = 121, ROC_EVECT_ORIGINAL = 211;
 // A shard keeps its rows in HBM as far as they fit (`n_res` rows, d_cderi) and the rest in page-locked host memory (h_cderi),
 // streamed through two staging buffers during every J/K build (the out-of-core twin of the reference, pyscf/df/outcore.py:109-232,
 // pyscf/df/df.py:167,214-242: there blocks of the HDF5 file, here blocks of pinned RAM under double-buffered H2D copies).
+// One persistent host thread per part of a multi-device handle (r05; r04 spawned a std::thread per part per PAMD_df_get_jk): the
+// thread binds its device once, keeps its HIP thread state, and runs the jobs the caller's thread posts to it.
+struct PartWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, quit = false;
+    int rc = 0;
+    std::string msg;
+    void start(int device);
+    void post(std::function<int()> f)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        job = std::move(f);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+        return rc;
+    }
+    ~PartWorker()
+    {
+        if (th.joinable()) {
+            { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); }
+            th.join();
+        }
+    }
+};
+
 struct PAMD_df {
     int device = 0;
     int nao = 0, naux = 0;                  // AO functions, auxiliary functions
@@ -221,7 +257,14 @@ struct PAMD_df {
     int stage_rows = 0;
     std::map<long, int> j2_policy;          // (nset, occupied counts) -> 0 overlap / 1 serial second J pass (PAMD_df_get_jk)
     std::vector<PAMD_df *> parts;           // multi-device handle: the shards (owned)
+    std::vector<PartWorker *> workers;      // multi: one persistent host thread per part
     int peer_ok = 0;                        // multi: partial results reach part 0 by direct peer copies
+    int partial = 0;                        // 1: one rank's shard of a multi-process job (PAMD_df_options.part / nparts): PARTIAL J/K
+    double *h_orb = nullptr;                // page-locked staging of the padded orbitals (persistent: no per-call allocation / sync)
+    size_t h_orb_len = 0;
+    // timings of the last PAMD_df_get_jk (PAMD_df_last_timing): per part contraction and push into the gather buffer, sum + download
+    double t_compute_ms = 0, t_push_ms = 0, t_sum_ms = 0;
+    size_t push_bytes = 0;
     std::map<std::string, std::pair<double *, size_t>> ws;
     double *workspace(const std::string &name, size_t ndoubles, int *rc)
     {
@@ -238,12 +281,14 @@ struct PAMD_df {
     }
     ~PAMD_df()
     {
+        for (PartWorker *w : workers) delete w;
         for (PAMD_df *p : parts) {
             (void)hipSetDevice(p->device);
             delete p;
         }
         if (!parts.empty()) (void)hipSetDevice(device);
         if (h_cderi) (void)hipHostFree(h_cderi);
+        if (h_orb) (void)hipHostFree(h_orb);
         for (int k = 0; k < 2; k++) {
             if (ev_ready[k]) (void)hipEventDestroy(ev_ready[k]);
             if (ev_free[k]) (void)hipEventDestroy(ev_free[k]);
@@ -254,6 +299,29 @@ struct PAMD_df {
         if (st) (void)hipStreamDestroy(st);
     }
 };
+
+void PartWorker::start(int device)
+{
+    th = std::thread([this, device]() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            std::function<int()> f;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return has_job || quit; });
+                if (quit) return;
+                f = std::move(job);
+                has_job = false;
+            }
+            const int r = f();
+            std::lock_guard<std::mutex> lk(m);
+            rc = r;
+            msg = r ? g_errmsg : "";            // g_errmsg is thread local: carry it over to the caller's thread
+            done = true;
+            cv.notify_all();
+        }
+    });
+}
 
 namespace {
 
@@ -935,6 +1003,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
         if (rc) return rc;
         PAMD_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nset * nsplit * n2 * 8, st));
         const double *op = orbo;
+        size_t orb_stage_off = 0;
         for (int s = 0; s < nset && orbo; s++) {
             OrbSet &o = orbs[s];
             o.no = nocc[s];
@@ -948,15 +1017,32 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
             ldo = std::max<long>(ldo, std::min(round_up(o.nocc_pad, 160), round_up(o.nocc_pad, 128)));
             ldo = std::max<long>(ldo, PAMD_e2_orb_ld(o.nocc_pad));
             o.ldo = ldo;
-            std::vector<double> oh((size_t)rows * ldo, 0.0);
-            for (int p = 0; p < nao; p++)
-                for (int i = 0; i < o.no; i++) oh[(size_t)p * ldo + i] = o_s[(size_t)p * o.no + i];
+            // padded image in the handle's page-locked staging area (all sets side by side; the call ends with a stream
+            // synchronisation, so the area is free again at the next call): no per-call allocation, no extra synchronisation
+            const size_t olen = (size_t)rows * ldo;
+            if (orb_stage_off + olen > h->h_orb_len) {
+                PAMD_CHECK_HIP(hipStreamSynchronize(st));                  // copies of the earlier sets still read the old area
+                size_t want = std::max<size_t>(2 * (orb_stage_off + olen), (size_t)1 << 20);
+                double *nb = nullptr;
+                PAMD_CHECK_HIP(hipHostMalloc((void **)&nb, want * 8, hipHostMallocPortable));
+                if (h->h_orb) (void)hipHostFree(h->h_orb);
+                h->h_orb = nb;
+                h->h_orb_len = want;
+                orb_stage_off = 0;
+            }
+            double *oh = h->h_orb + orb_stage_off;
+            orb_stage_off += olen;
+            for (int p = 0; p < nao; p++) {
+                double *row = oh + (size_t)p * ldo;
+                memcpy(row, o_s + (size_t)p * o.no, (size_t)o.no * 8);
+                if (ldo > o.no) memset(row + o.no, 0, (size_t)(ldo - o.no) * 8);
+            }
+            if (rows > nao) memset(oh + (size_t)nao * ldo, 0, (size_t)(rows - nao) * ldo * 8);
             char name[32];
             snprintf(name, sizeof(name), "orb%d", s);
-            o.d_orb = h->workspace(name, (size_t)rows * ldo, &rc);
+            o.d_orb = h->workspace(name, olen, &rc);
             if (rc) return rc;
-            PAMD_CHECK_HIP(hipMemcpyAsync(o.d_orb, oh.data(), oh.size() * 8, hipMemcpyHostToDevice, st));
-            PAMD_CHECK_HIP(hipStreamSynchronize(st));                      // oh goes out of scope
+            PAMD_CHECK_HIP(hipMemcpyAsync(o.d_orb, oh, olen * 8, hipMemcpyHostToDevice, st));
         }
     }
     // general-DM branch: the density itself is the "orbital" operand
@@ -1152,25 +1238,29 @@ __global__ void pack_lower_kernel(const double *__restrict__ full, int nao, doub
         tril[(size_t)p * (p + 1) / 2 + q] = full[(size_t)p * nao + q];
 }
 
-// every part contracts its shard on its own host thread; errors come back with their messages
+// every part contracts its shard on its own PERSISTENT host thread (PartWorker); errors come back with their messages
 struct PartResult { int rc = 0; std::string msg; };
 
 template <class F>
-int run_parts(const std::vector<PAMD_df *> &parts, F f)
+int run_parts(PAMD_df *m, F f)
 {
-    std::vector<PartResult> res(parts.size());
-    std::vector<std::thread> th;
-    for (size_t p = 0; p < parts.size(); p++)
-        th.emplace_back([&, p]() {
-            res[p].rc = f((int)p, parts[p]);
-            if (res[p].rc) res[p].msg = g_errmsg;          // g_errmsg is thread local: carry it over to the caller's thread
-        });
-    for (auto &t : th) t.join();
-    for (size_t p = 0; p < parts.size(); p++)
-        if (res[p].rc) {
-            snprintf(g_errmsg, sizeof(g_errmsg), "device %d (part %d): %s", parts[p]->device, (int)p, res[p].msg.c_str());
-            return res[p].rc;
+    const std::vector<PAMD_df *> &parts = m->parts;
+    if (m->workers.size() != parts.size()) {
+        for (PartWorker *w : m->workers) delete w;
+        m->workers.clear();
+        for (size_t p = 0; p < parts.size(); p++) {
+            m->workers.push_back(new PartWorker);
+            m->workers.back()->start(parts[p]->device);
         }
+    }
+    for (size_t p = 0; p < parts.size(); p++) m->workers[p]->post([&f, &parts, p]() { return f((int)p, parts[p]); });
+    int first = -1;
+    for (size_t p = 0; p < parts.size(); p++)
+        if (m->workers[p]->wait() && first < 0) first = (int)p;
+    if (first >= 0) {
+        snprintf(g_errmsg, sizeof(g_errmsg), "device %d (part %d): %s", parts[first]->device, first, m->workers[first]->msg.c_str());
+        return m->workers[first]->rc;
+    }
     return 0;
 }
 
@@ -1300,6 +1390,17 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
     if ((rc = make_tables(atm, bas, nbas_ao, nbas_aux, env, &t))) return rc;
     const size_t cap = opt->max_device_bytes > 0 ? (size_t)opt->max_device_bytes : 0;
     Metric m;
+    if (opt->flags & 2) {
+        // one rank's shard of a multi-process job: rows of part `part` of `nparts` (DF.shard_range) on devices[0], resident as
+        // far as the device / max_device_bytes allows, the rest streamed from page-locked host memory; PAMD_df_get_jk then
+        // returns this shard's PARTIAL J/K and the caller sums over the ranks (RCCL all-reduce in pyscf_amd.df.DF)
+        PAMD_REQUIRE(opt->nparts > 0 && opt->part >= 0 && opt->part < opt->nparts, "PAMD_df_create: part / nparts");
+        PAMD_df *h = nullptr;
+        if ((rc = create_shard(t, devs[0], opt->omega, opt->lindep, cap, &m, opt->part, opt->nparts, &h))) return rc;
+        h->partial = opt->nparts > 1;
+        *out = h;
+        return 0;
+    }
     if (opt->ndev <= 0 || (ndev == 1 && !(opt->flags & 1))) {
         // the plain single-device handle
         PAMD_df *h = nullptr;
@@ -1504,19 +1605,77 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
 {
     PAMD_REQUIRE(h, "PAMD_df_get_jk: null handle");
     PAMD_REQUIRE((!with_j || vj) && (!with_k || vk) && (with_j || with_k), "PAMD_df_get_jk: output pointers");
-    if (h->parts.empty()) return shard_get_jk(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, 1);
+    typedef std::chrono::steady_clock clk;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    if (h->parts.empty() || h->parts.size() == 1) {
+        // one shard: no gather, no sum - straight into the caller's arrays (r05: a one-entry device list used to pay the pack /
+        // push / sum / unpack round trip and a thread start per call: 122.7 against 110.5 ms at config 3)
+        PAMD_df *p = h->parts.empty() ? h : h->parts[0];
+        const auto t0 = clk::now();
+        const int r = shard_get_jk(p, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, 1);
+        p->t_compute_ms = ms_since(t0);
+        p->t_push_ms = 0;
+        p->push_bytes = 0;
+        h->t_sum_ms = 0;
+        return r;
+    }
     PAMD_REQUIRE(dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
     // one host thread per device contracts that device's shard (the serial decomposition this replaces: df_jk.py:362-381);
     // the partial [J~ | K] are summed on part 0's device and leave in one download
     MultiMsg mm;
     int rc = multi_prepare(h, nset, nao, with_j, with_k, orbo != nullptr, &mm);
     if (rc) return rc;
-    rc = run_parts(h->parts, [&](int ip, PAMD_df *p) -> int {
+    rc = run_parts(h, [&](int ip, PAMD_df *p) -> int {
+        const auto t0 = clk::now();
         const int r = shard_get_jk(p, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, nullptr, nullptr, 0);
-        return r ? r : multi_push(h, ip, mm);
+        p->t_compute_ms = ms_since(t0);
+        if (r) return r;
+        const auto t1 = clk::now();
+        const int r2 = multi_push(h, ip, mm);
+        p->t_push_ms = ms_since(t1);
+        p->push_bytes = p->device == h->parts[0]->device ? 0 : mm.len * 8;
+        return r2;
     });
     if (rc) return rc;
-    return multi_sum_download(h, mm, vj, vk);
+    const auto t2 = clk::now();
+    rc = multi_sum_download(h, mm, vj, vk);
+    h->t_sum_ms = ms_since(t2);
+    return rc;
+}
+
+// Host-clock timings of the LAST PAMD_df_get_jk on this handle (bench.py --single-process `comm`): out[0] = parts, out[1] = ms of the
+// fixed-order sum + unpack + download on part 0, out[2] = 1 when the partial results travelled by direct peer copies (xGMI), 0 for
+// the host bounce or a single device; then per part p: out[3 + 3p] = ms of the shard's contraction (kernels + synchronisation),
+// out[4 + 3p] = ms of laying out and pushing [J~ | K] into part 0's gather buffer, out[5 + 3p] = bytes that crossed devices.
+int PAMD_df_last_timing(const PAMD_df *h, double *out, int nout)
+{
+    PAMD_REQUIRE(h && out, "PAMD_df_last_timing: null argument");
+    std::vector<const PAMD_df *> ps;
+    if (h->parts.empty()) ps.push_back(h);
+    for (const PAMD_df *p : h->parts) ps.push_back(p);
+    PAMD_REQUIRE(nout >= 3 + 3 * (int)ps.size(), "PAMD_df_last_timing: out[3 + 3 * parts]");
+    bool cross = false;
+    for (const PAMD_df *p : ps) cross = cross || p->device != ps[0]->device;
+    out[0] = (double)ps.size();
+    out[1] = h->t_sum_ms;
+    out[2] = (cross && h->peer_ok) ? 1.0 : 0.0;
+    for (size_t i = 0; i < ps.size(); i++) {
+        out[3 + 3 * i] = ps[i]->t_compute_ms;
+        out[4 + 3 * i] = ps[i]->t_push_ms;
+        out[5 + 3 * i] = (double)ps[i]->push_bytes;
+    }
+    return 0;
+}
+
+// {first global row of this handle's rows, rows it holds, rows of the whole tensor, 1 when PAMD_df_get_jk returns PARTIAL sums}
+int PAMD_df_shard_info(const PAMD_df *h, int *info)
+{
+    PAMD_REQUIRE(h && info, "PAMD_df_shard_info: null argument");
+    info[0] = h->l0;
+    info[1] = h->nL;
+    info[2] = h->nL_total ? h->nL_total : h->nL;
+    info[3] = h->partial;
+    return 0;
 }
 
 }  // extern "C"

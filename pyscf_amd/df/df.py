@@ -323,31 +323,61 @@ class DF:
         self._naux = self.auxmol.nao_nr()
         l0, l1 = self.shard_range(self._naux, self.rank, self.world_size)
         try:
-            if self.outcore_device_bytes and (l1 - l0) * (self.mol.nao * (self.mol.nao + 1) // 2) * 8 > self.outcore_device_bytes:
-                raise MemoryError('tensor shard above DF.outcore_device_bytes')
+            # the fit check comes BEFORE any metric work (the metric used to be computed and factorised twice, once by
+            # cholesky_eri_gpu ahead of its own memory check and once more inside the C handle)
+            if not self.would_fit():
+                raise MemoryError('DF tensor shard of %d x %d doubles does not fit %s' % (
+                    l1 - l0, self.mol.nao * (self.mol.nao + 1) // 2,
+                    'DF.outcore_device_bytes' if self.outcore_device_bytes else 'the free device memory'))
             self._cderi_dev = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1,
                                                       lindep=self.lindep, omega=self.omega,
                                                       decompose_j2c=self.decompose_j2c)
         except MemoryError:
-            # r04 - the out-of-core twin (pyscf/df/outcore.py:109-232, pyscf/df/df.py:167): the tensor does not fit this device.
-            # A single-process object hands the job to the C handle, which keeps what fits in HBM, the rest in page-locked host
-            # memory, and streams it under the kernels in every build (PCIe-bound for those rows: slower, not wrong).  J/K, loop
-            # and range_coulomb go through it; the HBM-resident SCF loop and the gradients need the in-core tensor.
-            if self.world_size > 1 or getattr(self, '_shard_override', None) is not None or not getattr(self, 'outcore', True) \
-                    or getattr(self, 'decompose_j2c', 'CD') != 'CD':
+            # The out-of-core twin (pyscf/df/outcore.py:109-232, pyscf/df/df.py:167): the tensor (r05: or this RANK's shard of it)
+            # does not fit this device.  The object hands its rows to the C handle, which keeps what fits in HBM, the rest in
+            # page-locked host memory, and streams it under the kernels in every build (PCIe-bound for those rows: slower, not
+            # wrong).  J/K, loop, save and range_coulomb go through it - a rank of a multi-process job gets its shard's PARTIAL
+            # J/K from the handle and all-reduces them like the in-core path; the HBM-resident SCF loop and the gradients need
+            # the in-core tensor.
+            if not getattr(self, 'outcore', True) or getattr(self, 'decompose_j2c', 'CD') != 'CD':
                 raise
             from .native import NativeDF
             import torch as _torch
             idx = dev.index if dev.index is not None else _torch.cuda.current_device()
             _torch.cuda.empty_cache()                       # give the handle's hipMalloc the memory torch had cached
+            sharded = self.world_size > 1 or getattr(self, '_shard_override', None) is not None
             self._native = NativeDF(self.mol, self.auxbasis, auxmol=self.auxmol, device=idx, lindep=self.lindep, omega=self.omega,
-                                    max_device_bytes=int(getattr(self, 'outcore_device_bytes', 0))).build()
+                                    max_device_bytes=int(getattr(self, 'outcore_device_bytes', 0)),
+                                    shard=(self.rank, self.world_size) if sharded else None).build()
             self._naux = self._native.get_naoaux()
-            return self
         if isinstance(self._cderi_to_save, str):
             self.save(self._cderi_to_save)
         return self
     kernel = build
+
+    def would_fit(self):
+        """Cheap predicate (host arithmetic + one memory query, no integrals): does this rank's packed shard of the tensor,
+        with the slab work space of the build, fit the device - or the `outcore_device_bytes` cap?  build() asks it before any
+        metric work; scf.device_scf.eligible() asks it instead of building."""
+        import torch
+        if self._cderi_dev is not None:
+            return True
+        if getattr(self, '_native', None) is not None:
+            return False
+        if self.auxmol is None:
+            self.auxmol = addons.make_auxmol(self.mol, self.auxbasis)
+        naux = self.auxmol.nao_nr()
+        nao = self.mol.nao_nr() if hasattr(self.mol, 'nao_nr') else self.mol.nao
+        npair = nao * (nao + 1) // 2
+        l0, l1 = self.shard_range(naux, self.rank, self.world_size)
+        shard_b = (l1 - l0) * npair * 8
+        if self.outcore_device_bytes and shard_b > self.outcore_device_bytes:
+            return False
+        dev = self._device()
+        if dev.type != 'cuda':
+            return True
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return shard_b + min(24 << 30, npair * naux * 8) <= free
 
     def get_naoaux(self):
         if self._naux is None:
@@ -370,6 +400,9 @@ class DF:
         if blksize is None:
             blksize = self.blockdim
         if getattr(self, '_native', None) is not None:
+            if self._native.shard is not None and self._native.shard[1] > 1 and not local:
+                raise NotImplementedError('DF.loop(): this rank holds its shard of the tensor out of core (C handle); the collective '
+                                          'iteration over ALL aux rows needs the in-core shards - pass local=True for the rows of the shard')
             for blk in self._native.loop(blksize):
                 yield blk
             return
@@ -420,6 +453,7 @@ class DF:
         from .. import lib as _lib
         if self._cderi_dev is None:
             self.build()
+        self._need_in_core('get_eri')
         eri4 = self._pair_gram(self._cderi_dev, self._cderi_dev).cpu().numpy()
         return _lib.pack_tril(eri4)
     get_ao_eri = get_eri
@@ -463,6 +497,7 @@ class DF:
         `compact` (pyscf/df/df.py:278-296)."""
         if self._cderi_dev is None:
             self.build()
+        self._need_in_core('ao2mo')
         if isinstance(mo_coeffs, np.ndarray) and mo_coeffs.ndim == 2:
             mo_coeffs = (mo_coeffs,) * 4
         ci, cj, ck, cl = [np.asarray(c, dtype=np.float64) for c in mo_coeffs]
@@ -471,6 +506,13 @@ class DF:
         lkl = lij if sym else self._half_transform_pairs(ck, cl, compact)
         return self._pair_gram(lij, lkl).cpu().numpy()
     get_mo_eri = ao2mo
+
+    def _need_in_core(self, what):
+        """The consumers that work on the HBM-resident tensor say so when build() handed the tensor to the out-of-core handle
+        (they used to dereference `_cderi_dev = None`)."""
+        if self._cderi_dev is None and getattr(self, '_native', None) is not None:
+            raise NotImplementedError('DF.%s needs the in-core tensor; this object holds it out of core (%s): use more ranks / '
+                                      'devices, or iterate DF.loop() blocks on the host' % (what, self.out_of_core()))
 
     def _shard_path(self, path):
         return '%s.rank%dof%d.npz' % (path, self.rank, self.world_size)
@@ -487,6 +529,8 @@ class DF:
             self.build()
         if fmt is None:
             fmt = 'hdf5' if (hdf5.available() and not path.endswith(('.npy', '.npz'))) else 'npy'
+        if getattr(self, '_native', None) is not None:
+            return self._save_out_of_core(path, fmt)
         if fmt == 'hdf5':
             naux, npair = self._naux, self._cderi_dev.shape[1]
             l0, l1 = self.shard_range(naux, self.rank, self.world_size) if self.world_size > 1 else (0, naux)
@@ -511,6 +555,42 @@ class DF:
             np.save(f, self._cderi_dev.cpu().numpy())
         return path
 
+    def _save_out_of_core(self, path, fmt):
+        """save() of a tensor held by the out-of-core handle: the row blocks of NativeDF.loop() go to the file one after the other
+        (`_cderi_to_save` is honoured on this path too) - never more than one block on the host."""
+        from ..lib import hdf5
+        nat = self._native
+        nao = nat.nao
+        npair = nao * (nao + 1) // 2
+        naux = self._naux
+        l0, l1 = nat.shard_rows
+        sharded = nat.shard is not None and nat.shard[1] > 1
+        step = max(1, (1 << 30) // (npair * 8))
+        if fmt == 'hdf5':
+            world = self.world_size if sharded else 1
+            for turn in range(world):
+                if turn == (self.rank if sharded else 0):
+                    with hdf5.File(path, 'w' if turn == 0 else 'r+') as f:
+                        d = f.create_dataset('j3c', (naux, npair)) if turn == 0 else f['j3c']
+                        r0 = l0
+                        for blk in nat.loop(step):
+                            d.write_rows(r0, blk)
+                            r0 += blk.shape[0]
+                if sharded and getattr(self, '_shard_override', None) is None:
+                    import torch.distributed as dist
+                    dist.barrier(group=self.group)
+            return path
+        if sharded:
+            out = self._shard_path(path)
+            np.savez(out, j3c=np.vstack(list(nat.loop(step))), l0=l0, l1=l1, naux=naux)
+            return out
+        from numpy.lib import format as _fmt
+        with open(path, 'wb') as f:                    # a .npy written block by block
+            _fmt.write_array_header_1_0(f, {'descr': '<f8', 'fortran_order': False, 'shape': (naux, npair)})
+            for blk in nat.loop(step):
+                f.write(np.ascontiguousarray(blk).tobytes())
+        return path
+
     def range_coulomb(self, omega):
         """DF object holding the long-range (omega > 0, erf(omega r12)/r12) or short-range (omega < 0,
         erfc(|omega| r12)/r12) tensor, cached per omega (pyscf/df/df.py:298-333)."""
@@ -530,9 +610,33 @@ class DF:
     def get_jk(self, dm, hermi=1, with_j=True, with_k=True, direct_scf_tol=1e-13, omega=None):
         if omega is not None and omega != 0:
             return self.range_coulomb(omega).get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
+        if self._cderi_dev is None and getattr(self, '_native', None) is None:
+            self.build()
         if getattr(self, '_native', None) is not None:          # out of core: the C handle holds the tensor (build())
-            return self._native.get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
+            vj, vk = self._native.get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
+            if self._native.shard is not None:
+                vj, vk = self._allreduce_host(vj, vk)           # this rank's partial sums -> the sum over the aux shards
+            return vj, vk
         return df_jk.get_jk(self, dm, hermi, with_j, with_k, direct_scf_tol)
+
+    def _allreduce_host(self, vj, vk):
+        """Sum the host arrays of a sharded out-of-core handle over the ranks: RCCL on device copies (backend 'nccl'), in place
+        on the page-locked host arrays with 'gloo'; no-op without an active group (an emulated shard keeps its partial sums)."""
+        import torch
+        from ..lib import comm as _comm
+        if getattr(self, '_shard_override', None) is not None or not _comm.active(self.world_size):
+            return vj, vk
+        arrs = [a for a in (vj, vk) if a is not None]
+        if _comm.backend_name(self.group) == 'nccl':
+            dev = self._device()
+            ts = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
+            _comm.all_reduce(ts, self.group, self.world_size)
+            outs = [t.cpu().numpy() for t in ts]
+        else:
+            outs = [np.ascontiguousarray(a) for a in arrs]
+            _comm.all_reduce([torch.from_numpy(a) for a in outs], self.group, self.world_size)
+        it = iter(outs)
+        return (next(it) if vj is not None else None), (next(it) if vk is not None else None)
 
 
 GDF = DF

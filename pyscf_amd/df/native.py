@@ -25,10 +25,39 @@ def load():
         so = os.environ.get('PAMD_LIBRARY') or os.path.join(here, 'lib', 'libpyscf_amd.so')
         if not os.path.exists(so):
             raise ImportError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"`' % so)
+        _preload_hip_runtime()
         lib = _c.CDLL(so)
         lib.PAMD_last_error.restype = _c.c_char_p
         _lib = lib
     return _lib
+
+
+def _preload_hip_runtime():
+    """ONE HIP runtime per process.  libpyscf_amd.so names libamdhip64.so.7 by SONAME only; a PyTorch-ROCm wheel bundles its own copy
+    under torch/lib.  If this library pulled in the system runtime first and the process imported torch afterwards (a script that
+    builds a NativeDF and then uses pyscf_amd.scf), the second runtime found no device: "the integral engine needs a HIP device"
+    after a 560 GB build (r04's lost config-5 SCF, misread then as a memory problem).  So when a torch install exists but is not
+    imported yet, its bundled runtime is loaded here - WITHOUT importing torch - and a later `import torch` shares it; without a
+    torch install the system runtime is used.  PAMD_HIP_RUNTIME=<path> | system overrides."""
+    import sys
+    choice = os.environ.get('PAMD_HIP_RUNTIME', '')
+    if choice == 'system' or 'torch' in sys.modules:
+        return
+    path = choice
+    if not path:
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec('torch')
+            if spec is not None and spec.submodule_search_locations:
+                cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+                path = cand if os.path.exists(cand) else ''
+        except Exception:
+            path = ''
+    if path:
+        try:
+            _c.CDLL(path, mode=_c.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def _check(rc):
@@ -52,33 +81,29 @@ class _PinnedBlock:
             pass
 
 
-_pinned_pool = []        # [numpy float64 view of a whole block]: a block is handed out again once no result array refers to it
+def _alloc_pinned(nbytes):
+    blk = _PinnedBlock(nbytes)
+    return blk.ptr.value, blk
+
+
+_pool = None
 
 
 def pinned_empty(shape):
     """float64 array of `shape` in page-locked host memory (results of get_jk / nr_rks: the device -> host copy then runs at the
-    PCIe rate, ~50 GB/s, instead of the pageable ~10 GB/s plus first-touch page faults).  Blocks are recycled by reference count:
-    one is reused only when every array handed out from it is gone, so callers keep and modify results as long as they like.
-    Falls back to pageable numpy memory if the allocation is refused."""
-    import sys
+    PCIe rate, ~50 GB/s, instead of the pageable ~10 GB/s plus first-touch page faults).  Blocks are recycled through an explicit
+    free list (pyscf_amd/lib/pinned.py): one is reused only when the array handed out from it AND every view of that array are
+    gone, so callers keep and modify results as long as they like.  Falls back to pageable numpy memory if the allocation is
+    refused."""
+    global _pool
+    if _pool is None:
+        from ..lib.pinned import PinnedPool
+        _pool = PinnedPool(_alloc_pinned)
     n = int(np.prod(shape)) if len(shape) else 1
-    base = None
-    for arr in _pinned_pool:
-        if arr.size >= n and arr.size <= 4 * max(n, 1) and sys.getrefcount(arr) == 3:      # pool list + loop variable + argument
-            base = arr
-            break
-    if base is None:
-        if len(_pinned_pool) >= 8:
-            _pinned_pool[:] = [a for a in _pinned_pool if sys.getrefcount(a) > 3]
-        try:
-            blk = _PinnedBlock(max(n, 1) * 8)
-        except RuntimeError:
-            return np.empty(shape)
-        buf = (_c.c_double * max(n, 1)).from_address(blk.ptr.value)
-        buf._pamd_block = blk                                  # the block lives as long as the ctypes view (= the numpy base)
-        base = np.frombuffer(buf, dtype=np.float64)
-        _pinned_pool.append(base)
-    return base[:n].reshape(shape)
+    got = _pool.take(n)
+    if got is None:
+        return np.empty(shape)
+    return got[0][:n].reshape(shape)
 
 
 def _conc_env(atm1, bas1, env1, atm2, bas2, env2):
@@ -108,7 +133,7 @@ def _scaled_occupied(c, occ):
 class _Options(_c.Structure):
     """PAMD_df_options of include/pyscf_amd.h"""
     _fields_ = [('lindep', _c.c_double), ('omega', _c.c_double), ('devices', _c.POINTER(_c.c_int)), ('ndev', _c.c_int),
-                ('flags', _c.c_int), ('max_device_bytes', _c.c_longlong)]
+                ('flags', _c.c_int), ('max_device_bytes', _c.c_longlong), ('part', _c.c_int), ('nparts', _c.c_int)]
 
 
 class NativeDF:
@@ -119,7 +144,8 @@ class NativeDF:
     and streamed under the kernels in every build (out-of-core, PCIe-bound for those rows)."""
     blockdim = 240
 
-    def __init__(self, mol, auxbasis=None, auxmol=None, device=0, lindep=1e-7, devices=None, omega=0.0, max_device_bytes=0):
+    def __init__(self, mol, auxbasis=None, auxmol=None, device=0, lindep=1e-7, devices=None, omega=0.0, max_device_bytes=0,
+                 shard=None):
         self.mol = mol
         self.auxbasis = auxbasis
         self.auxmol = auxmol
@@ -128,6 +154,9 @@ class NativeDF:
         self.lindep = lindep
         self.omega = float(omega)
         self.max_device_bytes = int(max_device_bytes)
+        # (rank, world): this object holds ONE RANK's rows of the aux-sharded tensor (a multi-process job, one process per GPU);
+        # get_jk then returns that shard's PARTIAL J/K and the caller sums over the ranks (pyscf_amd.df.DF does, RCCL all-reduce)
+        self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
         self._h = None
         self._naux = None
         self._rsh_df = {}                         # omega -> NativeDF of that operator (pyscf/df/df.py:298-333 range_coulomb)
@@ -144,18 +173,31 @@ class NativeDF:
         h = _c.c_void_p()
         devs = self.devices if self.devices is not None else [int(self.device)]
         arr = (_c.c_int * len(devs))(*devs)
-        opt = _Options(self.lindep, self.omega, arr, len(devs), 1 if self.devices is not None else 0, self.max_device_bytes)
+        flags = (1 if self.devices is not None else 0) | (2 if self.shard is not None else 0)
+        part, nparts = self.shard if self.shard is not None else (0, 1)
+        opt = _Options(self.lindep, self.omega, arr, len(devs), flags, self.max_device_bytes, part, nparts)
         _check(load().PAMD_df_create_ex(atm.ctypes.data_as(_c.c_void_p), _c.c_int(len(atm)), bas.ctypes.data_as(_c.c_void_p),
                                         _c.c_int(len(mol._bas)), _c.c_int(len(aux._bas)), env.ctypes.data_as(_c.c_void_p),
                                         _c.c_int(len(env)), _c.byref(opt), _c.byref(h)))
         self._h = h
         n = _c.c_int()
-        _check(load().PAMD_df_naux(h, _c.byref(n)))
-        self._naux = n.value
+        info = (_c.c_int * 4)()
+        _check(load().PAMD_df_shard_info(h, info))
+        self.shard_rows = (info[0], info[0] + info[1])      # global rows this handle holds ([0, naux) unless `shard` is set)
+        self._naux = info[2]
         _check(load().PAMD_df_nao(h, _c.byref(n)))
         self.nao = n.value
         return self
     kernel = build
+
+    def last_timing(self):
+        """Host-clock timings of the last get_jk inside the handle (PAMD_df_last_timing): {'parts', 'sum_download_ms', 'peer',
+        'compute_ms': [...], 'push_ms': [...], 'push_bytes': [...]} - what bench.py --single-process reports as `comm`."""
+        out = (_c.c_double * (3 + 3 * 64))()
+        _check(load().PAMD_df_last_timing(self._h, out, _c.c_int(len(out))))
+        n = int(out[0])
+        return dict(parts=n, sum_download_ms=out[1], peer=int(out[2]), compute_ms=[out[3 + 3 * i] for i in range(n)],
+                    push_ms=[out[4 + 3 * i] for i in range(n)], push_bytes=[int(out[5 + 3 * i]) for i in range(n)])
 
     def layout(self):
         """{'parts', 'rows_resident', 'rows_host', 'rows_square', 'peer', 'part_rows'} of the built handle (PAMD_df_layout)."""
@@ -173,7 +215,7 @@ class NativeDF:
         key = '%.6f' % omega
         if key not in self._rsh_df:
             self._rsh_df[key] = NativeDF(self.mol, self.auxbasis, self.auxmol, self.device, self.lindep, self.devices, omega,
-                                         self.max_device_bytes)
+                                         self.max_device_bytes, self.shard)
         return self._rsh_df[key]
 
     def reset(self, mol=None):
@@ -203,8 +245,9 @@ class NativeDF:
         self.build()
         blksize = blksize or self.blockdim
         npair = self.nao * (self.nao + 1) // 2
-        for b0 in range(0, self._naux, blksize):
-            b1 = min(b0 + blksize, self._naux)
+        nrow = self.shard_rows[1] - self.shard_rows[0]       # (a rank's shard: its own rows, local numbering)
+        for b0 in range(0, nrow, blksize):
+            b1 = min(b0 + blksize, nrow)
             out = np.empty((b1 - b0, npair))
             _check(load().PAMD_df_export_cderi(self._h, _c.c_int(b0), _c.c_int(b1), out.ctypes.data_as(_c.c_void_p)))
             yield out

@@ -88,30 +88,30 @@ def tag_array(a, **kwargs):
     return t
 
 
+def _alloc_pinned_torch(nbytes):
+    import torch
+    t = torch.empty(nbytes // 8, dtype=torch.float64, pin_memory=True)
+    return t.data_ptr(), t
+
+
 def download(holder, tensors):
     """Device tensors -> numpy arrays with ONE asynchronous copy per tensor and ONE stream synchronisation, straight into
     page-locked host memory that the returned arrays then own a share of: no second host copy, no first-touch page faults (a
     pageable `.cpu()` per result, or a copy from a staging buffer into fresh numpy arrays, cost 10-25 ms per J/K build at
-    nao = 1856).  The pinned buffers are recycled by reference count: a buffer is handed out again only when no array returned
-    earlier (or any view of one) is alive any more, so callers may keep and modify results as long as they like."""
-    import sys
+    nao = 1856).  The pinned blocks are recycled through an explicit free list (lib/pinned.py): a block is handed out again only
+    when no array returned earlier (or any view of one) is alive any more, so callers may keep and modify results as long as they
+    like."""
     import torch
+    from .pinned import PinnedPool
     n = max(sum(t.numel() for t in tensors), 1)
     pool = getattr(holder, '_pinned_pool', None)
     if pool is None:
-        pool = holder._pinned_pool = []
-    base = None
-    for ent in pool:                                     # (numpy view of the whole pinned tensor, the tensor)
-        if ent[0].size >= n and sys.getrefcount(ent[0]) == 2:       # the pool's tuple + getrefcount's argument: no view alive
-            base = ent
-            break
-    if base is None:
-        if len(pool) >= 8:                               # drop idle buffers before growing without bound
-            pool[:] = [e for e in pool if sys.getrefcount(e[0]) > 2]
-        t = torch.empty(n, dtype=torch.float64, pin_memory=True)
-        base = (t.numpy(), t)
-        pool.append(base)
-    arr, pin = base
+        pool = holder._pinned_pool = PinnedPool(_alloc_pinned_torch)
+    got = pool.take(n)
+    if got is None:
+        raise MemoryError('page-locked host memory for %d doubles' % n)
+    arr, blk = got
+    pin = blk.owner
     off, outs = 0, []
     for t in tensors:
         m = t.numel()

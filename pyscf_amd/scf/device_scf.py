@@ -71,13 +71,17 @@ def eligible(mf, callback=None):
         from ..dft import libxc
         if libxc.xc_type(mf.xc) not in ('LDA', 'GGA', 'HF'):
             return False
-    # the loop works on the in-core device tensor: build it now; an out-of-core tensor (DF.build handed it to the C handle) keeps
-    # the host loop
-    if mf.with_df._cderi_dev is None and getattr(mf.with_df, '_native', None) is None:
-        mf.with_df.build()
+    # the loop works on the in-core device tensor; an out-of-core tensor (DF.build hands it to the C handle) keeps the host loop.
+    # A predicate must not build a tensor of hundreds of GB as a side effect: ask the cheap fit check
     if getattr(mf.with_df, '_native', None) is not None:
         return False
-    return True
+    if mf.with_df._cderi_dev is None and not isinstance(mf.with_df._cderi, (str, np.ndarray)) and not mf.with_df.would_fit():
+        return False
+    # every other condition holds and the tensor fits: the loop needs it now anyway (a build that still ends out of core - the
+    # estimate and the allocator disagreeing by a hair - keeps the host loop)
+    if mf.with_df._cderi_dev is None:
+        mf.with_df.build()
+    return getattr(mf.with_df, '_native', None) is None
 
 
 class DeviceDIIS:

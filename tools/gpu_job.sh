@@ -62,6 +62,10 @@ e2w)        # wide last orbital chunk of the half transform (taxol shape): kerne
 cfg5)       # BASELINE config 5 whole (560 GB) on one GPU through the out-of-core handle (opt-in test)
   PAMD_RUN_CONFIG5_FULL=1 timeout 1500 python -m pytest -q -x tests/test_gpu_native_r04.py::test_config5_whole_tensor_out_of_core_on_one_gpu_vs_oracle_goldens -m gpu > $O/pytest.log 2>&1; tail -5 $O/pytest.log
   tail -4 gpurun_out/_native_cfg45_worker_config5.log ;;
+cfg5scf)    # BASELINE config 5 converged on ONE GPU through the out-of-core handle; dumps the occupied orbitals (oracle energy golden input)
+  nproc > $O/host.txt; grep -E "MemTotal|MemAvailable" /proc/meminfo >> $O/host.txt; df -h /tmp . >> $O/host.txt; cat $O/host.txt
+  timeout 1500 python tools/run_scf.py --nwater 128 --basis cc-pvdz --xc '' --native --conv-tol ${1:-1e-10} --dump-orbitals $O/h2o128_rhf_orbitals.npz > $O/scf_h2o128_rhf_native.log 2>&1
+  grep -E "NativeDF built|cycle=|converged" $O/scf_h2o128_rhf_native.log | tail -40 ;;
 probe)      # one-off hardware probes
   ./tools/probe/cu_mask_probe.bin 2>&1 | tee $O/cu_mask_probe.log ;;
 kab)        # kbench A/B of tuning keys on the config-3 shape: gpu_job.sh kab "<tune1>" "<tune2>" ...  (use - for none)
