@@ -37,6 +37,61 @@ def _aux_label(b):
     return str(b)
 
 
+def _golden_case(args, nao, nocc):
+    """(file, key prefix, rank of the seeded density) of the oracle-only J/K golden that matches this workload, or None."""
+    if args.molecule == 'water' and args.nwater == 32 and args.basis == 'cc-pvtz':
+        return 'h2o32_ccpvtz_oracle.json', '', nocc
+    if args.molecule == 'taxol' and args.basis == 'def2-tzvp':
+        return 'taxol_def2tzvp_oracle.json', 'syn_', 32
+    return None
+
+
+def _golden_density(nao, rank):
+    """The seeded density of tools/gen_golden_*.py: D = 2 C C^T, C uniform in [-0.5, 0.5) / sqrt(nao) from RandomState(7)
+    (oracle/golden_util.synthetic_orbitals restated: three lines of numpy, so that an N > 1 run imports nothing from oracle/)."""
+    rng = np.random.RandomState(7)
+    c = (rng.random_sample((nao, rank)) - 0.5) / np.sqrt(nao) * np.sqrt(2.0)
+    cfull = np.zeros((nao, nao))
+    cfull[:, :rank] = c
+    occ = np.zeros(nao)
+    occ[:rank] = 1.0
+    return c.dot(c.T), cfull, occ
+
+
+def _parity_golden(args, nao, nocc, get_jk):
+    """In-run correctness evidence at ANY N, both launch modes: J and K of the seeded density of the committed
+    oracle-only golden (tests/golden/, computed by the CPU oracle alone at full size) through the same product path that was
+    timed - sharded, all-reduced / gathered - against the golden's fingerprints and 4096 sampled elements.  `get_jk(dm_tag)` is
+    called on EVERY rank (it contains the collective); the comparison is returned for rank 0 to print."""
+    case = _golden_case(args, nao, nocc)
+    if case is None:
+        return {'golden': None, 'why': 'no oracle-only J/K golden is committed for this workload (configs 3 and 4 have one)'}
+    fname, pre, rank_d = case
+    path = os.path.join(ROOT, 'tests', 'golden', fname)
+    if not os.path.exists(path):
+        return {'golden': None, 'why': '%s is missing' % fname}
+    g = json.load(open(path))
+    from pyscf_amd import lib
+    dm, cfull, occ = _golden_density(nao, rank_d)
+    vj, vk = get_jk(lib.tag_array(dm, mo_coeff=cfull, mo_occ=occ))
+    vj, vk = np.asarray(vj).reshape(nao, nao), np.asarray(vk).reshape(nao, nao)
+    rng = np.random.RandomState(int(g.get('sample_seed', 11)))
+    n = len(g[pre + 'vk_sample'])
+    ri, ci = rng.randint(0, nao, size=n), rng.randint(0, nao, size=n)
+    out = {'golden': 'tests/golden/' + fname, 'density': g.get(pre + 'density', g.get('jk_density')), 'tol': 1e-9}
+    ok = True
+    for name, m in (('vj', vj), ('vk', vk)):
+        fp = float(np.dot(np.cos(np.arange(m.size)), m.ravel()))
+        err_s = float(np.abs(m[ri, ci] - np.array(g[pre + name + '_sample'])).max() / g[pre + name + '_absmax'])
+        err_n = float(abs(np.linalg.norm(m) - g[pre + name + '_norm']) / g[pre + name + '_norm'])
+        err_f = float(abs(fp - g[pre + name + '_fp']) / g[pre + name + '_norm'])
+        out.update({'fp_' + name: fp, 'fp_%s_golden' % name: g[pre + name + '_fp'], 'max_rel_err_' + name: max(err_s, err_n, err_f)})
+        ok = ok and max(err_s, err_n, err_f) < 1e-9
+    out['max_rel_err'] = max(out['max_rel_err_vj'], out['max_rel_err_vk'])
+    out['ok'] = bool(ok)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -233,7 +288,11 @@ def main():
         naux_per_rank = [int(v) for v in rows_t.cpu()]
     else:
         naux_per_rank = [int(naux_local)]
-    assert sum(naux_per_rank) == naux, 'aux rows of the ranks do not add up to naux'
+    if sum(naux_per_rank) != naux:
+        raise SystemExit('bench.py: the aux rows of the ranks %r do not add up to naux = %d' % (naux_per_rank, naux))
+    # in-run correctness evidence at any N: the committed oracle-only golden through the sharded + all-reduced product path
+    parity_golden = _parity_golden(args, nao, nocc, lambda d: dfobj.get_jk(d, hermi=1))
+    fence()
 
     # per-kernel durations (one extra, untimed step with HIP events around every launch)
     # (J and K are issued back-to-back on one stream for this pass so that each kernel is timed alone;
@@ -463,13 +522,11 @@ def main():
             vj0, vk0, cpu_flops = ref_c.get_jk(sample, dm, c, mo_occ, blockdim=240, nthreads=ncore)
             cpu_s = time.perf_counter() - t0
             phases, kind = ref_c.get_jk.last_phases, 'reference'
-            ncore = ref_c.get_jk.last_threads            # the threads really used (capped at 64: scipy's OpenBLAS)
+            ncore = ref_c.get_jk.last_threads            # the threads really used (all host cores on the MKL variant, <= 64 on OpenBLAS)
             what = ("the reference's own C (AO2MOnr_e2_drv / AO2MOtranse2_nr_s2 / AO2MOmmm_bra_nr_s2 of lib/ao2mo/nr_ao2mo.c, NPdgemm / "
                     "NPdunpack_tril of lib/np_helper) compiled into oracle/_ref and called as pyscf/df/df_jk.py:329-381 does, blocks "
-                    "of 240 aux rows; %d OpenMP threads, BLAS serial inside the parallel regions (scipy's OpenBLAS is capped at 64 "
-                    "concurrent callers, so the reference's omp loops run on min(host cores, 64) threads with one BLAS thread each - "
-                    "`cores` is that number, the host has %d); the J line is numpy.matmul as in the reference"
-                    % (ref_c.get_jk.last_threads, os.cpu_count()))
+                    "of 240 aux rows; %s; the J line is numpy.matmul as in the reference; integral generation (libcint) is not "
+                    "part of it" % ref_c.describe())
         else:
             ref.get_jk_rows_parallel(sample[:min(nrow, 64)], dm, c, mo_occ, nthreads=ncore)      # warm the BLAS threads
             t0 = time.perf_counter()
@@ -512,11 +569,14 @@ def main():
         'kernels': kern, 'kernels_what': 'HIP events around every launch of the %d timed steps, per step (ms_total) and per launch '
                                          '(ms_avg); J runs overlapped with K there' % args.steps,
         'kernels_serial_pass': kern_serial, 'j_hbm_GBs': j_gbs, 'k_mfma_TFLOPs': k_tflops,
-        'build_s': round(build_s, 2), 'parity_sample': parity, 'xc_path': xc_info,
+        'build_s': round(build_s, 2), 'parity_golden': parity_golden, 'parity_sample': parity, 'xc_path': xc_info,
     }
     print(json.dumps(out))
     if grouped:
         dist.destroy_process_group()
+    if parity_golden.get('golden') and not parity_golden['ok']:
+        raise SystemExit('bench.py: J/K of the golden density differ from tests/golden by %.3e (relative): the number above is '
+                         'not a valid measurement' % parity_golden['max_rel_err'])
 
 
 def _pmc_passes(args):
@@ -603,6 +663,42 @@ def single_process_main(args):
     dt = time.perf_counter() - t0
     ms = dt / args.steps * 1e3
     lay = obj.layout()
+    tm = obj.last_timing()                                # of the last timed call: host clocks + HIP events inside the handle
+    if sum(lay['part_rows']) != naux:
+        raise SystemExit('bench.py --single-process: the aux rows of the parts %r do not add up to naux = %d' % (lay['part_rows'], naux))
+    ndist = len(set(devices))
+    if ndist > 1 and not lay['peer'] and os.environ.get('PAMD_DF_PEER', '') != '0':
+        raise SystemExit('bench.py --single-process: %d distinct devices but the partial J/K travel through the HOST (peer access was '
+                         'refused): this is not the xGMI path the number would be quoted for; set PAMD_DF_PEER=0 to time the host '
+                         'bounce on purpose' % ndist)
+    parity_golden = _parity_golden(args, nao, nocc, lambda d: obj.get_jk(d, hermi=1))
+    # roofline of the dominant kernel (the half transform) per part, from the HIP events the handle records on its launch stream
+    e2 = [t for t in tm['e2_ms']]
+    worst = int(np.argmax(e2)) if e2 else 0
+    roofline = None
+    if e2 and e2[worst] > 0:
+        fl = 2.0 * lay['part_rows'][worst] * nao * nao * nocc
+        ach = fl / (e2[worst] * 1e-3) / 1e12
+        roofline = {'bound': 'mfma', 'kernel': 'half transform of part %d (the slowest part), HIP events on its launch stream inside the '
+                    'handle (PAMD_df_last_timing)' % worst, 'achieved': round(ach, 3), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': None, 'ms': round(e2[worst], 3),
+                    'flops_per_step': fl, 'e2_ms_per_part': [round(t, 3) for t in tm['e2_ms']],
+                    'syrk_ms_per_part': [round(t, 3) for t in tm['syrk_ms']]}
+    moved = [b for b in tm['push_bytes'] if b > 0]
+    comm = {'what': 'every part pushes its packed [J~ | K] into its slot of the gather buffer on device %d from its own thread and '
+                    'stream (hipMemcpyPeerAsync over xGMI where peer access is granted), fixed-order sum there, one download' % devices[0],
+            'peer_copies': bool(lay['peer']) and ndist > 1, 'distinct_devices': ndist,
+            'bytes_per_part': tm['push_bytes'], 'push_ms_per_part': [round(t, 3) for t in tm['push_ms']],
+            'sum_download_ms': round(tm['sum_download_ms'], 3), 'compute_ms_per_part': [round(t, 2) for t in tm['compute_ms']],
+            'algorithm_GBs_per_link': round(max(moved) / (max(p for p, b in zip(tm['push_ms'], tm['push_bytes']) if b > 0) * 1e-3) / 1e9, 2)
+            if moved else None,
+            'xgmi_link_peak_GBs': 153.0, 'xgmi_links_per_gpu': 7,
+            'note': 'push_ms is a host clock around pack + copy + stream synchronisation of one part (it includes the wait for the '
+                    "part's own kernels to drain); with all parts on ONE device nothing crosses a link and bytes are 0"}
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline and args.gpus == 1:
+        cpu, parity = _cpu_baseline_native(args, obj, dm, c, mo_occ, nao, naux, npair)
     xc_info = None
     if args.xc:
         # the XC leg through the host-array handle over the same device list (grid tiles dealt round-robin over the parts)
@@ -634,14 +730,63 @@ def single_process_main(args):
                           label, args.basis, nao, naux, nocc, 8e-9 * naux * npair, args.gpus),
                       'parallelism': 'aux-index shards x%d in one process (C handle)' % args.gpus, 'devices': devices,
                       'naux_per_rank': lay['part_rows'], 'layout': lay},
-           'roofline': None,
+           'roofline': roofline,
            'roofline_step': {'executed_TFLOP': round(step_exec / 1e12, 3), 'achieved_TFLOPs': round(step_exec / (ms * 1e-3) / 1e12, 2),
                              'peak_TFLOPs': FP64_MFMA_PEAK_TFLOPS * len(set(devices)),
                              'frac': round(step_exec / (ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * len(set(devices))), 4)},
-           'cpu_baseline': None, 'build_s': round(build_s, 2), 'xc_path': xc_info,
+           'comm': comm, 'cpu_baseline': cpu, 'parity_golden': parity_golden, 'parity_sample': parity,
+           'build_s': round(build_s, 2), 'xc_path': xc_info,
            'checksum': {'fp_vj': lib.fp(vj), 'fp_vk': lib.fp(vk)}}
     print(json.dumps(out))
     obj.reset()
+    if parity_golden.get('golden') and not parity_golden['ok']:
+        raise SystemExit('bench.py: J/K of the golden density differ from tests/golden by %.3e (relative): the number above is '
+                         'not a valid measurement' % parity_golden['max_rel_err'])
+
+
+def _cpu_baseline_native(args, obj, dm, c, mo_occ, nao, naux, npair):
+    """The reference's own C (oracle/_ref) on the host cores over the rows exported from the handle (single-process mode, N = 1):
+    the same leg as the default mode's `cpu_baseline` + `parity_sample`."""
+    from oracle import ref, ref_c
+    ncore = args.cpu_threads or os.cpu_count()
+    nrow = args.cpu_sample_rows
+    if nrow <= 0:
+        avail = 0
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                avail = int(line.split()[1]) * 1024
+        nrow = naux if avail > 1.5 * 8.0 * naux * npair + (32 << 30) else -(-naux // 2)
+    nrow = min(nrow, naux)
+    sample = np.empty((nrow, npair))
+    from pyscf_amd.df import native as _nat
+    import ctypes as _ct
+    for r0 in range(0, nrow, 240):
+        r1 = min(r0 + 240, nrow)
+        _nat._check(_nat.load().PAMD_df_export_cderi(obj._h, _ct.c_int(r0), _ct.c_int(r1), sample[r0:r1].ctypes.data_as(_ct.c_void_p)))
+    if ref_c.available():
+        ref_c.get_jk(sample[:min(nrow, 240)], dm, c, mo_occ, nthreads=ncore)
+        t0 = time.perf_counter()
+        vj0, vk0, cpu_flops = ref_c.get_jk(sample, dm, c, mo_occ, blockdim=240, nthreads=ncore)
+        cpu_s = time.perf_counter() - t0
+        phases, kind, ncore = ref_c.get_jk.last_phases, 'reference', ref_c.get_jk.last_threads
+        what = "the reference's own C (oracle/_ref, pyscf/lib/ao2mo/nr_ao2mo.c + np_helper), %s" % ref_c.describe()
+    else:
+        ref.get_jk_rows_parallel(sample[:min(nrow, 64)], dm, c, mo_occ, nthreads=ncore)
+        t0 = time.perf_counter()
+        vj0, vk0, cpu_flops = ref.get_jk_rows_parallel(sample, dm, c, mo_occ, nthreads=ncore)
+        cpu_s = time.perf_counter() - t0
+        phases, kind = getattr(ref.get_jk_rows_parallel, 'last_phases', None), 'port'
+        what = 'oracle/ref.get_jk_rows_parallel (numpy restatement of df_jk.py:329-381; oracle/_ref was not built)'
+    cpu = {'value': round(cpu_s / nrow * naux * 1e3, 1),
+           'unit': 'ms/iter' + ('' if nrow == naux else ' (extrapolated from %d to all %d aux rows)' % (nrow, naux)),
+           'cores': ncore, 'kind': kind, 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1), 'phases_s': phases,
+           'sample': '%s; %d of %d aux rows of the GPU-built tensor: %.2f s' % (what, nrow, naux, cpu_s)}
+    parity = None
+    if nrow == naux:
+        vj1, vk1 = obj.get_jk(dm, hermi=1)
+        parity = {'rows': nrow, 'checker': kind, 'max_abs_err_vj': float(np.abs(vj1 - vj0).max()),
+                  'max_abs_err_vk': float(np.abs(vk1 - vk0).max())}
+    return cpu, parity
 
 
 class _Single:

@@ -354,8 +354,9 @@ typedef struct PAMD_df PAMD_df;
  *                         PAMD_df_get_jk returns that shard's PARTIAL J/K, the caller sums over the ranks (the accumulation over
  *                         `dfobj.loop()` blocks of pyscf/df/df_jk.py:362-381, spread over processes)
  *   PAMD_df_shard_info    info[4] = {first global row, rows held, rows of the whole tensor, 1 = partial sums}
- *   PAMD_df_last_timing   host-clock timings of the last PAMD_df_get_jk: out[3 + 3 parts] = {parts, ms of sum + download on part 0,
- *                         peer copies used 0/1, then per part: ms contraction, ms push into the gather buffer, bytes pushed across devices}
+ *   PAMD_df_last_timing   timings of the last PAMD_df_get_jk: out[3 + 5 parts] = {parts, host ms of sum + download on part 0, peer
+ *                         copies used 0/1, then per part: host ms contraction, host ms push into the gather buffer, bytes pushed
+ *                         across devices, HIP-event ms of the half-transform launches, of the SYRK launches}
  *   PAMD_df_layout        layout[5] = {parts, rows resident in HBM, rows in host memory, rows with a square image, peer copies 0 / 1},
  *                         part_rows[parts] (nullable) = rows per part */
 typedef struct PAMD_df_options {

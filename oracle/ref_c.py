@@ -12,10 +12,11 @@ DF J/K hot path (built by `make -C oracle ref` from the sources where they lie u
       ``vk += lib.dot(buf1.T, buf1)``                                    (:380)      -> NPdgemm (np_helper/npdot.c:32, OpenMP over k)
   * ``vj = lib.unpack_tril(vj, 1)``                                      (:410)      -> NPdunpack_tril_2d (pack_tril.c:214)
 
-Threading as in a stock PySCF build (OpenMP-threaded C, BLAS serial inside the parallel regions): the OpenBLAS that ships in
-scipy's wheel is pthread-based and compiled for at most 64 concurrent callers, so it is pinned to ONE thread per call and the
-reference's own `#pragma omp` loops run on min(host cores, 64) threads (more callers crashed it on the 256-core GPU host);
-`numpy.matmul` of the J line keeps numpy's own BLAS threading.
+Threading as in a stock PySCF build (OpenMP-threaded C, BLAS serial inside the parallel regions).  Two builds of the same sources:
+`libref_dfjk.so` on the OpenBLAS that ships in scipy's wheel (pthread-based, compiled for at most 64 concurrent callers: the
+reference's `#pragma omp` loops then run on min(host cores, 64) threads - more callers crashed it on the 256-core GPU host), and
+- r05 - `libref_dfjk_mkl.so` on the MKL inside libtorch_cpu.so (no cap: all host cores; chosen by `variant()` after a self-test in
+a child process).  `numpy.matmul` of the J line keeps numpy's own BLAS threading in both.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
 import ctypes
@@ -26,7 +27,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, '_ref', 'libref_dfjk.so')
+SO_MKL = os.path.join(HERE, '_ref', 'libref_dfjk_mkl.so')
 _lib = None
+_variant = None            # 'openblas' (scipy's, <= 64 concurrent callers) | 'mkl' (libtorch_cpu's, no cap: all host cores)
 
 
 def available():
@@ -34,11 +37,73 @@ def available():
 
 
 def build():
-    """(re)build oracle/_ref when the reference tree is present (this container); elsewhere use the prebuilt file."""
+    """(re)build oracle/_ref when the reference tree is present (this container); elsewhere use the prebuilt files."""
     if os.path.isdir('/root/reference/pyscf/lib'):
         import subprocess
         subprocess.check_call(['make', '-s', '-C', HERE, 'ref'])
+        try:
+            subprocess.check_call(['make', '-s', '-C', HERE, 'ref_mkl'])
+        except Exception:                       # no torch install to link against: the OpenBLAS variant alone
+            pass
     return available()
+
+
+def variant():
+    """Which BLAS the reference's C runs on.  r05: on a host with more cores than scipy's OpenBLAS admits concurrent callers (64)
+    the variant linked against the MKL inside libtorch_cpu.so is used - after a self-test in a CHILD process (all host cores
+    calling into it at once on a small case, checked against numpy), so that a BLAS that misbehaves takes down the child, not the
+    benchmark.  PAMD_REF_BLAS=openblas | mkl forces a choice."""
+    global _variant
+    if _variant is not None:
+        return _variant
+    want = os.environ.get('PAMD_REF_BLAS', '')
+    if want in ('openblas', 'mkl'):
+        _variant = want if (want == 'openblas' or os.path.exists(SO_MKL)) else 'openblas'
+        return _variant
+    _variant = 'openblas'
+    if os.path.exists(SO_MKL) and (os.cpu_count() or 1) > MAX_BLAS_CALLERS:
+        import subprocess
+        import sys
+        code = ("import sys; sys.path.insert(0, %r); import os; os.environ['PAMD_REF_BLAS'] = 'mkl'; "
+                "from oracle import ref_c; ref_c.selftest()" % os.path.dirname(HERE))
+        try:
+            p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+            if p.returncode == 0 and 'REF_C_SELFTEST_OK' in p.stdout:
+                _variant = 'mkl'
+        except Exception:
+            pass
+    return _variant
+
+
+def selftest():
+    """Small J/K through the loaded variant on ALL host cores against numpy; prints REF_C_SELFTEST_OK."""
+    rng = np.random.RandomState(3)
+    nao, naux, nocc = 96, 3 * (os.cpu_count() or 1) + 5, 24
+    npair = nao * (nao + 1) // 2
+    cderi = rng.rand(naux, npair) - .5
+    c = np.linalg.qr(rng.rand(nao, nao))[0]
+    occ = np.zeros(nao)
+    occ[:nocc] = 2
+    dm = (c * occ).dot(c.T)
+    for _ in range(3):                           # repeated: a caller-table overflow shows up under sustained load
+        vj, vk, _f = get_jk(cderi, dm, c, occ, blockdim=2 * (os.cpu_count() or 1), nthreads=os.cpu_count())
+    full = np.zeros((naux, nao, nao))
+    idx = np.tril_indices(nao)
+    full[:, idx[0], idx[1]] = cderi
+    full[:, idx[1], idx[0]] = cderi
+    vj0 = np.einsum('Lpq,L->pq', full, np.einsum('Lpq,pq->L', full, dm))
+    vk0 = np.einsum('Lpr,rs,Lqs->pq', full, dm, full)
+    assert np.abs(vj - vj0).max() < 1e-10 and np.abs(vk - vk0).max() < 1e-10, (np.abs(vj - vj0).max(), np.abs(vk - vk0).max())
+    print('REF_C_SELFTEST_OK %s threads %d' % (variant(), get_jk.last_threads), flush=True)
+
+
+def describe():
+    if variant() == 'mkl':
+        return ('BLAS = the MKL linked into libtorch_cpu.so (dgemm_; dsymm_ = triangle completion + dgemm_, oracle/ref_build/'
+                'dsymm_via_dgemm.c), one BLAS thread per call inside the reference\'s OpenMP regions, %d OpenMP threads = all host '
+                'cores (self-tested in a child process first)' % get_jk.last_threads)
+    return ("BLAS = scipy's OpenBLAS, one BLAS thread per call inside the reference's OpenMP regions; that build admits 64 concurrent "
+            "callers, so the omp loops run on min(host cores, 64) = %d threads (the host has %d)" % (get_jk.last_threads, os.cpu_count()))
 
 
 def lib():
@@ -46,8 +111,13 @@ def lib():
     if _lib is None:
         if not available():
             raise RuntimeError('oracle/_ref/libref_dfjk.so is missing: run `make -C oracle ref` where /root/reference exists')
-        _lib = ctypes.CDLL(SO)
-        _lib.scipy_openblas_set_num_threads.argtypes = [ctypes.c_int]
+        if variant() == 'mkl':
+            import torch                                   # libtorch_cpu.so (and its OpenMP runtime) first: ONE libgomp in the process
+            torch.set_num_threads(1)                       # MKL: one thread per dgemm_ call
+            _lib = ctypes.CDLL(SO_MKL)
+        else:
+            _lib = ctypes.CDLL(SO)
+            _lib.scipy_openblas_set_num_threads.argtypes = [ctypes.c_int]
         _lib.omp_get_max_threads.restype = ctypes.c_int
     return _lib
 
@@ -64,8 +134,13 @@ def set_threads(n):
     """OpenMP threads of the reference's C (lib.num_threads(), pyscf/lib/misc.py:195-224), capped at MAX_BLAS_CALLERS; BLAS
     stays at one thread per call.  Returns the thread count really used (bench.py reports it as `cores`)."""
     l = lib()
-    l.scipy_openblas_set_num_threads(1)
-    n = min(int(n or os.cpu_count() or 1), MAX_BLAS_CALLERS)
+    if variant() == 'mkl':
+        import torch
+        torch.set_num_threads(1)
+        n = int(n or os.cpu_count() or 1)                  # no cap on concurrent callers
+    else:
+        l.scipy_openblas_set_num_threads(1)
+        n = min(int(n or os.cpu_count() or 1), MAX_BLAS_CALLERS)
     l.omp_set_num_threads(ctypes.c_int(n))
     return l.omp_get_max_threads()
 

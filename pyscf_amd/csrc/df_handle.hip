@@ -265,6 +265,18 @@ struct PAMD_df {
     // timings of the last PAMD_df_get_jk (PAMD_df_last_timing): per part contraction and push into the gather buffer, sum + download
     double t_compute_ms = 0, t_push_ms = 0, t_sum_ms = 0;
     size_t push_bytes = 0;
+    // HIP events around the half-transform and SYRK launches of the last build, on the stream they are launched on
+    std::vector<hipEvent_t> tev;
+    double t_e2_ms = 0, t_syrk_ms = 0;
+    hipEvent_t timing_event(size_t i)
+    {
+        while (tev.size() <= i) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            tev.push_back(e);
+        }
+        return tev[i];
+    }
     std::map<std::string, std::pair<double *, size_t>> ws;
     double *workspace(const std::string &name, size_t ndoubles, int *rc)
     {
@@ -294,6 +306,7 @@ struct PAMD_df {
             if (ev_free[k]) (void)hipEventDestroy(ev_free[k]);
         }
         if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t e : tev) (void)hipEventDestroy(e);
         if (copy) (void)hipStreamDestroy(copy);
         if (side) (void)hipStreamDestroy(side);
         if (st) (void)hipStreamDestroy(st);
@@ -1063,6 +1076,16 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
         PAMD_CHECK_HIP(hipEventRecord(h->ev_ready[sg.stage], h->copy));
         return 0;
     };
+    // HIP events around the MFMA kernels of this build (kinds 0/1: half transform begin / end, 2/3: SYRK begin / end), read after
+    // the final synchronisation: PAMD_df_last_timing -> bench.py --single-process `roofline`
+    std::vector<int> mark_kind;
+    auto mark = [&](int kind) {
+        if (mark_kind.size() >= 512) return;
+        hipEvent_t e = h->timing_event(mark_kind.size());
+        if (!e) return;
+        (void)hipEventRecord(e, st);
+        mark_kind.push_back(kind);
+    };
     for (size_t i = 0; i < segs.size(); i++)
         if (segs[i].stage >= 0) { if ((rc = issue_copy(i))) return rc; break; }     // prime the first staged block
     for (size_t si = 0; si < segs.size(); si++) {
@@ -1105,6 +1128,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                     const int nb = (int)std::min<long>(blk, sg.n - b0);
                     const double *sub = sg.rows + (size_t)b0 * npair;
                     double *rho_b = fused ? d_rho + (size_t)s * nL + sg.row0 + b0 : nullptr;
+                    mark(0);
                     if (sg.sq)
                         rc = PAMD_nr_e2_square(sg.sq + (size_t)b0 * rows * rows, rows, rows, nb, nao, o.d_orb, (int)o.ldo, rows, xr,
                                                d_X, ldx, rho_b, d_rw, st);
@@ -1112,6 +1136,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                         rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, o.d_orb, (int)o.ldo, rows, xr, d_X, ldx, rho_b, d_rw,
                                                   sg.diag ? sg.diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st);
                     if (rc) return rc;
+                    mark(1);
                     if (fused) {
                         // second J pass of this block: in line, or on the side stream beside the block's SYRK (HBM- beside MFMA-bound)
                         if (serial_j2) {
@@ -1124,7 +1149,9 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                     }
                     const long kx = (long)nb * xr, kx16 = round_up(kx, 16);
                     if (kx16 > kx) { PAMD_CHECK_HIP(hipMemsetAsync(d_X + (size_t)kx * ldx, 0, (size_t)(kx16 - kx) * ldx * 8, st)); }
+                    mark(2);
                     if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, part_s, nao, nao, nao, kx16, syrk_flags, nsplit, st))) return rc;
+                    mark(3);
                 }
             } else {
                 // ---- general-DM branch: T_L = B_L D, K = sum_L T_L^T B_L (df_jk.py:382-407)
@@ -1183,6 +1210,13 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
     PAMD_CHECK_HIP(hipStreamSynchronize(st));
     PAMD_CHECK_HIP(hipStreamSynchronize(h->side));
     PAMD_CHECK_HIP(hipStreamSynchronize(h->copy));
+    h->t_e2_ms = h->t_syrk_ms = 0;
+    for (size_t i = 0; i + 1 < mark_kind.size(); i++)
+        if ((mark_kind[i] == 0 && mark_kind[i + 1] == 1) || (mark_kind[i] == 2 && mark_kind[i + 1] == 3)) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, h->tev[i], h->tev[i + 1]) == hipSuccess) (mark_kind[i] == 0 ? h->t_e2_ms : h->t_syrk_ms) += ms;
+        }
+    (void)hipGetLastError();
     return 0;
 }
 
@@ -1643,26 +1677,29 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
     return rc;
 }
 
-// Host-clock timings of the LAST PAMD_df_get_jk on this handle (bench.py --single-process `comm`): out[0] = parts, out[1] = ms of the
-// fixed-order sum + unpack + download on part 0, out[2] = 1 when the partial results travelled by direct peer copies (xGMI), 0 for
-// the host bounce or a single device; then per part p: out[3 + 3p] = ms of the shard's contraction (kernels + synchronisation),
-// out[4 + 3p] = ms of laying out and pushing [J~ | K] into part 0's gather buffer, out[5 + 3p] = bytes that crossed devices.
+// Timings of the LAST PAMD_df_get_jk on this handle (bench.py --single-process `roofline` / `comm`): out[0] = parts, out[1] = host ms
+// of the fixed-order sum + unpack + download on part 0, out[2] = 1 when the partial results travelled by direct peer copies (xGMI),
+// 0 for the host bounce or a single device; then per part p: out[3 + 5p] = host ms of the shard's contraction (kernels +
+// synchronisation), out[4 + 5p] = host ms of laying out and pushing [J~ | K] into part 0's gather buffer, out[5 + 5p] = bytes that
+// crossed devices, out[6 + 5p] / out[7 + 5p] = HIP-event ms of the half-transform / SYRK launches (MO branch) on their stream.
 int PAMD_df_last_timing(const PAMD_df *h, double *out, int nout)
 {
     PAMD_REQUIRE(h && out, "PAMD_df_last_timing: null argument");
     std::vector<const PAMD_df *> ps;
     if (h->parts.empty()) ps.push_back(h);
     for (const PAMD_df *p : h->parts) ps.push_back(p);
-    PAMD_REQUIRE(nout >= 3 + 3 * (int)ps.size(), "PAMD_df_last_timing: out[3 + 3 * parts]");
+    PAMD_REQUIRE(nout >= 3 + 5 * (int)ps.size(), "PAMD_df_last_timing: out[3 + 5 * parts]");
     bool cross = false;
     for (const PAMD_df *p : ps) cross = cross || p->device != ps[0]->device;
     out[0] = (double)ps.size();
     out[1] = h->t_sum_ms;
     out[2] = (cross && h->peer_ok) ? 1.0 : 0.0;
     for (size_t i = 0; i < ps.size(); i++) {
-        out[3 + 3 * i] = ps[i]->t_compute_ms;
-        out[4 + 3 * i] = ps[i]->t_push_ms;
-        out[5 + 3 * i] = (double)ps[i]->push_bytes;
+        out[3 + 5 * i] = ps[i]->t_compute_ms;
+        out[4 + 5 * i] = ps[i]->t_push_ms;
+        out[5 + 5 * i] = (double)ps[i]->push_bytes;
+        out[6 + 5 * i] = ps[i]->t_e2_ms;
+        out[7 + 5 * i] = ps[i]->t_syrk_ms;
     }
     return 0;
 }

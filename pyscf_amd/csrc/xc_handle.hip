@@ -501,9 +501,18 @@ int PAMD_xc_create_multi(const int *atm, int natm, const int *bas, int nbas, con
         if (devices[p] == devices[0]) continue;
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, devices[0], devices[p]) != hipSuccess || !can) { (void)hipGetLastError(); m->peer_ok = 0; break; }
-        const hipError_t e = hipDeviceEnablePeerAccess(devices[p], 0);
+        hipError_t e = hipDeviceEnablePeerAccess(devices[p], 0);
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) m->peer_ok = 0;
         (void)hipGetLastError();
+        // ... and the other direction: part p pushes into part 0's gather buffer from its own thread and stream (as
+        // PAMD_df_create_ex does; without it the copy may be staged through the host - ADVICE r04)
+        int can2 = 0;
+        if (hipDeviceCanAccessPeer(&can2, devices[p], devices[0]) != hipSuccess || !can2) { (void)hipGetLastError(); m->peer_ok = 0; break; }
+        PAMD_CHECK_HIP(hipSetDevice(devices[p]));
+        e = hipDeviceEnablePeerAccess(devices[0], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) m->peer_ok = 0;
+        (void)hipGetLastError();
+        PAMD_CHECK_HIP(hipSetDevice(devices[0]));
     }
     guard.p = nullptr;
     *out = m;

@@ -192,12 +192,14 @@ class NativeDF:
 
     def last_timing(self):
         """Host-clock timings of the last get_jk inside the handle (PAMD_df_last_timing): {'parts', 'sum_download_ms', 'peer',
-        'compute_ms': [...], 'push_ms': [...], 'push_bytes': [...]} - what bench.py --single-process reports as `comm`."""
-        out = (_c.c_double * (3 + 3 * 64))()
+        'compute_ms': [...], 'push_ms': [...], 'push_bytes': [...], 'e2_ms': [...], 'syrk_ms': [...]} - what bench.py
+        --single-process reports as `roofline` and `comm`."""
+        out = (_c.c_double * (3 + 5 * 64))()
         _check(load().PAMD_df_last_timing(self._h, out, _c.c_int(len(out))))
         n = int(out[0])
-        return dict(parts=n, sum_download_ms=out[1], peer=int(out[2]), compute_ms=[out[3 + 3 * i] for i in range(n)],
-                    push_ms=[out[4 + 3 * i] for i in range(n)], push_bytes=[int(out[5 + 3 * i]) for i in range(n)])
+        return dict(parts=n, sum_download_ms=out[1], peer=int(out[2]), compute_ms=[out[3 + 5 * i] for i in range(n)],
+                    push_ms=[out[4 + 5 * i] for i in range(n)], push_bytes=[int(out[5 + 5 * i]) for i in range(n)],
+                    e2_ms=[out[6 + 5 * i] for i in range(n)], syrk_ms=[out[7 + 5 * i] for i in range(n)])
 
     def layout(self):
         """{'parts', 'rows_resident', 'rows_host', 'rows_square', 'peer', 'part_rows'} of the built handle (PAMD_df_layout)."""

@@ -31,6 +31,18 @@ from ..gto.moleintor import _AuxClass, _Shells, _dev, c2s_matrix, get_engine
 NREP = 64          # replicated accumulators: spreads the FP64 atomics of the contraction kernel
 
 
+
+def _need_torch_df(dfobj):
+    """The gradient kernels work on the torch-resident tensor of pyscf_amd.df.DF.  `mf.density_fit(devices=...)` / PAMD_DEVICES put
+    the host-array handle object (NativeDF) in its place, which has no `_cderi_dev`: say so instead of an AttributeError
+    (ADVICE r04)."""
+    from ..df.native import NativeDF
+    if isinstance(dfobj, NativeDF):
+        raise NotImplementedError('analytic DF gradients need the torch-resident pyscf_amd.df.DF; this SCF object was routed to the '
+                                  'host-array handle (density_fit(devices=...) or PAMD_DEVICES): rebuild it with mf.density_fit() '
+                                  '(one process per GPU under torch.distributed for several devices)')
+
+
 def grad_nuc(mol, atmlst=None):
     """pyscf/grad/rhf.py:148-166."""
     z = mol.atom_charges().astype(float)
@@ -149,6 +161,7 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     tensor; returns the integral engine.  A long-range tensor (dfobj.omega > 0) differentiates the erf-attenuated
     integrals; a short-range one (omega < 0) the Coulomb integrals with (Z, Y) and the long-range ones with (-Z, -Y)."""
     import torch
+    _need_torch_df(dfobj)
     if dfobj._cderi_dev is None and getattr(dfobj, '_native', None) is None:
         dfobj.build()
     if getattr(dfobj, '_native', None) is not None:
@@ -254,6 +267,7 @@ def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_respo
     exact exchange of range-separated hybrids, pyscf/df/grad/rks.py:84-110)."""
     import torch
     so = _lib_mod.load_library()
+    _need_torch_df(dfobj)
     if dfobj._cderi_dev is None and getattr(dfobj, '_native', None) is None:
         dfobj.build()
     if getattr(dfobj, '_native', None) is not None:

@@ -427,6 +427,10 @@ class SCF:
         from .. import df
         if with_df is None and devices is None and os.environ.get('PAMD_DEVICES'):
             devices = [int(d) for d in os.environ['PAMD_DEVICES'].split(',') if d.strip() != '']
+            # a process-wide switch for unmodified scripts: say that it acted (the handle object has no device-resident SCF loop
+            # and no analytic gradients - ADVICE r04)
+            self._log('PAMD_DEVICES=%s: density_fit() uses the host-array handle over devices %s (NativeDF / NativeNumInt)',
+                      os.environ['PAMD_DEVICES'], devices)
         if with_df is None and devices is not None:
             from ..df.native import NativeDF
             with_df = NativeDF(self.mol, auxbasis, devices=list(devices))
@@ -606,25 +610,35 @@ def int1e_gpu(mol, device=None):
     nao = eng.ao.nao
     # nuclear attraction: (ij| point charge) = limit of a normalised s Gaussian, eta -> infinity
     natm = len(mol._atm)
-    nuc = _Shells.__new__(_Shells)
     eta = 1e30
-    nuc.l = np.zeros(natm, np.int32)
-    nuc.xyz = mol.atom_coords()
-    nuc.exps = [np.array([eta])] * natm
+    xyz_all = mol.atom_coords()
     z = mol.atom_charges().astype(float)
-    nuc.coefs = [np.array([-zi * (eta / np.pi) ** 1.5 / c2s_matrix(0)[0, 0]]) for zi in z]
-    nuc.ao0 = np.arange(natm, dtype=np.int32)
-    nuc.n = natm
-    nuc.nao = natm
-    ac = _AuxClass(nuc, 0, device)
     npair = nao * (nao + 1) // 2
-    V3 = torch.zeros((npair, natm), dtype=torch.float64, device=device)
+    # the nuclei go through the 3-centre kernels in chunks: the (nao_pair, atoms) buffer stays below ~1 GB (r05: all 384 atoms of
+    # (H2O)_128 at once were 14.5 GB - beside an out-of-core DF handle that has sized itself to the device there is no such room)
+    chunk = max(1, min(natm, int((1 << 30) // (npair * 8))))
+    vtril_dev = torch.zeros(npair, dtype=torch.float64, device=device)
     eng._omega_override = 0.0            # nuclear attraction is always the bare Coulomb operator
     try:
-        for pc in eng.pair_classes():
-            eng._launch(pc, 0, pc.n, ac, V3, natm, 0, 1, eng.ao_xyz, eng.ao_ao0)
+        for a0 in range(0, natm, chunk):
+            a1 = min(a0 + chunk, natm)
+            na = a1 - a0
+            nuc = _Shells.__new__(_Shells)
+            nuc.l = np.zeros(na, np.int32)
+            nuc.xyz = np.ascontiguousarray(xyz_all[a0:a1])
+            nuc.exps = [np.array([eta])] * na
+            nuc.coefs = [np.array([-zi * (eta / np.pi) ** 1.5 / c2s_matrix(0)[0, 0]]) for zi in z[a0:a1]]
+            nuc.ao0 = np.arange(na, dtype=np.int32)
+            nuc.n = na
+            nuc.nao = na
+            ac = _AuxClass(nuc, 0, device)
+            V3 = torch.zeros((npair, na), dtype=torch.float64, device=device)
+            for pc in eng.pair_classes():
+                eng._launch(pc, 0, pc.n, ac, V3, na, 0, 1, eng.ao_xyz, eng.ao_ao0)
+            vtril_dev += V3.sum(dim=1)
+            del V3
     finally:
         del eng._omega_override
-    vtril = V3.sum(dim=1).cpu().numpy()
+    vtril = vtril_dev.cpu().numpy()
     V = _lib_mod.unpack_tril(vtril, 1)
     return S.cpu().numpy(), T.cpu().numpy(), V

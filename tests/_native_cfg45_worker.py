@@ -103,11 +103,64 @@ def config5():
     assert abs(golden_util.fp(rect) - (ga['vj_rect_fp'] + gb['vj_rect_fp'])) < 1e-8 * (ga['vj_rect_norm'] + gb['vj_rect_norm'])
     print('    get_jk (rank-32 local density) %.2f s: %.0f GB streamed -> %.1f GB/s incl. compute' % (
         tj, lay['rows_host'] * npair * 8e-9, lay['rows_host'] * npair * 8e-9 / tj), flush=True)
+    config5_energy(mol, obj)
     obj.reset()
+
+
+def config5_energy(mol, obj):
+    """r05: the ENERGY of config 5 against an oracle-only golden, on the handle that already holds the whole
+    560 GB tensor.  tests/golden/h2o128_ccpvdz_energy_oracle.json is the oracle's DF-RHF energy functional at the density of
+    tests/golden/h2o128_ccpvdz_rhf_orbitals.npz (tools/gen_golden_energy_sweep.py: one sweep of the oracle's McMurchie-Davidson
+    integrals, the oracle's own Roothaan residual on the AO rows of two molecules).  Checked here:
+      (a) J rows and (K C) rows of the product's J/K build at those orbitals, element by element (1e-9);
+      (b) the product's energy functional at those orbitals (1e-8 Eh);
+      (c) the product's OWN SCF from its minao guess through the out-of-core handle converges to the same energy (1e-8 Eh) -
+          the north-star gate, pyscf/df/test/test_df_jk.py:57-59 at config-5 size."""
+    from oracle import golden_util
+    from pyscf_amd import lib, scf
+    gpath = os.path.join(ROOT, 'tests', 'golden', 'h2o128_ccpvdz_energy_oracle.json')
+    opath = os.path.join(ROOT, 'tests', 'golden', 'h2o128_ccpvdz_rhf_orbitals.npz')
+    if not (os.path.exists(gpath) and os.path.exists(opath)):
+        print('    config 5 energy golden not generated (tools/gen_golden_energy_sweep.py): energy checks skipped', flush=True)
+        print('NATIVE_CONFIG5_ENERGY_SKIPPED', flush=True)
+        return
+    ge = _golden('h2o128_ccpvdz_energy_oracle.json')
+    orbo = np.ascontiguousarray(np.load(opath)['orbo'])
+    nao, nocc = orbo.shape
+    assert (nao, nocc) == (ge['nao'], ge['nocc']) == (3072, 640)
+    dm = lib.tag_array(orbo.dot(orbo.T), mo_coeff=orbo / np.sqrt(2.0), mo_occ=np.full(nocc, 2.0))
+    t0 = time.perf_counter()
+    vj, vk = obj.get_jk(dm, hermi=1)
+    tj = time.perf_counter() - t0
+    rr, cc = golden_util.sample_positions(1 << 20, len(ge['row_samples'][0]['vj_rows_sample']), seed=ge['sample_seed'])
+    for rs in ge['row_samples']:
+        p0, p1 = rs['ao_rows']
+        npp = p1 - p0
+        jrows = np.ascontiguousarray(vj[p0:p1])
+        kc = vk[p0:p1].dot(orbo)
+        for name, m, cols in (('vj_rows', jrows, nao), ('vkc_rows', kc, nocc)):
+            scale = rs[name + '_absmax']
+            assert abs(np.linalg.norm(m) - rs[name + '_norm']) < 1e-9 * rs[name + '_norm'], (name, rs['molecule'])
+            assert abs(golden_util.fp(m) - rs[name + '_fp']) < 1e-8 * rs[name + '_norm'], (name, rs['molecule'])
+            err = np.abs(m[rr % npp, cc % cols] - np.array(rs[name + '_sample'])).max()
+            assert err < 1e-9 * scale, (name, rs['molecule'], err / scale)
+    mf = scf.RHF(mol).density_fit(with_df=obj)
+    h1e = mf.get_hcore()
+    e_fun = float(np.einsum('ij,ji', h1e, dm) + .5 * np.einsum('ij,ji', vj - .5 * vk, dm) + mol.energy_nuc())
+    print('    J/K at the golden orbitals %.2f s (nocc 640); E[D] product %.10f, oracle %.10f, diff %.2e; oracle Roothaan residual on '
+          'its sampled rows %.2e' % (tj, e_fun, ge['e_tot'], e_fun - ge['e_tot'], ge.get('roothaan_residual_norm_sampled_rows', -1)), flush=True)
+    assert abs(e_fun - ge['e_tot']) < 1e-8, (e_fun, ge['e_tot'])
+    mf.conv_tol = 1e-10
+    t0 = time.perf_counter()
+    e = mf.kernel()
+    print('    converged SCF from the minao guess through the out-of-core handle: %d cycles, %.1f s, E %.10f, oracle %.10f, diff %.2e'
+          % (mf.cycles, time.perf_counter() - t0, e, ge['e_tot'], e - ge['e_tot']), flush=True)
+    assert mf.converged and abs(e - ge['e_tot']) < 1e-8, (e, ge['e_tot'])
+    print('NATIVE_CONFIG5_ENERGY_OK', flush=True)
 
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'config4'
     {'config4': config4, 'config5': config5}[which]()
-    assert 'torch' not in sys.modules
+    assert which == 'config5' or 'torch' not in sys.modules      # (config 5 also drives the SCF loop, which keeps F / S on the device)
     print('NATIVE_%s_OK' % which.upper(), flush=True)

@@ -232,3 +232,42 @@ def test_config5_two_shards_summed_vs_oracle_golden():
     _check_shard_golden(vj3 + vj4, vk3 + vk4, g)
     # neither shard alone is the answer
     assert abs(np.linalg.norm(vk3) - g['vk_norm']) > 1e-3 * g['vk_norm'] and abs(np.linalg.norm(vk4) - g['vk_norm']) > 1e-3 * g['vk_norm']
+
+
+def test_config5_rank_shard_out_of_core_behind_DF_vs_oracle_golden():
+    """r05: a RANK of the aux-sharded job whose shard does not fit its device no longer raises - `df.DF.build`
+    hands the shard's rows to the C handle (PAMD_df_options part / nparts: resident rows + page-locked host rows streamed under the
+    kernels, the twin of pyscf/df/outcore.py:109-232).  Rank 3 of 8 of config 5 (1856 rows, 70 GB) with a 40 GB device cap through
+    the production object: its PARTIAL J/K against the oracle-only shard golden, 1e-9."""
+    import torch
+    from oracle import golden_util
+    from pyscf_amd import gto, df, lib
+    from pyscf_amd.data import clusters
+    g = _golden('h2o128_ccpvdz_rank3of8_local_oracle.json')
+    mol = gto.M(atom=clusters.water_cluster(128), basis='cc-pvdz')
+    obj = df.DF(mol)
+    obj._shard_override = (3, 8)
+    obj.outcore_device_bytes = 40 * 10 ** 9
+    assert not obj.would_fit()
+    obj.build()
+    lay = obj.out_of_core()
+    assert lay is not None and obj._cderi_dev is None and obj.get_naoaux() == 14848
+    assert list(obj._native.shard_rows) == g['aux_rows'] == [5568, 7424]
+    assert lay['rows_host'] > 0 and lay['rows_resident'] > 0 and lay['rows_resident'] + lay['rows_host'] == 1856, lay
+    nao = mol.nao
+    (a0, a1), nsyn = g['support_ao_range'], g['nsyn']
+    c = np.zeros((nao, nsyn))
+    c[a0:a1] = golden_util.synthetic_orbitals(a1 - a0, nsyn) * np.sqrt(2.0)
+    occ = np.zeros(nao)
+    occ[:nsyn] = 1.0
+    cfull = np.zeros((nao, nao))
+    cfull[:, :nsyn] = c
+    vj, vk = obj.get_jk(lib.tag_array(c.dot(c.T), mo_coeff=cfull, mo_occ=occ), hermi=1)
+    _check_shard_golden(vj, vk, g)
+    # the rows themselves: the first block of loop(local=True) is the head of the shard (resident), the last one streamed
+    blocks = list(obj.loop(464, local=True))
+    assert sum(b.shape[0] for b in blocks) == 1856 and all(np.isfinite(b).all() for b in (blocks[0], blocks[-1]))
+    with pytest.raises(NotImplementedError):
+        obj.get_eri()
+    obj.reset()
+    torch.cuda.empty_cache()

@@ -129,3 +129,29 @@ def test_orbital_leading_dimension_covers_every_half_transform_tiling():
             assert v >= nch * 128, n                     # room for the wide last chunk's 128-column panel
     assert ld(160) == 160 and ld(16) == 128              # config 3 unchanged; tiny operands already took one 128-column chunk
     assert ld(226) == ld(240) == 320 and ld(400) == 512
+
+
+def test_namespace_plugin_is_found_through_PYSCF_EXT_PATH(tmp_path):
+    """`PYSCF_EXT_PATH=<repo>/plugin` makes a `pyscf` namespace package find `pyscf.amd`
+    (pyscf/__init__.py:42-60 appends <dir>/pyscf to pyscf.__path__ when <dir> contains a `pyscf` folder).  PySCF itself cannot be
+    imported in this container, so a stub package that applies the same rule stands in for it."""
+    import subprocess
+    import sys
+    stub = tmp_path / 'site' / 'pyscf'
+    stub.mkdir(parents=True)
+    (stub / '__init__.py').write_text(
+        "import os\n"
+        "for p in (os.getenv('PYSCF_EXT_PATH') or '').split(':'):\n"
+        "    if os.path.isdir(p) and 'pyscf' in os.listdir(p):\n"
+        "        __path__.append(os.path.join(p, 'pyscf'))\n")
+    code = ("import sys; sys.path.insert(0, %r); import pyscf.amd as amd; "
+            "from pyscf_amd.df.native import NativeDF; from pyscf_amd.dft.native import NativeNumInt; "
+            "assert issubclass(amd.DF, NativeDF) and amd.NumInt is NativeNumInt and callable(amd.density_fit); "
+            "from pyscf_amd import gto, scf, dft; "
+            "mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis='sto-3g'); "
+            "mf = amd.density_fit(dft.RKS(mol, xc='b3lyp'), auxbasis='weigend', devices=[0, 1]); "
+            "assert isinstance(mf.with_df, amd.DF) and mf.with_df.devices == [0, 1] and isinstance(mf._numint, NativeNumInt); "
+            "print('PLUGIN_OK')" % str(tmp_path / 'site'))
+    env = dict(os.environ, PYSCF_EXT_PATH=os.path.join(ROOT, 'plugin'))
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and 'PLUGIN_OK' in p.stdout, p.stdout + p.stderr[-2000:]
