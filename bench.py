@@ -116,8 +116,11 @@ def main():
     ap.add_argument('--syrk-flags', type=int, default=-1, help='override DF.k_syrk_flags (A/B runs): 0 plain, 12 re-tiled + balanced')
     ap.add_argument('--single-process', action='store_true', help='N GPUs from ONE process through the C handle (PAMD_df_create_multi: '
                     'one host thread per device, peer gather + sum on device 0) instead of one rank per GPU under torch.distributed')
-    ap.add_argument('--pmc', action='store_true', help='re-measure roofline.traffic in this run: two extra rocprofv3 --pmc passes '
-                    '(FETCH_SIZE, WRITE_SIZE) of a short bench.py before the timed run (N = 1 only; adds ~2 minutes)')
+    ap.add_argument('--pmc', nargs='?', const='on', default='auto', choices=['auto', 'on', 'off'],
+                    help="roofline.traffic measured IN THIS RUN: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters "
+                    "alone with --kernel-trace) of a short child bench.py before the timed run (N = 1 only; adds ~1-2 minutes).  "
+                    "'auto' (default, r05): on when rocprofv3 is on PATH; 'off': the committed profiles/<round>/pmc_summary.json")
+    ap.add_argument('--no-pmc', dest='pmc', action='store_const', const='off')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.single_process:
@@ -173,8 +176,12 @@ def main():
             raise SystemExit('bench.py: pre-flight all-reduce returned %r, expected %d' % (one.item(), world))
 
     pmc_live = None
-    if args.pmc and world == 1 and not args.pmc_child:
+    import shutil
+    want_pmc = args.pmc == 'on' or (args.pmc == 'auto' and shutil.which('rocprofv3') is not None)
+    if want_pmc and world == 1 and not args.pmc_child and not grouped:
         pmc_live = _pmc_passes(args)         # before this process holds any HBM: the child runs need the whole device
+        if not pmc_live.get('FETCH_SIZE'):
+            pmc_live = None                  # profiler missing / failed: the committed summary is used (and named) instead
 
     from pyscf_amd import gto, df, lib
     from pyscf_amd.data import clusters
@@ -517,7 +524,7 @@ def main():
         if use_ref:
             # oracle/_ref/libref_dfjk.so = pyscf/lib/ao2mo/nr_ao2mo.c + pyscf/lib/np_helper/*.c compiled as they are, driven
             # call for call like pyscf/df/df_jk.py:329-381 (oracle/ref_c.get_jk): the reference's CPU path minus libcint
-            ref_c.get_jk(sample[:min(nrow, 240)], dm, c, mo_occ, nthreads=ncore)      # warm the thread pools
+            ref_c.calibrate(sample, dm, c, mo_occ, nthreads=ncore)      # warms the thread pools; picks the faster BLAS build
             t0 = time.perf_counter()
             vj0, vk0, cpu_flops = ref_c.get_jk(sample, dm, c, mo_occ, blockdim=240, nthreads=ncore)
             cpu_s = time.perf_counter() - t0
@@ -536,7 +543,8 @@ def main():
             what = ('oracle/ref.get_jk_rows_parallel (numpy restatement of df_jk.py:329-381; oracle/_ref was not built)')
         cpu = {'value': round(cpu_s / nrow * naux * 1e3, 1),
                'unit': 'ms/iter' + ('' if nrow == naux else ' (extrapolated from %d to all %d aux rows)' % (nrow, naux)),
-               'cores': ncore, 'kind': kind, 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1), 'phases_s': phases,
+               'cores': ncore, 'host_cores': os.cpu_count(), 'kind': kind, 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1), 'phases_s': phases,
+               'blas_calibration': getattr(ref_c, 'calibration', None) if use_ref else None,
                'sample': '%s; %d of %d aux rows of the GPU-built tensor: %.2f s' % (what, nrow, naux, cpu_s)}
         # parity at full size: the same rows through the HIP path
         sub = df.DF(mol)
@@ -591,7 +599,7 @@ def _pmc_passes(args):
              'gemm_tn_glds_kernel', 'vj_pass1_rows_kernel', 'vj_pass2_wide_kernel', 'vj_pass2_kernel')
     out = {}
     env = dict(os.environ, TMPDIR='/tmp')
-    child = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '0', '--no-cpu-baseline', '--xc', '', '--pmc-child',
+    child = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '0', '--no-cpu-baseline', '--xc', '', '--pmc-child', '--no-pmc',
              '--nwater', str(args.nwater), '--molecule', args.molecule, '--k-square', args.k_square, '--j2-policy', args.j2_policy]
     if args.basis:
         child += ['--basis', args.basis]
@@ -601,7 +609,7 @@ def _pmc_passes(args):
         d = tempfile.mkdtemp(prefix='pamd_pmc_', dir='/tmp')
         try:
             subprocess.run(['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--'] + child,
-                           cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+                           cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
             agg = {}
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
                 for r in csv.DictReader(open(f)):
@@ -764,7 +772,7 @@ def _cpu_baseline_native(args, obj, dm, c, mo_occ, nao, naux, npair):
         r1 = min(r0 + 240, nrow)
         _nat._check(_nat.load().PAMD_df_export_cderi(obj._h, _ct.c_int(r0), _ct.c_int(r1), sample[r0:r1].ctypes.data_as(_ct.c_void_p)))
     if ref_c.available():
-        ref_c.get_jk(sample[:min(nrow, 240)], dm, c, mo_occ, nthreads=ncore)
+        ref_c.calibrate(sample, dm, c, mo_occ, nthreads=ncore)
         t0 = time.perf_counter()
         vj0, vk0, cpu_flops = ref_c.get_jk(sample, dm, c, mo_occ, blockdim=240, nthreads=ncore)
         cpu_s = time.perf_counter() - t0
@@ -779,7 +787,8 @@ def _cpu_baseline_native(args, obj, dm, c, mo_occ, nao, naux, npair):
         what = 'oracle/ref.get_jk_rows_parallel (numpy restatement of df_jk.py:329-381; oracle/_ref was not built)'
     cpu = {'value': round(cpu_s / nrow * naux * 1e3, 1),
            'unit': 'ms/iter' + ('' if nrow == naux else ' (extrapolated from %d to all %d aux rows)' % (nrow, naux)),
-           'cores': ncore, 'kind': kind, 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1), 'phases_s': phases,
+           'cores': ncore, 'host_cores': os.cpu_count(), 'kind': kind, 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1), 'phases_s': phases,
+           'blas_calibration': getattr(ref_c, 'calibration', None) if kind == 'reference' else None,
            'sample': '%s; %d of %d aux rows of the GPU-built tensor: %.2f s' % (what, nrow, naux, cpu_s)}
     parity = None
     if nrow == naux:

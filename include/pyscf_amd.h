@@ -373,6 +373,12 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
                       const PAMD_df_options *opt, PAMD_df **out);
 int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                          double lindep, const int *devices, int ndev, PAMD_df **out);
+/* r05 - a handle over tensor rows the caller already holds: `DF._cderi` given as an array or as PySCF's own HDF5 file
+ * (pyscf/df/df.py:153-155; dataset 'j3c', outcore.py:217-221; read back block by block in DF.loop, df.py:214-242).
+ * rows[nrows][nao (nao + 1) / 2] f64 in HOST memory (a numpy array or an mmap of the contiguous dataset); what fits the device is
+ * uploaded once, the rest is streamed under the kernels in every PAMD_df_get_jk.  flags bit 0: stream straight from the caller's
+ * memory (must outlive the handle) instead of a page-locked copy. */
+int PAMD_df_create_from_rows(const double *rows, int nrows, int nao, int device, long long max_device_bytes, int flags, PAMD_df **out);
 int PAMD_df_layout(const PAMD_df *h, long *layout, int *part_rows);
 int PAMD_df_shard_info(const PAMD_df *h, int *info);
 int PAMD_df_last_timing(const PAMD_df *h, double *out, int nout);

@@ -48,11 +48,58 @@ def build():
     return available()
 
 
+calibration = None         # filled by calibrate(): {'openblas': {'threads', 'ms_per_row'}, 'mkl': {...}, 'chosen'}
+
+
+def mkl_usable():
+    """The MKL variant exists, the host has more cores than OpenBLAS admits callers, and the variant passed its self-test in a
+    CHILD process (all host cores calling into it at once on a small case, checked against numpy) - a BLAS that misbehaves takes
+    down the child, not the benchmark."""
+    global _mkl_ok
+    if _mkl_ok is None:
+        _mkl_ok = False
+        if os.path.exists(SO_MKL) and (os.cpu_count() or 1) > MAX_BLAS_CALLERS and os.environ.get('PAMD_REF_BLAS', '') != 'openblas':
+            import subprocess
+            import sys
+            code = ("import sys; sys.path.insert(0, %r); import os; os.environ['PAMD_REF_BLAS'] = 'mkl'; "
+                    "from oracle import ref_c; ref_c.selftest()" % os.path.dirname(HERE))
+            try:
+                p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+                _mkl_ok = p.returncode == 0 and 'REF_C_SELFTEST_OK' in p.stdout
+            except Exception:
+                pass
+    return _mkl_ok
+
+
+_mkl_ok = None
+
+
+def calibrate(cderi, dm, mo_coeff, mo_occ, nthreads=None, rows=240):
+    """r05: which build of the reference's C is the honest baseline on THIS host?  Both are timed on the first `rows` aux rows
+    (second of two runs each): scipy's OpenBLAS on min(cores, 64) threads, and the MKL of libtorch_cpu.so on all cores.  The FASTER
+    one is used for the timed run (on the AMD hosts of this pool MKL takes its generic code path and 256 threads of it are ~4x
+    slower than 64 threads of OpenBLAS - measured, r05); both figures are reported (`calibration`)."""
+    global _variant, calibration
+    import time as _t
+    want = os.environ.get('PAMD_REF_BLAS', '')
+    cands = ['openblas'] + (['mkl'] if mkl_usable() else [])
+    if want in cands:
+        cands = [want]
+    out = {}
+    sub = cderi[:min(rows, len(cderi))]
+    for v in cands:
+        get_jk(sub, dm, mo_coeff, mo_occ, nthreads=nthreads, which=v)
+        t0 = _t.perf_counter()
+        get_jk(sub, dm, mo_coeff, mo_occ, nthreads=nthreads, which=v)
+        out[v] = {'threads': get_jk.last_threads, 'ms_per_row': round((_t.perf_counter() - t0) / len(sub) * 1e3, 3)}
+    _variant = min(out, key=lambda k: out[k]['ms_per_row'])
+    out['chosen'] = _variant
+    calibration = out
+    return out
+
+
 def variant():
-    """Which BLAS the reference's C runs on.  r05: on a host with more cores than scipy's OpenBLAS admits concurrent callers (64)
-    the variant linked against the MKL inside libtorch_cpu.so is used - after a self-test in a CHILD process (all host cores
-    calling into it at once on a small case, checked against numpy), so that a BLAS that misbehaves takes down the child, not the
-    benchmark.  PAMD_REF_BLAS=openblas | mkl forces a choice."""
+    """Which BLAS the reference's C runs on: PAMD_REF_BLAS=openblas | mkl, else what calibrate() chose, else OpenBLAS."""
     global _variant
     if _variant is not None:
         return _variant
@@ -61,17 +108,6 @@ def variant():
         _variant = want if (want == 'openblas' or os.path.exists(SO_MKL)) else 'openblas'
         return _variant
     _variant = 'openblas'
-    if os.path.exists(SO_MKL) and (os.cpu_count() or 1) > MAX_BLAS_CALLERS:
-        import subprocess
-        import sys
-        code = ("import sys; sys.path.insert(0, %r); import os; os.environ['PAMD_REF_BLAS'] = 'mkl'; "
-                "from oracle import ref_c; ref_c.selftest()" % os.path.dirname(HERE))
-        try:
-            p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
-            if p.returncode == 0 and 'REF_C_SELFTEST_OK' in p.stdout:
-                _variant = 'mkl'
-        except Exception:
-            pass
     return _variant
 
 
@@ -98,6 +134,14 @@ def selftest():
 
 
 def describe():
+    extra = ''
+    if calibration and len(calibration) > 2:
+        extra = '; calibration on 240 rows: ' + ', '.join('%s %d threads %.2f ms/row' % (k, v['threads'], v['ms_per_row'])
+                                                          for k, v in calibration.items() if k != 'chosen') + ' -> the faster one is timed'
+    return _describe() + extra
+
+
+def _describe():
     if variant() == 'mkl':
         return ('BLAS = the MKL linked into libtorch_cpu.so (dgemm_; dsymm_ = triangle completion + dgemm_, oracle/ref_build/'
                 'dsymm_via_dgemm.c), one BLAS thread per call inside the reference\'s OpenMP regions, %d OpenMP threads = all host '
@@ -106,20 +150,24 @@ def describe():
             "callers, so the omp loops run on min(host cores, 64) = %d threads (the host has %d)" % (get_jk.last_threads, os.cpu_count()))
 
 
-def lib():
-    global _lib
-    if _lib is None:
+_libs = {}
+
+
+def lib(which=None):
+    which = which or variant()
+    if which not in _libs:
         if not available():
             raise RuntimeError('oracle/_ref/libref_dfjk.so is missing: run `make -C oracle ref` where /root/reference exists')
-        if variant() == 'mkl':
+        if which == 'mkl':
             import torch                                   # libtorch_cpu.so (and its OpenMP runtime) first: ONE libgomp in the process
             torch.set_num_threads(1)                       # MKL: one thread per dgemm_ call
-            _lib = ctypes.CDLL(SO_MKL)
+            l = ctypes.CDLL(SO_MKL)
         else:
-            _lib = ctypes.CDLL(SO)
-            _lib.scipy_openblas_set_num_threads.argtypes = [ctypes.c_int]
-        _lib.omp_get_max_threads.restype = ctypes.c_int
-    return _lib
+            l = ctypes.CDLL(SO)
+            l.scipy_openblas_set_num_threads.argtypes = [ctypes.c_int]
+        l.omp_get_max_threads.restype = ctypes.c_int
+        _libs[which] = l
+    return _libs[which]
 
 
 def _p(a):
@@ -130,11 +178,12 @@ MAX_BLAS_CALLERS = 64      # scipy's OpenBLAS is compiled for 64 threads: more C
                            # ("precompiled NUM_THREADS exceeded ... double free or corruption" on a 256-core host, r03)
 
 
-def set_threads(n):
+def set_threads(n, which=None):
     """OpenMP threads of the reference's C (lib.num_threads(), pyscf/lib/misc.py:195-224), capped at MAX_BLAS_CALLERS; BLAS
     stays at one thread per call.  Returns the thread count really used (bench.py reports it as `cores`)."""
-    l = lib()
-    if variant() == 'mkl':
+    which = which or variant()
+    l = lib(which)
+    if which == 'mkl':
         import torch
         torch.set_num_threads(1)
         n = int(n or os.cpu_count() or 1)                  # no cap on concurrent callers
@@ -145,8 +194,11 @@ def set_threads(n):
     return l.omp_get_max_threads()
 
 
+_current = None            # the variant get_jk is running on (the helpers below follow it)
+
+
 def pack_tril(mats):
-    l = lib()
+    l = lib(_current)
     mats = np.ascontiguousarray(mats, dtype=np.float64)
     count, nd = mats.shape[0], mats.shape[-1]
     out = np.empty((count, nd * (nd + 1) // 2))
@@ -155,7 +207,7 @@ def pack_tril(mats):
 
 
 def unpack_tril(tril, filltriu=1):
-    l = lib()
+    l = lib(_current)
     tril = np.ascontiguousarray(tril, dtype=np.float64)
     count = tril.shape[0]
     nd = int(round((np.sqrt(8 * tril.shape[1] + 1) - 1) / 2))
@@ -167,7 +219,7 @@ def unpack_tril(tril, filltriu=1):
 def lib_dot_tn(buf1):
     """lib.dot(buf1.T, buf1): ddot sees a = buf1.T (F-contiguous -> trans_a 'T', a = buf1) and b = buf1 (C-contiguous, 'N')
     and calls NPdgemm(trans_b, trans_a, n, m, k, ldb, lda, ldc, ...)  (pyscf/lib/numpy_helper.py:825-858,980-1004)."""
-    l = lib()
+    l = lib(_current)
     k, n = buf1.shape
     c = np.empty((n, n))
     l.NPdgemm(ctypes.c_char(b'N'), ctypes.c_char(b'T'), ctypes.c_int(n), ctypes.c_int(n), ctypes.c_int(k),
@@ -176,11 +228,14 @@ def lib_dot_tn(buf1):
     return c
 
 
-def get_jk(cderi, dm, mo_coeff, mo_occ, blockdim=240, nthreads=None):
+def get_jk(cderi, dm, mo_coeff, mo_occ, blockdim=240, nthreads=None, which=None):
     """J and K of ONE density (nset = 1, hermi = 1, MO branch) over the rows of `cderi` (naux_rows, nao_pair), exactly the call
     sequence of pyscf/df/df_jk.py:329-381.  Returns (vj, vk, flops, phases)."""
-    l = lib()
-    nth = set_threads(nthreads)
+    global _current
+    which = which or variant()
+    _current = which
+    l = lib(which)
+    nth = set_threads(nthreads, which)
     nao = dm.shape[-1]
     naux = cderi.shape[0]
     dms = np.ascontiguousarray(dm.reshape(1, nao, nao), dtype=np.float64)

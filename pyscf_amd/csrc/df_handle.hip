@@ -249,10 +249,11 @@ struct PAMD_df {
     double omega = 0.0;                     // 0 Coulomb, > 0 erf(omega r12)/r12, < 0 erfc(|omega| r12)/r12
     DevPool pool;
     hipStream_t st = nullptr, side = nullptr, copy = nullptr;
-    hipEvent_t ev = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    hipEvent_t ev = nullptr, ev_j = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     double *d_cderi = nullptr, *d_sq = nullptr, *d_diag = nullptr;
     int n_res = 0;                          // rows [0, n_res) resident in HBM, rows [n_res, nL) in h_cderi
-    double *h_cderi = nullptr;              // pinned host memory, (nL - n_res) x npair
+    double *h_cderi = nullptr;              // host rows, (nL - n_res) x npair: page-locked memory of the handle, or (h_borrowed) the caller's
+    int h_borrowed = 0, h_registered = 0;   // PAMD_df_create_from_rows: rows stay in the caller's array (e.g. an mmap of a `_cderi` file)
     double *d_stage[2] = {nullptr, nullptr};
     int stage_rows = 0;
     std::map<long, int> j2_policy;          // (nset, occupied counts) -> 0 overlap / 1 serial second J pass (PAMD_df_get_jk)
@@ -299,13 +300,15 @@ struct PAMD_df {
             delete p;
         }
         if (!parts.empty()) (void)hipSetDevice(device);
-        if (h_cderi) (void)hipHostFree(h_cderi);
+        if (h_cderi && h_registered) (void)hipHostUnregister(h_cderi);
+        if (h_cderi && !h_borrowed) (void)hipHostFree(h_cderi);
         if (h_orb) (void)hipHostFree(h_orb);
         for (int k = 0; k < 2; k++) {
             if (ev_ready[k]) (void)hipEventDestroy(ev_ready[k]);
             if (ev_free[k]) (void)hipEventDestroy(ev_free[k]);
         }
         if (ev) (void)hipEventDestroy(ev);
+        if (ev_j) (void)hipEventDestroy(ev_j);
         for (hipEvent_t e : tev) (void)hipEventDestroy(e);
         if (copy) (void)hipStreamDestroy(copy);
         if (side) (void)hipStreamDestroy(side);
@@ -636,6 +639,8 @@ int make_tables(const int *atm, const int *bas, int nbas_ao, int nbas_aux, const
     return 0;
 }
 
+int init_streams(PAMD_df *h);
+
 int init_shard(PAMD_df *h, const Tables &t, int device, double omega)
 {
     h->device = device;
@@ -644,10 +649,16 @@ int init_shard(PAMD_df *h, const Tables &t, int device, double omega)
     h->naux = t.aux.nao;
     h->npair = (long)h->nao * (h->nao + 1) / 2;
     h->rows = (int)round_up(h->nao, 16);
+    return init_streams(h);
+}
+
+int init_streams(PAMD_df *h)
+{
     PAMD_CHECK_HIP(hipStreamCreate(&h->st));
     PAMD_CHECK_HIP(hipStreamCreate(&h->side));
     PAMD_CHECK_HIP(hipStreamCreate(&h->copy));
     PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+    PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev_j, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
         PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev_ready[k], hipEventDisableTiming));
         PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev_free[k], hipEventDisableTiming));
@@ -962,6 +973,13 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
         if (rc) return rc;
         PAMD_CHECK_HIP(hipMemcpyAsync(d_dm, dm, (size_t)nset * n2 * 8, hipMemcpyHostToDevice, st));
     }
+    double *d_vjfull = nullptr;
+    if (with_j && download) {
+        // (claimed before any kernel is queued: a fresh work space is zeroed on `st`, and the unpack below runs on the side stream)
+        d_vjfull = h->workspace("vjfull", (size_t)nset * n2, &rc);
+        if (rc) return rc;
+    }
+    bool j_on_st = false;
     if (with_j) {
         d_vjt = h->workspace("vjtril", (size_t)nset * npair, &rc);
         if (rc) return rc;
@@ -1103,6 +1121,8 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                 if ((rc = PAMD_df_vj_pass1(sg.rows, npair, sg.n, d_dt + (size_t)s0 * npair, ns, d_rs, d_w1, st))) return rc;
                 if ((rc = PAMD_df_vj_pass2(sg.rows, npair, sg.n, d_rs, ns, d_vjt + (size_t)s0 * npair, st))) return rc;
             }
+            PAMD_CHECK_HIP(hipEventRecord(h->ev_j, st));
+            j_on_st = true;
         }
         for (int s = 0; s < nset && with_k; s++) {
             double *part_s = d_part + (size_t)s * nsplit * n2;
@@ -1141,6 +1161,8 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                         // second J pass of this block: in line, or on the side stream beside the block's SYRK (HBM- beside MFMA-bound)
                         if (serial_j2) {
                             if ((rc = PAMD_df_vj_pass2(sub, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, st))) return rc;
+                            PAMD_CHECK_HIP(hipEventRecord(h->ev_j, st));
+                            j_on_st = true;
                         } else {
                             PAMD_CHECK_HIP(hipEventRecord(h->ev, st));
                             PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev, 0));
@@ -1194,18 +1216,23 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
         if (!orbo || orbs[s].no)
             if ((rc = PAMD_reduce_splits(d_part + (size_t)s * nsplit * n2, nsplit, nao, nao, d_vk + (size_t)s * n2, nao, orbo ? 1 : 0, st)))
                 return rc;
-    if (fused && !serial_j2) {
+    if (download) {
+        // r05: J~ is complete as soon as its last second-pass kernel has run - before the SYRK of the last block ends.  Its unpack
+        // and its device -> host copy go to the SIDE stream, under the tail of the K work on `st` (1-2 ms of the host-array call
+        // at config 3); K follows on `st`.
+        if (with_k) PAMD_CHECK_HIP(hipMemcpyAsync(vk, d_vk, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
+        if (with_j) {
+            if (j_on_st) PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_j, 0));
+            if (nL == 0) {                          // nothing was queued: order the side stream behind the zero fill on `st`
+                PAMD_CHECK_HIP(hipEventRecord(h->ev_j, st));
+                PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_j, 0));
+            }
+            if ((rc = PAMD_unpack_tril(d_vjt, npair, nset, nao, d_vjfull, nao, nao, h->side))) return rc;
+            PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vjfull, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h->side));
+        }
+    } else if (fused && !serial_j2) {
         PAMD_CHECK_HIP(hipEventRecord(h->ev, h->side));
         PAMD_CHECK_HIP(hipStreamWaitEvent(st, h->ev, 0));
-    }
-    if (download) {
-        if (with_j) {
-            double *d_vj = h->workspace("vjfull", (size_t)nset * n2, &rc);
-            if (rc) return rc;
-            if ((rc = PAMD_unpack_tril(d_vjt, npair, nset, nao, d_vj, nao, nao, st))) return rc;
-            PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vj, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
-        }
-        if (with_k) PAMD_CHECK_HIP(hipMemcpyAsync(vk, d_vk, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
     }
     PAMD_CHECK_HIP(hipStreamSynchronize(st));
     PAMD_CHECK_HIP(hipStreamSynchronize(h->side));
@@ -1547,6 +1574,95 @@ int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, 
     opt.ndev = ndev;
     opt.flags = 1;                          // a one-entry list still goes through the sharded code path
     return PAMD_df_create_ex(atm, natm, bas, nbas_ao, nbas_aux, env, nenv, &opt, out);
+}
+
+// A handle over tensor rows the CALLER already has (r05; `DF._cderi = ndarray | 'file.h5'`, pyscf/df/df.py:153-155,214-242): rows
+// [nrows][nao_pair] f64 in host memory - a numpy array, or an mmap of the contiguous 'j3c' dataset of PySCF's own HDF5 file.  What
+// fits the device (or max_device_bytes) is uploaded once; the remaining rows are streamed block by block under the kernels in every
+// PAMD_df_get_jk, exactly like the host rows of an out-of-core PAMD_df_create_ex handle - flags bit 0: straight from the caller's
+// memory, which must then outlive the handle (no copy: a 560 GB file needs no 292 GB of page-locked RAM; the region is page-locked
+// in place when the driver allows, else it travels as pageable memory); without the flag the rows are copied into page-locked
+// memory of the handle.  No integrals, no metric: PAMD_df_naux = nrows.
+int PAMD_df_create_from_rows(const double *rows, int nrows, int nao, int device, long long max_device_bytes, int flags, PAMD_df **out)
+{
+    PAMD_REQUIRE(rows && out && nrows > 0 && nao > 0, "PAMD_df_create_from_rows: bad arguments");
+    *out = nullptr;
+    int ndevice = 0;
+    PAMD_CHECK_HIP(hipGetDeviceCount(&ndevice));
+    PAMD_REQUIRE(device >= 0 && device < ndevice, "PAMD_df_create_from_rows: device index out of range");
+    PAMD_CHECK_HIP(hipSetDevice(device));
+    std::lock_guard<std::mutex> lock(g_dev_mutex[device & 63]);
+    PAMD_df *h = new PAMD_df;
+    struct Guard { PAMD_df *p; ~Guard() { delete p; } } guard{h};
+    h->device = device;
+    h->nao = nao;
+    h->naux = nrows;
+    h->npair = (long)nao * (nao + 1) / 2;
+    h->rows = (int)round_up(nao, 16);
+    h->nL = h->nL_total = nrows;
+    int rc;
+    if ((rc = init_streams(h))) return rc;
+    const long npair = h->npair;
+    const size_t row_b = (size_t)npair * 8, tensor_b = (size_t)nrows * row_b;
+    size_t free_b = 0, total_b = 0;
+    PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t cap_in = max_device_bytes > 0 ? (size_t)max_device_bytes : 0;
+    const char *envcap = getenv("PAMD_DF_DEVICE_BYTES");
+    if (envcap && atof(envcap) > 0) cap_in = (size_t)atof(envcap);
+    const size_t cap = cap_in ? std::min(free_b, cap_in) : free_b;
+    const size_t margin = std::min<size_t>(1ul << 30, cap / 16);
+    size_t stage_b = 0;
+    if (tensor_b + margin <= cap) {
+        h->n_res = nrows;
+    } else {
+        stage_b = std::min<size_t>(4ul << 30, cap / 8);
+        const size_t work_b = std::min<size_t>(20ul << 30, cap / 4);
+        const size_t used = 2 * stage_b + work_b + margin + std::min<size_t>(4ul << 30, cap / 16);
+        h->stage_rows = (int)std::min<size_t>(stage_b / row_b, (size_t)nrows);
+        if (h->stage_rows < 1) {
+            snprintf(g_errmsg, sizeof(g_errmsg), "PAMD_df_create_from_rows: %.3f GB of device memory cannot stage one tensor row (%.3f GB)",
+                     cap * 1e-9, row_b * 1e-9);
+            return -2;
+        }
+        h->n_res = cap > used ? (int)std::min<size_t>((cap - used) / row_b, (size_t)nrows) : 0;
+        for (int k = 0; k < 2; k++)
+            if ((rc = h->pool.alloc((void **)&h->d_stage[k], (size_t)h->stage_rows * row_b + 256 * 8))) return rc;
+    }
+    if (h->n_res) {
+        if ((rc = h->pool.alloc((void **)&h->d_cderi, (size_t)h->n_res * row_b + 256 * 8))) return rc;
+        const int step = (int)std::max<size_t>(1, (1ul << 30) / row_b);
+        for (int r0 = 0; r0 < h->n_res; r0 += step) {
+            const int nb = std::min(step, h->n_res - r0);
+            PAMD_CHECK_HIP(hipMemcpy(h->d_cderi + (size_t)r0 * npair, rows + (size_t)r0 * npair, (size_t)nb * row_b, hipMemcpyHostToDevice));
+        }
+    }
+    if (h->n_res < nrows) {
+        const size_t host_b = (size_t)(nrows - h->n_res) * row_b;
+        const double *src = rows + (size_t)h->n_res * npair;
+        if (flags & 1) {
+            h->h_cderi = const_cast<double *>(src);
+            h->h_borrowed = 1;
+            if (hipHostRegister((void *)h->h_cderi, host_b, hipHostRegisterDefault) == hipSuccess) h->h_registered = 1;
+            (void)hipGetLastError();              // not registrable (a read-only file mapping, a locked-memory limit): pageable copies
+        } else {
+            if (hipHostMalloc((void **)&h->h_cderi, host_b, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                h->h_cderi = nullptr;
+                snprintf(g_errmsg, sizeof(g_errmsg), "PAMD_df_create_from_rows: %.1f GB of page-locked host memory could not be allocated "
+                         "(flags bit 0 streams from the caller's array instead)", host_b * 1e-9);
+                return -2;
+            }
+            memcpy(h->h_cderi, src, host_b);
+        }
+    }
+    const size_t held = (size_t)h->n_res * row_b + 2 * stage_b;
+    const size_t cap_left = cap_in ? (cap > held ? cap - held : 0) : ~(size_t)0;
+    if ((rc = build_square_image(h, cap_left))) return rc;
+    if ((rc = build_diag_image(h, cap_left))) return rc;
+    PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+    guard.p = nullptr;
+    *out = h;
+    return 0;
 }
 
 // Page-locked host memory for callers that want their result / input arrays copied at the PCIe rate (a pageable 8 nao^2-byte

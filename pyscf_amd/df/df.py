@@ -287,6 +287,18 @@ class DF:
                         raise RuntimeError("%s: 'j3c' holds %d columns, expected nao_pair = %d for nao = %d (s2-packed (naux, "
                                            "nao_pair) tensor, pyscf/df/df.py:59-72)" % (self._cderi, ncol, nao * (nao + 1) // 2, nao))
                     l0, l1 = self.shard_range(naux, self.rank, self.world_size)
+                    if self._rows_do_not_fit(l1 - l0, ncol, dev) and getattr(self, 'outcore', True):
+                        # r05: the file's rows of this rank do not fit the device - they are NOT loaded: the 'j3c' dataset is
+                        # mapped (np.memmap at H5Dget_offset) and the C handle streams the non-resident rows straight out of the
+                        # mapping under the kernels in every build (pyscf/df/df.py:214-242: the reference reads its file block by
+                        # block in DF.loop every iteration as well)
+                        off = blocks[0].file_offset() if len(blocks) == 1 else None
+                        if off is None:
+                            raise MemoryError("%s: the tensor does not fit the device and 'j3c' is not one contiguous dataset "
+                                              "(column-block group or chunked layout): rewrite it with DF.save()" % self._cderi)
+                        mm = np.memmap(self._cderi, dtype='<f8', mode='r', offset=off, shape=(naux, ncol))
+                        self._native_from_rows(mm[l0:l1], (l0, l1), naux, dev)
+                        return self
                     self._cderi_dev = torch.empty((l1 - l0, ncol), dtype=torch.float64, device=dev)
                     c0 = 0
                     for d in blocks:
@@ -314,6 +326,10 @@ class DF:
             # pre-computed FULL tensor handed over by the caller (pyscf/df/df.py:153-155); each rank keeps its rows
             naux = self._cderi.shape[0]
             l0, l1 = self.shard_range(naux, self.rank, self.world_size)
+            if self._rows_do_not_fit(l1 - l0, self._cderi.shape[1], dev) and getattr(self, 'outcore', True) \
+                    and self._cderi.flags.c_contiguous and self._cderi.dtype == np.float64:
+                self._native_from_rows(self._cderi[l0:l1], (l0, l1), naux, dev)     # streamed out of the caller's array
+                return self
             self._cderi_dev = torch.from_numpy(np.ascontiguousarray(self._cderi[l0:l1])).to(dev)
             self._naux = naux
             return self
@@ -354,6 +370,28 @@ class DF:
             self.save(self._cderi_to_save)
         return self
     kernel = build
+
+    def _rows_do_not_fit(self, nrows, ncol, dev):
+        import torch
+        need = nrows * ncol * 8
+        if self.outcore_device_bytes and need > self.outcore_device_bytes:
+            return True
+        if dev.type != 'cuda':
+            return False
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return need + (2 << 30) > free
+
+    def _native_from_rows(self, rows, shard_rows, naux, dev):
+        """Ready-made host rows (the caller's array / a mapped `_cderi` file) behind the out-of-core C handle."""
+        import torch
+        from .native import NativeDF
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        torch.cuda.empty_cache()
+        sharded = self.world_size > 1 or getattr(self, '_shard_override', None) is not None
+        self._native = NativeDF.from_rows(self.mol, rows, device=idx, max_device_bytes=int(getattr(self, 'outcore_device_bytes', 0)),
+                                          borrow=True, shard=(self.rank, self.world_size) if sharded else None,
+                                          shard_rows=shard_rows, naux=naux)
+        self._naux = naux
 
     def would_fit(self):
         """Cheap predicate (host arithmetic + one memory query, no integrals): does this rank's packed shard of the tensor,

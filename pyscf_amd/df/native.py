@@ -164,6 +164,8 @@ class NativeDF:
     def build(self):
         if self._h is not None:
             return self
+        if self.auxmol is False:
+            raise RuntimeError('this NativeDF was made from ready-made rows (from_rows) and has been reset: make a new one')
         if self.auxmol is None:
             from . import addons                  # host-only: basis tables (any object with _atm/_bas/_env works as auxmol)
             self.auxmol = addons.make_auxmol(self.mol, self.auxbasis)
@@ -189,6 +191,31 @@ class NativeDF:
         self.nao = n.value
         return self
     kernel = build
+
+    @classmethod
+    def from_rows(cls, mol, rows, device=0, max_device_bytes=0, borrow=True, shard=None, shard_rows=None, naux=None):
+        """A handle over tensor rows the caller already holds (PAMD_df_create_from_rows): `rows` (nrows, nao_pair) float64 C-order in
+        host memory - a numpy array or an np.memmap of the 'j3c' dataset of a PySCF `_cderi` file.  What fits the device is
+        uploaded, the rest is streamed under the kernels in every build - with `borrow` straight out of `rows` (kept alive by
+        this object; nothing the size of the tensor is allocated on the host).  `shard` / `shard_rows` / `naux`: the rows are
+        one rank's shard [r0, r1) of a tensor of `naux` rows (get_jk then returns partial sums)."""
+        rows = np.asarray(rows) if not isinstance(rows, np.memmap) else rows
+        if rows.dtype != np.float64 or rows.ndim != 2 or not rows.flags.c_contiguous:
+            raise ValueError('from_rows: a C-contiguous float64 (nrows, nao_pair) array')
+        nao = mol.nao_nr() if hasattr(mol, 'nao_nr') else mol.nao
+        if rows.shape[1] != nao * (nao + 1) // 2:
+            raise ValueError('from_rows: %d columns, expected nao_pair = %d' % (rows.shape[1], nao * (nao + 1) // 2))
+        self = cls(mol, device=device, max_device_bytes=max_device_bytes, shard=shard)
+        h = _c.c_void_p()
+        _check(load().PAMD_df_create_from_rows(_c.c_void_p(rows.ctypes.data), _c.c_int(rows.shape[0]), _c.c_int(nao), _c.c_int(int(device)),
+                                               _c.c_longlong(int(max_device_bytes)), _c.c_int(1 if borrow else 0), _c.byref(h)))
+        self._h = h
+        self._rows_keepalive = rows if borrow else None
+        self.nao = nao
+        self.shard_rows = tuple(shard_rows) if shard_rows is not None else (0, rows.shape[0])
+        self._naux = int(naux) if naux is not None else rows.shape[0]
+        self.auxmol = False                        # (no auxiliary molecule: the rows came ready-made)
+        return self
 
     def last_timing(self):
         """Host-clock timings of the last get_jk inside the handle (PAMD_df_last_timing): {'parts', 'sum_download_ms', 'peer',
@@ -225,6 +252,7 @@ class NativeDF:
             load().PAMD_df_destroy(self._h)
         self._h = None
         self._naux = None
+        self._rows_keepalive = None
         for o in getattr(self, '_rsh_df', {}).values():
             o.reset()
         self._rsh_df = {}
@@ -282,19 +310,41 @@ class NativeDF:
             blocks = [_scaled_occupied(mo_coeff[k], mo_occ[k]) for k in range(nset)]
             nocc = np.array([b.shape[1] for b in blocks], dtype=np.int32)
             orbo = np.concatenate([b.ravel() for b in blocks]) if nocc.sum() else np.zeros(1)
-            # dm == orbo orbo^T ?  (two matrix-vector products per density; the tag of this package's make_rdm1 promises it)
-            # (the package's own tag is probed as well: a tagged array edited in place keeps its attributes)
-            ok = None
-            if ok is None:
+            # dm == orbo orbo^T ?  One matrix-vector probe per density (the package's own tag is probed as well: a tagged array
+            # edited in place keeps its attributes).  r05: the probe (a 8 nao^2-byte read per density: 2-3 ms at nao 1856, the whole
+            # gap between this call and the bare C call) runs on a helper thread WHILE the device works - the build is issued
+            # optimistically with the fused first J pass; numpy and ctypes both release the GIL.  A mismatch (rare) redoes the call
+            # from the matrix.
+            import threading
+            verdict = {}
+
+            def probe():
                 v = np.random.RandomState(20240601).random_sample(nao) - 0.5
-                ok = all(np.abs(dms[k].dot(v) - blocks[k].dot(blocks[k].T.dot(v))).max() <= 1e-10 * max(1.0, np.abs(dms[k].dot(v)).max())
-                         for k in range(nset))
-            flags = 1 if ok else 0
+                good = True
+                for k in range(nset):
+                    dv = dms[k].dot(v)
+                    good = good and np.abs(dv - blocks[k].dot(blocks[k].T.dot(v))).max() <= 1e-10 * max(1.0, np.abs(dv).max())
+                verdict['ok'] = bool(good)
+            prober = threading.Thread(target=probe)
+            prober.start()
+            flags = 1
+        else:
+            prober = None
         vj = pinned_empty(dms.shape) if with_j else None
         vk = pinned_empty(dms.shape) if with_k else None
-        _check(load().PAMD_df_get_jk(
-            self._h, dms.ctypes.data_as(_c.c_void_p), orbo.ctypes.data_as(_c.c_void_p) if orbo is not None else None,
-            nocc.ctypes.data_as(_c.c_void_p) if nocc is not None else None, _c.c_int(nset), _c.c_int(nao), _c.c_int(hermi),
-            _c.c_int(int(with_j)), _c.c_int(int(with_k)), _c.c_int(flags),
-            vj.ctypes.data_as(_c.c_void_p) if with_j else None, vk.ctypes.data_as(_c.c_void_p) if with_k else None))
+
+        def call(fl):
+            _check(load().PAMD_df_get_jk(
+                self._h, dms.ctypes.data_as(_c.c_void_p), orbo.ctypes.data_as(_c.c_void_p) if orbo is not None else None,
+                nocc.ctypes.data_as(_c.c_void_p) if nocc is not None else None, _c.c_int(nset), _c.c_int(nao), _c.c_int(hermi),
+                _c.c_int(int(with_j)), _c.c_int(int(with_k)), _c.c_int(fl),
+                vj.ctypes.data_as(_c.c_void_p) if with_j else None, vk.ctypes.data_as(_c.c_void_p) if with_k else None))
+        try:
+            call(flags)
+        finally:
+            if prober is not None:
+                prober.join()
+        if prober is not None and not verdict.get('ok', False) and with_j:
+            call(0)                                    # the tag does not describe this matrix: J (and K) again without the promise
+        self._last_fused = bool(flags and verdict.get('ok', False)) if prober is not None else False
         return (vj.reshape(shape) if with_j else None), (vk.reshape(shape) if with_k else None)

@@ -102,6 +102,14 @@ class Dataset:
         self._io(self._lib.H5Dread, r0, out)
         return out
 
+    def file_offset(self):
+        """Byte offset of the raw data in the file when the dataset is stored CONTIGUOUSLY (what `create_dataset` here and
+        h5py's default write), else None (chunked / compressed layouts have no single offset) - H5Dget_offset."""
+        fn = self._lib.H5Dget_offset
+        fn.restype = ctypes.c_uint64
+        off = fn(_hid(self._id))
+        return None if off == 0xffffffffffffffff else int(off)
+
     def close(self):
         if self._id is not None:
             self._lib.H5Dclose(_hid(self._id))

@@ -43,6 +43,12 @@ def test_bench_gpus2_launches_two_ranks():
     # the roofline durations are those of the timed steps (live HIP events), the serial pass is reported beside them
     assert one['roofline']['launches_per_step'] >= 1 and one['kernels_serial_pass'] and 'e2_symm' in one['kernels']
     assert one['kernels']['e2_symm']['ms_total'] < one['ms_per_step']
+    # r05: in-run correctness evidence and live HBM counters are part of every line (the golden exists for configs 3 / 4 only)
+    for d in (one, two):
+        assert 'parity_golden' in d and d['parity_golden']['golden'] is None and 'why' in d['parity_golden']
+    import shutil
+    if shutil.which('rocprofv3') and one['roofline']['traffic'] is not None:
+        assert 'measured in this run' in one['roofline']['traffic_source'], one['roofline']['traffic_source']
 
 
 def test_bench_refuses_a_world_size_mismatch():

@@ -91,6 +91,20 @@ r04a)       # new tests of the round + bench modes
   timeout 1200 python -m pytest -q -x --durations=6 tests/test_gpu_native_r04.py::test_stock_script_with_a_device_list_reaches_the_reference_golden tests/test_gpu_fullsize_cfg45.py::test_config4_taxol_df_rks_xc_and_energy_vs_oracle_golden > $O/pytest.log 2>&1; tail -12 $O/pytest.log
   timeout 600 python bench.py --gpus 2 --single-process --steps 3 > $O/bench_single_process_2parts.json 2> $O/bench_sp.err; cut -c1-700 $O/bench_single_process_2parts.json; tail -2 $O/bench_sp.err
   timeout 1200 python bench.py --pmc --steps 10 --warmup 2 > $O/bench_pmc.json 2> $O/bench_pmc.err; tail -c 1500 $O/bench_pmc.json; tail -3 $O/bench_pmc.err ;;
+r05a)       # r05 validation: new handle paths, un-gated config 5, rank shard out of core, bench modes with parity_golden
+  timeout 2400 python -m pytest -q -x --durations=8 tests/test_gpu_native_abi.py tests/test_gpu_native_r04.py tests/test_gpu_fullsize_cfg45.py::test_config5_rank_shard_out_of_core_behind_DF_vs_oracle_golden tests/test_gpu_scf.py tests/test_gpu_grad.py -m gpu > $O/pytest.log 2>&1; tail -15 $O/pytest.log
+  tail -6 gpurun_out/_native_cfg45_worker_config5.log
+  timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python tools/bench_digest.py $O/bench_default.json; tail -3 $O/bench_default.err
+  timeout 600 python bench.py --gpus 1 --single-process --steps 5 > $O/bench_sp1.json 2> $O/bench_sp1.err; python tools/bench_digest.py $O/bench_sp1.json; tail -3 $O/bench_sp1.err
+  timeout 600 python bench.py --gpus 2 --single-process --steps 5 --no-cpu-baseline --xc '' > $O/bench_sp2.json 2> $O/bench_sp2.err; python tools/bench_digest.py $O/bench_sp2.json; tail -3 $O/bench_sp2.err
+  timeout 600 python bench.py --gpus 2 --backend gloo --steps 3 --no-cpu-baseline --xc '' > $O/bench_gloo2.json 2> $O/bench_gloo2.err; python tools/bench_digest.py $O/bench_gloo2.json; tail -3 $O/bench_gloo2.err
+  timeout 300 python tools/native_bench.py > $O/native_bench.log 2>&1; tail -4 $O/native_bench.log ;;
+r05b)       # r05: threaded probe + overlapped J download + calibrated CPU baseline + default pmc; mmap streaming test
+  timeout 1500 python -m pytest -q -x --durations=6 tests/test_gpu_native_abi.py tests/test_gpu_native_r04.py::test_cderi_file_is_streamed_from_an_mmap_when_it_does_not_fit tests/test_gpu_native_r04.py::test_torch_resident_df_falls_back_to_the_streaming_handle_when_the_tensor_does_not_fit tests/test_gpu_native_r04.py::test_multi_device_handle_streaming_and_omega_without_torch tests/test_gpu_native_r04.py::test_config3_through_the_native_handle_vs_oracle_golden tests/test_gpu_bench_launch.py tests/test_gpu_device_scf.py -m gpu > $O/pytest.log 2>&1; tail -12 $O/pytest.log
+  /usr/bin/time -v -o $O/bench_default.time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python tools/bench_digest.py $O/bench_default.json; tail -3 $O/bench_default.err; grep -E "Elapsed" $O/bench_default.time
+  timeout 600 python bench.py --gpus 1 --single-process --steps 10 --xc '' > $O/bench_sp1.json 2> $O/bench_sp1.err; python tools/bench_digest.py $O/bench_sp1.json; tail -3 $O/bench_sp1.err
+  timeout 600 python bench.py --gpus 2 --single-process --steps 5 --no-cpu-baseline --xc '' > $O/bench_sp2.json 2> $O/bench_sp2.err; python tools/bench_digest.py $O/bench_sp2.json; tail -3 $O/bench_sp2.err
+  timeout 300 python tools/native_bench.py > $O/native_bench.log 2>&1; tail -4 $O/native_bench.log ;;
 evidence)   # the round's measured evidence (everything except the test suite): gpu_job.sh evidence <tag>
   TAG=${1:-r04}
   bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log
