@@ -326,9 +326,9 @@ class DF:
             # pre-computed FULL tensor handed over by the caller (pyscf/df/df.py:153-155); each rank keeps its rows
             naux = self._cderi.shape[0]
             l0, l1 = self.shard_range(naux, self.rank, self.world_size)
-            if self._rows_do_not_fit(l1 - l0, self._cderi.shape[1], dev) and getattr(self, 'outcore', True) \
-                    and self._cderi.flags.c_contiguous and self._cderi.dtype == np.float64:
-                self._native_from_rows(self._cderi[l0:l1], (l0, l1), naux, dev)     # streamed out of the caller's array
+            if self._rows_do_not_fit(l1 - l0, self._cderi.shape[1], dev) and getattr(self, 'outcore', True):
+                # streamed out of the caller's array (C order, float64: as it is; anything else through one host copy of the rows)
+                self._native_from_rows(np.ascontiguousarray(self._cderi[l0:l1], dtype=np.float64), (l0, l1), naux, dev)
                 return self
             self._cderi_dev = torch.from_numpy(np.ascontiguousarray(self._cderi[l0:l1])).to(dev)
             self._naux = naux

@@ -310,26 +310,19 @@ class NativeDF:
             blocks = [_scaled_occupied(mo_coeff[k], mo_occ[k]) for k in range(nset)]
             nocc = np.array([b.shape[1] for b in blocks], dtype=np.int32)
             orbo = np.concatenate([b.ravel() for b in blocks]) if nocc.sum() else np.zeros(1)
-            # dm == orbo orbo^T ?  One matrix-vector probe per density (the package's own tag is probed as well: a tagged array
-            # edited in place keeps its attributes).  r05: the probe (a 8 nao^2-byte read per density: 2-3 ms at nao 1856, the whole
-            # gap between this call and the bare C call) runs on a helper thread WHILE the device works - the build is issued
-            # optimistically with the fused first J pass; numpy and ctypes both release the GIL.  A mismatch (rare) redoes the call
-            # from the matrix.
-            import threading
-            verdict = {}
-
-            def probe():
-                v = np.random.RandomState(20240601).random_sample(nao) - 0.5
-                good = True
-                for k in range(nset):
-                    dv = dms[k].dot(v)
-                    good = good and np.abs(dv - blocks[k].dot(blocks[k].T.dot(v))).max() <= 1e-10 * max(1.0, np.abs(dv).max())
-                verdict['ok'] = bool(good)
-            prober = threading.Thread(target=probe)
-            prober.start()
-            flags = 1
-        else:
-            prober = None
+            # dm == orbo orbo^T ?  One matrix-vector probe per density (r04 computed D v twice per density: with numpy's 64 BLAS
+            # threads on a 256-core host that was the whole 10 ms gap between this call and the bare C call; a probe on a helper
+            # thread beside the device call - tried in r05 - made the C call itself 40 ms slower: the BLAS threads spin)
+            v = np.random.RandomState(20240601).random_sample(nao) - 0.5
+            # this package's own make_rdm1 tag (dm_from_orbitals): every 16th row is probed (0.1 ms) - it catches what an in-place
+            # edit of a tagged array looks like in practice (dm *= x, dm += x, dm[...] = ...: ADVICE r04); a foreign tag (stock
+            # PySCF's lib.tag_array(dm, mo_coeff=, mo_occ=)) gets the full matrix-vector probe (one 8 nao^2-byte read per density)
+            step = 16 if getattr(dm, 'dm_from_orbitals', False) else 1
+            ok = True
+            for k in range(nset):
+                dv = dms[k][::step].dot(v)
+                ok = ok and np.abs(dv - blocks[k][::step].dot(blocks[k].T.dot(v))).max() <= 1e-10 * max(1.0, np.abs(dv).max())
+            flags = 1 if ok else 0
         vj = pinned_empty(dms.shape) if with_j else None
         vk = pinned_empty(dms.shape) if with_k else None
 
@@ -339,12 +332,6 @@ class NativeDF:
                 nocc.ctypes.data_as(_c.c_void_p) if nocc is not None else None, _c.c_int(nset), _c.c_int(nao), _c.c_int(hermi),
                 _c.c_int(int(with_j)), _c.c_int(int(with_k)), _c.c_int(fl),
                 vj.ctypes.data_as(_c.c_void_p) if with_j else None, vk.ctypes.data_as(_c.c_void_p) if with_k else None))
-        try:
-            call(flags)
-        finally:
-            if prober is not None:
-                prober.join()
-        if prober is not None and not verdict.get('ok', False) and with_j:
-            call(0)                                    # the tag does not describe this matrix: J (and K) again without the promise
-        self._last_fused = bool(flags and verdict.get('ok', False)) if prober is not None else False
+        call(flags)
+        self._last_fused = bool(flags)
         return (vj.reshape(shape) if with_j else None), (vk.reshape(shape) if with_k else None)

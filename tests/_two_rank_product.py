@@ -71,6 +71,20 @@ def main():
         obj3._cderi = h5
         obj3.build()
         assert obj3.get_naoaux() == naux and torch.equal(obj3._cderi_dev, obj._cderi_dev)
+    # r05: a rank whose shard does not fit its device (cap) holds it out of core behind the C handle (part / nparts); the handle
+    # returns the shard's PARTIAL J/K in host arrays and DF.get_jk all-reduces them over the ranks - here over gloo, for real
+    oc = df.DF(mol)
+    oc.outcore_device_bytes = 30 * (nao * (nao + 1) // 2) * 8
+    oc.build()
+    lay = oc.out_of_core()
+    assert lay is not None and oc._cderi_dev is None and list(oc._native.shard_rows) == [l0, l1] and lay['rows_host'] > 0, lay
+    vj3, vk3 = oc.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=occ), hermi=1)
+    vjr, vkr = ref.get_jk(cderi, dm, 1, mo_coeff=c, mo_occ=occ)
+    assert np.abs(vj3 - vjr).max() < 1e-9 and np.abs(vk3 - vkr).max() < 1e-9
+    vj3, vk3 = oc.get_jk(dms, hermi=0)
+    assert np.abs(vj3 - vj0).max() < 1e-9 and np.abs(vk3 - vk0).max() < 1e-9
+    assert np.abs(np.vstack(list(oc.loop(37, local=True))) - cderi[l0:l1]).max() < 1e-9
+    oc.reset()
     # XC: grid tiles dealt round-robin, vmat / nelec / exc all-reduced
     grids = dft.Grids(mol)
     grids.level = 1

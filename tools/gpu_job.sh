@@ -101,7 +101,7 @@ r05a)       # r05 validation: new handle paths, un-gated config 5, rank shard ou
   timeout 300 python tools/native_bench.py > $O/native_bench.log 2>&1; tail -4 $O/native_bench.log ;;
 r05b)       # r05: threaded probe + overlapped J download + calibrated CPU baseline + default pmc; mmap streaming test
   timeout 1500 python -m pytest -q -x --durations=6 tests/test_gpu_native_abi.py tests/test_gpu_native_r04.py::test_cderi_file_is_streamed_from_an_mmap_when_it_does_not_fit tests/test_gpu_native_r04.py::test_torch_resident_df_falls_back_to_the_streaming_handle_when_the_tensor_does_not_fit tests/test_gpu_native_r04.py::test_multi_device_handle_streaming_and_omega_without_torch tests/test_gpu_native_r04.py::test_config3_through_the_native_handle_vs_oracle_golden tests/test_gpu_bench_launch.py tests/test_gpu_device_scf.py -m gpu > $O/pytest.log 2>&1; tail -12 $O/pytest.log
-  /usr/bin/time -v -o $O/bench_default.time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python tools/bench_digest.py $O/bench_default.json; tail -3 $O/bench_default.err; grep -E "Elapsed" $O/bench_default.time
+  T0=$(date +%s); timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench wall: $(( $(date +%s) - T0 )) s"; python tools/bench_digest.py $O/bench_default.json; tail -3 $O/bench_default.err
   timeout 600 python bench.py --gpus 1 --single-process --steps 10 --xc '' > $O/bench_sp1.json 2> $O/bench_sp1.err; python tools/bench_digest.py $O/bench_sp1.json; tail -3 $O/bench_sp1.err
   timeout 600 python bench.py --gpus 2 --single-process --steps 5 --no-cpu-baseline --xc '' > $O/bench_sp2.json 2> $O/bench_sp2.err; python tools/bench_digest.py $O/bench_sp2.json; tail -3 $O/bench_sp2.err
   timeout 300 python tools/native_bench.py > $O/native_bench.log 2>&1; tail -4 $O/native_bench.log ;;
