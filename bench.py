@@ -726,6 +726,23 @@ def single_process_main(args):
         xc_info = {'xc': args.xc, 'nr_rks_ms_per_call': round(float(np.median(xt)), 1), 'nr_rks_ms_calls': [round(t, 1) for t in xt],
                    'ngrids': int(grids.size), 'grid_build_s': round(grid_s, 2), 'plan_build_s': round(plan_s, 2), 'nelec': float(nel),
                    'plan': ni.plan_info(mol, grids, args.xc), 'what': 'NativeNumInt(devices=...).nr_rks with numpy in / out (PAMD_xc_nr_rks)'}
+        # roofline of the XC leg from the HIP events the handle records around its kernels (slowest part); with several parts the
+        # executed flops are those of ALL parts, so the fraction is priced against parts x the peak
+        xt_ = ni.last_timing(mol, grids)
+        nd_ = len(set(devices))
+        xr = {}
+        for k_ in ('ao_dot_mo', 'ao_dot_aow'):
+            if xt_['ms'][k_] > 0:
+                ach_ = xt_['flops'][k_] / xt_['ms'][k_] * 1e-9
+                xr[k_] = {'bound': 'mfma', 'executed_TFLOP': round(xt_['flops'][k_] * 1e-12, 4), 'ms': round(xt_['ms'][k_], 3),
+                          'achieved': round(ach_, 2), 'peak': FP64_MFMA_PEAK_TFLOPS * nd_, 'unit': 'TFLOP/s',
+                          'frac': round(ach_ / (FP64_MFMA_PEAK_TFLOPS * nd_), 4)}
+        if xt_['ms']['scale_ao'] > 0:
+            gbs_ = xt_['scale_bytes'] / xt_['ms']['scale_ao'] * 1e-6
+            xr['scale_ao'] = {'bound': 'hbm', 'bytes': xt_['scale_bytes'], 'ms': round(xt_['ms']['scale_ao'], 3), 'achieved': round(gbs_, 1),
+                              'peak': HBM_PEAK_GBS * nd_, 'unit': 'GB/s', 'frac': round(gbs_ / (HBM_PEAK_GBS * nd_), 4)}
+        xc_info['kernels_ms'] = {k_: round(v_, 3) for k_, v_ in xt_['ms'].items()}
+        xc_info['roofline'] = xr
         ni.reset()
     nt = -(-nao // 128)
     step_exec = 2.0 * naux * nao * nao * nocc * (1.0 + (nt * (nt + 1) / 2) / (float(nt) * nt))

@@ -429,6 +429,9 @@ int PAMD_xc_create_multi(const int *atm, int natm, const int *bas, int nbas, con
 void PAMD_xc_destroy(PAMD_xc *h);
 int PAMD_xc_nao(const PAMD_xc *h, int *nao);
 int PAMD_xc_plan_info(PAMD_xc *h, int xctype, double *info);
+/* r05: HIP-event timings of the last PAMD_xc_nr_rks / _nr_uks: out[10] = {parts, ms of the slowest part's orbital product (+ densities),
+ * eval_xc, scale, vmat; sum of the tiles' compact widths, of their squares; points per tile; components; padded orbital count} */
+int PAMD_xc_last_timing(const PAMD_xc *h, double *out, int nout);
 int PAMD_xc_nr_rks(PAMD_xc *h, const double *fac, int xctype, int nset, const double *orbs, const int *nocc, const double *signs,
                    double *nelec, double *exc, double *vmat);
 int PAMD_xc_nr_uks(PAMD_xc *h, const double *fac, int xctype, const double *orbs, const int *nocc, const double *signs, double *nelec,

@@ -108,6 +108,21 @@ struct PAMD_xc {
     XcPlan plan[2];                                              // LDA (1 component), GGA (4)
     std::vector<PAMD_xc *> parts;                                // multi-device handle: grid tiles dealt round-robin (owned)
     int peer_ok = 0;
+    // HIP events around the kernels of the last contraction, on the launch stream (PAMD_xc_last_timing; r05):
+    // kinds 0 orbital product (+ rho), 1 eval_xc, 2 scale, 3 vmat
+    std::vector<hipEvent_t> tev;
+    double t_ms[4] = {0, 0, 0, 0};
+    double last_sum_ld = 0, last_sum_ld2 = 0;
+    int last_ncomp = 1, last_nocc_pad = 0;
+    hipEvent_t timing_event(size_t i)
+    {
+        while (tev.size() <= i) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            tev.push_back(e);
+        }
+        return tev[i];
+    }
     std::map<std::string, std::pair<double *, size_t>> ws;
     double *workspace(const std::string &name, size_t ndoubles, int *rc)
     {
@@ -129,6 +144,7 @@ struct PAMD_xc {
             delete p;
         }
         if (!parts.empty()) (void)hipSetDevice(device);
+        for (hipEvent_t e : tev) (void)hipEventDestroy(e);
         if (st) (void)hipStreamDestroy(st);
     }
 };
@@ -304,6 +320,14 @@ int xc_contract(PAMD_xc *h, const double *fac, int gga, int spin, OrbOp *ops, do
     if (rc) return rc;
     PAMD_CHECK_HIP(hipMemsetAsync(d_M, 0, (size_t)nset * n2 * 8, st));
     PAMD_CHECK_HIP(hipMemsetAsync(d_acc, 0, 4 * 8, st));
+    std::vector<int> mark_kind;                 // event i opens (kind) / event i + 1 closes it
+    auto mark = [&](int kind) {
+        if (mark_kind.size() >= 1024) return;
+        hipEvent_t e = h->timing_event(mark_kind.size());
+        if (!e) return;
+        (void)hipEventRecord(e, st);
+        mark_kind.push_back(kind);
+    };
     for (const XcChunk &ch : pl.chunks) {
         const int t0 = ch.t0, nt = ch.nt;
         const long npts = (long)nt * G;
@@ -317,13 +341,14 @@ int xc_contract(PAMD_xc *h, const double *fac, int gga, int spin, OrbOp *ops, do
                 continue;
             }
             const long cs = (long)ops[s].nocc_pad * npts;
+            mark(0);
             if (gga) {
                 // rho / grad rho in the orbital product's epilogue (no c[comp][i][g] buffer); 1 = no fused kernel for this shape
                 if (ops[s].nocc_pad > 160) PAMD_CHECK_HIP(hipMemsetAsync(rho_s, 0, (size_t)4 * ldg * 8, st));
                 rc = PAMD_sub_orb_rho(pl.d_ao_c, ao_off, idx_off, ld, pl.d_idx, nt, G, ops[s].d_orb, (int)ops[s].ldo, ops[s].nocc,
                                       ops[s].nocc_pad, ops[s].d_sign, rho_s, ldg, st);
                 if (rc < 0) return rc;
-                if (rc == 0) continue;
+                if (rc == 0) { mark(-1); continue; }
             }
             if (!d_cmo) {
                 d_cmo = h->workspace("cmo", (size_t)ncomp * nocc_pad_max * ldg, &rc);
@@ -333,18 +358,24 @@ int xc_contract(PAMD_xc *h, const double *fac, int gga, int spin, OrbOp *ops, do
                                        d_cmo, cs, npts, st)))
                 return rc;
             if ((rc = PAMD_rho_from_mo(d_cmo, cs, npts, ops[s].nocc, ncomp, npts, rho_s, ldg, ops[s].d_sign, st))) return rc;
+            mark(-1);
         }
+        mark(1);
         if (spin)
             rc = PAMD_eval_xc_pol(fac, gga, d_rho, d_rho + (size_t)4 * ldg, w_ch, npts, ldg, d_wv, d_wv + (size_t)4 * ldg, d_acc, nullptr, st);
         else
             rc = PAMD_eval_xc(fac, gga, d_rho, w_ch, npts, ldg, d_wv, nullptr, d_acc, st);
         if (rc) return rc;
+        mark(-1);
         for (int s = 0; s < nset; s++) {
+            mark(2);
             if ((rc = PAMD_sub_scale_ao(pl.d_ao_c, ao_off, aow_off, ld, nt, G, ncomp, ch.ld_max, d_wv + (size_t)s * 4 * ldg, ldg, d_aow, st)))
                 return rc;
+            mark(3);
             if ((rc = PAMD_sub_vmat_sym(pl.d_ao_c, ao_off, d_aow, aow_off, idx_off, ld, pl.d_idx, ch.d_work, (int)ch.nwork, G, nao,
                                         d_M + (size_t)s * n2, nao, st)))
                 return rc;
+            mark(-1);
         }
     }
     for (int s = 0; s < nset; s++)
@@ -352,6 +383,17 @@ int xc_contract(PAMD_xc *h, const double *fac, int gga, int spin, OrbOp *ops, do
     PAMD_CHECK_HIP(hipMemcpyAsync(acc_h, d_acc, 4 * 8, hipMemcpyDeviceToHost, st));
     if (vmat) PAMD_CHECK_HIP(hipMemcpyAsync(vmat, d_V, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
     PAMD_CHECK_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 4; k++) h->t_ms[k] = 0;
+    for (size_t i = 0; i + 1 < mark_kind.size(); i++)
+        if (mark_kind[i] >= 0) {               // (a scale mark is closed by the vmat mark that follows it)
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, h->tev[i], h->tev[i + 1]) == hipSuccess) h->t_ms[mark_kind[i]] += ms;
+        }
+    (void)hipGetLastError();
+    h->last_sum_ld = h->last_sum_ld2 = 0;
+    for (int v : pl.ld) { h->last_sum_ld += v; h->last_sum_ld2 += (double)v * v; }
+    h->last_ncomp = ncomp;
+    h->last_nocc_pad = nocc_pad_max;
     return 0;
 }
 
@@ -608,6 +650,34 @@ int PAMD_xc_plan_info(PAMD_xc *h, int xctype, double *info)
     info[0] = pl.ntile;
     info[1] = pl.density;
     info[2] = pl.ao_total * 8e-9;
+    return 0;
+}
+
+// HIP-event timings of the kernels of the LAST PAMD_xc_nr_rks / _nr_uks (bench.py --single-process `xc_path.roofline`; r05):
+// out[0] = parts; then the SLOWEST part's ms of {orbital product (+ densities), eval_xc, scale, vmat} in out[1..4]; out[5] = sum over
+// ALL tiles of all parts of the compact widths ld_t, out[6] = of ld_t^2 (the flops the two MFMA products execute: 2 ncomp G sum(ld)
+// nocc_pad and 2 G sum(ld^2)), out[7] = points per tile G, out[8] = components, out[9] = padded orbital count.
+int PAMD_xc_last_timing(const PAMD_xc *h, double *out, int nout)
+{
+    PAMD_REQUIRE(h && out && nout >= 10, "PAMD_xc_last_timing: out[10]");
+    std::vector<const PAMD_xc *> ps;
+    if (h->parts.empty()) ps.push_back(h);
+    for (const PAMD_xc *p : h->parts) ps.push_back(p);
+    for (int i = 0; i < 10; i++) out[i] = 0;
+    out[0] = (double)ps.size();
+    double worst = -1;
+    for (const PAMD_xc *p : ps) {
+        const double tot = p->t_ms[0] + p->t_ms[1] + p->t_ms[2] + p->t_ms[3];
+        if (tot > worst) {
+            worst = tot;
+            for (int k = 0; k < 4; k++) out[1 + k] = p->t_ms[k];
+        }
+        out[5] += p->last_sum_ld;
+        out[6] += p->last_sum_ld2;
+        out[8] = p->last_ncomp;
+        out[9] = p->last_nocc_pad;
+    }
+    out[7] = XC_G;
     return 0;
 }
 

@@ -517,6 +517,38 @@ def _dm_matches_orbitals(dms_dev, orb_list, nao):
     return float(worst) <= 1e-10
 
 
+class _HostDM:
+    """Density matrices still on the HOST, uploaded on first use (r05).  With J taken from the orbitals (fused first pass) no kernel
+    of the MO branch reads the matrix: the 8 nao^2-byte upload of a pageable caller array per density (2.5-3 ms at nao 1856) then
+    never happens - the host API `with_df.get_jk(dm)` costs what the device-resident step costs plus the download."""
+
+    def __init__(self, dms, device):
+        self._host, self.device, self.shape, self._t = dms, device, dms.shape, None
+
+    def tensor(self):
+        if self._t is None:
+            self._t = _torch().from_numpy(self._host).to(self.device)
+        return self._t
+
+
+def _dm_tensor(d):
+    return d.tensor() if isinstance(d, _HostDM) else d
+
+
+def _host_dm_mismatch(dms, blocks, own_tag):
+    """max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) on the host for one fixed pseudo-random vector (the probe of the C handle's
+    binding, pyscf_amd/df/native.py): this package's own make_rdm1 tag on every 16th row (0.1 ms: what an in-place edit of a
+    tagged array looks like in practice - dm *= x, dm += x - shows there), a foreign tag on the full matrix."""
+    nao = dms.shape[-1]
+    v = np.random.RandomState(20240601).random_sample(nao) - 0.5
+    step = 16 if own_tag else 1
+    worst = 0.0
+    for k in range(len(dms)):
+        dv = dms[k][::step].dot(v)
+        worst = max(worst, float(np.abs(dv - blocks[k][::step].dot(blocks[k].T.dot(v))).max() / max(1.0, np.abs(dv).max())))
+    return worst
+
+
 def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_from_orbitals=None):
     """Device-resident J/K build: inputs and outputs stay in HBM.
       dms_dev   (nset, nao, nao) f64 CUDA tensor
@@ -532,7 +564,7 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
     torch = _torch()
     overlap = with_j and with_k and orb_list is not None and getattr(dfobj, 'overlap_jk', False)
     if with_j and not overlap:
-        vjtril = _vj(dfobj, lib, dms_dev, nset, nao)
+        vjtril = _vj(dfobj, lib, _dm_tensor(dms_dev), nset, nao)
         outs.append(vjtril)
     if with_k:
         if orb_list is not None:
@@ -552,7 +584,7 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                     # that built D from these orbitals say so (dm_from_orbitals=True: no check, no host sync, no library
                     # GEMM in the hot loop); otherwise a random-vector probe D v = C (C^T v) decides - two GEMVs and one
                     # scalar read-back instead of the nao^2 nocc product; PAMD_DEBUG_CHECK_DM=1 restores the full comparison.
-                    fused = dm_from_orbitals is None and _dm_matches_orbitals(dms_dev, orb_list, nao)
+                    fused = dm_from_orbitals is None and _dm_matches_orbitals(_dm_tensor(dms_dev), orb_list, nao)
                 dfobj._last_fused = bool(fused)
                 if fused:
                     # pass 1 comes out of the half transform (PAMD_nr_e2_square); pass 2 of each K block follows either on the
@@ -615,7 +647,7 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
                         if 'rho' not in holder:
-                            holder['rho'] = _vj_pass1(dfobj, lib, dms_dev, nset, nao)
+                            holder['rho'] = _vj_pass1(dfobj, lib, _dm_tensor(dms_dev), nset, nao)
                             if getattr(dfobj, 'overlap_split', True):
                                 return
                         holder['vj'] = _vj_pass2(dfobj, lib, holder['rho'], nset)
@@ -630,7 +662,7 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
             else:
                 vk_dev = _vk_mo(dfobj, lib, orb_list, nao)
         else:
-            vk_dev = _vk_general(dfobj, lib, dms_dev, nset, nao)
+            vk_dev = _vk_general(dfobj, lib, _dm_tensor(dms_dev), nset, nao)
         outs.append(vk_dev)
     if (_comm.active(dfobj.world_size) and getattr(dfobj, '_shard_override', None) is None and orb_list is not None and
             vjtril is not None and vk_dev is not None and getattr(dfobj, 'packed_allreduce', True)):
@@ -664,7 +696,7 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
     dms = np.ascontiguousarray(dms.reshape(-1, nao, nao), dtype=np.float64)
     nset = dms.shape[0]
     dev = dfobj._cderi_dev.device
-    dms_dev = torch.from_numpy(dms).to(dev)
+    dms_dev = _HostDM(dms, dev)                 # uploaded only if a kernel reads the matrix (not on the fused MO branch)
     lowrank = getattr(dm, 'lowrank', None)
     if with_k and lowrank is not None and getattr(dfobj, 'lowrank_exchange', True):
         # factorised trial densities (tag: lowrank = (lefts, rights, sym), D_k = L_k R_k^T [+ h.c.]): J from the full
@@ -672,7 +704,7 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         lib = _lib_mod.load_library()
         lefts, rights, sym = lowrank
         assert len(lefts) == nset == len(rights)
-        vjtril = _vj(dfobj, lib, dms_dev, nset, nao) if with_j else None
+        vjtril = _vj(dfobj, lib, dms_dev.tensor(), nset, nao) if with_j else None
         vk_dev = _vk_lowrank(dfobj, lib, lefts, rights, sym, nao)
         _allreduce(dfobj, [t for t in (vjtril, vk_dev) if t is not None])
         return _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k)
@@ -689,8 +721,8 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
             mo_occa = np.array(mo_occ > 0, dtype=np.double)
             mo_occb = np.array(mo_occ == 2, dtype=np.double)
             mo_occ = np.vstack((mo_occa, mo_occb))
-        orb_list = [pad_orbitals(mo_coeff[k][:, mo_occ[k] > 0] * np.sqrt(mo_occ[k][mo_occ[k] > 0]), dev)
-                    for k in range(nset)]
+        host_blocks = [mo_coeff[k][:, mo_occ[k] > 0] * np.sqrt(mo_occ[k][mo_occ[k] > 0]) for k in range(nset)]
+        orb_list = [pad_orbitals(b, dev) for b in host_blocks]
     neg_sets = None
     if with_k and orb_list is None and hermi == 1 and getattr(dfobj, 'factorize_hermitian_dm', True):
         # No orbitals came with the density (initial guesses, user-built DMs): the reference then pays 4 naux nao^3
@@ -699,7 +731,8 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         # guess an order of magnitude less.
         pos, neg = [], []
         for k in range(nset):
-            w, v = torch.linalg.eigh((dms_dev[k] + dms_dev[k].T) * .5)
+            dk = dms_dev.tensor()[k]
+            w, v = torch.linalg.eigh((dk + dk.T) * .5)
             thr = 1e-13 * max(float(w.abs().max()), 1e-300)
             cp = (v[:, w > thr] * w[w > thr].sqrt()).cpu().numpy()
             cn = (v[:, w < -thr] * (-w[w < -thr]).sqrt()).cpu().numpy()
@@ -717,8 +750,10 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         # in the rare case of a tag that does not match its matrix J is redone from the matrix by the two-pass kernels below.
         # r04 (ADVICE): the package's own tag is probed as well - a tagged array edited in place (dm *= .5, dm[...] += x) keeps its
         # attributes; only the internal device loop (get_jk_device, densities it built itself) runs unchecked
+        # r05: the probe runs on the HOST, after the kernels have been queued and while they run (this thread is free until the
+        # download) - the matrix is no longer uploaded for it
         promise = True
-        check = _dm_orbital_mismatch(dms_dev, orb_list, nao)
+        check = lambda: _host_dm_mismatch(dms, host_blocks, bool(getattr(dm, 'dm_from_orbitals', False)))
     elif neg_sets is not None or orb_list is not None:
         promise = False if neg_sets is not None else None
     vjtril, vk_dev = get_jk_device(dfobj, dms_dev, orb_list, with_j, with_k, dm_from_orbitals=promise)
@@ -729,11 +764,12 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         _allreduce(dfobj, [vk_neg])
         for j, k in enumerate(idx):
             vk_dev[k] -= vk_neg[j]
+    mismatch = check() if check is not None else 0.0          # (host arithmetic beside the queued kernels)
     vj, vk = _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k)
-    if check is not None and float(check) > 1e-10:
+    if mismatch > 1e-10:
         # the tag did not describe the matrix: J from the matrix itself (the K of the MO branch follows the tag, as in the reference)
         lib = _lib_mod.load_library()
-        vjtril = _vj(dfobj, lib, dms_dev, nset, nao)
+        vjtril = _vj(dfobj, lib, dms_dev.tensor(), nset, nao)
         _allreduce(dfobj, [vjtril])
         vj = _to_host(dfobj, vjtril, None, nset, nao, dm_shape, True, False)[0]
     return vj, vk

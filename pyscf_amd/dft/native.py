@@ -136,6 +136,16 @@ class NativeNumInt:
         _native._check(_native.load().PAMD_xc_plan_info(self._handle(mol, grids), _c.c_int(int(_xc.xc_type(xc_code) == 'GGA')), info))
         return dict(tiles=int(info[0]), density=info[1], compact_GB=info[2])
 
+    def last_timing(self, mol, grids):
+        """HIP-event timings of the kernels of the last nr_rks / nr_uks inside the handle (PAMD_xc_last_timing) and the executed flops
+        of its two MFMA products - what bench.py --single-process prices as `xc_path.roofline`."""
+        out = (_c.c_double * 10)()
+        _native._check(_native.load().PAMD_xc_last_timing(self._handle(mol, grids), out, _c.c_int(10)))
+        g, ncomp, npad = out[7], out[8], out[9]
+        return dict(parts=int(out[0]), ms={'ao_dot_mo': out[1], 'eval_xc': out[2], 'scale_ao': out[3], 'ao_dot_aow': out[4]},
+                    flops={'ao_dot_mo': 2.0 * ncomp * g * out[5] * npad, 'ao_dot_aow': 2.0 * g * out[6]},
+                    scale_bytes=8.0 * (ncomp + 1) * g * out[5])
+
     @staticmethod
     def _factors(dm, mo_coeff, mo_occ):
         """(orb (nao, r) C order, signs (r) | None): D = sum_i s_i c_i c_i^T - the tag's occupied orbitals scaled by sqrt(occ)

@@ -408,6 +408,15 @@ def test_foreign_tag_that_does_not_match_its_matrix(h2o):
     vj1, _ = ref.get_jk(cderi, other, 1)
     vj, vk = obj.get_jk(lib.tag_array(other, mo_coeff=c, mo_occ=occ), hermi=1)
     assert np.abs(vj - vj1).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11
+    # this package's OWN tag (make_rdm1: dm_from_orbitals) edited in place keeps its attributes: the probe - r05: on the
+    # host, every 16th row for the own tag, beside the queued kernels, no upload of the matrix - still catches it
+    own = lib.tag_array(dm.copy(), mo_coeff=c, mo_occ=occ, dm_from_orbitals=True)
+    vj, vk = obj.get_jk(own, hermi=1)
+    assert obj._last_fused and np.abs(vj - vj0).max() < 1e-11
+    own *= 0.5
+    assert getattr(own, 'dm_from_orbitals', False)
+    vj, vk = obj.get_jk(own, hermi=1)
+    assert np.abs(vj - 0.5 * vj0).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11
 
 
 def test_second_j_pass_schedules(h2o):
