@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--k-square', default='auto', choices=['auto', 'off'], help="'off': no unpacked image - the K half transform "
                     "reads the packed rows (+ the diagonal-block side image, 14 %% of the tensor): what a rank without 2x the "
                     "tensor size of spare HBM runs")
-    ap.add_argument('--j2-policy', default='auto', choices=['auto', 'overlap', 'serial'], help='second J pass beside the SYRK on a '
+    ap.add_argument('--j2-policy', default='auto', choices=['auto', 'overlap', 'serial', 'fused'], help='second J pass beside the SYRK on a '
                     'side stream, or in line before a re-tiled SYRK; auto: both timed once in the first (warm-up) build')
     ap.add_argument('--syrk-flags', type=int, default=-1, help='override DF.k_syrk_flags (A/B runs): 0 plain, 12 re-tiled + balanced')
     ap.add_argument('--single-process', action='store_true', help='N GPUs from ONE process through the C handle (PAMD_df_create_multi: '
@@ -267,6 +267,12 @@ def main():
                  'comm_ms_per_step': round(comm_ms / max(args.steps, 1), 4) if grouped else None,
                  'bytes_per_step': int(comm_bytes / max(args.steps, 1)),
                  'what': '[J~ || K] packed f64 all-reduce (2 nao_pair doubles per density), HIP events on the launch stream'}
+    if grouped and ctimer.records and comm_ms > 0:
+        # algorithm bandwidth = message / time; bus bandwidth = what a ring moves over every link, 2 (N - 1) / N x that (the RCCL
+        # convention); the yardstick: 7 xGMI links x ~153 GB/s per GPU, point to point - a ring is bound by ONE link per hop
+        algbw = comm_bytes / (comm_ms * 1e-3) / 1e9
+        comm_info.update({'algorithm_GBs': round(algbw, 2), 'bus_GBs': round(algbw * 2.0 * (world - 1) / max(world, 1), 2),
+                          'xgmi_link_peak_GBs': 153.0, 'xgmi_links_per_gpu': 7})
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

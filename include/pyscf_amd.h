@@ -213,6 +213,11 @@ int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, lo
 int PAMD_dgemm_tn(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc, int m,
                   int n, long k, int lower_only, int nsplit, void *stream); /* C[s] += A^T B (k split s) */
 /* screened GEMM (VXCdot_ao_ao_sparse role): maskA[k/16][m/128], maskB[k/16][n/128] bytes, operands as flag 2 */
+/* r05: the SYRK of PAMD_dgemm_tn (A = B = X, lower triangle, re-tiled) with the second J pass of the same tensor rows folded into
+ * the kernel: d_vj[pq] += sum_L d_rho[L] d_B[L][pq] (pyscf/df/df_jk.py:367 and :380 in one launch).  Returns 1 (nothing launched)
+ * when the shape has no fused form. */
+int PAMD_syrk_jfused(const double *d_X, int ldx, double *d_C, int ldc, int m, long k, int flags, int nsplit, const double *d_B,
+                     long npair, int nb, const double *d_rho, double *d_vj, void *stream);
 int PAMD_dgemm_tn_masked(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc, int m,
                          int n, long k, int nsplit, const unsigned char *d_maskA, const unsigned char *d_maskB,
                          void *stream);

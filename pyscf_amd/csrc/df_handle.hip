@@ -938,7 +938,8 @@ struct OrbSet {                            // one density's occupied orbitals on
 // flags bit 0: the caller guarantees dm[s] = orbo_s orbo_s^T (what make_rdm1 builds) - the first J pass then comes out of the
 //      half transform's epilogue instead of a pass over the tensor.
 // vj, vk caller-owned [nset][nao][nao] (NULL with with_j / with_k = 0).
-// serial_j2: the second J pass of the fused path in line before a re-tiled SYRK (1) or on the side stream beside a plain one (0)
+// serial_j2: the second J pass of the fused path in line before a re-tiled SYRK (1), on the side stream beside a plain one (0), or -
+// r05 - inside the re-tiled SYRK kernel itself (2: PAMD_syrk_jfused; shapes without a fused form fall back to 1)
 // download = 0: the results stay on the device (work spaces "vjtril": packed J~ [nset][npair], "vk": [nset][nao][nao]) for the
 //      multi-device reduction; the stream is synchronised either way.
 // Rows in host memory (out-of-core shard) arrive block by block in two staging buffers, the copy of block b + 1 under the kernels
@@ -1020,7 +1021,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
         // df_jk.syrk_plan: re-tiled triangle + balanced k split when the matrix has an odd number of 64-column blocks
         const int nb64 = (nao + 63) / 64;
         // beside a co-running J pass 2 the balanced schedule leaves SYRK_RESERVE of the 512 workgroup slots to the pass (df_jk._vk_mo)
-        const int reserve = (fused && !serial_j2) ? SYRK_RESERVE : 0;
+        const int reserve = (fused && serial_j2 == 0) ? SYRK_RESERVE : 0;
         if (orbo && nb64 % 2 == 1 && nb64 >= 5) {
             const int ntl = nb64 / 2, units = ntl * (ntl - 1) / 2 + ntl + (ntl + 2) / 3;
             double best = 0;
@@ -1157,7 +1158,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                                                   sg.diag ? sg.diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st);
                     if (rc) return rc;
                     mark(1);
-                    if (fused) {
+                    if (fused && serial_j2 != 2) {
                         // second J pass of this block: in line, or on the side stream beside the block's SYRK (HBM- beside MFMA-bound)
                         if (serial_j2) {
                             if ((rc = PAMD_df_vj_pass2(sub, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, st))) return rc;
@@ -1172,7 +1173,19 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                     const long kx = (long)nb * xr, kx16 = round_up(kx, 16);
                     if (kx16 > kx) { PAMD_CHECK_HIP(hipMemsetAsync(d_X + (size_t)kx * ldx, 0, (size_t)(kx16 - kx) * ldx * 8, st)); }
                     mark(2);
-                    if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, part_s, nao, nao, nao, kx16, syrk_flags, nsplit, st))) return rc;
+                    if (fused && serial_j2 == 2) {
+                        // r05: the second J pass of these rows INSIDE the SYRK kernel (PAMD_syrk_jfused); 1 = no fused form for the
+                        // shape, nothing launched: the pass in line, then the plain SYRK
+                        rc = PAMD_syrk_jfused(d_X, ldx, part_s, nao, nao, kx16, syrk_flags, nsplit, sub, npair, nb, rho_b,
+                                              d_vjt + (size_t)s * npair, st);
+                        if (rc < 0) return rc;
+                        if (rc == 1) {
+                            if ((rc = PAMD_df_vj_pass2(sub, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, st))) return rc;
+                            if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, part_s, nao, nao, nao, kx16, syrk_flags, nsplit, st))) return rc;
+                        }
+                        PAMD_CHECK_HIP(hipEventRecord(h->ev_j, st));
+                        j_on_st = true;
+                    } else if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, part_s, nao, nao, nao, kx16, syrk_flags, nsplit, st))) return rc;
                     mark(3);
                 }
             } else {
@@ -1230,7 +1243,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
             if ((rc = PAMD_unpack_tril(d_vjt, npair, nset, nao, d_vjfull, nao, nao, h->side))) return rc;
             PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vjfull, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h->side));
         }
-    } else if (fused && !serial_j2) {
+    } else if (fused && serial_j2 == 0) {
         PAMD_CHECK_HIP(hipEventRecord(h->ev, h->side));
         PAMD_CHECK_HIP(hipStreamWaitEvent(st, h->ev, 0));
     }
@@ -1248,8 +1261,9 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
 }
 
 // Schedule of the second J pass on the fused path (DF.j2_policy of the Python layer): which of the two is faster depends on the
-// shape (config 3: overlapped, taxol on one GPU: in line), so a tensor of 4 GB and more gets both timed once per (nset, occupied
-// count) - two extra builds at the first call - and the choice is kept in the handle.  PAMD_DF_J2 = overlap | serial overrides.
+// shape (config 3: overlapped, taxol on one GPU: in line or - r05 - inside the SYRK kernel), so a tensor of 4 GB and more gets all
+// three timed once per (nset, occupied count) - three extra builds at the first call - and the choice is kept in the handle.
+// PAMD_DF_J2 = overlap | serial | fused overrides.
 static int shard_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
                         int with_k, int flags, double *vj, double *vk, int download)
 {
@@ -1257,21 +1271,23 @@ static int shard_get_jk(PAMD_df *h, const double *dm, const double *orbo, const 
     int serial = 0;
     if (fused && h->n_res == h->nL) {
         const char *env = getenv("PAMD_DF_J2");
-        if (env && (env[0] == 's' || env[0] == 'o')) {
-            serial = env[0] == 's';
+        if (env && (env[0] == 's' || env[0] == 'o' || env[0] == 'f')) {
+            serial = env[0] == 's' ? 1 : (env[0] == 'f' ? 2 : 0);
         } else if ((size_t)h->nL * (size_t)h->npair * 8 >= (4ul << 30) && nocc) {
             long key = nset;
             for (int s = 0; s < nset; s++) key = key * 4099 + nocc[s];
             auto it = h->j2_policy.find(key);
             if (it == h->j2_policy.end()) {
-                double ms[2] = {0, 0};
-                for (int trial = 0; trial < 3; trial++) {             // overlap (priming, untimed), overlap, serial
+                double ms[3] = {0, 0, 0};
+                for (int trial = 0; trial < 4; trial++) {             // overlap (priming, untimed), overlap, serial, fused into the SYRK
                     const auto t0 = std::chrono::steady_clock::now();
-                    const int rc = df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, trial == 2, download);
+                    const int rc = df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, trial ? trial - 1 : 0, download);
                     if (rc) return rc;
                     if (trial) ms[trial - 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 }
-                it = h->j2_policy.emplace(key, ms[1] < 0.99 * ms[0] ? 1 : 0).first;
+                int best = ms[1] < 0.99 * ms[0] ? 1 : 0;
+                if (ms[2] < 0.99 * ms[best]) best = 2;
+                it = h->j2_policy.emplace(key, best).first;
             }
             serial = it->second;
         }

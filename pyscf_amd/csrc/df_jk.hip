@@ -1208,10 +1208,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
 //   * diagonal tile I + one block of the odd last block row r:  slots {2I, 2I+1, r}: (2I,2I), (2I+1,2I), (2I+1,2I+1), (r,2I)
 //   * the other blocks of row r three at a time: slots {r, c1, c2, c3}: (r,c1), (r,c2), (r,c3) [+ the corner (r,r)]
 // 110 items with 435 live blocks instead of 120 tiles at nao = 1856.  k loop, DMA scheme and epilogue as gemm_tn_glds2.
-template <int PROBE>                  // PROBE = 1: benchmarking probe, skips the "B" DMA of every k-row (half the L2 -> LDS traffic, wrong results)
+// r05 - the second J pass INSIDE the SYRK ("one kernel with a fixed issue order" instead of two kernels that
+// share the CUs).  The packed tensor rows of the block, B[nb][npair], are cut into row-loads (one aux row x 512 consecutive packed
+// columns = 16 bytes per lane of the workgroup); the row-loads are dealt to the workgroups in dispatch order in proportion to the
+// k-tiles each one works through (JStream), every k-tile issues its share (<= 4, one per MFMA group) as plain global loads into
+// registers and folds the loads of the PREVIOUS k-tile (landed by the s_waitcnt at the top of the tile) into two accumulators per
+// lane: vj[col] += rho[L] * B[L][col].  A workgroup walks down the aux rows of a 512-column chunk and adds its partial sum into vj
+// (atomic: two workgroups may share a chunk) when the chunk ends.
+struct JStream {
+    const double *B;        // packed rows of this K block [nb][npair]
+    const double *rho;      // [nb] first-pass result of the same rows
+    double *vj;             // [npair], accumulated
+    long npair;
+    int nb;
+    long total_steps;       // k-tiles of ALL workgroups of the launch (nitems x sum over the splits)
+    long total_rows;        // row-loads: ceil(npair / 512) * nb
+};
+
+template <int PROBE, bool JF>         // PROBE = 1: benchmarking probe, skips the "B" DMA of every k-row (half the L2 -> LDS traffic, wrong results)
 __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
     const double *__restrict__ A, int lda, double *__restrict__ C, int ldc, int m, long kdim, const int *__restrict__ items,
-    long kchunk, int prio)
+    long kchunk, int prio, JStream js)
 {
     if (prio) __builtin_amdgcn_s_setprio(3);
     const int bsplit = blockIdx.y;
@@ -1249,9 +1266,93 @@ __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
         dma_row(r_a, dst + k * LDN, voff_a, (k0 + k) * lda8);
         if (PROBE == 0) dma_row(r_a, dst + PA + k * LDN, voff_b, (k0 + k) * lda8);
     };
+    // ---- fused second J pass (JF): this workgroup's run of row-loads, dealt in dispatch order by k-tile count.  All of this
+    // state is wave-uniform; it is pinned to SGPRs with readfirstlane so that rho[L] is a scalar load and the row-load guards are
+    // scalar branches
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+    int j_left = 0;                               // row-loads of the run not issued yet
+    int j_c = 0, j_L = 0;                         // 512-column chunk and aux row of the next row-load
+    int j_q = 0, j_rem = 0, j_bres = 0, j_steps = 1;   // row-loads per k-tile: j_q (+ 1 when the Bresenham remainder rolls over)
+    double2_t jv[4];                              // loads of the previous k-tile
+    double jrho[4] = {0, 0, 0, 0};
+    int jch[4] = {0, 0, 0, 0};
+    int jpend = 0;
+    double2_t jacc = double2_t{0, 0};
+    int jacc_c = -1;
+    const long jcol0 = (long)tid * 2;
+    if (JF) {
+        const int nsp = (int)gridDim.y;
+        long before = 0, mine = 0;
+        for (int y = 0; y < nsp; y++) {
+            long kb = (long)y * kchunk;
+            if (kb > kdim) kb = kdim;
+            const long ke = (kb + kchunk < kdim && y + 1 < nsp) ? kb + kchunk : kdim;
+            const long st_y = (ke - kb + KB - 1) / KB;
+            if (y < bsplit) before += st_y * (long)gridDim.x;
+            if (y == bsplit) mine = st_y;
+        }
+        const long base = before + (long)blockIdx.x * mine;
+        const long r0 = base * js.total_rows / js.total_steps;
+        const long r1 = (base + mine) * js.total_rows / js.total_steps;
+        j_c = UNI((int)(r0 / js.nb));
+        j_L = UNI((int)(r0 - (long)j_c * js.nb));
+        j_left = UNI((int)(r1 - r0));
+        j_steps = UNI(mine > 0 ? (int)mine : 1);
+        j_q = UNI(j_left / j_steps);
+        j_rem = UNI(j_left - j_q * j_steps);
+#pragma unroll
+        for (int u = 0; u < 4; u++) jv[u] = double2_t{0, 0};
+    }
+    auto j_flush = [&]() {
+        if (jacc_c >= 0) {
+            const long col = (long)jacc_c * 512 + jcol0;
+            if (col < js.npair) {
+                unsafeAtomicAdd(js.vj + col, jacc[0]);
+                unsafeAtomicAdd(js.vj + col + 1, jacc[1]);
+            }
+        }
+        jacc = double2_t{0, 0};
+    };
+    auto j_consume = [&]() {                       // the previous k-tile's loads have landed (s_waitcnt vmcnt(0) at the top of the tile)
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (u < jpend) {
+                if (jch[u] != jacc_c) { j_flush(); jacc_c = jch[u]; }
+                jacc[0] += jrho[u] * jv[u][0];
+                jacc[1] += jrho[u] * jv[u][1];
+            }
+        jpend = 0;
+    };
+    int j_quota = 0;
+    auto j_begin_step = [&]() {
+        j_consume();
+        int qn = j_q;
+        j_bres += j_rem;
+        if (j_bres >= j_steps) { j_bres -= j_steps; qn++; }
+        if (qn > 4) qn = 4;                        // (the launcher only fuses shapes with <= 4 row-loads per k-tile; the tail loop takes the rest)
+        if (qn > j_left) qn = j_left;
+        j_quota = UNI(qn);
+        j_bres = UNI(j_bres);
+    };
+    auto j_issue = [&](int u) {                    // one row-load per MFMA group
+        if (u < j_quota) {
+            const long col = (long)j_c * 512 + jcol0;
+            jv[u] = col < js.npair ? __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(js.B + (long)j_L * js.npair + col))
+                                   : double2_t{0, 0};
+            jrho[u] = js.rho[j_L];
+            jch[u] = j_c;
+            jpend = u + 1;
+            j_left = UNI(j_left - 1);
+            const int ln = j_L + 1;
+            const bool wrap = ln == js.nb;
+            j_L = UNI(wrap ? 0 : ln);
+            j_c = UNI(wrap ? j_c + 1 : j_c);
+        }
+    };
     auto step = [&](const double *cur, double *nxt, int k0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (JF) j_begin_step();
         const int kn = (k0 + KB < nk) ? k0 + KB : k0;
 #pragma unroll
         for (int kk = 0; kk < KB; kk += 4) {
@@ -1261,6 +1362,7 @@ __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
 #pragma unroll
             for (int b = 0; b < 4; b++) bf[b] = cur[offb + kk * LDN + b * 16];
             stage_row(kn, nxt, kk >> 2);
+            if (JF) j_issue(kk >> 2);
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -1270,10 +1372,33 @@ __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
     auto step_idle = [&](double *nxt, int k0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (JF) j_begin_step();
         const int kn = (k0 + KB < nk) ? k0 + KB : k0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) stage_row(kn, nxt, j);
+        for (int j = 0; j < 4; j++) {
+            stage_row(kn, nxt, j);
+            if (JF) j_issue(j);
+        }
     };
+    auto j_finish = [&]() {                        // loads still pending, row-loads the k-tiles did not get to, the last partial sum
+        if (!JF) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        j_consume();
+        while (j_left > 0) {
+            const long col = (long)j_c * 512 + jcol0;
+            if (j_c != jacc_c) { j_flush(); jacc_c = j_c; }
+            if (col < js.npair) {
+                const double2_t b = *reinterpret_cast<const double2_t *>(js.B + (long)j_L * js.npair + col);
+                const double r = js.rho[j_L];
+                jacc[0] += r * b[0];
+                jacc[1] += r * b[1];
+            }
+            j_left--;
+            if (++j_L == js.nb) { j_L = 0; j_c++; }
+        }
+        j_flush();
+    };
+#undef UNI
     if (nk > 0) {
 #pragma unroll
         for (int j = 0; j < 4; j++) stage_row(0, sb0, j);
@@ -1283,12 +1408,14 @@ __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
             step(sb0, sb1, k0);
             if (k0 + KB < nk) step(sb1, sb0, k0 + KB);
         }
+        j_finish();
     } else {
         for (int k0 = 0; k0 < nk; k0 += 2 * KB) {
             step_idle(sb1, k0);
             if (k0 + KB < nk) step_idle(sb0, k0 + KB);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        j_finish();
         return;
     }
     double *out = C + (long)bsplit * m * ldc;
@@ -1879,7 +2006,7 @@ static int syrk_items(int m, const int **d_items, int *nitems)
 
 static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc,
                          int m, int n, long k, int lower_only, int nsplit, const unsigned char *d_maskA,
-                         const unsigned char *d_maskB, void *stream)
+                         const unsigned char *d_maskB, void *stream, JStream *js = nullptr)
 {
     PAMD_REQUIRE(nsplit >= 1, "nsplit >= 1");
     PAMD_REQUIRE(!(lower_only & 1) || m == n, "lower_only needs a square result");
@@ -1928,12 +2055,34 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
         if (rc) return rc;
         if (nitems > 0) {
             dim3 g2(nitems, nsplit);
-            if (g_syrk_probe) syrk_slots_kernel<1><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems), g_mfma_prio);
-            else syrk_slots_kernel<0><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, balanced_chunk(nitems), g_mfma_prio);
+            const long kc = balanced_chunk(nitems);
+            if (js) {
+                // k-tiles of the whole launch, exactly as the kernel counts them; fuse only when a k-tile has room for its share
+                long steps = 0;
+                for (int y = 0; y < nsplit; y++) {
+                    long kb = (long)y * kc;
+                    if (kb > k) kb = k;
+                    const long ke = (kb + kc < k && y + 1 < nsplit) ? kb + kc : k;
+                    steps += (ke - kb + KB - 1) / KB;
+                }
+                js->total_steps = steps * nitems;
+                js->total_rows = ceil_div(js->npair, 512L) * js->nb;
+                if (js->total_steps <= 0 || js->npair % 2 || ((uintptr_t)js->B % 16) ||
+                    (double)js->total_rows > 3.9 * (double)js->total_steps)
+                    return 1;                                  // not a shape for the fused pass: the caller runs the pass by itself
+                syrk_slots_kernel<0, true><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, *js);
+                PAMD_CHECK_LAUNCH();
+                return 0;
+            }
+            JStream none;
+            memset(&none, 0, sizeof(none));
+            if (g_syrk_probe) syrk_slots_kernel<1, false><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, none);
+            else syrk_slots_kernel<0, false><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, none);
             PAMD_CHECK_LAUNCH();
             return 0;
         }
     }
+    if (js) return 1;                                          // no re-tiled SYRK for this shape: nothing launched
     if (v2) {
         if (lower_only & 1) kchunk = balanced_chunk(ntiles);
         gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio);
@@ -1963,6 +2112,25 @@ int PAMD_dgemm_tn(const double *d_A, int lda, const double *d_B, int ldb, double
 // Screened variant (numint._dot_ao_ao_sparse, pyscf/dft/numint.py:836-874 / VXCdot_ao_ao_sparse):
 // d_maskA[ceil(k/16)][ceil(m/128)], d_maskB[ceil(k/16)][ceil(n/128)] bytes; a k-tile is skipped for an output
 // tile when either panel tile is flagged 0.  Requires the aligned-operand contract of flag 2.
+// r05: K[split] += X^T X (the re-tiled SYRK of PAMD_dgemm_tn, flags as there) WITH the second J pass of the same tensor rows inside
+// the kernel: d_vj[pq] += sum_L d_rho[L] d_B[L][pq] for the nb packed rows d_B (syrk_slots_kernel<JF>).  Returns 0 when the fused
+// kernel ran, 1 when the shape has no fused form (no re-tiled triangle, odd nao_pair, more than ~4 row-loads per k-tile): NOTHING
+// was launched then and the caller issues PAMD_df_vj_pass2 + PAMD_dgemm_tn itself.  Replaces the pair `vj += rho . eri1` /
+// `vk += lib.dot(buf1.T, buf1)` of pyscf/df/df_jk.py:367,380 by one launch.
+int PAMD_syrk_jfused(const double *d_X, int ldx, double *d_C, int ldc, int m, long k, int flags, int nsplit, const double *d_B,
+                     long npair, int nb, const double *d_rho, double *d_vj, void *stream)
+{
+    PAMD_REQUIRE(d_X && d_C && d_B && d_rho && d_vj && nb > 0 && npair > 0, "PAMD_syrk_jfused: bad arguments");
+    JStream js;
+    memset(&js, 0, sizeof(js));
+    js.B = d_B;
+    js.rho = d_rho;
+    js.vj = d_vj;
+    js.npair = npair;
+    js.nb = nb;
+    return dgemm_tn_impl(d_X, ldx, d_X, ldx, d_C, ldc, m, m, k, flags, nsplit, nullptr, nullptr, stream, &js);
+}
+
 int PAMD_dgemm_tn_masked(const double *d_A, int lda, const double *d_B, int ldb, double *d_C, int ldc,
                          int m, int n, long k, int nsplit, const unsigned char *d_maskA,
                          const unsigned char *d_maskB, void *stream)

@@ -15,6 +15,17 @@ import numpy as np
 from . import addons, df_jk
 
 
+def _mol_nao(mol):
+    """AO count of any molecule-like object: a Mole of this package or of stock PySCF, or a bare holder of libcint tables
+    (spherical functions: sum over shells of (2 l + 1) nctr, pyscf/gto/mole.py ao_loc_nr)."""
+    if hasattr(mol, 'nao_nr'):
+        return int(mol.nao_nr())
+    if hasattr(mol, 'nao'):
+        return int(mol.nao)
+    bas = np.asarray(mol._bas)
+    return int(((2 * bas[:, 1] + 1) * bas[:, 3]).sum())
+
+
 class DF:
     blockdim = 240     # pyscf/df/df.py:95
 
@@ -33,9 +44,10 @@ class DF:
         self.group = group
         # HBM budget for the half-transformed block X (MI355X: 288 GB per GPU)
         self.k_block_bytes = 12 << 30      # X block: config 3 in ONE block (10.6 GB; one kernel boundary less per step, -0.5 %)
-        self.j2_policy = 'auto'    # second J pass 'overlap' (side stream, beside a plain SYRK) | 'serial' (in line, re-tiled SYRK) |
+        self.j2_policy = 'auto'    # second J pass 'overlap' (side stream, beside a plain SYRK) | 'serial' (in line, re-tiled SYRK) | 'fused' (r05: inside the SYRK kernel) |
                                    # 'auto': both timed once per shape (df_jk.get_jk_device)
         self.j2_tune_min_bytes = 4 << 30
+        self.j2_try_fused = True   # 'auto' also times the pass INSIDE the SYRK kernel (PAMD_syrk_jfused, r05) and takes it when >= 1 % faster
         self.k_e2_pipeline = 1     # sub-blocks of a K block whose half transforms are queued back to back (df_jk._vk_mo)
         self.k_nsplit = None       # k-splits of the K = X^T X product; None: df_jk.syrk_plan picks tile shape and splits
         self.k_syrk_reserve = 16   # > 0: beside a co-running J pass 2 the balanced re-tiled SYRK, sized to leave that many of the
@@ -282,7 +294,7 @@ class DF:
                     blocks = f.column_blocks('j3c') or [f['j3c']]
                     naux = blocks[0].shape[0]
                     ncol = sum(b.shape[1] for b in blocks)
-                    nao = self.mol.nao_nr() if hasattr(self.mol, 'nao_nr') else self.mol.nao
+                    nao = _mol_nao(self.mol)
                     if any(len(b.shape) != 2 or b.shape[0] != naux for b in blocks) or ncol != nao * (nao + 1) // 2:
                         raise RuntimeError("%s: 'j3c' holds %d columns, expected nao_pair = %d for nao = %d (s2-packed (naux, "
                                            "nao_pair) tensor, pyscf/df/df.py:59-72)" % (self._cderi, ncol, nao * (nao + 1) // 2, nao))
@@ -343,7 +355,7 @@ class DF:
             # cholesky_eri_gpu ahead of its own memory check and once more inside the C handle)
             if not self.would_fit():
                 raise MemoryError('DF tensor shard of %d x %d doubles does not fit %s' % (
-                    l1 - l0, self.mol.nao * (self.mol.nao + 1) // 2,
+                    l1 - l0, _mol_nao(self.mol) * (_mol_nao(self.mol) + 1) // 2,
                     'DF.outcore_device_bytes' if self.outcore_device_bytes else 'the free device memory'))
             self._cderi_dev = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1,
                                                       lindep=self.lindep, omega=self.omega,
@@ -405,7 +417,7 @@ class DF:
         if self.auxmol is None:
             self.auxmol = addons.make_auxmol(self.mol, self.auxbasis)
         naux = self.auxmol.nao_nr()
-        nao = self.mol.nao_nr() if hasattr(self.mol, 'nao_nr') else self.mol.nao
+        nao = _mol_nao(self.mol)
         npair = nao * (nao + 1) // 2
         l0, l1 = self.shard_range(naux, self.rank, self.world_size)
         shard_b = (l1 - l0) * npair * 8
@@ -648,8 +660,6 @@ class DF:
     def get_jk(self, dm, hermi=1, with_j=True, with_k=True, direct_scf_tol=1e-13, omega=None):
         if omega is not None and omega != 0:
             return self.range_coulomb(omega).get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
-        if self._cderi_dev is None and getattr(self, '_native', None) is None:
-            self.build()
         if getattr(self, '_native', None) is not None:          # out of core: the C handle holds the tensor (build())
             vj, vk = self._native.get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
             if self._native.shard is not None:

@@ -216,7 +216,7 @@ def pad_orbitals(orbo, device):
     return orb, (nocc_pad if nocc else 0), ldo
 
 
-def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True):
+def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True, j_fused=None):
     """K_pq = sum_{L,i} X[L,i,p] X[L,i,q],  X[L,i,p] = sum_q B_L[p,q] orbo[q,i]
     (df_jk.py:353-380; nr_ao2mo.c:399-419,1240-1266).  orb_list: [(orb_dev, nocc_pad, ldo)]."""
     torch = _torch()
@@ -227,6 +227,8 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True):
     ldx = _round_up(nao, 16)
     kflags = getattr(dfobj, 'k_syrk_flags', None)
     reserve = 0
+    if j_fused is not None:
+        j_corun = False                      # r05: the second J pass rides INSIDE the SYRK kernel (PAMD_syrk_jfused): full balanced grid
     if kflags is None and after_e2 is not None and j_corun:
         # the second J pass runs beside this SYRK on the side stream: it hides in the 32 workgroup slots the plain 120 x 4 grid
         # leaves idle (J/K 108.8 ms) but not beside the balanced schedule that fills them (110.0 ms; K alone: 35.6 vs 39.7 ms): the
@@ -281,12 +283,29 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True):
                     _e2_packed(dfobj, lib, s0, ns, nao, orb, ldo, xr, xs, ldx,
                                _ptr(fuse_j[iset][s0:]) if fuse_j is not None else None,
                                _rho_work(dfobj, lib, ns, ldx, nocc_pad) if fuse_j is not None else None, st)
-                if after_e2 is not None:
+                if after_e2 is not None and j_fused is None:
                     after_e2(s0, ns, iset)
             kx = nb * xr
             kx16 = _round_up(kx, 16)
             if kx16 > kx:
                 X[kx:kx16].zero_()
+            if j_fused is not None:
+                # vj[pq] += sum_L rho[L] B[L][pq] for the rows [b0, b1) inside the SYRK kernel of the same rows; 1 = no fused form for
+                # this shape (nothing launched): the pass in line, then the plain call
+                vj_f = j_fused
+                box = {}
+
+                def fused_call(*a):
+                    box['rc'] = lib.PAMD_syrk_jfused(*a)
+                    return 0 if box['rc'] == 1 else box['rc']
+                _call(dfobj, 'dgemm_tn', fused_call, _ptr(X), _c.c_int(ldx), _ptr(part), _c.c_int(nao), _c.c_int(nao),
+                      _c.c_long(kx16), _c.c_int(syrk_flags), _c.c_int(nsplit), _ptr(cderi[b0:b1]), _c.c_long(npair),
+                      _c.c_int(nb), _ptr(fuse_j[iset][b0:]), _ptr(vj_f[iset]), st)
+                rc = box['rc']
+                if rc == 0:
+                    continue
+                _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(cderi[b0:b1]), _c.c_long(npair), _c.c_int(nb),
+                      _ptr(fuse_j[iset][b0:]), _c.c_int(1), _ptr(vj_f[iset]), st)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
                   _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(kx16), _c.c_int(syrk_flags),
                   _c.c_int(nsplit), st)
@@ -596,6 +615,9 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                     def run_fused(serial):
                         rho_f = torch.zeros((nset, naux_l), dtype=torch.float64, device=dms_dev.device)
                         vj_f = torch.zeros((nset, npair_l), dtype=torch.float64, device=dms_dev.device)
+                        if serial == 'fused':                       # r05: second pass inside the SYRK kernel (PAMD_syrk_jfused)
+                            vk = _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=rho_f, j_fused=vj_f)
+                            return vj_f, vk
 
                         def pass2_block(b0, nb, iset):
                             if serial:
@@ -625,19 +647,22 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                             timer, dfobj.kernel_timer = getattr(dfobj, 'kernel_timer', None), None
                             run_fused(False)                                     # priming: lazy images, workspaces
                             times = {}
-                            for name in ('overlap', 'serial'):
+                            for name in ('overlap', 'serial') + (('fused',) if getattr(dfobj, 'j2_try_fused', False) else ()):
                                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                                 torch.cuda.current_stream().wait_stream(side)
                                 e0.record()
-                                run_fused(name == 'serial')
+                                run_fused('fused' if name == 'fused' else name == 'serial')
                                 torch.cuda.current_stream().wait_stream(side)
                                 e1.record()
                                 e1.synchronize()
                                 times[name] = e0.elapsed_time(e1)
-                            policy = cache[key] = 'serial' if times['serial'] < 0.99 * times['overlap'] else 'overlap'
+                            policy = 'serial' if times['serial'] < 0.99 * times['overlap'] else 'overlap'
+                            if 'fused' in times and times['fused'] < 0.99 * times[policy]:
+                                policy = 'fused'
+                            cache[key] = policy
                             dfobj._j2_policy_times = dict(times, chosen=policy)
                             dfobj.kernel_timer = timer
-                    holder['vj'], vk_dev = run_fused(policy == 'serial')
+                    holder['vj'], vk_dev = run_fused('fused' if policy == 'fused' else policy == 'serial')
 
                 def launch_j(*_a):
                     if 'vj' in holder:
@@ -683,8 +708,9 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
     if dfobj._cderi_dev is None and getattr(dfobj, '_native', None) is None:
         dfobj.build()
     if getattr(dfobj, '_native', None) is not None:
-        # the tensor did not fit the device: the C handle holds it (HBM + page-locked host rows, DF.build) and answers
-        return dfobj._native.get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
+        # the tensor did not fit the device: the C handle holds it (HBM + page-locked host rows, DF.build) and answers - through
+        # DF.get_jk, which sums a rank's partial result over the ranks
+        return dfobj.get_jk(dm, hermi, with_j, with_k, direct_scf_tol)
     dms = np.asarray(dm)
     if np.iscomplexobj(dms):
         # real/imag split, as _DFHF.get_jk does for complex DMs (df_jk.py:160-171)

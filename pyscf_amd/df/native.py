@@ -202,7 +202,8 @@ class NativeDF:
         rows = np.asarray(rows) if not isinstance(rows, np.memmap) else rows
         if rows.dtype != np.float64 or rows.ndim != 2 or not rows.flags.c_contiguous:
             raise ValueError('from_rows: a C-contiguous float64 (nrows, nao_pair) array')
-        nao = mol.nao_nr() if hasattr(mol, 'nao_nr') else mol.nao
+        from .df import _mol_nao                       # (host-only helper; importing the module pulls in no torch)
+        nao = _mol_nao(mol)
         if rows.shape[1] != nao * (nao + 1) // 2:
             raise ValueError('from_rows: %d columns, expected nao_pair = %d' % (rows.shape[1], nao * (nao + 1) // 2))
         self = cls(mol, device=device, max_device_bytes=max_device_bytes, shard=shard)

@@ -39,7 +39,7 @@ def test_bench_gpus2_launches_two_ranks():
     assert one['unit'] == 'ms' and abs(one['value'] - one['ms_per_step']) < 1e-9 and 'workload' in one['config']
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(one['roofline'])
     assert abs(one['roofline']['frac'] - one['roofline']['achieved'] / one['roofline']['peak']) < 1e-3
-    assert one['jk_schedule']['chosen'] in ('overlap', 'serial', 'auto')
+    assert one['jk_schedule']['chosen'] in ('overlap', 'serial', 'fused', 'auto')
     # the roofline durations are those of the timed steps (live HIP events), the serial pass is reported beside them
     assert one['roofline']['launches_per_step'] >= 1 and one['kernels_serial_pass'] and 'e2_symm' in one['kernels']
     assert one['kernels']['e2_symm']['ms_total'] < one['ms_per_step']

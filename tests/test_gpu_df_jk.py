@@ -419,6 +419,35 @@ def test_foreign_tag_that_does_not_match_its_matrix(h2o):
     assert np.abs(vj - 0.5 * vj0).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11
 
 
+def test_second_j_pass_inside_the_syrk_kernel():
+    """r05: PAMD_syrk_jfused - the second J pass of a K block folded INTO the re-tiled SYRK kernel of the same
+    rows (syrk_slots_kernel<JF>: row-loads dealt to the workgroups by k-tile count, issued between the MFMA groups).  A shape with a
+    fused form (odd number of 64-column blocks, <= 4 row-loads per k-tile), several K blocks, and a shape without one (falls back
+    to the in-line pass): same J and K as the oracle."""
+    from pyscf_amd import lib
+    from pyscf_amd.df import df_jk
+    for nao, naux, nocc, fused_form in ((300, 96, 120, True), (300, 40, 21, False), (200, 64, 90, False)):
+        rng = np.random.default_rng(21)
+        cderi = rng.standard_normal((naux, nao * (nao + 1) // 2)) / np.sqrt(nao)
+        c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+        occ = np.zeros(nao)
+        occ[:nocc] = 2
+        dm = lib.tag_array((c * occ).dot(c.T), mo_coeff=c, mo_occ=occ)
+        vj0, vk0 = ref.get_jk(cderi, np.asarray(dm), 1, mo_coeff=c, mo_occ=occ)
+        for blocks in (1, 3):
+            obj = _dfobj(None, cderi)
+            obj.j2_policy = 'fused'
+            if blocks > 1:
+                obj.k_block_bytes = -(-naux // blocks) * ((nocc + 15) // 16 * 16) * ((nao + 15) // 16 * 16) * 8
+            obj.kernel_timer = df_jk.KernelTimer()
+            vj, vk = obj.get_jk(dm, hermi=1)
+            names = set(obj.kernel_timer.summary())
+            assert obj._last_fused
+            assert ('vj_pass2' in names) == (not fused_form), (nao, nocc, names)      # the separate pass only where no fused form exists
+            assert np.abs(vj - vj0).max() < 1e-11 * max(1.0, np.abs(vj0).max()), (nao, naux, nocc, blocks)
+            assert np.abs(vk - vk0).max() < 1e-11 * max(1.0, np.abs(vk0).max()), (nao, naux, nocc, blocks)
+
+
 def test_second_j_pass_schedules(h2o):
     """DF.j2_policy: the second J pass on the side stream beside a plain SYRK ('overlap'), in line before the re-tiled SYRK
     ('serial'), or whichever a one-off timing of both finds faster ('auto', tensors above j2_tune_min_bytes): same J and K."""
@@ -442,5 +471,5 @@ def test_second_j_pass_schedules(h2o):
             assert np.abs(vj - vj0).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11, policy
         if policy == 'auto':
             t = obj._j2_policy_times
-            assert t['chosen'] in ('overlap', 'serial') and t['overlap'] > 0 and t['serial'] > 0
+            assert t['chosen'] in ('overlap', 'serial', 'fused') and t['overlap'] > 0 and t['serial'] > 0
             assert list(obj._j2_policy_cache.values()) == [t['chosen']]

@@ -105,6 +105,24 @@ r05b)       # r05: threaded probe + overlapped J download + calibrated CPU basel
   timeout 600 python bench.py --gpus 1 --single-process --steps 10 --xc '' > $O/bench_sp1.json 2> $O/bench_sp1.err; python tools/bench_digest.py $O/bench_sp1.json; tail -3 $O/bench_sp1.err
   timeout 600 python bench.py --gpus 2 --single-process --steps 5 --no-cpu-baseline --xc '' > $O/bench_sp2.json 2> $O/bench_sp2.err; python tools/bench_digest.py $O/bench_sp2.json; tail -3 $O/bench_sp2.err
   timeout 300 python tools/native_bench.py > $O/native_bench.log 2>&1; tail -4 $O/native_bench.log ;;
+jf)         # r05: second J pass inside the SYRK kernel (PAMD_syrk_jfused) - tests, then kbench / bench A/B at config 3 and taxol shape
+  timeout 600 python -m pytest -q -x tests/test_gpu_df_jk.py -m gpu > $O/pytest.log 2>&1; tail -6 $O/pytest.log
+  : > $O/kbench.log
+  for pol in overlap fused serial overlap fused; do
+    echo "== config3 $pol" >> $O/kbench.log
+    timeout 300 python tools/kbench.py --steps 5 --j2-policy $pol --syrk-reserve 16 2>&1 | tail -1 >> $O/kbench.log
+  done
+  for pol in serial fused; do
+    echo "== taxol $pol" >> $O/kbench.log
+    timeout 400 python tools/kbench.py --steps 4 --nao 2228 --naux 5598 --nocc 226 --j2-policy $pol 2>&1 | tail -1 >> $O/kbench.log
+  done
+  cut -c1-420 $O/kbench.log
+  timeout 600 python bench.py --j2-policy fused --no-cpu-baseline --no-pmc --xc '' --steps 10 > $O/bench_fused.json 2> $O/bench_fused.err; python tools/bench_digest.py $O/bench_fused.json; tail -3 $O/bench_fused.err
+  timeout 600 python bench.py --j2-policy overlap --no-cpu-baseline --no-pmc --xc '' --steps 10 > $O/bench_overlap.json 2> $O/bench_overlap.err; python tools/bench_digest.py $O/bench_overlap.json; tail -3 $O/bench_overlap.err ;;
+jf2)        # host API under the fused policy (diagnostic), df_jk tests, taxol bench with the fused policy
+  timeout 600 python -m pytest -q -x tests/test_gpu_df_jk.py -m gpu > $O/pytest.log 2>&1; tail -6 $O/pytest.log
+  for pol in overlap fused; do timeout 300 python tools/host_api_probe.py --j2-policy $pol > $O/host_api_$pol.log 2>&1; grep -E "host API|cumtime|get_jk|_to_host|download|mismatch|dot|synchronize|run_fused|_vk_mo" $O/host_api_$pol.log | head -24; done
+  timeout 900 python bench.py --molecule taxol --j2-policy fused --no-cpu-baseline --no-pmc --xc '' > $O/bench_taxol_fused.json 2> $O/bench_taxol_fused.err; python tools/bench_digest.py $O/bench_taxol_fused.json; tail -3 $O/bench_taxol_fused.err ;;
 evidence)   # the round's measured evidence (everything except the test suite): gpu_job.sh evidence <tag>
   TAG=${1:-r04}
   bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log

@@ -19,7 +19,7 @@ ap.add_argument('--no-overlap', action='store_true')
 ap.add_argument('--no-split', action='store_true')
 ap.add_argument('--no-square', action='store_true')
 ap.add_argument('--e2-pipeline', type=int, default=0)
-ap.add_argument('--j2-policy', default='overlap', choices=['auto', 'overlap', 'serial'])
+ap.add_argument('--j2-policy', default='overlap', choices=['auto', 'overlap', 'serial', 'fused'])
 ap.add_argument('--block-gb', type=float, default=0)
 ap.add_argument('--no-fuse', action='store_true')
 ap.add_argument('--ksplit', type=int, default=0)
@@ -94,4 +94,11 @@ vj_full = torch.zeros((a.nao, a.nao), dtype=torch.float64, device=dev)
 vj_full[idx[0], idx[1]] = vj2[0]
 out['err_vk'] = float((vk2[0] - vk_ref).abs().max() / vk_ref.abs().max())
 out['err_vj'] = float((vj_full.tril() - vj_ref.tril()).abs().max() / vj_ref.abs().max())
+if a.j2_policy == 'fused':
+    # the fused kernel against the in-line schedule on the full tensor
+    obj.kernel_timer = None
+    obj.j2_policy = 'serial'
+    vj_s, vk_s = df_jk.get_jk_device(obj, dms, orb, not a.no_j, True)
+    out['fused_vs_serial_vj'] = float((vj - vj_s).abs().max() / vj_s.abs().max())
+    out['fused_vs_serial_vk'] = float((vk - vk_s).abs().max() / vk_s.abs().max())
 print(json.dumps(out))

@@ -22,7 +22,7 @@ occ = np.zeros(nao)
 occ[:nocc] = 2
 dm = lib.tag_array((c * occ).dot(c.T), mo_coeff=c, mo_occ=occ, dm_from_orbitals=True)
 ref = None
-for sched in ('auto', 'overlap', 'serial'):
+for sched in ('auto', 'overlap', 'serial', 'fused'):
     if sched == 'auto':
         os.environ.pop('PAMD_DF_J2', None)
     else:

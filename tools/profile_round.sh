@@ -7,7 +7,7 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$PWD}
 export TMPDIR=/tmp
 cd /tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --xc b3lyp"
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --xc b3lyp"
 mkdir -p $R/gpurun_out
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -o $TAG -- $B > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_fetch -o $TAG -- $B > $R/gpurun_out/prof_${TAG}_fetch.log 2>&1
