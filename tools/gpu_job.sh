@@ -124,22 +124,19 @@ jf2)        # host API under the fused policy (diagnostic), df_jk tests, taxol b
   for pol in overlap fused; do timeout 300 python tools/host_api_probe.py --j2-policy $pol > $O/host_api_$pol.log 2>&1; grep -E "host API|cumtime|get_jk|_to_host|download|mismatch|dot|synchronize|run_fused|_vk_mo" $O/host_api_$pol.log | head -24; done
   timeout 900 python bench.py --molecule taxol --j2-policy fused --no-cpu-baseline --no-pmc --xc '' > $O/bench_taxol_fused.json 2> $O/bench_taxol_fused.err; python tools/bench_digest.py $O/bench_taxol_fused.json; tail -3 $O/bench_taxol_fused.err ;;
 evidence)   # the round's measured evidence (everything except the test suite): gpu_job.sh evidence <tag>
-  TAG=${1:-r04}
+  TAG=${1:-r05}
   bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log
-  timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench_h2o32_1gpu_steps20.json 2> $O/bench20.err; cut -c1-260 $O/bench_h2o32_1gpu_steps20.json
-  timeout 900 python bench.py --pmc --no-cpu-baseline > $O/bench_h2o32_1gpu_pmc.json 2> $O/bench_pmc.err; cut -c1-200 $O/bench_h2o32_1gpu_pmc.json
-  timeout 600 python bench.py --k-square off --no-cpu-baseline --xc '' > $O/bench_h2o32_1gpu_ksquare_off.json 2> $O/bench_ksq.err; cut -c1-200 $O/bench_h2o32_1gpu_ksquare_off.json
-  timeout 900 python bench.py --molecule taxol --no-cpu-baseline > $O/bench_taxol_1gpu.json 2> $O/bench_taxol.err; cut -c1-200 $O/bench_taxol_1gpu.json
-  timeout 600 python bench.py --gpus 1 --single-process --steps 5 > $O/bench_single_process_1part.json 2> $O/bench_sp1.err; cut -c1-200 $O/bench_single_process_1part.json
-  timeout 600 python bench.py --gpus 2 --single-process --steps 5 > $O/bench_single_process_2parts_1gpu.json 2> $O/bench_sp2.err; cut -c1-200 $O/bench_single_process_2parts_1gpu.json
+  timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench_h2o32_1gpu_steps20.json 2> $O/bench20.err; python tools/bench_digest.py $O/bench_h2o32_1gpu_steps20.json; tail -2 $O/bench20.err
+  timeout 600 python bench.py --k-square off --no-cpu-baseline --no-pmc --xc '' > $O/bench_h2o32_1gpu_ksquare_off.json 2> $O/bench_ksq.err; cut -c1-200 $O/bench_h2o32_1gpu_ksquare_off.json
+  timeout 900 python bench.py --molecule taxol --no-cpu-baseline > $O/bench_taxol_1gpu.json 2> $O/bench_taxol.err; python tools/bench_digest.py $O/bench_taxol_1gpu.json; python -c "import json; d=json.loads(open('$O/bench_taxol_1gpu.json').read().strip().splitlines()[-1]); print('   taxol schedule', d['jk_schedule'])"
+  timeout 600 python bench.py --gpus 1 --single-process --steps 10 > $O/bench_single_process_1part.json 2> $O/bench_sp1.err; python tools/bench_digest.py $O/bench_single_process_1part.json
+  timeout 600 python bench.py --gpus 2 --single-process --steps 5 --no-cpu-baseline > $O/bench_single_process_2parts_1gpu.json 2> $O/bench_sp2.err; python tools/bench_digest.py $O/bench_single_process_2parts_1gpu.json
+  timeout 300 python tools/native_bench.py > $O/native_bench.log 2>&1; tail -5 $O/native_bench.log
+  for pol in overlap; do timeout 300 python tools/host_api_probe.py --j2-policy $pol > $O/host_api_$pol.log 2>&1; grep -E "host API|gc gen" $O/host_api_$pol.log | head -12; done
   timeout 600 python tools/run_scf.py --nwater 32 --xc b3lyp --conv-tol 1e-10 > $O/scf_h2o32_b3lyp.log 2>&1; tail -2 $O/scf_h2o32_b3lyp.log
   timeout 600 python tools/run_scf.py --nwater 32 --xc '' --conv-tol 1e-10 > $O/scf_h2o32_rhf.log 2>&1; tail -1 $O/scf_h2o32_rhf.log
   timeout 600 python tools/run_scf.py --molecule taxol --xc b3lyp --conv-tol 1e-9 > $O/scf_taxol_b3lyp.log 2>&1; tail -1 $O/scf_taxol_b3lyp.log
   timeout 600 python tools/grad_bench.py --nwater 32 > $O/grad_h2o32_rhf.json 2> $O/grad.err; cat $O/grad_h2o32_rhf.json | cut -c1-300
-  : > $O/shard_probe_h2o32_world1_2_4_8.jsonl
-  for w in 1 2 4 8; do timeout 300 python tools/shard_probe.py --nwater 32 --basis cc-pvtz --world $w --rank 0 2>/dev/null | tail -1 >> $O/shard_probe_h2o32_world1_2_4_8.jsonl; done
-  cut -c1-220 $O/shard_probe_h2o32_world1_2_4_8.jsonl
-  timeout 600 python tools/shard_probe.py --nwater 128 --basis cc-pvdz --world 8 --rank 3 2>/dev/null | tail -1 > $O/shard_probe_h2o128_rank3of8.json; cut -c1-300 $O/shard_probe_h2o128_rank3of8.json
   find gpurun_out -name "*.db" -delete ;;
 run)        # arbitrary command line, logged: gpu_job.sh run <tag> <cmd...>
   T=$1; shift; timeout 1500 "$@" > $O/$T.log 2>&1; tail -30 $O/$T.log ;;

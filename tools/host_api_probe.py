@@ -28,9 +28,20 @@ tag = lib.tag_array(dm, mo_coeff=c, mo_occ=occ, **({'dm_from_orbitals': True} if
 for _ in range(2):
     obj.get_jk(tag, hermi=1)
 torch.cuda.synchronize()
-import cProfile, pstats
+import cProfile, pstats, gc
+_g = {}
+
+
+def _gc_cb(phase, info):
+    if phase == 'start':
+        _g['t'] = time.perf_counter()
+    else:
+        print('   gc gen %d: %.1f ms, collected %d' % (info['generation'], (time.perf_counter() - _g['t']) * 1e3, info['collected']), flush=True)
+
+
+gc.callbacks.append(_gc_cb)
 ts = []
-for _ in range(5):
+for _ in range(8):
     t0 = time.perf_counter(); obj.get_jk(tag, hermi=1); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
 print('policy', a.j2_policy, 'own_tag', a.own_tag, 'host API ms per call', [round(t, 1) for t in ts])
 pr = cProfile.Profile(); pr.enable()
