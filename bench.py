@@ -760,6 +760,9 @@ def single_process_main(args):
             gbs_ = xt_['scale_bytes'] / xt_['ms']['scale_ao'] * 1e-6
             xr['scale_ao'] = {'bound': 'hbm', 'bytes': xt_['scale_bytes'], 'ms': round(xt_['ms']['scale_ao'], 3), 'achieved': round(gbs_, 1),
                               'peak': HBM_PEAK_GBS * nd_, 'unit': 'GB/s', 'frac': round(gbs_ / (HBM_PEAK_GBS * nd_), 4)}
+        if nd_ < args.gpus:
+            xr['note'] = ('%d parts share %d device(s) (self-test layout): the executed flops are those of ALL parts, the time is one '
+                          "part's - fractions above are not meaningful here" % (args.gpus, nd_))
         xc_info['kernels_ms'] = {k_: round(v_, 3) for k_, v_ in xt_['ms'].items()}
         xc_info['roofline'] = xr
         ni.reset()
