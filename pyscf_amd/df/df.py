@@ -26,18 +26,6 @@ def _mol_nao(mol):
     return int(((2 * bas[:, 1] + 1) * bas[:, 3]).sum())
 
 
-def _settle_gc():
-    """Once per tensor build: collect, then move what survives (basis tables, grids, the torch runtime: ~1 M container objects)
-    out of the garbage collector's way (`gc.freeze`; the collector stays on).  A generation-2 collection of such a process takes
-    ~50 ms and struck about every eighth J/K call of an SCF loop (r05: `profiles/r05/host_api_overlap.log`) - half a J/K build of
-    host jitter per hit.  PAMD_GC_FREEZE=0 leaves the interpreter alone."""
-    import gc
-    import os
-    if os.environ.get('PAMD_GC_FREEZE', '1') not in ('', '0'):
-        gc.collect()
-        gc.freeze()
-
-
 class DF:
     blockdim = 240     # pyscf/df/df.py:95
 
@@ -392,7 +380,6 @@ class DF:
             self._naux = self._native.get_naoaux()
         if isinstance(self._cderi_to_save, str):
             self.save(self._cderi_to_save)
-        _settle_gc()
         return self
     kernel = build
 

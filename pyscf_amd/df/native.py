@@ -189,12 +189,6 @@ class NativeDF:
         self._naux = info[2]
         _check(load().PAMD_df_nao(h, _c.byref(n)))
         self.nao = n.value
-        if os.environ.get('PAMD_GC_FREEZE', '1') not in ('', '0'):
-            # once per build: a generation-2 collection of the calling process costs ~50 ms about every eighth J/K call (r05);
-            # what exists now (basis tables, the caller's molecule objects) is moved out of the collector's way - it stays enabled
-            import gc
-            gc.collect()
-            gc.freeze()
         return self
     kernel = build
 

@@ -12,6 +12,15 @@ suite)      # whole GPU suite, default bench line, smoke
   timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 800 $O/bench_default.json; tail -3 $O/bench_default.err
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
   timeout 900 python bench.py --molecule taxol --no-cpu-baseline > $O/bench_taxol_1gpu.json 2> $O/bench_taxol.err; cut -c1-240 $O/bench_taxol_1gpu.json; tail -2 $O/bench_taxol.err ;;
+suiteA)     # GPU suite in three parts (a lost box takes its logs with it): A = bench_launch .. fullsize
+  timeout 2000 python -m pytest -q -x --durations=8 -m gpu tests/test_gpu_bench_launch.py tests/test_gpu_cabi_kernels.py tests/test_gpu_device_scf.py tests/test_gpu_df_jk.py tests/test_gpu_dft.py tests/test_gpu_fullsize.py > $O/pytest.log 2>&1; tail -14 $O/pytest.log ;;
+suiteB)     # B = fullsize_cfg45, grad, int3c2e
+  timeout 2000 python -m pytest -q -x --durations=8 -m gpu tests/test_gpu_fullsize_cfg45.py tests/test_gpu_fullsize_scf.py tests/test_gpu_grad.py tests/test_gpu_int3c2e.py > $O/pytest.log 2>&1; tail -14 $O/pytest.log ;;
+suiteC)     # C = native_abi .. xc_sparse, then the default bench line and smoke
+  timeout 2400 python -m pytest -q -x --durations=8 -m gpu tests/test_gpu_native_abi.py tests/test_gpu_native_r04.py tests/test_gpu_rccl.py tests/test_gpu_response.py tests/test_gpu_scf.py tests/test_gpu_soscf.py tests/test_gpu_tdscf.py tests/test_gpu_vhf.py tests/test_gpu_xc_sparse.py > $O/pytest.log 2>&1; tail -14 $O/pytest.log
+  tail -8 gpurun_out/_native_cfg45_worker_config5.log
+  timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python tools/bench_digest.py $O/bench_default.json; tail -3 $O/bench_default.err
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
 tests)      # selected tests: gpu_job.sh tests <pytest args>
   timeout 1800 python -m pytest -q -x --durations=8 "$@" > $O/pytest.log 2>&1; tail -25 $O/pytest.log ;;
 taxol_dump) # converged DF-RKS B3LYP orbitals of config 4 (input of the oracle functional golden) + VALU counters of the build
