@@ -256,6 +256,7 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    gc.disable()                          # ... and, as `timeit` does, no cyclic collection inside the timed regions (re-enabled below)
     ctimer = comm.CommTimer()
     comm.set_timer(ctimer)                # HIP events around every collective of the timed steps
     live_timer = df_jk.KernelTimer()      # ... and around every kernel launch, each on the stream it is launched on: the
@@ -300,6 +301,7 @@ def main():
         fence()
         host_calls.append((time.perf_counter() - t0) * 1e3)
     host_api_ms = float(np.median(host_calls))
+    gc.enable()
     host_fused = getattr(dfobj, '_last_fused', None)       # was the first J pass fused for the foreign (unpromised) tag?
     if world > 1:
         tmax = torch.tensor([host_api_ms], dtype=torch.float64, device=dev)
@@ -684,10 +686,12 @@ def single_process_main(args):
     import gc
     gc.collect()
     gc.freeze()                                           # (see main(): a 50 ms generation-2 collection is not part of a step)
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         vj, vk = obj.get_jk(dm, hermi=1)
     dt = time.perf_counter() - t0
+    gc.enable()
     ms = dt / args.steps * 1e3
     lay = obj.layout()
     tm = obj.last_timing()                                # of the last timed call: host clocks + HIP events inside the handle
