@@ -363,6 +363,31 @@ struct Engine {                            // device tables of one part, alive d
 
 std::mutex g_dev_mutex[64];                // builds on the same device are serialised (a devices list may repeat a device)
 
+// Bytes this process may still take before it hits its container's memory limit (cgroup v2 `memory.max` - `memory.current`, else
+// v1), or SIZE_MAX when there is no limit.  Page-locked host memory is charged to the cgroup like any other: r05 lost two GPU boxes
+// to the kernel's OOM killer when the 301 GB of host rows of config 5 met a 300 GiB container limit (/proc/meminfo showed 3 TB).
+size_t container_memory_left()
+{
+    auto read_num = [](const char *path, bool *is_max) -> long long {
+        FILE *f = fopen(path, "r");
+        if (!f) return -1;
+        char buf[64] = {0};
+        const bool ok = fgets(buf, sizeof(buf), f) != nullptr;
+        fclose(f);
+        if (!ok) return -1;
+        if (is_max && !strncmp(buf, "max", 3)) { *is_max = true; return 0; }
+        return atoll(buf);
+    };
+    bool unlimited = false;
+    long long lim = read_num("/sys/fs/cgroup/memory.max", &unlimited), cur = read_num("/sys/fs/cgroup/memory.current", nullptr);
+    if (lim < 0 && !unlimited) {
+        lim = read_num("/sys/fs/cgroup/memory/memory.limit_in_bytes", nullptr);
+        cur = read_num("/sys/fs/cgroup/memory/memory.usage_in_bytes", nullptr);
+    }
+    if (unlimited || lim <= 0 || lim > (1LL << 60) || cur < 0) return ~(size_t)0;
+    return lim > cur ? (size_t)(lim - cur) : 0;
+}
+
 int launch_class(const Engine &e, const PairClass &pc, int i0, int i1, const AuxClass &ac, double *T, long ldT, long row_offset,
                  int tril, const double *shell_xyz, const int *shell_ao0, double omega, hipStream_t st)
 {
@@ -806,9 +831,11 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
         h->n_res = nL;
     } else {
         // out of core: a share of the cap each for the slab work space, the two staging buffers and the J/K work space
-        slab_bytes = std::min<size_t>(slab_bytes, std::min<size_t>(6ul << 30, cap / (4 * npass)));
-        stage_b = std::min<size_t>(4ul << 30, cap / 8);
-        const size_t work_b = std::min<size_t>(20ul << 30, cap / 4);
+        // (r05: smaller reserves - 3 GB slabs, 2 GB staging buffers, 12 GB of J/K work space instead of 6 / 4 / 20 - keep ~15 GB
+        // more of the tensor resident: that much less page-locked host memory, which is what a container limit is charged for)
+        slab_bytes = std::min<size_t>(slab_bytes, std::min<size_t>(3ul << 30, cap / (4 * npass)));
+        stage_b = std::min<size_t>(2ul << 30, cap / 8);
+        const size_t work_b = std::min<size_t>(12ul << 30, cap / 4);
         // head room for the other clients of the device in this process (a torch context created AFTER the handle found no
         // memory at config 5 - "no HIP device" in the SCF driver): 4 GB or 1/16 of the cap stay unclaimed
         const size_t used = npass * slab_bytes + 2 * stage_b + work_b + margin + std::min<size_t>(4ul << 30, cap / 16);
@@ -820,6 +847,14 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
         }
         h->n_res = cap > used ? (int)std::min<size_t>((cap - used) / row_b, (size_t)nL) : 0;
         const size_t host_b = (size_t)(nL - h->n_res) * row_b;
+        const size_t left = container_memory_left();
+        if (left != ~(size_t)0 && host_b + (12ul << 30) > left) {
+            // refuse BEFORE the kernel's OOM killer does: the process (and on a GPU box the whole container) would be killed
+            snprintf(g_errmsg, sizeof(g_errmsg), "PAMD_df_create: %.1f GB of the tensor do not fit the device and the %.1f GB of page-locked "
+                     "host memory they need exceed what the container's memory limit leaves (%.1f GB incl. a 12 GB margin): use more "
+                     "devices / ranks", tensor_b * 1e-9, host_b * 1e-9, left * 1e-9);
+            return -3;
+        }
         if (hipHostMalloc((void **)&h->h_cderi, std::max<size_t>(host_b, 8), hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             h->h_cderi = nullptr;
@@ -1661,6 +1696,12 @@ int PAMD_df_create_from_rows(const double *rows, int nrows, int nao, int device,
             if (hipHostRegister((void *)h->h_cderi, host_b, hipHostRegisterDefault) == hipSuccess) h->h_registered = 1;
             (void)hipGetLastError();              // not registrable (a read-only file mapping, a locked-memory limit): pageable copies
         } else {
+            const size_t left = container_memory_left();
+            if (left != ~(size_t)0 && host_b + (12ul << 30) > left) {
+                snprintf(g_errmsg, sizeof(g_errmsg), "PAMD_df_create_from_rows: a page-locked copy of %.1f GB exceeds what the container's "
+                         "memory limit leaves (%.1f GB): flags bit 0 streams from the caller's array instead", host_b * 1e-9, left * 1e-9);
+                return -3;
+            }
             if (hipHostMalloc((void **)&h->h_cderi, host_b, hipHostMallocDefault) != hipSuccess) {
                 (void)hipGetLastError();
                 h->h_cderi = nullptr;

@@ -103,33 +103,6 @@ def test_config4_taxol_sharded_eight_ways_through_the_handle_vs_oracle_golden():
     _run('_native_cfg45_worker.py', 'NATIVE_CONFIG4_OK', 1500, 'config4')
 
 
-@pytest.mark.gpu
-def test_config5_whole_tensor_out_of_core_on_one_gpu_vs_oracle_goldens():
-    """BASELINE config 5, all 14 848 aux rows (560 GB) on ONE GPU: resident rows + ~330 GB streamed from page-locked host memory
-    per build; J / K of a seeded local density against the sum of two oracle-only goldens covering every row."""
-    for name in ('h2o128_ccpvdz_rows0-7424_local_oracle.json', 'h2o128_ccpvdz_rows7424-14848_local_oracle.json'):
-        if not os.path.exists(os.path.join(ROOT, 'tests', 'golden', name)):
-            pytest.skip('%s not generated (tools/gen_golden_shard_local.py --rows ...)' % name)
-    # r05: no opt-in gate any more - the case runs whenever the host has the memory (~300 GB page-locked beside the run time;
-    # the GPU boxes of this pool have 3 TB).  PAMD_SKIP_CONFIG5_FULL=1 skips it on purpose (quick local runs).
-    if os.environ.get('PAMD_SKIP_CONFIG5_FULL'):
-        pytest.skip('PAMD_SKIP_CONFIG5_FULL is set')
-    avail_gb = 0.0
-    try:
-        with open('/proc/meminfo') as f:
-            for line in f:
-                if line.startswith('MemAvailable:'):
-                    avail_gb = float(line.split()[1]) * 1e-6
-    except OSError:
-        pass
-    if avail_gb < 450:
-        pytest.skip('needs ~300 GB of page-locked host memory beside the run time: %.0f GB available on this host' % avail_gb)
-    out = _run('_native_cfg45_worker.py', 'NATIVE_CONFIG5_OK', 1500, 'config5')
-    # the energy leg (oracle-only golden + converged SCF, 1e-8 Eh) must have RUN, not been skipped, once its golden is committed
-    if os.path.exists(os.path.join(ROOT, 'tests', 'golden', 'h2o128_ccpvdz_energy_oracle.json')):
-        assert 'NATIVE_CONFIG5_ENERGY_OK' in out, out[-3000:]
-
-
 def test_library_exports_the_r04_handle_api_without_torch():
     code = ("import sys; sys.path.insert(0, %r); from pyscf_amd.df import native; lib = native.load(); "
             "[getattr(lib, n) for n in ('PAMD_df_create_ex', 'PAMD_df_create_multi', 'PAMD_df_layout', 'PAMD_grid_weights_host', 'PAMD_xc_create', 'PAMD_xc_nr_rks', 'PAMD_xc_nr_uks', 'PAMD_xc_plan_info', 'PAMD_xc_destroy')]; from pyscf_amd.dft import native as xn; "

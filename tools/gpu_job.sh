@@ -69,7 +69,7 @@ e2w)        # wide last orbital chunk of the half transform (taxol shape): kerne
   done
   cut -c1-600 $O/kbench.log ;;
 cfg5)       # BASELINE config 5 whole (560 GB) on one GPU through the out-of-core handle (opt-in test)
-  PAMD_RUN_CONFIG5_FULL=1 timeout 1500 python -m pytest -q -x tests/test_gpu_native_r04.py::test_config5_whole_tensor_out_of_core_on_one_gpu_vs_oracle_goldens -m gpu > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+  timeout 1500 python -m pytest -q -x tests/test_gpu_00_config5_whole_tensor.py -m gpu > $O/pytest.log 2>&1; tail -5 $O/pytest.log
   tail -4 gpurun_out/_native_cfg45_worker_config5.log ;;
 cfg5scf)    # BASELINE config 5 converged on ONE GPU through the out-of-core handle; dumps the occupied orbitals (oracle energy golden input)
   nproc > $O/host.txt; grep -E "MemTotal|MemAvailable" /proc/meminfo >> $O/host.txt; df -h /tmp . >> $O/host.txt; cat $O/host.txt
