@@ -627,7 +627,7 @@ def _pmc_passes(args):
         d = tempfile.mkdtemp(prefix='pamd_pmc_', dir='/tmp')
         try:
             subprocess.run(['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--'] + child,
-                           cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+                           cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
             agg = {}
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
                 for r in csv.DictReader(open(f)):

@@ -385,6 +385,16 @@ size_t container_memory_left()
         cur = read_num("/sys/fs/cgroup/memory/memory.usage_in_bytes", nullptr);
     }
     if (unlimited || lim <= 0 || lim > (1LL << 60) || cur < 0) return ~(size_t)0;
+    // file cache is charged too but the kernel reclaims it before it kills anything: count it as available
+    long long cache = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/memory.stat", "r")) {
+        char key[64];
+        long long val;
+        while (fscanf(f, "%63s %lld", key, &val) == 2)
+            if (!strcmp(key, "inactive_file") || !strcmp(key, "active_file")) cache += val;
+        fclose(f);
+    }
+    if (cache > 0 && cache <= cur) cur -= cache;
     return lim > cur ? (size_t)(lim - cur) : 0;
 }
 

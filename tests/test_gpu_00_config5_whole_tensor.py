@@ -30,6 +30,11 @@ def _container_memory_left_gb():
             if lim == 'max':
                 break
             lim, cur = int(lim), int(open(cur_p).read().strip())
+            try:                                            # file cache is charged as well but reclaimed before anything is killed
+                stat = dict(line.split() for line in open(os.path.join(os.path.dirname(lim_p), 'memory.stat')))
+                cur -= min(cur, int(stat.get('inactive_file', 0)) + int(stat.get('active_file', 0)))
+            except (OSError, ValueError):
+                pass
             if 0 < lim < 1 << 60:
                 left = min(left, (lim - cur) * 1e-9)
             break
