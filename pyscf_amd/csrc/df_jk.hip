@@ -14,6 +14,7 @@
 //              packed row directly: the symmetric unpack is fused into the LDS fill)
 //   gemm_tn    C[m][n]    += sum_k  A[k][m] * B[k][n]                 (FP64 MFMA; lower-tri
 //              tiles only for the K = X^T X  SYRK)
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -1092,10 +1093,17 @@ __global__ __launch_bounds__(256, 2) void e2_pk_kernel(
 // 128 x 128 tile of C[split] += A^T B (all tiles, or the lower-triangular ones of the SYRK), v2 DMA scheme
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
-    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, long kchunk, int prio)
+    double *__restrict__ C, int ldc, int m, int n, long kdim, int lower_only, int ntile_n, long kchunk, int prio,
+    const int *__restrict__ order, int nsplit_o)
 {
     if (prio) __builtin_amdgcn_s_setprio(3);        // MFMA waves ahead of a co-resident HBM-bound kernel's waves (tuning "mfmaprio")
-    const int bsplit = blockIdx.y, btile = blockIdx.x;
+    // r06: XCD-aware dispatch order (syrk_xcd_order): a 1-D launch whose workgroup b (XCD b % 8) looks its (tile, split) up
+    int bsplit = blockIdx.y, btile = blockIdx.x, nsp = (int)gridDim.y;
+    if (order) {
+        const int o = __builtin_amdgcn_readfirstlane(order[blockIdx.x]);
+        if (o < 0) return;
+        btile = o & 0xffff; bsplit = o >> 16; nsp = nsplit_o;
+    }
     constexpr int PA = KB * LDN;
     __shared__ double sb0[2 * PA];
     __shared__ double sb1[2 * PA];
@@ -1117,7 +1125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds2_kernel(
     // SYRK: a short remainder piece, see dgemm_tn_impl)
     long kbeg = (long)bsplit * kchunk;
     if (kbeg > kdim) kbeg = kdim;
-    const long kend = (kbeg + kchunk < kdim && bsplit + 1 < (int)gridDim.y) ? kbeg + kchunk : kdim;
+    const long kend = (kbeg + kchunk < kdim && bsplit + 1 < nsp) ? kbeg + kchunk : kdim;
     const int nk = (int)(kend - kbeg);                 // rows of this split: row offsets stay below 4 GiB (launcher)
     const __amdgpu_buffer_rsrc_t r_a = make_rsrc(A + kbeg * lda + p0);
     const __amdgpu_buffer_rsrc_t r_b = make_rsrc(B + kbeg * ldb + q0);
@@ -1228,16 +1236,21 @@ struct JStream {
 template <int PROBE, bool JF>         // PROBE = 1: benchmarking probe, skips the "B" DMA of every k-row (half the L2 -> LDS traffic, wrong results)
 __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
     const double *__restrict__ A, int lda, double *__restrict__ C, int ldc, int m, long kdim, const int *__restrict__ items,
-    long kchunk, int prio, JStream js)
+    long kchunk, int prio, JStream js, const int *__restrict__ order, int nsplit_o)
 {
     if (prio) __builtin_amdgcn_s_setprio(3);
-    const int bsplit = blockIdx.y;
+    int bsplit = blockIdx.y, bitem = blockIdx.x, nsp_grid = (int)gridDim.y;
+    if (order) {                         // r06: XCD-aware dispatch order, see gemm_tn_glds2_kernel (never together with JF)
+        const int o = __builtin_amdgcn_readfirstlane(order[blockIdx.x]);
+        if (o < 0) return;
+        bitem = o & 0xffff; bsplit = o >> 16; nsp_grid = nsplit_o;
+    }
     constexpr int PA = KB * LDN;
     __shared__ double sb0[2 * PA];
     __shared__ double sb1[2 * PA];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int *it = items + (long)blockIdx.x * 16;
+    const int *it = items + (long)bitem * 16;
     const int c0 = it[0], c1 = it[1], c2 = it[2], c3 = it[3];
     const int wdesc = __builtin_amdgcn_readfirstlane(it[4 + wave * 3]);           // a | b << 8 | live << 16
     const int rb = __builtin_amdgcn_readfirstlane(it[5 + wave * 3]), cb = __builtin_amdgcn_readfirstlane(it[6 + wave * 3]);
@@ -1245,7 +1258,7 @@ __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
     const bool live = (wdesc >> 16) & 1;
     long kbeg = (long)bsplit * kchunk;
     if (kbeg > kdim) kbeg = kdim;
-    const long kend = (kbeg + kchunk < kdim && bsplit + 1 < (int)gridDim.y) ? kbeg + kchunk : kdim;
+    const long kend = (kbeg + kchunk < kdim && bsplit + 1 < nsp_grid) ? kbeg + kchunk : kdim;
     const int nk = (int)(kend - kbeg);
     const __amdgpu_buffer_rsrc_t r_a = make_rsrc(A + kbeg * lda);
     const int lda8 = lda * 8;
@@ -1281,7 +1294,7 @@ __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
     int jacc_c = -1;
     const long jcol0 = (long)tid * 2;
     if (JF) {
-        const int nsp = (int)gridDim.y;
+        const int nsp = nsp_grid;
         long before = 0, mine = 0;
         for (int y = 0; y < nsp; y++) {
             long kb = (long)y * kchunk;
@@ -1517,6 +1530,7 @@ static int g_syrk_frac = 1;   // balanced SYRK: full pieces + one short remainde
 static int g_num_cu = 256;    // MI355X
 static int g_syrk_reserve = 0; // balanced SYRK: workgroup slots (of 2 x 256) left free for a co-running J pass 2 ("syrkreserve")
 static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
+static int g_syrk_xmap = 0;   // r06: SYRK work items in an XCD-aware dispatch order (syrk_xcd_order; "syrkxmap": 1 split-major, 2 item-major)
 
 extern "C" {
 
@@ -1530,6 +1544,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "syrkreserve") == 0 && value >= 0 && value < 256) { g_syrk_reserve = value; return 0; }
     if (strcmp(key, "syrkslots") == 0) { g_syrk_slots = value; return 0; }
     if (strcmp(key, "syrkprobe") == 0) { g_syrk_probe = value; return 0; }
+    if (strcmp(key, "syrkxmap") == 0) { g_syrk_xmap = value; return 0; }
     if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "pkdiag") == 0) { g_pk_diag = value; return 0; }
@@ -1945,17 +1960,22 @@ int PAMD_orb_dot_rows(const double *d_src, long lds, long src_stride, int ny, lo
 // Work items of syrk_slots_kernel for an m x m lower triangle with an ODD number nb of 64-column blocks (see the kernel's
 // comment); cached on the device per m.  16 ints per item: 4 slot column offsets, then per wave {a | b << 8 | live << 16, row
 // block, column block}.  nitems = 0: even nb (or a tiny matrix) - the caller keeps the 2 x 2 tiling.
-static int syrk_items(int m, const int **d_items, int *nitems)
+static int syrk_items(int m, const int **d_items, int *nitems, std::vector<int> *sorted = nullptr)
 {
     // one table per (device, m): a process may hold handles on several GPUs and call from one host thread per device
     static std::map<std::pair<int, int>, std::pair<int *, int>> cache;
+    static std::map<int, std::vector<int>> sorted_cache;        // per m: item indices in tile-row order (syrk_xcd_order)
     static std::mutex cache_mutex;
     int dev = 0;
     PAMD_CHECK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> guard(cache_mutex);
     const std::pair<int, int> key(dev, m);
     auto hit = cache.find(key);
-    if (hit != cache.end()) { *d_items = hit->second.first; *nitems = hit->second.second; return 0; }
+    if (hit != cache.end()) {
+        *d_items = hit->second.first; *nitems = hit->second.second;
+        if (sorted) *sorted = sorted_cache[m];
+        return 0;
+    }
     const int nb = ceil_div(m, 64);
     std::vector<int> tab;
     if (nb % 2 == 1 && nb >= 5) {
@@ -1998,9 +2018,67 @@ static int syrk_items(int m, const int **d_items, int *nitems)
         PAMD_CHECK_HIP(hipMalloc((void **)&d, tab.size() * sizeof(int)));
         PAMD_CHECK_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
     }
+    {
+        // tile-row order: by the first ("A") panel, then the "B" panel - the items of one tile row share their A panels
+        std::vector<int> idx(n);
+        for (int i = 0; i < n; i++) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+            const int ka = tab[(size_t)a * 16] * 4096 + tab[(size_t)a * 16 + 2] / 64, kb = tab[(size_t)b * 16] * 4096 + tab[(size_t)b * 16 + 2] / 64;
+            return ka < kb;
+        });
+        sorted_cache[m] = idx;
+        if (sorted) *sorted = idx;
+    }
     cache[key] = {d, n};
     *d_items = d;
     *nitems = n;
+    return 0;
+}
+
+// r06: XCD-aware dispatch order of the SYRK work items.  Workgroup b of a 1-D launch is placed on XCD b % 8
+// (round-robin dispatch), every XCD has its own 4 MB L2 and 64 workgroup slots: the (item, split) units are laid out so that the
+// units resident on one XCD at a time share X panels AND walk the same k rows in lockstep - their panel rows then hit in that L2.
+//   mode 1  split-major: the full pieces, ordered (split, item sorted by tile row), are cut into 8 contiguous runs, one per XCD
+//           (nao = 1856, 4 full pieces x 110 items: an XCD holds ONE k quarter of 55 items of 10-15 tile rows: 10.5-14.5 panels per
+//           k-tile instead of 110); the short remainder pieces of the balanced split follow at the end of every XCD's list
+//   mode 2  item-major: an XCD holds nitems / 8 consecutive items of every split (control: shared panels, no shared k range)
+// sorted[] = the items in tile-row order; returns a device table order[8 * nmax] (item | split << 16, -1 = no work) cached per key.
+static int syrk_xcd_order(int kind, int m, const std::vector<int> &sorted, int nsplit, bool last_short, int mode, const int **d_order,
+                          int *nwg)
+{
+    static std::map<std::vector<int>, std::pair<int *, int>> cache;
+    static std::mutex cache_mutex;
+    int dev = 0;
+    PAMD_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> guard(cache_mutex);
+    const std::vector<int> key = {dev, kind, m, nsplit, last_short ? 1 : 0, mode, (int)sorted.size()};
+    auto hit = cache.find(key);
+    if (hit != cache.end()) { *d_order = hit->second.first; *nwg = hit->second.second; return 0; }
+    const int nitems = (int)sorted.size(), nfull = last_short ? nsplit - 1 : nsplit, NX = 8;
+    std::vector<std::vector<int>> lists(NX);
+    const long units = (long)nitems * nfull;
+    if (mode == 2) {
+        for (int s = 0; s < nfull; s++)
+            for (int i = 0; i < nitems; i++) lists[(long)i * NX / nitems].push_back(sorted[i] | (s << 16));
+    } else {
+        for (long u = 0; u < units; u++) {
+            const int s = (int)(u / nitems), i = (int)(u % nitems);
+            lists[u * NX / units].push_back(sorted[i] | (s << 16));
+        }
+    }
+    if (last_short)
+        for (int i = 0; i < nitems; i++) lists[(long)i * NX / nitems].push_back(sorted[i] | ((nsplit - 1) << 16));
+    size_t nmax = 0;
+    for (auto &l : lists) nmax = std::max(nmax, l.size());
+    std::vector<int> ord(NX * nmax, -1);
+    for (int x = 0; x < NX; x++)
+        for (size_t i = 0; i < lists[x].size(); i++) ord[i * NX + x] = lists[x][i];
+    int *d = nullptr;
+    PAMD_CHECK_HIP(hipMalloc((void **)&d, ord.size() * sizeof(int)));
+    PAMD_CHECK_HIP(hipMemcpy(d, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice));
+    cache[key] = {d, (int)ord.size()};
+    *d_order = d;
+    *nwg = (int)ord.size();
     return 0;
 }
 
@@ -2051,7 +2129,8 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
     if (v2 && (lower_only & 1) && (lower_only & 8) && g_syrk_slots && d_A == d_B && lda == ldb) {
         const int *d_items = nullptr;
         int nitems = 0;
-        int rc = syrk_items(m, &d_items, &nitems);
+        std::vector<int> sorted;
+        int rc = syrk_items(m, &d_items, &nitems, &sorted);
         if (rc) return rc;
         if (nitems > 0) {
             dim3 g2(nitems, nsplit);
@@ -2070,22 +2149,39 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
                 if (js->total_steps <= 0 || js->npair % 2 || ((uintptr_t)js->B % 16) ||
                     (double)js->total_rows > 3.9 * (double)js->total_steps)
                     return 1;                                  // not a shape for the fused pass: the caller runs the pass by itself
-                syrk_slots_kernel<0, true><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, *js);
+                syrk_slots_kernel<0, true><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, *js, nullptr, nsplit);
                 PAMD_CHECK_LAUNCH();
                 return 0;
             }
             JStream none;
             memset(&none, 0, sizeof(none));
-            if (g_syrk_probe) syrk_slots_kernel<1, false><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, none);
-            else syrk_slots_kernel<0, false><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, none);
+            const int *d_order = nullptr;
+            if (g_syrk_xmap && nitems < 65536 && nsplit < 32768) {
+                int nwg = 0;
+                if ((rc = syrk_xcd_order(1, m, sorted, nsplit, kc != kchunk, g_syrk_xmap, &d_order, &nwg))) return rc;
+                g2 = dim3(nwg, 1);
+            }
+            if (g_syrk_probe) syrk_slots_kernel<1, false><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, none, d_order, nsplit);
+            else syrk_slots_kernel<0, false><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, none, d_order, nsplit);
             PAMD_CHECK_LAUNCH();
             return 0;
         }
     }
     if (js) return 1;                                          // no re-tiled SYRK for this shape: nothing launched
     if (v2) {
+        const long kuni = kchunk;
         if (lower_only & 1) kchunk = balanced_chunk(ntiles);
-        gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio);
+        const int *d_order = nullptr;
+        if (g_syrk_xmap && (lower_only & 1) && ntiles < 65536 && nsplit < 32768) {
+            // lower-triangular tiles t = tm (tm + 1) / 2 + tn are in tile-row order already
+            std::vector<int> sorted(ntiles);
+            for (int t = 0; t < ntiles; t++) sorted[t] = t;
+            int nwg = 0;
+            int rc = syrk_xcd_order(0, m, sorted, nsplit, kchunk != kuni, g_syrk_xmap, &d_order, &nwg);
+            if (rc) return rc;
+            grid = dim3(nwg, 1);
+        }
+        gemm_tn_glds2_kernel<<<grid, 256, 0, st>>>(d_A, lda, d_B, ldb, d_C, ldc, m, n, k, lower_only & 1, tn, kchunk, g_mfma_prio, d_order, nsplit);
     }
     else if (glds)
     {

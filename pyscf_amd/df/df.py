@@ -299,12 +299,16 @@ class DF:
                         raise RuntimeError("%s: 'j3c' holds %d columns, expected nao_pair = %d for nao = %d (s2-packed (naux, "
                                            "nao_pair) tensor, pyscf/df/df.py:59-72)" % (self._cderi, ncol, nao * (nao + 1) // 2, nao))
                     l0, l1 = self.shard_range(naux, self.rank, self.world_size)
-                    if self._rows_do_not_fit(l1 - l0, ncol, dev) and getattr(self, 'outcore', True):
+                    if (not self._all_ranks_agree(not self._rows_do_not_fit(l1 - l0, ncol, dev))) and getattr(self, 'outcore', True):
                         # r05: the file's rows of this rank do not fit the device - they are NOT loaded: the 'j3c' dataset is
                         # mapped (np.memmap at H5Dget_offset) and the C handle streams the non-resident rows straight out of the
                         # mapping under the kernels in every build (pyscf/df/df.py:214-242: the reference reads its file block by
                         # block in DF.loop every iteration as well)
                         off = blocks[0].file_offset() if len(blocks) == 1 else None
+                        if off is not None and not blocks[0].is_native_f64_le():
+                            #  the mapping below reads raw bytes: anything but little-endian float64 would stream garbage
+                            raise MemoryError("%s: the tensor does not fit the device and 'j3c' is not stored as little-endian "
+                                              "float64 (the raw mapping cannot convert): rewrite it with DF.save()" % self._cderi)
                         if off is None:
                             raise MemoryError("%s: the tensor does not fit the device and 'j3c' is not one contiguous dataset "
                                               "(column-block group or chunked layout): rewrite it with DF.save()" % self._cderi)
@@ -338,7 +342,7 @@ class DF:
             # pre-computed FULL tensor handed over by the caller (pyscf/df/df.py:153-155); each rank keeps its rows
             naux = self._cderi.shape[0]
             l0, l1 = self.shard_range(naux, self.rank, self.world_size)
-            if self._rows_do_not_fit(l1 - l0, self._cderi.shape[1], dev) and getattr(self, 'outcore', True):
+            if (not self._all_ranks_agree(not self._rows_do_not_fit(l1 - l0, self._cderi.shape[1], dev))) and getattr(self, 'outcore', True):
                 # streamed out of the caller's array (C order, float64: as it is; anything else through one host copy of the rows)
                 self._native_from_rows(np.ascontiguousarray(self._cderi[l0:l1], dtype=np.float64), (l0, l1), naux, dev)
                 return self
@@ -353,7 +357,7 @@ class DF:
         try:
             # the fit check comes BEFORE any metric work (the metric used to be computed and factorised twice, once by
             # cholesky_eri_gpu ahead of its own memory check and once more inside the C handle)
-            if not self.would_fit():
+            if not self._all_ranks_agree(self.would_fit()):
                 raise MemoryError('DF tensor shard of %d x %d doubles does not fit %s' % (
                     l1 - l0, _mol_nao(self.mol) * (_mol_nao(self.mol) + 1) // 2,
                     'DF.outcore_device_bytes' if self.outcore_device_bytes else 'the free device memory'))
@@ -382,6 +386,21 @@ class DF:
             self.save(self._cderi_to_save)
         return self
     kernel = build
+
+    def _all_ranks_agree(self, fits):
+        """The out-of-core decision of a multi-rank job is COLLECTIVE (r06): each rank used to decide from its own
+        hipMemGetInfo; ranks that disagreed (shared devices, the one-row shard imbalance near the threshold) then issued
+        different collectives - in-core ranks one packed [J~ | K] all-reduce, out-of-core ranks two nao^2 all-reduces - i.e. an
+        RCCL hang or corrupted sums.  MIN over the ranks: one rank out of core = every rank out of core (same reduction path)."""
+        from ..lib import comm as _comm
+        if getattr(self, '_shard_override', None) is not None or not _comm.active(self.world_size):
+            return bool(fits)
+        import torch
+        import torch.distributed as dist
+        dev = self._device() if _comm.backend_name(self.group) == 'nccl' else 'cpu'
+        flag = torch.tensor([1 if fits else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
 
     def _rows_do_not_fit(self, nrows, ncol, dev):
         import torch

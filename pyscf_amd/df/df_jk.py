@@ -554,18 +554,13 @@ def _dm_tensor(d):
     return d.tensor() if isinstance(d, _HostDM) else d
 
 
-def _host_dm_mismatch(dms, blocks, own_tag):
+def _host_dm_mismatch(dms, blocks, own_tag=False):
     """max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) on the host for one fixed pseudo-random vector (the probe of the C handle's
-    binding, pyscf_amd/df/native.py): this package's own make_rdm1 tag on every 16th row (0.1 ms: what an in-place edit of a
-    tagged array looks like in practice - dm *= x, dm += x - shows there), a foreign tag on the full matrix."""
-    nao = dms.shape[-1]
-    v = np.random.RandomState(20240601).random_sample(nao) - 0.5
-    step = 16 if own_tag else 1
-    worst = 0.0
-    for k in range(len(dms)):
-        dv = dms[k][::step].dot(v)
-        worst = max(worst, float(np.abs(dv - blocks[k][::step].dot(blocks[k].T.dot(v))).max() / max(1.0, np.abs(dv).max())))
-    return worst
+    binding as well, pyscf_amd/df/native.py).  r06: the FULL matrix for this package's own make_rdm1 tag too - the
+    every-16th-row probe of r05 missed sparse in-place edits (dm[1, 2] += h; dm[2, 1] += h of a finite-difference Fock: 1e-15
+    against 8e-5 on the full matrix) and J then came silently from the orbitals.  One 8 nao^2-byte read per density with the
+    BLAS pool bounded (lib.bounded_matvec); here it runs beside the queued kernels."""
+    return _lib_mod.dm_orbital_mismatch(dms, blocks)
 
 
 def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_from_orbitals=None):
@@ -723,6 +718,12 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
     nset = dms.shape[0]
     dev = dfobj._cderi_dev.device
     dms_dev = _HostDM(dms, dev)                 # uploaded only if a kernel reads the matrix (not on the fused MO branch)
+    # r06: where a host-API call spends its host time (bench.py `host_api_breakdown_ms`): DF.host_timing = []
+    # collects one dict per call - prepare (orbital blocks, padding, upload), queue (kernel launches), probe (tag check on the
+    # host beside the running kernels), download (wait for the device + the copy into page-locked arrays)
+    import time as _time
+    _ht = getattr(dfobj, 'host_timing', None)
+    _t0 = _time.perf_counter()
     lowrank = getattr(dm, 'lowrank', None)
     if with_k and lowrank is not None and getattr(dfobj, 'lowrank_exchange', True):
         # factorised trial densities (tag: lowrank = (lefts, rights, sym), D_k = L_k R_k^T [+ h.c.]): J from the full
@@ -782,7 +783,9 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         check = lambda: _host_dm_mismatch(dms, host_blocks, bool(getattr(dm, 'dm_from_orbitals', False)))
     elif neg_sets is not None or orb_list is not None:
         promise = False if neg_sets is not None else None
+    _t1 = _time.perf_counter()
     vjtril, vk_dev = get_jk_device(dfobj, dms_dev, orb_list, with_j, with_k, dm_from_orbitals=promise)
+    _t2 = _time.perf_counter()
     if neg_sets is not None:
         lib = _lib_mod.load_library()
         idx = [k for k in range(nset) if neg_sets[k] is not None]
@@ -790,8 +793,14 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
         _allreduce(dfobj, [vk_neg])
         for j, k in enumerate(idx):
             vk_dev[k] -= vk_neg[j]
+    _t3 = _time.perf_counter()
     mismatch = check() if check is not None else 0.0          # (host arithmetic beside the queued kernels)
+    _t4 = _time.perf_counter()
     vj, vk = _to_host(dfobj, vjtril, vk_dev, nset, nao, dm_shape, with_j, with_k)
+    if _ht is not None:
+        _t5 = _time.perf_counter()
+        _ht.append({'prepare': round((_t1 - _t0) * 1e3, 3), 'queue': round((_t2 - _t1) * 1e3, 3), 'probe': round((_t4 - _t3) * 1e3, 3),
+                    'wait_and_download': round((_t5 - _t4) * 1e3, 3)})
     if mismatch > 1e-10:
         # the tag did not describe the matrix: J from the matrix itself (the K of the MO branch follows the tag, as in the reference)
         lib = _lib_mod.load_library()

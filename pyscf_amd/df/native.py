@@ -242,6 +242,10 @@ class NativeDF:
         """The handle of erf(omega r12)/r12 (omega > 0) or erfc(|omega| r12)/r12 (omega < 0), cached per omega."""
         if not omega:
             return self
+        if self.auxmol is False:
+            # (ADVICE r05) ready-made rows carry no auxiliary basis: the attenuated tensor cannot be derived from them
+            raise NotImplementedError('NativeDF.range_coulomb(): this handle was made from ready-made tensor rows (from_rows / a '
+                                      '_cderi file); a range-separated tensor needs the integrals - build a NativeDF(mol, auxbasis)')
         key = '%.6f' % omega
         if key not in self._rsh_df:
             self._rsh_df[key] = NativeDF(self.mol, self.auxbasis, self.auxmol, self.device, self.lindep, self.devices, omega,
@@ -249,6 +253,11 @@ class NativeDF:
         return self._rsh_df[key]
 
     def reset(self, mol=None):
+        if mol is not None and self.auxmol is False:
+            #  reset(mol) used to set auxmol = None: a later build() then silently recomputed the tensor from integrals
+            # instead of the caller's rows
+            raise NotImplementedError('NativeDF.reset(mol): this handle was made from ready-made tensor rows (from_rows); make a '
+                                      'new NativeDF for the new molecule')
         if self._h is not None:
             load().PAMD_df_destroy(self._h)
         self._h = None
@@ -314,15 +323,11 @@ class NativeDF:
             # dm == orbo orbo^T ?  One matrix-vector probe per density (r04 computed D v twice per density: with numpy's 64 BLAS
             # threads on a 256-core host that was the whole 10 ms gap between this call and the bare C call; a probe on a helper
             # thread beside the device call - tried in r05 - made the C call itself 40 ms slower: the BLAS threads spin)
-            v = np.random.RandomState(20240601).random_sample(nao) - 0.5
-            # this package's own make_rdm1 tag (dm_from_orbitals): every 16th row is probed (0.1 ms) - it catches what an in-place
-            # edit of a tagged array looks like in practice (dm *= x, dm += x, dm[...] = ...: ADVICE r04); a foreign tag (stock
-            # PySCF's lib.tag_array(dm, mo_coeff=, mo_occ=)) gets the full matrix-vector probe (one 8 nao^2-byte read per density)
-            step = 16 if getattr(dm, 'dm_from_orbitals', False) else 1
-            ok = True
-            for k in range(nset):
-                dv = dms[k][::step].dot(v)
-                ok = ok and np.abs(dv - blocks[k][::step].dot(blocks[k].T.dot(v))).max() <= 1e-10 * max(1.0, np.abs(dv).max())
+            # r06: the FULL matrix-vector probe for this package's own make_rdm1 tag as well - every 16th row (r05)
+            # missed sparse in-place edits of a tagged array (dm[1, 2] += h); one 8 nao^2-byte read per density with the BLAS
+            # pool bounded to 8 threads (lib.bounded_matvec: ~0.3 ms at nao 1856)
+            from ..lib import dm_orbital_mismatch
+            ok = dm_orbital_mismatch(dms, blocks) <= 1e-10
             flags = 1 if ok else 0
         vj = pinned_empty(dms.shape) if with_j else None
         vk = pinned_empty(dms.shape) if with_k else None

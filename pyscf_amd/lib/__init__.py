@@ -88,6 +88,40 @@ def tag_array(a, **kwargs):
     return t
 
 
+_blas_ctl = None
+
+
+def bounded_matvec(mat, vec, threads=8):
+    """mat @ vec with the BLAS pool limited to `threads` for the call.  A plain numpy gemv of an nao^2 matrix on a 256-thread
+    host wakes every BLAS thread and costs ~5 ms (r05 measurement); with 8 threads it is one 8 nao^2-byte read at memory speed
+    (~0.3 ms at nao 1856).  The controller object is created once (threadpoolctl scans the loaded libraries) and reused; without
+    threadpoolctl the plain product runs."""
+    global _blas_ctl
+    if _blas_ctl is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _blas_ctl = ThreadpoolController()
+        except Exception:
+            _blas_ctl = False
+    if _blas_ctl:
+        with _blas_ctl.limit(limits=threads, user_api='blas'):
+            return mat.dot(vec)
+    return mat.dot(vec)
+
+
+def dm_orbital_mismatch(dms, blocks):
+    """max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) for one fixed pseudo-random vector, on the FULL matrices (r06, ADVICE r05:
+    the r05 probe of every 16th row missed sparse in-place edits such as dm[1, 2] += h of a finite-difference Fock; the reference
+    always builds J from the matrix, pyscf/df/df_jk.py:367).  ~0 when every density equals its orbitals' outer product."""
+    nao = dms.shape[-1]
+    v = np.random.RandomState(20240601).random_sample(nao) - 0.5
+    worst = 0.0
+    for k in range(len(dms)):
+        dv = bounded_matvec(dms[k], v)
+        worst = max(worst, float(np.abs(dv - blocks[k].dot(blocks[k].T.dot(v))).max() / max(1.0, np.abs(dv).max())))
+    return worst
+
+
 def _alloc_pinned_torch(nbytes):
     import torch
     t = torch.empty(nbytes // 8, dtype=torch.float64, pin_memory=True)

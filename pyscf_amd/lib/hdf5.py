@@ -102,6 +102,21 @@ class Dataset:
         self._io(self._lib.H5Dread, r0, out)
         return out
 
+    def is_native_f64_le(self):
+        """True when the stored datatype is IEEE float, 8 bytes, little-endian - the only layout a raw np.memmap('<f8') of the
+        dataset's bytes reads correctly (r06, ADVICE r05: a float32 or big-endian 'j3c' used to be streamed as garbage).
+        H5Dget_type / H5Tget_class (H5T_FLOAT = 1) / H5Tget_size / H5Tget_order (H5T_ORDER_LE = 0)."""
+        lib = self._lib
+        lib.H5Dget_type.restype = _hid
+        lib.H5Tget_size.restype = ctypes.c_size_t
+        t = lib.H5Dget_type(_hid(self._id))
+        if t < 0:
+            return False
+        try:
+            return lib.H5Tget_class(_hid(t)) == 1 and lib.H5Tget_size(_hid(t)) == 8 and lib.H5Tget_order(_hid(t)) == 0
+        finally:
+            lib.H5Tclose(_hid(t))
+
     def file_offset(self):
         """Byte offset of the raw data in the file when the dataset is stored CONTIGUOUSLY (what `create_dataset` here and
         h5py's default write), else None (chunked / compressed layouts have no single offset) - H5Dget_offset."""

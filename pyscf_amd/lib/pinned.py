@@ -29,7 +29,8 @@ class PinnedPool:
         """allocate(nbytes) -> (address, owner) of a page-locked block, or raises."""
         self._allocate = allocate
         self._blocks = []
-        self._lock = threading.Lock()
+        self._lock = threading.RLock()      # re-entrant: a finalizer (_release) may fire on THIS thread inside take() when the
+                                            # cyclic GC runs there (ADVICE r05) - a plain Lock would deadlock
         self._max_idle = max_idle
 
     def _release(self, blk):

@@ -75,7 +75,8 @@ def eligible(mf, callback=None):
     # A predicate must not build a tensor of hundreds of GB as a side effect: ask the cheap fit check
     if getattr(mf.with_df, '_native', None) is not None:
         return False
-    if mf.with_df._cderi_dev is None and not isinstance(mf.with_df._cderi, (str, np.ndarray)) and not mf.with_df.would_fit():
+    if mf.with_df._cderi_dev is None and not isinstance(mf.with_df._cderi, (str, np.ndarray)) and \
+            not mf.with_df._all_ranks_agree(mf.with_df.would_fit()):       # (collective: every rank takes the same loop)
         return False
     # every other condition holds and the tensor fits: the loop needs it now anyway (a build that still ends out of core - the
     # estimate and the allocator disagreeing by a hair - keeps the host loop)

@@ -50,19 +50,19 @@ def test_config5_whole_tensor_out_of_core_on_one_gpu_vs_oracle_goldens():
       * r05: J rows / (K C) rows and the energy functional at the orbitals of tests/golden/h2o128_ccpvdz_rhf_orbitals.npz against
         the oracle-only ENERGY golden (tools/gen_golden_energy_sweep.py), and the product's OWN SCF from its minao guess through
         the handle converging to that energy - 1e-8 Eh, pyscf/df/test/test_df_jk.py:57-59 at config-5 size."""
-    for name in ('h2o128_ccpvdz_rows0-7424_local_oracle.json', 'h2o128_ccpvdz_rows7424-14848_local_oracle.json'):
-        if not os.path.exists(os.path.join(ROOT, 'tests', 'golden', name)):
-            pytest.skip('%s not generated (tools/gen_golden_shard_local.py --rows ...)' % name)
-    if os.environ.get('PAMD_SKIP_CONFIG5_FULL'):
-        pytest.skip('PAMD_SKIP_CONFIG5_FULL is set')
+    # r06 (VERDICT r05 item 9, ADVICE r05): ONE skip path - memory.  The goldens are committed (a missing one FAILS), a worker that
+    # does not finish in 25 minutes FAILS (normal: 4-5; a hang in the part workers or the pinned pool is a product bug, not an
+    # environment), and of the worker's error texts only the handle's own explicit refusals of the host allocation skip.  A skip
+    # prints CONFIG5_SKIPPED in the suite summary (tests/conftest.py), so that a silent skip on a smaller box cannot pass for N3.
+    for name in ('h2o128_ccpvdz_rows0-7424_local_oracle.json', 'h2o128_ccpvdz_rows7424-14848_local_oracle.json',
+                 'h2o128_ccpvdz_energy_oracle.json'):
+        assert os.path.exists(os.path.join(ROOT, 'tests', 'golden', name)), '%s is not in tests/golden' % name
     left = _container_memory_left_gb()
     if left < 305:
-        pytest.skip('needs ~285 GB of page-locked host memory + margin inside the container limit: %.0f GB left here' % left)
-    try:
-        p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_native_cfg45_worker.py'), 'config5'], capture_output=True,
-                           text=True, timeout=1500)
-    except subprocess.TimeoutExpired:
-        pytest.skip('the 560 GB case did not finish in 25 minutes on this host (normally 4-5)')
+        pytest.skip('CONFIG5_SKIPPED memory: needs ~285 GB of page-locked host memory + margin inside the container limit, '
+                    '%.0f GB left here' % left)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_native_cfg45_worker.py'), 'config5'], capture_output=True,
+                       text=True, timeout=1500)                       # TimeoutExpired = failure
     try:
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', '_native_cfg45_worker_config5.log'), 'w') as f:
@@ -71,11 +71,9 @@ def test_config5_whole_tensor_out_of_core_on_one_gpu_vs_oracle_goldens():
         pass
     out = p.stdout + p.stderr
     if p.returncode != 0 and 'AssertionError' not in out and any(k in out for k in (
-            "container's memory limit", 'page-locked host memory could not be allocated', 'out of memory', 'hipErrorOutOfMemory',
-            'MemoryError', 'Killed')):
-        # an environment that cannot hold the case (memory limits, a smaller device): not a parity statement
-        pytest.skip('the host / device cannot hold the 560 GB case: ' + out.strip().splitlines()[-1][-300:])
+            "container's memory limit", 'page-locked host memory could not be allocated')):
+        # the handle itself refused the host rows (PAMD_df_create: ...): the environment cannot hold the case - not a parity statement
+        pytest.skip('CONFIG5_SKIPPED memory: ' + out.strip().splitlines()[-1][-300:])
     assert p.returncode == 0 and 'NATIVE_CONFIG5_OK' in p.stdout, p.stdout[-3000:] + p.stderr[-4000:]
-    # the energy leg (oracle-only golden + converged SCF, 1e-8 Eh) must have RUN, not been skipped, once its golden is committed
-    if os.path.exists(os.path.join(ROOT, 'tests', 'golden', 'h2o128_ccpvdz_energy_oracle.json')):
-        assert 'NATIVE_CONFIG5_ENERGY_OK' in p.stdout, p.stdout[-3000:]
+    # the energy leg (oracle-only golden + converged SCF, 1e-8 Eh) must have RUN, not been skipped
+    assert 'NATIVE_CONFIG5_ENERGY_OK' in p.stdout, p.stdout[-3000:]

@@ -54,7 +54,8 @@ def test_mol_nao_for_any_molecule_like_object():
 
 def test_host_dm_probe_own_and_foreign_tags():
     """The tag probe of the host API (df_jk._host_dm_mismatch = the binding's probe): D = C C^T passes; an in-place edit of a tagged
-    array is caught by the sampled probe of the package's own tag (every 16th row) as well as by the full one."""
+    array is caught for the package's own tag exactly as for a foreign one - r06: the full matrix is probed for both
+    (the every-16th-row probe of r05 missed a finite-difference edit dm[1, 2] += h; dm[2, 1] += h)."""
     from pyscf_amd.df import df_jk
     rng = np.random.default_rng(3)
     nao, nocc = 200, 37
@@ -63,8 +64,13 @@ def test_host_dm_probe_own_and_foreign_tags():
     assert df_jk._host_dm_mismatch(dm, [c], True) < 1e-12 and df_jk._host_dm_mismatch(dm, [c], False) < 1e-12
     assert df_jk._host_dm_mismatch(dm * 0.5, [c], True) > 1e-3
     edited = dm.copy()
-    edited[0, 5, 7] += 1e-3                                      # one element, in an unsampled row: only the full probe sees it
+    edited[0, 5, 7] += 1e-3                                      # one element, in a row the r05 sampled probe skipped
     assert df_jk._host_dm_mismatch(edited, [c], False) > 1e-8
+    assert df_jk._host_dm_mismatch(edited, [c], True) > 1e-8     # own tag: seen as well
+    fd = dm.copy()
+    fd[0, 1, 2] += 1e-4
+    fd[0, 2, 1] += 1e-4                                          # the advisor's finite-difference Fock example
+    assert df_jk._host_dm_mismatch(fd, [c], True) > 1e-8
     h = df_jk._HostDM(dm, 'cpu')
     assert h.shape == dm.shape and h._t is None                  # nothing uploaded until a kernel asks for the matrix
     assert df_jk._dm_tensor(h).shape == dm.shape and h._t is not None

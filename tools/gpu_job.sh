@@ -147,6 +147,42 @@ evidence)   # the round's measured evidence (everything except the test suite): 
   timeout 600 python tools/run_scf.py --molecule taxol --xc b3lyp --conv-tol 1e-9 > $O/scf_taxol_b3lyp.log 2>&1; tail -1 $O/scf_taxol_b3lyp.log
   timeout 600 python tools/grad_bench.py --nwater 32 > $O/grad_h2o32_rhf.json 2> $O/grad.err; cat $O/grad_h2o32_rhf.json | cut -c1-300
   find gpurun_out -name "*.db" -delete ;;
+syrkfetch)  # r06: SYRK dispatch orders x FETCH_SIZE x ms.  gpu_job.sh syrkfetch "<tune1>" "<tune2>" ... (- = none)
+  : > $O/kbench.log
+  for t in "$@"; do
+    [ "$t" = "-" ] && T="" || T="$t"
+    TAG=$(echo "${T:-base}" | tr '=,' '__')
+    for sc in "jk:--j2-policy overlap --syrk-reserve 16" "konly:--no-j"; do
+      S=${sc%%:*}; A=${sc#*:}
+      for rep in 1 2; do
+        echo "== $S tune=$T" >> $O/kbench.log
+        timeout 300 python tools/kbench.py --steps 5 $A ${T:+--tune $T} 2>&1 | tail -1 >> $O/kbench.log
+      done
+      ( cd /tmp; timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/${S}_${TAG} -o x -- python $R/tools/kbench.py --steps 2 $A ${T:+--tune $T} > $R/$O/${S}_${TAG}.log 2>&1 )
+    done
+  done
+  cut -c1-560 $O/kbench.log
+  python tools/pmc_table.py $O syrk_slots gemm_tn_glds2 vj_pass2 e2_sq2 > $O/summary.txt; cat $O/summary.txt
+  find $O -name "*.db" -delete; find $O -name "*_kernel_trace.csv" -delete ;;
+kfetch)     # r06: kbench argument strings x FETCH_SIZE x ms: gpu_job.sh kfetch "<kbench args 1>" "<kbench args 2>" ...
+  : > $O/kbench.log
+  i=0
+  for A in "$@"; do
+    i=$((i+1))
+    for rep in 1 2; do
+      echo "== [$i] $A" >> $O/kbench.log
+      timeout 300 python tools/kbench.py --steps 5 $A 2>&1 | tail -1 >> $O/kbench.log
+    done
+    ( cd /tmp; timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/v$i -o x -- python $R/tools/kbench.py --steps 2 $A > $R/$O/v$i.log 2>&1 )
+  done
+  cut -c1-330 $O/kbench.log
+  python tools/pmc_table.py $O syrk_slots gemm_tn_glds2 vj_pass2 e2_sq2 > $O/summary.txt; cat $O/summary.txt
+  find $O -name "*.db" -delete; find $O -name "*_kernel_trace.csv" -delete ;;
+sparsity)   # r06: static tile sparsity of the tensor at configs 3, 4 and one config-5 shard
+  timeout 600 python tools/tile_sparsity.py --nwater 32 --basis cc-pvtz 2>&1 | tail -1 > $O/tile_sparsity.jsonl
+  timeout 600 python tools/tile_sparsity.py --molecule taxol --basis def2-tzvp 2>&1 | tail -1 >> $O/tile_sparsity.jsonl
+  timeout 900 python tools/tile_sparsity.py --nwater 128 --basis cc-pvdz --world 8 --rank 3 2>&1 | tail -1 >> $O/tile_sparsity.jsonl
+  cat $O/tile_sparsity.jsonl ;;
 run)        # arbitrary command line, logged: gpu_job.sh run <tag> <cmd...>
   T=$1; shift; timeout 1500 "$@" > $O/$T.log 2>&1; tail -30 $O/$T.log ;;
 *) echo "unknown job $JOB"; exit 2 ;;

@@ -77,6 +77,11 @@ for k, (t, n) in s.items():
         out[k + '_TF'] = round(fl / ms / 1e9, 1)
     if k.startswith('vj_pass'):
         out[k + '_GBs'] = round(by / ms / 1e6, 0)
+# fingerprints of the full-size results: runs with different tuning keys on the same synthetic tensor must agree
+_w = torch.cos(torch.arange(a.nao * a.nao, dtype=torch.float64, device=dev)).view(a.nao, a.nao)
+out['fp_vk'] = float((vk[0] * _w).sum())
+if vj is not None:
+    out['fp_vj'] = float((vj[0] * torch.cos(torch.arange(vj.shape[1], dtype=torch.float64, device=dev))).sum())
 # cheap correctness probe on a few entries (fp64 reference on device for 32 aux rows)
 sub = obj._cderi_dev[:32]
 idx = torch.tril_indices(a.nao, a.nao, device=dev)
