@@ -41,6 +41,8 @@ def _golden_case(args, nao, nocc):
     """(file, key prefix, rank of the seeded density) of the oracle-only J/K golden that matches this workload, or None."""
     if args.molecule == 'water' and args.nwater == 32 and args.basis == 'cc-pvtz':
         return 'h2o32_ccpvtz_oracle.json', '', nocc
+    if args.molecule == 'water' and args.nwater == 8 and args.basis == 'cc-pvtz':       # the small case of the launch tests
+        return 'h2o8_ccpvtz_oracle.json', '', nocc
     if args.molecule == 'taxol' and args.basis == 'def2-tzvp':
         return 'taxol_def2tzvp_oracle.json', 'syn_', 32
     return None
@@ -122,6 +124,7 @@ def main():
                     "'auto' (default, r05): on when rocprofv3 is on PATH; 'off': the committed profiles/<round>/pmc_summary.json")
     ap.add_argument('--no-pmc', dest='pmc', action='store_const', const='off')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--pmc-shard', default='', help=argparse.SUPPRESS)      # 'r,w': the child builds and contracts rank r's shard of w only
     args = ap.parse_args()
     if args.single_process:
         return single_process_main(args)
@@ -182,6 +185,13 @@ def main():
         pmc_live = _pmc_passes(args)         # before this process holds any HBM: the child runs need the whole device
         if not pmc_live.get('FETCH_SIZE'):
             pmc_live = None                  # profiler missing / failed: the committed summary is used (and named) instead
+    elif args.pmc == 'on' and world > 1 and rank == 0 and not args.pmc_child:
+        # r06: at N > 1 rank 0 measures the traffic of ITS shard's launch on ITS device - a child run outside
+        # the process group that builds and contracts rank 0's rows only (--pmc-shard 0,N) - while the other ranks build and wait at
+        # the first barrier.  Opt-in (--pmc on): the default at N > 1 is the committed figure scaled by rows, labelled as such.
+        pmc_live = _pmc_passes(args, shard=(0, world), device=dev_index)
+        if not pmc_live.get('FETCH_SIZE'):
+            pmc_live = None
 
     from pyscf_amd import gto, df, lib
     from pyscf_amd.data import clusters
@@ -194,6 +204,8 @@ def main():
     mol = gto.M(atom=clusters.taxol() if args.molecule == 'taxol' else clusters.water_cluster(args.nwater), basis=args.basis)
     nao, nocc = mol.nao, mol.nelectron // 2
     dfobj = df.DF(mol)                      # aux basis by the reference's rule (cc-pvtz -> cc-pvtz-jkfit)
+    if args.pmc_child and args.pmc_shard:
+        dfobj._shard_override = tuple(int(v) for v in args.pmc_shard.split(','))     # one rank's rows, no collectives
     if args.syrk_flags >= 0:
         dfobj.k_syrk_flags = args.syrk_flags
     if args.k_square == 'off':
@@ -206,7 +218,7 @@ def main():
     # when HBM allows); refuse with a clear message instead of an out-of-memory error inside the build
     from pyscf_amd.lib import comm
     naux_all = df.make_auxmol(mol, dfobj.auxbasis).nao_nr()
-    l0_, l1_ = dfobj.shard_range(naux_all, rank, world)
+    l0_, l1_ = dfobj.shard_range(naux_all, dfobj.rank, dfobj.world_size)
     shard_gb = 8e-9 * (l1_ - l0_) * (nao * (nao + 1) // 2)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     preflight = {'device_count': ndev, 'hbm_free_GB': round(free_b / 1e9, 1), 'hbm_total_GB': round(total_b / 1e9, 1),
@@ -285,6 +297,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
+    if args.pmc_child:
+        # the counters of the timed launches are all the parent wants from this run
+        print(json.dumps({'pmc_child': True, 'ms_per_step': round(ms_per_step, 3), 'naux_local': int(naux_local)}))
+        return
     jk_schedule = dict(getattr(dfobj, '_j2_policy_times', {'chosen': dfobj.j2_policy}))     # of the TIMED workload (the golden density
                                                                                           # below has its own shape and its own trial)
 
@@ -295,12 +311,14 @@ def main():
     fence()
     nh = max(1, min(args.steps, 5))
     host_calls = []
+    dfobj.host_timing = []                    # r06: where each call spends its host time (df_jk.get_jk), printed beside the list
     for _ in range(nh):                       # every call fenced and timed by itself: the MEDIAN is reported (a single call now
         t0 = time.perf_counter()              # and then carries a 40 ms host hiccup - the list is in the line as well)
         vj_h, vk_h = dfobj.get_jk(dm_tag, hermi=1)
         fence()
         host_calls.append((time.perf_counter() - t0) * 1e3)
     host_api_ms = float(np.median(host_calls))
+    host_breakdown, dfobj.host_timing = dfobj.host_timing, None
     gc.enable()
     host_fused = getattr(dfobj, '_last_fused', None)       # was the first J pass fused for the foreign (unpromised) tag?
     if world > 1:
@@ -479,8 +497,12 @@ def main():
                     'traffic_source': (traffic_src if pmc_live is not None else
                                        '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured '
                                        'in this run - bench.py --pmc does)' % traffic_src) if traffic is not None else None,
+                    'traffic_measured_in_run': bool(pmc_live is not None and traffic is not None),
                     'avg_launch_ms': round(dtot / dcnt, 4), 'launches_per_step': round(dcnt, 2),
                     'flops_per_step': fl}
+        if traffic is not None and pmc_live is None and world > 1:
+            roofline['traffic_source'] += ('; SCALED from the N = 1 launch by aux rows per launch (%d here): not measured at this N - '
+                                           '`bench.py --gpus N --pmc on` measures it on rank 0' % int(naux_local / max(dcnt, 1)))
     else:
         ach = bytes_j / (dtot * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -519,7 +541,9 @@ def main():
 
     cpu = None
     parity = None
-    if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
+    if not args.no_cpu_baseline:
+        # r06: at N > 1 rank 0 times the reference C on ITS SHARD's rows (a bounded sample of the same
+        # workload: 1 / N of the rows) - `value` is extrapolated to all aux rows and says so, `shard_value` is what was timed
         from oracle import ref, ref_c
         ncore = args.cpu_threads or os.cpu_count()
         use_ref = ref_c.available()
@@ -563,7 +587,12 @@ def main():
                'unit': 'ms/iter' + ('' if nrow == naux else ' (extrapolated from %d to all %d aux rows)' % (nrow, naux)),
                'cores': ncore, 'host_cores': os.cpu_count(), 'kind': kind, 'host_gflops': round(cpu_flops / cpu_s / 1e9, 1), 'phases_s': phases,
                'blas_calibration': getattr(ref_c, 'calibration', None) if use_ref else None,
-               'sample': '%s; %d of %d aux rows of the GPU-built tensor: %.2f s' % (what, nrow, naux, cpu_s)}
+               'sample': '%s; %d of %d aux rows of the GPU-built tensor%s: %.2f s' % (
+                   what, nrow, naux, '' if world == 1 else " (rank 0's shard of %d ranks)" % world, cpu_s)}
+        if world > 1:
+            cpu.update({'shard_value': round(cpu_s * 1e3, 1), 'shard_rows': int(nrow), 'shard_unit': "ms for rank 0's rows, as timed",
+                        'extrapolation': 'value = shard_value x naux / shard_rows (x %.3f): the whole iteration on the host cores of '
+                                         "rank 0's box" % (naux / float(nrow))})
         # parity at full size: the same rows through the HIP path
         sub = df.DF(mol)
         sub._cderi_dev = dfobj._cderi_dev[:nrow]
@@ -589,6 +618,7 @@ def main():
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
                    'naux_local': naux_local, 'naux_per_rank': naux_per_rank},
         'value_host_api_ms': round(host_api_ms, 3), 'host_api_ms_calls': [round(t, 2) for t in host_calls], 'host_api_fused_j': host_fused,
+        'host_api_breakdown_ms': host_breakdown,
         'roofline': roofline, 'roofline_step': step_roof,
         'cpu_baseline': cpu, 'comm': comm_info, 'preflight': preflight,
         'jk_schedule': jk_schedule,
@@ -605,20 +635,32 @@ def main():
                          'not a valid measurement' % parity_golden['max_rel_err'])
 
 
-def _pmc_passes(args):
+def _pmc_passes(args, shard=None, device=None):
     """{'FETCH_SIZE': {kernel: {'max', 'mean', 'n'}}, 'WRITE_SIZE': ...} in KiB per launch from two rocprofv3 --pmc passes of a short
-    child run of this file (counters alone with --kernel-trace, as the profiling guide prescribes; never with other trace domains)."""
+    child run of this file (counters alone with --kernel-trace, as the profiling guide prescribes; never with other trace domains).
+    shard = (r, w): the child builds and contracts rank r's rows of w only (what a rank of an N > 1 job launches), on HIP device
+    `device`, outside any process group (the launcher's rendezvous variables are removed from its environment)."""
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     short = ('e2_sq2_kernel', 'e2_sq_kernel', 'e2_pk_kernel', 'e2_symm_kernel', 'syrk_slots_kernel', 'gemm_tn_glds2_kernel',
              'gemm_tn_glds_kernel', 'vj_pass1_rows_kernel', 'vj_pass2_wide_kernel', 'vj_pass2_kernel')
     out = {}
     env = dict(os.environ, TMPDIR='/tmp')
+    for k in list(env):
+        if k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'ROLE_WORLD_SIZE', 'MASTER_ADDR',
+                 'MASTER_PORT', 'PAMD_DIST_BACKEND') or k.startswith('TORCHELASTIC_'):
+            del env[k]
+    if device is not None:
+        vis = [v for v in env.get('HIP_VISIBLE_DEVICES', '').split(',') if v != '']
+        env['HIP_VISIBLE_DEVICES'] = vis[device] if device < len(vis) else str(device)
     child = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '0', '--no-cpu-baseline', '--xc', '', '--pmc-child', '--no-pmc',
              '--nwater', str(args.nwater), '--molecule', args.molecule, '--k-square', args.k_square, '--j2-policy', args.j2_policy]
+    if shard is not None:
+        child += ['--pmc-shard', '%d,%d' % tuple(shard)]
     if args.basis:
         child += ['--basis', args.basis]
     if args.tune:
@@ -626,8 +668,15 @@ def _pmc_passes(args):
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         d = tempfile.mkdtemp(prefix='pamd_pmc_', dir='/tmp')
         try:
-            subprocess.run(['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--'] + child,
-                           cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+            # own session: a timeout ends the profiler AND the python under it (a survivor would keep its HBM on this device)
+            pr = subprocess.Popen(['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--'] + child,
+                                  cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.wait(timeout=180)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                raise
             agg = {}
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
                 for r in csv.DictReader(open(f)):

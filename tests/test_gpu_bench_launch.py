@@ -45,10 +45,43 @@ def test_bench_gpus2_launches_two_ranks():
     assert one['kernels']['e2_symm']['ms_total'] < one['ms_per_step']
     # r05: in-run correctness evidence and live HBM counters are part of every line (the golden exists for configs 3 / 4 only)
     for d in (one, two):
-        assert 'parity_golden' in d and d['parity_golden']['golden'] is None and 'why' in d['parity_golden']
+        assert d['parity_golden']['golden'] == 'tests/golden/h2o8_ccpvtz_oracle.json' and d['parity_golden']['ok'] is True
+        assert d['parity_golden']['max_rel_err'] < 1e-9
     import shutil
     if shutil.which('rocprofv3') and one['roofline']['traffic'] is not None:
         assert 'measured in this run' in one['roofline']['traffic_source'], one['roofline']['traffic_source']
+
+
+def test_bench_two_rank_line_is_complete():
+    """r06: an N > 1 line carries everything an N = 1 line does - `roofline` (with the traffic of rank 0's
+    shard MEASURED in the run under --pmc on, or scaled and labelled so), `cpu_baseline` (the reference C on rank 0's shard rows,
+    shard value + the extrapolation to all rows, labelled), `comm`, `parity_golden` - before it is ever run on 8 GPUs."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    import shutil
+    have_prof = shutil.which('rocprofv3') is not None
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--nwater', '8', '--steps', '2', '--warmup', '1', '--xc', '',
+                          '--gpus', '2', '--backend', 'gloo', '--cpu-threads', '16'] + (['--pmc', 'on'] if have_prof else []),
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    two = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert two['n_gpus'] == 2 and len(two['config']['naux_per_rank']) == 2
+    r = two['roofline']
+    assert r is not None and r['frac'] > 0 and 'traffic_measured_in_run' in r and r['traffic_source']
+    if have_prof and r['traffic'] is not None and r['traffic_measured_in_run']:
+        assert 'measured in this run' in r['traffic_source']
+    elif r['traffic'] is not None:
+        assert 'SCALED' in r['traffic_source']
+    c = two['cpu_baseline']
+    assert c is not None and c['value'] > 0 and c['kind'] in ('reference', 'port') and c['cores'] >= 1
+    assert c['shard_rows'] == two['config']['naux_per_rank'][0] and c['shard_value'] > 0 and 'extrapolation' in c
+    assert abs(c['value'] - c['shard_value'] * sum(two['config']['naux_per_rank']) / c['shard_rows']) < 0.2 + 1e-3 * c['value']
+    assert two['comm'] is not None and two['comm']['backend'] == 'gloo' and two['comm']['collectives_per_step'] >= 1
+    assert two['comm']['bytes_per_step'] > 0
+    assert two['parity_golden']['ok'] is True and two['parity_sample'] is not None
+    assert two['parity_sample']['max_abs_err_vk'] < 1e-8 and two['parity_sample']['max_abs_err_vj'] < 1e-8
+    assert isinstance(two['host_api_breakdown_ms'], list) and two['host_api_breakdown_ms'] and 'probe' in two['host_api_breakdown_ms'][0]
 
 
 def test_bench_refuses_a_world_size_mismatch():
