@@ -83,6 +83,8 @@ mf.conv_tol = 1e-10
 check('G5 DF-RHF e_tot through mf.with_df', mf.kernel(), -76.025936299702536, 1e-8)
 
 # G8 (DF-RKS B88,VWN, aux weigend) through pyscf.amd.density_fit: J/K handle + XC handle (mf._numint)
+# (the reference's test class switches the atom-specific Treutler grids off, pyscf/dft/test/test_h2o.py:86-89)
+dft.radi.ATOM_SPECIFIC_TREUTLER_GRIDS = False
 mol631 = gto.M(atom=H2O, basis='631g', verbose=0)
 mk2 = dft.RKS(mol631)
 mk2.xc = 'b88,vwn'
