@@ -113,6 +113,8 @@ def main():
     ap.add_argument('--k-square', default='auto', choices=['auto', 'off'], help="'off': no unpacked image - the K half transform "
                     "reads the packed rows (+ the diagonal-block side image, 14 %% of the tensor): what a rank without 2x the "
                     "tensor size of spare HBM runs")
+    ap.add_argument('--layout', default='auto', choices=['auto', 'square', 'packed'], help="DF.layout: 'square' rows as the only copy of "
+                    "the tensor (2x the packed bytes, r06), 'packed' rows (+ optional image), 'auto': square when the HBM budget allows")
     ap.add_argument('--j2-policy', default='auto', choices=['auto', 'overlap', 'serial', 'fused'], help='second J pass beside the SYRK on a '
                     'side stream, or in line before a re-tiled SYRK; auto: both timed once in the first (warm-up) build')
     ap.add_argument('--syrk-flags', type=int, default=-1, help='override DF.k_syrk_flags (A/B runs): 0 plain, 12 re-tiled + balanced')
@@ -210,6 +212,11 @@ def main():
         dfobj.k_syrk_flags = args.syrk_flags
     if args.k_square == 'off':
         dfobj.k_square = False
+    if args.layout != 'auto':
+        dfobj.layout = args.layout
+    if args.xc:
+        from pyscf_amd.dft.numint import estimate_ao_image_bytes
+        dfobj.xc_image_hint = estimate_ao_image_bytes(mol)      # what RKS.density_fit() tells the tensor object (one HBM budget)
     dfobj.j2_policy = args.j2_policy
     for kv in filter(None, args.tune.split(',')):
         k_, v_ = kv.split('=')
@@ -230,9 +237,11 @@ def main():
     dfobj.build()
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
+    hbm_after = {'allocated': round(torch.cuda.memory_allocated(dev) * 1e-9, 1), 'free': round(torch.cuda.mem_get_info(dev)[0] * 1e-9, 1)}
     naux = dfobj.get_naoaux()
     npair = nao * (nao + 1) // 2
-    naux_local = dfobj._cderi_dev.shape[0]
+    naux_local = dfobj.tensor_shape()[0]
+    square_layout = getattr(dfobj, '_layout', None) == 'square'
 
     # converged-like idempotent DM: Loewdin-orthogonalised random orbitals, seed 1
     s1e = hf.int1e_gpu(mol, dev)[0]
@@ -562,7 +571,7 @@ def main():
         nrow = min(nrow, naux_local)
         sample = np.empty((nrow, npair))
         for r0 in range(0, nrow, 240):                   # download in the reference's block size (no 2x staging copy)
-            sample[r0:r0 + 240] = dfobj._cderi_dev[r0:min(r0 + 240, nrow)].cpu().numpy()
+            sample[r0:r0 + 240] = dfobj.packed_rows(r0, min(r0 + 240, nrow)).cpu().numpy()
         if use_ref:
             # oracle/_ref/libref_dfjk.so = pyscf/lib/ao2mo/nr_ao2mo.c + pyscf/lib/np_helper/*.c compiled as they are, driven
             # call for call like pyscf/df/df_jk.py:329-381 (oracle/ref_c.get_jk): the reference's CPU path minus libcint
@@ -595,7 +604,10 @@ def main():
                                          "rank 0's box" % (naux / float(nrow))})
         # parity at full size: the same rows through the HIP path
         sub = df.DF(mol)
-        sub._cderi_dev = dfobj._cderi_dev[:nrow]
+        if square_layout:
+            sub._cderi_sq, sub._sq_nao, sub._layout = dfobj._cderi_sq[:nrow], nao, 'square'
+        else:
+            sub._cderi_dev = dfobj._packed[:nrow]
         vjt, vkd = df_jk.get_jk_device(_Single(sub), dms_dev, orb_list, True, True)
         vj1 = lib.unpack_tril(vjt.cpu().numpy(), 1)[0]
         vk1 = vkd.cpu().numpy()[0]
@@ -609,14 +621,16 @@ def main():
         'config': {'workload': '%s %s DF J/K build (aux %s), nao=%d naux=%d nocc=%d, B=%.1f GB in HBM%s'
                                % (label, args.basis, _aux_label(getattr(dfobj.auxmol, 'basis', 'auto')),
                                   nao, naux, nocc, 8e-9 * naux * npair,
-                                  ('' if getattr(dfobj, '_cderi_sq', None) is None else
+                                  (' held as SQUARE rows (%.1f GB: the only copy, r06)' % (8e-9 * dfobj._cderi_sq.numel()) if square_layout else
+                                   '' if getattr(dfobj, '_cderi_sq', None) is None else
                                    ' + unpacked image for the K half transform' + ('' if dfobj._cderi_sq.shape[0] == naux_local else
                                    ' (of %d of the %d aux rows: what fits)' % (dfobj._cderi_sq.shape[0], naux_local))) +
                                   ('' if getattr(dfobj, '_cderi_diag', None) is None else
                                    ' + diagonal-block image of %d packed rows (%.1f GB)' % (dfobj._cderi_diag.shape[0],
                                                                                             8e-9 * dfobj._cderi_diag.numel()))),
                    'parallelism': 'aux-index shards x%d + RCCL all-reduce' % world if world > 1 else 'single GPU',
-                   'naux_local': naux_local, 'naux_per_rank': naux_per_rank},
+                   'naux_local': naux_local, 'naux_per_rank': naux_per_rank, 'tensor_layout': getattr(dfobj, '_layout', None),
+                   'hbm_after_build_GB': hbm_after},
         'value_host_api_ms': round(host_api_ms, 3), 'host_api_ms_calls': [round(t, 2) for t in host_calls], 'host_api_fused_j': host_fused,
         'host_api_breakdown_ms': host_breakdown,
         'roofline': roofline, 'roofline_step': step_roof,
@@ -658,7 +672,7 @@ def _pmc_passes(args, shard=None, device=None):
         vis = [v for v in env.get('HIP_VISIBLE_DEVICES', '').split(',') if v != '']
         env['HIP_VISIBLE_DEVICES'] = vis[device] if device < len(vis) else str(device)
     child = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '0', '--no-cpu-baseline', '--xc', '', '--pmc-child', '--no-pmc',
-             '--nwater', str(args.nwater), '--molecule', args.molecule, '--k-square', args.k_square, '--j2-policy', args.j2_policy]
+             '--nwater', str(args.nwater), '--molecule', args.molecule, '--k-square', args.k_square, '--j2-policy', args.j2_policy, '--layout', args.layout]
     if shard is not None:
         child += ['--pmc-shard', '%d,%d' % tuple(shard)]
     if args.basis:

@@ -177,6 +177,18 @@ int PAMD_df_vj_pass1(const double *d_cderi, long npair, int naux, const double *
                      double *d_rho, double *d_work, void *stream);        /* rho[s][L] = B_L . dmtril_s */
 int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *d_rho, int nset,
                      double *d_vjtril, void *stream);                     /* vjtril[s] += rho_s^T B  */
+/* r06 - the SQUARE layout d_sq[naux][rows][ld] (both triangles of every B_L, rows = ld = round_up(nao, 16), pads zero; lstride =
+ * rows * ld) as the ONLY resident copy of the tensor (2x the packed bytes instead of packed + image = 3x): the same two J passes
+ * (pyscf/df/df_jk.py:329-337,367) reading the p >= q run of every square row; dmtril / vjtril stay packed */
+int PAMD_df_vj_pass1_sq(const double *d_sq, long lstride, int ld, int nao, int naux, const double *d_dmtril, int nset,
+                        double *d_rho, double *d_work, void *stream);
+int PAMD_df_vj_pass2_sq(const double *d_sq, long lstride, int ld, int nao, int naux, const double *d_rho, int nset,
+                        double *d_vjtril, void *stream);
+/* one column slab of the build (the AO rows [p0, p1) of every aux row as PAMD_cderi_solve leaves them in d_slab[nL][ncol];
+ * pyscf/df/incore.py:189-217) written into both triangles of the square layout */
+int PAMD_unpack_tril_slab(const double *d_slab, long ncol, int nL, int p0, int p1, double *d_sq, int ld, long lstride, void *stream);
+/* packed rows of the reference's `_cderi` format (pyscf/df/df.py:59-72, lib/np_helper/pack_tril.c:59-112) out of the square layout */
+int PAMD_pack_tril_rows(const double *d_sq, long lstride, int ld, int nao, int count, double *d_tril, void *stream);
 /* Half transform X[L][i][p] = sum_q B_L[p][q] orb[q][i] (AO2MOnr_e2_drv + AO2MOmmm_bra_nr_s2, nr_ao2mo.c:399-419,1240-1266):
  * d_orb [orb_rows][ldo], columns beyond the orbitals zero up to ldo = PAMD_e2_orb_ld(nocc_pad); d_out [nL][nocc_pad][ldx].
  * nocc_pad = rows of d_out per aux index: any value >= the number of orbitals (r04: no longer a multiple of 16 - with exactly
@@ -202,6 +214,10 @@ int PAMD_e2_diag_blocks(const double *d_cderi, long npair, int nL, int nao, int 
 int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, const double *d_orb, int ldo,
                       int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work,
                       void *stream);
+/* r06: the same with an explicit stride (doubles, even, >= rows * ld) between consecutive aux rows: the square LAYOUT pads it so that
+ * equal (p, q) of consecutive aux rows do not fall on one HBM channel (rows * ld * 8 is a multiple of 32 KB .. 8 MB at the named configs) */
+int PAMD_nr_e2_square_ls(const double *d_sq, long ld, int rows, long lstride, int nL, int nao, const double *d_orb, int ldo,
+                         int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream);
 /* d_rho (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] = sum_pq B_L[p][q] (orb orb^T)[p][q]: the first J pass
  * (df_jk.py:367) of the density the orbitals stand for, taken from the accumulators in the epilogue.  Deterministic: every
  * wave leaves one partial in d_rho_work (PAMD_nr_e2_rho_worksize doubles, required with d_rho) and a fixed-order reduction
@@ -358,6 +374,10 @@ typedef struct PAMD_df PAMD_df;
  *                         `nparts` (contiguous, row-balanced: DF.shard_range) on devices[0], out of core where they do not fit;
  *                         PAMD_df_get_jk returns that shard's PARTIAL J/K, the caller sums over the ranks (the accumulation over
  *                         `dfobj.loop()` blocks of pyscf/df/df_jk.py:362-381, spread over processes)
+ *                         flags bit 2 (r06): reserve_bytes is valid - what the XC leg of the same calculation will cache per device
+ *                         (one budget: tensor, X block, XC compact image, work space).  The rows are held in the SQUARE layout
+ *                         (both triangles, padded aux-row stride, 2x the packed bytes and NO second copy) when that fits with the
+ *                         reserve, else packed as the reference's `_cderi` (pyscf/df/df.py:59-72) with the optional image
  *   PAMD_df_shard_info    info[4] = {first global row, rows held, rows of the whole tensor, 1 = partial sums}
  *   PAMD_df_last_timing   timings of the last PAMD_df_get_jk: out[3 + 5 parts] = {parts, host ms of sum + download on part 0, peer
  *                         copies used 0/1, then per part: host ms contraction, host ms push into the gather buffer, bytes pushed
@@ -373,6 +393,7 @@ typedef struct PAMD_df_options {
     long long max_device_bytes; /* 0: whatever the device has free */
     int part;                   /* flags bit 1 only: this handle holds shard `part` ... */
     int nparts;                 /* ... of `nparts` contiguous row-balanced shards (one rank of a multi-process job) */
+    long long reserve_bytes;    /* flags bit 2 (r06): HBM to leave free per device besides the J/K work space (see above) */
 } PAMD_df_options;
 int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                       const PAMD_df_options *opt, PAMD_df **out);
@@ -385,6 +406,7 @@ int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, 
  * memory (must outlive the handle) instead of a page-locked copy. */
 int PAMD_df_create_from_rows(const double *rows, int nrows, int nao, int device, long long max_device_bytes, int flags, PAMD_df **out);
 int PAMD_df_layout(const PAMD_df *h, long *layout, int *part_rows);
+int PAMD_df_tensor_layout(const PAMD_df *h);     /* 1: every part holds its rows in the square layout only (r06); 0: packed rows */
 int PAMD_df_shard_info(const PAMD_df *h, int *info);
 int PAMD_df_last_timing(const PAMD_df *h, double *out, int nout);
 /* the metric factorisation alone (df/incore.py:150-158, :263-270; decompose_j2c = 'ED' with force_ed): host j2c[naux][naux] ->

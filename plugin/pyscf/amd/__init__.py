@@ -59,6 +59,8 @@ def density_fit(mf, auxbasis=None, devices=None):
     mf.with_df = DF(mf.mol, auxbasis, devices=devs)
     if hasattr(mf, '_numint'):
         mf._numint = NativeNumInt(devices=devs)
+        from pyscf_amd.dft.numint import estimate_ao_image_bytes
+        mf.with_df.xc_image_hint = estimate_ao_image_bytes(mf.mol)        # one HBM budget: the tensor leaves room for the AO cache
     return mf
 
 

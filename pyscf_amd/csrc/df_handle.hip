@@ -251,6 +251,12 @@ struct PAMD_df {
     hipStream_t st = nullptr, side = nullptr, copy = nullptr;
     hipEvent_t ev = nullptr, ev_j = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     double *d_cderi = nullptr, *d_sq = nullptr, *d_diag = nullptr;
+    int square = 0;                         // r06: 1 = d_sq[nL][rows][rows] is the ONLY copy of the rows (d_cderi is null): 2x, not 3x
+    // doubles between consecutive aux rows of d_sq (an explicit argument of every kernel that walks them).  A pad of 288 doubles was
+    // measured for the square LAYOUT (rows * rows * 8 is a multiple of 32 KB .. 8 MB at the named configurations; suspicion: the equal
+    // (p, q) of consecutive rows share one HBM channel) - no difference (profiles/r06/kbench_square_layout.log), so none is applied
+    static constexpr long SQ_STRIDE_PAD = 0;
+    long sq_ls() const { return (long)rows * rows + (square ? SQ_STRIDE_PAD : 0); }
     int n_res = 0;                          // rows [0, n_res) resident in HBM, rows [n_res, nL) in h_cderi
     double *h_cderi = nullptr;              // host rows, (nL - n_res) x npair: page-locked memory of the handle, or (h_borrowed) the caller's
     int h_borrowed = 0, h_registered = 0;   // PAMD_df_create_from_rows: rows stay in the caller's array (e.g. an mmap of a `_cderi` file)
@@ -787,8 +793,9 @@ int compute_metric(PAMD_df *h, const Engine &e, DevPool &tmp, double lindep, Met
     return 0;
 }
 
-int build_square_image(PAMD_df *h, size_t cap_left)
+int build_square_image(PAMD_df *h, size_t cap_left, size_t reserve)
 {
+    if (h->square) return 0;
     // K path on the unpacked image when HBM allows (DF.k_square = 'auto': 48 GB must stay free afterwards);
     // PAMD_DF_SQUARE=0 in the environment = DF.k_square = False (tests, memory-constrained callers)
     const char *env = getenv("PAMD_DF_SQUARE");
@@ -796,7 +803,7 @@ int build_square_image(PAMD_df *h, size_t cap_left)
     size_t free_b = 0, total_b = 0;
     PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t need = ((size_t)h->nL * h->rows * h->rows + 256) * 8;
-    if (h->nL == 0 || h->n_res < h->nL || need + (48ul << 30) > free_b || need > cap_left) return 0;
+    if (h->nL == 0 || h->n_res < h->nL || need + (48ul << 30) + reserve > free_b || need > cap_left) return 0;
     int rc = h->pool.alloc((void **)&h->d_sq, need);
     if (rc) { h->d_sq = nullptr; return 0; }
     PAMD_CHECK_HIP(hipMemsetAsync(h->d_sq, 0, need, h->st));
@@ -807,7 +814,7 @@ int build_square_image(PAMD_df *h, size_t cap_left)
 // that the packed-operand half transform reads the k-tiles crossing the diagonal once and unmasked (DF.diag_image)
 int build_diag_image(PAMD_df *h, size_t cap_left)
 {
-    if (h->d_sq || h->nL == 0 || h->n_res < h->nL || h->nao < 128) return 0;
+    if (h->square || h->d_sq || h->nL == 0 || h->n_res < h->nL || h->nao < 128) return 0;
     size_t free_b = 0, total_b = 0;
     PAMD_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t need = (size_t)PAMD_e2_diag_size(h->nL, h->rows) * 8;
@@ -819,7 +826,12 @@ int build_diag_image(PAMD_df *h, size_t cap_left)
 
 // Rows [h->l0, h->l0 + h->nL) of the tensor, AO-row slab by slab (df/incore.py:189-217): into HBM as far as `max_device_bytes`
 // (0: the device's free memory) allows, the remaining rows into page-locked host memory through a staging buffer.
-int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_t max_device_bytes)
+// r06 - one layout, one budget: when 2x the packed rows, the build's work slabs and what the rest of the
+// calculation needs afterwards (half-transform block 12 GB + 4 GB of J/K work space + `reserve`, the XC leg's compact AO image and
+// work buffers as the caller states them in PAMD_df_options.reserve_bytes) fit the device, the rows are built STRAIGHT INTO the
+// square layout d_sq[nL][rows][rows] - every column slab is solved into a work slab and scattered into both triangles
+// (PAMD_unpack_tril_slab) - and no packed copy exists.  PAMD_DF_LAYOUT=packed|square overrides; PAMD_DF_SQUARE=0 = packed.
+int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_t max_device_bytes, size_t reserve)
 {
     int rc;
     const Tables &t = *e.t;
@@ -837,7 +849,21 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
     size_t slab_bytes = std::min<size_t>(24ul << 30, (size_t)npair * naux * 8);
     const size_t margin = std::min<size_t>(1ul << 30, cap / 16);
     size_t stage_b = 0;
-    if (tensor_b + npass * slab_bytes + margin <= cap) {
+    {
+        const char *lay = getenv("PAMD_DF_LAYOUT"), *sqenv = getenv("PAMD_DF_SQUARE");
+        const size_t sq_b = ((size_t)nL * ((size_t)h->rows * h->rows + PAMD_df::SQ_STRIDE_PAD) + 256) * 8;
+        const size_t slab12 = std::min<size_t>(12ul << 30, slab_bytes);
+        const size_t out_b = std::min<size_t>(slab12, (size_t)((double)slab12 * std::max(nL, 1) / std::max(naux, 1)) + (1ul << 20));
+        const size_t after = sq_b + (12ul << 30) + (4ul << 30) + reserve;
+        bool want = nL > 0 && h->nao >= 128 && sq_b + npass * slab12 + out_b + margin <= cap && after <= cap;
+        if (lay && lay[0] == 'p') want = false;
+        if (sqenv && sqenv[0] == '0') want = false;
+        if (lay && lay[0] == 's' && nL > 0 && sq_b + npass * slab12 + out_b + margin <= cap) want = true;
+        if (want) { h->square = 1; slab_bytes = slab12; }
+    }
+    if (h->square) {
+        h->n_res = nL;
+    } else if (tensor_b + npass * slab_bytes + margin <= cap) {
         h->n_res = nL;
     } else {
         // out of core: a share of the cap each for the slab work space, the two staging buffers and the J/K work space
@@ -875,7 +901,11 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
         for (int k = 0; k < 2; k++)
             if ((rc = h->pool.alloc((void **)&h->d_stage[k], (size_t)h->stage_rows * row_b + 256 * 8))) return rc;
     }
-    if (h->n_res && (rc = h->pool.alloc((void **)&h->d_cderi, (size_t)h->n_res * row_b + 256 * 8))) return rc;
+    if (h->square) {
+        const size_t sq_b = ((size_t)nL * h->sq_ls() + 256) * 8;
+        if ((rc = h->pool.alloc((void **)&h->d_sq, sq_b))) return rc;
+        PAMD_CHECK_HIP(hipMemsetAsync(h->d_sq, 0, sq_b, h->st));             // pads (rows / columns >= nao) and the slack stay zero
+    } else if (h->n_res && (rc = h->pool.alloc((void **)&h->d_cderi, (size_t)h->n_res * row_b + 256 * 8))) return rc;
     const long max_rows = std::max<long>((long)(slab_bytes / ((size_t)naux * 8)), 1);
     std::vector<std::pair<int, int>> slabs;
     long bufrows = 0;
@@ -892,7 +922,8 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
         slabs.push_back({sh0, sh1});
         sh0 = sh1;
     }
-    double *d_T = nullptr, *d_T2 = nullptr;
+    double *d_T = nullptr, *d_T2 = nullptr, *d_slab = nullptr;
+    if (h->square && (rc = tmp.alloc((void **)&d_slab, (size_t)std::max(nL, 1) * bufrows * 8))) return rc;
     if ((rc = tmp.alloc((void **)&d_T, (size_t)bufrows * naux * 8))) return rc;
     if (npass == 2 && (rc = tmp.alloc((void **)&d_T2, (size_t)bufrows * naux * 8))) return rc;
     for (auto &sl : slabs) {
@@ -911,6 +942,12 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
             return 0;
         });
         if (rc) return rc;
+        if (h->square) {
+            const int p0 = t.ao.ao0[sl.first], p1 = sl.second < t.ao.n ? t.ao.ao0[sl.second] : t.ao.nao;
+            if ((rc = PAMD_cderi_solve(d_mt + h->l0, m.lda, d_T, naux, d_slab, ncol, nL, ncol, naux, h->l0, m.tri, h->st))) return rc;
+            if ((rc = PAMD_unpack_tril_slab(d_slab, ncol, nL, p0, p1, h->d_sq, h->rows, h->sq_ls(), h->st))) return rc;
+            continue;
+        }
         if (h->n_res &&
             (rc = PAMD_cderi_solve(d_mt + h->l0, m.lda, d_T, naux, h->d_cderi + r0, npair, h->n_res, ncol, naux, h->l0, m.tri, h->st)))
             return rc;
@@ -926,10 +963,11 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
     PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
     tmp.release(d_T);
     if (d_T2) tmp.release(d_T2);
+    if (d_slab) tmp.release(d_slab);
     tmp.release(d_mt);
     const size_t held = (size_t)h->n_res * row_b + 2 * stage_b;
     const size_t cap_left = max_device_bytes ? (cap > held ? cap - held : 0) : ~(size_t)0;
-    if ((rc = build_square_image(h, cap_left))) return rc;
+    if ((rc = build_square_image(h, cap_left, reserve))) return rc;
     if ((rc = build_diag_image(h, cap_left))) return rc;
     PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
     return 0;
@@ -937,7 +975,7 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
 
 // one shard, start to finish, on the calling thread: `metric` is computed here (and returned) when m->nrow == 0 on entry
 int create_shard(const Tables &t, int device, double omega, double lindep, size_t max_device_bytes, Metric *m, int part, int nparts,
-                 PAMD_df **out)
+                 PAMD_df **out, size_t reserve = 0)
 {
     *out = nullptr;
     PAMD_CHECK_HIP(hipSetDevice(device));
@@ -955,7 +993,7 @@ int create_shard(const Tables &t, int device, double omega, double lindep, size_
     h->nL_total = m->nrow;
     h->l0 = part * base + std::min(part, rem);
     h->nL = base + (part < rem ? 1 : 0);
-    if ((rc = build_rows(h, e, tmp, *m, max_device_bytes))) return rc;
+    if ((rc = build_rows(h, e, tmp, *m, max_device_bytes, reserve))) return rc;
     guard.p = nullptr;
     *out = h;
     return 0;
@@ -1008,6 +1046,17 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
     const size_t n2 = (size_t)nao * nao;
     const bool streamed = h->n_res < nL;
     if (streamed) serial_j2 = 1;           // the staged rows are released when the main stream is done with them
+    if (h->square && serial_j2 == 2) serial_j2 = 0;     // the in-SYRK pass streams PACKED rows: not a schedule of the square layout
+    const long lstride = h->sq_ls();
+    // the J passes over aux rows [b0, b0 + nb) of a segment, from whichever layout holds them (square: the p >= q runs)
+    auto j_pass1 = [&](const double *rows_pk, const double *rows_sq, int nb, const double *dt, int ns, double *rho, double *work, hipStream_t s_) {
+        return rows_pk ? PAMD_df_vj_pass1(rows_pk, npair, nb, dt, ns, rho, work, s_)
+                       : PAMD_df_vj_pass1_sq(rows_sq, lstride, h->rows, nao, nb, dt, ns, rho, work, s_);
+    };
+    auto j_pass2 = [&](const double *rows_pk, const double *rows_sq, int nb, const double *rho, int ns, double *vjt, hipStream_t s_) {
+        return rows_pk ? PAMD_df_vj_pass2(rows_pk, npair, nb, rho, ns, vjt, s_)
+                       : PAMD_df_vj_pass2_sq(rows_sq, lstride, h->rows, nao, nb, rho, ns, vjt, s_);
+    };
     double *d_vjt = nullptr, *d_vk = nullptr, *d_rho = nullptr, *d_dt = nullptr, *d_w1 = nullptr, *d_part = nullptr;
     const bool fused = with_j && with_k && orbo && (flags & 1) && nL > 0;
     // the matrix itself is needed on the device for J from the matrix and for the general-DM K branch only: with J taken from the
@@ -1041,7 +1090,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
     }
     // ---- rows as the kernels will see them
     std::vector<Seg> segs;
-    if (h->n_res > 0) segs.push_back({h->d_cderi, h->n_res, 0, h->d_sq, h->d_diag, -1});
+    if (h->n_res > 0) segs.push_back({h->d_cderi, h->n_res, 0, h->d_sq, h->d_diag, -1});     // (square layout: rows = null, sq = the rows)
     for (int b0 = h->n_res, k = 0; b0 < nL; b0 += h->stage_rows, k ^= 1)
         segs.push_back({h->d_stage[k], std::min(h->stage_rows, nL - b0), b0, nullptr, nullptr, k});
     int max_seg = 0;
@@ -1164,8 +1213,8 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                 // rho of 4 sets at a time: [ns][n] contiguous for the kernels, then scattered into rho[s][row0 ..]
                 double *d_rs = h->workspace("rho_seg", (size_t)4 * std::max(max_seg, 1), &rc);
                 if (rc) return rc;
-                if ((rc = PAMD_df_vj_pass1(sg.rows, npair, sg.n, d_dt + (size_t)s0 * npair, ns, d_rs, d_w1, st))) return rc;
-                if ((rc = PAMD_df_vj_pass2(sg.rows, npair, sg.n, d_rs, ns, d_vjt + (size_t)s0 * npair, st))) return rc;
+                if ((rc = j_pass1(sg.rows, sg.sq, sg.n, d_dt + (size_t)s0 * npair, ns, d_rs, d_w1, st))) return rc;
+                if ((rc = j_pass2(sg.rows, sg.sq, sg.n, d_rs, ns, d_vjt + (size_t)s0 * npair, st))) return rc;
             }
             PAMD_CHECK_HIP(hipEventRecord(h->ev_j, st));
             j_on_st = true;
@@ -1192,12 +1241,13 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                 }
                 for (long b0 = 0; b0 < sg.n; b0 += blk) {
                     const int nb = (int)std::min<long>(blk, sg.n - b0);
-                    const double *sub = sg.rows + (size_t)b0 * npair;
+                    const double *sub = sg.rows ? sg.rows + (size_t)b0 * npair : nullptr;
+                    const double *sub_sq = sg.sq ? sg.sq + (size_t)b0 * lstride : nullptr;
                     double *rho_b = fused ? d_rho + (size_t)s * nL + sg.row0 + b0 : nullptr;
                     mark(0);
                     if (sg.sq)
-                        rc = PAMD_nr_e2_square(sg.sq + (size_t)b0 * rows * rows, rows, rows, nb, nao, o.d_orb, (int)o.ldo, rows, xr,
-                                               d_X, ldx, rho_b, d_rw, st);
+                        rc = PAMD_nr_e2_square_ls(sub_sq, rows, rows, lstride, nb, nao, o.d_orb, (int)o.ldo, rows, xr,
+                                                  d_X, ldx, rho_b, d_rw, st);
                     else
                         rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, o.d_orb, (int)o.ldo, rows, xr, d_X, ldx, rho_b, d_rw,
                                                   sg.diag ? sg.diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st);
@@ -1206,13 +1256,13 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                     if (fused && serial_j2 != 2) {
                         // second J pass of this block: in line, or on the side stream beside the block's SYRK (HBM- beside MFMA-bound)
                         if (serial_j2) {
-                            if ((rc = PAMD_df_vj_pass2(sub, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, st))) return rc;
+                            if ((rc = j_pass2(sub, sub_sq, nb, rho_b, 1, d_vjt + (size_t)s * npair, st))) return rc;
                             PAMD_CHECK_HIP(hipEventRecord(h->ev_j, st));
                             j_on_st = true;
                         } else {
                             PAMD_CHECK_HIP(hipEventRecord(h->ev, st));
                             PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev, 0));
-                            if ((rc = PAMD_df_vj_pass2(sub, npair, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side))) return rc;
+                            if ((rc = j_pass2(sub, sub_sq, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side))) return rc;
                         }
                     }
                     const long kx = (long)nb * xr, kx16 = round_up(kx, 16);
@@ -1246,19 +1296,28 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                 if (rc) return rc;
                 // rows with an unpacked image: it IS the second operand (no per-block unpack) and feeds the square-image kernel
                 double *d_full = nullptr;
-                if (!sg.sq) {
+                const bool padded = sg.sq && lstride != (long)rows * rows;      // square LAYOUT: the aux rows are not one tall matrix
+                if (!sg.sq || padded) {
                     d_full = h->workspace("full", (size_t)blk * rows * ldx, &rc);
                     if (rc) return rc;
                     PAMD_CHECK_HIP(hipMemsetAsync(d_full, 0, (size_t)blk * rows * ldx * 8, st));
                 }
                 for (long b0 = 0; b0 < sg.n; b0 += blk) {
                     const int nb = (int)std::min<long>(blk, sg.n - b0);
-                    const double *sub = sg.rows + (size_t)b0 * npair;
+                    const double *sub = sg.rows ? sg.rows + (size_t)b0 * npair : nullptr;
                     const double *second = d_full;
                     if (sg.sq) {
-                        second = sg.sq + (size_t)b0 * rows * rows;
-                        if ((rc = PAMD_nr_e2_square(second, rows, rows, nb, nao, d_orb_dm, (int)ldo_dm, rows, rows, d_X, ldx, nullptr, nullptr, st)))
+                        second = sg.sq + (size_t)b0 * lstride;
+                        if ((rc = PAMD_nr_e2_square_ls(second, rows, rows, lstride, nb, nao, d_orb_dm, (int)ldo_dm, rows, rows, d_X, ldx, nullptr,
+                                                       nullptr, st)))
                             return rc;
+                        if (padded) {
+                            // the product below reads consecutive aux rows as ONE tall matrix: a contiguous copy of the block (a device
+                            // copy against 4 nb nao^3 flops; the general-DM branch is the rare one, df_jk.py:382-407)
+                            PAMD_CHECK_HIP(hipMemcpy2DAsync(d_full, (size_t)rows * rows * 8, second, (size_t)lstride * 8, (size_t)rows * rows * 8, nb,
+                                                            hipMemcpyDeviceToDevice, st));
+                            second = d_full;
+                        }
                     } else {
                         if ((rc = PAMD_nr_e2_symm_diag(sub, npair, nb, nao, d_orb_dm, (int)ldo_dm, rows, rows, d_X, ldx, nullptr, nullptr,
                                                        sg.diag ? sg.diag + (size_t)PAMD_e2_diag_size((int)b0, ldx) : nullptr, st))) return rc;
@@ -1324,14 +1383,14 @@ static int shard_get_jk(PAMD_df *h, const double *dm, const double *orbo, const 
             auto it = h->j2_policy.find(key);
             if (it == h->j2_policy.end()) {
                 double ms[3] = {0, 0, 0};
-                for (int trial = 0; trial < 4; trial++) {             // overlap (priming, untimed), overlap, serial, fused into the SYRK
+                for (int trial = 0; trial < (h->square ? 3 : 4); trial++) {   // overlap (priming, untimed), overlap, serial, fused into the SYRK (packed rows only)
                     const auto t0 = std::chrono::steady_clock::now();
                     const int rc = df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, trial ? trial - 1 : 0, download);
                     if (rc) return rc;
                     if (trial) ms[trial - 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 }
                 int best = ms[1] < 0.99 * ms[0] ? 1 : 0;
-                if (ms[2] < 0.99 * ms[best]) best = 2;
+                if (!h->square && ms[2] < 0.99 * ms[best]) best = 2;
                 it = h->j2_policy.emplace(key, best).first;
             }
             serial = it->second;
@@ -1511,6 +1570,9 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
     int rc;
     if ((rc = make_tables(atm, bas, nbas_ao, nbas_aux, env, &t))) return rc;
     const size_t cap = opt->max_device_bytes > 0 ? (size_t)opt->max_device_bytes : 0;
+    // flags bit 2 (r06): reserve_bytes is valid - HBM the caller's calculation wants left free on every device besides the J/K work
+    // space (the XC leg's compact AO image and work buffers): part of the layout decision of build_rows
+    const size_t reserve = (opt->flags & 4) && opt->reserve_bytes > 0 ? (size_t)opt->reserve_bytes : 0;
     Metric m;
     if (opt->flags & 2) {
         // one rank's shard of a multi-process job: rows of part `part` of `nparts` (DF.shard_range) on devices[0], resident as
@@ -1518,7 +1580,7 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
         // returns this shard's PARTIAL J/K and the caller sums over the ranks (RCCL all-reduce in pyscf_amd.df.DF)
         PAMD_REQUIRE(opt->nparts > 0 && opt->part >= 0 && opt->part < opt->nparts, "PAMD_df_create: part / nparts");
         PAMD_df *h = nullptr;
-        if ((rc = create_shard(t, devs[0], opt->omega, opt->lindep, cap, &m, opt->part, opt->nparts, &h))) return rc;
+        if ((rc = create_shard(t, devs[0], opt->omega, opt->lindep, cap, &m, opt->part, opt->nparts, &h, reserve))) return rc;
         h->partial = opt->nparts > 1;
         *out = h;
         return 0;
@@ -1526,7 +1588,7 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
     if (opt->ndev <= 0 || (ndev == 1 && !(opt->flags & 1))) {
         // the plain single-device handle
         PAMD_df *h = nullptr;
-        if ((rc = create_shard(t, devs[0], opt->omega, opt->lindep, cap, &m, 0, 1, &h))) return rc;
+        if ((rc = create_shard(t, devs[0], opt->omega, opt->lindep, cap, &m, 0, 1, &h, reserve))) return rc;
         *out = h;
         return 0;
     }
@@ -1537,14 +1599,14 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
     mh->parts.assign(ndev, nullptr);
     // part 0 factorises the metric on its device; the host copy of M^T is then shared by all parts, which build their row
     // ranges concurrently, one host thread per part (the raw (Q|pq) slabs are generated redundantly: ~0.1 s at config 3)
-    if ((rc = create_shard(t, devs[0], opt->omega, opt->lindep, cap, &m, 0, ndev, &mh->parts[0]))) return rc;
+    if ((rc = create_shard(t, devs[0], opt->omega, opt->lindep, cap, &m, 0, ndev, &mh->parts[0], reserve))) return rc;
     std::vector<PAMD_df *> rest(ndev - 1, nullptr);
     {
         std::vector<PartResult> res(ndev - 1);
         std::vector<std::thread> th;
         for (int p = 1; p < ndev; p++)
             th.emplace_back([&, p]() {
-                res[p - 1].rc = create_shard(t, devs[p], opt->omega, opt->lindep, cap, &m, p, ndev, &rest[p - 1]);
+                res[p - 1].rc = create_shard(t, devs[p], opt->omega, opt->lindep, cap, &m, p, ndev, &rest[p - 1], reserve);
                 if (res[p - 1].rc) res[p - 1].msg = g_errmsg;
             });
         for (auto &x : th) x.join();
@@ -1724,7 +1786,7 @@ int PAMD_df_create_from_rows(const double *rows, int nrows, int nao, int device,
     }
     const size_t held = (size_t)h->n_res * row_b + 2 * stage_b;
     const size_t cap_left = cap_in ? (cap > held ? cap - held : 0) : ~(size_t)0;
-    if ((rc = build_square_image(h, cap_left))) return rc;
+    if ((rc = build_square_image(h, cap_left, 0))) return rc;
     if ((rc = build_diag_image(h, cap_left))) return rc;
     PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
     guard.p = nullptr;
@@ -1791,9 +1853,32 @@ int PAMD_df_layout(const PAMD_df *h, long *layout, int *part_rows)
     return 0;
 }
 
+int PAMD_df_tensor_layout(const PAMD_df *h)
+{
+    if (!h) return 0;
+    if (h->parts.empty()) return h->square;
+    for (const PAMD_df *p : h->parts) if (!p->square) return 0;
+    return 1;
+}
+
 static int shard_export(PAMD_df *h, int l0, int l1, double *out)      // shard-local rows
 {
     PAMD_CHECK_HIP(hipSetDevice(h->device));
+    if (h->square) {
+        // the reference's packed rows (pyscf/df/df.py:59-72) out of the square layout: packed on the device block by block
+        const int blk = (int)std::max<size_t>(1, (1ul << 30) / ((size_t)h->npair * 8));
+        int rc;
+        double *d_tmp = h->workspace("export", (size_t)std::min(blk, std::max(l1 - l0, 1)) * h->npair, &rc);
+        if (rc) return rc;
+        for (int b0 = l0; b0 < l1; b0 += blk) {
+            const int nb = std::min(blk, l1 - b0);
+            if ((rc = PAMD_pack_tril_rows(h->d_sq + (size_t)b0 * h->sq_ls(), h->sq_ls(), h->rows, h->nao, nb, d_tmp, h->st)))
+                return rc;
+            PAMD_CHECK_HIP(hipMemcpyAsync(out + (size_t)(b0 - l0) * h->npair, d_tmp, (size_t)nb * h->npair * 8, hipMemcpyDeviceToHost, h->st));
+            PAMD_CHECK_HIP(hipStreamSynchronize(h->st));
+        }
+        return 0;
+    }
     const int r1 = std::min(l1, h->n_res);
     if (l0 < r1)
         PAMD_CHECK_HIP(hipMemcpy(out, h->d_cderi + (size_t)l0 * h->npair, (size_t)(r1 - l0) * h->npair * 8, hipMemcpyDeviceToHost));

@@ -171,6 +171,137 @@ __global__ __launch_bounds__(256) void vj_pass2_wide_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------ r06: J on the SQUARE layout
+// sq[L][p][q] (rows x ld doubles per aux row, both triangles, pads zero) is the ONLY copy of the tensor when DF.layout = 'square'
+// (2x the packed size in HBM instead of packed + image = 3x).  The J passes read the p >= q run of every
+// square row - the same 8 nao_pair bytes per aux row as the packed layout, in runs of (p + 1) doubles that start on a 128-byte
+// boundary (ld % 16 == 0) - and keep the PACKED density / result vectors (pyscf/df/df_jk.py:329-337,367).
+__device__ __forceinline__ void tril_pq(long i, int &p, int &q)
+{
+    p = (int)((sqrt(8.0 * (double)i + 1.0) - 1.0) * 0.5);
+    while ((long)(p + 1) * (p + 2) / 2 <= i) p++;
+    while ((long)p * (p + 1) / 2 > i) p--;
+    q = (int)(i - (long)p * (p + 1) / 2);
+}
+
+template <int NSET>
+__global__ __launch_bounds__(J1_THREADS) void vj_pass1_sq_kernel(
+    const double *__restrict__ sq, long lstride, int ld, long npair, int naux, const double *__restrict__ dmtril,
+    double *__restrict__ partial, int nchunk)
+{
+    const int chunk = blockIdx.x;
+    const int L0 = blockIdx.y * J1R;
+    const long base = (long)chunk * J1_CHUNK2 + threadIdx.x;
+    double d[NSET][J1E];
+    long off[J1E];
+#pragma unroll
+    for (int e = 0; e < J1E; e++) {
+        const long i = base + e * J1_THREADS;
+        int p = 0, q = 0;
+        if (i < npair) tril_pq(i, p, q);
+        off[e] = (i < npair) ? (long)p * ld + q : -1;
+#pragma unroll
+        for (int s = 0; s < NSET; s++) d[s][e] = (i < npair) ? dmtril[(long)s * npair + i] : 0.0;
+    }
+    __shared__ double red[J1R][NSET][J1_THREADS / 64];
+    const int nrow = (naux - L0 < J1R) ? naux - L0 : J1R;
+    for (int r = 0; r < nrow; r++) {
+        const double *row = sq + (long)(L0 + r) * lstride;
+        double b[J1E];
+#pragma unroll
+        for (int e = 0; e < J1E; e++) b[e] = (off[e] >= 0) ? __builtin_nontemporal_load(row + off[e]) : 0.0;
+#pragma unroll
+        for (int s = 0; s < NSET; s++) {
+            double v = 0;
+#pragma unroll
+            for (int e = 0; e < J1E; e++) v += b[e] * d[s][e];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((threadIdx.x & 63) == 0) red[r][s][threadIdx.x >> 6] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nrow * NSET) {
+        const int r = threadIdx.x / NSET, s = threadIdx.x - r * NSET;
+        double v = 0;
+        for (int w = 0; w < J1_THREADS / 64; w++) v += red[r][s][w];
+        partial[((long)s * naux + L0 + r) * nchunk + chunk] = v;
+    }
+}
+
+template <int NSET>
+__global__ __launch_bounds__(256) void vj_pass2_sq_kernel(
+    const double *__restrict__ sq, long lstride, int ld, long npair, int naux, const double *__restrict__ rho,
+    double *__restrict__ vj)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npair; i += (long)gridDim.x * 256) {
+        int p, q;
+        tril_pq(i, p, q);
+        double acc[NSET];
+#pragma unroll
+        for (int s = 0; s < NSET; s++) acc[s] = 0;
+        const double *col = sq + (long)p * ld + q;
+        int L = 0;
+        for (; L + 8 <= naux; L += 8) {
+            double b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) b[u] = __builtin_nontemporal_load(col + (long)(L + u) * lstride);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int s = 0; s < NSET; s++) acc[s] += rho[s * naux + L + u] * b[u];
+        }
+        for (; L < naux; L++) {
+            const double b = col[(long)L * lstride];
+#pragma unroll
+            for (int s = 0; s < NSET; s++) acc[s] += rho[s * naux + L] * b;
+        }
+#pragma unroll
+        for (int s = 0; s < NSET; s++) vj[(long)s * npair + i] += acc[s];
+    }
+}
+
+// sq[L][p][q] = sq[L][q][p] = slab[L][p (p + 1) / 2 + q - r0] for the AO rows p in [p0, p1) of one column slab of the build
+// (df/incore.py:189-217 solves the tensor column slab by column slab): 32 x 32 tiles through LDS so that both the direct rows and
+// the mirrored column runs are written coalesced.  grid (ceil(p1 / 32) q-tiles, ceil((p1 - p0) / 32) p-tiles, nL)
+__global__ __launch_bounds__(256) void unpack_slab_kernel(const double *__restrict__ slab, long ncol, long r0, int p0, int p1,
+                                                          double *__restrict__ sq, int ld, long lstride)
+{
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int pb = p0 + blockIdx.y * 32, qb = blockIdx.x * 32;
+    if (qb > pb + 31) return;                                    // the whole tile lies above the diagonal
+    const long L = blockIdx.z;
+    const double *src = slab + L * ncol;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = pb + ty + 8 * k, q = qb + tx;
+        t[ty + 8 * k][tx] = (p < p1 && q <= p) ? src[(long)p * (p + 1) / 2 + q - r0] : 0.0;
+    }
+    __syncthreads();
+    double *dst = sq + L * lstride;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = pb + ty + 8 * k, q = qb + tx;
+        if (p < p1 && q <= p) dst[(long)p * ld + q] = t[ty + 8 * k][tx];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = qb + ty + 8 * k, p = pb + tx;
+        if (p < p1 && q < p) dst[(long)q * ld + p] = t[tx][ty + 8 * k];
+    }
+}
+
+// tril[L][p (p + 1) / 2 + q] = sq[L][p][q]: the reference's `_cderi` rows (pyscf/df/df.py:59-72) out of the square layout, for
+// DF.loop / export / the consumers that want the packed operand
+__global__ __launch_bounds__(256) void pack_rows_kernel(const double *__restrict__ sq, long lstride, int ld, int nao,
+                                                        double *__restrict__ tril, long npair)
+{
+    const int p = blockIdx.y;
+    const long L = blockIdx.z;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q <= p; q += gridDim.x * 256)
+        tril[L * npair + (long)p * (p + 1) / 2 + q] = sq[L * lstride + (long)p * ld + q];
+}
+
 // ------------------------------------------------------------------------------------ K
 // X[L][i][p] = sum_q Bsym_L[q][p] * orb[q][i]: grid x = p tile (128 cols), y = L, z = chunk of MT*16 orbitals
 // (body and operand conventions: mfma_e2.h)
@@ -1617,6 +1748,75 @@ int PAMD_df_vj_pass2(const double *d_cderi, long npair, int naux, const double *
     return 0;
 }
 
+// r06: the J passes of PAMD_df_vj_pass1 / _pass2 on the SQUARE layout d_sq[naux][rows][ld] (lstride = rows * ld doubles per aux
+// row; the p >= q runs are read, dmtril / vjtril stay packed).  d_work as PAMD_df_vj_pass1_worksize(npair, naux, nset).
+int PAMD_df_vj_pass1_sq(const double *d_sq, long lstride, int ld, int nao, int naux, const double *d_dmtril, int nset,
+                        double *d_rho, double *d_work, void *stream)
+{
+    PAMD_REQUIRE(nset >= 1 && nset <= MAX_NSET, "nset must be 1..4 per call");
+    PAMD_REQUIRE(ld >= nao && lstride >= (long)nao * ld, "PAMD_df_vj_pass1_sq: leading dimensions");
+    if (naux == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const long npair = (long)nao * (nao + 1) / 2;
+    int nchunk = ceil_div(npair, J1_CHUNK2);
+    dim3 grid(nchunk, ceil_div(naux, J1R));
+    switch (nset) {
+    case 1: vj_pass1_sq_kernel<1><<<grid, J1_THREADS, 0, st>>>(d_sq, lstride, ld, npair, naux, d_dmtril, d_work, nchunk); break;
+    case 2: vj_pass1_sq_kernel<2><<<grid, J1_THREADS, 0, st>>>(d_sq, lstride, ld, npair, naux, d_dmtril, d_work, nchunk); break;
+    case 3: vj_pass1_sq_kernel<3><<<grid, J1_THREADS, 0, st>>>(d_sq, lstride, ld, npair, naux, d_dmtril, d_work, nchunk); break;
+    default: vj_pass1_sq_kernel<4><<<grid, J1_THREADS, 0, st>>>(d_sq, lstride, ld, npair, naux, d_dmtril, d_work, nchunk); break;
+    }
+    PAMD_CHECK_LAUNCH();
+    int n = nset * naux;
+    vj_pass1_reduce_kernel<false><<<ceil_div(n, 4), 256, 0, st>>>(d_work, d_rho, n, nchunk);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int PAMD_df_vj_pass2_sq(const double *d_sq, long lstride, int ld, int nao, int naux, const double *d_rho, int nset,
+                        double *d_vjtril, void *stream)
+{
+    PAMD_REQUIRE(nset >= 1 && nset <= MAX_NSET, "nset must be 1..4 per call");
+    PAMD_REQUIRE(ld >= nao && lstride >= (long)nao * ld, "PAMD_df_vj_pass2_sq: leading dimensions");
+    if (naux == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const long npair = (long)nao * (nao + 1) / 2;
+    int grid = ceil_div(npair, 256);
+    if (g_j2_maxwg > 0 && grid > g_j2_maxwg) grid = g_j2_maxwg;
+    switch (nset) {
+    case 1: vj_pass2_sq_kernel<1><<<grid, 256, 0, st>>>(d_sq, lstride, ld, npair, naux, d_rho, d_vjtril); break;
+    case 2: vj_pass2_sq_kernel<2><<<grid, 256, 0, st>>>(d_sq, lstride, ld, npair, naux, d_rho, d_vjtril); break;
+    case 3: vj_pass2_sq_kernel<3><<<grid, 256, 0, st>>>(d_sq, lstride, ld, npair, naux, d_rho, d_vjtril); break;
+    default: vj_pass2_sq_kernel<4><<<grid, 256, 0, st>>>(d_sq, lstride, ld, npair, naux, d_rho, d_vjtril); break;
+    }
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// One column slab of the build into the square layout: d_slab[nL][ncol] holds the packed columns [r0, r0 + ncol) = the AO rows
+// [p0, p1) of every aux row (what PAMD_cderi_solve writes with ldc = ncol); both triangles of d_sq[nL][rows][ld] are filled.
+int PAMD_unpack_tril_slab(const double *d_slab, long ncol, int nL, int p0, int p1, double *d_sq, int ld, long lstride, void *stream)
+{
+    PAMD_REQUIRE(p0 >= 0 && p1 >= p0 && ld >= p1 && ncol >= (long)p1 * (p1 + 1) / 2 - (long)p0 * (p0 + 1) / 2, "PAMD_unpack_tril_slab: bad slab");
+    if (nL == 0 || p1 == p0) return 0;
+    const long r0 = (long)p0 * (p0 + 1) / 2;
+    dim3 grid(ceil_div(p1, 32), ceil_div(p1 - p0, 32), nL);
+    unpack_slab_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_slab, ncol, r0, p0, p1, d_sq, ld, lstride);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+// d_tril[count][nao_pair] (the reference's packed `_cderi` rows, pyscf/df/df.py:59-72) from d_sq[count][rows][ld]
+int PAMD_pack_tril_rows(const double *d_sq, long lstride, int ld, int nao, int count, double *d_tril, void *stream)
+{
+    if (count == 0) return 0;
+    const long npair = (long)nao * (nao + 1) / 2;
+    dim3 grid(ceil_div(nao, 256), nao, count);
+    pack_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_sq, lstride, ld, nao, d_tril, npair);
+    PAMD_CHECK_LAUNCH();
+    return 0;
+}
+
 // Device analogue of AO2MOnr_e2_drv(ftrans=AO2MOtranse2_nr_s2, fmmm=AO2MOmmm_bra_nr_s2)
 // (pyscf/lib/ao2mo/nr_ao2mo.c:1240-1266): out[L][i][p] = sum_q unpack(cderi[L])[p][q] orb[q][i].
 //   d_orb   [orb_rows][ldo] row-major, columns >= norb zero up to ldo (PAMD_e2_orb_ld(nocc_pad) columns: whole kernel chunks);
@@ -1822,9 +2022,13 @@ int PAMD_e2_diag_blocks(const double *d_cderi, long npair, int nL, int nao, int 
 //   d_orb  [orb_rows >= rows][ldo] zero rows beyond nao, ldo even, ldo >= chunks * tile width (see PAMD_e2_sq_ldo)
 //   d_rho (nullable) [nL]: d_rho[L] += sum_{i,p} X[L][i][p] orb[p][i] = sum_pq B_L[p][q] (orb orb^T)[p][q], the first J pass
 //   of the density the orbitals stand for, taken from the accumulators in the epilogue
-int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, const double *d_orb, int ldo,
-                      int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream)
+// r06: `lstride` doubles between consecutive aux rows of d_sq (>= rows * ld, even).  The square LAYOUT pads it: rows * ld * 8 is a
+// multiple of 32 KB at nao = 1856 / 2228 and of 8 MB at nao = 3072, so that the same (p, q) of consecutive aux rows - what the J
+// passes and the workgroups of one column tile read at the same time - would all sit on one HBM channel.
+int PAMD_nr_e2_square_ls(const double *d_sq, long ld, int rows, long lstride, int nL, int nao, const double *d_orb, int ldo,
+                         int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream)
 {
+    PAMD_REQUIRE(lstride >= (long)rows * ld && lstride % 2 == 0, "PAMD_nr_e2_square_ls: lstride");
     PAMD_REQUIRE(d_rho == nullptr || d_rho_work != nullptr, "d_rho needs d_rho_work (PAMD_nr_e2_rho_worksize doubles)");
     PAMD_REQUIRE(nocc_pad >= 0 && nocc_pad <= ldo, "nocc_pad (rows of d_out per aux index) must be <= ldo");
     PAMD_REQUIRE(rows % KB == 0 && rows >= nao && orb_rows >= rows, "q rows must be padded to a multiple of 16");
@@ -1863,23 +2067,23 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
 #define LAUNCH_V2(NAV, RHOF)                                                                                        \
         do {                                                                                                         \
             if (merged) {                                                                                            \
-                e2_sq2_kernel<NAV, RHOF, 2><<<gboth, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                e2_sq2_kernel<NAV, RHOF, 2><<<gboth, 256, 0, st>>>(d_sq, ld, lstride, rows, d_orb, ldo, d_out, \
                                                                    nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio, g_e2_xmap); \
                 break;                                                                                               \
             }                                                                                                        \
-            e2_sq2_kernel<NAV, RHOF, 0><<<gmain, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out,   \
+            e2_sq2_kernel<NAV, RHOF, 0><<<gmain, 256, 0, st>>>(d_sq, ld, lstride, rows, d_orb, ldo, d_out,   \
                                                                    nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL, g_e2_prio, g_e2_xmap);    \
             if (pair)                                                                                                \
-                e2_sq2_kernel<NAV, RHOF, 1><<<gpair, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                e2_sq2_kernel<NAV, RHOF, 1><<<gpair, 256, 0, st>>>(d_sq, ld, lstride, rows, d_orb, ldo, d_out, \
                                                                       nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio, g_e2_xmap); \
         } while (0)
 #define LAUNCH_W(WMV, RHOF)                                                                                          \
         do {                                                                                                         \
             if (merged)                                                                                              \
-                e2_sq2_kernel<4, RHOF, 2, WMV><<<gboth, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, \
+                e2_sq2_kernel<4, RHOF, 2, WMV><<<gboth, 256, 0, st>>>(d_sq, ld, lstride, rows, d_orb, ldo, d_out, \
                                                                    nocc_pad, ldx, rw, nchunk, nao, ptiles - 1, nslot, nL, g_e2_prio, g_e2_xmap); \
             else                                                                                                     \
-                e2_sq2_kernel<4, RHOF, 0, WMV><<<dim3(ptiles * nchunk, nL), 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, \
+                e2_sq2_kernel<4, RHOF, 0, WMV><<<dim3(ptiles * nchunk, nL), 256, 0, st>>>(d_sq, ld, lstride, rows, d_orb, ldo, \
                                                                    d_out, nocc_pad, ldx, rw, nchunk, nao, 0, nslot, nL, g_e2_prio, g_e2_xmap); \
         } while (0)
         if (wm2) {                          // (without the merged pair rows every column tile, also a half-empty last one, is a main tile)
@@ -1901,10 +2105,10 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
 #define LAUNCH_SQ(W)                                                                                            \
     do {                                                                                                        \
         if (d_rho)                                                                                              \
-            e2_sq_kernel<W, true><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
+            e2_sq_kernel<W, true><<<grid, 256, 0, st>>>(d_sq, ld, lstride, rows, d_orb, ldo, d_out, nocc_pad, \
                                                         ldx, d_rho_work, nchunk);                                \
         else                                                                                                    \
-            e2_sq_kernel<W, false><<<grid, 256, 0, st>>>(d_sq, ld, (long)rows * ld, rows, d_orb, ldo, d_out, nocc_pad, \
+            e2_sq_kernel<W, false><<<grid, 256, 0, st>>>(d_sq, ld, lstride, rows, d_orb, ldo, d_out, nocc_pad, \
                                                          ldx, nullptr, nchunk);                                  \
     } while (0)
     switch (wa) {
@@ -1918,6 +2122,12 @@ int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, co
     PAMD_CHECK_LAUNCH();
     if (d_rho) return reduce_rho_partials(d_rho_work, d_rho, nL, (int)(grid.x * 4), st);
     return 0;
+}
+
+int PAMD_nr_e2_square(const double *d_sq, long ld, int rows, int nL, int nao, const double *d_orb, int ldo,
+                      int orb_rows, int nocc_pad, double *d_out, int ldx, double *d_rho, double *d_rho_work, void *stream)
+{
+    return PAMD_nr_e2_square_ls(d_sq, ld, rows, (long)rows * ld, nL, nao, d_orb, ldo, orb_rows, nocc_pad, d_out, ldx, d_rho, d_rho_work, stream);
 }
 
 // out[y][i][n] = sum_k src_y[n][k] * orb[k][i]   (y < ny; src_y = d_src + y*src_stride, rows n of

@@ -37,7 +37,14 @@ class DF:
         self._auxbasis = auxbasis
         self.auxmol = None
         self._cderi = None          # optional host ndarray (naux, nao_pair) to upload
-        self._cderi_dev = None      # torch CUDA tensor: rows [l0, l1)
+        self._packed = None         # torch CUDA tensor [rows l0..l1][nao_pair]: the reference's packed layout (`_cderi_dev` property)
+        # r06: ONE resident copy of the tensor.  'square': sq[L][rows][rows] (both triangles, what the K half
+        # transform streams by LDS-DMA) INSTEAD of the packed rows - 2x the packed bytes, not packed + image = 3x; the J passes
+        # read the p >= q runs of the square rows, loop / save / export pack on the fly.  'packed': the reference's rows (+ the
+        # optional partial image / diagonal-block image of r03) when 2x does not fit.  'auto': square when the budget allows.
+        self.layout = 'auto'
+        self._layout = None         # what build() decided
+        self.xc_image_hint = 0      # bytes the XC leg of the same calculation will cache in HBM (KS objects set it): part of the budget
         self._cderi_to_save = None
         self._naux = None
         self.device = device
@@ -64,6 +71,7 @@ class DF:
         self.k_square = 'auto'
         self.k_square_reserve = 48 << 30     # HBM left free after the copy (X block, partial K, XC blocks, ...)
         self._cderi_sq = None
+        self._sq_nao = 0
         self.k_diag = True                  # packed-operand rows: keep the diagonal 128 x 128 blocks unpacked (diag_image)
         self._cderi_diag = None
         self._diag_row0 = 0
@@ -98,6 +106,98 @@ class DF:
             return dist.get_rank(self.group)
         return 0
 
+    # -- the tensor, whichever layout holds it -------------------------------------------------------
+    @property
+    def _cderi_dev(self):
+        """The PACKED rows (naux_local, nao_pair) - the reference's `_cderi` layout (pyscf/df/df.py:59-72).  In the square layout
+        they do not exist until somebody asks: the first access packs a copy out of the square rows (gradients, get_eri / ao2mo,
+        tests; the J/K path never does).  Internal code tests `has_tensor()` / `_packed`, never this property against None."""
+        if self._packed is None and self._cderi_sq is not None and self._layout == 'square':
+            self._packed = self.packed_rows(0, self._cderi_sq.shape[0])
+        return self._packed
+
+    @_cderi_dev.setter
+    def _cderi_dev(self, value):
+        self._packed = value
+        if value is not None and self._layout is None:
+            self._layout = 'packed'                  # a caller-provided packed tensor (tools, tests): the r03-r05 path
+
+    SQ_STRIDE_PAD = 0            # doubles added to rows * ld between consecutive aux rows of the square layout.  rows * ld * 8 is a
+                                 # multiple of 32 KB at nao = 1856 / 2228 and of 8 MB at nao = 3072, and the same (p, q) of consecutive
+                                 # aux rows is what a J pass has in flight - an HBM channel conflict was the suspicion when the square
+                                 # J pass measured 5.2 instead of 6.6 TB/s.  Measured with 288 (profiles/r06/kbench_square_layout.log):
+                                 # no difference (11.33 vs 11.22 ms alone, 111.9-114.3 vs 111.4-112.4 ms per step) - so no pad; the
+                                 # stride stays an explicit argument of every kernel that walks the square rows
+
+    @classmethod
+    def alloc_square(cls, nL, rows, device):
+        """Zeroed square rows sq[nL][rows][rows] with the padded aux-row stride (a strided view of one flat buffer, 256 doubles of
+        slack behind the last row for the LDS-DMA kernels' whole-panel reads)."""
+        import torch
+        ls = rows * rows + cls.SQ_STRIDE_PAD
+        buf = torch.zeros(max(nL, 1) * ls + 256, dtype=torch.float64, device=device)
+        return buf.as_strided((nL, rows, rows), (ls, rows, 1))
+
+    def has_tensor(self):
+        return self._packed is not None or (self._layout == 'square' and self._cderi_sq is not None)
+
+    def tensor_shape(self):
+        """(local aux rows, nao_pair) without materialising anything."""
+        if self._packed is not None:
+            return tuple(self._packed.shape)
+        sq = self._cderi_sq
+        nao = self._sq_nao
+        return sq.shape[0], nao * (nao + 1) // 2
+
+    def tensor_device(self):
+        return (self._packed if self._packed is not None else self._cderi_sq).device
+
+    def packed_rows(self, b0, b1, out=None):
+        """Device tensor (b1 - b0, nao_pair) of the packed rows [b0, b1) of this rank: a view in the packed layout, a fresh
+        pack (PAMD_pack_tril_rows) out of the square layout."""
+        import torch
+        import ctypes as _c
+        from .. import lib as _lib
+        if self._packed is not None:
+            return self._packed[b0:b1]
+        sq = self._cderi_sq
+        nao = self._sq_nao
+        npair = nao * (nao + 1) // 2
+        if out is None:
+            out = torch.empty((b1 - b0, npair), dtype=torch.float64, device=sq.device)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if b1 > b0:
+            _lib.check(_lib.load_library().PAMD_pack_tril_rows(_c.c_void_p(sq[b0:b1].data_ptr()), _c.c_long(sq.stride(0)),
+                                                               _c.c_int(sq.shape[2]), _c.c_int(nao), _c.c_int(b1 - b0),
+                                                               _c.c_void_p(out.data_ptr()), st))
+        return out[:b1 - b0]
+
+    def to_packed_layout(self):
+        """The consumers that need the packed tensor AND the memory of the square one (analytic gradients: W has the tensor's
+        size): pack a copy when both fit, else drop the square rows and rebuild the tensor packed from the integrals."""
+        import torch
+        if self._layout != 'square' or not self.has_tensor():
+            return self
+        dev = self.tensor_device()
+        nL, npair = self.tensor_shape()
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        if self._packed is None and nL * npair * 8 + (8 << 30) <= free:
+            self._packed = self.packed_rows(0, nL)
+        if self._packed is not None:
+            self._cderi_sq = None
+            self._layout = 'packed'
+            torch.cuda.empty_cache()
+            return self
+        mol_ok = self.mol is not None and not isinstance(self._cderi, (str, np.ndarray))
+        if not mol_ok:
+            raise MemoryError('DF.to_packed_layout: no room for a packed copy beside the square tensor and no integrals to rebuild from')
+        self._cderi_sq = None
+        self._ws = {}
+        torch.cuda.empty_cache()
+        self._layout = None
+        self.layout, self.k_square = 'packed', False
+        return self.build()
+
     @staticmethod
     def shard_range(naux, rank, world):
         """Contiguous, row-count-balanced aux range of `rank`."""
@@ -108,7 +208,7 @@ class DF:
     def _side_stream(self):
         import torch
         if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream(device=self._cderi_dev.device)
+            self._side = torch.cuda.Stream(device=self.tensor_device())
         return self._side
 
     # -- integral-direct J support (no tensor) ---------------------------------------------------
@@ -153,18 +253,21 @@ class DF:
         import torch
         import ctypes as _c
         from .. import lib as _lib
-        if self._cderi_sq is not None or self.k_square is False or self._cderi_dev is None:
+        if self._cderi_sq is not None or self.k_square is False or self._packed is None:
             return self._cderi_sq
-        naux, npair = self._cderi_dev.shape
+        naux, npair = self._packed.shape
         nao = int((np.sqrt(8.0 * npair + 1) - 1) / 2 + .5)
         rows = (nao + 15) // 16 * 16
         if naux == 0 or nao * (nao + 1) // 2 != npair:
             return None
         nsq = naux
         if self.k_square == 'auto':
-            free = torch.cuda.mem_get_info(self._cderi_dev.device)[0] + torch.cuda.memory_reserved(self._cderi_dev.device) \
-                - torch.cuda.memory_allocated(self._cderi_dev.device)
-            room = free - self.k_square_reserve - 256 * 8
+            free = torch.cuda.mem_get_info(self._packed.device)[0] + torch.cuda.memory_reserved(self._packed.device) \
+                - torch.cuda.memory_allocated(self._packed.device)
+            # the optional image takes what the budget leaves: the reserve AND what the XC leg will cache (never a K image that
+            # evicts the AO cache)
+            from ..lib import hbm
+            room = free - self.k_square_reserve - max(0, int(self.xc_image_hint) - hbm.held(self._packed.device, 'xc_image')) - 256 * 8
             nsq = min(naux, int(room // (rows * rows * 8))) if room > 0 else 0
             if getattr(self, 'k_square_max_rows', None) is not None:       # cap (tests, tuning)
                 nsq = min(nsq, int(self.k_square_max_rows))
@@ -175,14 +278,15 @@ class DF:
                 return None
         so = _lib.load_library()
         # unpack_tril writes every [p < nao][q < rows] entry; only the pad rows p >= nao (and the slack) need zeroing
-        buf = torch.empty(nsq * rows * rows + 256, dtype=torch.float64, device=self._cderi_dev.device)
+        buf = torch.empty(nsq * rows * rows + 256, dtype=torch.float64, device=self._packed.device)
         buf[nsq * rows * rows:].zero_()
         if rows > nao:
             buf[:nsq * rows * rows].view(nsq, rows, rows)[:, nao:, :].zero_()
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(so.PAMD_unpack_tril(_c.c_void_p(self._cderi_dev.data_ptr()), _c.c_long(npair), _c.c_int(nsq),
+        _lib.check(so.PAMD_unpack_tril(_c.c_void_p(self._packed.data_ptr()), _c.c_long(npair), _c.c_int(nsq),
                                        _c.c_int(nao), _c.c_void_p(buf.data_ptr()), _c.c_int(rows), _c.c_int(rows), st))
         self._cderi_sq = buf[:nsq * rows * rows].view(nsq, rows, rows)
+        self._sq_nao = nao
         return self._cderi_sq
 
     def diag_image(self):
@@ -193,9 +297,9 @@ class DF:
         import torch
         import ctypes as _c
         from .. import lib as _lib
-        if self._cderi_diag is not None or not getattr(self, 'k_diag', True) or self._cderi_dev is None:
+        if self._cderi_diag is not None or not getattr(self, 'k_diag', True) or self._packed is None:
             return self._cderi_diag, self._diag_row0
-        naux, npair = self._cderi_dev.shape
+        naux, npair = self._packed.shape
         nao = int((np.sqrt(8.0 * npair + 1) - 1) / 2 + .5)
         if naux == 0 or nao * (nao + 1) // 2 != npair or nao < 128:
             return None, 0
@@ -207,14 +311,14 @@ class DF:
         so = _lib.load_library()
         so.PAMD_e2_diag_size.restype = _c.c_long
         n = so.PAMD_e2_diag_size(_c.c_int(naux - row0), _c.c_int(ldx))
-        dev = self._cderi_dev.device
+        dev = self._packed.device
         free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         if free - (4 << 30) < n * 8:       # (the square image has left k_square_reserve free; the work buffers live in there)
             self.k_diag = False
             return None, 0
         buf = torch.empty(n, dtype=torch.float64, device=dev)
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(so.PAMD_e2_diag_blocks(_c.c_void_p(self._cderi_dev[row0:].data_ptr()), _c.c_long(npair),
+        _lib.check(so.PAMD_e2_diag_blocks(_c.c_void_p(self._packed[row0:].data_ptr()), _c.c_long(npair),
                                           _c.c_int(naux - row0), _c.c_int(nao), _c.c_int(ldx), _c.c_void_p(buf.data_ptr()), st))
         self._cderi_diag = buf.view(naux - row0, -1)
         self._diag_row0 = row0
@@ -223,6 +327,8 @@ class DF:
     def drop_square_image(self):
         """Give the HBM of the square copy back (the gradient path needs it for W and Z)."""
         import torch
+        if self._layout == 'square':
+            self.to_packed_layout()             # the square rows ARE the tensor: pack them (or rebuild packed) first
         self._cderi_sq = None
         self._cderi_diag = None
         self._diag_row0 = 0
@@ -233,9 +339,9 @@ class DF:
         import torch
         n = int(np.prod(shape))
         buf = self._ws.get(name)
-        if buf is None or buf.numel() < n or buf.device != self._cderi_dev.device:
+        if buf is None or buf.numel() < n or buf.device != self.tensor_device():
             # +256 doubles of slack: the LDS-DMA GEMM reads whole 128-column panel rows
-            buf = torch.zeros(n + 256, dtype=torch.float64, device=self._cderi_dev.device)
+            buf = torch.zeros(n + 256, dtype=torch.float64, device=self.tensor_device())
             self._ws[name] = buf
         return buf[:n].view(*shape)
 
@@ -255,7 +361,8 @@ class DF:
             self.mol = mol
         self.auxmol = None
         self._cderi = None
-        self._cderi_dev = None
+        self._packed = None
+        self._layout = None
         self._cderi_sq = None
         self._cderi_diag = None
         self._diag_row0 = 0
@@ -324,7 +431,7 @@ class DF:
                             self._cderi_dev[r0 - l0:r1 - l0, c0:c0 + d.shape[1]] = torch.from_numpy(d.read_rows(r0, r1)).to(dev)
                         c0 += d.shape[1]
                 self._naux = naux
-                return self
+                return self._maybe_square()
             shard = self._shard_path(self._cderi)
             if self.world_size > 1 and os.path.exists(shard):
                 # written by save() of a run with the same world size: this rank's rows, no re-sharding
@@ -335,7 +442,7 @@ class DF:
                                        % (shard, l0, l1, naux, self.rank, self.world_size))
                 self._cderi_dev = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
                 self._naux = naux
-                return self
+                return self._maybe_square()
             with open(self._cderi, 'rb') as f:        # one file = the FULL tensor (written by a single-rank run)
                 self._cderi = np.load(f)
         if self._cderi is not None and isinstance(self._cderi, np.ndarray):
@@ -348,7 +455,7 @@ class DF:
                 return self
             self._cderi_dev = torch.from_numpy(np.ascontiguousarray(self._cderi[l0:l1])).to(dev)
             self._naux = naux
-            return self
+            return self._maybe_square()
         if self.auxmol is None:
             self.auxmol = addons.make_auxmol(self.mol, self.auxbasis)
         from . import incore
@@ -361,9 +468,14 @@ class DF:
                 raise MemoryError('DF tensor shard of %d x %d doubles does not fit %s' % (
                     l1 - l0, _mol_nao(self.mol) * (_mol_nao(self.mol) + 1) // 2,
                     'DF.outcore_device_bytes' if self.outcore_device_bytes else 'the free device memory'))
-            self._cderi_dev = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1,
-                                                      lindep=self.lindep, omega=self.omega,
-                                                      decompose_j2c=self.decompose_j2c)
+            lay = self._choose_layout(l1 - l0, dev)
+            t = incore.cholesky_eri_gpu(self.mol, self.auxmol, dev, l0, l1, lindep=self.lindep, omega=self.omega,
+                                        decompose_j2c=self.decompose_j2c, layout=lay,
+                                        slab_bytes=(12 << 30) if lay == 'square' else (24 << 30))
+            if lay == 'square':
+                self._cderi_sq, self._sq_nao, self._layout, self._packed = t, _mol_nao(self.mol), 'square', None
+            else:
+                self._packed, self._layout = t, 'packed'
         except MemoryError:
             # The out-of-core twin (pyscf/df/outcore.py:109-232, pyscf/df/df.py:167): the tensor (r05: or this RANK's shard of it)
             # does not fit this device.  The object hands its rows to the C handle, which keeps what fits in HBM, the rest in
@@ -386,6 +498,72 @@ class DF:
             self.save(self._cderi_to_save)
         return self
     kernel = build
+
+    def _reserve_after_build(self, nL, rows):
+        """HBM the rest of the calculation needs once the tensor is resident - the single budget of VERDICT r05 item 1, in the
+        order tensor, X block, XC compact image, work space: the half-transformed block (DF.k_block_bytes; at most nL nao rows),
+        split-K partials / J vectors / orbitals (4 GB), and - when the calculation has an XC leg (`xc_image_hint`, set by the
+        Kohn-Sham classes) - the compact AO image plus the XC work buffers (12 GB)."""
+        from ..lib import hbm
+        r = min(int(self.k_block_bytes), nL * rows * rows * 8) + (4 << 30)
+        if self.xc_image_hint:
+            # (an SCF builds its XC plan BEFORE the tensor: what the plan already holds is not asked for twice)
+            r += max(0, int(self.xc_image_hint) - hbm.held(self._device(), 'xc_image')) + (12 << 30)
+        return r
+
+    def _maybe_square(self):
+        """Uploaded packed rows (a caller's array, a `_cderi` file) -> the square layout when DF.layout asks for it or ('auto')
+        the budget allows: unpacked once (PAMD_unpack_tril), then the packed rows are released - 2x, not 3x."""
+        import torch
+        import ctypes as _c
+        from .. import lib as _lib
+        from ..lib import hbm
+        if self._layout != 'packed' or self._packed is None or self.layout == 'packed' or self.k_square is False:
+            return self
+        nL, npair = self._packed.shape
+        nao = int((np.sqrt(8.0 * npair + 1) - 1) / 2 + .5)
+        if nL == 0 or nao * (nao + 1) // 2 != npair:
+            return self
+        rows = (nao + 15) // 16 * 16
+        dev = self._packed.device
+        if self.layout != 'square':
+            fits = nao >= 128 and nL * rows * rows * 8 + max(self._reserve_after_build(nL, rows), 4 << 30) <= hbm.free_bytes(dev)
+            if not self._all_ranks_agree(fits):
+                return self
+        sq = self.alloc_square(nL, rows, dev)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        step = max(1, (4 << 30) // (npair * 8))
+        for b0 in range(0, nL, step):             # (PAMD_unpack_tril_slab with the whole triangle as one slab: explicit aux-row stride)
+            nb = min(step, nL - b0)
+            _lib.check(_lib.load_library().PAMD_unpack_tril_slab(_c.c_void_p(self._packed[b0:].data_ptr()), _c.c_long(npair), _c.c_int(nb),
+                                                                 _c.c_int(0), _c.c_int(nao), _c.c_void_p(sq[b0:].data_ptr()), _c.c_int(rows),
+                                                                 _c.c_long(sq.stride(0)), st))
+        torch.cuda.current_stream().synchronize()
+        self._cderi_sq, self._sq_nao, self._layout, self._packed = sq, nao, 'square', None
+        self._cderi_diag, self._diag_row0 = None, 0
+        torch.cuda.empty_cache()
+        return self
+
+    def _choose_layout(self, nL, dev):
+        """'square' when 2x the packed shard + the build's slab work space + the reserve fit the device (or DF.layout says
+        so), else 'packed'.  Collective over the ranks like the out-of-core decision: one layout per job."""
+        import torch
+        if self.layout in ('packed', 'square'):
+            return self.layout
+        if self.k_square is False or dev.type != 'cuda':
+            return 'packed'
+        nao = _mol_nao(self.mol)
+        if nao < 128:
+            return 'packed'                       # tiny tensors: the exact-tile kernels read the packed rows directly
+        rows = (nao + 15) // 16 * 16
+        naux = self.auxmol.nao_nr()
+        npair = nao * (nao + 1) // 2
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        slab = min(12 << 30, npair * naux * 8)
+        build_need = nL * rows * rows * 8 + slab + min(slab, slab * max(nL, 1) // max(naux, 1) + (1 << 20)) + (2 << 30)
+        after_need = nL * rows * rows * 8 + self._reserve_after_build(nL, rows)
+        fits = max(build_need, after_need) <= free
+        return 'square' if self._all_ranks_agree(fits) else 'packed'
 
     def _all_ranks_agree(self, fits):
         """The out-of-core decision of a multi-rank job is COLLECTIVE (r06): each rank used to decide from its own
@@ -429,7 +607,7 @@ class DF:
         with the slab work space of the build, fit the device - or the `outcore_device_bytes` cap?  build() asks it before any
         metric work; scf.device_scf.eligible() asks it instead of building."""
         import torch
-        if self._cderi_dev is not None:
+        if self.has_tensor():
             return True
         if getattr(self, '_native', None) is not None:
             return False
@@ -464,7 +642,7 @@ class DF:
         iteration (it is a collective: each block is assembled from its owners' rows by an all-reduce of a zero-padded
         buffer) and every rank receives every block.  `local=True`: only this rank's rows [l0, l1), no communication."""
         import torch
-        if self._cderi_dev is None:
+        if not self.has_tensor() and getattr(self, '_native', None) is None:
             self.build()
         if blksize is None:
             blksize = self.blockdim
@@ -475,7 +653,7 @@ class DF:
             for blk in self._native.loop(blksize):
                 yield blk
             return
-        n = self._cderi_dev.shape[0]
+        n, npair = self.tensor_shape()
         from ..lib import comm as _comm
         sharded = _comm.active(self.world_size) and getattr(self, '_shard_override', None) is None
         if getattr(self, '_shard_override', None) is not None and self._shard_override[1] > 1 and not local:
@@ -483,47 +661,72 @@ class DF:
                                'rows; pass local=True for the rows of the shard' % tuple(self._shard_override))
         if local or not sharded:
             for b0 in range(0, n, blksize):
-                yield self._cderi_dev[b0:b0 + blksize].cpu().numpy()
+                yield self.packed_rows(b0, min(b0 + blksize, n)).cpu().numpy()
             return
         naux = self.get_naoaux()
         l0, l1 = self.shard_range(naux, self.rank, self.world_size)
-        npair = self._cderi_dev.shape[1]
-        buf = torch.empty((min(blksize, naux), npair), dtype=torch.float64, device=self._cderi_dev.device)
+        buf = torch.empty((min(blksize, naux), npair), dtype=torch.float64, device=self.tensor_device())
         for b0 in range(0, naux, blksize):
             b1 = min(b0 + blksize, naux)
             blk = buf[:b1 - b0]
             blk.zero_()
             a0, a1 = max(b0, l0), min(b1, l1)
             if a1 > a0:
-                blk[a0 - b0:a1 - b0] = self._cderi_dev[a0 - l0:a1 - l0]
+                blk[a0 - b0:a1 - b0] = self.packed_rows(a0 - l0, a1 - l0)
             _comm.all_reduce([blk], self.group, self.world_size)
             yield blk.cpu().numpy()
 
     # -- downstream consumers of the tensor ----------------------------------
-    def _pair_gram(self, a, b):
-        """sum_L a[L,:]^T b[L,:] over this rank's rows, all-reduced over the aux shards."""
+    def _row_blocks(self, blksize):
+        """(b0, packed device rows [nb][nao_pair]) over THIS rank's rows, whatever holds them: the packed tensor (views), the
+        square rows (packed block by block), or - r06, VERDICT r05 Missing 4 - the out-of-core C handle (its loop() blocks,
+        uploaded): the reference's consumers need nothing but DF.loop() either (pyscf/df/df.py:214-242,269-296)."""
+        import torch
+        nat = getattr(self, '_native', None)
+        if nat is not None:
+            dev = self._device()
+            b0 = 0
+            for blk in nat.loop(blksize):
+                yield b0, torch.from_numpy(np.ascontiguousarray(blk)).to(dev)
+                b0 += blk.shape[0]
+            return
+        n = self.tensor_shape()[0]
+        for b0 in range(0, n, blksize):
+            yield b0, self.packed_rows(b0, min(b0 + blksize, n))
+
+    def _pair_gram(self, a_blocks, m, n, dev):
+        """sum_L a[L,:]^T b[L,:] over this rank's rows - `a_blocks` yields (a_blk, b_blk) row blocks -, all-reduced over the shards."""
         import torch
         import ctypes as _c
         from .. import lib as _lib
         so = _lib.load_library()
-        m, n, k = a.shape[1], b.shape[1], a.shape[0]
-        out = torch.zeros((1, m, n), dtype=torch.float64, device=a.device)
-        if k:
-            st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
-            df_jk._call(self, 'dgemm_tn', so.PAMD_dgemm_tn, _c.c_void_p(a.data_ptr()), _c.c_int(a.stride(0)),
-                        _c.c_void_p(b.data_ptr()), _c.c_int(b.stride(0)), _c.c_void_p(out.data_ptr()), _c.c_int(n),
-                        _c.c_int(m), _c.c_int(n), _c.c_long(k), _c.c_int(0), _c.c_int(1), st)
+        out = torch.zeros((1, m, n), dtype=torch.float64, device=dev)
+        st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for a, b in a_blocks:
+            if a.shape[0]:
+                df_jk._call(self, 'dgemm_tn', so.PAMD_dgemm_tn, _c.c_void_p(a.data_ptr()), _c.c_int(a.stride(0)),
+                            _c.c_void_p(b.data_ptr()), _c.c_int(b.stride(0)), _c.c_void_p(out.data_ptr()), _c.c_int(n),
+                            _c.c_int(m), _c.c_int(n), _c.c_long(a.shape[0]), _c.c_int(0), _c.c_int(1), st)
+                torch.cuda.current_stream().synchronize()      # (the block may be a temporary: keep it alive until the product ran)
         df_jk._allreduce(self, [out])
         return out[0]
 
+    def _tensor_dev_npair(self):
+        nat = getattr(self, '_native', None)
+        if nat is not None:
+            return self._device(), nat.nao * (nat.nao + 1) // 2
+        return self.tensor_device(), self.tensor_shape()[1]
+
     def get_eri(self):
         """8-fold packed (pq|rs) ~ sum_L B[L,pq] B[L,rs] (pyscf/df/df.py:269-276: lib.dot(eri1.T, eri1)
-        then ao2mo.restore(8, ...)): the lower triangle of the (nao_pair, nao_pair) matrix."""
+        then ao2mo.restore(8, ...)): the lower triangle of the (nao_pair, nao_pair) matrix.  Row block by row block, so that the
+        out-of-core handle (r06) and the square layout serve it as well."""
         from .. import lib as _lib
-        if self._cderi_dev is None:
+        if not self.has_tensor() and getattr(self, '_native', None) is None:
             self.build()
-        self._need_in_core('get_eri')
-        eri4 = self._pair_gram(self._cderi_dev, self._cderi_dev).cpu().numpy()
+        dev, npair = self._tensor_dev_npair()
+        blk = max(1, (1 << 30) // (npair * 8))
+        eri4 = self._pair_gram(((r, r) for _b0, r in self._row_blocks(blk)), npair, npair, dev).cpu().numpy()
         return _lib.pack_tril(eri4)
     get_ao_eri = get_eri
 
@@ -534,52 +737,51 @@ class DF:
         import ctypes as _c
         from .. import lib as _lib
         so = _lib.load_library()
-        cderi = self._cderi_dev
-        naux, npair = cderi.shape
+        dev, npair = self._tensor_dev_npair()
         nao = self.mol.nao_nr()
-        dev = cderi.device
         same = compact and ci.shape == cj.shape and abs(ci - cj).max() < 1e-13      # iden_coeffs, ao2mo/incore.py
         orb, ni_pad, ldo = df_jk.pad_orbitals(np.asarray(ci, dtype=np.float64), dev)
         ni, nj = ci.shape[1], cj.shape[1]
         cj_dev = torch.from_numpy(np.ascontiguousarray(cj, dtype=np.float64)).to(dev)
         ldx = (nao + 15) // 16 * 16
-        blk = max(1, min(max(naux, 1), int((1 << 30) // (max(ni_pad, 16) * ldx * 8))))
+        blk = max(1, int((1 << 30) // (max(ni_pad, 16) * ldx * 8)))
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
-        out = torch.empty((naux, ni * (ni + 1) // 2 if same else ni * nj), dtype=torch.float64, device=dev)
+        outs = []
         if same:
             ti, tj = np.tril_indices(ni)
             sel = torch.from_numpy(ti * nj + tj).to(dev)
-        for b0 in range(0, naux, blk):
-            nb = min(blk, naux - b0)
+        for _b0, rows in self._row_blocks(blk):
+            nb = rows.shape[0]
             X = torch.zeros((nb, ni_pad, ldx), dtype=torch.float64, device=dev)
-            df_jk._call(self, 'e2_symm', so.PAMD_nr_e2_symm, _c.c_void_p(cderi[b0:b0 + nb].data_ptr()), _c.c_long(npair),
+            df_jk._call(self, 'e2_symm', so.PAMD_nr_e2_symm, _c.c_void_p(rows.data_ptr()), _c.c_long(npair),
                         _c.c_int(nb), _c.c_int(nao), _c.c_void_p(orb.data_ptr()), _c.c_int(ldo),
                         _c.c_int(orb.shape[0]), _c.c_int(ni_pad), _c.c_void_p(X.data_ptr()), _c.c_int(ldx),
                         _c.c_void_p(0), _c.c_void_p(0), st)
             y = torch.matmul(X[:, :ni, :nao], cj_dev).reshape(nb, ni * nj)      # second index: plain library GEMM
-            out[b0:b0 + nb] = y[:, sel] if same else y
-        return out
+            outs.append(y[:, sel] if same else y)
+        if not outs:
+            return torch.zeros((0, ni * (ni + 1) // 2 if same else ni * nj), dtype=torch.float64, device=dev)
+        return torch.cat(outs)
 
     def ao2mo(self, mo_coeffs, compact=True):
         """(ij|kl) in the MO bases mo_coeffs = (Ci, Cj, Ck, Cl) (or one matrix for all four):
         matrix (nij_pair, nkl_pair), pairs packed when the two coefficient blocks coincide and
-        `compact` (pyscf/df/df.py:278-296)."""
-        if self._cderi_dev is None:
+        `compact` (pyscf/df/df.py:278-296).  r06: works on an out-of-core tensor too (row blocks of the handle's loop())."""
+        if not self.has_tensor() and getattr(self, '_native', None) is None:
             self.build()
-        self._need_in_core('ao2mo')
         if isinstance(mo_coeffs, np.ndarray) and mo_coeffs.ndim == 2:
             mo_coeffs = (mo_coeffs,) * 4
         ci, cj, ck, cl = [np.asarray(c, dtype=np.float64) for c in mo_coeffs]
         lij = self._half_transform_pairs(ci, cj, compact)
         sym = ci.shape == ck.shape and cj.shape == cl.shape and abs(ci - ck).max() < 1e-13 and abs(cj - cl).max() < 1e-13
         lkl = lij if sym else self._half_transform_pairs(ck, cl, compact)
-        return self._pair_gram(lij, lkl).cpu().numpy()
+        return self._pair_gram([(lij, lkl)], lij.shape[1], lkl.shape[1], lij.device).cpu().numpy()
     get_mo_eri = ao2mo
 
     def _need_in_core(self, what):
         """The consumers that work on the HBM-resident tensor say so when build() handed the tensor to the out-of-core handle
         (they used to dereference `_cderi_dev = None`)."""
-        if self._cderi_dev is None and getattr(self, '_native', None) is not None:
+        if not self.has_tensor() and getattr(self, '_native', None) is not None:
             raise NotImplementedError('DF.%s needs the in-core tensor; this object holds it out of core (%s): use more ranks / '
                                       'devices, or iterate DF.loop() blocks on the host' % (what, self.out_of_core()))
 
@@ -594,14 +796,14 @@ class DF:
         `path.rank<r>of<w>.npz` archives with (l0, l1, naux).  `DF(mol)._cderi = path` loads either back in build()."""
         from ..lib import hdf5
         path = path or self._cderi_to_save
-        if self._cderi_dev is None:
+        if not self.has_tensor() and getattr(self, '_native', None) is None:
             self.build()
         if fmt is None:
             fmt = 'hdf5' if (hdf5.available() and not path.endswith(('.npy', '.npz'))) else 'npy'
         if getattr(self, '_native', None) is not None:
             return self._save_out_of_core(path, fmt)
         if fmt == 'hdf5':
-            naux, npair = self._naux, self._cderi_dev.shape[1]
+            naux, npair = self._naux, self.tensor_shape()[1]
             l0, l1 = self.shard_range(naux, self.rank, self.world_size) if self.world_size > 1 else (0, naux)
             step = max(1, (1 << 30) // (npair * 8))
             for turn in range(self.world_size):
@@ -610,7 +812,7 @@ class DF:
                         d = f.create_dataset('j3c', (naux, npair)) if turn == 0 else f['j3c']
                         for r0 in range(l0, l1, step):
                             r1 = min(r0 + step, l1)
-                            d.write_rows(r0, self._cderi_dev[r0 - l0:r1 - l0].cpu().numpy())
+                            d.write_rows(r0, self.packed_rows(r0 - l0, r1 - l0).cpu().numpy())
                 if self.world_size > 1 and getattr(self, '_shard_override', None) is None:
                     import torch.distributed as dist
                     dist.barrier(group=self.group)
@@ -618,10 +820,14 @@ class DF:
         if self.world_size > 1:
             l0, l1 = self.shard_range(self._naux, self.rank, self.world_size)
             out = self._shard_path(path)
-            np.savez(out, j3c=self._cderi_dev.cpu().numpy(), l0=l0, l1=l1, naux=self._naux)
+            np.savez(out, j3c=np.vstack([b for b in self.loop(local=True)]), l0=l0, l1=l1, naux=self._naux)
             return out
-        with open(path, 'wb') as f:
-            np.save(f, self._cderi_dev.cpu().numpy())
+        from numpy.lib import format as _fmt
+        nloc, npair = self.tensor_shape()
+        with open(path, 'wb') as f:                    # a .npy written block by block (no second host copy of the tensor)
+            _fmt.write_array_header_1_0(f, {'descr': '<f8', 'fortran_order': False, 'shape': (nloc, npair)})
+            for blk in self.loop(max(1, (1 << 30) // (npair * 8)), local=True):
+                f.write(np.ascontiguousarray(blk).tobytes())
         return path
 
     def _save_out_of_core(self, path, fmt):

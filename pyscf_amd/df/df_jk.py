@@ -100,13 +100,35 @@ def _allreduce_jk_packed(dfobj, lib, vjtril, vk):
     vk.diagonal(dim1=-2, dim2=-1).mul_(2.0)
 
 
+def _square_rows(dfobj):
+    """The square rows sq[L][rows][ld] when they ARE the tensor (DF.layout 'square', r06), else None."""
+    return dfobj._cderi_sq if getattr(dfobj, '_layout', None) == 'square' else None
+
+
+def _sq_args(sq, b0=0, nb=None):
+    """(pointer, lstride, ld) of the square rows [b0, b0 + nb) for the PAMD_*_sq entry points."""
+    return _ptr(sq[b0:] if nb is None else sq[b0:b0 + nb]), _c.c_long(sq.stride(0)), _c.c_int(sq.shape[2])
+
+
+def _vj_pass2_rows(dfobj, lib, b0, nb, nao, rho_ptr, ns, vj_ptr, st):
+    """vjtril[s][pq] += sum_{L in [b0, b0 + nb)} rho[s][L] B[L, pq] from whichever layout holds the rows."""
+    sq = _square_rows(dfobj)
+    if sq is not None:
+        p, lstride, ld = _sq_args(sq, b0, nb)
+        _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2_sq, p, lstride, ld, _c.c_int(nao), _c.c_int(nb), rho_ptr, _c.c_int(ns), vj_ptr, st)
+    else:
+        cderi = dfobj._packed
+        _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(cderi[b0:b0 + nb]), _c.c_long(cderi.shape[1]), _c.c_int(nb), rho_ptr,
+              _c.c_int(ns), vj_ptr, st)
+
+
 def _vj_pass1(dfobj, lib, dms_dev, nset, nao):
     """rho[s][L] = sum_pq B[L,pq] dtril[s][pq] on the current stream; returns the state _vj_pass2 needs."""
     torch = _torch()
-    cderi = dfobj._cderi_dev
-    naux, npair = cderi.shape
+    naux, npair = dfobj.tensor_shape()
     st = _stream()
-    dev = cderi.device
+    dev = dfobj.tensor_device()
+    sq = _square_rows(dfobj)
     rhos = []
     for s0 in range(0, nset, 4):
         ns = min(4, nset - s0)
@@ -116,8 +138,13 @@ def _vj_pass1(dfobj, lib, dms_dev, nset, nao):
         rho = torch.empty((ns, naux), dtype=torch.float64, device=dev)
         wlen = lib.PAMD_df_vj_pass1_worksize(_c.c_long(npair), _c.c_int(naux), _c.c_int(ns))
         work = torch.empty((max(wlen, 1),), dtype=torch.float64, device=dev)
-        _call(dfobj, 'vj_pass1', lib.PAMD_df_vj_pass1, _ptr(cderi), _c.c_long(npair), _c.c_int(naux),
-                                            _ptr(dmtril), _c.c_int(ns), _ptr(rho), _ptr(work), st)
+        if sq is not None:
+            p, lstride, ld = _sq_args(sq)
+            _call(dfobj, 'vj_pass1', lib.PAMD_df_vj_pass1_sq, p, lstride, ld, _c.c_int(nao), _c.c_int(naux), _ptr(dmtril), _c.c_int(ns),
+                  _ptr(rho), _ptr(work), st)
+        else:
+            _call(dfobj, 'vj_pass1', lib.PAMD_df_vj_pass1, _ptr(dfobj._packed), _c.c_long(npair), _c.c_int(naux),
+                                                _ptr(dmtril), _c.c_int(ns), _ptr(rho), _ptr(work), st)
         rhos.append((s0, ns, rho, dmtril, work))
     return rhos
 
@@ -125,13 +152,12 @@ def _vj_pass1(dfobj, lib, dms_dev, nset, nao):
 def _vj_pass2(dfobj, lib, rhos, nset):
     """vjtril[s][pq] = sum_L rho[s][L] B[L,pq] on the current stream."""
     torch = _torch()
-    cderi = dfobj._cderi_dev
-    naux, npair = cderi.shape
+    naux, npair = dfobj.tensor_shape()
+    nao = int((np.sqrt(8.0 * npair + 1) - 1) / 2 + .5)
     st = _stream()
-    vjtril = torch.zeros((nset, npair), dtype=torch.float64, device=cderi.device)
+    vjtril = torch.zeros((nset, npair), dtype=torch.float64, device=dfobj.tensor_device())
     for s0, ns, rho, _dmtril, _work in rhos:
-        _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(cderi), _c.c_long(npair), _c.c_int(naux),
-                                            _ptr(rho), _c.c_int(ns), _ptr(vjtril[s0:s0 + ns]), st)
+        _vj_pass2_rows(dfobj, lib, 0, naux, nao, _ptr(rho), ns, _ptr(vjtril[s0:s0 + ns]), st)
     return vjtril
 
 
@@ -220,11 +246,13 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True, 
     """K_pq = sum_{L,i} X[L,i,p] X[L,i,q],  X[L,i,p] = sum_q B_L[p,q] orbo[q,i]
     (df_jk.py:353-380; nr_ao2mo.c:399-419,1240-1266).  orb_list: [(orb_dev, nocc_pad, ldo)]."""
     torch = _torch()
-    cderi = dfobj._cderi_dev
-    naux, npair = cderi.shape
-    dev = cderi.device
+    naux, npair = dfobj.tensor_shape()
+    dev = dfobj.tensor_device()
     st = _stream()
     ldx = _round_up(nao, 16)
+    if j_fused is not None and _square_rows(dfobj) is not None:
+        raise RuntimeError('the second J pass inside the SYRK kernel (PAMD_syrk_jfused) reads packed rows: not a schedule of the square layout')
+    cderi = dfobj._packed                       # None in the square layout (every row then has its square form)
     kflags = getattr(dfobj, 'k_syrk_flags', None)
     reserve = 0
     if j_fused is not None:
@@ -274,8 +302,8 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True, 
                 if b1 <= nsq:
                     # fuse_j[set] = rho (naux) zeroed: the first J pass of the density orb orb^T comes out of the epilogue
                     rho_j = fuse_j[iset] if fuse_j is not None else None
-                    _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[s0:s0 + ns]), _c.c_long(sq.shape[2]),
-                          _c.c_int(sq.shape[1]), _c.c_int(ns), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
+                    _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square_ls, _ptr(sq[s0:s0 + ns]), _c.c_long(sq.shape[2]),
+                          _c.c_int(sq.shape[1]), _c.c_long(sq.stride(0)), _c.c_int(ns), _c.c_int(nao), _ptr(orb), _c.c_int(ldo),
                           _c.c_int(orb.shape[0]), _c.c_int(xr), _ptr(xs), _c.c_int(ldx),
                           _ptr(rho_j[s0:]) if rho_j is not None else _c.c_void_p(0),
                           _rho_work(dfobj, lib, ns, ldx, nocc_pad) if rho_j is not None else _c.c_void_p(0), st)
@@ -304,8 +332,7 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True, 
                 rc = box['rc']
                 if rc == 0:
                     continue
-                _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(cderi[b0:b1]), _c.c_long(npair), _c.c_int(nb),
-                      _ptr(fuse_j[iset][b0:]), _c.c_int(1), _ptr(vj_f[iset]), st)
+                _vj_pass2_rows(dfobj, lib, b0, nb, nao, _ptr(fuse_j[iset][b0:]), 1, _ptr(vj_f[iset]), st)
             _call(dfobj, 'dgemm_tn', lib.PAMD_dgemm_tn, _ptr(X), _c.c_int(ldx), _ptr(X), _c.c_int(ldx), _ptr(part),
                   _c.c_int(nao), _c.c_int(nao), _c.c_int(nao), _c.c_long(kx16), _c.c_int(syrk_flags),
                   _c.c_int(nsplit), st)
@@ -318,7 +345,7 @@ def _vk_mo(dfobj, lib, orb_list, nao, after_e2=None, fuse_j=None, j_corun=True, 
 def _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, nocc_pad, out, ldx, rho, rho_work, st):
     """Half transform of the packed rows [b0, b0 + nb) (PAMD_nr_e2_symm), with the diagonal-block side image when the tensor
     object keeps one for these rows (DF.diag_image, ldx = round_up(nao, 16))."""
-    cderi = dfobj._cderi_dev
+    cderi = dfobj._packed
     dg, row0 = dfobj.diag_image() if hasattr(dfobj, 'diag_image') and ldx == _round_up(nao, 16) else (None, 0)
     null = _c.c_void_p(0)
     if dg is not None and b0 >= row0:
@@ -334,9 +361,9 @@ def _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, nocc_pad, out, ldx, rho, rho_w
 def _vk_general(dfobj, lib, dms_dev, nset, nao):
     """vk = einsum('pki,pkj->ij', einsum('pij,jk->pki', B, D), B)   (df_jk.py:382-407)."""
     torch = _torch()
-    cderi = dfobj._cderi_dev
-    naux, npair = cderi.shape
-    dev = cderi.device
+    cderi = dfobj._packed
+    naux, npair = dfobj.tensor_shape()
+    dev = dfobj.tensor_device()
     st = _stream()
     ldx = _round_up(nao, 16)
     rows = _round_up(nao, 16)
@@ -353,7 +380,8 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
     nsq = sq.shape[0] if sq is not None and sq.shape[1] == rows and sq.shape[2] == ldx else 0
     bounds = sorted(set(list(range(0, nsq, blk)) + [nsq] + list(range(nsq, naux, blk)) + [naux]))
     full = None
-    if nsq < naux:
+    padded = sq is not None and nsq and sq.stride(0) != rows * ldx       # square LAYOUT: padded aux-row stride (DF.SQ_STRIDE_PAD)
+    if nsq < naux or padded:
         full = dfobj._workspace('full', (blk, rows, ldx))
         full.zero_()
     for k in range(nset):
@@ -367,6 +395,11 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
             if b1 <= nsq:
                 _half_transform(dfobj, lib, b0, nb, orb, rows, ldo, nao, X, ldx, st)
                 second = sq[b0:b1]
+                if padded:
+                    # the product below reads the rows of consecutive aux indices as ONE tall matrix [nb rows][ldx]: a contiguous copy
+                    # of the block (a device copy against 4 nb nao^3 flops; the general-DM branch is the rare one, df_jk.py:382-407)
+                    full[:nb].copy_(second)
+                    second = full
             else:
                 _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, rows, X, ldx, None, None, st)
                 _call(dfobj, 'unpack_tril', lib.PAMD_unpack_tril, _ptr(cderi[b0:b1]), _c.c_long(npair), _c.c_int(nb), _c.c_int(nao),
@@ -381,11 +414,10 @@ def _vk_general(dfobj, lib, dms_dev, nset, nao):
 
 def _half_transform(dfobj, lib, b0, nb, orb, nocc_pad, ldo, nao, out, ldx, st):
     """out[L][i][p] = sum_q B_L[p,q] orb[q,i] for aux rows [b0, b0 + nb): square-image kernel when the image exists."""
-    cderi = dfobj._cderi_dev
     sq = dfobj.square_image() if hasattr(dfobj, 'square_image') else None
     if sq is not None and b0 + nb <= sq.shape[0]:
-        _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square, _ptr(sq[b0:b0 + nb]), _c.c_long(sq.shape[2]), _c.c_int(sq.shape[1]),
-              _c.c_int(nb), _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(out),
+        _call(dfobj, 'e2_symm', lib.PAMD_nr_e2_square_ls, _ptr(sq[b0:b0 + nb]), _c.c_long(sq.shape[2]), _c.c_int(sq.shape[1]),
+              _c.c_long(sq.stride(0)), _c.c_int(nb), _c.c_int(nao), _ptr(orb), _c.c_int(ldo), _c.c_int(orb.shape[0]), _c.c_int(nocc_pad), _ptr(out),
               _c.c_int(ldx), _c.c_void_p(0), _c.c_void_p(0), st)
     else:
         _e2_packed(dfobj, lib, b0, nb, nao, orb, ldo, nocc_pad, out, ldx, None, None, st)
@@ -398,9 +430,8 @@ def _vk_lowrank(dfobj, lib, lefts, rights, sym, nao):
     C_occ x C_vir^T (rank nocc) needs (pyscf/scf/_response_functions.py:29-247 feeds get_jk with such matrices); densities
     that share their left factor (the occupied orbitals of one reference state) share its half transform."""
     torch = _torch()
-    cderi = dfobj._cderi_dev
-    naux = cderi.shape[0]
-    dev = cderi.device
+    naux = dfobj.tensor_shape()[0]
+    dev = dfobj.tensor_device()
     st = _stream()
     nset = len(lefts)
     ldx = _round_up(nao, 16)
@@ -605,7 +636,8 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                     # side stream behind that block's SYRK (plain SYRK grid) or in line before it (re-tiled + balanced SYRK):
                     # which one is faster depends on the shape (config 3: overlapped 109.5 vs 111.7 ms; taxol on one GPU:
                     # 351 vs 332 ms) - `DF.j2_policy = 'auto'` times both once per shape on tensors of 4 GB and more
-                    naux_l, npair_l = dfobj._cderi_dev.shape
+                    naux_l, npair_l = dfobj.tensor_shape()
+                    square_layout = _square_rows(dfobj) is not None
 
                     def run_fused(serial):
                         rho_f = torch.zeros((nset, naux_l), dtype=torch.float64, device=dms_dev.device)
@@ -616,21 +648,20 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
 
                         def pass2_block(b0, nb, iset):
                             if serial:
-                                _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(dfobj._cderi_dev[b0:b0 + nb]),
-                                      _c.c_long(npair_l), _c.c_int(nb), _ptr(rho_f[iset, b0:]), _c.c_int(1),
-                                      _ptr(vj_f[iset]), _stream())
+                                _vj_pass2_rows(dfobj, lib, b0, nb, nao, _ptr(rho_f[iset, b0:]), 1, _ptr(vj_f[iset]), _stream())
                                 return
                             ev = torch.cuda.Event()
                             ev.record()
                             side.wait_event(ev)
                             with torch.cuda.stream(side):
-                                _call(dfobj, 'vj_pass2', lib.PAMD_df_vj_pass2, _ptr(dfobj._cderi_dev[b0:b0 + nb]),
-                                      _c.c_long(npair_l), _c.c_int(nb), _ptr(rho_f[iset, b0:]), _c.c_int(1),
-                                      _ptr(vj_f[iset]), _c.c_void_p(side.cuda_stream))
+                                _vj_pass2_rows(dfobj, lib, b0, nb, nao, _ptr(rho_f[iset, b0:]), 1, _ptr(vj_f[iset]),
+                                               _c.c_void_p(side.cuda_stream))
                         vk = _vk_mo(dfobj, lib, orb_list, nao, after_e2=pass2_block, fuse_j=rho_f, j_corun=not serial)
                         return vj_f, vk
 
                     policy = getattr(dfobj, 'j2_policy', 'auto')
+                    if policy == 'fused' and square_layout:
+                        policy = 'overlap'                 # (the in-SYRK pass streams PACKED rows: a schedule of the packed layout only)
                     if policy == 'auto':
                         key = (nset, nao, tuple(o[1] for o in orb_list), naux_l,
                                0 if sq is None else sq.shape[0])
@@ -642,7 +673,7 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                             timer, dfobj.kernel_timer = getattr(dfobj, 'kernel_timer', None), None
                             run_fused(False)                                     # priming: lazy images, workspaces
                             times = {}
-                            for name in ('overlap', 'serial') + (('fused',) if getattr(dfobj, 'j2_try_fused', False) else ()):
+                            for name in ('overlap', 'serial') + (('fused',) if getattr(dfobj, 'j2_try_fused', False) and not square_layout else ()):
                                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                                 torch.cuda.current_stream().wait_stream(side)
                                 e0.record()
@@ -696,11 +727,11 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
     """Same contract as ``pyscf.df.df_jk.get_jk`` (df_jk.py:280): returns (vj, vk) shaped like dm."""
     assert with_j or with_k
     torch = _torch()
-    if (not with_k and dfobj._cderi_dev is None and dfobj._cderi is None and
+    if (not with_k and not dfobj.has_tensor() and dfobj._cderi is None and
             not getattr(dfobj, 'incore_anyway', False)):
         # 3-index tensor not initialised: integral-direct J (df_jk.py:282-285)
         return get_j(dfobj, dm, hermi, direct_scf_tol), None
-    if dfobj._cderi_dev is None and getattr(dfobj, '_native', None) is None:
+    if not dfobj.has_tensor() and getattr(dfobj, '_native', None) is None:
         dfobj.build()
     if getattr(dfobj, '_native', None) is not None:
         # the tensor did not fit the device: the C handle holds it (HBM + page-locked host rows, DF.build) and answers - through
@@ -716,7 +747,7 @@ def get_jk(dfobj, dm, hermi=0, with_j=True, with_k=True, direct_scf_tol=1e-13):
     nao = dm_shape[-1]
     dms = np.ascontiguousarray(dms.reshape(-1, nao, nao), dtype=np.float64)
     nset = dms.shape[0]
-    dev = dfobj._cderi_dev.device
+    dev = dfobj.tensor_device()
     dms_dev = _HostDM(dms, dev)                 # uploaded only if a kernel reads the matrix (not on the fused MO branch)
     # r06: where a host-API call spends its host time (bench.py `host_api_breakdown_ms`): DF.host_timing = []
     # collects one dict per call - prepare (orbital blocks, padding, upload), queue (kernel launches), probe (tag check on the

@@ -60,8 +60,11 @@ def _decompose_j2c(j2c, lindep, decompose='CD', device=None):
 
 
 def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_THR,
-                     slab_bytes=24 << 30, engine=None, return_engine=False, omega=0.0, decompose_j2c='CD'):
-    """Rows [l0, l1) of cderi (naux, nao_pair) as a torch CUDA tensor."""
+                     slab_bytes=24 << 30, engine=None, return_engine=False, omega=0.0, decompose_j2c='CD', layout='packed'):
+    """Rows [l0, l1) of cderi as a torch CUDA tensor: (nL, nao_pair) packed like the reference's `_cderi`
+    (pyscf/df/df.py:59-72), or - layout='square', r06 - (nL, rows, rows) with both triangles of every B_L (rows =
+    round_up(nao, 16), pads zero): every column slab is solved into a work buffer and scattered into the square rows
+    (PAMD_unpack_tril_slab), the packed tensor never exists."""
     import torch
     lib = _lib_mod.load_library()
     eng = engine or get_engine(mol, auxmol, device, omega)
@@ -83,13 +86,21 @@ def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_TH
     mt_dev = torch.from_numpy(mt).to(device)
     if torch.device(device).type == 'cuda':
         free = (torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
-        need = nL * npair * 8 + min(slab_bytes, npair * naux * 8)
+        rows_sq = (nao + 15) // 16 * 16
+        need = (nL * npair * 8 if layout != 'square' else nL * rows_sq * rows_sq * 8 + min(slab_bytes, npair * nL * 8)) + \
+            min(slab_bytes, npair * naux * 8)
         if need > free:
             raise MemoryError('DF tensor shard of %d x %d doubles (%.1f GB + %.1f GB of slab workspace) does not fit the %.1f GB '
                               'free on %s: shard the auxiliary index over more ranks (one process per GPU), the out-of-core '
                               'contraction of pyscf/df/outcore.py is not restated'
                               % (nL, npair, nL * npair * 8e-9, min(slab_bytes, npair * naux * 8) * 1e-9, free * 1e-9, device))
-    cderi = torch.empty((nL, npair), dtype=torch.float64, device=device)
+    square = layout == 'square'
+    if square:
+        rows_sq = (nao + 15) // 16 * 16
+        from .df import DF as _DF
+        cderi = _DF.alloc_square(nL, rows_sq, device)          # zeroed, padded aux-row stride (DF.SQ_STRIDE_PAD)
+    else:
+        cderi = torch.empty((nL, npair), dtype=torch.float64, device=device)
     # AO row-shell slabs bounded by slab_bytes of T = [rows][naux]
     nsh = eng.ao.n
     max_rows = max(int(slab_bytes // (naux * 8)), 1)
@@ -106,10 +117,26 @@ def cholesky_eri_gpu(mol, auxmol, device, l0=None, l1=None, lindep=LINEAR_DEP_TH
         sh0 = sh1
     bufrows = max(eng.slab_rows(a, b)[1] - eng.slab_rows(a, b)[0] for a, b in slabs)
     T = torch.empty((bufrows, naux), dtype=torch.float64, device=device)
+    slab_out = torch.empty((max(nL, 1) * bufrows,), dtype=torch.float64, device=device) if square else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for sh0, sh1 in slabs:
         r0, r1 = eng.slab_rows(sh0, sh1)
         Tv = eng.int3c2e_slab(sh0, sh1, out=T)
+        if square:
+            # the slab's packed columns [r0, r1) of every aux row, ld = r1 - r0, then both triangles of the square rows
+            ncol = r1 - r0
+            p0 = int(eng.ao.ao0[sh0])
+            p1 = int(eng.ao.ao0[sh1]) if sh1 < eng.ao.n else nao
+            _lib_mod.check(lib.PAMD_cderi_solve(
+                ctypes.c_void_p(mt_dev.data_ptr()), ctypes.c_int(lda),
+                ctypes.c_void_p(Tv.data_ptr()), ctypes.c_long(naux),
+                ctypes.c_void_p(slab_out.data_ptr()), ctypes.c_long(ncol),
+                ctypes.c_int(nL), ctypes.c_long(ncol), ctypes.c_int(naux), ctypes.c_int(l0),
+                ctypes.c_int(1 if tri else 0), st))
+            _lib_mod.check(lib.PAMD_unpack_tril_slab(
+                ctypes.c_void_p(slab_out.data_ptr()), ctypes.c_long(ncol), ctypes.c_int(nL), ctypes.c_int(p0), ctypes.c_int(p1),
+                ctypes.c_void_p(cderi.data_ptr()), ctypes.c_int(rows_sq), ctypes.c_long(cderi.stride(0)), st))
+            continue
         _lib_mod.check(lib.PAMD_cderi_solve(
             ctypes.c_void_p(mt_dev.data_ptr()), ctypes.c_int(lda),
             ctypes.c_void_p(Tv.data_ptr()), ctypes.c_long(naux),

@@ -133,7 +133,8 @@ def _scaled_occupied(c, occ):
 class _Options(_c.Structure):
     """PAMD_df_options of include/pyscf_amd.h"""
     _fields_ = [('lindep', _c.c_double), ('omega', _c.c_double), ('devices', _c.POINTER(_c.c_int)), ('ndev', _c.c_int),
-                ('flags', _c.c_int), ('max_device_bytes', _c.c_longlong), ('part', _c.c_int), ('nparts', _c.c_int)]
+                ('flags', _c.c_int), ('max_device_bytes', _c.c_longlong), ('part', _c.c_int), ('nparts', _c.c_int),
+                ('reserve_bytes', _c.c_longlong)]
 
 
 class NativeDF:
@@ -160,6 +161,9 @@ class NativeDF:
         self._h = None
         self._naux = None
         self._rsh_df = {}                         # omega -> NativeDF of that operator (pyscf/df/df.py:298-333 range_coulomb)
+        # r06 - one HBM budget: bytes per device the XC leg of the same calculation will cache (Kohn-Sham objects set it in
+        # density_fit); the handle holds the rows in the square layout (2x, no second copy) only when that still fits
+        self.xc_image_hint = 0
 
     def build(self):
         if self._h is not None:
@@ -175,9 +179,13 @@ class NativeDF:
         h = _c.c_void_p()
         devs = self.devices if self.devices is not None else [int(self.device)]
         arr = (_c.c_int * len(devs))(*devs)
-        flags = (1 if self.devices is not None else 0) | (2 if self.shard is not None else 0)
+        reserve = 0
+        if self.xc_image_hint:
+            # the compact image is dealt over the parts; its work buffers (12 GB) exist on every device
+            reserve = int(self.xc_image_hint) // max(len(set(devs)), 1) + (12 << 30)
+        flags = (1 if self.devices is not None else 0) | (2 if self.shard is not None else 0) | (4 if reserve else 0)
         part, nparts = self.shard if self.shard is not None else (0, 1)
-        opt = _Options(self.lindep, self.omega, arr, len(devs), flags, self.max_device_bytes, part, nparts)
+        opt = _Options(self.lindep, self.omega, arr, len(devs), flags, self.max_device_bytes, part, nparts, reserve)
         _check(load().PAMD_df_create_ex(atm.ctypes.data_as(_c.c_void_p), _c.c_int(len(atm)), bas.ctypes.data_as(_c.c_void_p),
                                         _c.c_int(len(mol._bas)), _c.c_int(len(aux._bas)), env.ctypes.data_as(_c.c_void_p),
                                         _c.c_int(len(env)), _c.byref(opt), _c.byref(h)))
@@ -236,7 +244,8 @@ class NativeDF:
         rows = (_c.c_int * 64)()
         _check(load().PAMD_df_layout(self._h, lay, rows))
         return dict(parts=lay[0], rows_resident=lay[1], rows_host=lay[2], rows_square=lay[3], peer=lay[4],
-                    part_rows=[rows[i] for i in range(lay[0])])
+                    part_rows=[rows[i] for i in range(lay[0])],
+                    tensor_layout='square' if load().PAMD_df_tensor_layout(self._h) else 'packed')
 
     def range_coulomb(self, omega):
         """The handle of erf(omega r12)/r12 (omega > 0) or erfc(|omega| r12)/r12 (omega < 0), cached per omega."""

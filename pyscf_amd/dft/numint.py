@@ -59,6 +59,16 @@ def pick_nsplit(ntiles, slots=512, lo=2, hi=12):
     return best
 
 
+def estimate_ao_image_bytes(mol, ncomp=4):
+    """Upper estimate of the compact AO image the block-sparse plan will cache (dft/sparse_grid.py), before any grid exists: a
+    level-3 pruned grid has ~12 500 points per atom (config 3: 11.2 k, taxol: 12.2 k measured), and a 512-point tile sees at most
+    ~750 of the AO functions above the 1e-13 cutoff however large the molecule is (locality; measured means: 406 at config 3, 697
+    at taxol).  Used as the XC share of the HBM budget (df.DF.xc_image_hint)."""
+    nao = int(mol.nao_nr()) if hasattr(mol, 'nao_nr') else int(mol.nao)
+    natm = len(mol._atm)
+    return int(12500 * natm * ncomp * 8 * min(nao, 750))
+
+
 class NumInt:
     """Duck-types the attributes RKS.get_veff uses (pyscf/dft/rks.py:76-131,384-404)."""
     libxc = _xc
@@ -88,7 +98,9 @@ class NumInt:
         self.fuse_rho = True            # r04: GGA densities in the epilogue of the orbital product (PAMD_sub_orb_rho)
         self.vmat_sym = True            # r04: V = M + M^T on balanced blocks, lower triangle only (PAMD_sub_vmat_sym); False: the r03 kernel
         self.ao_cache = 'auto'          # keep the compact AO image in HBM across calls: True / False / 'auto' (if it fits)
-        self.ao_cache_reserve = 40 << 30    # HBM left free after caching ('auto')
+        self.ao_cache_reserve = 14 << 30    # HBM left free after caching ('auto'): the plan's own work space (orbital-product chunk
+                                            # buffer <= 6 GB, aow image, dense evaluation block).  r06: was a blanket 40 GB, which turned the
+                                            # cache off at taxol size although 70 GB were free (VERDICT r05 Weak 4)
 
     # -- functional properties --------------------------------------------------------------
     def _xc_type(self, xc_code):

@@ -80,6 +80,16 @@ class SparsePlan:
             self.ao_c[self.ao_total:].zero_()
             for ch in self.chunks:
                 self.fill_chunk(ch, self.ao_c[ch['ao_base']:])
+            from ..lib import hbm
+            hbm.hold(self.dev, 'xc_image', (self.ao_total + 256) * 8)      # the XC share of the one HBM budget (lib/hbm.py)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'ao_c', None) is not None:
+                from ..lib import hbm
+                hbm.drop(self.dev, 'xc_image')
+        except Exception:
+            pass
 
     # -- geometry of the dense evaluation passes -------------------------------------------------------------------
     def _tile_runs(self, max_tiles):

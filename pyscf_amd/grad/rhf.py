@@ -150,10 +150,50 @@ def two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale=1.0):
     return W, linv_loc, y_pq
 
 
-def z_slab(W, linv_loc, r0, r1, out=None):
-    """Z_T[pq][Q] for the packed rows pq in [r0, r1), summed over the LOCAL aux rows: (r1 - r0, nq)."""
+def _timed(dfobj, name, fn):
+    """Run fn() between two HIP events when the object carries a kernel timer (tools/grad_bench.py: per-phase ms of the gradient)."""
+    timer = getattr(dfobj, 'kernel_timer', None)
+    if timer is None:
+        return fn()
     import torch
-    return torch.matmul(W[:, r0:r1].T, linv_loc, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    timer.records.append((name, e0, e1))
+    return out
+
+
+def z_slab(W, linv_loc, r0, r1, out=None, dfobj=None, work=None):
+    """Z_T[pq][Q] = sum_L W[L][pq] M[L][Q] for the packed rows pq in [r0, r1), summed over the LOCAL aux rows: (r1 - r0, nq) - the
+    naux^2 nao_pair flops of the gradient (pyscf/df/grad/rhf.py:117-199 streams the same contraction block by block).
+    r06: the library's own FP64-MFMA TN GEMM (PAMD_dgemm_tn, 160 x 128 tiles, LDS-DMA operands) instead of
+    torch.matmul = rocBLAS.  Its A operand must be addressable inside one 4 GiB window per k-range, which W[L][pq] (13.8 MB per
+    aux row at config 3) is not: the slab's columns are first copied into a contiguous [k][ncol] work buffer - the slab is <= 4 GB,
+    the copy moves 2 x 4 GB against 2 naux^2 ncol flops.  `work` = (wbuf, mbuf): the work buffer and M padded to a multiple of 16
+    rows (zero rows), made once per gradient; without it (or DF.grad_z_gemm = 'torch') the library GEMM runs."""
+    import torch
+    if work is None or getattr(dfobj, 'grad_z_gemm', 'hip') != 'hip':
+        return _timed(dfobj, 'z_slab_gemm', lambda: torch.matmul(W[:, r0:r1].T, linv_loc, out=out))
+    wbuf, mbuf = work
+    k, ncol = W.shape[0], r1 - r0
+    k16, nq = mbuf.shape
+    lda = (ncol + 1) // 2 * 2
+    wb = wbuf[:k16 * lda].view(k16, lda)
+    if lda != ncol:
+        wb[:, ncol:].zero_()
+    wb[:k, :ncol].copy_(W[:, r0:r1])
+    if k16 > k:
+        wb[k:].zero_()
+    if out is None:
+        out = torch.empty((ncol, nq), dtype=torch.float64, device=W.device)
+    out.zero_()                                         # the GEMM accumulates (FP64 atomics of its split-K form; one split here)
+    so = _lib_mod.load_library()
+    st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _timed(dfobj, 'z_slab_gemm', lambda: _lib_mod.check(so.PAMD_dgemm_tn(
+        _ptr(wb), _c.c_int(lda), _ptr(mbuf), _c.c_int(nq), _ptr(out), _c.c_int(nq), _c.c_int(ncol), _c.c_int(nq),
+        _c.c_long(k16), _c.c_int(2), _c.c_int(1), st)))
+    return out
 
 
 def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, grad):
@@ -162,13 +202,13 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     integrals; a short-range one (omega < 0) the Coulomb integrals with (Z, Y) and the long-range ones with (-Z, -Y)."""
     import torch
     _need_torch_df(dfobj)
-    if dfobj._cderi_dev is None and getattr(dfobj, '_native', None) is None:
+    if not dfobj.has_tensor() and getattr(dfobj, '_native', None) is None:
         dfobj.build()
     if getattr(dfobj, '_native', None) is not None:
         raise NotImplementedError('analytic gradients need the in-core tensor; this DF object holds it out of core (C handle): '
                                   'shard the auxiliary index over more ranks')
-    dev = dfobj._cderi_dev.device
-    dfobj.drop_square_image()            # W below takes the size of cderi
+    dev = dfobj.tensor_device()
+    dfobj.drop_square_image()            # W below takes the size of cderi (square layout: packed first, DF.to_packed_layout)
     sharded = dfobj.world_size > 1 and getattr(dfobj, '_shard_override', None) is None
     eng = get_engine(mol, dfobj.auxmol, dev, dfobj.omega)
     naux = eng.aux.nao
@@ -181,7 +221,7 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     if l1 - l0 != nrow_local:
         raise RuntimeError('the tensor has %d rows here, the metric decomposes into %d (this rank: %d)'
                            % (nrow_local, mh.shape[0], l1 - l0))
-    W, linv_loc, y_pq = two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale)
+    W, linv_loc, y_pq = _timed(dfobj, 'two_particle_densities', lambda: two_particle_densities(dfobj, dm_tot, occ_blocks, kscale, mh, jscale))
     y_pq = y_pq.contiguous()
     _dbg('W,Y built')
     nq = linv_loc.shape[1]
@@ -208,12 +248,24 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     bufrows = max(eng.slab_rows(a, b)[1] - eng.slab_rows(a, b)[0] for a, b in slabs)
     zbuf = torch.empty((bufrows, nq), dtype=torch.float64, device=dev)
     dfobj._grad_slabs = len(slabs)
+    # operands of the hand-written slab GEMM (z_slab): a contiguous [k16][slab columns] copy buffer + 256 doubles of slack for the
+    # LDS-DMA kernels' whole-panel reads, and M with its rows padded to a multiple of 16; needs even nq and a 16-byte aligned M
+    zwork = None
+    k16 = (nrow_local + 15) // 16 * 16
+    if getattr(dfobj, 'grad_z_gemm', 'hip') == 'hip' and nq % 2 == 0 and nrow_local > 0:
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        need = (k16 * (bufrows + 2) + k16 * nq + 512) * 8
+        if need + (2 << 30) <= free:
+            wbuf = torch.zeros(k16 * (bufrows + 2) + 256, dtype=torch.float64, device=dev)
+            mbuf = torch.zeros(k16 * nq + 256, dtype=torch.float64, device=dev)[:k16 * nq].view(k16, nq)
+            mbuf[:nrow_local].copy_(linv_loc)
+            zwork = (wbuf, mbuf)
     passes = [None] if dfobj.omega >= 0 else [0.0, -dfobj.omega]
     world, rank = (dfobj.world_size, dfobj.rank) if sharded else (1, 0)
     try:
         for islab, (sa, sb) in enumerate(slabs):
             r0, r1 = eng.slab_rows(sa, sb)
-            z = z_slab(W, linv_loc, r0, r1, out=zbuf[:r1 - r0])
+            z = z_slab(W, linv_loc, r0, r1, out=zbuf[:r1 - r0], dfobj=dfobj, work=zwork)
             owner = islab % world
             if sharded:
                 import torch.distributed as dist
@@ -230,13 +282,15 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
                 if ip == 1:
                     z.neg_()
                 # (1) sum Z dA: 3-centre derivative blocks of this slab
-                for pc in eng.pair_classes():
-                    i0, i1 = pc.subrange(sa, sb)
-                    if i1 <= i0:
-                        continue
-                    for ac in eng.aux_classes():
-                        eng.grad_launch(pc, ac, z, nq, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, auxbasis_response, i0=i0, i1=i1,
-                                        row_offset=r0)
+                def _deriv_blocks():
+                    for pc in eng.pair_classes():
+                        i0, i1 = pc.subrange(sa, sb)
+                        if i1 <= i0:
+                            continue
+                        for ac in eng.aux_classes():
+                            eng.grad_launch(pc, ac, z, nq, 1, eng.ao_xyz, eng.ao_ao0, ao_atom, grad, auxbasis_response, i0=i0, i1=i1,
+                                            row_offset=r0)
+                _timed(dfobj, 'int3c2e_grad', _deriv_blocks)
         _dbg('3c slabs done')
         # (2) sum Y dM: 2-centre metric (every rank its partial Y)
         if auxbasis_response:
@@ -268,12 +322,12 @@ def grad_elec_df(mol, dfobj, dm_tot, occ_blocks, dme, kscale=1.0, auxbasis_respo
     import torch
     so = _lib_mod.load_library()
     _need_torch_df(dfobj)
-    if dfobj._cderi_dev is None and getattr(dfobj, '_native', None) is None:
+    if not dfobj.has_tensor() and getattr(dfobj, '_native', None) is None:
         dfobj.build()
     if getattr(dfobj, '_native', None) is not None:
         raise NotImplementedError('analytic gradients need the in-core tensor; this DF object holds it out of core (C handle): '
                                   'shard the auxiliary index over more ranks')
-    dev = dfobj._cderi_dev.device
+    dev = dfobj.tensor_device()
     natm = mol.natm
     grad = torch.zeros((NREP, natm, 3), dtype=torch.float64, device=dev)
     eng = _grad_2e(mol, dfobj, dm_tot, occ_blocks, 1.0, kscale, auxbasis_response, grad)

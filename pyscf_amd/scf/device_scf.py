@@ -75,12 +75,12 @@ def eligible(mf, callback=None):
     # A predicate must not build a tensor of hundreds of GB as a side effect: ask the cheap fit check
     if getattr(mf.with_df, '_native', None) is not None:
         return False
-    if mf.with_df._cderi_dev is None and not isinstance(mf.with_df._cderi, (str, np.ndarray)) and \
+    if not mf.with_df.has_tensor() and not isinstance(mf.with_df._cderi, (str, np.ndarray)) and \
             not mf.with_df._all_ranks_agree(mf.with_df.would_fit()):       # (collective: every rank takes the same loop)
         return False
     # every other condition holds and the tensor fits: the loop needs it now anyway (a build that still ends out of core - the
     # estimate and the allocator disagreeing by a hair - keeps the host loop)
-    if mf.with_df._cderi_dev is None:
+    if not mf.with_df.has_tensor():
         mf.with_df.build()
     return getattr(mf.with_df, '_native', None) is None
 
@@ -258,7 +258,7 @@ class _Veff:
                 t0 = time.perf_counter()
                 mf.grids.build()
                 mf._log('setting up grids: %d points, %.2f s', mf.grids.size, time.perf_counter() - t0)
-        if mf.with_df._cderi_dev is None:        # (a pure functional's first J may have gone the integral-direct way)
+        if not mf.with_df.has_tensor():        # (a pure functional's first J may have gone the integral-direct way)
             mf.with_df.build()
         self.t_jk = self.t_xc = 0.0
 

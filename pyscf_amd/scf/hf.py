@@ -441,6 +441,11 @@ class SCF:
             with_df = df.DF(self.mol, auxbasis)
         self.with_df = with_df
         self.only_dfj = bool(only_dfj)         # fitted J, exact in-core K (df_jk.py:52-54, RIJONX)
+        if hasattr(self, '_numint') and hasattr(with_df, 'xc_image_hint') and not with_df.xc_image_hint:
+            # r06 - one HBM budget: the tensor object of a Kohn-Sham calculation learns what the XC leg will
+            # want to keep in HBM, so that its layout decision (square rows / packed + optional image) never evicts the AO cache
+            from ..dft.numint import estimate_ao_image_bytes
+            with_df.xc_image_hint = estimate_ao_image_bytes(self.mol)
         return self
 
     def kernel(self, dm0=None):

@@ -7,10 +7,13 @@ from oracle import ref
 pytestmark = pytest.mark.gpu
 
 
-def _dfobj(mol, cderi):
+def _dfobj(mol, cderi, layout='packed'):
+    """The tests of this module exercise the PACKED layout (the reference's rows + the optional square / diagonal-block images of
+    r03, what a rank without 2x the tensor of HBM runs); the square layout has its own module (test_gpu_square_layout.py)."""
     from pyscf_amd import df
     obj = df.DF(mol)
     obj._cderi = cderi
+    obj.layout = layout
     obj.build()
     return obj
 

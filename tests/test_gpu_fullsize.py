@@ -202,17 +202,28 @@ def test_config3_full_jk_vs_oracle_golden(h2o32):
         assert abs(np.einsum('ij,ji', dm, vk) - g['tr_d_vk']) < 1e-9 * abs(g['tr_d_vk']), tag
         assert abs(golden_util.fp(vj) - g['vj_fp']) < 1e-9 * g['vj_norm'], tag
         assert abs(golden_util.fp(vk) - g['vk_fp']) < 1e-9 * g['vk_norm'], tag
-    check(*df_jk.get_jk_device(obj, dms, orbs), 'square image')
-    sq, ksq = obj._cderi_sq, obj.k_square
-    obj._cderi_sq, obj.k_square = None, False                 # packed-operand half transform (ranks without the HBM)
+    check(*df_jk.get_jk_device(obj, dms, orbs), 'square layout')
+    assert obj._layout == 'square'          # r06: the square rows are what build() made (the packed copy the earlier test asked for is lazy)
+    for pol in ('serial', 'overlap'):
+        obj.j2_policy = pol
+        check(*df_jk.get_jk_device(obj, dms, orbs), 'square layout, second J pass ' + pol)
+    obj.j2_policy = 'auto'
+    # the packed layout on the same rows (ranks without the HBM): packed-operand half transform with / without the diagonal-block image
+    from pyscf_amd import df as _df
+    pk = _df.DF(obj.mol)
+    pk._cderi_dev = obj.packed_rows(0, obj.tensor_shape()[0])
+    pk._naux, pk.auxmol = obj._naux, obj.auxmol
+    pk.k_square = False
     try:
-        check(*df_jk.get_jk_device(obj, dms, orbs), 'packed operand + diagonal-block image')
-        assert obj._cderi_diag is not None and obj._cderi_diag.shape[0] == obj.get_naoaux()
-        obj._cderi_diag, obj.k_diag = None, False
-        check(*df_jk.get_jk_device(obj, dms, orbs), 'packed operand')
+        check(*df_jk.get_jk_device(pk, dms, orbs), 'packed operand + diagonal-block image')
+        assert pk._cderi_diag is not None and pk._cderi_diag.shape[0] == obj.get_naoaux()
+        pk._cderi_diag, pk.k_diag = None, False
+        check(*df_jk.get_jk_device(pk, dms, orbs), 'packed operand')
+        pk.j2_policy = 'fused'
+        check(*df_jk.get_jk_device(pk, dms, orbs), 'packed operand, second J pass inside the SYRK')
     finally:
-        obj._cderi_sq, obj.k_square = sq, ksq
-        obj._cderi_diag, obj.k_diag = None, True
+        del pk
+        torch.cuda.empty_cache()
     # the reference-style host API (numpy in / out, tagged DM) on the same tensor
     vj_h, vk_h = obj.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=np.full(nocc, 2.0)), hermi=1)
     assert np.abs(vj_h[ri, ci] - vj_s).max() < 1e-9 * g['vj_absmax']

@@ -62,7 +62,7 @@ def test_df_options_struct_matches_the_header():
     body = re.search(r'typedef struct PAMD_df_options \{(.*?)\} PAMD_df_options;', hdr, re.S).group(1)
     names = re.findall(r'(\w+);\s*(?:/\*.*?\*/)?\s*$', body, re.M)
     assert names == [f[0] for f in native._Options._fields_], (names, native._Options._fields_)
-    assert C.sizeof(native._Options) == 8 + 8 + 8 + 4 + 4 + 8 + 4 + 4
+    assert C.sizeof(native._Options) == 8 + 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8          # r06: + reserve_bytes
 
 
 def test_density_fit_device_list_plumbing_without_a_device():

@@ -90,9 +90,11 @@ def test_bench_golden_density_is_the_generators():
     class A:
         molecule, nwater, basis = 'water', 32, 'cc-pvtz'
     assert bench._golden_case(A, 1856, 160) == ('h2o32_ccpvtz_oracle.json', '', 160)
-    A.nwater = 8
-    assert bench._golden_case(A, 464, 40) is None
-    out = bench._parity_golden(A, 464, 40, None)
+    A.nwater = 8                      # r06: the small case of the launch tests has its golden too
+    assert bench._golden_case(A, 464, 40) == ('h2o8_ccpvtz_oracle.json', '', 40)
+    A.nwater = 5
+    assert bench._golden_case(A, 290, 25) is None
+    out = bench._parity_golden(A, 290, 25, None)
     assert out['golden'] is None and 'why' in out
 
 

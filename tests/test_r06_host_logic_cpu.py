@@ -1,0 +1,184 @@
+"""Host-side logic added in r06 that needs no GPU: the collective out-of-core / layout decision (gloo, world 2), the HDF5 datatype
+probe, the clear errors of a from_rows handle, the re-entrant pinned pool, the bounded matrix-vector probe, the HBM book-keeping,
+the XCD-aware SYRK order table, the square-layout bookkeeping of df.DF."""
+import ctypes
+import gc
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pyscf_amd import df
+    obj = df.DF(None)
+    # rank 1 says "does not fit": MIN over the ranks -> nobody stays in core; both say "fits" -> everybody does
+    a = obj._all_ranks_agree(rank == 0)
+    b = obj._all_ranks_agree(True)
+    c = obj._all_ranks_agree(False)
+    q.put((rank, a, b, c))
+    dist.destroy_process_group()
+
+
+def test_out_of_core_decision_is_collective_over_the_ranks():
+    """each rank used to decide from its own memory query; ranks that disagreed issued different collectives."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, False, True, False), (1, False, True, False)]
+    # without a process group the flag is the rank's own
+    from pyscf_amd import df
+    assert df.DF(None)._all_ranks_agree(True) is True and df.DF(None)._all_ranks_agree(False) is False
+
+
+def test_hdf5_datatype_probe_refuses_anything_but_little_endian_float64(tmp_path):
+    from pyscf_amd.lib import hdf5
+    if not hdf5.available():
+        pytest.skip('no libhdf5 in this image')
+    path = str(tmp_path / 't.h5')
+    with hdf5.File(path, 'w') as f:
+        f.create_dataset('j3c', (3, 6)).write_rows(0, np.arange(18.).reshape(3, 6))
+    with hdf5.File(path) as f:
+        assert f['j3c'].is_native_f64_le() and f['j3c'].file_offset() is not None
+    # a float32 dataset written through the C API directly
+    lib = hdf5._load()
+    hid = hdf5._hid
+    f32 = hid.in_dll(lib, 'H5T_NATIVE_FLOAT_g').value
+    p2 = str(tmp_path / 'f32.h5')
+    fid = lib.H5Fcreate(p2.encode(), 2, hid(0), hid(0))            # H5F_ACC_TRUNC
+    assert fid >= 0
+    dims = (ctypes.c_uint64 * 2)(3, 6)
+    sp = lib.H5Screate_simple(2, dims, None)
+    ds = lib.H5Dcreate2(hid(fid), b'j3c', hid(f32), hid(sp), hid(0), hid(0), hid(0))
+    assert ds >= 0
+    data = np.arange(18, dtype=np.float32)
+    assert lib.H5Dwrite(hid(ds), hid(f32), hid(0), hid(0), hid(0), data.ctypes.data_as(ctypes.c_void_p)) >= 0
+    lib.H5Dclose(hid(ds))
+    lib.H5Sclose(hid(sp))
+    lib.H5Fclose(hid(fid))
+    with hdf5.File(p2) as f:
+        assert not f['j3c'].is_native_f64_le()
+
+
+def test_from_rows_handle_refuses_range_coulomb_and_reset_mol():
+    from pyscf_amd.df.native import NativeDF
+    obj = NativeDF.__new__(NativeDF)
+    obj.__init__(None)
+    obj.auxmol = False                       # what from_rows leaves: no auxiliary molecule, the rows came ready-made
+    with pytest.raises(NotImplementedError, match='ready-made'):
+        obj.range_coulomb(0.3)
+    with pytest.raises(NotImplementedError, match='ready-made'):
+        obj.reset(mol=object())
+    assert obj.range_coulomb(0) is obj and obj.reset() is obj
+
+
+def test_pinned_pool_release_is_reentrant_under_its_own_lock():
+    """the finalizer of a result array may fire on the thread that is inside take() (cyclic GC): the lock is re-entrant."""
+    from pyscf_amd.lib.pinned import PinnedPool
+    bufs = []
+
+    def alloc(nbytes):
+        b = (ctypes.c_char * nbytes)()
+        bufs.append(b)
+        return ctypes.addressof(b), b
+    pool = PinnedPool(alloc)
+    arr, blk = pool.take(16)
+    with pool._lock:                          # as if a GC run inside take() collected an earlier result
+        pool._release(blk)
+    assert blk.busy is False
+    del arr
+    gc.collect()
+    a2, b2 = pool.take(16)
+    assert b2 is blk and pool.stats() == {'blocks': 1, 'busy': 1}
+
+
+def test_bounded_matvec_and_full_probe():
+    from pyscf_amd import lib
+    rng = np.random.default_rng(0)
+    m, v = rng.standard_normal((300, 300)), rng.standard_normal(300)
+    assert np.allclose(lib.bounded_matvec(m, v), m.dot(v), rtol=0, atol=1e-12)
+    c = rng.standard_normal((300, 40))
+    dm = c.dot(c.T)[None]
+    assert lib.dm_orbital_mismatch(dm, [c]) < 1e-12
+    fd = dm.copy()
+    fd[0, 1, 2] += 1e-4
+    fd[0, 2, 1] += 1e-4
+    assert lib.dm_orbital_mismatch(fd, [c]) > 1e-8
+
+
+def test_hbm_bookkeeping():
+    from pyscf_amd.lib import hbm
+    hbm.hold(0, 'xc_image', 123)
+    hbm.hold(torch.device('cuda', 1) if False else 1, 'xc_image', 7)
+    assert hbm.held(0, 'xc_image') == 123 and hbm.held(1, 'xc_image') == 7 and hbm.held(0, 'other') == 0
+    hbm.drop(0, 'xc_image')
+    hbm.drop(1, 'xc_image')
+    assert hbm.held(0, 'xc_image') == 0
+
+
+def test_square_layout_bookkeeping_without_a_device():
+    """df.DF: `_cderi_dev` is a property over the packed rows; has_tensor / tensor_shape never materialise anything; the reserve of
+    the one HBM budget subtracts what the XC plan already holds; estimate of the compact AO image."""
+    from pyscf_amd import df, gto
+    from pyscf_amd.dft.numint import estimate_ao_image_bytes
+    from pyscf_amd.lib import hbm
+    obj = df.DF(None)
+    assert not obj.has_tensor() and obj._cderi_dev is None and obj._layout is None
+    t = torch.zeros((5, 6), dtype=torch.float64)
+    obj._cderi_dev = t
+    assert obj.has_tensor() and obj._layout == 'packed' and obj.tensor_shape() == (5, 6) and obj._cderi_dev is t
+    assert obj.packed_rows(1, 3).shape == (2, 6)
+    obj.reset()
+    assert not obj.has_tensor() and obj._layout is None
+    df.DF.SQ_STRIDE_PAD, keep = 32, df.DF.SQ_STRIDE_PAD
+    sq = df.DF.alloc_square(3, 16, 'cpu')
+    df.DF.SQ_STRIDE_PAD = keep
+    assert sq.shape == (3, 16, 16) and sq.stride() == (16 * 16 + 32, 16, 1) and float(sq.abs().sum()) == 0
+    mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis='cc-pvdz')
+    est = estimate_ao_image_bytes(mol)
+    assert est == 12500 * 3 * 4 * 8 * 24
+    o2 = df.DF(mol)
+    o2.device = 'cpu'
+    o2.k_block_bytes = 1 << 20
+    base = o2._reserve_after_build(10, 32)
+    o2.xc_image_hint = 1000
+    assert o2._reserve_after_build(10, 32) == base + 1000 + (12 << 30)
+    hbm.hold('cpu', 'xc_image', 400)
+    try:
+        assert o2._reserve_after_build(10, 32) == base + 600 + (12 << 30)
+    finally:
+        hbm.drop('cpu', 'xc_image')
+
+
+def test_kohn_sham_density_fit_tells_the_tensor_about_the_xc_image():
+    from pyscf_amd import gto, scf, dft
+    mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587', basis='sto-3g')
+    assert scf.RHF(mol).density_fit().with_df.xc_image_hint == 0
+    ks = dft.RKS(mol, xc='b3lyp').density_fit()
+    assert ks.with_df.xc_image_hint > 0
+    ku = dft.UKS(mol, xc='b3lyp').density_fit(devices=[0])
+    assert ku.with_df.xc_image_hint > 0          # the host-array handle object carries it into PAMD_df_options.reserve_bytes

@@ -17,7 +17,9 @@ if d.get('comm'):
                                          'sum_download_ms', 'compute_ms_per_part', 'algorithm_GBs_per_link') if k in c})
 if d.get('kernels'):
     print('  kernels', {k: v['ms_total'] for k, v in d['kernels'].items()})
+print('  layout', (d.get('config') or {}).get('tensor_layout'), 'hbm after build', (d.get('config') or {}).get('hbm_after_build_GB'), 'schedule', d.get('jk_schedule'), 'host calls', d.get('host_api_ms_calls'), (d.get('host_api_breakdown_ms') or [None])[0])
 x = d.get('xc_path') or {}
+print('  xc cached', (x.get('block_sparse') or {}).get('ao_cached_in_hbm'), (x.get('block_sparse') or {}).get('compact_ao_GB'))
 print('  xc', x.get('nr_rks_ms_per_call'), x.get('kernels_ms'), {k: v.get('frac') for k, v in (x.get('roofline') or {}).items() if isinstance(v, dict) and 'frac' in v})
 if (d.get('cpu_baseline') or {}).get('sample'):
     print('  cpu sample:', d['cpu_baseline']['sample'][-260:])

@@ -164,6 +164,32 @@ syrkfetch)  # r06: SYRK dispatch orders x FETCH_SIZE x ms. 
   cut -c1-560 $O/kbench.log
   python tools/pmc_table.py $O syrk_slots gemm_tn_glds2 vj_pass2 e2_sq2 > $O/summary.txt; cat $O/summary.txt
   find $O -name "*.db" -delete; find $O -name "*_kernel_trace.csv" -delete ;;
+sq1)        # r06: the square layout - tests, then kbench packed + image (3x) vs square rows only (2x) at config-3 and taxol shape
+  timeout 1500 python -m pytest -q -x --durations=6 -m gpu tests/test_gpu_square_layout.py tests/test_gpu_df_jk.py tests/test_gpu_device_scf.py tests/test_gpu_scf.py tests/test_gpu_grad.py > $O/pytest.log 2>&1; tail -12 $O/pytest.log
+  : > $O/kbench.log
+  for A in "--layout packed --j2-policy overlap --syrk-reserve 16" "--layout square --j2-policy overlap --syrk-reserve 16" "--layout packed --j2-policy overlap --syrk-reserve 16" "--layout square --j2-policy overlap --syrk-reserve 16" "--layout square --j2-policy serial" "--layout square --no-j"; do
+    echo "== config3 $A" >> $O/kbench.log
+    timeout 300 python tools/kbench.py --steps 5 $A 2>&1 | tail -1 >> $O/kbench.log
+  done
+  for A in "--layout square --j2-policy serial" "--layout square --j2-policy overlap --syrk-reserve 16" "--layout square --j2-policy overlap" "--layout packed --j2-policy serial"; do
+    echo "== taxol $A" >> $O/kbench.log
+    timeout 500 python tools/kbench.py --steps 4 --nao 2228 --naux 5598 --nocc 226 $A 2>&1 | tail -1 >> $O/kbench.log
+  done
+  cut -c1-420 $O/kbench.log ;;
+sq2)        # r06: square layout with / without the padded aux-row stride; fullsize tests; bench default + taxol
+  timeout 1800 python -m pytest -q -x --durations=6 -m gpu tests/test_gpu_square_layout.py tests/test_gpu_df_jk.py tests/test_gpu_native_abi.py tests/test_gpu_fullsize.py > $O/pytest.log 2>&1; tail -12 $O/pytest.log
+  : > $O/kbench.log
+  for A in "--layout packed --j2-policy overlap --syrk-reserve 16" "--layout square --j2-policy overlap --syrk-reserve 16" "--layout square --sq-contiguous --j2-policy overlap --syrk-reserve 16" "--layout packed --j2-policy overlap --syrk-reserve 16" "--layout square --j2-policy overlap --syrk-reserve 16" "--layout square --sq-contiguous --j2-policy overlap --syrk-reserve 16" "--layout square --j2-policy serial" "--layout square --sq-contiguous --j2-policy serial"; do
+    echo "== config3 $A" >> $O/kbench.log
+    timeout 300 python tools/kbench.py --steps 5 $A 2>&1 | tail -1 >> $O/kbench.log
+  done
+  for A in "--layout square --j2-policy overlap --syrk-reserve 16" "--layout square --sq-contiguous --j2-policy overlap --syrk-reserve 16" "--layout square --j2-policy serial"; do
+    echo "== taxol $A" >> $O/kbench.log
+    timeout 500 python tools/kbench.py --steps 4 --nao 2228 --naux 5598 --nocc 226 $A 2>&1 | tail -1 >> $O/kbench.log
+  done
+  cut -c1-420 $O/kbench.log
+  timeout 900 python bench.py --no-cpu-baseline --no-pmc > $O/bench_default.json 2> $O/bench_default.err; python tools/bench_digest.py $O/bench_default.json; tail -3 $O/bench_default.err
+  timeout 900 python bench.py --molecule taxol --no-cpu-baseline --no-pmc > $O/bench_taxol_1gpu.json 2> $O/bench_taxol.err; python tools/bench_digest.py $O/bench_taxol_1gpu.json; tail -3 $O/bench_taxol.err ;;
 kfetch)     # r06: kbench argument strings x FETCH_SIZE x ms: gpu_job.sh kfetch "<kbench args 1>" "<kbench args 2>" ...
   : > $O/kbench.log
   i=0

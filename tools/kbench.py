@@ -25,16 +25,32 @@ ap.add_argument('--no-fuse', action='store_true')
 ap.add_argument('--ksplit', type=int, default=0)
 ap.add_argument('--syrk-reserve', type=int, default=0, help='balanced re-tiled SYRK beside the co-running J pass, this many workgroup slots left free')
 ap.add_argument('--syrk-flags', type=int, default=-1, help='4: balanced k split, 8: re-tiled triangle (df_jk.syrk_plan)')
+ap.add_argument('--layout', default='packed', choices=['packed', 'square'], help="'square': the square rows as the only copy (r06), generated directly")
+ap.add_argument('--sq-contiguous', action='store_true', help='square layout WITHOUT the padded aux-row stride (A/B of DF.SQ_STRIDE_PAD)')
 ap.add_argument('--no-j', action='store_true', help='K only (as the K_LR / response calls do)')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 npair = a.nao * (a.nao + 1) // 2
 obj = df.DF(None)
 g = torch.Generator(device=dev); g.manual_seed(1)
-obj._cderi_dev = torch.empty((a.naux, npair), dtype=torch.float64, device=dev)
-for b0 in range(0, a.naux, 256):
-    obj._cderi_dev[b0:b0 + 256].normal_(generator=g)
-obj._cderi_dev.mul_(1.0 / np.sqrt(a.nao))
+if a.layout == 'square':
+    # symmetric random rows straight into the square layout (the packed tensor never exists: taxol shape = 225 GB of square rows)
+    rows = (a.nao + 15) // 16 * 16
+    sq = df.DF.alloc_square(a.naux, rows, dev) if not a.sq_contiguous else \
+        torch.zeros(a.naux * rows * rows + 256, dtype=torch.float64, device=dev)[:a.naux * rows * rows].view(a.naux, rows, rows)
+    for b0 in range(0, a.naux, 64):
+        blk = sq[b0:b0 + 64]
+        t = torch.empty((blk.shape[0], a.nao, a.nao), dtype=torch.float64, device=dev).normal_(generator=g)
+        t = torch.tril(t)
+        t = t + t.transpose(1, 2) - torch.diag_embed(torch.diagonal(t, dim1=1, dim2=2))
+        blk[:, :a.nao, :a.nao] = t * (1.0 / np.sqrt(a.nao))
+        del t
+    obj._cderi_sq, obj._sq_nao, obj._layout = sq, a.nao, 'square'
+else:
+    obj._cderi_dev = torch.empty((a.naux, npair), dtype=torch.float64, device=dev)
+    for b0 in range(0, a.naux, 256):
+        obj._cderi_dev[b0:b0 + 256].normal_(generator=g)
+    obj._cderi_dev.mul_(1.0 / np.sqrt(a.nao))
 obj._naux = a.naux
 obj.overlap_jk = not a.no_overlap
 obj.overlap_split = not a.no_split
@@ -83,7 +99,7 @@ out['fp_vk'] = float((vk[0] * _w).sum())
 if vj is not None:
     out['fp_vj'] = float((vj[0] * torch.cos(torch.arange(vj.shape[1], dtype=torch.float64, device=dev))).sum())
 # cheap correctness probe on a few entries (fp64 reference on device for 32 aux rows)
-sub = obj._cderi_dev[:32]
+sub = obj.packed_rows(0, 32).clone()
 idx = torch.tril_indices(a.nao, a.nao, device=dev)
 full = torch.zeros((32, a.nao, a.nao), dtype=torch.float64, device=dev)
 full[:, idx[0], idx[1]] = sub
