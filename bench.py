@@ -468,7 +468,7 @@ def main():
         square = getattr(dfobj, '_cderi_sq', None) is not None
         cands = {'e2_symm': ['e2_sq2_kernel', 'e2_sq_kernel'] if square else ['e2_pk_kernel', 'e2_symm_kernel', 'e2_symm'],
                  'dgemm_tn': ['syrk_slots_kernel', 'gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel'], 'vj_pass1': ['vj_pass1_rows_kernel'],
-                 'vj_pass2': ['vj_pass2_kernel']}[dom]
+                 'vj_pass2': ['vj_pass2_sq_kernel', 'vj_pass2_kernel']}[dom]
         pk = [k for k in cands if k in pm][0]
         # gfx950: FETCH_SIZE reports half the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM section).
         # Calibrated on kernels whose byte count is known (profiles/r01): vj_pass1 0.53x and vj_pass2 0.50x of their
@@ -484,7 +484,7 @@ def main():
         square = getattr(dfobj, '_cderi_sq', None) is not None
         names = {'e2_symm': ['e2_sq2_kernel', 'e2_sq_kernel'] if square else ['e2_pk_kernel', 'e2_symm_kernel'],
                  'dgemm_tn': ['syrk_slots_kernel', 'gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel'], 'vj_pass1': ['vj_pass1_rows_kernel'],
-                 'vj_pass2': ['vj_pass2_kernel', 'vj_pass2_wide_kernel']}[dom]
+                 'vj_pass2': ['vj_pass2_sq_kernel', 'vj_pass2_kernel', 'vj_pass2_wide_kernel']}[dom]
         hit = [k for k in names if k in pmc_live.get('FETCH_SIZE', {})]
         if hit:
             k0 = hit[0]
@@ -499,7 +499,8 @@ def main():
     if dom in ('e2_symm', 'dgemm_tn'):
         fl = flops_e2 if dom == 'e2_symm' else flops_syrk
         ach = fl / (dtot * 1e-3) / 1e12
-        kname = {'e2_symm': 'e2_sq (half transform on the unpacked image)' if getattr(dfobj, '_cderi_sq', None) is not None
+        kname = {'e2_symm': ('e2_sq2 (half transform on the square rows: the only copy of the tensor)' if square_layout else
+                             'e2_sq2 (half transform on the unpacked image)') if getattr(dfobj, '_cderi_sq', None) is not None
                  else 'e2_symm (half transform)', 'dgemm_tn': 'gemm_tn_glds (SYRK)'}[dom]
         roofline = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
@@ -661,7 +662,7 @@ def _pmc_passes(args, shard=None, device=None):
     import subprocess
     import tempfile
     short = ('e2_sq2_kernel', 'e2_sq_kernel', 'e2_pk_kernel', 'e2_symm_kernel', 'syrk_slots_kernel', 'gemm_tn_glds2_kernel',
-             'gemm_tn_glds_kernel', 'vj_pass1_rows_kernel', 'vj_pass2_wide_kernel', 'vj_pass2_kernel')
+             'gemm_tn_glds_kernel', 'vj_pass1_rows_kernel', 'vj_pass2_wide_kernel', 'vj_pass2_kernel', 'vj_pass2_sq_kernel', 'vj_pass1_sq_kernel')
     out = {}
     env = dict(os.environ, TMPDIR='/tmp')
     for k in list(env):

@@ -23,6 +23,7 @@
 using namespace pamd;
 
 static int g_orb_dot_dma = 1;
+static int g_orb_rho_128 = 1;    // r06: 128-orbital chunks in PAMD_sub_orb_rho when they need fewer MFMA tiles than 160-wide ones ("orbrho128")
 static int g_orb_rho_fused = 1;  // GGA: rho / grad rho in the orbital product's epilogue (PAMD_sub_orb_rho); A/B switch "orbrho"
 static int g_vmat_probe = 0;   // benchmarking probes of sub_vmat_sym ("vmatprobe", see the kernel)
 static int g_vmat_burst = 0;   // sub_vmat_sym: DMA rows of the next k-tile in one burst behind the first MFMA group ("vmatburst")
@@ -177,10 +178,15 @@ __global__ __launch_bounds__(256, 2) void sub_orb_dot2_kernel(const double *__re
 // are lane-local products; the sums over the orbitals run over (a, r) in the lane, over fk by two wave shuffles, over the two
 // wave rows through 2 KB of LDS.  Orbital chunks beyond the first (nocc_pad > 160) add up by FP64 atomics into the zeroed rho.
 // grid: x = 32-point slice of the tile, z = tile * nchunk + chunk.
+// r06: REM = false is the 128-orbital chunk (no remainder block: 4 instead of 5 MFMA tiles per wave row, no remainder DMA) for
+// orbital counts that several BALANCED chunks cover with less padding than 160-wide ones (nocc = 226 -> 15 tiles: 8 + 7 in two
+// 128-chunks = 16 tiles of work instead of 10 + 10 = 20: the taxol shape's ao . C product loses its 20 % of zero columns).
+template <bool REM>
 __global__ __launch_bounds__(256, 2) void sub_orb_rho_kernel(const double *__restrict__ ao_c, SubTiles tl, int G, int nchunk,
                                                              const double *__restrict__ orb, int ldo, int nocc,
                                                              const double *__restrict__ sign, double *__restrict__ rho, long ldg)
 {
+    constexpr int NA = REM ? 5 : 4, CW = REM ? 160 : 128;
     __shared__ double sa0[KB * LDN + KB * 32];
     __shared__ double sa1[KB * LDN + KB * 32];
     __shared__ double sq0[KB * LDN];
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void sub_orb_rho_kernel(const double *__res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = blockIdx.z / nchunk, chunk = blockIdx.z - t * nchunk;
     const int ld = tl.ld[t];
-    const int g0 = blockIdx.x * 32, m0 = chunk * 160;
+    const int g0 = blockIdx.x * 32, m0 = chunk * CW;
     const int *idx = tl.idx + tl.idx_off[t];
     const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc((void *)(ao_c + tl.ao_off[t] + (long)g0 * ld), 0, 0xffffffff,
                                                                         0x00020000);
@@ -219,9 +225,9 @@ __global__ __launch_bounds__(256, 2) void sub_orb_rho_kernel(const double *__res
         voff_tr[j] = (int)((((long)comp * G + pt) * ld + 2 * kp) * 8);
     }
 
-    double4_t acc[5][4];
+    double4_t acc[NA][4];
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < NA; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
 
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void sub_orb_rho_kernel(const double *__res
         const int row = idx[k0 + k];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_orb, (__attribute__((address_space(3))) void *)(da + k * LDN), 16, voff, row * ldo8, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_b, (__attribute__((address_space(3))) void *)(db + k * 128), 16, voff_tr[j], k0 * 8, 0, 0);
-        if (j == 0) {
+        if (REM && j == 0) {
             const int rowl = idx[k0 + wave * 4 + rrow];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_orb, (__attribute__((address_space(3))) void *)(da + RB + wave * 128), 16,
                                                      rowl * ldo8 + voff_remcol, 0, 0, 0);
@@ -242,15 +248,15 @@ __global__ __launch_bounds__(256, 2) void sub_orb_rho_kernel(const double *__res
         const int kn = (k0 + KB < ld) ? k0 + KB : k0;
 #pragma unroll
         for (int kk = 0; kk < KB; kk += 4) {
-            double af[5], bf[4];
+            double af[NA], bf[4];
 #pragma unroll
             for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
-            af[4] = ca[offr + kk * 32];
+            if (REM) af[NA - 1] = ca[offr + kk * 32];
 #pragma unroll
             for (int b = 0; b < 4; b++) bf[b] = cb[atr[kk >> 2] + b * 256];
             stage_row(kn, na, nb, kk >> 2);
 #pragma unroll
-            for (int a = 0; a < 5; a++)
+            for (int a = 0; a < NA; a++)
 #pragma unroll
                 for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
         }
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void sub_orb_rho_kernel(const double *__res
     // ---- rho, grad rho of the wave's 16 points over its 80 orbitals
     double p0 = 0, px = 0, py = 0, pz = 0;
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < NA; a++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int i = m0 + (a < 4 ? wr * 64 + a * 16 : 128 + wr * 16) + fk + 4 * r;
@@ -622,6 +628,7 @@ int PAMD_set_tuning_xc(const char *key, int value)
 {
     if (strcmp(key, "orbdotdma") == 0) { g_orb_dot_dma = value; return 0; }
     if (strcmp(key, "orbrho") == 0) { g_orb_rho_fused = value; return 0; }
+    if (strcmp(key, "orbrho128") == 0) { g_orb_rho_128 = value; return 0; }
     if (strcmp(key, "vmatxcd") == 0) { g_vmat_xcd = value; return 0; }
     if (strcmp(key, "vmatburst") == 0) { g_vmat_burst = value; return 0; }
     if (strcmp(key, "vmatprobe") == 0) { g_vmat_probe = value; return 0; }
@@ -688,14 +695,20 @@ int PAMD_sub_orb_rho(const double *d_ao_c, const long *d_ao_off, const long *d_i
     PAMD_REQUIRE(G % NT == 0, "tile size must be a multiple of 128");
     if (ntile == 0 || nocc_pad == 0) return 0;
     const int mt_total = nocc_pad / 16;
-    const int nchunk = ceil_div(mt_total, 10);
+    int nchunk = ceil_div(mt_total, 10);
     const int mt = ceil_div(mt_total, nchunk);
-    if (!(g_orb_rho_fused && g_orb_dot_dma && mt >= 8 && ldo >= nchunk * 160 && ldo % 2 == 0 && (uintptr_t)d_orb % 16 == 0 &&
+    // r06: 128-orbital chunks when they cover the orbitals with fewer MFMA tiles than 160-wide ones (nocc_pad = 240: 2 x 8 = 16
+    // tiles instead of 2 x 10 = 20); tuning key "orbrho128" = 0 keeps the 160-wide chunks
+    const int n128 = ceil_div(mt_total, 8);
+    const bool narrow = g_orb_rho_128 && n128 * 8 < nchunk * 10 && ldo >= n128 * 128 + 32;
+    if (narrow) nchunk = n128;
+    if (!(g_orb_rho_fused && g_orb_dot_dma && mt >= 8 && ldo >= nchunk * (narrow ? 128 : 160) && ldo % 2 == 0 && (uintptr_t)d_orb % 16 == 0 &&
           (uintptr_t)d_ao_c % 16 == 0 && (long)ntile * nchunk < 65536))
         return 1;
     SubTiles tl{d_ao_off, nullptr, d_idx_off, d_ld, d_idx};
     dim3 grid(G / 32, 1, ntile * nchunk);
-    sub_orb_rho_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_ao_c, tl, G, nchunk, d_orb, ldo, nocc, d_sign, d_rho, ldg);
+    if (narrow) sub_orb_rho_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(d_ao_c, tl, G, nchunk, d_orb, ldo, nocc, d_sign, d_rho, ldg);
+    else sub_orb_rho_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(d_ao_c, tl, G, nchunk, d_orb, ldo, nocc, d_sign, d_rho, ldg);
     PAMD_CHECK_LAUNCH();
     return 0;
 }

@@ -700,6 +700,11 @@ class DF:
         import ctypes as _c
         from .. import lib as _lib
         so = _lib.load_library()
+        if torch.device(dev).type == 'cuda':
+            from ..lib import hbm
+            if m * n * 8 + (1 << 30) > hbm.free_bytes(dev):
+                raise MemoryError('the (%d, %d) pair matrix (%.1f GB) does not fit the device: this is the O(nao^4) object density '
+                                  'fitting exists to avoid - iterate DF.loop() blocks instead' % (m, n, m * n * 8e-9))
         out = torch.zeros((1, m, n), dtype=torch.float64, device=dev)
         st = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
         for a, b in a_blocks:

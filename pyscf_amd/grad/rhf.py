@@ -171,9 +171,13 @@ def z_slab(W, linv_loc, r0, r1, out=None, dfobj=None, work=None):
     torch.matmul = rocBLAS.  Its A operand must be addressable inside one 4 GiB window per k-range, which W[L][pq] (13.8 MB per
     aux row at config 3) is not: the slab's columns are first copied into a contiguous [k][ncol] work buffer - the slab is <= 4 GB,
     the copy moves 2 x 4 GB against 2 naux^2 ncol flops.  `work` = (wbuf, mbuf): the work buffer and M padded to a multiple of 16
-    rows (zero rows), made once per gradient; without it (or DF.grad_z_gemm = 'torch') the library GEMM runs."""
+    rows (zero rows), made once per gradient.
+    MEASURED (profiles/r06/grad_h2o32_rhf_{hip,torch}.json, config-3 size, one box): the library GEMM runs the 6.8e13 flops in
+    935.6 ms = 72.9 TF/s = 0.927 of the FP64 matrix peak, the hand-written path in 1024.4 ms = 66.6 TF/s = 0.847 (its 160 x 128
+    tile kernel is the r01 DMA scheme, and it pays the slab copy).  A plain GEMM at 0.93 is what the task leaves to the library:
+    DF.grad_z_gemm = 'torch' is the default, 'hip' keeps the hand-written path selectable."""
     import torch
-    if work is None or getattr(dfobj, 'grad_z_gemm', 'hip') != 'hip':
+    if work is None or getattr(dfobj, 'grad_z_gemm', 'torch') != 'hip':
         return _timed(dfobj, 'z_slab_gemm', lambda: torch.matmul(W[:, r0:r1].T, linv_loc, out=out))
     wbuf, mbuf = work
     k, ncol = W.shape[0], r1 - r0
@@ -252,7 +256,7 @@ def _grad_2e(mol, dfobj, dm_tot, occ_blocks, jscale, kscale, auxbasis_response, 
     # LDS-DMA kernels' whole-panel reads, and M with its rows padded to a multiple of 16; needs even nq and a 16-byte aligned M
     zwork = None
     k16 = (nrow_local + 15) // 16 * 16
-    if getattr(dfobj, 'grad_z_gemm', 'hip') == 'hip' and nq % 2 == 0 and nrow_local > 0:
+    if getattr(dfobj, 'grad_z_gemm', 'torch') == 'hip' and nq % 2 == 0 and nrow_local > 0:
         free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         need = (k16 * (bufrows + 2) + k16 * nq + 512) * 8
         if need + (2 << 30) <= free:

@@ -21,7 +21,8 @@ def _setup():
     return torch, so, dev, st, lib
 
 
-@pytest.mark.parametrize('G,ncomp,nocc', [(128, 1, 5), (256, 4, 37), (128, 4, 170), (256, 4, 160), (128, 1, 139), (384, 4, 300)])
+@pytest.mark.parametrize('G,ncomp,nocc', [(128, 1, 5), (256, 4, 37), (128, 4, 170), (256, 4, 160), (128, 1, 139), (384, 4, 300),
+                                           (256, 4, 226), (128, 4, 340)])      # r06: 2 x 128 / 3 x 128 orbital chunks in PAMD_sub_orb_rho (taxol's nocc)
 def test_sub_kernels_vs_numpy(G, ncomp, nocc):
     """PAMD_sub_gather_ao / _orb_dot / _scale_ao / _vmat on ragged tiles (ld = 16 ... 272, partial 128-blocks, padding
     columns, an empty tile) against dense numpy."""

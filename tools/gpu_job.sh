@@ -190,6 +190,20 @@ sq2)        # r06: square layout with / without the padded aux-row stride; fulls
   cut -c1-420 $O/kbench.log
   timeout 900 python bench.py --no-cpu-baseline --no-pmc > $O/bench_default.json 2> $O/bench_default.err; python tools/bench_digest.py $O/bench_default.json; tail -3 $O/bench_default.err
   timeout 900 python bench.py --molecule taxol --no-cpu-baseline --no-pmc > $O/bench_taxol_1gpu.json 2> $O/bench_taxol.err; python tools/bench_digest.py $O/bench_taxol_1gpu.json; tail -3 $O/bench_taxol.err ;;
+r06b)       # r06: rest of the suite after the layout change, gradient Z-slab GEMM A/B, layout A/B of the bench line on ONE box
+  timeout 2400 python -m pytest -q -x --durations=8 -m gpu tests/test_gpu_fullsize_cfg45.py tests/test_gpu_fullsize_scf.py tests/test_gpu_grad.py tests/test_gpu_int3c2e.py tests/test_gpu_xc_sparse.py tests/test_gpu_native_r04.py > $O/pytest.log 2>&1; tail -14 $O/pytest.log
+  for z in hip torch; do
+    PAMD_GRAD_ZGEMM=$z timeout 600 python tools/grad_bench.py --nwater 32 > $O/grad_h2o32_rhf_$z.json 2> $O/grad_$z.err; cut -c1-900 $O/grad_h2o32_rhf_$z.json; tail -2 $O/grad_$z.err
+  done
+  for lay in packed auto packed auto; do
+    timeout 600 python bench.py --layout $lay --no-cpu-baseline --no-pmc --xc '' --steps 10 > $O/bench_layout_$lay.json 2> $O/bench_$lay.err
+    python - <<PY
+import json
+d=json.loads(open('$O/bench_layout_$lay.json').read().strip().splitlines()[-1])
+print('layout $lay ->', d['config']['tensor_layout'], 'ms', d['value'], 'host', d['value_host_api_ms'], d['host_api_ms_calls'], {k: v['ms_total'] for k, v in d['kernels'].items()}, d['config']['hbm_after_build_GB'], d['jk_schedule'])
+PY
+  done
+  timeout 900 python bench.py --molecule taxol --no-cpu-baseline --no-pmc > $O/bench_taxol_1gpu.json 2> $O/bench_taxol.err; python tools/bench_digest.py $O/bench_taxol_1gpu.json; tail -3 $O/bench_taxol.err ;;
 kfetch)     # r06: kbench argument strings x FETCH_SIZE x ms: gpu_job.sh kfetch "<kbench args 1>" "<kbench args 2>" ...
   : > $O/kbench.log
   i=0

@@ -20,7 +20,7 @@ t0 = time.perf_counter()
 mf = (dft.RKS(mol, xc=a.xc) if a.xc else scf.RHF(mol)).density_fit().run(conv_tol=1e-11)
 t_scf = time.perf_counter() - t0
 from pyscf_amd.df import df_jk
-ap_z = os.environ.get('PAMD_GRAD_ZGEMM', 'hip')          # 'torch': the library GEMM (rocBLAS) for the Z slabs, as in r04 / r05
+ap_z = os.environ.get('PAMD_GRAD_ZGEMM', 'torch')          # 'torch': the library GEMM (rocBLAS) for the Z slabs, as in r04 / r05
 mf.with_df.grad_z_gemm = ap_z
 mf.with_df.kernel_timer = df_jk.KernelTimer()
 torch.cuda.synchronize()

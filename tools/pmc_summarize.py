@@ -22,7 +22,7 @@ for sub, name, dst in copies:
         shutil.copy(f, os.path.join(out, dst))
 SHORT = ['syrk_slots_kernel', 'e2_sq2_kernel', 'e2_sq_kernel', 'e2_symm', 'gemm_tn_glds2_kernel', 'gemm_tn_glds_kernel', 'gemm_tn_kernel',
          'vj_pass1_rows_kernel', 'vj_pass2_kernel', 'cderi_solve_kernel', 'eval_ao_kernel', 'int3c2e_kernel', 'scale_ao_kernel',
-         'sub_orb_rho_kernel', 'sub_orb_dot2_kernel', 'sub_orb_dot_kernel', 'sub_vmat_sym_kernel', 'sub_vmat_kernel', 'sub_scale_kernel', 'sub_gather_kernel', 'vj_pass2_wide_kernel']
+         'sub_orb_rho_kernel', 'sub_orb_dot2_kernel', 'sub_orb_dot_kernel', 'sub_vmat_sym_kernel', 'sub_vmat_kernel', 'sub_scale_kernel', 'sub_gather_kernel', 'vj_pass2_wide_kernel', 'vj_pass2_sq_kernel', 'vj_pass1_sq_kernel', 'unpack_slab_kernel']
 
 
 def short(n):
