@@ -187,6 +187,12 @@ def main():
         pmc_live = _pmc_passes(args)         # before this process holds any HBM: the child runs need the whole device
         if not pmc_live.get('FETCH_SIZE'):
             pmc_live = None                  # profiler missing / failed: the committed summary is used (and named) instead
+        # the driver hands a finished child's HBM back with a delay: wait for it (the tensor's layout decision reads the free memory)
+        for _ in range(100):
+            f_, t_ = torch.cuda.mem_get_info(dev)
+            if f_ > 0.97 * t_:
+                break
+            time.sleep(0.2)
     elif args.pmc == 'on' and world > 1 and rank == 0 and not args.pmc_child:
         # r06: at N > 1 rank 0 measures the traffic of ITS shard's launch on ITS device - a child run outside
         # the process group that builds and contracts rank 0's rows only (--pmc-shard 0,N) - while the other ranks build and wait at

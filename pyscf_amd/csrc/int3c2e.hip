@@ -109,6 +109,107 @@ __global__ __launch_bounds__(256, 2) void cderi_solve_kernel(
         }
 }
 
+// r06: the same product with BOTH operands by buffer-resource LDS-DMA, double-buffered, one barrier per
+// 16-deep k-tile, the DMA issue spread over the four MFMA groups - the loop of gemm_tn_glds2 / sub_orb_dot2 instead of the r01
+// register-staged one above (58 TF/s = 0.74, matrix pipe busy 0.77, two barriers per k-tile, bounds checks in the inner loads).
+//   A = At[k][m] (k-major rows: one 1 KiB row DMA per k row of the 128-column tile);
+//   B = Bt[n][k] (k contiguous for a fixed n - the "transposed" operand of e2_pk / sub_orb_dot2: one DMA moves eight pq rows x
+//       16 k with per-lane source addresses into XOR-swizzled 16-byte chunks, fragment reads conflict-free).
+// Out-of-range rows / columns need no branches: both buffer resources carry their true byte counts, loads beyond them return 0
+// (k beyond kdim or beyond the diagonal block of a triangular factor multiplies zeros of L^-1 anyway).
+__global__ __launch_bounds__(256, 2) void cderi_solve2_kernel(
+    const double *__restrict__ At, int lda, const double *__restrict__ Bt, long ldb,
+    double *__restrict__ C, long ldc, int m, long n, int kdim, int m_off, int triangular)
+{
+    __shared__ double sa0[KB * LDN];
+    __shared__ double sa1[KB * LDN];
+    __shared__ double sq0[KB * LDN];
+    __shared__ double sq1[KB * LDN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * NT;
+    const long n0 = (long)blockIdx.x * NT;
+    int kend = kdim;
+    if (triangular) {
+        const int lim = m_off + m0 + NT;
+        if (lim < kend) kend = lim;
+    }
+    // (A may be handed over with a column offset into a larger [kdim][lda] buffer: only the m columns of the last row are surely there)
+    const long a_bytes = ((long)(kdim - 1) * lda + ((m + 1) & ~1) - m0) * 8, b_bytes = (n - n0) * ldb * 8;
+    const __amdgpu_buffer_rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc((void *)(At + m0), 0,
+                                                                        (int)(a_bytes < 0 ? 0 : (a_bytes < 0x7fffffffL ? a_bytes : 0x7fffffffL)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc((void *)(Bt + n0 * ldb), 0,
+                                                                        (int)(b_bytes < 0x7fffffffL ? b_bytes : 0x7fffffffL), 0x00020000);
+    const int lda8 = lda * 8;
+    const int voff = lane * 16;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fk = lane >> 4, fn = lane & 15;
+    const int offa = fk * LDN + wr * 64 + fn;
+    const int pl = fn & 7, bodd = (fn >> 3) & 1;
+    const int offb_tr = (wc * 8 + (fn >> 3)) * 128 + (((pl ^ bodd) * 8) + ((fk >> 1) ^ (pl & 1))) * 2 + (fk & 1);
+    int atr[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) atr[g] = offb_tr + (((2 * g) ^ (pl & 6))) * 2;
+    int voff_tr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int blk = wave * 4 + j;
+        const int pl_s = (lane >> 3) ^ (blk & 1);
+        const int kp = (lane & 7) ^ pl_s;
+        voff_tr[j] = (int)((((long)(blk * 8 + pl_s)) * ldb + 2 * kp) * 8);
+    }
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    auto stage_row = [&](int k0, double *da, double *db, int j) {
+        const int k = wave * 4 + j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(da + k * LDN), 16, voff, (k0 + k) * lda8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_b, (__attribute__((address_space(3))) void *)(db + k * 128), 16, voff_tr[j], k0 * 8, 0, 0);
+    };
+    auto step = [&](const double *ca, const double *cb, double *na, double *nb, int k0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kn = (k0 + KB < kend) ? k0 + KB : k0;
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = ca[offa + kk * LDN + a * 16];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = cb[atr[kk >> 2] + b * 256];
+            stage_row(kn, na, nb, kk >> 2);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+        }
+    };
+    if (kend > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) stage_row(0, sa0, sq0, j);
+    }
+    for (int k0 = 0; k0 < kend; k0 += 2 * KB) {
+        step(sa0, sq0, sa1, sq1, k0);
+        if (k0 + KB < kend) step(sa1, sq1, sa0, sq0, k0 + KB);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const long col = n0 + wc * 64 + b * 16 + fn;
+            if (col >= n) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = m0 + wr * 64 + a * 16 + fk + 4 * r;
+                if (row < m) C[(long)row * ldc + col] = acc[a][b][r];
+            }
+        }
+}
+
 // ---- integral-direct J (pyscf/df/df_jk.py:415-506 get_j): contract a freshly generated slab
 // T[row][Q] = (pq|Q) in place, without ever forming cderi.
 constexpr int DJ_ROWS = 512;
@@ -231,6 +332,15 @@ int PAMD_cderi_solve(const double *d_linvT, int lda, const double *d_T, long ldT
 {
     if (nL == 0 || npq == 0) return 0;
     dim3 grid(ceil_div(npq, NT), ceil_div(nL, NT));
+    // r06: all-DMA kernel when the operands allow 16-byte loads (even leading dimensions, aligned bases) and the 32-bit DMA offsets
+    // cover a k range of A / 128 rows of T; PAMD_SOLVE_V2=0 in the environment keeps the r01 kernel (A/B runs)
+    static const int solve_v2 = [] { const char *e = getenv("PAMD_SOLVE_V2"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (solve_v2 && lda % 2 == 0 && ldT % 2 == 0 && ((uintptr_t)d_linvT % 16 == 0) && ((uintptr_t)d_T % 16 == 0) &&
+        (long)naux * lda * 8 < (1L << 31) && 128L * ldT * 8 < (1L << 31)) {
+        cderi_solve2_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_linvT, lda, d_T, ldT, d_cderi, ldc, nL, npq, naux, l_off, triangular);
+        PAMD_CHECK_LAUNCH();
+        return 0;
+    }
     cderi_solve_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_linvT, lda, d_T, ldT, d_cderi, ldc, nL, npq,
                                                                naux, l_off, triangular);
     PAMD_CHECK_LAUNCH();

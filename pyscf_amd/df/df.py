@@ -476,6 +476,7 @@ class DF:
                 self._cderi_sq, self._sq_nao, self._layout, self._packed = t, _mol_nao(self.mol), 'square', None
             else:
                 self._packed, self._layout = t, 'packed'
+            torch.cuda.empty_cache()          # the build's slab work space (<= 2 x 24 GB) back to the device: the budget's next clients see it
         except MemoryError:
             # The out-of-core twin (pyscf/df/outcore.py:109-232, pyscf/df/df.py:167): the tensor (r05: or this RANK's shard of it)
             # does not fit this device.  The object hands its rows to the C handle, which keeps what fits in HBM, the rest in
@@ -558,7 +559,8 @@ class DF:
         rows = (nao + 15) // 16 * 16
         naux = self.auxmol.nao_nr()
         npair = nao * (nao + 1) // 2
-        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        from ..lib import hbm
+        free = hbm.free_bytes(dev)
         slab = min(12 << 30, npair * naux * 8)
         build_need = nL * rows * rows * 8 + slab + min(slab, slab * max(nL, 1) // max(naux, 1) + (1 << 20)) + (2 << 30)
         after_need = nL * rows * rows * 8 + self._reserve_after_build(nL, rows)

@@ -127,27 +127,38 @@ def test_square_layout_built_from_the_integrals_vs_oracle():
         assert abs(e['square'] - e0) < 1e-8
 
 
-def test_layout_budget_keeps_room_for_the_xc_image():
-    """The single HBM budget: with an XC hint larger than what 2x the tensor leaves, 'auto' falls back to the packed rows, and the
-    optional image of the packed layout shrinks by the hint; what the XC plan already holds (lib.hbm) is not asked for twice."""
+def test_layout_budget_keeps_room_for_the_xc_image(monkeypatch):
+    """The single HBM budget: with an XC hint larger than what 2x the tensor leaves, 'auto' falls back to the packed rows; what the XC
+    plan already holds (lib.hbm) is not asked for twice.  The free-memory figure is pinned (100 GB) so that the decision does not
+    depend on what earlier tests of the same process left on the device."""
     import torch
     from pyscf_amd import gto, df
     from pyscf_amd.lib import hbm
     from pyscf_amd.data import clusters
     mol = gto.M(atom=clusters.water_cluster(3), basis='cc-pvtz')
     dev = torch.device('cuda', torch.cuda.current_device())
-    free = hbm.free_bytes(dev)
-    a = df.DF(mol)
-    a.xc_image_hint = free                      # an XC leg that wants the whole device
-    a.build()
-    assert a._layout == 'packed'
-    hbm.hold(dev, 'xc_image', free)             # ... which the plan already holds: nothing left to reserve
+    pinned = 100 << 30
+    monkeypatch.setattr(hbm, 'free_bytes', lambda d: pinned)
+    kept = hbm.held(dev, 'xc_image')
+    hbm.drop(dev, 'xc_image')
     try:
+        a = df.DF(mol)
+        a.xc_image_hint = pinned                    # an XC leg that wants everything that is free
+        a.build()
+        assert a._layout == 'packed'
+        hbm.hold(dev, 'xc_image', pinned)           # ... which the plan already holds: nothing left to reserve
         b = df.DF(mol)
-        b.xc_image_hint = free
+        b.xc_image_hint = pinned
         b.build()
         assert b._layout == 'square'
+        hbm.drop(dev, 'xc_image')
+        c = df.DF(mol).build()
+        assert c._layout == 'square'
+        d = df.DF(mol)
+        d.xc_image_hint = 60 << 30                  # tensor (tiny) + X block + 4 GB + 60 GB + 12 GB of XC work space <= 100 GB
+        d.build()
+        assert d._layout == 'square'
     finally:
         hbm.drop(dev, 'xc_image')
-    c = df.DF(mol).build()
-    assert c._layout == 'square'
+        if kept:
+            hbm.hold(dev, 'xc_image', kept)

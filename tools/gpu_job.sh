@@ -204,6 +204,15 @@ print('layout $lay ->', d['config']['tensor_layout'], 'ms', d['value'], 'host', 
 PY
   done
   timeout 900 python bench.py --molecule taxol --no-cpu-baseline --no-pmc > $O/bench_taxol_1gpu.json 2> $O/bench_taxol.err; python tools/bench_digest.py $O/bench_taxol_1gpu.json; tail -3 $O/bench_taxol.err ;;
+r06c)       # r06: the tests the -x stop of the suite did not reach + the all-DMA cderi_solve (tensor tests, build A/B, counters)
+  timeout 2400 python -m pytest -q -x --durations=6 -m gpu tests/test_gpu_square_layout.py tests/test_gpu_tdscf.py tests/test_gpu_vhf.py tests/test_gpu_xc_sparse.py tests/test_gpu_int3c2e.py tests/test_gpu_fullsize.py tests/test_gpu_scf.py tests/test_gpu_native_abi.py > $O/pytest.log 2>&1; tail -8 $O/pytest.log
+  for v in 0 1 0 1; do PAMD_SOLVE_V2=$v timeout 300 python tools/build_only.py --time --layout packed 2>/dev/null | tail -1; done | tee $O/build_ab.jsonl
+  PAMD_SOLVE_V2=1 timeout 300 python tools/build_only.py --time --layout square 2>/dev/null | tail -1 | tee -a $O/build_ab.jsonl
+  ( cd /tmp; for v in 0 1; do PAMD_SOLVE_V2=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/solve_stats_v$v -o b -- python $R/tools/build_only.py > $R/$O/solve_stats_v$v.log 2>&1; done
+    PAMD_SOLVE_V2=1 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/solve_mfma -o b -- python $R/tools/build_only.py > $R/$O/solve_mfma.log 2>&1 )
+  for v in 0 1; do f=$(find $O/solve_stats_v$v -name "*kernel_stats.csv" | head -1); echo "== PAMD_SOLVE_V2=$v"; grep -E "cderi_solve|unpack_slab|int3c2e_kernel<3, 3, 4>" $f | cut -c1-220 | head -5; done
+  python tools/pmc_table.py $O cderi_solve | tee $O/solve_pmc.txt
+  find $O -name "*.db" -delete; find $O -name "*_kernel_trace.csv" -delete ;;
 kfetch)     # r06: kbench argument strings x FETCH_SIZE x ms: gpu_job.sh kfetch "<kbench args 1>" "<kbench args 2>" ...
   : > $O/kbench.log
   i=0
