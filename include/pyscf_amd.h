@@ -355,6 +355,11 @@ int PAMD_mirror_tril(const double *d_part, int m, int ldc, double *d_out, void *
  *   PAMD_df_get_jk        replaces df_jk.get_jk (pyscf/df/df_jk.py:280-413): dm[nset][nao][nao]; orbo = NULL -> general-DM
  *                         branch (:382-408); else the sqrt(occ)-scaled occupied orbitals of every density, (nao, nocc[s]) C order
  *                         one after the other -> MO branch (:339-381).  flags bit 0: dm[s] == orbo_s orbo_s^T is guaranteed
+ *                         (the first J pass then comes out of the half transform's epilogue); flags bit 1 (r06): NOT guaranteed -
+ *                         verify it inside the call: one D v = C (C^T v) probe per density on the calling thread while the queued
+ *                         kernels run (hidden), and when it fails J is recomputed from the matrix before the call returns - what
+ *                         the reference always does (df_jk.py:367), K keeps following the tag (df_jk.py:340);
+ *                         PAMD_df_last_mismatch(h) = the probe's result
  *   PAMD_df_export_cderi  rows [l0, l1) of `_cderi` (naux, nao_pair) into out (DF.loop, pyscf/df/df.py:214-242)
  *   PAMD_df_naux          rows of the tensor (get_naoaux, :248-257: fewer than the aux functions after an eigen-decomposition) */
 typedef struct PAMD_df PAMD_df;
@@ -406,6 +411,7 @@ int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, 
  * memory (must outlive the handle) instead of a page-locked copy. */
 int PAMD_df_create_from_rows(const double *rows, int nrows, int nao, int device, long long max_device_bytes, int flags, PAMD_df **out);
 int PAMD_df_layout(const PAMD_df *h, long *layout, int *part_rows);
+double PAMD_df_last_mismatch(const PAMD_df *h);
 int PAMD_df_tensor_layout(const PAMD_df *h);     /* 1: every part holds its rows in the square layout only (r06); 0: packed rows */
 int PAMD_df_shard_info(const PAMD_df *h, int *info);
 int PAMD_df_last_timing(const PAMD_df *h, double *out, int nout);

@@ -275,6 +275,7 @@ struct PAMD_df {
     // HIP events around the half-transform and SYRK launches of the last build, on the stream they are launched on
     std::vector<hipEvent_t> tev;
     double t_e2_ms = 0, t_syrk_ms = 0;
+    double last_mismatch = 0;               // r06: result of the in-call tag probe (PAMD_df_get_jk flags bit 1)
     hipEvent_t timing_event(size_t i)
     {
         while (tev.size() <= i) {
@@ -1030,6 +1031,45 @@ struct OrbSet {                            // one density's occupied orbitals on
 // SYRK into the split-K partials) while it is on the device - one sweep over the host rows per build.
 static const int SYRK_RESERVE = 16;          // DF.k_syrk_reserve of the torch path
 
+// r06 - the tag probe INSIDE the call (PAMD_df_get_jk flags bit 1).  "Is dm[s] == orbo_s orbo_s^T?" decides whether the first J pass
+// may come out of the half transform's epilogue; the binding used to answer it on the host BEFORE the blocking call (one D v product
+// per density: with the probe now on the FULL matrix - ADVICE r05 - 5-7 ms of a 256-thread host's BLAS start-up per call at config
+// 3).  Here it runs on the calling thread AFTER the kernels have been queued and before the final synchronisation: the GPU works
+// ~100 ms, the probe ~3 ms - hidden.  max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) for one fixed pseudo-random vector.
+static double host_dm_mismatch(const double *dm, const double *orbo, const int *nocc, int nset, int nao)
+{
+    std::vector<double> v(nao), t, u(nao);
+    unsigned long long x = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < nao; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;                         // xorshift64: any fixed vector will do
+        v[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+    double worst = 0;
+    const double *c = orbo;
+    for (int s = 0; s < nset; s++) {
+        const int no = nocc[s];
+        t.assign(std::max(no, 1), 0.0);
+        for (int p = 0; p < nao; p++) {
+            const double *row = c + (size_t)p * no;
+            for (int i = 0; i < no; i++) t[i] += row[i] * v[p];
+        }
+        double dmax = 1.0, emax = 0.0;
+        const double *d = dm + (size_t)s * nao * nao;
+        for (int p = 0; p < nao; p++) {
+            const double *drow = d + (size_t)p * nao, *row = c + (size_t)p * no;
+            double a = 0, b = 0;
+            for (int q = 0; q < nao; q++) a += drow[q] * v[q];
+            for (int i = 0; i < no; i++) b += row[i] * t[i];
+            u[p] = a - b;
+            dmax = std::max(dmax, std::fabs(a));
+            emax = std::max(emax, std::fabs(u[p]));
+        }
+        worst = std::max(worst, emax / dmax);
+        c += (size_t)nao * no;
+    }
+    return worst;
+}
+
 static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
                           int with_k, int flags, double *vj, double *vk, int serial_j2, int download)
 {
@@ -1058,7 +1098,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                        : PAMD_df_vj_pass2_sq(rows_sq, lstride, h->rows, nao, nb, rho, ns, vjt, s_);
     };
     double *d_vjt = nullptr, *d_vk = nullptr, *d_rho = nullptr, *d_dt = nullptr, *d_w1 = nullptr, *d_part = nullptr;
-    const bool fused = with_j && with_k && orbo && (flags & 1) && nL > 0;
+    const bool fused = with_j && with_k && orbo && (flags & 3) && nL > 0;       // bit 0: promised; bit 1: verified below, beside the kernels
     // the matrix itself is needed on the device for J from the matrix and for the general-DM K branch only: with J taken from the
     // orbitals (fused) the 8 nao^2-byte upload of a pageable caller array per set (per part of a device list) is skipped
     const bool need_dm = (with_j && !fused) || (with_k && !orbo);
@@ -1351,6 +1391,9 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
         PAMD_CHECK_HIP(hipEventRecord(h->ev, h->side));
         PAMD_CHECK_HIP(hipStreamWaitEvent(st, h->ev, 0));
     }
+    // r06: everything is queued - the tag probe runs now, on this thread, beside the kernels (flags bit 1 without bit 0)
+    h->last_mismatch = 0;
+    if (fused && (flags & 2) && !(flags & 1)) h->last_mismatch = host_dm_mismatch(dm, orbo, nocc, nset, nao);
     PAMD_CHECK_HIP(hipStreamSynchronize(st));
     PAMD_CHECK_HIP(hipStreamSynchronize(h->side));
     PAMD_CHECK_HIP(hipStreamSynchronize(h->copy));
@@ -1371,7 +1414,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
 static int shard_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *nocc, int nset, int nao, int hermi, int with_j,
                         int with_k, int flags, double *vj, double *vk, int download)
 {
-    const bool fused = with_j && with_k && orbo && (flags & 1) && h->nL > 0;
+    const bool fused = with_j && with_k && orbo && (flags & 3) && h->nL > 0;
     int serial = 0;
     if (fused && h->n_res == h->nL) {
         const char *env = getenv("PAMD_DF_J2");
@@ -1914,11 +1957,18 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
         // push / sum / unpack round trip and a thread start per call: 122.7 against 110.5 ms at config 3)
         PAMD_df *p = h->parts.empty() ? h : h->parts[0];
         const auto t0 = clk::now();
-        const int r = shard_get_jk(p, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, 1);
+        int r = shard_get_jk(p, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, 1);
+        const double mis = p->last_mismatch;
+        if (!r && with_j && with_k && orbo && (flags & 2) && !(flags & 1) && mis > 1e-10)
+            // the tag did not describe the matrix: J from the matrix itself (the K of the MO branch follows the tag, as in the
+            // reference, df_jk.py:340) - the rare path pays a second, J-only call
+            r = shard_get_jk(p, dm, nullptr, nullptr, nset, nao, hermi, 1, 0, 0, vj, nullptr, 1);
+        p->last_mismatch = mis;
         p->t_compute_ms = ms_since(t0);
         p->t_push_ms = 0;
         p->push_bytes = 0;
         h->t_sum_ms = 0;
+        h->last_mismatch = p->last_mismatch;
         return r;
     }
     PAMD_REQUIRE(dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
@@ -1929,7 +1979,9 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
     if (rc) return rc;
     rc = run_parts(h, [&](int ip, PAMD_df *p) -> int {
         const auto t0 = clk::now();
-        const int r = shard_get_jk(p, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, nullptr, nullptr, 0);
+        // (the tag probe of flags bit 1 runs once, on part 0's thread; the other parts take the tag as promised)
+        const int fl = (ip == 0 || !(flags & 2)) ? flags : ((flags & ~2) | 1);
+        const int r = shard_get_jk(p, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, fl, nullptr, nullptr, 0);
         p->t_compute_ms = ms_since(t0);
         if (r) return r;
         const auto t1 = clk::now();
@@ -1942,8 +1994,15 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
     const auto t2 = clk::now();
     rc = multi_sum_download(h, mm, vj, vk);
     h->t_sum_ms = ms_since(t2);
+    const double mis = h->parts[0]->last_mismatch;
+    if (!rc && with_j && with_k && orbo && (flags & 2) && !(flags & 1) && mis > 1e-10)
+        rc = PAMD_df_get_jk(h, dm, nullptr, nullptr, nset, nao, hermi, 1, 0, 0, vj, nullptr);     // J from the matrix (see the one-part path)
+    h->last_mismatch = mis;
     return rc;
 }
+
+// max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) found by the tag probe of the last PAMD_df_get_jk (flags bit 1); 0 when none ran
+double PAMD_df_last_mismatch(const PAMD_df *h) { return h ? h->last_mismatch : 0.0; }
 
 // Timings of the LAST PAMD_df_get_jk on this handle (bench.py --single-process `roofline` / `comm`): out[0] = parts, out[1] = host ms
 // of the fixed-order sum + unpack + download on part 0, out[2] = 1 when the partial results travelled by direct peer copies (xGMI),

@@ -1577,6 +1577,139 @@ __global__ __launch_bounds__(256, 2) void syrk_slots_kernel(
         }
 }
 
+// r06 experiment ("syrkring" = 1): the re-tiled SYRK with a FOUR-stage LDS ring of 8-deep k-tiles instead of two stages of 16.
+// Same LDS (4 x 2 x 8 x 144 doubles = 73.7 KB: still two workgroups per CU), same work items, same epilogue; what changes is how
+// far ahead the operands are requested: the DMA rows of tile t + 3 are issued during tile t and the top of tile t waits with
+// s_waitcnt vmcnt(8) for tile t only (tiles t + 1, t + 2 stay in flight) - at least two whole tile times of lead (>= 8 k cycles
+// of wall time with two workgroups sharing the matrix pipe) where the 2-stage loop gives the last rows of a tile a quarter of
+// one.  r05 read the ~6 ms the co-running second J pass costs the SYRK as DMA LATENCY (tiles arriving late at the k-tile barrier
+// while 1.5 TB/s of foreign traffic is in flight) and stopped at "a deeper ring does not fit": it does, at the price of a barrier
+// every 32 instead of 64 MFMAs per wave.
+__global__ __launch_bounds__(256, 2) void syrk_ring4_kernel(
+    const double *__restrict__ A, int lda, double *__restrict__ C, int ldc, int m, long kdim, const int *__restrict__ items,
+    long kchunk, const int *__restrict__ order, int nsplit_o)
+{
+    constexpr int K8 = 8, P8 = K8 * LDN, ST = 2 * P8;          // one stage: "A" panel rows [8][144], then the "B" panel
+    // four SEPARATE arrays: the compiler's wait-count insertion tracks LDS-DMA targets per object - one array for the whole ring
+    // made it put s_waitcnt vmcnt(0) before every fragment read (any DMA in flight might alias), which is the 2-stage loop again
+    __shared__ double st0[ST];
+    __shared__ double st1[ST];
+    __shared__ double st2[ST];
+    __shared__ double st3[ST];
+    int bsplit = blockIdx.y, bitem = blockIdx.x, nsp_grid = (int)gridDim.y;
+    if (order) {
+        const int o = __builtin_amdgcn_readfirstlane(order[blockIdx.x]);
+        if (o < 0) return;
+        bitem = o & 0xffff; bsplit = o >> 16; nsp_grid = nsplit_o;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int *it = items + (long)bitem * 16;
+    const int c0 = it[0], c1 = it[1], c2 = it[2], c3 = it[3];
+    const int wdesc = __builtin_amdgcn_readfirstlane(it[4 + wave * 3]);
+    const int rb = __builtin_amdgcn_readfirstlane(it[5 + wave * 3]), cb = __builtin_amdgcn_readfirstlane(it[6 + wave * 3]);
+    const int sa = wdesc & 0xff, sbt = (wdesc >> 8) & 0xff;
+    const bool live = (wdesc >> 16) & 1;
+    long kbeg = (long)bsplit * kchunk;
+    if (kbeg > kdim) kbeg = kdim;
+    const long kend = (kbeg + kchunk < kdim && bsplit + 1 < nsp_grid) ? kbeg + kchunk : kdim;
+    const int nk = (int)(kend - kbeg);                              // a multiple of 16 (launcher)
+    const int ntile = nk / K8;
+    const __amdgpu_buffer_rsrc_t r_a = make_rsrc(A + kbeg * lda);
+    const int lda8 = lda * 8;
+    const int voff_a = (lane & 31) * 16 + ((lane >> 5) ? c1 : c0) * 8;
+    const int voff_b = (lane & 31) * 16 + ((lane >> 5) ? c3 : c2) * 8;
+    const int fk = lane >> 4, fn = lane & 15;
+    const int offa = (sa >> 1) * P8 + (sa & 1) * 64 + fk * LDN + fn;
+    const int offb = (sbt >> 1) * P8 + (sbt & 1) * 64 + fk * LDN + fn;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    // tile index -> first k row (tiles beyond the range re-load the last one: the DMA count per step stays uniform for vmcnt)
+    auto tile_k0 = [&](int t) { return (t < ntile ? t : ntile - 1) * K8; };
+    auto stage_row = [&](int t, double *dst, int j) {              // j = 0, 1: this wave's two rows of the 8-row tile
+        const int k = wave * 2 + j, k0 = tile_k0(t);
+        dma_row(r_a, dst + k * LDN, voff_a, (k0 + k) * lda8);
+        dma_row(r_a, dst + P8 + k * LDN, voff_b, (k0 + k) * lda8);
+    };
+    if (ntile <= 0) return;
+#pragma unroll
+    for (int j = 0; j < 2; j++) stage_row(0, st0, j);
+#pragma unroll
+    for (int j = 0; j < 2; j++) stage_row(1, st1, j);
+#pragma unroll
+    for (int j = 0; j < 2; j++) stage_row(2, st2, j);
+    // Schedule of step t (stage s = t % 4), one barrier per step, fragment reads software-pipelined ACROSS it:
+    //   group 0: read the fragments of (tile t, k-group 1); DMA row 0 of tile t + 3 -> stage (t + 3) % 4; MFMAs on (tile t, group 0)
+    //   group 1: read the fragments of (tile t + 1, group 0); DMA row 1 of tile t + 3;                    MFMAs on (tile t, group 1)
+    //   end:     s_waitcnt vmcnt(4) = this wave's rows of tile t + 2 have landed (tile t + 3 may fly); s_barrier = tile t + 2 is
+    //            visible to everybody from now on, and nobody reads stage t % 4 any more (tile t + 4 goes there in step t + 1).
+    // Tile t + 1 is readable during step t because the barrier at the end of step t - 1 covered it.
+    double a0[4], b0[4], a1[4], b1[4];
+    auto frag = [&](const double *cur, int kk, double (&af)[4], double (&bf)[4]) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) af[a] = cur[offa + kk * LDN + a * 16];
+#pragma unroll
+        for (int b = 0; b < 4; b++) bf[b] = cur[offb + kk * LDN + b * 16];
+    };
+    auto mma = [&](const double (&af)[4], const double (&bf)[4]) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] = mfma_f64_16x16x4(af[a], bf[b], acc[a][b]);
+    };
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");          // tiles 0 and 1 landed and visible
+    if (live) {
+        frag(st0, 0, a0, b0);
+        auto step = [&](const double *cur, const double *nextt, double *dma, int t) {
+            frag(cur, 4, a1, b1);
+            stage_row(t + 3, dma, 0);
+            mma(a0, b0);
+            frag(nextt, 0, a0, b0);
+            stage_row(t + 3, dma, 1);
+            mma(a1, b1);
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        };
+        for (int t = 0; t < ntile; t += 4) {
+            step(st0, st1, st3, t);
+            if (t + 1 < ntile) step(st1, st2, st0, t + 1);
+            if (t + 2 < ntile) step(st2, st3, st1, t + 2);
+            if (t + 3 < ntile) step(st3, st0, st2, t + 3);
+        }
+    } else {
+        auto step_idle = [&](double *dma, int t) {                      // a wave without a live block only stages its DMA rows
+#pragma unroll
+            for (int j = 0; j < 2; j++) stage_row(t + 3, dma, j);
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        };
+        for (int t = 0; t < ntile; t += 4) {
+            step_idle(st3, t);
+            if (t + 1 < ntile) step_idle(st0, t + 1);
+            if (t + 2 < ntile) step_idle(st1, t + 2);
+            if (t + 3 < ntile) step_idle(st2, t + 3);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!live) return;
+    double *out = C + (long)bsplit * m * ldc;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int col = cb * 64 + b * 16 + fn;
+            if (col >= m) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rowi = rb * 64 + a * 16 + fk + 4 * r;
+                if (rowi < m) unsafeAtomicAdd(out + (long)rowi * ldc + col, acc[a][b][r]);
+            }
+        }
+}
+
 // flag[rt][ct] = max |src[16 rt .. 16 rt + 15][16 ct .. 16 ct + 15]| > thr   (rows >= nrows count as zero)
 __global__ __launch_bounds__(256) void tile_mask_kernel(const double *__restrict__ src, long ld, long nrows, double thr,
                                                         unsigned char *__restrict__ out, int nct)
@@ -1661,6 +1794,7 @@ static int g_syrk_frac = 1;   // balanced SYRK: full pieces + one short remainde
 static int g_num_cu = 256;    // MI355X
 static int g_syrk_reserve = 0; // balanced SYRK: workgroup slots (of 2 x 256) left free for a co-running J pass 2 ("syrkreserve")
 static int g_dma_v2 = 1;      // buffer-resource LDS-DMA with the issue spread over the MFMA groups (e2_sq2 / gemm_tn_glds2)
+static int g_syrk_ring = 0;   // r06 experiment: re-tiled SYRK with a 4-stage ring of 8-deep k-tiles (syrk_ring4_kernel; "syrkring")
 static int g_syrk_xmap = 0;   // r06: SYRK work items in an XCD-aware dispatch order (syrk_xcd_order; "syrkxmap": 1 split-major, 2 item-major)
 
 extern "C" {
@@ -1676,6 +1810,7 @@ int PAMD_set_tuning(const char *key, int value)
     if (strcmp(key, "syrkslots") == 0) { g_syrk_slots = value; return 0; }
     if (strcmp(key, "syrkprobe") == 0) { g_syrk_probe = value; return 0; }
     if (strcmp(key, "syrkxmap") == 0) { g_syrk_xmap = value; return 0; }
+    if (strcmp(key, "syrkring") == 0) { g_syrk_ring = value; return 0; }
     if (strcmp(key, "numcu") == 0 && value > 0) { g_num_cu = value; return 0; }
     if (strcmp(key, "pkdma") == 0) { g_pk_dma = value; return 0; }
     if (strcmp(key, "pkdiag") == 0) { g_pk_diag = value; return 0; }
@@ -2370,6 +2505,11 @@ static int dgemm_tn_impl(const double *d_A, int lda, const double *d_B, int ldb,
                 int nwg = 0;
                 if ((rc = syrk_xcd_order(1, m, sorted, nsplit, kc != kchunk, g_syrk_xmap, &d_order, &nwg))) return rc;
                 g2 = dim3(nwg, 1);
+            }
+            if (g_syrk_ring && !g_syrk_probe) {
+                syrk_ring4_kernel<<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, d_order, nsplit);
+                PAMD_CHECK_LAUNCH();
+                return 0;
             }
             if (g_syrk_probe) syrk_slots_kernel<1, false><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, none, d_order, nsplit);
             else syrk_slots_kernel<0, false><<<g2, 256, 0, st>>>(d_A, lda, d_C, ldc, m, k, d_items, kc, g_mfma_prio, none, d_order, nsplit);

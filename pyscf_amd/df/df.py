@@ -508,8 +508,9 @@ class DF:
         from ..lib import hbm
         r = min(int(self.k_block_bytes), nL * rows * rows * 8) + (4 << 30)
         if self.xc_image_hint:
-            # (an SCF builds its XC plan BEFORE the tensor: what the plan already holds is not asked for twice)
-            r += max(0, int(self.xc_image_hint) - hbm.held(self._device(), 'xc_image')) + (12 << 30)
+            # (an SCF builds its XC plan BEFORE the tensor: what the plan already holds - image and work buffers - is not asked for twice)
+            held = hbm.held(self._device(), 'xc_image')
+            r += max(0, int(self.xc_image_hint) - held) + ((4 << 30) if held else (12 << 30))
         return r
 
     def _maybe_square(self):

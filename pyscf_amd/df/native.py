@@ -332,12 +332,11 @@ class NativeDF:
             # dm == orbo orbo^T ?  One matrix-vector probe per density (r04 computed D v twice per density: with numpy's 64 BLAS
             # threads on a 256-core host that was the whole 10 ms gap between this call and the bare C call; a probe on a helper
             # thread beside the device call - tried in r05 - made the C call itself 40 ms slower: the BLAS threads spin)
-            # r06: the FULL matrix-vector probe for this package's own make_rdm1 tag as well - every 16th row (r05)
-            # missed sparse in-place edits of a tagged array (dm[1, 2] += h); one 8 nao^2-byte read per density with the BLAS
-            # pool bounded to 8 threads (lib.bounded_matvec: ~0.3 ms at nao 1856)
-            from ..lib import dm_orbital_mismatch
-            ok = dm_orbital_mismatch(dms, blocks) <= 1e-10
-            flags = 1 if ok else 0
+            # Is dm == orbo orbo^T?  r06: the FULL-matrix probe (the every-16th-row probe of r05 missed sparse in-place
+            # edits of a tagged array) runs INSIDE the C call, on the calling thread beside the queued kernels (flags bit 1): the
+            # host pays nothing for it (before: 5-7 ms of BLAS start-up per call on a 256-thread host), and a tag that does not
+            # describe its matrix gets J recomputed from the matrix before the call returns (PAMD_df_last_mismatch says so)
+            flags = 2
         vj = pinned_empty(dms.shape) if with_j else None
         vk = pinned_empty(dms.shape) if with_k else None
 
@@ -348,5 +347,7 @@ class NativeDF:
                 _c.c_int(int(with_j)), _c.c_int(int(with_k)), _c.c_int(fl),
                 vj.ctypes.data_as(_c.c_void_p) if with_j else None, vk.ctypes.data_as(_c.c_void_p) if with_k else None))
         call(flags)
-        self._last_fused = bool(flags)
+        load().PAMD_df_last_mismatch.restype = _c.c_double
+        self._last_mismatch = float(load().PAMD_df_last_mismatch(self._h)) if flags else 0.0
+        self._last_fused = bool(flags) and self._last_mismatch <= 1e-10
         return (vj.reshape(shape) if with_j else None), (vk.reshape(shape) if with_k else None)

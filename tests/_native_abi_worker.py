@@ -67,6 +67,16 @@ def main():
         vj, vk = o2.get_jk(lib.tag_array(dm_other, mo_coeff=c, mo_occ=occ), hermi=1)
         vj0b, _ = ref.get_jk(cd, dm_other, 1)
         assert np.abs(vj - vj0b).max() < 1e-9 and np.abs(vk - vk0).max() < 1e-9
+        assert o2._last_mismatch > 1e-6 and not o2._last_fused          # r06: found by the probe INSIDE the call (flags bit 1)
+        # the advisor's finite-difference edit of a tagged array: two elements, caught by the full-matrix probe
+        fd = dm.copy()
+        fd[1, 2] += 1e-4
+        fd[2, 1] += 1e-4
+        vj, vk = o2.get_jk(lib.tag_array(fd, mo_coeff=c, mo_occ=occ, dm_from_orbitals=True), hermi=1)
+        vj0c, _ = ref.get_jk(cd, fd, 1)
+        assert np.abs(vj - vj0c).max() < 1e-9 and o2._last_mismatch > 1e-8
+        vj, vk = o2.get_jk(lib.tag_array(dm, mo_coeff=c, mo_occ=occ), hermi=1)
+        assert o2._last_fused and o2._last_mismatch < 1e-12 and np.abs(vj - vj0).max() < 1e-9
         # UHF-style: two densities with their own orbitals
         occ_b = np.zeros(n)
         occ_b[:nocc - 1] = 1

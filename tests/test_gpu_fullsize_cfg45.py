@@ -160,6 +160,11 @@ def test_config4_taxol_df_rks_xc_and_energy_vs_oracle_golden():
         # and the SCF restarted there converges to the same number (the density was converged to 1e-10: stationary)
         e = mf.kernel(dm0=dm)
         assert mf.converged and abs(e - g['xc_b3lyp_e_rks_functional']) < 1e-8, (e, g['xc_b3lyp_e_rks_functional'])
+        # r06: ONE copy of the tensor (225 GB of square rows, every row on the square kernel) AND the 30.6 GB
+        # compact AO image cached beside it - the single HBM budget at its tightest named case (the XC plan was built first here,
+        # as in any Kohn-Sham SCF: what it holds is not reserved a second time)
+        plan = mf._numint.sparse_plan(mol, mf.grids, True)
+        assert mf.with_df._layout == 'square' and mf.with_df._packed is None and plan.ao_c is not None, (mf.with_df._layout, plan.ao_c is None)
     mf.with_df.reset()
     mf._numint.reset()
     del mf

@@ -146,6 +146,10 @@ evidence)   # the round's measured evidence (everything except the test suite): 
   timeout 600 python tools/run_scf.py --nwater 32 --xc '' --conv-tol 1e-10 > $O/scf_h2o32_rhf.log 2>&1; tail -1 $O/scf_h2o32_rhf.log
   timeout 600 python tools/run_scf.py --molecule taxol --xc b3lyp --conv-tol 1e-9 > $O/scf_taxol_b3lyp.log 2>&1; tail -1 $O/scf_taxol_b3lyp.log
   timeout 600 python tools/grad_bench.py --nwater 32 > $O/grad_h2o32_rhf.json 2> $O/grad.err; cat $O/grad_h2o32_rhf.json | cut -c1-300
+  # r06: a complete N = 2 line (two gloo ranks on the one GPU: cpu_baseline on rank 0's shard, live PMC of the shard, parity_golden)
+  timeout 900 python bench.py --gpus 2 --backend gloo --pmc on --steps 5 > $O/bench_h2o32_2rank_gloo_1gpu.json 2> $O/bench_gloo2.err; python tools/bench_digest.py $O/bench_h2o32_2rank_gloo_1gpu.json; tail -2 $O/bench_gloo2.err
+  # r06: the compute partition mode of the device, READ ONLY (a CPX run of 8 RCCL ranks on one MI355X was not attempted: see profiles/r06/README.md)
+  ( rocm-smi --showcomputepartition --showmemorypartition 2>&1 | head -20; amd-smi partition 2>&1 | head -30 ) > $O/partition_query.txt 2>&1; head -12 $O/partition_query.txt
   find gpurun_out -name "*.db" -delete ;;
 syrkfetch)  # r06: SYRK dispatch orders x FETCH_SIZE x ms.  gpu_job.sh syrkfetch "<tune1>" "<tune2>" ... (- = none)
   : > $O/kbench.log
