@@ -696,8 +696,22 @@ int init_shard(PAMD_df *h, const Tables &t, int device, double omega)
 
 int init_streams(PAMD_df *h)
 {
-    PAMD_CHECK_HIP(hipStreamCreate(&h->st));
-    PAMD_CHECK_HIP(hipStreamCreate(&h->side));
+    {
+        // r06: the MFMA kernels' stream at the device's HIGHEST queue priority, the side stream (second J pass) at the LOWEST: the
+        // dispatcher then places the SYRK's one-round grid before the pass's 6700 long-running workgroups instead of racing them
+        // for wave slots (bimodal 45 / 50 ms SYRK in the square layout, profiles/r06/native_percall_stream_priority.log).
+        // PAMD_DF_STREAM_PRIO=0: plain hipStreamCreate as in r03-r05.
+        const char *e = getenv("PAMD_DF_STREAM_PRIO");
+        int lo = 0, hi = 0;
+        if (!(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+            PAMD_CHECK_HIP(hipStreamCreateWithPriority(&h->st, hipStreamDefault, hi));
+            PAMD_CHECK_HIP(hipStreamCreateWithPriority(&h->side, hipStreamDefault, lo));
+        } else {
+            (void)hipGetLastError();
+            PAMD_CHECK_HIP(hipStreamCreate(&h->st));
+            PAMD_CHECK_HIP(hipStreamCreate(&h->side));
+        }
+    }
     PAMD_CHECK_HIP(hipStreamCreate(&h->copy));
     PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
     PAMD_CHECK_HIP(hipEventCreateWithFlags(&h->ev_j, hipEventDisableTiming));
@@ -1088,6 +1102,8 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
     if (streamed) serial_j2 = 1;           // the staged rows are released when the main stream is done with them
     if (h->square && serial_j2 == 2) serial_j2 = 0;     // the in-SYRK pass streams PACKED rows: not a schedule of the square layout
     const long lstride = h->sq_ls();
+    static const bool j2_before = [] { const char *e = getenv("PAMD_DF_J2_ORDER"); return e && e[0] == 'b'; }();
+    bool j2_deferred = false;
     // the J passes over aux rows [b0, b0 + nb) of a segment, from whichever layout holds them (square: the p >= q runs)
     auto j_pass1 = [&](const double *rows_pk, const double *rows_sq, int nb, const double *dt, int ns, double *rho, double *work, hipStream_t s_) {
         return rows_pk ? PAMD_df_vj_pass1(rows_pk, npair, nb, dt, ns, rho, work, s_)
@@ -1302,7 +1318,11 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                         } else {
                             PAMD_CHECK_HIP(hipEventRecord(h->ev, st));
                             PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev, 0));
-                            if ((rc = j_pass2(sub, sub_sq, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side))) return rc;
+                            // r06: the pass is ENQUEUED after the SYRK (below) unless PAMD_DF_J2_ORDER=before: launched first, its
+                            // 6700 long-running workgroups sometimes take the CUs' wave slots before the SYRK's 496 workgroups
+                            // arrive, and the balanced one-round SYRK then starts part of its grid late (bimodal: 45 or 50 ms)
+                            if (j2_before && (rc = j_pass2(sub, sub_sq, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side))) return rc;
+                            j2_deferred = !j2_before;
                         }
                     }
                     const long kx = (long)nb * xr, kx16 = round_up(kx, 16);
@@ -1322,6 +1342,10 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                         j_on_st = true;
                     } else if ((rc = PAMD_dgemm_tn(d_X, ldx, d_X, ldx, part_s, nao, nao, nao, kx16, syrk_flags, nsplit, st))) return rc;
                     mark(3);
+                    if (j2_deferred) {
+                        if ((rc = j_pass2(sub, sub_sq, nb, rho_b, 1, d_vjt + (size_t)s * npair, h->side))) return rc;
+                        j2_deferred = false;
+                    }
                 }
             } else {
                 // ---- general-DM branch: T_L = B_L D, K = sum_L T_L^T B_L (df_jk.py:382-407)
@@ -1393,7 +1417,18 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
     }
     // r06: everything is queued - the tag probe runs now, on this thread, beside the kernels (flags bit 1 without bit 0)
     h->last_mismatch = 0;
-    if (fused && (flags & 2) && !(flags & 1)) h->last_mismatch = host_dm_mismatch(dm, orbo, nocc, nset, nao);
+    if (fused && (flags & 2) && !(flags & 1)) {
+        static const int dbg = [] { const char *e = getenv("PAMD_DF_DEBUG_TIMING"); return (e && e[0] == '1') ? 1 : 0; }();
+        const auto tp0 = std::chrono::steady_clock::now();
+        h->last_mismatch = host_dm_mismatch(dm, orbo, nocc, nset, nao);
+        if (dbg) {
+            const double tp = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
+            const hipError_t q = hipStreamQuery(st);
+            (void)hipGetLastError();
+            fprintf(stderr, "PAMD_df_get_jk: tag probe %.2f ms on the host; main stream %s when it ended\n", tp,
+                    q == hipSuccess ? "already IDLE" : "still busy");
+        }
+    }
     PAMD_CHECK_HIP(hipStreamSynchronize(st));
     PAMD_CHECK_HIP(hipStreamSynchronize(h->side));
     PAMD_CHECK_HIP(hipStreamSynchronize(h->copy));
