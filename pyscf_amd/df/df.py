@@ -208,7 +208,9 @@ class DF:
     def _side_stream(self):
         import torch
         if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream(device=self.tensor_device())
+            # (k_side_priority = 1: the lowest queue priority for the second J pass's stream - what cured a bimodal SYRK in the C
+            # handle, csrc/df_handle.hip; measured neutral here, profiles/r06/README.md: default 0)
+            self._side = torch.cuda.Stream(device=self.tensor_device(), priority=int(getattr(self, 'k_side_priority', 0)))
         return self._side
 
     # -- integral-direct J support (no tensor) ---------------------------------------------------

@@ -27,6 +27,7 @@ ap.add_argument('--syrk-reserve', type=int, default=0, help='balanced re-tiled S
 ap.add_argument('--syrk-flags', type=int, default=-1, help='4: balanced k split, 8: re-tiled triangle (df_jk.syrk_plan)')
 ap.add_argument('--layout', default='packed', choices=['packed', 'square'], help="'square': the square rows as the only copy (r06), generated directly")
 ap.add_argument('--sq-contiguous', action='store_true', help='square layout WITHOUT the padded aux-row stride (A/B of DF.SQ_STRIDE_PAD)')
+ap.add_argument('--side-priority', type=int, default=0, help='queue priority of the J side stream (1: lowest, 0: default)')
 ap.add_argument('--no-j', action='store_true', help='K only (as the K_LR / response calls do)')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
@@ -61,6 +62,7 @@ if a.block_gb: obj.k_block_bytes = int(a.block_gb * (1 << 30))
 if a.no_fuse: obj.fuse_j_pass1 = False
 if a.ksplit: obj.k_nsplit = a.ksplit
 obj.k_syrk_reserve = a.syrk_reserve
+obj.k_side_priority = a.side_priority
 obj.k_syrk_flags = None if a.syrk_flags < 0 else a.syrk_flags
 import ctypes
 from pyscf_amd import lib as _L
