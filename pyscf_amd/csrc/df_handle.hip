@@ -1460,12 +1460,15 @@ static int shard_get_jk(PAMD_df *h, const double *dm, const double *orbo, const 
             for (int s = 0; s < nset; s++) key = key * 4099 + nocc[s];
             auto it = h->j2_policy.find(key);
             if (it == h->j2_policy.end()) {
-                double ms[3] = {0, 0, 0};
-                for (int trial = 0; trial < (h->square ? 3 : 4); trial++) {   // overlap (priming, untimed), overlap, serial, fused into the SYRK (packed rows only)
+                double ms[3] = {1e30, 1e30, 1e30};
+                // overlap (priming, untimed), then overlap, serial, fused into the SYRK (packed rows only) - r06: the BEST of two runs
+                // each (a single run now and then carries a 20 ms hiccup and used to pick the slower schedule for good)
+                for (int trial = 0; trial < (h->square ? 5 : 7); trial++) {
+                    const int sched = trial ? (trial - 1) / 2 : 0;
                     const auto t0 = std::chrono::steady_clock::now();
-                    const int rc = df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, trial ? trial - 1 : 0, download);
+                    const int rc = df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, sched, download);
                     if (rc) return rc;
-                    if (trial) ms[trial - 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    if (trial) ms[sched] = std::min(ms[sched], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                 }
                 int best = ms[1] < 0.99 * ms[0] ? 1 : 0;
                 if (!h->square && ms[2] < 0.99 * ms[best]) best = 2;

@@ -674,14 +674,21 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                             run_fused(False)                                     # priming: lazy images, workspaces
                             times = {}
                             for name in ('overlap', 'serial') + (('fused',) if getattr(dfobj, 'j2_try_fused', False) and not square_layout else ()):
-                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                                torch.cuda.current_stream().wait_stream(side)
-                                e0.record()
-                                run_fused('fused' if name == 'fused' else name == 'serial')
-                                torch.cuda.current_stream().wait_stream(side)
-                                e1.record()
-                                e1.synchronize()
-                                times[name] = e0.elapsed_time(e1)
+                                # r06: the BEST of three runs per candidate - a single run now and then carries a 20 ms hiccup
+                                # (profiles/r06/bench_h2o32_1gpu_default_final.json, first version: overlap timed once at 135.9 ms,
+                                # 'serial' chosen, the whole bench line 5 ms slower than the schedule it should have run)
+                                best_t = None
+                                for _rep in range(3):
+                                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                    torch.cuda.current_stream().wait_stream(side)
+                                    e0.record()
+                                    run_fused('fused' if name == 'fused' else name == 'serial')
+                                    torch.cuda.current_stream().wait_stream(side)
+                                    e1.record()
+                                    e1.synchronize()
+                                    t_ = e0.elapsed_time(e1)
+                                    best_t = t_ if best_t is None else min(best_t, t_)
+                                times[name] = best_t
                             policy = 'serial' if times['serial'] < 0.99 * times['overlap'] else 'overlap'
                             if 'fused' in times and times['fused'] < 0.99 * times[policy]:
                                 policy = 'fused'
