@@ -228,14 +228,39 @@ __global__ __launch_bounds__(J1_THREADS) void vj_pass1_sq_kernel(
     }
 }
 
+// Work units of the square second pass: (row p, 256-column chunk c) with c * 256 <= p - every wave then reads 64 consecutive doubles
+// that START ON A 512-BYTE BOUNDARY of its row (rows start on 128-byte boundaries: ld % 16 == 0).  The first version walked the flat
+// packed index space, so a wave's 512 bytes began anywhere inside the row: 9 sectors of 64 bytes instead of 8, and with the
+// non-temporal loads the neighbour fetched the shared sector again - FETCH_SIZE 74.3 GB for 61.3 GB of operand (+21 %,
+// profiles/r06/pmc_summary.json) and a pass that cost the co-running SYRK more than the packed pass does (whose 2 KiB chunks are
+// sector-aligned by construction).  Rows 256 g .. 256 g + 255 have g + 1 chunks each: unit u -> (g, p, c) in closed form.
+__device__ __forceinline__ void sq_unit(long u, int &p, int &c)
+{
+    int g = (int)((sqrt(1.0 + (double)u / 32.0) - 1.0) * 0.5);          // 128 g (g + 1) <= u
+    while (128L * (g + 1) * (g + 2) <= u) g++;
+    while (128L * g * (g + 1) > u) g--;
+    const int r = (int)(u - 128L * g * (g + 1));
+    p = 256 * g + r / (g + 1);
+    c = r - (r / (g + 1)) * (g + 1);
+}
+__host__ __device__ inline long sq_units(int nao)
+{
+    const long g = nao / 256, rem = nao - 256 * g;                       // full groups of 256 rows, then `rem` rows with g + 1 chunks
+    return 128L * g * (g + 1) + rem * (g + 1);
+}
+
 template <int NSET>
 __global__ __launch_bounds__(256) void vj_pass2_sq_kernel(
-    const double *__restrict__ sq, long lstride, int ld, long npair, int naux, const double *__restrict__ rho,
+    const double *__restrict__ sq, long lstride, int ld, int nao, int naux, const double *__restrict__ rho,
     double *__restrict__ vj)
 {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npair; i += (long)gridDim.x * 256) {
-        int p, q;
-        tril_pq(i, p, q);
+    const long nunit = sq_units(nao);
+    const long npair = (long)nao * (nao + 1) / 2;
+    for (long u = blockIdx.x; u < nunit; u += gridDim.x) {
+        int p, c;
+        sq_unit(u, p, c);
+        const int q = c * 256 + threadIdx.x;
+        if (q > p) continue;                                            // (idle lanes of a row's last chunk: no memory traffic)
         double acc[NSET];
 #pragma unroll
         for (int s = 0; s < NSET; s++) acc[s] = 0;
@@ -244,17 +269,18 @@ __global__ __launch_bounds__(256) void vj_pass2_sq_kernel(
         for (; L + 8 <= naux; L += 8) {
             double b[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) b[u] = __builtin_nontemporal_load(col + (long)(L + u) * lstride);
+            for (int k = 0; k < 8; k++) b[k] = __builtin_nontemporal_load(col + (long)(L + k) * lstride);
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int k = 0; k < 8; k++)
 #pragma unroll
-                for (int s = 0; s < NSET; s++) acc[s] += rho[s * naux + L + u] * b[u];
+                for (int s = 0; s < NSET; s++) acc[s] += rho[s * naux + L + k] * b[k];
         }
         for (; L < naux; L++) {
             const double b = col[(long)L * lstride];
 #pragma unroll
             for (int s = 0; s < NSET; s++) acc[s] += rho[s * naux + L] * b;
         }
+        const long i = (long)p * (p + 1) / 2 + q;
 #pragma unroll
         for (int s = 0; s < NSET; s++) vj[(long)s * npair + i] += acc[s];
     }
@@ -1915,14 +1941,13 @@ int PAMD_df_vj_pass2_sq(const double *d_sq, long lstride, int ld, int nao, int n
     PAMD_REQUIRE(ld >= nao && lstride >= (long)nao * ld, "PAMD_df_vj_pass2_sq: leading dimensions");
     if (naux == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const long npair = (long)nao * (nao + 1) / 2;
-    int grid = ceil_div(npair, 256);
+    long grid = sq_units(nao);
     if (g_j2_maxwg > 0 && grid > g_j2_maxwg) grid = g_j2_maxwg;
     switch (nset) {
-    case 1: vj_pass2_sq_kernel<1><<<grid, 256, 0, st>>>(d_sq, lstride, ld, npair, naux, d_rho, d_vjtril); break;
-    case 2: vj_pass2_sq_kernel<2><<<grid, 256, 0, st>>>(d_sq, lstride, ld, npair, naux, d_rho, d_vjtril); break;
-    case 3: vj_pass2_sq_kernel<3><<<grid, 256, 0, st>>>(d_sq, lstride, ld, npair, naux, d_rho, d_vjtril); break;
-    default: vj_pass2_sq_kernel<4><<<grid, 256, 0, st>>>(d_sq, lstride, ld, npair, naux, d_rho, d_vjtril); break;
+    case 1: vj_pass2_sq_kernel<1><<<(unsigned)grid, 256, 0, st>>>(d_sq, lstride, ld, nao, naux, d_rho, d_vjtril); break;
+    case 2: vj_pass2_sq_kernel<2><<<(unsigned)grid, 256, 0, st>>>(d_sq, lstride, ld, nao, naux, d_rho, d_vjtril); break;
+    case 3: vj_pass2_sq_kernel<3><<<(unsigned)grid, 256, 0, st>>>(d_sq, lstride, ld, nao, naux, d_rho, d_vjtril); break;
+    default: vj_pass2_sq_kernel<4><<<(unsigned)grid, 256, 0, st>>>(d_sq, lstride, ld, nao, naux, d_rho, d_vjtril); break;
     }
     PAMD_CHECK_LAUNCH();
     return 0;

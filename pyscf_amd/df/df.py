@@ -43,6 +43,8 @@ class DF:
         # read the p >= q runs of the square rows, loop / save / export pack on the fly.  'packed': the reference's rows (+ the
         # optional partial image / diagonal-block image of r03) when 2x does not fit.  'auto': square when the budget allows.
         self.layout = 'auto'
+        self.prefer_image = True    # 'auto': packed rows + a full image while all three copies fit the budget (the fastest layout
+                                    # beside the co-running SYRK, measured); False: the square rows whenever 2x fits
         self._layout = None         # what build() decided
         self.xc_image_hint = 0      # bytes the XC leg of the same calculation will cache in HBM (KS objects set it): part of the budget
         self._cderi_to_save = None
@@ -531,7 +533,12 @@ class DF:
         rows = (nao + 15) // 16 * 16
         dev = self._packed.device
         if self.layout != 'square':
-            fits = nao >= 128 and nL * rows * rows * 8 + max(self._reserve_after_build(nL, rows), 4 << 30) <= hbm.free_bytes(dev)
+            free = hbm.free_bytes(dev)
+            # (the packed rows are resident already: a full image beside them is preferred where it fits - see _choose_layout)
+            luxury = nL * rows * rows * 8 + max(self._reserve_after_build(nL, rows), int(self.k_square_reserve))
+            if getattr(self, 'prefer_image', True) and self._all_ranks_agree(luxury + (2 << 30) <= free):
+                return self
+            fits = nao >= 128 and nL * rows * rows * 8 + max(self._reserve_after_build(nL, rows), 4 << 30) <= free
             if not self._all_ranks_agree(fits):
                 return self
         sq = self.alloc_square(nL, rows, dev)
@@ -567,6 +574,14 @@ class DF:
         slab = min(12 << 30, npair * naux * 8)
         build_need = nL * rows * rows * 8 + slab + min(slab, slab * max(nL, 1) // max(naux, 1) + (1 << 20)) + (2 << 30)
         after_need = nL * rows * rows * 8 + self._reserve_after_build(nL, rows)
+        # The order of preference, from measurement (profiles/r06/README.md): (1) packed rows + a FULL image when the budget has room
+        # for all three copies - beside the co-running SYRK the packed second J pass costs less than the square one (same bytes,
+        # same alignment: 41.5-42.1 vs 45.9-47.4 ms of SYRK on one box), so config 3 keeps its r05 speed; (2) the square rows alone
+        # when 3x does not fit and 2x does (taxol on one GPU, large shards): every row on the square kernel, no second copy, the XC
+        # image beside it; (3) packed rows + whatever partial image / diagonal blocks the budget leaves.
+        luxury = nL * npair * 8 + nL * rows * rows * 8 + max(self._reserve_after_build(nL, rows), int(self.k_square_reserve))
+        if getattr(self, 'prefer_image', True) and self._all_ranks_agree(luxury + (2 << 30) <= free):
+            return 'packed'
         fits = max(build_need, after_need) <= free
         return 'square' if self._all_ranks_agree(fits) else 'packed'
 

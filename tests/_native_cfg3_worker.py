@@ -41,13 +41,20 @@ def main():
 
     tagged = lib.tag_array(dm, mo_coeff=mo, mo_occ=occ)
     npair = nao * (nao + 1) // 2
-    for tag, kw in (('one shard in HBM', dict()), ('two parts on device 0', dict(devices=[0, 0])),
+    for tag, kw in (('one shard in HBM', dict()), ('one shard in HBM, SQUARE rows only (r06)', dict(square=True)),
+                    ('two parts on device 0', dict(devices=[0, 0])),
+                    ('two parts on device 0, SQUARE rows only (r06)', dict(devices=[0, 0], square=True)),
                     ('a 69 GB device-memory cap (about 40 %% of the rows in host memory)', dict(max_device_bytes=int(69e9)))):
         t0 = time.perf_counter()
+        want_square = kw.pop('square', False)
+        # (the handle keeps packed rows + a full image while 3x fits the budget; PAMD_DF_PREFER_IMAGE=0 = the square layout, the
+        # one a tensor whose 3x does not fit - taxol on one GPU - gets by itself)
+        os.environ['PAMD_DF_PREFER_IMAGE'] = '0' if want_square else '1'
         obj = native.NativeDF(mol, **kw).build()
         tb = time.perf_counter() - t0
         assert obj.get_naoaux() == g['naux'] == 4448
         lay = obj.layout()
+        assert lay['tensor_layout'] == ('square' if want_square else 'packed'), lay
         vj, vk = obj.get_jk(tagged, hermi=1)                       # first call: schedule timing included
         check(vj, vk, tag)
         ts = []

@@ -34,7 +34,9 @@ def h2o32():
     from pyscf_amd import gto, df
     from pyscf_amd.data import clusters
     mol = gto.M(atom=clusters.water_cluster(32), basis='cc-pvtz')
-    obj = df.DF(mol).build()
+    obj = df.DF(mol)
+    obj.prefer_image = False          # the SQUARE layout at full size (r06); the packed layouts are exercised on the same rows below
+    obj.build()
     torch.cuda.synchronize()
     yield mol, obj
     obj.reset()                      # 61 GB tensor + 123 GB square image back to the allocator for the next module

@@ -142,22 +142,27 @@ def test_layout_budget_keeps_room_for_the_xc_image(monkeypatch):
     kept = hbm.held(dev, 'xc_image')
     hbm.drop(dev, 'xc_image')
     try:
-        a = df.DF(mol)
-        a.xc_image_hint = pinned                    # an XC leg that wants everything that is free
-        a.build()
-        assert a._layout == 'packed'
+        def make(hint, prefer_image):
+            o = df.DF(mol)
+            o.xc_image_hint, o.prefer_image = hint, prefer_image
+            return o.build()
+        # an XC leg that wants everything that is free: neither 3x nor 2x leaves it room -> packed rows (+ what is left)
+        assert make(pinned, False)._layout == 'packed' and make(pinned, True)._layout == 'packed'
         hbm.hold(dev, 'xc_image', pinned)           # ... which the plan already holds: nothing left to reserve
-        b = df.DF(mol)
-        b.xc_image_hint = pinned
-        b.build()
-        assert b._layout == 'square'
+        assert make(pinned, False)._layout == 'square'
         hbm.drop(dev, 'xc_image')
-        c = df.DF(mol).build()
-        assert c._layout == 'square'
-        d = df.DF(mol)
-        d.xc_image_hint = 60 << 30                  # tensor (tiny) + X block + 4 GB + 60 GB + 12 GB of XC work space <= 100 GB
-        d.build()
-        assert d._layout == 'square'
+        assert make(0, False)._layout == 'square'
+        assert make(60 << 30, False)._layout == 'square'     # tensor (tiny) + X block + 4 GB + 60 GB + 12 GB of XC work space <= 100 GB
+        # the default preference: packed rows + a FULL image while all three copies fit (the faster second J pass beside the SYRK)
+        e = make(0, True)
+        assert e._layout == 'packed'
+        import numpy as np
+        from pyscf_amd import lib
+        c = np.linalg.qr(np.random.default_rng(0).standard_normal((mol.nao, mol.nao)))[0]
+        occ = np.zeros(mol.nao)
+        occ[:mol.nelectron // 2] = 2
+        e.get_jk(lib.tag_array((c * occ).dot(c.T), mo_coeff=c, mo_occ=occ), hermi=1)
+        assert e._cderi_sq is not None and e._cderi_sq.shape[0] == e.tensor_shape()[0]        # the whole image was built
     finally:
         hbm.drop(dev, 'xc_image')
         if kept:

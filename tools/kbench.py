@@ -26,6 +26,7 @@ ap.add_argument('--ksplit', type=int, default=0)
 ap.add_argument('--syrk-reserve', type=int, default=0, help='balanced re-tiled SYRK beside the co-running J pass, this many workgroup slots left free')
 ap.add_argument('--syrk-flags', type=int, default=-1, help='4: balanced k split, 8: re-tiled triangle (df_jk.syrk_plan)')
 ap.add_argument('--layout', default='packed', choices=['packed', 'square'], help="'square': the square rows as the only copy (r06), generated directly")
+ap.add_argument('--sq-pad', type=int, default=-1, help='doubles added to the aux-row stride of the square layout (A/B of DF.SQ_STRIDE_PAD)')
 ap.add_argument('--sq-contiguous', action='store_true', help='square layout WITHOUT the padded aux-row stride (A/B of DF.SQ_STRIDE_PAD)')
 ap.add_argument('--side-priority', type=int, default=0, help='queue priority of the J side stream (1: lowest, 0: default)')
 ap.add_argument('--no-j', action='store_true', help='K only (as the K_LR / response calls do)')
@@ -34,6 +35,8 @@ dev = torch.device('cuda', 0)
 npair = a.nao * (a.nao + 1) // 2
 obj = df.DF(None)
 g = torch.Generator(device=dev); g.manual_seed(1)
+if a.sq_pad >= 0:
+    df.DF.SQ_STRIDE_PAD = a.sq_pad
 if a.layout == 'square':
     # symmetric random rows straight into the square layout (the packed tensor never exists: taxol shape = 225 GB of square rows)
     rows = (a.nao + 15) // 16 * 16
