@@ -224,6 +224,7 @@ def main():
         from pyscf_amd.dft.numint import estimate_ao_image_bytes
         dfobj.xc_image_hint = estimate_ao_image_bytes(mol)      # what RKS.density_fit() tells the tensor object (one HBM budget)
     dfobj.j2_policy = args.j2_policy
+    dfobj.j2_tune = 'eager'             # the schedule is settled by trial builds in the set-up call, before the warm-up and the timed steps
     for kv in filter(None, args.tune.split(',')):
         k_, v_ = kv.split('=')
         lib.check(lib.load_library().PAMD_set_tuning(k_.encode(), int(v_)))

@@ -27,6 +27,7 @@ static int g_orb_rho_128 = 1;    // r06: 128-orbital chunks in PAMD_sub_orb_rho 
 static int g_orb_rho_fused = 1;  // GGA: rho / grad rho in the orbital product's epilogue (PAMD_sub_orb_rho); A/B switch "orbrho"
 static int g_vmat_probe = 0;   // benchmarking probes of sub_vmat_sym ("vmatprobe", see the kernel)
 static int g_vmat_burst = 0;   // sub_vmat_sym: DMA rows of the next k-tile in one burst behind the first MFMA group ("vmatburst")
+static int g_vmat_flip = 0;    // sub_vmat_sym: which workgroups swap the roles of their waves ("vmatflip", see the kernel)
 static int g_vmat_xcd = 1;     // sub_vmat*: work items of one tile on ONE XCD (its L2 then serves the panel re-reads); A/B switch "vmatxcd"
 
 namespace {
@@ -454,20 +455,24 @@ __global__ __launch_bounds__(256, 2) void sub_vmat_kernel(const double *__restri
 template <bool BURST, int PROBE>  // BURST: all DMA rows of k-tile t + 1 behind the FIRST MFMA group of tile t instead of one row per group
 __global__ __launch_bounds__(256, 2) void sub_vmat_sym_kernel(const double *__restrict__ ao_c, const double *__restrict__ aow_c,
                                                               SubTiles tl, const int *__restrict__ work, int G, int nao,
-                                                              double *__restrict__ vmat, long ldv, int xcd)
+                                                              double *__restrict__ vmat, long ldv, int flip)
 {
     __shared__ double sb0[2 * KB * LDN];
     __shared__ double sb1[2 * KB * LDN];
     constexpr int PA = KB * LDN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    (void)xcd;
     const int *w = work + 6 * (long)blockIdx.x;       // the list is in dispatch order (PAMD_sub_vmat_work)
     const int t = w[0], p0 = w[1], gp = w[2], q0 = w[3], gq = w[4], diag = w[5];
     if (gp == 0) return;                              // padding item of a shorter XCD queue (uniform for the workgroup)
     const int ld = tl.ld[t];
     const int voff = lane * 16, ld8 = ld * 8;
-    const int wr = wave >> 1, wc = wave & 1;
+    // An odd piece (7 groups = 4 + 3) gives wave (0, 0) 16 MFMA tiles per k-group and wave (1, 1) 9.  Wave w of every workgroup sits
+    // on SIMD w % 4, so with the same roles in both co-resident workgroups SIMD 0 carries 16 + 16 and SIMD 3 9 + 9.  Workgroups whose
+    // `flip` bit is set hand the large share to wave 3 instead: a pair with different bits loads every SIMD with 16 + 9 | 12 + 12.
+    // flip: 0 none, 1 by the parity of the XCD-queue slot (blockIdx.x >> 3), 2 by the parity of the 256-workgroup round
+    const int role = wave ^ ((flip == 1 ? (blockIdx.x >> 3) & 1 : flip == 2 ? (blockIdx.x >> 8) & 1 : 0) ? 3 : 0);
+    const int wr = role >> 1, wc = role & 1;
     const int fk = lane >> 4, fn = lane & 15;
     // even split of the piece between the two wave rows / columns
     const int ga0 = (gp + 1) >> 1, gb0 = (gq + 1) >> 1;
@@ -630,6 +635,7 @@ int PAMD_set_tuning_xc(const char *key, int value)
     if (strcmp(key, "orbrho") == 0) { g_orb_rho_fused = value; return 0; }
     if (strcmp(key, "orbrho128") == 0) { g_orb_rho_128 = value; return 0; }
     if (strcmp(key, "vmatxcd") == 0) { g_vmat_xcd = value; return 0; }
+    if (strcmp(key, "vmatflip") == 0) { g_vmat_flip = value; return 0; }
     if (strcmp(key, "vmatburst") == 0) { g_vmat_burst = value; return 0; }
     if (strcmp(key, "vmatprobe") == 0) { g_vmat_probe = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
@@ -737,7 +743,7 @@ int PAMD_sub_vmat(const double *d_ao_c, const long *d_ao_off, const double *d_ao
     PAMD_REQUIRE(((uintptr_t)d_ao_c | (uintptr_t)d_aow_c) % 16 == 0, "16-byte aligned operands");
     if (nwork == 0) return 0;
     SubTiles tl{d_ao_off, d_aow_off, d_idx_off, d_ld, d_idx};
-    sub_vmat_kernel<<<nwork, 256, 0, (hipStream_t)stream>>>(d_ao_c, d_aow_c, tl, d_work, G, nao, d_vmat, ldv, g_vmat_xcd);
+    sub_vmat_kernel<<<nwork, 256, 0, (hipStream_t)stream>>>(d_ao_c, d_aow_c, tl, d_work, G, nao, d_vmat, ldv, g_vmat_flip);
     PAMD_CHECK_LAUNCH();
     return 0;
 }
@@ -754,7 +760,7 @@ int PAMD_sub_vmat_sym(const double *d_ao_c, const long *d_ao_off, const double *
     PAMD_REQUIRE(((uintptr_t)d_ao_c | (uintptr_t)d_aow_c) % 16 == 0, "16-byte aligned operands");
     if (nwork == 0) return 0;
     SubTiles tl{d_ao_off, d_aow_off, d_idx_off, d_ld, d_idx};
-    #define LAUNCH_VS(B, P) sub_vmat_sym_kernel<B, P><<<nwork, 256, 0, (hipStream_t)stream>>>(d_ao_c, d_aow_c, tl, d_work, G, nao, d_vmat, ldv, g_vmat_xcd)
+    #define LAUNCH_VS(B, P) sub_vmat_sym_kernel<B, P><<<nwork, 256, 0, (hipStream_t)stream>>>(d_ao_c, d_aow_c, tl, d_work, G, nao, d_vmat, ldv, g_vmat_flip)
     if (g_vmat_probe == 1) LAUNCH_VS(false, 1);
     else if (g_vmat_probe == 2) LAUNCH_VS(false, 2);
     else if (g_vmat_probe == 3) LAUNCH_VS(false, 3);

@@ -55,6 +55,9 @@ class DF:
         self.k_block_bytes = 12 << 30      # X block: config 3 in ONE block (10.6 GB; one kernel boundary less per step, -0.5 %)
         self.j2_policy = 'auto'    # second J pass 'overlap' (side stream, beside a plain SYRK) | 'serial' (in line, re-tiled SYRK) | 'fused' (r05: inside the SYRK kernel) |
                                    # 'auto': both timed once per shape (df_jk.get_jk_device)
+        self.j2_tune = 'lazy'      # how 'auto' times them: 'lazy' - on the caller's own calls, one candidate per call, no extra builds
+                                   # (an SCF pays nothing); 'eager' - trial builds before the first answer (bench.py, kernel tools)
+        self.j2_lazy_reps = 2      # samples per candidate before 'lazy' settles
         self.j2_tune_min_bytes = 4 << 30
         self.j2_try_fused = True   # 'auto' also times the pass INSIDE the SYRK kernel (PAMD_syrk_jfused, r05) and takes it when >= 1 % faster
         self.k_e2_pipeline = 1     # sub-blocks of a K block whose half transforms are queued back to back (df_jk._vk_mo)
@@ -378,6 +381,8 @@ class DF:
         self._eng = None
         self._rsh_df = {}          # pyscf/df/df.py:210: the range-separated children hold the old mol / auxmol
         self._side = None
+        self.__dict__.pop('_j2_lazy', None)            # half-finished schedule trials belong to the old tensor
+        self.__dict__.pop('_j2_policy_cache', None)
         return self
 
     def _device(self):

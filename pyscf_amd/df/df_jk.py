@@ -669,11 +669,21 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                         policy = cache.get(key)
                         if policy is None and naux_l * npair_l * 8 < getattr(dfobj, 'j2_tune_min_bytes', 4 << 30):
                             policy = cache[key] = 'overlap'
-                        if policy is None:
+                        cands = ('overlap', 'serial') + (('fused',) if getattr(dfobj, 'j2_try_fused', False) and not square_layout else ())
+
+                        def decide(times):
+                            pol = 'serial' if times['serial'] < 0.99 * times['overlap'] else 'overlap'
+                            if 'fused' in times and times['fused'] < 0.99 * times[pol]:
+                                pol = 'fused'
+                            cache[key] = pol
+                            dfobj._j2_policy_times = dict(times, chosen=pol)
+                            return pol
+                        if policy is None and getattr(dfobj, 'j2_tune', 'lazy') == 'eager':
+                            # trial builds before the first answer (bench.py: the schedule is settled before the timed region)
                             timer, dfobj.kernel_timer = getattr(dfobj, 'kernel_timer', None), None
                             run_fused(False)                                     # priming: lazy images, workspaces
                             times = {}
-                            for name in ('overlap', 'serial') + (('fused',) if getattr(dfobj, 'j2_try_fused', False) and not square_layout else ()):
+                            for name in cands:
                                 # r06: the BEST of three runs per candidate - a single run now and then carries a 20 ms hiccup
                                 # (profiles/r06/bench_h2o32_1gpu_default_final.json, first version: overlap timed once at 135.9 ms,
                                 # 'serial' chosen, the whole bench line 5 ms slower than the schedule it should have run)
@@ -689,13 +699,40 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                                     t_ = e0.elapsed_time(e1)
                                     best_t = t_ if best_t is None else min(best_t, t_)
                                 times[name] = best_t
-                            policy = 'serial' if times['serial'] < 0.99 * times['overlap'] else 'overlap'
-                            if 'fused' in times and times['fused'] < 0.99 * times[policy]:
-                                policy = 'fused'
-                            cache[key] = policy
-                            dfobj._j2_policy_times = dict(times, chosen=policy)
+                            policy = decide(times)
                             dfobj.kernel_timer = timer
-                    holder['vj'], vk_dev = run_fused('fused' if policy == 'fused' else policy == 'serial')
+                        elif policy is None:
+                            # r06, the default ('lazy'): no trial builds - the caller's OWN calls are the trials (as in the C handle).
+                            # The first call of a shape primes (images, work space) on 'overlap'; each following call runs the
+                            # candidate with the fewest samples between two events, read back at the NEXT call (finished long
+                            # before); after `j2_lazy_reps` samples of each the best is kept.  Every schedule returns the same J
+                            # and K, so an SCF pays nothing for the tuning (eager: ~1 s at config 3, ~3 s at taxol, in cycle 1).
+                            st = dfobj.__dict__.setdefault('_j2_lazy', {}).setdefault(
+                                key, {'times': {n: [] for n in cands}, 'pending': None, 'calls': 0})
+                            if st['pending'] is not None:
+                                name, e0, e1 = st['pending']
+                                e1.synchronize()
+                                st['times'][name].append(e0.elapsed_time(e1))
+                                st['pending'] = None
+                            reps = getattr(dfobj, 'j2_lazy_reps', 2)
+                            todo = [n for n in cands if len(st['times'][n]) < reps]
+                            st['calls'] += 1
+                            if st['calls'] == 1:
+                                policy = 'overlap'
+                            elif not todo:
+                                policy = decide({n: min(t) for n, t in st['times'].items()})
+                                del dfobj._j2_lazy[key]
+                            else:
+                                policy = min(todo, key=lambda n: len(st['times'][n]))
+                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                torch.cuda.current_stream().wait_stream(side)
+                                e0.record()
+                                holder['vj'], vk_dev = run_fused('fused' if policy == 'fused' else policy == 'serial')
+                                torch.cuda.current_stream().wait_stream(side)
+                                e1.record()
+                                st['pending'] = (policy, e0, e1)
+                    if 'vj' not in holder:
+                        holder['vj'], vk_dev = run_fused('fused' if policy == 'fused' else policy == 'serial')
 
                 def launch_j(*_a):
                     if 'vj' in holder:

@@ -463,16 +463,22 @@ def test_second_j_pass_schedules(h2o):
     occ[:nocc] = 2
     dm = lib.tag_array((c * occ).dot(c.T), mo_coeff=c, mo_occ=occ)
     vj0, vk0 = ref.get_jk(cderi, np.asarray(dm), 1, mo_coeff=c, mo_occ=occ)
-    for policy in ('overlap', 'serial', 'auto'):
+    for policy in ('overlap', 'serial', 'auto', 'auto-lazy'):
         obj = _dfobj(None, cderi)
-        obj.j2_policy = policy
+        obj.j2_policy = policy.split('-')[0]
+        obj.j2_tune = 'lazy' if policy == 'auto-lazy' else 'eager'
         obj.j2_tune_min_bytes = 0                       # 'auto': time both schedules even on this small tensor
         obj.k_block_bytes = 40 * 48 * 208 * 8           # several K blocks
-        for _ in range(2):
+        # 'lazy' (the default, r06): the caller's own calls are the trials - priming call + 2 samples of each of the 3 candidates,
+        # settled on the 8th call; 'eager': trial builds inside the first call
+        for call in range(9 if policy == 'auto-lazy' else 2):
             vj, vk = obj.get_jk(dm, hermi=1)
             assert obj._last_fused
-            assert np.abs(vj - vj0).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11, policy
-        if policy == 'auto':
+            assert np.abs(vj - vj0).max() < 1e-11 and np.abs(vk - vk0).max() < 1e-11, (policy, call)
+            if policy == 'auto-lazy':
+                assert hasattr(obj, '_j2_policy_times') == (call >= 7), call
+        if policy.startswith('auto'):
             t = obj._j2_policy_times
             assert t['chosen'] in ('overlap', 'serial', 'fused') and t['overlap'] > 0 and t['serial'] > 0
             assert list(obj._j2_policy_cache.values()) == [t['chosen']]
+            assert not getattr(obj, '_j2_lazy', {})

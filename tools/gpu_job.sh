@@ -217,6 +217,21 @@ r06c)       # r06: the tests the -x stop of the suite did not reach + the all-DM
   for v in 0 1; do f=$(find $O/solve_stats_v$v -name "*kernel_stats.csv" | head -1); echo "== PAMD_SOLVE_V2=$v"; grep -E "cderi_solve|unpack_slab|int3c2e_kernel<3, 3, 4>" $f | cut -c1-220 | head -5; done
   python tools/pmc_table.py $O cderi_solve | tee $O/solve_pmc.txt
   find $O -name "*.db" -delete; find $O -name "*_kernel_trace.csv" -delete ;;
+r06e)       # r06: sub_vmat_sym wave-role flip A/B + the wave-balance model of the plan's ld distribution; host profile of a whole SCF
+  : > $O/xcbench.log
+  for v in "vmatflip=0" "vmatflip=1" "vmatflip=2" "vmatflip=0" "vmatflip=1" "vmatflip=2"; do
+    echo "== $v" >> $O/xcbench.log
+    timeout 400 python tools/xcbench.py --steps 5 --tune-xc $v 2>/dev/null | tail -1 >> $O/xcbench.log
+  done
+  python - <<'PY'
+import json
+for l in open('gpurun_out/r06e/xcbench.log'):
+    if l.startswith('=='): print(l.strip()); continue
+    d=json.loads(l); print('   wall', d['wall_ms_per_call'], d['kernel_ms'], d['executed']['ao_dot_aow'], 'balance model', d.get('vmat_sym_wave_balance_model'))
+print('ld / 16 histogram', d.get('ld_groups_hist'))
+PY
+  for A in "" "--no-image" "" "--no-image"; do timeout 600 python tools/run_scf.py --nwater 32 --xc b3lyp --conv-tol 1e-10 $A 2>&1 | grep -E "df vj|init E|cycle= [12] |converged" | cut -c1-260; done | tee $O/scf_layouts.log
+  timeout 600 python tools/prof_scf.py --max-cycle 4 > $O/prof_scf.log 2>&1; grep -E "^clocks|cycle=|converged" $O/prof_scf.log | head; sed -n '/cumulative/,+45p' $O/prof_scf.log | cut -c1-170 | head -60 ;;
 kfetch)     # r06: kbench argument strings x FETCH_SIZE x ms: gpu_job.sh kfetch "<kbench args 1>" "<kbench args 2>" ...
   : > $O/kbench.log
   i=0

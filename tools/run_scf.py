@@ -17,6 +17,8 @@ ap.add_argument('--dump-orbitals', default='', help='.npz: orbo = C_occ sqrt(occ
 ap.add_argument('--host-loop', action='store_true', help='the numpy SCF loop instead of the HBM-resident one')
 ap.add_argument('--native', action='store_true', help='J/K through the host-array C handle (NativeDF): rows that do not fit HBM are streamed from '
                 'page-locked host memory - e.g. (H2O)_128 cc-pVDZ (560 GB tensor) on ONE GPU')
+ap.add_argument('--layout', default='', help="tensor layout of df.DF: '' (the budget's choice) | packed | square; --no-image: square rows whenever 2x fits")
+ap.add_argument('--no-image', action='store_true')
 ap.add_argument('--devices', default='', help='with --native: comma list of HIP devices for the handle')
 a = ap.parse_args()
 if a.basis is None:
@@ -31,6 +33,10 @@ if a.native:
     print('NativeDF built in %.1f s: layout %s' % (time.perf_counter() - t0, mf.with_df.layout()), flush=True)
 else:
     mf = mf.density_fit()
+    if a.layout:
+        mf.with_df.layout = a.layout
+    if a.no_image:
+        mf.with_df.prefer_image = False
 mf.conv_tol = a.conv_tol
 mf.level_shift = a.level_shift
 mf.max_cycle = a.max_cycle
@@ -38,8 +44,9 @@ if a.host_loop:
     mf.device_scf = False
 t0 = time.perf_counter()
 e = mf.kernel()
-print('converged=%s cycles=%d E=%.10f wall=%.1f s (nao=%d naux=%d)' %
-      (mf.converged, mf.cycles, e, time.perf_counter() - t0, mol.nao, mf.with_df.get_naoaux()), flush=True)
+print('converged=%s cycles=%d E=%.10f wall=%.1f s (nao=%d naux=%d) layout=%s j2=%s' %
+      (mf.converged, mf.cycles, e, time.perf_counter() - t0, mol.nao, mf.with_df.get_naoaux(), getattr(mf.with_df, '_layout', None),
+       getattr(mf.with_df, '_j2_policy_times', None)), flush=True)
 if a.dump_orbitals:
     import numpy as np
     occ = mf.mo_occ > 0

@@ -72,6 +72,28 @@ if ni.sparse:
     npad = (nocc + 15) // 16 * 16
     fl_mo = 2.0 * plan.ncomp * plan.G * float(ldh.sum()) * npad
     fl_vm = 2.0 * plan.G * float((ldh ** 2).sum())
+    # r06: how much of sub_vmat_sym's matrix-pipe time is lost to the uneven split of a piece between the two wave rows / columns
+    # (7 groups = 4 + 3: the 3 x 3 wave idles while the 4 x 4 wave of the same workgroup multiplies): useful / (4 x slowest wave)
+    def _balance(ldh):
+        use = tot = 0.0
+        hist = {}
+        for g in (ldh / 16).astype(int):
+            hist[int(g)] = hist.get(int(g), 0) + 1
+        for g, cnt in hist.items():
+            npc = (g + 7) // 8
+            if npc == 0:
+                continue
+            base, rem = divmod(g, npc)
+            pcs = [base + (1 if i < rem else 0) for i in range(npc)]
+            for i in range(npc):
+                for j in range(i + 1):
+                    ph = 1 if i == j else 2
+                    use += cnt * ph * pcs[i] * pcs[j]
+                    tot += cnt * ph * 4 * ((pcs[i] + 1) // 2) * ((pcs[j] + 1) // 2)
+        return round(use / tot, 4), dict(sorted(hist.items()))
+    eff, hist = _balance(ldh)
+    out['vmat_sym_wave_balance_model'] = eff
+    out['ld_groups_hist'] = hist
     out['vmat_sym'] = bool(ni.vmat_sym)
     out['executed'] = {k: {'TF': round(f * 1e-12, 4), 'ms': round(s[k][0] / a.steps, 2), 'TFs': round(f / (s[k][0] / a.steps) * 1e-9, 1),
                            'frac_of_78.6': round(f / (s[k][0] / a.steps) * 1e-9 / 78.6, 3)}
