@@ -27,6 +27,7 @@ static int g_orb_rho_128 = 1;    // r06: 128-orbital chunks in PAMD_sub_orb_rho 
 static int g_orb_rho_fused = 1;  // GGA: rho / grad rho in the orbital product's epilogue (PAMD_sub_orb_rho); A/B switch "orbrho"
 static int g_vmat_probe = 0;   // benchmarking probes of sub_vmat_sym ("vmatprobe", see the kernel)
 static int g_vmat_burst = 0;   // sub_vmat_sym: DMA rows of the next k-tile in one burst behind the first MFMA group ("vmatburst")
+static int g_vmat_even = 1;    // PAMD_sub_vmat_work: pieces of an even number of 16-column groups ("vmateven"; 0: nearly equal pieces, r04)
 static int g_vmat_flip = 0;    // sub_vmat_sym: which workgroups swap the roles of their waves ("vmatflip", see the kernel)
 static int g_vmat_xcd = 1;     // sub_vmat*: work items of one tile on ONE XCD (its L2 then serves the panel re-reads); A/B switch "vmatxcd"
 
@@ -636,6 +637,7 @@ int PAMD_set_tuning_xc(const char *key, int value)
     if (strcmp(key, "orbrho128") == 0) { g_orb_rho_128 = value; return 0; }
     if (strcmp(key, "vmatxcd") == 0) { g_vmat_xcd = value; return 0; }
     if (strcmp(key, "vmatflip") == 0) { g_vmat_flip = value; return 0; }
+    if (strcmp(key, "vmateven") == 0) { g_vmat_even = value; return 0; }
     if (strcmp(key, "vmatburst") == 0) { g_vmat_burst = value; return 0; }
     if (strcmp(key, "vmatprobe") == 0) { g_vmat_probe = value; return 0; }
     return pamd::set_error(-3, "unknown tuning key", __FILE__, __LINE__);
@@ -789,9 +791,18 @@ long PAMD_sub_vmat_work(const int *ld, int ntile, int *work)
     for (int t : order) {
         const int g = ld[t] / 16, np = (g + 7) / 8;
         if (np == 0) continue;
-        const int base = g / np, rem = g % np;
         std::vector<int> first(np + 1, 0);
-        for (int i = 0; i < np; i++) first[i + 1] = first[i] + base + (i < rem ? 1 : 0);
+        if (g_vmat_even) {
+            // r06: pieces of an EVEN number of groups wherever possible.  A piece is split between two wave rows (columns); an odd
+            // piece (7 = 4 + 3) leaves the workgroup waiting at every k-tile barrier for its 4 x 4 wave while the 3 x 3 wave idles
+            // (model over config 3's plan: useful / (4 x slowest wave) = 0.859 with nearly equal pieces, 0.963 with these).  The
+            // (g + 1) / 2 pairs of groups are dealt nearly equally; an odd g takes its one group off a largest piece (8 -> 7).
+            const int h = (g + 1) / 2, base = h / np, rem = h % np;
+            for (int i = 0; i < np; i++) first[i + 1] = first[i] + 2 * (base + (i < rem ? 1 : 0)) - (i == 0 && (g & 1) ? 1 : 0);
+        } else {
+            const int base = g / np, rem = g % np;
+            for (int i = 0; i < np; i++) first[i + 1] = first[i] + base + (i < rem ? 1 : 0);
+        }
         int qi = 0;
         for (int k = 1; k < nq; k++) if (load[k] < load[qi]) qi = k;
         for (int i = 0; i < np; i++)

@@ -177,7 +177,7 @@ class DF:
                                                                _c.c_void_p(out.data_ptr()), st))
         return out[:b1 - b0]
 
-    def to_packed_layout(self):
+    def to_packed_layout(self, release=True):
         """The consumers that need the packed tensor AND the memory of the square one (analytic gradients: W has the tensor's
         size): pack a copy when both fit, else drop the square rows and rebuild the tensor packed from the integrals."""
         import torch
@@ -191,7 +191,8 @@ class DF:
         if self._packed is not None:
             self._cderi_sq = None
             self._layout = 'packed'
-            torch.cuda.empty_cache()
+            if release:
+                torch.cuda.empty_cache()
             return self
         mol_ok = self.mol is not None and not isinstance(self._cderi, (str, np.ndarray))
         if not mol_ok:
@@ -331,15 +332,20 @@ class DF:
         self._diag_row0 = row0
         return self._cderi_diag, row0
 
-    def drop_square_image(self):
+    def drop_square_image(self, release=False):
         """Give the HBM of the square copy back (the gradient path needs it for W and Z)."""
         import torch
         if self._layout == 'square':
-            self.to_packed_layout()             # the square rows ARE the tensor: pack them (or rebuild packed) first
+            self.to_packed_layout(release)      # the square rows ARE the tensor: pack them (or rebuild packed) first
         self._cderi_sq = None
         self._cderi_diag = None
         self._diag_row0 = 0
-        torch.cuda.empty_cache()
+        # r06: the block stays in torch's caching allocator - W and the Z slabs are carved out of it.  Handing it back to the driver
+        # (empty_cache) and asking again costs a VRAM clear of ~38 ms per GB on this stack (tools/probe/alloc_after_exit.py: 123 GB of
+        # never-used HBM in 0.48 s, the same 123 GB after a free in 4.7 s): the gradient's 61 GB W then took 3.6 s instead of 0.39 s
+        # whenever the driver handed it the pages just released (profiles/r06/grad_h2o32_rhf_dirty_pages.json)
+        if release:
+            torch.cuda.empty_cache()
 
     def _workspace(self, name, shape):
         """Persistent HBM scratch (no per-iteration hipMalloc): returns a view of `shape`."""

@@ -189,8 +189,12 @@ def arg_group_grids(mol, coords, box_size=GROUP_BOX_SIZE):
     box_ids[box_ids < -1] = -1
     for k in range(3):
         box_ids[box_ids[:, k] > boxes[k], k] = boxes[k]
-    rev_idx = np.unique(box_ids, axis=0, return_inverse=True)[1]
-    return rev_idx.ravel().argsort(kind='stable')
+    # the reference ranks the boxes with numpy.unique(box_ids, axis=0) (lexicographic in the three box indices) and sorts the
+    # points stably by that rank (gen_grid.py:386-388).  One scalar key per point that is monotone in the same lexicographic
+    # order gives the SAME permutation from a single stable sort (r06: 0.6 s -> 0.1 s of a config-3 SCF's set-up)
+    n1, n2 = int(boxes[1]) + 2, int(boxes[2]) + 2
+    key = ((box_ids[:, 0] + 1).astype(np.int64) * n1 + (box_ids[:, 1] + 1)) * n2 + (box_ids[:, 2] + 1)
+    return key.argsort(kind='stable')
 
 
 def make_mask(mol, coords, relativity=0, shls_slice=None, cutoff=1e-15, verbose=None):

@@ -142,22 +142,38 @@ class SparsePlan:
         nao, G = self.nao, self.G
         ao0 = sh['ao0'].cpu().numpy()
         nfn = 2 * sh['l'].cpu().numpy() + 1
-        ld = np.zeros(self.nloc, np.int32)
-        idx_list = []
-        for i in range(self.nloc):
-            shells = np.nonzero(active[i])[0]
-            fns = np.concatenate([np.arange(ao0[s], ao0[s] + nfn[s]) for s in shells]) if len(shells) else np.zeros(0, int)
-            l = _round_up(max(len(fns), 1), 16)
-            ld[i] = l
-            row = np.full(l, nao, np.int32)
-            row[:len(fns)] = fns
-            idx_list.append(row)
+        nsh = len(ao0)
+        if nsh and np.array_equal(ao0, np.concatenate([[0], np.cumsum(nfn)[:-1]])):
+            # shells in AO order (always, for this package's Mole): one boolean [tile][function] table instead of a Python loop over
+            # the tiles (r06: 0.23 s -> 0.03 s of the plan at config 3); row-major nonzero() lists a tile's functions ascending,
+            # exactly the concatenation of its active shells' ranges
+            fmask = active[:, np.repeat(np.arange(nsh), nfn)]
+            cnt = fmask.sum(axis=1)
+            ld = (np.maximum(cnt, 1) + 15) // 16 * 16
+            ld = ld.astype(np.int32)
+            off = np.concatenate([[0], np.cumsum(ld)[:-1]]).astype(np.int64) if self.nloc else np.zeros(0, np.int64)
+            idx_all = np.full(int(ld.sum()), nao, np.int32)
+            rows, cols = np.nonzero(fmask)
+            first = np.concatenate([[0], np.cumsum(cnt)[:-1]]) if self.nloc else np.zeros(0, np.int64)
+            idx_all[off[rows] + (np.arange(len(rows)) - first[rows])] = cols
+            self.nsub_host = cnt.astype(np.int64)
+        else:
+            ld = np.zeros(self.nloc, np.int32)
+            idx_list = []
+            for i in range(self.nloc):
+                shells = np.nonzero(active[i])[0]
+                fns = np.concatenate([np.arange(ao0[s], ao0[s] + nfn[s]) for s in shells]) if len(shells) else np.zeros(0, int)
+                l = _round_up(max(len(fns), 1), 16)
+                ld[i] = l
+                row = np.full(l, nao, np.int32)
+                row[:len(fns)] = fns
+                idx_list.append(row)
+            self.nsub_host = np.array([int((r < nao).sum()) for r in idx_list])
+            idx_all = np.concatenate(idx_list) if self.nloc else np.zeros(0, np.int32)
         self.ld_host = ld
-        self.nsub_host = np.array([int((r < nao).sum()) for r in idx_list])
         self.density = float(self.nsub_host.mean() / nao) if self.nloc else 0.0
         self.density2 = float((self.nsub_host.astype(float) ** 2).mean() / nao ** 2) if self.nloc else 0.0
         self.idx_off_host = np.concatenate([[0], np.cumsum(ld)[:-1]]).astype(np.int64) if self.nloc else np.zeros(0, np.int64)
-        idx_all = np.concatenate(idx_list) if self.nloc else np.zeros(0, np.int32)
         self.idx = torch.from_numpy(idx_all).to(self.dev)
         self.ld = torch.from_numpy(ld).to(self.dev)
         self.idx_off = torch.from_numpy(self.idx_off_host).to(self.dev)

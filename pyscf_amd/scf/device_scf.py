@@ -81,7 +81,9 @@ def eligible(mf, callback=None):
     # every other condition holds and the tensor fits: the loop needs it now anyway (a build that still ends out of core - the
     # estimate and the allocator disagreeing by a hair - keeps the host loop)
     if not mf.with_df.has_tensor():
+        t0 = time.perf_counter()
         mf.with_df.build()
+        mf._log('DF tensor: %s layout, built in %.2f s', getattr(mf.with_df, '_layout', None), time.perf_counter() - t0)
     return getattr(mf.with_df, '_native', None) is None
 
 
@@ -309,9 +311,11 @@ def kernel_device(mf, conv_tol=1e-10, conv_tol_grad=None, dm0=None, conv_check=T
     mol = mf.mol
     dev = mf.with_df._device()
     f64 = torch.float64
+    t_1e = time.perf_counter()
     s1e_h = mf.get_ovlp(mol)
     h1e_h = mf.get_hcore(mol)
     dm_h = mf.get_init_guess(mol, mf.init_guess, s1e=s1e_h) if dm0 is None else dm0
+    mf._log('one-electron integrals and initial guess: %.2f s', time.perf_counter() - t_1e)
     # the first Fock build goes through the public host API: the start density may be anything (untagged, any rank)
     t_setup = time.perf_counter()
     vhf_h = mf.get_veff(mol, dm_h)

@@ -35,12 +35,14 @@ def test_sub_vmat_work_list_covers_every_block_pair_once_and_balances_the_xcd_qu
         g = ld[t] // 16
         diag = mine[mine[:, 5] == 1]
         pieces = sorted((int(p0), int(gp)) for p0, gp in diag[:, 1:3])
-        # the pieces tile [0, ld) without gaps, sizes differ by at most one group
+        # the pieces tile [0, ld) without gaps; r06: sizes are even (at most ONE odd piece, for an odd group count) and differ by
+        # at most two groups - an even piece splits evenly between the two wave rows / columns of a workgroup
         pos = 0
         for p0, gp in pieces:
             assert p0 == pos
             pos += gp * 16
-        assert pos == ld[t] and max(gp for _, gp in pieces) - min(gp for _, gp in pieces) <= 1
+        assert pos == ld[t] and max(gp for _, gp in pieces) - min(gp for _, gp in pieces) <= 2
+        assert sum(gp & 1 for _, gp in pieces) == (g & 1)
         npc = len(pieces)
         assert npc == -(-g // 8) and len(mine) == npc * (npc + 1) // 2
         # every pair (i >= j) exactly once, none above the diagonal

@@ -232,6 +232,20 @@ print('ld / 16 histogram', d.get('ld_groups_hist'))
 PY
   for A in "" "--no-image" "" "--no-image"; do timeout 600 python tools/run_scf.py --nwater 32 --xc b3lyp --conv-tol 1e-10 $A 2>&1 | grep -E "df vj|init E|cycle= [12] |converged" | cut -c1-260; done | tee $O/scf_layouts.log
   timeout 600 python tools/prof_scf.py --max-cycle 4 > $O/prof_scf.log 2>&1; grep -E "^clocks|cycle=|converged" $O/prof_scf.log | head; sed -n '/cumulative/,+45p' $O/prof_scf.log | cut -c1-170 | head -60 ;;
+r06f)       # r06: even pieces in the sub_vmat_sym work list (A/B + XC tests); whole-SCF wall, packed / square alternating, with the build clock
+  timeout 900 python -m pytest -q -x -m gpu tests/test_gpu_xc_sparse.py tests/test_gpu_dft.py -k "not fxc" > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+  : > $O/xcbench.log
+  for v in "vmateven=0" "vmateven=1" "vmateven=0" "vmateven=1"; do
+    echo "== $v" >> $O/xcbench.log
+    timeout 400 python tools/xcbench.py --steps 5 --tune-xc $v 2>/dev/null | tail -1 >> $O/xcbench.log
+  done
+  python - <<'PY'
+import json
+for l in open('gpurun_out/r06f/xcbench.log'):
+    if l.startswith('=='): print(l.strip()); continue
+    d=json.loads(l); print('   wall', d['wall_ms_per_call'], 'nelec %.10f exc %.10f' % (d['nelec'], d['exc']), d['kernel_ms'], d['executed']['ao_dot_aow'])
+PY
+  for A in "" "--no-image" "" "--no-image"; do timeout 600 python tools/run_scf.py --nwater 32 --xc b3lyp --conv-tol 1e-10 $A 2>&1 | grep -E "DF tensor|one-electron|setting up|df vj|init E|cycle= [12] |converged" | cut -c1-260; done | tee $O/scf_layouts.log ;;
 kfetch)     # r06: kbench argument strings x FETCH_SIZE x ms: gpu_job.sh kfetch "<kbench args 1>" "<kbench args 2>" ...
   : > $O/kbench.log
   i=0
