@@ -246,6 +246,35 @@ for l in open('gpurun_out/r06f/xcbench.log'):
     d=json.loads(l); print('   wall', d['wall_ms_per_call'], 'nelec %.10f exc %.10f' % (d['nelec'], d['exc']), d['kernel_ms'], d['executed']['ao_dot_aow'])
 PY
   for A in "" "--no-image" "" "--no-image"; do timeout 600 python tools/run_scf.py --nwater 32 --xc b3lyp --conv-tol 1e-10 $A 2>&1 | grep -E "DF tensor|one-electron|setting up|df vj|init E|cycle= [12] |converged" | cut -c1-260; done | tee $O/scf_layouts.log ;;
+r06g)       # r06 (second half): int3c2e classes - LDS bank-conflict share and time per class after the odd unit stride
+  timeout 900 python -m pytest -q -x -m gpu tests/test_gpu_int3c2e.py tests/test_gpu_cabi_kernels.py > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+  ( cd /tmp; B="python $R/tools/build_only.py"
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/build_stats -o b -- $B > $R/$O/build_stats.log 2>&1
+    timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/$O/build_lds -o b -- $B > $R/$O/build_lds.log 2>&1 )
+  python - <<'PY'
+import csv, glob, re, json
+st = glob.glob('gpurun_out/r06g/build_stats/**/*kernel_stats.csv', recursive=True)[0]
+ms = {}
+for r in csv.DictReader(open(st)):
+    m = re.search(r'int3c2e_kernel<(\d+), (\d+), (\d+)', r['Name'])
+    if m: ms['%s,%s|%s' % m.groups()] = (float(r['TotalDurationNs']) * 1e-6, int(r['Calls']))
+pc = glob.glob('gpurun_out/r06g/build_lds/**/*counter_collection.csv', recursive=True)[0]
+agg = {}
+for r in csv.DictReader(open(pc)):
+    m = re.search(r'int3c2e_kernel<(\d+), (\d+), (\d+)', r['Kernel_Name'])
+    if not m: continue
+    d = agg.setdefault('%s,%s|%s' % m.groups(), {})
+    d[r['Counter_Name']] = d.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+out = []
+for k, (t, n) in sorted(ms.items(), key=lambda kv: -kv[1][0]):
+    d = agg.get(k, {})
+    out.append({'kernel': 'int3c2e<%s>' % k, 'launches': n, 'ms': round(t, 2),
+                'lds_bank_conflict_frac': round(d.get('SQ_LDS_BANK_CONFLICT', 0) / max(d.get('SQ_LDS_IDX_ACTIVE', 0), 1), 3)})
+json.dump(out, open('gpurun_out/r06g/pmc_build_path_int3c2e.json', 'w'), indent=0)
+print('total int3c2e ms', round(sum(o['ms'] for o in out), 1))
+for o in out[:22]: print(o)
+PY
+  find $O -name "*.db" -delete; find $O -name "*_kernel_trace.csv" -delete ;;
 kfetch)     # r06: kbench argument strings x FETCH_SIZE x ms: gpu_job.sh kfetch "<kbench args 1>" "<kbench args 2>" ...
   : > $O/kbench.log
   i=0
