@@ -725,6 +725,8 @@ def single_process_main(args):
     (PAMD_df_create_multi via pyscf_amd.df.native.NativeDF(devices=range(N))) - no torch, no torch.distributed, one process.
     A step is one `with_df.get_jk(dm)` with numpy arrays in and out, so `value` here INCLUDES the PCIe transfers of D, the
     orbitals, J and K (the device-resident figure is the default mode's `value`)."""
+    os.environ.setdefault('PAMD_DF_J2_TUNE', 'eager')      # the handle settles its second-J-pass schedule by trial builds in the first (untimed) call
+
     from pyscf_amd import gto, lib
     from pyscf_amd.data import clusters
     from pyscf_amd.df.native import NativeDF

@@ -263,6 +263,8 @@ struct PAMD_df {
     double *d_stage[2] = {nullptr, nullptr};
     int stage_rows = 0;
     std::map<long, int> j2_policy;          // (nset, occupied counts) -> 0 overlap / 1 serial second J pass (PAMD_df_get_jk)
+    struct J2Trial { int calls = 0, n[3] = {0, 0, 0}; double ms[3] = {1e30, 1e30, 1e30}; };
+    std::map<long, J2Trial> j2_trial;       // r06: schedules still being timed on the caller's own calls (PAMD_DF_J2_TUNE != eager)
     std::vector<PAMD_df *> parts;           // multi-device handle: the shards (owned)
     std::vector<PartWorker *> workers;      // multi: one persistent host thread per part
     int peer_ok = 0;                        // multi: partial results reach part 0 by direct peer copies
@@ -1465,6 +1467,34 @@ static int shard_get_jk(PAMD_df *h, const double *dm, const double *orbo, const 
             long key = nset;
             for (int s = 0; s < nset; s++) key = key * 4099 + nocc[s];
             auto it = h->j2_policy.find(key);
+            const char *tune = getenv("PAMD_DF_J2_TUNE");
+            const int ncand = h->square ? 2 : 3;
+            if (it == h->j2_policy.end() && !(tune && tune[0] == 'e')) {
+                // r06, the default: no trial builds - the caller's OWN calls are the trials (as df_jk.get_jk_device, DF.j2_tune =
+                // 'lazy').  First call of a shape: overlap, untimed (work spaces, page-locked buffers); each following call runs the
+                // candidate with the fewest samples under the host clock; after two samples of each the best is kept.  Every
+                // schedule returns the same J and K.  PAMD_DF_J2_TUNE=eager: the seven builds inside the first call (bench.py).
+                PAMD_df::J2Trial &t = h->j2_trial[key];
+                int sched = 0;
+                if (t.calls > 0)
+                    for (int c = 1; c < ncand; c++) if (t.n[c] < t.n[sched]) sched = c;
+                if (t.calls > 0 && t.n[sched] >= 2) {
+                    int best = t.ms[1] < 0.99 * t.ms[0] ? 1 : 0;
+                    if (ncand == 3 && t.ms[2] < 0.99 * t.ms[best]) best = 2;
+                    h->j2_policy.emplace(key, best);
+                    h->j2_trial.erase(key);
+                    return df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, best, download);
+                }
+                const bool timed = t.calls++ > 0;
+                const auto t0 = std::chrono::steady_clock::now();
+                const int rc = df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, sched, download);
+                if (rc == 0 && timed) {
+                    PAMD_df::J2Trial &t2 = h->j2_trial[key];
+                    t2.ms[sched] = std::min(t2.ms[sched], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                    t2.n[sched]++;
+                }
+                return rc;
+            }
             if (it == h->j2_policy.end()) {
                 double ms[3] = {1e30, 1e30, 1e30};
                 // overlap (priming, untimed), then overlap, serial, fused into the SYRK (packed rows only) - r06: the BEST of two runs

@@ -30,6 +30,14 @@ for sched in ('auto', 'overlap', 'serial', 'fused'):
     t0 = time.perf_counter()
     vj, vk = obj.get_jk(dm, hermi=1)
     first = time.perf_counter() - t0
+    if sched == 'auto':
+        # r06: the handle times its schedules on the caller's own calls (one candidate per call, two samples each): 7 more calls settle it
+        settle = []
+        for _ in range(7):
+            t1 = time.perf_counter()
+            obj.get_jk(dm, hermi=1)
+            settle.append(round((time.perf_counter() - t1) * 1e3, 1))
+        print('auto     calls 2-8 (overlap / serial / fused in turn): %s ms' % settle, flush=True)
     t0 = time.perf_counter()
     for _ in range(3):
         vj, vk = obj.get_jk(dm, hermi=1)
