@@ -182,3 +182,51 @@ def test_kohn_sham_density_fit_tells_the_tensor_about_the_xc_image():
     assert ks.with_df.xc_image_hint > 0
     ku = dft.UKS(mol, xc='b3lyp').density_fit(devices=[0])
     assert ku.with_df.xc_image_hint > 0          # the host-array handle object carries it into PAMD_df_options.reserve_bytes
+
+
+def test_grid_box_sort_is_the_reference_permutation():
+    """gen_grid.arg_group_grids: one stable sort of a scalar key = the reference's numpy.unique(box_ids, axis=0) ranks + stable argsort
+    (pyscf/dft/gen_grid.py:369-388), point for point."""
+    from pyscf_amd import gto
+    from pyscf_amd.dft import gen_grid
+    mol = gto.M(atom='O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587; O 4.1 0.3 -2.2; H 4.1 1.1 -1.7; H 3.4 0.4 -2.8', basis='sto-3g')
+    rng = np.random.default_rng(3)
+    coords = rng.uniform(-14.0, 14.0, size=(20000, 3))             # some far outside the padded molecular box: clipped box ids
+    got = gen_grid.arg_group_grids(mol, coords)
+    ac = mol.atom_coords()
+    lo, hi = ac.min(axis=0) - gen_grid.GROUP_BOUNDARY_PENALTY, ac.max(axis=0) + gen_grid.GROUP_BOUNDARY_PENALTY
+    boxes = ((hi - lo) * (1. / gen_grid.GROUP_BOX_SIZE)).round().astype(int)
+    box_ids = np.floor((coords - lo) * (1. / ((hi - lo) / boxes))).astype(int)
+    box_ids[box_ids < -1] = -1
+    for k in range(3):
+        box_ids[box_ids[:, k] > boxes[k], k] = boxes[k]
+    want = np.unique(box_ids, axis=0, return_inverse=True)[1].ravel().argsort(kind='stable')
+    assert np.array_equal(got, want)
+
+
+def test_sparse_plan_tables_vectorised_equal_the_per_tile_loop():
+    """dft/sparse_grid._tables: ld / idx / nsub from one boolean [tile][function] table = the per-tile concatenation of the active
+    shells' function ranges (padding columns = nao, ld rounded up to 16, an empty tile keeps 16 columns)."""
+    from pyscf_amd.dft import sparse_grid
+    rng = np.random.default_rng(5)
+    nsh, nloc = 37, 61
+    l = rng.integers(0, 4, size=nsh)
+    nfn = 2 * l + 1
+    ao0 = np.concatenate([[0], np.cumsum(nfn)[:-1]])
+    nao = int(nfn.sum())
+    active = rng.random((nloc, nsh)) < 0.35
+    active[7] = False
+    plan = sparse_grid.SparsePlan.__new__(sparse_grid.SparsePlan)
+    plan.nloc, plan.nao, plan.G, plan.dev = nloc, nao, 512, torch.device('cpu')
+    plan._tables({'ao0': torch.from_numpy(ao0), 'l': torch.from_numpy(l)}, active)
+    ld, rows = [], []
+    for i in range(nloc):
+        fns = np.concatenate([np.arange(ao0[s], ao0[s] + nfn[s]) for s in np.nonzero(active[i])[0]] + [np.zeros(0, int)])
+        n = (max(len(fns), 1) + 15) // 16 * 16
+        row = np.full(n, nao, np.int32)
+        row[:len(fns)] = fns
+        ld.append(n)
+        rows.append(row)
+    assert np.array_equal(plan.ld_host, np.array(ld)) and np.array_equal(plan.idx.numpy(), np.concatenate(rows))
+    assert np.array_equal(plan.nsub_host, np.array([(r < nao).sum() for r in rows]))
+    assert np.array_equal(plan.idx_off_host, np.concatenate([[0], np.cumsum(ld)[:-1]]))
