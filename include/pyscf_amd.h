@@ -198,6 +198,10 @@ int PAMD_nr_e2_symm(const double *d_cderi, long npair, int nL, int nao, const do
                     void *stream);
 long PAMD_nr_e2_rho_worksize(int nL, int ldx, int nocc_pad);             /* doubles of d_rho_work */
 int  PAMD_e2_orb_ld(int nocc_pad);                                       /* ldo that lets every half-transform kernel tile nocc_pad columns */
+/* r06: tile shape and k splits of the K = X^T X product that follows the half transform (lib.dot(buf1.T, buf1), pyscf/df/df_jk.py:367,380)
+ * - the one rule both host layers use.  flags_in < 0 / nsplit_in <= 0: defaults; reserve: workgroup slots left to a co-running pass. */
+int  PAMD_syrk_item_count(int nao);                                      /* work items of the re-tiled triangle, 0 = 128 x 128 tiles */
+int  PAMD_syrk_plan(int nao, int reserve, int flags_in, int nsplit_in, int *flags_out, int *nsplit_out);
 /* packed-operand transform with the diagonal-block side image d_diag[nL][ceil(ldx/128)][128][128] of the same aux rows
  * (both triangles of the 128 x 128 blocks on the diagonal of every B_L, 0 beyond nao; 14 % of the packed size at nao 1856):
  * the k-tiles that cross the diagonal are then read once, unmasked - what AO2MOtranse2_nr_s2's per-row NPdunpack_tril

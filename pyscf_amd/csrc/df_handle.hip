@@ -1176,19 +1176,11 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
         d_vk = h->workspace("vk", (size_t)nset * n2, &rc);
         if (rc) return rc;
         PAMD_CHECK_HIP(hipMemsetAsync(d_vk, 0, (size_t)nset * n2 * 8, st));
-        // df_jk.syrk_plan: re-tiled triangle + balanced k split when the matrix has an odd number of 64-column blocks
-        const int nb64 = (nao + 63) / 64;
-        // beside a co-running J pass 2 the balanced schedule leaves SYRK_RESERVE of the 512 workgroup slots to the pass (df_jk._vk_mo)
+        // tile shape and k splits of K = X^T X: PAMD_syrk_plan, the one rule of both orchestrations (r06).  Beside a co-running J pass 2
+        // the balanced schedule leaves SYRK_RESERVE of the 512 workgroup slots to the pass (flag bits 8-15 of PAMD_dgemm_tn)
         const int reserve = (fused && serial_j2 == 0) ? SYRK_RESERVE : 0;
-        if (orbo && nb64 % 2 == 1 && nb64 >= 5) {
-            const int ntl = nb64 / 2, units = ntl * (ntl - 1) / 2 + ntl + (ntl + 2) / 3;
-            double best = 0;
-            int bn = 0;
-            for (int n = 1; n < 8; n++)
-                for (int m = 1; m < 9; m++)
-                    if (units * n + (units + m - 1) / m <= 512 - reserve && n + 1.0 / m > best) { best = n + 1.0 / m; bn = n; }
-            if (bn && units >= 32) { nsplit = bn + 1; syrk_flags = 1 | 2 | 4 | 8 | ((reserve / 4) << 8); }
-        }
+        if ((rc = PAMD_syrk_plan(nao, reserve, orbo ? -1 : 0, 0, &syrk_flags, &nsplit))) return rc;
+        if (reserve && (syrk_flags & 4)) syrk_flags |= (reserve / 4) << 8;
         d_part = h->workspace("kpart", (size_t)nset * nsplit * n2, &rc);
         if (rc) return rc;
         PAMD_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nset * nsplit * n2 * 8, st));

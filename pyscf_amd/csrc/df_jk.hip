@@ -2009,6 +2009,44 @@ static bool v2_wide(int nocc_pad, int *nchunk, int *wm, double *waste)
 // padded MFMA work a v2 kernel may spend before the exact-tile kernels (lower matrix-pipe efficiency) are the better choice
 static const double V2_WASTE_SQUARE = 0.13, V2_WASTE_PACKED = 0.30;
 
+// r06 (first step): the ONE copy of the K = X^T X plan - tile shape and k splits.  Both orchestrations call it
+// (df_jk.syrk_plan of the Python layer, df_get_jk_impl of the C handle); before, each carried its own transcription of the rule
+// and the two had already drifted apart for small matrices with an odd block count.
+//   flags_in < 0: the default - the RE-TILED triangle (flag 8: work items of four live 64 x 64 wave blocks) with the BALANCED k
+//   split (flag 4) when the matrix has an odd number >= 5 of 64-column blocks, else 128 x 128 tiles; nsplit_in > 0 wins.
+//   Balanced split: n full pieces + one 1/m-length remainder piece per work item such that units (n + ceil(1/m)) fits the 512
+//   workgroup slots minus `reserve` (slots left to a co-running second J pass); needs >= 32 work items, else 4 uniform splits.
+// Returns flags (bit 0 lower triangle, bit 1 LDS-DMA operands always set) and the number of partial-sum slabs.
+int PAMD_syrk_item_count(int nao)
+{
+    const int nb = ceil_div(nao, 64);
+    if (nb % 2 == 0 || nb < 5) return 0;
+    const int nt = nb / 2;
+    return nt * (nt - 1) / 2 + nt + ceil_div(nt, 3);
+}
+
+int PAMD_syrk_plan(int nao, int reserve, int flags_in, int nsplit_in, int *flags_out, int *nsplit_out)
+{
+    PAMD_REQUIRE(flags_out && nsplit_out && nao > 0, "PAMD_syrk_plan: arguments");
+    const int items = PAMD_syrk_item_count(nao);
+    const int flags = flags_in < 0 ? (items ? 12 : 0) : flags_in;
+    const int base = 1 | 2 | flags;
+    if (nsplit_in > 0) { *flags_out = base; *nsplit_out = nsplit_in; return 0; }
+    if (flags & 4) {
+        const int nt = ceil_div(nao, 128);
+        const int units = ((flags & 8) && items) ? items : nt * (nt + 1) / 2;
+        double best = 0;
+        int bn = 0;
+        for (int n = 1; n < 8; n++)
+            for (int m = 1; m < 9; m++)
+                if (units * n + ceil_div(units, m) <= 512 - reserve && n + 1.0 / m > best) { best = n + 1.0 / m; bn = n; }
+        if (bn && units >= 32) { *flags_out = base; *nsplit_out = bn + 1; return 0; }
+    }
+    *flags_out = base & ~4;
+    *nsplit_out = 4;
+    return 0;
+}
+
 // Leading dimension (columns, zero beyond the orbitals) the half-transform kernels want for nocc_pad orbital columns: whole
 // chunks of the exact-tile kernels, of the uniform v2 tilings and - r04 - of the 128-column chunks with a wide last chunk.
 int PAMD_e2_orb_ld(int nocc_pad)

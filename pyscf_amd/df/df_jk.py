@@ -182,17 +182,14 @@ def _rho_work(dfobj, lib, nb, ldx, nocc_pad):
 
 
 def syrk_items(nao):
-    """Work items of the re-tiled SYRK triangle (csrc/df_jk.hip::syrk_items): 0 when the 2 x 2 tiling is kept (even number of
-    64-column blocks, small matrices)."""
-    nb = -(-nao // 64)
-    if nb % 2 == 0 or nb < 5:
-        return 0
-    nt = nb // 2
-    return nt * (nt - 1) // 2 + nt + -(-nt // 3)
+    """Work items of the re-tiled SYRK triangle (PAMD_syrk_item_count): 0 when the 2 x 2 tiling is kept (even number of 64-column
+    blocks, small matrices)."""
+    return int(_lib_mod.load_library().PAMD_syrk_item_count(_c.c_int(int(nao))))
 
 
 def syrk_plan(nao, nsplit=None, flags=None, reserve=0):
-    """(flags, nsplit) of the K = X^T X product (flag 1: lower triangle, flag 2: LDS-DMA operands).
+    """(flags, nsplit) of the K = X^T X product (flag 1: lower triangle, flag 2: LDS-DMA operands) - r06: from the library's
+    PAMD_syrk_plan, the ONE copy of the rule (the C handle calls the same function; the Python transcription is gone).
 
     Default when the matrix has an odd number of 64-column blocks (nao = 1856: 29): the RE-TILED triangle (flag 8,
     syrk_slots_kernel: work items of four live 64 x 64 wave blocks, 110 items instead of 120 tiles with 45 dead wave blocks)
@@ -201,23 +198,10 @@ def syrk_plan(nao, nsplit=None, flags=None, reserve=0):
     splits instead of 4.  Measured (profiles/r03/kbench_syrk_variants.log, K only): uniform 39.7 ms, balanced alone 41.2, re-tiled
     alone 39.6, both 35.4.  Otherwise 128 x 128 tiles and 4 uniform splits (120 x 4 = 480 slots, one round).  Earlier variants
     that lost (profiles/r02): 17 uniform splits (46.4 vs 44.0 ms), 160 x 128 tiles x 5 splits (42.0 vs 41.6), stream-K (41.5 vs 39.6)."""
-    base = 1 | 2
-    if flags is None:
-        flags = 12 if syrk_items(nao) else 0
-    base |= flags
-    if nsplit:
-        return base, nsplit
-    if flags & 4:
-        nt = -(-nao // 128)
-        units = syrk_items(nao) if (flags & 8) and syrk_items(nao) else nt * (nt + 1) // 2
-        best = None
-        for n in range(1, 8):
-            for m in range(1, 9):
-                if units * n + -(-units // m) <= 512 - reserve and (best is None or n + 1.0 / m > best[0]):
-                    best = (n + 1.0 / m, n)
-        if best is not None and units >= 32:
-            return base, best[1] + 1
-    return base & ~4, 4
+    f, n = _c.c_int(), _c.c_int()
+    _lib_mod.check(_lib_mod.load_library().PAMD_syrk_plan(_c.c_int(int(nao)), _c.c_int(int(reserve)), _c.c_int(-1 if flags is None else int(flags)),
+                                                          _c.c_int(int(nsplit or 0)), _c.byref(f), _c.byref(n)))
+    return f.value, n.value
 
 
 def orbital_ld(nocc_pad):

@@ -44,6 +44,34 @@ def test_syrk_plan_and_items():
     assert 110 * 4 + -(-110 // 2) <= 512 < 110 * 4 + 110
     assert syrk_plan(1856, None, 0) == (3, 4) and syrk_plan(464) == (3, 4)
     assert syrk_plan(1856, 7)[1] == 7                                  # explicit split count wins
+    # r06: the rule lives in the library (PAMD_syrk_plan) - the Python layer and the C handle call the same function.  The old
+    # Python transcription, kept here as the checker, over shapes and reserves
+    def old_plan(nao, nsplit=None, flags=None, reserve=0):
+        nb = -(-nao // 64)
+        nt2 = nb // 2
+        items = 0 if (nb % 2 == 0 or nb < 5) else nt2 * (nt2 - 1) // 2 + nt2 + -(-nt2 // 3)
+        base = 1 | 2
+        if flags is None:
+            flags = 12 if items else 0
+        base |= flags
+        if nsplit:
+            return base, nsplit
+        if flags & 4:
+            nt = -(-nao // 128)
+            units = items if (flags & 8) and items else nt * (nt + 1) // 2
+            best = None
+            for n in range(1, 8):
+                for m in range(1, 9):
+                    if units * n + -(-units // m) <= 512 - reserve and (best is None or n + 1.0 / m > best[0]):
+                        best = (n + 1.0 / m, n)
+            if best is not None and units >= 32:
+                return base, best[1] + 1
+        return base & ~4, 4
+    for nao in (61, 130, 257, 320, 700, 1856, 2228, 2496, 3072, 4000):
+        for reserve in (0, 16, 48):
+            for flags in (None, 0, 4, 12):
+                assert syrk_plan(nao, None, flags, reserve) == old_plan(nao, None, flags, reserve), (nao, reserve, flags)
+        assert syrk_plan(nao, 3, None, 0) == old_plan(nao, 3, None, 0)
 
 
 def test_collective_switch():
