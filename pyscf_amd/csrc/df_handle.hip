@@ -1193,12 +1193,8 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
             op += (size_t)nao * o.no;
             if (o.no == 0) continue;
             o.nocc_pad = (int)round_up(o.no, 16);
-            long ldo = o.nocc_pad > 160 ? round_up(o.nocc_pad, 160) : o.nocc_pad;       // df_jk.pad_orbitals
-            const int mt = o.nocc_pad / 16, nchunk = (mt + 9) / 10;
-            ldo = std::max<long>(ldo, (long)nchunk * (((mt + nchunk - 1) / nchunk + 1) / 2) * 32);
-            ldo = std::max<long>(ldo, std::min(round_up(o.nocc_pad, 160), round_up(o.nocc_pad, 128)));
-            ldo = std::max<long>(ldo, PAMD_e2_orb_ld(o.nocc_pad));
-            o.ldo = ldo;
+            const long ldo = PAMD_e2_orb_ld(o.nocc_pad);       // the library's one rule (df_jk.pad_orbitals asks the same function; r06: the
+            o.ldo = ldo;                                         // handle's own transcription of its first three terms is gone)
             // padded image in the handle's page-locked staging area (all sets side by side; the call ends with a stream
             // synchronisation, so the area is free again at the next call): no per-call allocation, no extra synchronisation
             const size_t olen = (size_t)rows * ldo;
