@@ -200,6 +200,8 @@ long PAMD_nr_e2_rho_worksize(int nL, int ldx, int nocc_pad);             /* doub
 int  PAMD_e2_orb_ld(int nocc_pad);                                       /* ldo that lets every half-transform kernel tile nocc_pad columns */
 /* r06: tile shape and k splits of the K = X^T X product that follows the half transform (lib.dot(buf1.T, buf1), pyscf/df/df_jk.py:367,380)
  * - the one rule both host layers use.  flags_in < 0 / nsplit_in <= 0: defaults; reserve: workgroup slots left to a co-running pass. */
+long PAMD_k_block_rows(long naux, int rows_per_aux, int ldx, long long budget_bytes);   /* aux rows per X block (`blksize`, df_jk.py:359-360), equal blocks */
+int  PAMD_j2_schedule_pick(const double *ms, int ncand);                  /* 0 overlap / 1 serial / 2 fused from the candidates' best times (1 % margin) */
 int  PAMD_syrk_item_count(int nao);                                      /* work items of the re-tiled triangle, 0 = 128 x 128 tiles */
 int  PAMD_syrk_plan(int nao, int reserve, int flags_in, int nsplit_in, int *flags_out, int *nsplit_out);
 /* packed-operand transform with the diagonal-block side image d_diag[nL][ceil(ldx/128)][128][128] of the same aux rows
@@ -408,6 +410,9 @@ int PAMD_df_create_ex(const int *atm, int natm, const int *bas, int nbas_ao, int
                       const PAMD_df_options *opt, PAMD_df **out);
 int PAMD_df_create_multi(const int *atm, int natm, const int *bas, int nbas_ao, int nbas_aux, const double *env, int nenv,
                          double lindep, const int *devices, int ndev, PAMD_df **out);
+/* The tag probe of a density that carries its orbitals (lib.tag_array, pyscf/scf/hf.py:855-868; the reference trusts the tag,
+ * "#TODO: test whether dm.mo_coeff matching dm", pyscf/df/df_jk.py:340): max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) on host arrays. */
+int PAMD_dm_orbital_mismatch(const double *dm, const double *orbo, const int *nocc, int nset, int nao, double *out);
 /* r05 - a handle over tensor rows the caller already holds: `DF._cderi` given as an array or as PySCF's own HDF5 file
  * (pyscf/df/df.py:153-155; dataset 'j3c', outcore.py:217-221; read back block by block in DF.loop, df.py:214-242).
  * rows[nrows][nao (nao + 1) / 2] f64 in HOST memory (a numpy array or an mmap of the contiguous dataset); what fits the device is

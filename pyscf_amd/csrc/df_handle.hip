@@ -1277,10 +1277,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                 // ---- MO branch: X_L = B_L C~, K += X^T X (df_jk.py:353-380)
                 const OrbSet &o = orbs[s];
                 if (o.no == 0) continue;
-                long blk = std::max<long>(1, (long)(budget / ((size_t)o.nocc_pad * ldx * 8)));
-                blk = std::min<long>(blk, sg.n);
-                const long nblk = (sg.n + blk - 1) / blk;
-                blk = (sg.n + nblk - 1) / nblk;
+                const long blk = PAMD_k_block_rows(sg.n, o.nocc_pad, ldx, (long long)budget);      // (df_jk._k_blocksize asks the same function)
                 // rows per aux index in X = the orbitals themselves (no padding to 16): the SYRK contracts nb * no rows, padded with
                 // zero rows to a whole k-tile at the END of the block only
                 const int xr = o.no;
@@ -1467,8 +1464,7 @@ static int shard_get_jk(PAMD_df *h, const double *dm, const double *orbo, const 
                 if (t.calls > 0)
                     for (int c = 1; c < ncand; c++) if (t.n[c] < t.n[sched]) sched = c;
                 if (t.calls > 0 && t.n[sched] >= 2) {
-                    int best = t.ms[1] < 0.99 * t.ms[0] ? 1 : 0;
-                    if (ncand == 3 && t.ms[2] < 0.99 * t.ms[best]) best = 2;
+                    const int best = PAMD_j2_schedule_pick(t.ms, ncand);
                     h->j2_policy.emplace(key, best);
                     h->j2_trial.erase(key);
                     return df_get_jk_impl(h, dm, orbo, nocc, nset, nao, hermi, with_j, with_k, flags, vj, vk, best, download);
@@ -1494,8 +1490,7 @@ static int shard_get_jk(PAMD_df *h, const double *dm, const double *orbo, const 
                     if (rc) return rc;
                     if (trial) ms[sched] = std::min(ms[sched], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                 }
-                int best = ms[1] < 0.99 * ms[0] ? 1 : 0;
-                if (!h->square && ms[2] < 0.99 * ms[best]) best = 2;
+                const int best = PAMD_j2_schedule_pick(ms, ncand);
                 it = h->j2_policy.emplace(key, best).first;
             }
             serial = it->second;
@@ -2071,6 +2066,16 @@ double PAMD_df_last_mismatch(const PAMD_df *h) { return h ? h->last_mismatch : 0
 // 0 for the host bounce or a single device; then per part p: out[3 + 5p] = host ms of the shard's contraction (kernels +
 // synchronisation), out[4 + 5p] = host ms of laying out and pushing [J~ | K] into part 0's gather buffer, out[5 + 5p] = bytes that
 // crossed devices, out[6 + 5p] / out[7 + 5p] = HIP-event ms of the half-transform / SYRK launches (MO branch) on their stream.
+// max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) on HOST arrays for one fixed pseudo-random vector: the tag probe of BOTH host layers
+// (r06: pyscf_amd.lib.dm_orbital_mismatch calls this; PAMD_df_get_jk runs the same loops beside its queued kernels, flags bit 1).
+// dm [nset][nao][nao]; orbo: the nset blocks [nao][nocc[s]] one after the other.
+int PAMD_dm_orbital_mismatch(const double *dm, const double *orbo, const int *nocc, int nset, int nao, double *out)
+{
+    PAMD_REQUIRE(dm && orbo && nocc && out && nset > 0 && nao > 0, "PAMD_dm_orbital_mismatch: arguments");
+    *out = host_dm_mismatch(dm, orbo, nocc, nset, nao);
+    return 0;
+}
+
 int PAMD_df_last_timing(const PAMD_df *h, double *out, int nout)
 {
     PAMD_REQUIRE(h && out, "PAMD_df_last_timing: null argument");

@@ -2047,6 +2047,30 @@ int PAMD_syrk_plan(int nao, int reserve, int flags_in, int nsplit_in, int *flags
     return 0;
 }
 
+// Which schedule of the second J pass to keep, from the best time of each candidate (ms[0] overlap: side stream beside the SYRK,
+// ms[1] serial: in line before the re-tiled SYRK, ms[2] fused: inside the SYRK kernel; ncand = 2 without the last): a challenger
+// must win by 1 % (the trials are noisy at that level and 'overlap' is the schedule the kernels were tuned beside).  One rule for
+// df_jk.get_jk_device's trials and the C handle's (r06).
+int PAMD_j2_schedule_pick(const double *ms, int ncand)
+{
+    if (!ms || ncand < 2) return 0;
+    int best = ms[1] < 0.99 * ms[0] ? 1 : 0;
+    if (ncand > 2 && ms[2] < 0.99 * ms[best]) best = 2;
+    return best;
+}
+
+// Aux rows per half-transform block of the MO branch: the X block ([blk][rows_per_aux][ldx] doubles) sized against `budget_bytes`
+// of HBM like the reference's `blksize` against max_memory (pyscf/df/df_jk.py:359-360), then EQUAL blocks (each block's second J
+// pass hides behind one SYRK).  The one rule of both host layers (r06).
+long PAMD_k_block_rows(long naux, int rows_per_aux, int ldx, long long budget_bytes)
+{
+    const long n = naux > 1 ? naux : 1;
+    long blk = (long)(budget_bytes / ((long long)(rows_per_aux > 0 ? rows_per_aux : 1) * (ldx > 0 ? ldx : 1) * 8));
+    blk = blk < 1 ? 1 : (blk > n ? n : blk);
+    const long nblk = (n + blk - 1) / blk;
+    return (n + nblk - 1) / nblk;
+}
+
 // Leading dimension (columns, zero beyond the orbitals) the half-transform kernels want for nocc_pad orbital columns: whole
 // chunks of the exact-tile kernels, of the uniform v2 tilings and - r04 - of the 128-column chunks with a wide last chunk.
 int PAMD_e2_orb_ld(int nocc_pad)

@@ -168,11 +168,9 @@ def _vj(dfobj, lib, dms_dev, nset, nao):
 def _k_blocksize(dfobj, naux, rows, ldx):
     """aux rows per half-transform block: X block (blk*rows*ldx*8 B) sized from max_memory
     like the reference's `blksize` (df_jk.py:359-360), but against HBM (default 16 GB)."""
-    budget = dfobj.k_block_bytes
-    blk = max(1, int(budget // (rows * ldx * 8)))
-    blk = min(blk, max(naux, 1))
-    nblk = -(-max(naux, 1) // blk)
-    return -(-max(naux, 1) // nblk)          # equal blocks (the J passes are hidden behind one SYRK each)
+    so = _lib_mod.load_library()             # r06: the library's rule (PAMD_k_block_rows; the C handle asks the same function)
+    so.PAMD_k_block_rows.restype = _c.c_long
+    return int(so.PAMD_k_block_rows(_c.c_long(int(naux)), _c.c_int(int(rows)), _c.c_int(int(ldx)), _c.c_longlong(int(dfobj.k_block_bytes))))
 
 
 def _rho_work(dfobj, lib, nb, ldx, nocc_pad):
@@ -656,9 +654,9 @@ def get_jk_device(dfobj, dms_dev, orb_list=None, with_j=True, with_k=True, dm_fr
                         cands = ('overlap', 'serial') + (('fused',) if getattr(dfobj, 'j2_try_fused', False) and not square_layout else ())
 
                         def decide(times):
-                            pol = 'serial' if times['serial'] < 0.99 * times['overlap'] else 'overlap'
-                            if 'fused' in times and times['fused'] < 0.99 * times[pol]:
-                                pol = 'fused'
+                            order = ('overlap', 'serial', 'fused')[:len(times)]          # the library's rule (PAMD_j2_schedule_pick: the C
+                            ms = (_c.c_double * 3)(*[times[n] for n in order])             # handle's trials end in the same function)
+                            pol = order[lib.PAMD_j2_schedule_pick(ms, _c.c_int(len(order)))]
                             cache[key] = pol
                             dfobj._j2_policy_times = dict(times, chosen=pol)
                             return pol

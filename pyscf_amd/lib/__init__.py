@@ -113,13 +113,17 @@ def dm_orbital_mismatch(dms, blocks):
     """max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) for one fixed pseudo-random vector, on the FULL matrices (r06, ADVICE r05:
     the r05 probe of every 16th row missed sparse in-place edits such as dm[1, 2] += h of a finite-difference Fock; the reference
     always builds J from the matrix, pyscf/df/df_jk.py:367).  ~0 when every density equals its orbitals' outer product."""
+    import ctypes as _c
     nao = dms.shape[-1]
-    v = np.random.RandomState(20240601).random_sample(nao) - 0.5
-    worst = 0.0
-    for k in range(len(dms)):
-        dv = bounded_matvec(dms[k], v)
-        worst = max(worst, float(np.abs(dv - blocks[k].dot(blocks[k].T.dot(v))).max() / max(1.0, np.abs(dv).max())))
-    return worst
+    d = np.ascontiguousarray(dms, dtype=np.float64).reshape(-1, nao, nao)
+    nocc = np.array([b.shape[1] for b in blocks], dtype=np.int32)
+    orbo = np.concatenate([np.ascontiguousarray(b, dtype=np.float64).reshape(-1) for b in blocks]) if len(blocks) else np.zeros(0)
+    out = _c.c_double()
+    # r06: ONE probe for both host layers - the library's own loops (PAMD_dm_orbital_mismatch; PAMD_df_get_jk runs the same function
+    # beside its queued kernels).  Plain C on the calling thread: no BLAS pool to resize on a 256-thread host
+    check(load_library().PAMD_dm_orbital_mismatch(d.ctypes.data_as(_c.c_void_p), orbo.ctypes.data_as(_c.c_void_p),
+                                                  nocc.ctypes.data_as(_c.c_void_p), _c.c_int(len(d)), _c.c_int(nao), _c.byref(out)))
+    return float(out.value)
 
 
 def _alloc_pinned_torch(nbytes):

@@ -230,3 +230,29 @@ def test_sparse_plan_tables_vectorised_equal_the_per_tile_loop():
     assert np.array_equal(plan.ld_host, np.array(ld)) and np.array_equal(plan.idx.numpy(), np.concatenate(rows))
     assert np.array_equal(plan.nsub_host, np.array([(r < nao).sum() for r in rows]))
     assert np.array_equal(plan.idx_off_host, np.concatenate([[0], np.cumsum(ld)[:-1]]))
+
+
+def test_library_rules_shared_by_both_host_layers():
+    """r06 (first steps): the K-block size, the SYRK plan and the J2 schedule decision are library functions
+    that df_jk (torch layer) and df_handle.hip (C handle) both call - here against the formulas they replaced."""
+    import itertools
+    from pyscf_amd import lib
+    so = lib.load_library()
+    so.PAMD_k_block_rows.restype = ctypes.c_long
+
+    def old_blk(naux, rows, ldx, budget):
+        blk = max(1, int(budget // (rows * ldx * 8)))
+        blk = min(blk, max(naux, 1))
+        nblk = -(-max(naux, 1) // blk)
+        return -(-max(naux, 1) // nblk)
+    for naux, rows, ldx, b in itertools.product((0, 1, 17, 556, 4448, 5598, 14848), (16, 160, 240, 640), (64, 1856, 2240, 3072),
+                                                (1 << 20, 4 << 30, 12 << 30)):
+        got = so.PAMD_k_block_rows(ctypes.c_long(naux), ctypes.c_int(rows), ctypes.c_int(ldx), ctypes.c_longlong(b))
+        assert got == old_blk(naux, rows, ldx, b), (naux, rows, ldx, b)
+
+    def pick(*ms):
+        return so.PAMD_j2_schedule_pick((ctypes.c_double * 3)(*ms), ctypes.c_int(len(ms)))
+    assert pick(108.0, 112.0, 107.5) == 0          # neither challenger wins by 1 %
+    assert pick(108.0, 106.0) == 1 and pick(108.0, 106.0, 106.5) == 1
+    assert pick(108.0, 112.0, 106.0) == 2 and pick(108.0, 105.0, 103.0) == 2
+    assert pick(300.0, 290.0, 289.0) == 1          # fused must beat the CURRENT best by 1 %, not the first candidate
