@@ -202,6 +202,7 @@ int  PAMD_e2_orb_ld(int nocc_pad);                                       /* ldo 
  * - the one rule both host layers use.  flags_in < 0 / nsplit_in <= 0: defaults; reserve: workgroup slots left to a co-running pass. */
 long PAMD_k_block_rows(long naux, int rows_per_aux, int ldx, long long budget_bytes);   /* aux rows per X block (`blksize`, df_jk.py:359-360), equal blocks */
 int  PAMD_j2_schedule_pick(const double *ms, int ncand);                  /* 0 overlap / 1 serial / 2 fused from the candidates' best times (1 % margin) */
+int  PAMD_df_layout_pick(long long need_packed_image, long long need_square_build, long long need_square_after, long long free_bytes, int prefer_image);   /* 2 packed + full image / 1 square rows / 0 packed */
 int  PAMD_syrk_item_count(int nao);                                      /* work items of the re-tiled triangle, 0 = 128 x 128 tiles */
 int  PAMD_syrk_plan(int nao, int reserve, int flags_in, int nsplit_in, int *flags_out, int *nsplit_out);
 /* packed-operand transform with the diagonal-block side image d_diag[nL][ceil(ldx/128)][128][128] of the same aux rows

@@ -872,13 +872,15 @@ int build_rows(PAMD_df *h, const Engine &e, DevPool &tmp, const Metric &m, size_
         const size_t slab12 = std::min<size_t>(12ul << 30, slab_bytes);
         const size_t out_b = std::min<size_t>(slab12, (size_t)((double)slab12 * std::max(nL, 1) / std::max(naux, 1)) + (1ul << 20));
         const size_t after = sq_b + (12ul << 30) + (4ul << 30) + reserve;
-        bool want = nL > 0 && h->nao >= 128 && sq_b + npass * slab12 + out_b + margin <= cap && after <= cap;
-        // ... but packed rows + a FULL image are preferred while all three copies fit the budget (48 GB + reserve stay free after
-        // the image, build_square_image): beside the co-running SYRK the packed second J pass costs less than the square one
-        // (measured, profiles/r06/README.md).  The square layout is for the tensors whose 3x does not fit (taxol on one GPU).
+        // packed rows + a FULL image are preferred while all three copies fit the budget (48 GB + reserve stay free after the image,
+        // build_square_image): beside the co-running SYRK the packed second J pass costs less than the square one (measured,
+        // profiles/r06/README.md).  The square layout is for the tensors whose 3x does not fit (taxol on one GPU).  The order of
+        // preference is the library's (PAMD_df_layout_pick, shared with df.DF._choose_layout); the byte counts are this layer's.
         const char *pref = getenv("PAMD_DF_PREFER_IMAGE");
-        if (!(pref && pref[0] == '0') && tensor_b + npass * slab_bytes + margin <= cap && tensor_b + sq_b + (48ul << 30) + reserve + margin <= cap)
-            want = false;
+        const bool sq_ok = nL > 0 && h->nao >= 128;
+        const long long need_pi = tensor_b + npass * slab_bytes + margin <= cap ? (long long)(tensor_b + sq_b + (48ul << 30) + reserve + margin) : 0;
+        bool want = PAMD_df_layout_pick(need_pi, sq_ok ? (long long)(sq_b + npass * slab12 + out_b + margin) : 0, (long long)after, (long long)cap,
+                                        !(pref && pref[0] == '0')) == 1;
         if (lay && lay[0] == 'p') want = false;
         if (sqenv && sqenv[0] == '0') want = false;
         if (lay && lay[0] == 's' && nL > 0 && sq_b + npass * slab12 + out_b + margin <= cap) want = true;

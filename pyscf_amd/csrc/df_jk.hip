@@ -2047,6 +2047,19 @@ int PAMD_syrk_plan(int nao, int reserve, int flags_in, int nsplit_in, int *flags
     return 0;
 }
 
+// Which layout the tensor gets, from what each candidate needs and what is free (bytes; each host layer prices its own work
+// space and reserve): 2 = packed rows + a FULL square image while all three copies fit (`need_packed_image`, 0 = not on offer) - the
+// fastest second J pass beside the co-running SYRK, measured; 1 = the square rows alone when that fits both while it is built and
+// afterwards (`need_square_build`, `need_square_after`; 0 = not on offer); 0 = packed rows and whatever partial image is left.
+// The ORDER of preference in one place for df.DF._choose_layout and the C handle's build_rows (r06).
+int PAMD_df_layout_pick(long long need_packed_image, long long need_square_build, long long need_square_after, long long free_bytes,
+                        int prefer_image)
+{
+    if (prefer_image && need_packed_image > 0 && need_packed_image <= free_bytes) return 2;
+    if (need_square_build > 0 && need_square_build <= free_bytes && need_square_after <= free_bytes) return 1;
+    return 0;
+}
+
 // Which schedule of the second J pass to keep, from the best time of each candidate (ms[0] overlap: side stream beside the SYRK,
 // ms[1] serial: in line before the re-tiled SYRK, ms[2] fused: inside the SYRK kernel; ncand = 2 without the last): a challenger
 // must win by 1 % (the trials are noisy at that level and 'overlap' is the schedule the kernels were tuned beside).  One rule for

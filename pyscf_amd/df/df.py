@@ -591,7 +591,14 @@ class DF:
         # when 3x does not fit and 2x does (taxol on one GPU, large shards): every row on the square kernel, no second copy, the XC
         # image beside it; (3) packed rows + whatever partial image / diagonal blocks the budget leaves.
         luxury = nL * npair * 8 + nL * rows * rows * 8 + max(self._reserve_after_build(nL, rows), int(self.k_square_reserve))
-        if getattr(self, 'prefer_image', True) and self._all_ranks_agree(luxury + (2 << 30) <= free):
+        # the order of preference is the library's (PAMD_df_layout_pick, shared with the C handle's build_rows); the byte counts are
+        # this layer's.  Collective: a rank that cannot have a layout takes every rank to the next one
+        import ctypes as _c
+        from .. import lib as _lib
+        so = _lib.load_library()
+        pick = int(so.PAMD_df_layout_pick(_c.c_longlong(int(luxury + (2 << 30))), _c.c_longlong(int(build_need)), _c.c_longlong(int(after_need)),
+                                          _c.c_longlong(int(free)), _c.c_int(1 if getattr(self, 'prefer_image', True) else 0)))
+        if getattr(self, 'prefer_image', True) and self._all_ranks_agree(pick == 2):
             return 'packed'
         fits = max(build_need, after_need) <= free
         return 'square' if self._all_ranks_agree(fits) else 'packed'

@@ -256,3 +256,20 @@ def test_library_rules_shared_by_both_host_layers():
     assert pick(108.0, 106.0) == 1 and pick(108.0, 106.0, 106.5) == 1
     assert pick(108.0, 112.0, 106.0) == 2 and pick(108.0, 105.0, 103.0) == 2
     assert pick(300.0, 290.0, 289.0) == 1          # fused must beat the CURRENT best by 1 %, not the first candidate
+
+
+def test_layout_preference_order_is_one_library_function():
+    """PAMD_df_layout_pick: packed + full image while 3x fits (2), square rows when only 2x fits (1), packed otherwise (0) - the order
+    both df.DF._choose_layout and the C handle's build_rows ask for (each with its own byte counts)."""
+    from pyscf_amd import lib
+    so = lib.load_library()
+    GB = 1 << 30
+
+    def pick(lux, build, after, free, prefer=1):
+        return so.PAMD_df_layout_pick(ctypes.c_longlong(lux), ctypes.c_longlong(build), ctypes.c_longlong(after), ctypes.c_longlong(free),
+                                      ctypes.c_int(prefer))
+    assert pick(234 * GB, 170 * GB, 165 * GB, 287 * GB) == 2            # config 3: all three copies fit
+    assert pick(234 * GB, 170 * GB, 165 * GB, 287 * GB, prefer=0) == 1  # ... unless the caller wants ONE copy
+    assert pick(391 * GB, 270 * GB, 281 * GB, 287 * GB) == 1            # taxol: 3x does not fit, 2x does
+    assert pick(391 * GB, 270 * GB, 290 * GB, 287 * GB) == 0            # ... not with a larger XC reserve afterwards
+    assert pick(0, 0, 0, 287 * GB) == 0 and pick(0, 170 * GB, 165 * GB, 287 * GB) == 1
