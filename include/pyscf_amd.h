@@ -367,6 +367,9 @@ int PAMD_mirror_tril(const double *d_part, int m, int ldc, double *d_out, void *
  *                         kernels run (hidden), and when it fails J is recomputed from the matrix before the call returns - what
  *                         the reference always does (df_jk.py:367), K keeps following the tag (df_jk.py:340);
  *                         PAMD_df_last_mismatch(h) = the probe's result
+ *                         flags bit 3 (r06): dm, orbo, vj, vk are DEVICE pointers on the handle's device (one-part handles): the
+ *                         HBM-resident SCF loop over a handle-held tensor - nothing crosses PCIe; the tag then counts as
+ *                         promised (bit 0) or absent (the host cannot probe device memory)
  *   PAMD_df_export_cderi  rows [l0, l1) of `_cderi` (naux, nao_pair) into out (DF.loop, pyscf/df/df.py:214-242)
  *   PAMD_df_naux          rows of the tensor (get_naoaux, :248-257: fewer than the aux functions after an eigen-decomposition) */
 typedef struct PAMD_df PAMD_df;

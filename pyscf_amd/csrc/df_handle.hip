@@ -1098,6 +1098,13 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                           int with_k, int flags, double *vj, double *vk, int serial_j2, int download)
 {
     (void)hermi;
+    // r06: flags bit 3 - dm, orbo, vj and vk are DEVICE pointers on this handle's device (the HBM-resident SCF
+    // loop over a handle-held tensor: nothing crosses PCIe).  The tag cannot be probed from the host then: it counts as promised
+    // (bit 0) or not given at all (J from the matrix).
+    const bool dev_io = (flags & 8) != 0;
+    if (dev_io) flags &= ~2;
+    const hipMemcpyKind k_in = dev_io ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind k_out = dev_io ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     PAMD_REQUIRE(h && dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
     PAMD_REQUIRE(!download || ((!with_j || vj) && (!with_k || vk)), "PAMD_df_get_jk: output pointers");
     PAMD_REQUIRE(with_j || with_k, "PAMD_df_get_jk: nothing to do");
@@ -1132,7 +1139,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
     if (need_dm) {
         d_dm = h->workspace("dm", (size_t)nset * n2, &rc);
         if (rc) return rc;
-        PAMD_CHECK_HIP(hipMemcpyAsync(d_dm, dm, (size_t)nset * n2 * 8, hipMemcpyHostToDevice, st));
+        PAMD_CHECK_HIP(hipMemcpyAsync(d_dm, dm, (size_t)nset * n2 * 8, k_in, st));
     }
     double *d_vjfull = nullptr;
     if (with_j && download) {
@@ -1197,9 +1204,19 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
             o.nocc_pad = (int)round_up(o.no, 16);
             const long ldo = PAMD_e2_orb_ld(o.nocc_pad);       // the library's one rule (df_jk.pad_orbitals asks the same function; r06: the
             o.ldo = ldo;                                         // handle's own transcription of its first three terms is gone)
+            const size_t olen = (size_t)rows * ldo;
+            if (dev_io) {
+                // device orbitals [nao][no] -> the zero-padded operand [rows][ldo], on the stream
+                char name[32];
+                snprintf(name, sizeof(name), "orb%d", s);
+                o.d_orb = h->workspace(name, olen, &rc);
+                if (rc) return rc;
+                PAMD_CHECK_HIP(hipMemsetAsync(o.d_orb, 0, olen * 8, st));
+                PAMD_CHECK_HIP(hipMemcpy2DAsync(o.d_orb, (size_t)ldo * 8, o_s, (size_t)o.no * 8, (size_t)o.no * 8, nao, hipMemcpyDeviceToDevice, st));
+                continue;
+            }
             // padded image in the handle's page-locked staging area (all sets side by side; the call ends with a stream
             // synchronisation, so the area is free again at the next call): no per-call allocation, no extra synchronisation
-            const size_t olen = (size_t)rows * ldo;
             if (orb_stage_off + olen > h->h_orb_len) {
                 PAMD_CHECK_HIP(hipStreamSynchronize(st));                  // copies of the earlier sets still read the old area
                 size_t want = std::max<size_t>(2 * (orb_stage_off + olen), (size_t)1 << 20);
@@ -1396,7 +1413,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
         // r05: J~ is complete as soon as its last second-pass kernel has run - before the SYRK of the last block ends.  Its unpack
         // and its device -> host copy go to the SIDE stream, under the tail of the K work on `st` (1-2 ms of the host-array call
         // at config 3); K follows on `st`.
-        if (with_k) PAMD_CHECK_HIP(hipMemcpyAsync(vk, d_vk, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, st));
+        if (with_k) PAMD_CHECK_HIP(hipMemcpyAsync(vk, d_vk, (size_t)nset * n2 * 8, k_out, st));
         if (with_j) {
             if (j_on_st) PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_j, 0));
             if (nL == 0) {                          // nothing was queued: order the side stream behind the zero fill on `st`
@@ -1404,7 +1421,7 @@ static int df_get_jk_impl(PAMD_df *h, const double *dm, const double *orbo, cons
                 PAMD_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_j, 0));
             }
             if ((rc = PAMD_unpack_tril(d_vjt, npair, nset, nao, d_vjfull, nao, nao, h->side))) return rc;
-            PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vjfull, (size_t)nset * n2 * 8, hipMemcpyDeviceToHost, h->side));
+            PAMD_CHECK_HIP(hipMemcpyAsync(vj, d_vjfull, (size_t)nset * n2 * 8, k_out, h->side));
         }
     } else if (fused && serial_j2 == 0) {
         PAMD_CHECK_HIP(hipEventRecord(h->ev, h->side));
@@ -2031,6 +2048,7 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
         return r;
     }
     PAMD_REQUIRE(dm && nset > 0 && nao == h->nao, "PAMD_df_get_jk: bad arguments (nao must equal the handle's)");
+    PAMD_REQUIRE(!(flags & 8), "PAMD_df_get_jk: device pointers (flags bit 3) need a one-part handle");
     // one host thread per device contracts that device's shard (the serial decomposition this replaces: df_jk.py:362-381);
     // the partial [J~ | K] are summed on part 0's device and leave in one download
     MultiMsg mm;
@@ -2063,11 +2081,6 @@ int PAMD_df_get_jk(PAMD_df *h, const double *dm, const double *orbo, const int *
 // max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) found by the tag probe of the last PAMD_df_get_jk (flags bit 1); 0 when none ran
 double PAMD_df_last_mismatch(const PAMD_df *h) { return h ? h->last_mismatch : 0.0; }
 
-// Timings of the LAST PAMD_df_get_jk on this handle (bench.py --single-process `roofline` / `comm`): out[0] = parts, out[1] = host ms
-// of the fixed-order sum + unpack + download on part 0, out[2] = 1 when the partial results travelled by direct peer copies (xGMI),
-// 0 for the host bounce or a single device; then per part p: out[3 + 5p] = host ms of the shard's contraction (kernels +
-// synchronisation), out[4 + 5p] = host ms of laying out and pushing [J~ | K] into part 0's gather buffer, out[5 + 5p] = bytes that
-// crossed devices, out[6 + 5p] / out[7 + 5p] = HIP-event ms of the half-transform / SYRK launches (MO branch) on their stream.
 // max_s |D_s v - C_s (C_s^T v)| / max(1, |D_s v|) on HOST arrays for one fixed pseudo-random vector: the tag probe of BOTH host layers
 // (r06: pyscf_amd.lib.dm_orbital_mismatch calls this; PAMD_df_get_jk runs the same loops beside its queued kernels, flags bit 1).
 // dm [nset][nao][nao]; orbo: the nset blocks [nao][nocc[s]] one after the other.
@@ -2078,6 +2091,11 @@ int PAMD_dm_orbital_mismatch(const double *dm, const double *orbo, const int *no
     return 0;
 }
 
+// Timings of the LAST PAMD_df_get_jk on this handle (bench.py --single-process `roofline` / `comm`): out[0] = parts, out[1] = host ms
+// of the fixed-order sum + unpack + download on part 0, out[2] = 1 when the partial results travelled by direct peer copies (xGMI),
+// 0 for the host bounce or a single device; then per part p: out[3 + 5p] = host ms of the shard's contraction (kernels +
+// synchronisation), out[4 + 5p] = host ms of laying out and pushing [J~ | K] into part 0's gather buffer, out[5 + 5p] = bytes that
+// crossed devices, out[6 + 5p] / out[7 + 5p] = HIP-event ms of the half-transform / SYRK launches (MO branch) on their stream.
 int PAMD_df_last_timing(const PAMD_df *h, double *out, int nout)
 {
     PAMD_REQUIRE(h && out, "PAMD_df_last_timing: null argument");
